@@ -1,0 +1,248 @@
+"""ctypes binding of oracle/libgkr_oracle.so (the C restatement).  TEST INFRASTRUCTURE ONLY.
+
+Field-element arrays are numpy uint64 arrays of shape (n, 4): the gnark-crypto `fr.Element` memory
+image (little-endian Montgomery limbs), i.e. exactly what a Go `[]fr.Element` holds.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_here, "libgkr_oracle.so")
+
+GATE_IDENTITY, GATE_CIPHER = 0, 1
+
+
+def build():
+    subprocess.check_call(["make", "-C", _here, "-s"])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    P = C.c_void_p
+    sig = {
+        "oracle_fr_from_u64": (None, [P, C.c_uint64]),
+        "oracle_fr_mul": (None, [P, P, P]),
+        "oracle_fr_add": (None, [P, P, P]),
+        "oracle_fr_sub": (None, [P, P, P]),
+        "oracle_fr_inverse": (None, [P, P]),
+        "oracle_fr_to_regular": (None, [P, P]),
+        "oracle_fr_from_regular": (None, [P, P]),
+        "oracle_mimc_hash": (None, [P, P, C.c_size_t]),
+        "oracle_mimc_keyed_permutation": (None, [P, P, P]),
+        "oracle_random_fr_array": (None, [P, C.c_size_t]),
+        "oracle_get_ark": (None, [P, C.c_int]),
+        "oracle_fold": (None, [P, C.c_size_t, P]),
+        "oracle_evaluate": (None, [P, P, C.c_size_t, P, C.c_int]),
+        "oracle_eval_eq": (None, [P, P, P, C.c_int]),
+        "oracle_folded_eq_table": (None, [P, P, C.c_int, P]),
+        "oracle_chunk_of_eq_table": (None, [P, C.c_size_t, C.c_size_t, P, C.c_int, P]),
+        "oracle_eval_univariate": (None, [P, P, C.c_int, P]),
+        "oracle_lagrange_coefficient": (None, [P, C.c_int]),
+        "oracle_interpolate_on_range": (C.c_int, [P, P, C.c_int]),
+        "oracle_gate_eval_batch": (None, [C.c_int, P, P, P, C.c_int, C.c_size_t]),
+        "oracle_sumcheck_prove": (C.c_int, [C.c_int, P, C.c_int, C.c_int, P, P, C.c_int, P, C.c_int, P, P, P]),
+        "oracle_sumcheck_verify": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, P, P, P]),
+        "oracle_evaluation": (None, [P, C.c_int, P, P, C.c_int, C.c_int, P, C.c_int, P, C.c_int]),
+        "oracle_mimc_proof_len": (C.c_size_t, [C.c_int]),
+        "oracle_gkr_prove_mimc": (C.c_int, [C.c_int, P, P, P, P, P, P]),
+        "oracle_gkr_verify_mimc": (C.c_int, [C.c_int, P, P, P, P, P]),
+        "oracle_num_threads": (C.c_int, []),
+        "oracle_set_num_threads": (None, [C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def fr(n=1):
+    return np.zeros((n, 4), dtype=np.uint64)
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def _ptr_array(tables):
+    arr = (C.c_void_p * len(tables))(*[t.ctypes.data for t in tables])
+    return arr
+
+
+def from_u64(v):
+    o = fr()
+    lib.oracle_fr_from_u64(_p(o), int(v))
+    return o
+
+
+def from_ints(vals):
+    """Regular-form Python ints -> Montgomery (n,4) array."""
+    vals = list(vals)
+    reg = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for k in range(4):
+            reg[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    out = fr(len(vals))
+    for i in range(len(vals)):
+        lib.oracle_fr_from_regular(out[i:].ctypes.data, reg[i:].ctypes.data)
+    return out
+
+
+def to_ints(arr):
+    arr = np.ascontiguousarray(arr).reshape(-1, 4)
+    out = []
+    tmp = np.zeros(4, dtype=np.uint64)
+    for i in range(arr.shape[0]):
+        lib.oracle_fr_to_regular(tmp.ctypes.data, arr[i:].ctypes.data)
+        out.append(sum(int(tmp[k]) << (64 * k) for k in range(4)))
+    return out
+
+
+def mimc_hash(arr):
+    o = fr()
+    arr = np.ascontiguousarray(arr)
+    lib.oracle_mimc_hash(_p(o), _p(arr), arr.shape[0])
+    return o
+
+
+def mimc_keyed_permutation(x, key):
+    o = fr()
+    lib.oracle_mimc_keyed_permutation(_p(o), _p(x), _p(key))
+    return o
+
+
+def random_fr_array(n):
+    o = fr(n)
+    lib.oracle_random_fr_array(_p(o), n)
+    return o
+
+
+def fold(tbl, r):
+    t = np.array(tbl, copy=True)
+    lib.oracle_fold(_p(t), t.shape[0], _p(r))
+    return t[: t.shape[0] // 2].copy()
+
+
+def evaluate(tbl, coords):
+    o = fr()
+    lib.oracle_evaluate(_p(o), _p(np.ascontiguousarray(tbl)), tbl.shape[0], _p(np.ascontiguousarray(coords)),
+                        coords.shape[0])
+    return o
+
+
+def eval_eq(q, h):
+    o = fr()
+    lib.oracle_eval_eq(_p(o), _p(q), _p(h), q.shape[0])
+    return o
+
+
+def folded_eq_table(q, mult=None):
+    n = q.shape[0]
+    o = fr(1 << n)
+    lib.oracle_folded_eq_table(_p(o), _p(np.ascontiguousarray(q)), n, _p(mult))
+    return o
+
+
+def chunked_eq_table(q, chunk_size, mult=None):
+    n = q.shape[0]
+    o = fr(1 << n)
+    for cid in range((1 << n) // chunk_size):
+        lib.oracle_chunk_of_eq_table(_p(o), cid, chunk_size, _p(q), n, _p(mult))
+    return o
+
+
+def eval_univariate(coeffs, x):
+    o = fr()
+    lib.oracle_eval_univariate(_p(o), _p(np.ascontiguousarray(coeffs)), coeffs.shape[0], _p(x))
+    return o
+
+
+def lagrange_coefficient(domain):
+    o = fr(domain * domain)
+    lib.oracle_lagrange_coefficient(_p(o), domain)
+    return o.reshape(domain, domain, 4)
+
+
+def interpolate_on_range(values):
+    o = fr(values.shape[0])
+    rc = lib.oracle_interpolate_on_range(_p(o), _p(np.ascontiguousarray(values)), values.shape[0])
+    assert rc == 0
+    return o
+
+
+def gate_degree(gate):
+    return 7 if gate == GATE_CIPHER else 1
+
+
+def sumcheck_prove(gate, ark, X, qprimes, claims):
+    """X: list of (2^bN,4) arrays (copied; the C function consumes its inputs). qprimes: (nq,bN,4)."""
+    qprimes = np.ascontiguousarray(qprimes)
+    nq, bN = qprimes.shape[0], qprimes.shape[1]
+    Xc = [np.array(x, copy=True) for x in X]
+    nc = gate_degree(gate) + 2
+    proof, chal, final = fr(max(bN * nc, 1)), fr(max(bN, 1)), fr(len(X) + 1)
+    claims = np.ascontiguousarray(claims).reshape(-1, 4)
+    ark = fr() if ark is None else ark
+    rc = lib.oracle_sumcheck_prove(gate, _p(ark), len(Xc), bN, _ptr_array(Xc), _p(qprimes), nq,
+                                   _p(claims) if claims.shape[0] else None, claims.shape[0],
+                                   _p(proof), _p(chal), _p(final))
+    if rc != 0:
+        raise RuntimeError("oracle_sumcheck_prove rc=%d" % rc)
+    return proof[: bN * nc].reshape(bN, nc, 4), chal[:bN], final
+
+
+def sumcheck_verify(claims, proof):
+    bN, nc = proof.shape[0], proof.shape[1]
+    chal, final, recomb = fr(max(bN, 1)), fr(), fr()
+    claims = np.ascontiguousarray(claims).reshape(-1, 4)
+    rc = lib.oracle_sumcheck_verify(_p(claims), claims.shape[0], _p(np.ascontiguousarray(proof)), bN, nc,
+                                    _p(chal), _p(final), _p(recomb))
+    return rc, chal[:bN], final, recomb
+
+
+def evaluation(gate, ark, qprimes, claims, X):
+    qprimes = np.ascontiguousarray(qprimes)
+    nq, bN = qprimes.shape[0], qprimes.shape[1]
+    claims = np.ascontiguousarray(claims).reshape(-1, 4)
+    o = fr()
+    ark = fr() if ark is None else ark
+    Xc = [np.ascontiguousarray(x) for x in X]
+    lib.oracle_evaluation(_p(o), gate, _p(ark), _p(qprimes), nq, bN, _p(claims) if claims.shape[0] else None,
+                          claims.shape[0], _ptr_array(Xc), len(Xc))
+    return o
+
+
+def mimc_proof_len(bN):
+    return lib.oracle_mimc_proof_len(bN)
+
+
+def gkr_prove_mimc(bN, in0, in1, qprime, want_outputs=True):
+    flat = fr(mimc_proof_len(bN))
+    outs = fr(1 << bN) if want_outputs else None
+    secs = C.c_double(0.0)
+    qprime = np.ascontiguousarray(qprime).reshape(-1, 4)
+    rc = lib.oracle_gkr_prove_mimc(bN, _p(np.ascontiguousarray(in0)), _p(np.ascontiguousarray(in1)),
+                                   _p(qprime) if bN else None, _p(flat), _p(outs), C.byref(secs))
+    if rc != 0:
+        raise RuntimeError("oracle_gkr_prove_mimc rc=%d" % rc)
+    return flat, outs, secs.value
+
+
+def gkr_verify_mimc(bN, flat, in0, in1, outputs, qprime):
+    qprime = np.ascontiguousarray(qprime).reshape(-1, 4)
+    return lib.oracle_gkr_verify_mimc(bN, _p(np.ascontiguousarray(flat)), _p(np.ascontiguousarray(in0)),
+                                      _p(np.ascontiguousarray(in1)), _p(np.ascontiguousarray(outputs)),
+                                      _p(qprime) if bN else None)

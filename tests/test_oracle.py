@@ -1,0 +1,199 @@
+"""CPU tests: pin the oracle (C restatement + Python big-int restatement) on the reference's known
+answers, on the committed golden vectors, and on the reference's self-consistency tests restated.
+
+Mirrors: hash/hash_test.go, poly/multilin_test.go, poly/eq_test.go, poly/lagrange_test.go,
+sumcheck/prover_test.go (genericTest), gkr/gkr_test.go (TestGKR), examples/mimc_test.go."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import coracle as c
+import pyoracle as o
+from util import fr_to_hex, hex_to_fr, load
+
+
+def test_mimc_case_kat():
+    # hash/hash_test.go:21-27
+    want = 1808205620575546259657963589762746470347087906694759866517376279978241663265
+    assert o.mimc_hash([12]) == want
+    assert c.to_ints(c.mimc_hash(c.from_ints([12])))[0] == want
+
+
+def test_montgomery_layout():
+    # Montgomery(12) limbs
+    want = [0x4b649097efffffc1, 0x1b39d62a0b5d4c40, 0xa43ed816212b4113, 0x1750b1ba94c995bb]
+    assert [int(v) for v in c.from_u64(12)[0]] == want
+    assert o.to_mont_limbs(12) == want
+
+
+def test_fold_kat():
+    # poly/multilin_test.go:12-31
+    out = c.fold(c.from_ints([0, 1, 2, 3]), c.from_u64(5))
+    assert c.to_ints(out) == [10, 11]
+
+
+def test_fold_chunk_equals_whole():
+    # poly/multilin_test.go:33-53 (chunked == whole): the C fold is chunked over OpenMP tasks
+    t = c.random_fr_array(1 << 13)
+    r = c.mimc_hash(c.from_u64(3))
+    assert c.to_ints(c.fold(t, r)) == o.fold(o.random_fr_array(1 << 13), c.to_ints(r)[0])
+
+
+def test_lagrange_kat():
+    # poly/lagrange_test.go:10-29
+    L = c.lagrange_coefficient(7)[2]
+    for i in range(7):
+        y = c.to_ints(c.eval_univariate(L, c.from_u64(i)))[0]
+        assert y == (1 if i == 2 else 0)
+
+
+def test_univariate_kat():
+    # snark/polynomial/univariate_test.go:39-45: X^3+2X^2+3X+4
+    p = c.from_ints([4, 3, 2, 1])
+    s = (c.to_ints(c.eval_univariate(p, c.from_u64(0)))[0] + c.to_ints(c.eval_univariate(p, c.from_u64(1)))[0]) % o.Q
+    assert s == 14
+    assert c.to_ints(c.eval_univariate(p, c.from_u64(5)))[0] == 194
+
+
+def test_golden_kat_file():
+    k = load("kat.json")
+    for e in k["mimc_hash"]:
+        assert fr_to_hex(c.mimc_hash(hex_to_fr(e["in"]))) == [e["out"]]
+        assert o.to_hex(o.mimc_hash([o.from_hex(h) for h in e["in"]])) == e["out"]
+    for e in k["mimc_perm"]:
+        assert fr_to_hex(c.mimc_keyed_permutation(hex_to_fr(e["x"]), hex_to_fr(e["key"]))) == [e["out"]]
+    assert fr_to_hex(c.random_fr_array(16)) == k["random_fr_array_16"]
+    assert fr_to_hex(c.lagrange_coefficient(9).reshape(-1, 4)) == sum(k["lagrange_9"], [])
+    for e in k["gmimc_hash"]:
+        assert o.to_hex(o.gmimc_hash([o.from_hex(h) for h in e["in"]], e["t"])) == e["out"]
+
+
+def test_golden_poly_file():
+    p = load("poly.json")
+    for e in p["fold"]:
+        assert fr_to_hex(c.fold(hex_to_fr(e["tbl"]), hex_to_fr(e["r"]))) == e["out"]
+    for e in p["eq"]:
+        q = hex_to_fr(e["q"])
+        m = hex_to_fr(e["mult"]) if e["mult"] else None
+        assert fr_to_hex(c.folded_eq_table(q, m)) == e["out"]
+    for e in p["eval_eq"]:
+        assert fr_to_hex(c.eval_eq(hex_to_fr(e["q"]), hex_to_fr(e["h"]))) == [e["out"]]
+
+
+@pytest.mark.parametrize("bn", range(0, 13))
+def test_eq_table_vs_eval_eq(bn):
+    # poly/eq_test.go:12-26: EvalEq(q,h) == FoldedEqTable(q).Evaluate(h)
+    q, h = c.random_fr_array(bn), c.random_fr_array(bn)
+    assert (c.evaluate(c.folded_eq_table(q), h) == c.eval_eq(q, h)).all()
+
+
+@pytest.mark.parametrize("bn", range(2, 12))
+def test_eq_table_chunks(bn):
+    # poly/eq_test.go:28-58
+    q = c.random_fr_array(bn)
+    whole = c.folded_eq_table(q)
+    for lg in range(1, bn):
+        assert (c.chunked_eq_table(q, 1 << lg) == whole).all()
+
+
+def _golden_sumcheck():
+    return load("sumcheck.json")
+
+
+def test_golden_sumcheck_file():
+    for e in _golden_sumcheck():
+        bn = e["bn"]
+        n = 1 << bn
+        X = [c.from_ints(range(n)), c.from_ints(range(n))]
+        qs = np.stack([hex_to_fr(q).reshape(bn, 4) for q in e["qprimes"]]) if bn else np.zeros((len(e["qprimes"]), 0, 4), np.uint64)
+        gate = c.GATE_CIPHER if e["kind"] == "cipher" else c.GATE_IDENTITY
+        ark = hex_to_fr(e["ark"]) if e["ark"] else None
+        proof, chal, final = c.sumcheck_prove(gate, ark, X, qs, hex_to_fr(e["claims"]))
+        assert [fr_to_hex(r) for r in proof] == e["proof"]
+        assert fr_to_hex(chal) == e["challenges"]
+        assert fr_to_hex(final) == e["final"]
+
+
+@pytest.mark.parametrize("bn", range(0, 13))
+@pytest.mark.parametrize("kind", ["cipher", "multi"])
+def test_sumcheck_generic(bn, kind):
+    """sumcheck/prover_test.go:42-94 (genericTest) on the C oracle."""
+    n = 1 << bn
+    X = [c.from_ints(range(n)), c.from_ints(range(n))]
+    if kind == "cipher":
+        gate, ark = c.GATE_CIPHER, c.from_u64(145646)
+        qs = c.random_fr_array(bn).reshape(1, bn, 4)
+        claims = c.evaluation(gate, ark, qs, c.fr(0), X)
+    else:
+        gate, ark = c.GATE_IDENTITY, None
+        ninst = 10
+        qs = np.stack([c.from_ints([(i * j + i) for j in range(bn)]).reshape(bn, 4) for i in range(ninst)])
+        claims = np.concatenate([c.evaluation(gate, ark, qs[i:i + 1], c.fr(0), X) for i in range(ninst)])
+    claim_test = c.evaluation(gate, ark, qs, claims, X)
+    rnd = c.mimc_hash(claims)
+    assert (c.eval_univariate(claims, rnd) == claim_test).all()
+    proof, chal, final = c.sumcheck_prove(gate, ark, X, qs, claims)
+    rc, vchal, expected, recomb = c.sumcheck_verify(claims, proof)
+    assert rc == 0
+    assert (vchal == chal).all() and (recomb == rnd).all()
+    g = o.CipherGate(145646) if kind == "cipher" else o.IdentityGate()
+    fin = c.to_ints(final)
+    assert g.eval(*fin[1:]) * fin[0] % o.Q == c.to_ints(expected)[0]
+
+
+def test_golden_gkr_file():
+    for e in load("gkr_mimc.json"):
+        bn = e["bn"]
+        i0, qp = c.random_fr_array(1 << bn), c.random_fr_array(bn)
+        flat, outs, _ = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)
+        assert fr_to_hex(flat) == e["flat"]
+        assert fr_to_hex(outs) == e["outputs"]
+        assert c.gkr_verify_mimc(bn, flat, i0, i0, outs, qp) == 0
+
+
+def test_golden_gkr_bn10_digest():
+    """BASELINE config 1 (bN = 10, gkr/gkr_test.go path) against the committed digest."""
+    d = load("gkr_mimc_bn10_digest.json")
+    bn = d["bn"]
+    i0, qp = c.random_fr_array(1 << bn), c.random_fr_array(bn)
+    flat, outs, _ = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)
+    assert flat.shape[0] == d["n_elements"]
+    assert hashlib.sha256(flat.astype("<u8").tobytes()).hexdigest() == d["sha256_flat"]
+    assert hashlib.sha256(outs.astype("<u8").tobytes()).hexdigest() == d["sha256_outputs"]
+    assert c.gkr_verify_mimc(bn, flat, i0, i0, outs, qp) == 0
+
+
+@pytest.mark.parametrize("bn", [0, 1, 2, 4, 7, 11])
+def test_gkr_claims_consistent_and_verified(bn):
+    """gkr/gkr_test.go:14-78: every claim equals Evaluate(layer table, point); Verify accepts;
+    a corrupted proof is rejected."""
+    i0, qp = c.random_fr_array(1 << bn), c.random_fr_array(bn)
+    flat, outs, _ = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)
+    assert c.gkr_verify_mimc(bn, flat, i0, i0, outs, qp) == 0
+    if bn <= 4:
+        circ = o.mimc_circuit()
+        ins = [o.random_fr_array(1 << bn)] * 2
+        a = o.assign(circ, *ins)
+        p = o.gkr_prove(circ, a, o.random_fr_array(bn))
+        assert o.gkr_proof_to_vec(p) == c.to_ints(flat)
+        for layer in range(len(circ)):
+            for j, claim in enumerate(p.claims[layer]):
+                assert o.evaluate(a[layer], p.q_primes[layer][j]) == claim
+    if bn > 0:
+        bad = flat.copy()
+        bad[5, 0] ^= np.uint64(1)
+        assert c.gkr_verify_mimc(bn, bad, i0, i0, outs, qp) != 0
+
+
+def test_mimc_circuit_is_mimc():
+    # examples/mimc_test.go:19-42: a[93][0] == MimcKeyedPermutation(payload[0], key[0])
+    bn = 3
+    i0 = c.random_fr_array(1 << bn)
+    i1 = c.from_ints([7 * i + 3 for i in range(1 << bn)])
+    _, outs, _ = c.gkr_prove_mimc(bn, i0, i1, c.random_fr_array(bn))
+    for k in range(1 << bn):
+        assert (c.mimc_keyed_permutation(i1[k:k + 1], i0[k:k + 1]) == outs[k]).all()
+    circ = o.mimc_circuit()
+    for lay in circ:  # TestCircuitForm :44-53
+        assert lay.Out == sorted(lay.Out)
