@@ -1,0 +1,140 @@
+// fr_bn254.h -- BN254 scalar-field (Fr) arithmetic for gfx950 lanes: 8 x 32-bit limbs, Montgomery
+// form with R = 2^256, bit-compatible with gnark-crypto's fr.Element ([4]uint64 little-endian,
+// always canonical in [0,q)); replaces the fr.Mul/Square/Add/Sub calls the reference makes at e.g.
+// poly/multilin.go:32-34, circuit/gates/cipher.go:34-40, sumcheck/algo.go:124-125,157,165,183,190.
+//
+// One lane owns one element.  The multiplication is the generated column schedule in
+// fr_mont_gen.inc (v_mad_u64_u32 + v_addc_co_u32 per limb product; no MFMA: this is exact integer
+// modular arithmetic, not a contraction).  The same header compiles for the host (portable branch),
+// which is how the schedule is unit-tested without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define FR_HD __host__ __device__ __forceinline__
+#else
+#define FR_HD inline
+#endif
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct Fr {
+    u32 v[8];
+};
+
+// q = 21888242871839275222246405745257275088548364400416034343698204186575808495617 (hash/ark.go:7)
+#define FRQ0 0xf0000001u
+#define FRQ1 0x43e1f593u
+#define FRQ2 0x79b97091u
+#define FRQ3 0x2833e848u
+#define FRQ4 0x8181585du
+#define FRQ5 0xb85045b6u
+#define FRQ6 0xe131a029u
+#define FRQ7 0x30644e72u
+#define FR_QINV32 0xefffffffu  // -q^-1 mod 2^32
+
+// portable multiply-accumulate into the 96-bit column accumulator (host branch of the schedule)
+#define FR_MADC(acc, ovf, x, y)              \
+    do {                                     \
+        u64 _p = (u64)(x) * (u64)(y);        \
+        u64 _s = (acc) + _p;                 \
+        (ovf) += (_s < _p) ? 1u : 0u;        \
+        (acc) = _s;                          \
+    } while (0)
+
+FR_HD u32 fr_addc(u32 a, u32 b, u32 cin, u32* cout) {
+#if defined(__clang__)
+    return __builtin_addc(a, b, cin, cout);
+#else
+    u64 s = (u64)a + b + cin;
+    *cout = (u32)(s >> 32);
+    return (u32)s;
+#endif
+}
+FR_HD u32 fr_subb(u32 a, u32 b, u32 bin, u32* bout) {
+#if defined(__clang__)
+    return __builtin_subc(a, b, bin, bout);
+#else
+    u64 s = (u64)a - b - bin;
+    *bout = (u32)(s >> 63);
+    return (u32)s;
+#endif
+}
+
+FR_HD Fr fr_zero() {
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = 0;
+    return r;
+}
+// Montgomery form of 1 (2^256 mod q)
+FR_HD Fr fr_one() {
+    Fr r = {{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u}};
+    return r;
+}
+
+// r = t - q if t >= q else t        (t < 2q)
+FR_HD Fr fr_reduce_once(const Fr& t) {
+    const u32 q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
+    u32 d[8];
+    u32 br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = fr_subb(t.v[j], q[j], br, &br);
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = br ? t.v[j] : d[j];
+    return r;
+}
+
+// a + b mod q, canonical inputs and output
+FR_HD Fr fr_add(const Fr& a, const Fr& b) {
+    Fr s;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s.v[j] = fr_addc(a.v[j], b.v[j], c, &c);
+    return fr_reduce_once(s);  // a+b < 2q < 2^255: no carry out of limb 7
+}
+
+// a - b mod q, canonical inputs and output
+FR_HD Fr fr_sub(const Fr& a, const Fr& b) {
+    const u32 q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
+    u32 s[8];
+    u32 br = 0, c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = fr_subb(a.v[j], b.v[j], br, &br);
+    const u32 mask = 0u - br;
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = fr_addc(s[j], q[j] & mask, c, &c);
+    return r;
+}
+
+FR_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
+
+// Montgomery product a*b/2^256 mod q, result in [0, 2q)  (inputs < 2q is enough: 4q^2 + q*2^256 < 2q*2^256)
+FR_HD Fr fr_mont_mul_raw(const Fr& a, const Fr& b) {
+    Fr r;
+#include "fr_mont_gen.inc"
+    return r;
+}
+
+// canonical product
+FR_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_reduce_once(fr_mont_mul_raw(a, b)); }
+FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_mul_raw(a, a)); }
+
+// x^7 as the reference does it: sq, mul, sq, mul (hash/poseidon.go:129-135, circuit/gates/cipher.go:36-40)
+FR_HD Fr fr_pow7(const Fr& x) {
+    Fr t = fr_mont_mul_raw(x, x);   // x^2  (< 2q)
+    t = fr_mont_mul_raw(t, x);      // x^3
+    t = fr_mont_mul_raw(t, t);      // x^6
+    return fr_mul(t, x);            // x^7, canonical
+}
+
+FR_HD bool fr_eq(const Fr& a, const Fr& b) {
+    u32 d = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) d |= a.v[j] ^ b.v[j];
+    return d == 0;
+}

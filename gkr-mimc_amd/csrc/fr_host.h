@@ -1,0 +1,229 @@
+// fr_host.h -- host-side BN254-Fr arithmetic (4 x 64-bit Montgomery limbs) for the serial parts of the
+// prover that stay on a CPU core: Fiat-Shamir (hash.MimcHash, reference hash/mimc.go:11-49 via
+// common/challenge.go:10-12), Lagrange interpolation of the round polynomial (poly/lagrange.go:96-111),
+// the reduction of the limb-split device sums, claim routing and the tiny tail rounds.
+// Product code: never includes or links anything under oracle/.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+namespace hfr {
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+struct E {
+    u64 l[4];
+    bool operator==(const E& o) const { return memcmp(l, o.l, 32) == 0; }
+    bool operator!=(const E& o) const { return !(*this == o); }
+};
+
+static const u64 Q[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const u64 QINV = 0xc2e1f593efffffffULL;
+static const E ONE = {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}};
+static const E R2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+static const E ZERO = {{0, 0, 0, 0}};
+
+static const E ARKS[100] = {
+#include "arks_bn254.inc"
+};
+static const int MIMC_ROUNDS = 91;  // hash/mimc.go:8
+
+static inline bool geq_q(const u64 t[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (t[i] != Q[i]) return t[i] > Q[i];
+    }
+    return true;
+}
+static inline void sub_q(u64 t[4]) {
+    u64 b = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)t[i] - Q[i] - b;
+        t[i] = (u64)d;
+        b = (u64)(d >> 64) & 1;
+    }
+}
+
+static inline E mul(const E& x, const E& y) {
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#define HFR_ROW(yi)                                                            \
+    {                                                                          \
+        u128 a = (u128)x.l[0] * (yi) + t0;                                     \
+        u64 lo0 = (u64)a;                                                      \
+        a = (u128)x.l[1] * (yi) + t1 + (u64)(a >> 64);                         \
+        u64 lo1 = (u64)a;                                                      \
+        a = (u128)x.l[2] * (yi) + t2 + (u64)(a >> 64);                         \
+        u64 lo2 = (u64)a;                                                      \
+        a = (u128)x.l[3] * (yi) + t3 + (u64)(a >> 64);                         \
+        u64 lo3 = (u64)a;                                                      \
+        u64 hi = (u64)(a >> 64);                                               \
+        u64 m = lo0 * QINV;                                                    \
+        a = (u128)m * Q[0] + lo0;                                              \
+        a = (u128)m * Q[1] + lo1 + (u64)(a >> 64);                             \
+        t0 = (u64)a;                                                           \
+        a = (u128)m * Q[2] + lo2 + (u64)(a >> 64);                             \
+        t1 = (u64)a;                                                           \
+        a = (u128)m * Q[3] + lo3 + (u64)(a >> 64);                             \
+        t2 = (u64)a;                                                           \
+        t3 = hi + (u64)(a >> 64); /* q < 2^254: no overflow (no-carry CIOS) */ \
+    }
+    HFR_ROW(y.l[0])
+    HFR_ROW(y.l[1])
+    HFR_ROW(y.l[2])
+    HFR_ROW(y.l[3])
+#undef HFR_ROW
+    E r = {{t0, t1, t2, t3}};
+    if (geq_q(r.l)) sub_q(r.l);
+    return r;
+}
+static inline E sqr(const E& x) { return mul(x, x); }
+static inline E add(const E& x, const E& y) {
+    E r;
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)x.l[i] + y.l[i];
+        r.l[i] = (u64)c;
+        c >>= 64;
+    }
+    if (geq_q(r.l)) sub_q(r.l);
+    return r;
+}
+static inline E sub(const E& x, const E& y) {
+    E r;
+    u64 b = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)x.l[i] - y.l[i] - b;
+        r.l[i] = (u64)d;
+        b = (u64)(d >> 64) & 1;
+    }
+    if (b) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)r.l[i] + Q[i];
+            r.l[i] = (u64)c;
+            c >>= 64;
+        }
+    }
+    return r;
+}
+static inline E neg(const E& x) { return sub(ZERO, x); }
+static inline E from_u64(u64 v) {
+    E t = {{v, 0, 0, 0}};
+    return mul(t, R2);
+}
+static inline E pow_q_minus_2(const E& a) {  // a^-1 (0 -> 0, as gnark-crypto's Inverse)
+    u64 e[4] = {Q[0] - 2, Q[1], Q[2], Q[3]};
+    E res = ONE, base = a;
+    for (int i = 0; i < 256; i++) {
+        if ((e[i / 64] >> (i % 64)) & 1) res = mul(res, base);
+        base = sqr(base);
+    }
+    return res;
+}
+static inline bool is_canonical(const E& a) { return !geq_q(a.l); }
+
+static inline E pow7(const E& x) {  // hash/poseidon.go:129-135
+    E t = sqr(x);
+    t = mul(t, x);
+    t = sqr(t);
+    return mul(t, x);
+}
+
+// hash/mimc.go:31-39
+static inline E mimc_keyed_permutation(const E& x, const E& key) {
+    E res = x;
+    for (int i = 0; i < MIMC_ROUNDS; i++) res = pow7(add(add(res, key), ARKS[i]));
+    return res;
+}
+// hash/mimc.go:11-28,43-49 : state <- state + (Perm_state(x) + state) + x
+static inline E mimc_hash(const E* in, size_t n) {
+    E state = ZERO;
+    for (size_t k = 0; k < n; k++) {
+        E ns = add(mimc_keyed_permutation(in[k], state), state);
+        state = add(add(state, ns), in[k]);
+    }
+    return state;
+}
+
+// poly/lagrange.go:31-39
+static inline E eval_univariate(const E* c, int n, const E& x) {
+    E res = c[n - 1];
+    for (int i = n - 2; i >= 0; i--) res = add(mul(res, x), c[i]);
+    return res;
+}
+
+// poly/eq.go:19-32
+static inline E eval_eq(const E* q, const E* h, int n) {
+    E res = ONE;
+    for (int i = 0; i < n; i++) {
+        E nxt = mul(q[i], h[i]);
+        nxt = add(add(nxt, nxt), ONE);
+        nxt = sub(nxt, add(q[i], h[i]));
+        res = mul(res, nxt);
+    }
+    return res;
+}
+
+// Monomial-basis Lagrange matrices on {0..n-1} (poly/lagrange.go:42-92), built once per n.
+struct Lagrange {
+    std::vector<std::vector<E>> mats;  // mats[n][i*n + j] = coefficient j of L_i
+    Lagrange() : mats(13) {
+        for (int n = 1; n <= 12; n++) {
+            mats[n].assign((size_t)n * n, ZERO);
+            for (int l = 0; l < n; l++) {
+                std::vector<E> acc(n, ZERO);
+                acc[0] = ONE;
+                int deg = 0;
+                for (int i = 0; i < n; i++) {
+                    if (i == l) continue;
+                    E mi = neg(from_u64((u64)i));  // multiply acc by (X - i)
+                    std::vector<E> up(n, ZERO);
+                    for (int j = 0; j <= deg; j++) {
+                        up[j] = add(up[j], mul(acc[j], mi));
+                        up[j + 1] = add(up[j + 1], acc[j]);
+                    }
+                    acc = up;
+                    deg++;
+                }
+                E norm = pow_q_minus_2(eval_univariate(acc.data(), n, from_u64((u64)l)));
+                for (int j = 0; j < n; j++) mats[n][(size_t)l * n + j] = mul(acc[j], norm);
+            }
+        }
+    }
+    // poly/lagrange.go:96-111
+    void interpolate(E* out, const E* values, int n) const {
+        for (int j = 0; j < n; j++) out[j] = ZERO;
+        const std::vector<E>& m = mats[n];
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) out[j] = add(out[j], mul(m[(size_t)i * n + j], values[i]));
+    }
+};
+
+// Reduce a limb-split sum (8 u64 lanes, lane j = sum over terms of 32-bit limb j) to a canonical
+// element.  Valid for up to 2^31 terms (each lane < 2^63).  Field addition is exact, so the order in
+// which device lanes / blocks / ranks were summed is irrelevant (reference: consumeAccumulate sums
+// chunk results in arrival order, sumcheck/prover.go:236-245).
+static inline E reduce_limbsplit(const u64 lanes[8]) {
+    // carry-propagate into 9 x 32-bit words + overflow
+    u64 w[10];
+    u128 c = 0;
+    for (int j = 0; j < 8; j++) {
+        c += lanes[j];
+        w[j] = (u64)c & 0xffffffffULL;
+        c >>= 32;
+    }
+    w[8] = (u64)c & 0xffffffffULL;
+    w[9] = (u64)(c >> 32);
+    E lo = {{w[0] | (w[1] << 32), w[2] | (w[3] << 32), w[4] | (w[5] << 32), w[6] | (w[7] << 32)}};
+    u64 hi = w[8] | (w[9] << 32);  // value = lo + hi * 2^256, hi < 2^63
+    // lo mod q : lo < 2^256 < 6q
+    while (geq_q(lo.l)) sub_q(lo.l);
+    // hi * 2^256 mod q = mont_mul(hi_as_plain_integer, R2) * ... : 2^256 = R, so hi*R mod q = mul(E{hi}, R2)
+    E hv = {{hi, 0, 0, 0}};
+    E hr = mul(hv, R2);  // = hi * R^2 / R = hi * R mod q
+    return add(lo, hr);
+}
+
+}  // namespace hfr

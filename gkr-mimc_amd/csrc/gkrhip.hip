@@ -1,0 +1,955 @@
+// gkrhip.hip -- C ABI (include/gkrhip.h) and host drivers of the MI355X GKR/sumcheck prover.
+//
+// Host side mirrors the reference's orchestration (sumcheck/prover.go:46-144, gkr/prover.go:21-91)
+// with every table-sized step replaced by a HIP kernel from kernels.hip.h.  Nothing here includes,
+// links or calls anything under oracle/.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gkrhip.h"
+#include "fr_host.h"
+#include "kernels.hip.h"
+
+using hfr::E;
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevTable {
+    uint4* base = nullptr;
+    size_t cap = 0;  // elements per plane
+    Planes planes() const { return Planes{base, base + cap}; }
+    CPlanes cplanes() const { return CPlanes{base, base + cap}; }
+};
+
+struct Profile {
+    size_t min_n = (size_t)1 << 62;
+    uint64_t fold_launches = 0, peval_launches = 0;
+    double fold_bytes = 0, peval_modmuls = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_ev, peval_ev;
+    std::vector<hipEvent_t> pool;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums
+    unsigned long long* d_sums = nullptr;      // reduced sums (device)
+    unsigned long long* h_sums = nullptr;      // pinned
+    uint4* d_small = nullptr;                  // gather buffer (AoS)
+    uint4* h_small = nullptr;                  // pinned
+    Fr* d_q = nullptr;                         // qPrime coordinates + seeds staging
+    size_t d_q_cap = 0;
+    int max_grid = 2048;
+    int n_cu = 256;
+    hfr::Lagrange* lag = nullptr;
+    Profile prof;
+    std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
+};
+
+Ctx g;
+std::mutex g_mu;
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIPCHK(x)                                                                                 \
+    do {                                                                                          \
+        hipError_t _e = (x);                                                                      \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)                  \
+    do {                        \
+        int _r = (x);           \
+        if (_r != 0) return _r; \
+    } while (0)
+
+const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
+
+int ctx_init(int dev) {
+    if (g.ready) {
+        if (dev >= 0 && dev != g.device) return fail("gkrhip already initialised on device %d", g.device);
+        return 0;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail("no HIP device available (%s): libgkrhip has no CPU fallback", hipGetErrorString(e));
+    if (dev < 0) dev = 0;
+    if (dev >= n) return fail("device ordinal %d out of range (%d devices)", dev, n);
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("device %d is %s; libgkrhip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+    g.n_cu = prop.multiProcessorCount;
+    g.max_grid = g.n_cu * 8;
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
+    HIPCHK(hipMalloc(&g.d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
+    HIPCHK(hipMalloc(&g.d_sums, sizeof(unsigned long long) * nwords));
+    HIPCHK(hipHostMalloc(&g.h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&g.d_small, sizeof(uint4) * 2 * 8));
+    HIPCHK(hipHostMalloc(&g.h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));
+    g.lag = new hfr::Lagrange();
+    g.device = dev;
+    g.ready = true;
+    return 0;
+}
+
+int ensure_ctx() {
+    if (!g.ready) return ctx_init(-1);
+    HIPCHK(hipSetDevice(g.device));
+    return 0;
+}
+
+// ---- device table arena (replaces poly/pool.go:69-126; no 2^24 cap) ---------------------------------
+int table_alloc(DevTable* t, size_t cap) {
+    if (cap == 0) cap = 1;
+    for (size_t i = 0; i < g.free_list.size(); i++) {
+        if (g.free_list[i].first == cap) {
+            t->base = g.free_list[i].second;
+            t->cap = cap;
+            g.free_list.erase(g.free_list.begin() + i);
+            return 0;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& f : g.free_list) (void)hipFree(f.second);
+        g.free_list.clear();
+        e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
+        if (e != hipSuccess) return fail("hipMalloc of a %zu-element table failed: %s", cap, hipGetErrorString(e));
+    }
+    t->base = (uint4*)p;
+    t->cap = cap;
+    return 0;
+}
+void table_release(DevTable* t) {
+    if (t->base) g.free_list.emplace_back(t->cap, t->base);
+    t->base = nullptr;
+    t->cap = 0;
+}
+void table_free(DevTable* t) {
+    if (t->base) (void)hipFree(t->base);
+    t->base = nullptr;
+    t->cap = 0;
+}
+
+inline int grid_for(size_t n, int cap_blocks) {
+    size_t b = (n + GKR_BLOCK - 1) / GKR_BLOCK;
+    if (b < 1) b = 1;
+    return (int)std::min<size_t>(b, (size_t)cap_blocks);
+}
+
+inline Fr to_dev(const E& e) {
+    Fr r;
+    memcpy(r.v, e.l, 32);
+    return r;
+}
+
+// ---- boundary copies -----------------------------------------------------------------------------
+// host AoS -> device planes.  Staged through a device AoS buffer and transposed by k_aos_to_planes.
+int upload_table(DevTable* t, const uint64_t* host_aos, size_t n) {
+    uint4* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, 32 * n));
+    HIPCHK(hipMemcpyAsync(stage, host_aos, 32 * n, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_aos_to_planes, dim3(grid_for(n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, stage, t->planes(), n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipFree(stage));
+    return 0;
+}
+int download_table(const DevTable* t, uint64_t* host_aos, size_t n) {
+    uint4* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, 32 * n));
+    hipLaunchKernelGGL(k_planes_to_aos, dim3(grid_for(n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, t->cplanes(), stage, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_aos, stage, 32 * n, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipFree(stage));
+    return 0;
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+hipEvent_t prof_event() {
+    if (!g.prof.pool.empty()) {
+        hipEvent_t e = g.prof.pool.back();
+        g.prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// ---- kernel launch wrappers ------------------------------------------------------------------------
+int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab, size_t mid, const E& r) {
+    FoldArgs a;
+    memset(&a, 0, sizeof a);
+    for (int t = 0; t < ntab; t++) {
+        a.src[t] = src[t]->cplanes();
+        a.dst[t] = dst[t]->planes();
+    }
+    a.ntab = ntab;
+    a.mid = mid;
+    a.r = to_dev(r);
+    const bool timed = 2 * mid >= g.prof.min_n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        e0 = prof_event();
+        e1 = prof_event();
+        HIPCHK(hipEventRecord(e0, g.stream));
+    }
+    hipLaunchKernelGGL(k_fold, dim3(grid_for(mid, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, a);
+    HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(e1, g.stream));
+        g.prof.fold_ev.emplace_back(e0, e1);
+        g.prof.fold_launches++;
+        g.prof.fold_bytes += 96.0 * ntab * (double)mid;
+    }
+    return 0;
+}
+
+template <int GATE, int ARITY, int NEV>
+int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, int* nblocks) {
+    PartialEvalArgs a;
+    memset(&a, 0, sizeof a);
+    a.eq = eq->cplanes();
+    for (int k = 0; k < ARITY; k++) a.x[k] = x[k]->cplanes();
+    a.mid = mid;
+    a.ark = to_dev(ark);
+    a.partials = g.d_partials;
+    const int grid = grid_for(mid, kPartialBlocks);
+    hipLaunchKernelGGL((k_partial_eval<GATE, ARITY, NEV>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+    *nblocks = grid;
+    return 0;
+}
+
+// evals[t] (t < nev) for the current round.  Launches the partial evaluation, the block reduction,
+// copies the limb-split sums to the host and reduces them mod q.
+int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, E* evals,
+                  int nev) {
+    int nblocks = 0;
+    const bool timed = 2 * mid >= g.prof.min_n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        e0 = prof_event();
+        e1 = prof_event();
+        HIPCHK(hipEventRecord(e0, g.stream));
+    }
+    if (gate == GKRHIP_GATE_CIPHER && arity == 2) {
+        CHK((launch_partial_eval_t<GKR_GATE_CIPHER, 2, 9>(eq, x, mid, ark, &nblocks)));
+    } else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) {
+        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 1, 3>(eq, x, mid, ark, &nblocks)));
+    } else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) {
+        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 2, 3>(eq, x, mid, ark, &nblocks)));
+    } else {
+        return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
+    }
+    HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(e1, g.stream));
+        g.prof.peval_ev.emplace_back(e0, e1);
+        g.prof.peval_launches++;
+        g.prof.peval_modmuls += (gate == GKRHIP_GATE_CIPHER ? 45.0 : 3.0) * (double)mid;
+    }
+    const int nwords = nev * GKR_ACC_WORDS;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nwords), dim3(GKR_BLOCK), 0, g.stream, g.d_partials, g.d_sums, nblocks, nwords);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g.h_sums, g.d_sums, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int t = 0; t < nev; t++) {
+        // 9 lanes: fold lane 8 (the 2^256 column) into the 8-lane reducer
+        const unsigned long long* w = g.h_sums + (size_t)t * GKR_ACC_WORDS;
+        hfr::u64 lanes[8];
+        for (int j = 0; j < 8; j++) lanes[j] = w[j];
+        E lo = hfr::reduce_limbsplit(lanes);
+        E hv = {{w[8], 0, 0, 0}};                 // w[8] * 2^256 mod q
+        evals[t] = hfr::add(lo, hfr::mul(hv, hfr::R2));
+    }
+    return 0;
+}
+
+// Build Eq = sum_j seed_j * eq(q_j, .) over 2^bN entries (poly/eq.go:41-59 + sumcheck/prover.go:102-144).
+int build_eq(DevTable* eq, const E* qprimes, int nq, int bN, const E* seeds) {
+    const size_t n = (size_t)1 << bN;
+    const int nhi = bN / 2, nlo = bN - nhi;
+    const size_t shi = (size_t)1 << nhi, slo = (size_t)1 << nlo;
+    // stage coordinates + seeds (+ the constant one for the lo tables)
+    const size_t nfr = (size_t)nq * bN + 2 * (size_t)nq;
+    if (nfr > g.d_q_cap) {
+        if (g.d_q) HIPCHK(hipFree(g.d_q));
+        HIPCHK(hipMalloc(&g.d_q, sizeof(Fr) * nfr));
+        g.d_q_cap = nfr;
+    }
+    std::vector<Fr> stage(nfr);
+    for (size_t i = 0; i < (size_t)nq * bN; i++) stage[i] = to_dev(qprimes[i]);
+    for (int j = 0; j < nq; j++) {
+        stage[(size_t)nq * bN + j] = to_dev(seeds[j]);
+        stage[(size_t)nq * bN + nq + j] = to_dev(hfr::ONE);
+    }
+    HIPCHK(hipMemcpyAsync(g.d_q, stage.data(), sizeof(Fr) * nfr, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));  // `stage` is pageable host memory
+
+    DevTable thi, tlo;
+    CHK(table_alloc(&thi, shi * nq));
+    CHK(table_alloc(&tlo, slo * nq));
+    EqSmallArgs s;
+    s.q = g.d_q;
+    s.q_stride = bN;
+    s.out = thi.planes();
+    s.seeds = g.d_q + (size_t)nq * bN;
+    s.nbits = nhi;
+    s.q_off = 0;
+    s.tab_stride = shi;
+    hipLaunchKernelGGL(k_eq_small, dim3(nq), dim3(1024), 0, g.stream, s);
+    s.out = tlo.planes();
+    s.seeds = g.d_q + (size_t)nq * bN + nq;
+    s.nbits = nlo;
+    s.q_off = nhi;
+    s.tab_stride = slo;
+    hipLaunchKernelGGL(k_eq_small, dim3(nq), dim3(1024), 0, g.stream, s);
+    EqExpandArgs x;
+    x.out = eq->planes();
+    x.thi = thi.cplanes();
+    x.tlo = tlo.cplanes();
+    x.hi_stride = shi;
+    x.lo_stride = slo;
+    x.nclaims = nq;
+    x.nlo = nlo;
+    x.n = n;
+    hipLaunchKernelGGL(k_eq_expand, dim3(grid_for(n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, x);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    table_release(&thi);
+    table_release(&tlo);
+    return 0;
+}
+
+int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }
+
+// sumcheck.Prove on device-resident tables (sumcheck/prover.go:46-90).  X is read-only.
+// proof: bN*(deg+2), challenges: bN, final: arity+1.
+int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
+                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims) {
+    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    if (nq < 1) return fail("need at least one evaluation point");
+    if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
+        return fail("provided a multi-instance %d but the number of claims does not match %d", nq, nclaims);
+    const size_t n = (size_t)1 << bN;
+    const int nev = gate_degree(gate) + 2;
+
+    // ---- makeEqTable (prover.go:102-144)
+    std::vector<E> seeds(nq, hfr::ONE);
+    int nq_used = 1;
+    if (nclaims >= 1) {
+        const E rho = hfr::mimc_hash(claims, (size_t)nclaims);  // computed even when unused, as the reference
+        E m = rho;
+        for (int j = 1; j < nq; j++) {
+            seeds[j] = m;
+            m = hfr::mul(m, rho);
+        }
+        nq_used = nq;
+    }
+    DevTable eq;
+    CHK(table_alloc(&eq, n));
+    CHK(build_eq(&eq, qprimes, nq_used, bN, seeds.data()));
+
+    DevTable scratch[GKR_MAX_ARITY];
+    for (int k = 0; k < arity; k++) CHK(table_alloc(&scratch[k], std::max<size_t>(n / 2, 1)));
+
+    const DevTable* cur[GKR_MAX_ARITY];
+    for (int k = 0; k < arity; k++) cur[k] = X[k];
+
+    for (int k = 0; k < bN; k++) {  // prover.go:70-76
+        const size_t mid = n >> (k + 1);
+        E evals[GKR_MAX_EVALS];
+        CHK(partial_evals(gate, arity, &eq, cur, mid, ark, evals, nev));
+        E* coeffs = proof + (size_t)k * nev;
+        g.lag->interpolate(coeffs, evals, nev);
+        const E r = hfr::mimc_hash(coeffs, (size_t)nev);
+        challenges[k] = r;
+        const DevTable* src[GKR_MAX_ARITY + 1];
+        const DevTable* dst[GKR_MAX_ARITY + 1];
+        src[0] = &eq;
+        dst[0] = &eq;
+        for (int t = 0; t < arity; t++) {
+            src[1 + t] = cur[t];
+            dst[1 + t] = &scratch[t];
+        }
+        CHK(launch_fold(src, dst, arity + 1, mid, r));
+        for (int t = 0; t < arity; t++) cur[t] = &scratch[t];
+    }
+
+    // finalClaims (prover.go:79-86)
+    Gather0Args ga;
+    memset(&ga, 0, sizeof ga);
+    ga.t[0] = eq.cplanes();
+    for (int t = 0; t < arity; t++) ga.t[1 + t] = cur[t]->cplanes();
+    ga.ntab = arity + 1;
+    ga.out = g.d_small;
+    hipLaunchKernelGGL(k_gather0, dim3(1), dim3(64), 0, g.stream, ga);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g.h_small, g.d_small, 32 * (arity + 1), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(final_claims, g.h_small, 32 * (arity + 1));
+
+    table_release(&eq);
+    for (int k = 0; k < arity; k++) table_release(&scratch[k]);
+    return 0;
+}
+
+template <int GATE, int ARITY>
+void launch_gate_eval(const AssignArgs& a) {
+    hipLaunchKernelGGL((k_gate_eval_batch<GATE, ARITY>), dim3(grid_for(a.n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, a);
+}
+int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, const DevTable* out, size_t n) {
+    AssignArgs a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < arity; k++) a.in[k] = in[k]->cplanes();
+    a.out = out->planes();
+    a.arity = arity;
+    a.n = n;
+    a.ark = to_dev(ark);
+    if (gate == GKRHIP_GATE_CIPHER && arity == 2) launch_gate_eval<GKR_GATE_CIPHER, 2>(a);
+    else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) launch_gate_eval<GKR_GATE_IDENTITY, 1>(a);
+    else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) launch_gate_eval<GKR_GATE_IDENTITY, 2>(a);
+    else return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// MultiLin.Evaluate on a device table (poly/multilin.go:59-66): fold chain into scratch.
+int evaluate_dev(const DevTable* t, size_t n, const E* coords, int nc, E* out) {
+    if (((size_t)1 << nc) != n) return fail("Evaluate: table has %zu elements but %d coordinates were given", n, nc);
+    DevTable s;
+    CHK(table_alloc(&s, std::max<size_t>(n / 2, 1)));
+    const DevTable* cur = t;
+    for (int k = 0; k < nc; k++) {
+        const size_t mid = n >> (k + 1);
+        const DevTable* src[1] = {cur};
+        const DevTable* dst[1] = {&s};
+        CHK(launch_fold(src, dst, 1, mid, coords[k]));
+        cur = &s;
+    }
+    Gather0Args ga;
+    memset(&ga, 0, sizeof ga);
+    ga.t[0] = cur->cplanes();
+    ga.ntab = 1;
+    ga.out = g.d_small;
+    hipLaunchKernelGGL(k_gather0, dim3(1), dim3(64), 0, g.stream, ga);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g.h_small, g.d_small, 32, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out, g.h_small, 32);
+    table_release(&s);
+    return 0;
+}
+
+// synthetic inputs: element j = Montgomery(((i*i) mod 2^64) ^ 0xf45c9df123f), i = j*stride + offset
+__global__ void __launch_bounds__(GKR_BLOCK) k_random_fr_array(Planes out, size_t n, unsigned long long stride,
+                                                               unsigned long long offset) {
+    const Fr r2 = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long i = (unsigned long long)j * stride + offset;
+        const unsigned long long v = (i * i) ^ 0xf45c9df123fULL;
+        Fr x = fr_zero();
+        x.v[0] = (u32)v;
+        x.v[1] = (u32)(v >> 32);
+        st_fr(out.lo, out.hi, j, fr_mul(x, r2));
+    }
+}
+// table[i] = Montgomery(i)  (BenchmarkFolding's table, poly/multilin_test.go:60-63)
+__global__ void __launch_bounds__(GKR_BLOCK) k_iota(Planes out, size_t n) {
+    const Fr r2 = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        Fr x = fr_zero();
+        x.v[0] = (u32)j;
+        x.v[1] = (u32)((unsigned long long)j >> 32);
+        st_fr(out.lo, out.hi, j, fr_mul(x, r2));
+    }
+}
+
+// ---- circuit description (circuit/circuit.go:11-44) -------------------------------------------------
+struct Layer {
+    std::vector<int> in, out;
+    int gate = -1;  // -1: input layer
+    E ark = hfr::ZERO;
+};
+typedef std::vector<Layer> Circuit;
+
+Circuit mimc_circuit() {  // examples/mimc.go:10-37
+    Circuit c(94);
+    c[2].in = {0};
+    c[2].gate = GKRHIP_GATE_IDENTITY;
+    for (int i = 0; i < 91; i++) {
+        c[i + 3].in = {2, i == 0 ? 1 : i + 2};
+        c[i + 3].gate = GKRHIP_GATE_CIPHER;
+        c[i + 3].ark = hfr::ARKS[i];
+    }
+    for (size_t l = 0; l < c.size(); l++)  // BuildCircuit
+        for (int p : c[l].in) c[p].out.push_back((int)l);
+    return c;
+}
+
+size_t proof_len(const Circuit& c, int bN) {  // hints.go:76-116
+    size_t sc = 0, cl = 0, qp = 0;
+    for (const Layer& l : c) {
+        if (l.gate >= 0) sc += (size_t)bN * (gate_degree(l.gate) + 2);
+        cl += l.out.size();
+        qp += (size_t)bN * l.out.size();
+    }
+    return sc + cl + qp + bN;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// resident session
+// ------------------------------------------------------------------------------------------------
+struct gkrhip_mimc_session {
+    int bN = 0;
+    size_t n = 0;
+    Circuit c;
+    std::vector<DevTable> a;     // assignment; identity layers alias their input (no storage)
+    std::vector<int> alias;      // alias[l] = layer whose table layer l shares, or l
+    bool have_inputs = false, assigned = false;
+};
+
+namespace {
+
+int session_alloc(gkrhip_mimc_session* s) {
+    const size_t L = s->c.size();
+    s->a.assign(L, DevTable());
+    s->alias.resize(L);
+    for (size_t l = 0; l < L; l++) {
+        s->alias[l] = (int)l;
+        if (s->c[l].gate == GKRHIP_GATE_IDENTITY) {
+            // a copy layer holds exactly its input's values (circuit/gates/copy.go:15-17); Prove never
+            // mutates assignment tables here, so the copy is an alias.
+            s->alias[l] = s->alias[s->c[l].in[0]];
+            continue;
+        }
+        CHK(table_alloc(&s->a[l], s->n));
+    }
+    return 0;
+}
+const DevTable* session_table(const gkrhip_mimc_session* s, int l) { return &s->a[s->alias[l]]; }
+
+int session_assign(gkrhip_mimc_session* s) {  // circuit/assignment.go:12-32
+    if (!s->have_inputs) return fail("session has no inputs");
+    for (size_t l = 0; l < s->c.size(); l++) {
+        const Layer& lay = s->c[l];
+        if (lay.gate < 0 || s->alias[l] != (int)l) continue;
+        const DevTable* in[GKR_MAX_ARITY];
+        for (size_t k = 0; k < lay.in.size(); k++) in[k] = session_table(s, lay.in[k]);
+        CHK(gate_eval_dev(lay.gate, lay.ark, in, (int)lay.in.size(), &s->a[l], s->n));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    s->assigned = true;
+    return 0;
+}
+
+int session_prove(gkrhip_mimc_session* s, const E* qprime, E* flat) {  // gkr/prover.go:21-91
+    if (!s->assigned) return fail("session is not assigned");
+    const Circuit& c = s->c;
+    const int L = (int)c.size(), bN = s->bN;
+    std::vector<std::vector<E>> claims(L), qps(L), sc(L);
+    std::vector<char> has_claims(L, 0);
+    for (int l = 0; l < L; l++) {
+        const size_t slots = std::max<size_t>(c[l].out.size(), 1);
+        claims[l].assign(slots, hfr::ZERO);
+        qps[l].assign(slots * std::max(bN, 1), hfr::ZERO);
+    }
+    for (int k = 0; k < bN; k++) qps[L - 1][k] = qprime[k];
+
+    for (int layer = L - 1; layer >= 0; layer--) {
+        const Layer& lay = c[layer];
+        if (lay.gate < 0) break;
+        const int arity = (int)lay.in.size();
+        const DevTable* X[GKR_MAX_ARITY];
+        for (int k = 0; k < arity; k++) X[k] = session_table(s, lay.in[k]);
+        const int nev = gate_degree(lay.gate) + 2;
+        sc[layer].assign((size_t)std::max(bN, 1) * nev, hfr::ZERO);
+        std::vector<E> next_q(std::max(bN, 1));
+        E fin[GKR_MAX_ARITY + 1];
+        const int nq = layer == L - 1 ? 1 : (int)lay.out.size();
+        const int ncl = has_claims[layer] ? (int)lay.out.size() : 0;
+        CHK(sumcheck_prove_dev(lay.gate, lay.ark, arity, bN, X, qps[layer].data(), nq, claims[layer].data(), ncl,
+                               sc[layer].data(), next_q.data(), fin));
+        for (int i = 1; i <= arity; i++) {  // updateWithSumcheck, prover.go:66-90
+            const int inp = lay.in[i - 1];
+            const std::vector<int>& o = c[inp].out;
+            const auto it = std::lower_bound(o.begin(), o.end(), layer);
+            if (it == o.end() || *it != layer)
+                return fail("circuit misformatted, In and Out are inconsistent between layers %d and %d", layer, inp);
+            const size_t w = (size_t)(it - o.begin());
+            has_claims[inp] = 1;
+            claims[inp][w] = fin[i];
+            for (int k = 0; k < bN; k++) qps[inp][w * bN + k] = next_q[k];
+        }
+    }
+    // GkrProofToVec order (hints.go:236-271)
+    size_t cur = 0;
+    for (int l = 0; l < L; l++)
+        if (c[l].gate >= 0) {
+            const size_t cnt = (size_t)bN * (gate_degree(c[l].gate) + 2);
+            memcpy(flat + cur, sc[l].data(), cnt * sizeof(E));
+            cur += cnt;
+        }
+    for (int l = 0; l < L; l++) {
+        memcpy(flat + cur, claims[l].data(), c[l].out.size() * sizeof(E));
+        cur += c[l].out.size();
+    }
+    for (int l = 0; l < L; l++) {
+        const size_t slots = l == L - 1 ? 1 : c[l].out.size();
+        memcpy(flat + cur, qps[l].data(), slots * bN * sizeof(E));
+        cur += slots * bN;
+    }
+    if (cur != proof_len(c, bN)) return fail("internal: flat proof length mismatch");
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int gkrhip_init(int device_ordinal) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return ctx_init(device_ordinal);
+}
+
+void gkrhip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    for (auto& f : g.free_list) (void)hipFree(f.second);
+    g.free_list.clear();
+    (void)hipFree(g.d_partials);
+    (void)hipFree(g.d_sums);
+    (void)hipHostFree(g.h_sums);
+    (void)hipFree(g.d_small);
+    (void)hipHostFree(g.h_small);
+    if (g.d_q) (void)hipFree(g.d_q);
+    g.d_q = nullptr;
+    g.d_q_cap = 0;
+    (void)hipStreamDestroy(g.stream);
+    delete g.lag;
+    g.lag = nullptr;
+    g.ready = false;
+    g.device = -1;
+}
+
+int gkrhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* gkrhip_last_error(void) { return g_err.c_str(); }
+const char* gkrhip_version(void) { return "gkrhip 0.1 (gfx950)"; }
+
+int gkrhip_device_synchronize(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int gkrhip_fold(uint64_t* table, size_t n, const uint64_t r[4]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (n < 2 || (n & (n - 1))) return fail("Fold: table length %zu is not a power of two >= 2", n);
+    DevTable t, o;
+    CHK(table_alloc(&t, n));
+    CHK(table_alloc(&o, n / 2));
+    CHK(upload_table(&t, table, n));
+    E re;
+    memcpy(re.l, r, 32);
+    const DevTable* src[1] = {&t};
+    const DevTable* dst[1] = {&o};
+    CHK(launch_fold(src, dst, 1, n / 2, re));
+    CHK(download_table(&o, table, n / 2));
+    table_release(&t);
+    table_release(&o);
+    return 0;
+}
+
+int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint64_t* coords, int ncoords) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (n < 1 || (n & (n - 1))) return fail("Evaluate: table length %zu is not a power of two", n);
+    DevTable t;
+    CHK(table_alloc(&t, n));
+    CHK(upload_table(&t, table, n));
+    E res;
+    CHK(evaluate_dev(&t, n, (const E*)coords, ncoords, &res));
+    memcpy(out, res.l, 32);
+    table_release(&t);
+    return 0;
+}
+
+int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mult_or_null) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (bN < 0 || bN > 30) return fail("eq table: bN %d out of range", bN);
+    DevTable t;
+    const size_t n = (size_t)1 << bN;
+    CHK(table_alloc(&t, n));
+    E seed = hfr::ONE;
+    if (mult_or_null) memcpy(seed.l, mult_or_null, 32);
+    CHK(build_eq(&t, (const E*)q, 1, bN, &seed));
+    CHK(download_table(&t, out, n));
+    table_release(&t);
+    return 0;
+}
+
+int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res, const uint64_t* const* xs, int arity,
+                           size_t n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    DevTable in[GKR_MAX_ARITY], out;
+    const DevTable* inp[GKR_MAX_ARITY];
+    for (int k = 0; k < arity; k++) {
+        CHK(table_alloc(&in[k], n));
+        CHK(upload_table(&in[k], xs[k], n));
+        inp[k] = &in[k];
+    }
+    CHK(table_alloc(&out, n));
+    E ark = hfr::ZERO;
+    if (ark_or_null) memcpy(ark.l, ark_or_null, 32);
+    CHK(gate_eval_dev(gate, ark, inp, arity, &out, n));
+    CHK(download_table(&out, res, n));
+    for (int k = 0; k < arity; k++) table_release(&in[k]);
+    table_release(&out);
+    return 0;
+}
+
+int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int bN, const uint64_t* const* X,
+                          const uint64_t* qprimes, int nq, const uint64_t* claims, int nclaims, uint64_t* proof,
+                          uint64_t* challenges, uint64_t* final_claims) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (bN < 0 || bN > 30) return fail("bN %d out of range", bN);
+    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    const size_t n = (size_t)1 << bN;
+    DevTable tabs[GKR_MAX_ARITY];
+    const DevTable* X_[GKR_MAX_ARITY];
+    for (int k = 0; k < arity; k++) {
+        CHK(table_alloc(&tabs[k], n));
+        CHK(upload_table(&tabs[k], X[k], n));
+        X_[k] = &tabs[k];
+    }
+    E ark = hfr::ZERO;
+    if (ark_or_null) memcpy(ark.l, ark_or_null, 32);
+    const int rc = sumcheck_prove_dev(gate, ark, arity, bN, X_, (const E*)qprimes, nq, (const E*)claims, nclaims,
+                                      (E*)proof, (E*)challenges, (E*)final_claims);
+    for (int k = 0; k < arity; k++) table_release(&tabs[k]);
+    return rc;
+}
+
+size_t gkrhip_mimc_proof_len(int bN) { return (size_t)822 * bN + 183 + (size_t)184 * bN; }
+
+int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
+    gkrhip_mimc_session* s = new gkrhip_mimc_session();
+    s->bN = bN;
+    s->n = (size_t)1 << bN;
+    s->c = mimc_circuit();
+    const int rc = session_alloc(s);
+    if (rc != 0) {
+        for (auto& t : s->a) table_free(&t);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return 0;
+}
+
+int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session* s, const uint64_t* in0, const uint64_t* in1) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    CHK(upload_table(&s->a[0], in0, s->n));
+    CHK(upload_table(&s->a[1], in1, s->n));
+    s->have_inputs = true;
+    s->assigned = false;
+    return 0;
+}
+
+int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session* s, uint64_t index_stride, uint64_t index_offset) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    for (int l = 0; l < 2; l++) {
+        hipLaunchKernelGGL(k_random_fr_array, dim3(grid_for(s->n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream,
+                           s->a[l].planes(), s->n, (unsigned long long)index_stride, (unsigned long long)index_offset);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    s->have_inputs = true;
+    s->assigned = false;
+    return 0;
+}
+
+int gkrhip_mimc_session_assign(gkrhip_mimc_session* s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    return session_assign(s);
+}
+
+int gkrhip_mimc_session_prove(gkrhip_mimc_session* s, const uint64_t* qprime, uint64_t* flat) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    return session_prove(s, (const E*)qprime, (E*)flat);
+}
+
+int gkrhip_mimc_session_outputs(gkrhip_mimc_session* s, uint64_t* outputs) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (!s->assigned) return fail("session is not assigned");
+    return download_table(session_table(s, (int)s->c.size() - 1), outputs, s->n);
+}
+
+int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session* s, int layer, const uint64_t* coords, uint64_t out[4]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (layer < 0 || layer >= (int)s->c.size()) return fail("layer %d out of range", layer);
+    if (!s->assigned && layer >= 2) return fail("session is not assigned");
+    E res;
+    CHK(evaluate_dev(session_table(s, layer), s->n, (const E*)coords, s->bN, &res));
+    memcpy(out, res.l, 32);
+    return 0;
+}
+
+void gkrhip_mimc_session_destroy(gkrhip_mimc_session* s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.ready) (void)hipSetDevice(g.device);
+    for (auto& t : s->a) table_free(&t);
+    delete s;
+}
+
+int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
+                          uint64_t* outputs_or_null) {
+    gkrhip_mimc_session* s = nullptr;
+    CHK(gkrhip_mimc_session_create(&s, bN));
+    int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
+    if (rc == 0) rc = gkrhip_mimc_session_assign(s);
+    if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
+    if (rc == 0 && outputs_or_null) rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
+    gkrhip_mimc_session_destroy(s);
+    return rc;
+}
+
+int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (n < 2 || (n & (n - 1)) || ntab < 1 || ntab > GKR_MAX_ARITY + 1) return fail("bench_fold: bad arguments");
+    std::vector<DevTable> src(ntab), dst(ntab);
+    const DevTable* sp[GKR_MAX_ARITY + 1];
+    const DevTable* dp[GKR_MAX_ARITY + 1];
+    for (int t = 0; t < ntab; t++) {
+        CHK(table_alloc(&src[t], n));
+        CHK(table_alloc(&dst[t], n / 2));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, src[t].planes(), n);
+        HIPCHK(hipGetLastError());
+        sp[t] = &src[t];
+        dp[t] = &dst[t];
+    }
+    const E r = hfr::from_u64(5);
+    const size_t saved_min = g.prof.min_n;
+    g.prof.min_n = (size_t)1 << 62;  // keep these launches out of the profile accounting
+    for (int i = 0; i < warmup; i++) CHK(launch_fold(sp, dp, ntab, n / 2, r));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g.stream));
+    for (int i = 0; i < iters; i++) CHK(launch_fold(sp, dp, ntab, n / 2, r));
+    HIPCHK(hipEventRecord(e1, g.stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = (double)ms / iters;
+    g.prof.min_n = saved_min;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (int t = 0; t < ntab; t++) {
+        table_free(&src[t]);
+        table_free(&dst[t]);
+    }
+    return 0;
+}
+
+int gkrhip_profile_reset(size_t min_n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (auto& p : g.prof.fold_ev) {
+        g.prof.pool.push_back(p.first);
+        g.prof.pool.push_back(p.second);
+    }
+    for (auto& p : g.prof.peval_ev) {
+        g.prof.pool.push_back(p.first);
+        g.prof.pool.push_back(p.second);
+    }
+    g.prof.fold_ev.clear();
+    g.prof.peval_ev.clear();
+    g.prof.fold_launches = g.prof.peval_launches = 0;
+    g.prof.fold_bytes = g.prof.peval_modmuls = 0;
+    g.prof.min_n = min_n == 0 ? ((size_t)1 << 62) : min_n;
+    return 0;
+}
+
+int gkrhip_profile_get(uint64_t* fold_launches, double* fold_ms, double* fold_bytes, uint64_t* peval_launches,
+                       double* peval_ms, double* peval_modmuls) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    double fm = 0, pm = 0;
+    for (auto& p : g.prof.fold_ev) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        fm += ms;
+    }
+    for (auto& p : g.prof.peval_ev) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        pm += ms;
+    }
+    if (fold_launches) *fold_launches = g.prof.fold_launches;
+    if (fold_ms) *fold_ms = fm;
+    if (fold_bytes) *fold_bytes = g.prof.fold_bytes;
+    if (peval_launches) *peval_launches = g.prof.peval_launches;
+    if (peval_ms) *peval_ms = pm;
+    if (peval_modmuls) *peval_modmuls = g.prof.peval_modmuls;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// kernels.hip.h -- gfx950 kernels of the GKR/sumcheck hot path.
+//
+// Device layout of a multilinear table ("bookkeeping table", reference poly/multilin.go:12): two
+// limb planes of 16-byte words.  Element i = { lo[i] : limbs 0..3 , hi[i] : limbs 4..7 } (32-bit
+// limbs of the Montgomery residue).  One lane owns one element / one index pair, so every global
+// access is a coalesced 16 B-per-lane (1 KiB per wave) load or store.  The reference's AoS
+// `[]fr.Element` exists only at the C-ABI boundary (k_aos_to_planes / k_planes_to_aos).
+//
+// Variable order follows the reference: a round binds the TOP index bit, i.e. pairs (i, i+mid)
+// (poly/multilin.go:26-35).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fr_bn254.h"
+
+#define GKR_BLOCK 256
+#define GKR_MAX_ARITY 4
+#define GKR_MAX_EVALS 9   // cipher gate: degree 8 -> 9 evaluation points (sumcheck/prover.go:95, algo.go:57)
+#define GKR_ACC_WORDS 9   // un-reduced 288-bit lane accumulators
+
+enum { GKR_GATE_IDENTITY = 0, GKR_GATE_CIPHER = 1 };
+
+struct Planes {
+    uint4* lo;
+    uint4* hi;
+};
+struct CPlanes {
+    const uint4* lo;
+    const uint4* hi;
+};
+
+__device__ __forceinline__ Fr ld_fr(const uint4* __restrict__ lo, const uint4* __restrict__ hi, size_t i) {
+    const uint4 a = lo[i], b = hi[i];
+    Fr r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+__device__ __forceinline__ void st_fr(uint4* __restrict__ lo, uint4* __restrict__ hi, size_t i, const Fr& x) {
+    lo[i] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    hi[i] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// boundary: Go []fr.Element (AoS, 32 B per element) <-> limb planes
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GKR_BLOCK) k_aos_to_planes(const uint4* __restrict__ aos, Planes out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        out.lo[i] = aos[2 * i];
+        out.hi[i] = aos[2 * i + 1];
+    }
+}
+__global__ void __launch_bounds__(GKR_BLOCK) k_planes_to_aos(CPlanes in, uint4* __restrict__ aos, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        aos[2 * i] = in.lo[i];
+        aos[2 * i + 1] = in.hi[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fold: dst[i] = src[i] + r * (src[i+mid] - src[i])   for every table of the instance, same r
+// (poly/multilin.go:26-36 applied by sumcheck/algo.go:46-51).  96 algorithmic bytes and one
+// modular multiplication per output element per table: the HBM-bound kernel of the path.
+// dst may alias src (each lane reads its own pair before writing its own output).
+// ------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    CPlanes src[GKR_MAX_ARITY + 1];
+    Planes dst[GKR_MAX_ARITY + 1];
+    int ntab;
+    size_t mid;
+    Fr r;
+};
+__global__ void __launch_bounds__(GKR_BLOCK) k_fold(FoldArgs a) {
+    const Fr r = a.r;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.mid; i += (size_t)gridDim.x * blockDim.x) {
+        for (int t = 0; t < a.ntab; t++) {
+            const Fr lo = ld_fr(a.src[t].lo, a.src[t].hi, i);
+            const Fr hi = ld_fr(a.src[t].lo, a.src[t].hi, i + a.mid);
+            const Fr d = fr_mul(fr_sub(hi, lo), r);
+            st_fr(a.dst[t].lo, a.dst[t].hi, i, fr_add(lo, d));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// eq tables (poly/eq.go:41-89).  eq(q, i) factorises over index bits (the reference's chunked
+// builder relies on the same identity, eq.go:74-88): with i = (i_hi << nlo) | i_lo,
+//   eq(q, i) = eq(q[0:nhi], i_hi) * eq(q[nhi:], i_lo).
+// k_eq_small builds one factor table (<= 2^13 entries) by the reference's doubling recurrence in a
+// single workgroup; k_eq_expand writes the full table with one multiplication per element, summing
+// over claims for the multi-claim layer (sumcheck/prover.go:128-138: Eq = sum_j rho^j eq(q_j, .),
+// rho^j folded into factor table j's seed).
+// ------------------------------------------------------------------------------------------------
+struct EqSmallArgs {
+    Planes out;          // nclaims tables, table j at element offset j * tab_stride
+    const Fr* q;         // nclaims * q_stride coordinates (device), this factor uses q[j*q_stride + q_off .. +nbits)
+    const Fr* seeds;     // nclaims seeds (multipliers)
+    int nbits, q_stride, q_off;
+    size_t tab_stride;
+};
+__global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
+    const int j = blockIdx.x;
+    uint4* lo = a.out.lo + (size_t)j * a.tab_stride;
+    uint4* hi = a.out.hi + (size_t)j * a.tab_stride;
+    const Fr* q = a.q + (size_t)j * a.q_stride + a.q_off;
+    const int n = a.nbits;
+    if (threadIdx.x == 0) st_fr(lo, hi, 0, a.seeds[j]);
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        const Fr r = q[i];
+        for (size_t t = threadIdx.x; t < ((size_t)1 << i); t += blockDim.x) {
+            const size_t J = t << (n - i);
+            const size_t JN = J + ((size_t)1 << (n - 1 - i));
+            const Fr cur = ld_fr(lo, hi, J);
+            const Fr up = fr_mul(r, cur);          // t[JN] = q_i * t[J]
+            st_fr(lo, hi, JN, up);
+            st_fr(lo, hi, J, fr_sub(cur, up));     // t[J] -= t[JN]
+        }
+        __syncthreads();
+    }
+}
+
+struct EqExpandArgs {
+    Planes out;
+    CPlanes thi, tlo;    // factor tables: claim j at offset j*hi_stride / j*lo_stride
+    size_t hi_stride, lo_stride;
+    int nclaims, nlo;    // i_lo has nlo bits
+    size_t n;
+};
+__global__ void __launch_bounds__(GKR_BLOCK) k_eq_expand(EqExpandArgs a) {
+    const size_t mask = ((size_t)1 << a.nlo) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ih = i >> a.nlo, il = i & mask;
+        Fr acc = fr_mul(ld_fr(a.thi.lo, a.thi.hi, ih), ld_fr(a.tlo.lo, a.tlo.hi, il));
+        for (int j = 1; j < a.nclaims; j++) {
+            const Fr h = ld_fr(a.thi.lo, a.thi.hi, (size_t)j * a.hi_stride + ih);
+            const Fr l = ld_fr(a.tlo.lo, a.tlo.hi, (size_t)j * a.lo_stride + il);
+            acc = fr_add(acc, fr_mul(h, l));
+        }
+        st_fr(a.out.lo, a.out.hi, i, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gates (circuit/gates/cipher.go:25-55, circuit/gates/copy.go:15-22)
+// ------------------------------------------------------------------------------------------------
+template <int GATE>
+__device__ __forceinline__ Fr gate_eval(const Fr* x, const Fr& ark) {
+    if (GATE == GKR_GATE_CIPHER) {
+        return fr_pow7(fr_add(fr_add(x[1], ark), x[0]));
+    } else {
+        return x[0];
+    }
+}
+
+// layer assignment: out = Gate(in0, in1)   (circuit/circuit.go:48-64 -> Gate.EvalBatch)
+struct AssignArgs {
+    CPlanes in[GKR_MAX_ARITY];
+    Planes out;
+    int arity;
+    size_t n;
+    Fr ark;
+};
+template <int GATE, int ARITY>
+__global__ void __launch_bounds__(GKR_BLOCK) k_gate_eval_batch(AssignArgs a) {
+    const Fr ark = a.ark;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr x[ARITY];
+#pragma unroll
+        for (int k = 0; k < ARITY; k++) x[k] = ld_fr(a.in[k].lo, a.in[k].hi, i);
+        st_fr(a.out.lo, a.out.hi, i, gate_eval<GATE>(x, ark));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-round partial evaluation (sumcheck/algo.go:54-205):
+//   evals[t] = sum_{x < mid} Eq(t,x) * Gate(X_1(t,x), ..., X_n(t,x)),   t = 0 .. deg+1
+// with T(t,x) = T[x] + t*(T[x+mid]-T[x]) obtained by repeated addition of the difference exactly as
+// the reference does.  One lane per index pair (grid-stride); each lane keeps NEV un-reduced 288-bit
+// accumulators; wave reduction by cross-lane adds of 64-bit limb sums, LDS across the waves of the
+// block; one "limb-split" partial (NEV x 9 u64 lanes) per block.  k_reduce_partials sums the blocks.
+// The limb-split form is an exact integer sum, so it can also be all-reduced across GPUs with a
+// plain u64 ncclSum before the single host-side reduction mod q (fr_host.h reduce_limbsplit).
+// ------------------------------------------------------------------------------------------------
+struct Acc9 {
+    u32 w[GKR_ACC_WORDS];
+};
+__device__ __forceinline__ void acc_add(Acc9& a, const Fr& x) {
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) a.w[j] = fr_addc(a.w[j], x.v[j], c, &c);
+    a.w[8] += c;
+}
+
+struct PartialEvalArgs {
+    CPlanes eq;
+    CPlanes x[GKR_MAX_ARITY];
+    size_t mid;
+    Fr ark;
+    unsigned long long* partials;  // [gridDim.x][NEV][9]
+};
+
+template <int GATE, int ARITY, int NEV>
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a) {
+    __shared__ unsigned long long red[GKR_BLOCK / 64][NEV * GKR_ACC_WORDS];
+    Acc9 acc[NEV];
+#pragma unroll
+    for (int t = 0; t < NEV; t++)
+#pragma unroll
+        for (int j = 0; j < GKR_ACC_WORDS; j++) acc[t].w[j] = 0;
+    const Fr ark = a.ark;
+    const size_t mid = a.mid;
+
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mid; i += (size_t)gridDim.x * blockDim.x) {
+        Fr e = ld_fr(a.eq.lo, a.eq.hi, i);
+        Fr de = fr_sub(ld_fr(a.eq.lo, a.eq.hi, i + mid), e);
+        Fr x[ARITY], d[ARITY];
+#pragma unroll
+        for (int k = 0; k < ARITY; k++) {
+            x[k] = ld_fr(a.x[k].lo, a.x[k].hi, i);
+            d[k] = fr_sub(ld_fr(a.x[k].lo, a.x[k].hi, i + mid), x[k]);
+        }
+        // t = 0 .. NEV-1: T(t) = T(t-1) + (T_hi - T_lo).  The loop stays rolled (one gate evaluation of
+        // code, I-cache resident); the accumulators rotate through acc[0] so that every index is a
+        // compile-time constant (registers, not scratch).  After NEV iterations they are back in place.
+#pragma unroll 1
+        for (int t = 0; t < NEV; t++) {
+            acc_add(acc[0], fr_mul(e, gate_eval<GATE>(x, ark)));
+            const Acc9 first = acc[0];
+#pragma unroll
+            for (int u = 0; u + 1 < NEV; u++) acc[u] = acc[u + 1];
+            acc[NEV - 1] = first;
+            e = fr_add(e, de);
+#pragma unroll
+            for (int k = 0; k < ARITY; k++) x[k] = fr_add(x[k], d[k]);
+        }
+    }
+
+    // wave reduction of the limb words as 64-bit integer sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < NEV; t++) {
+#pragma unroll
+        for (int j = 0; j < GKR_ACC_WORDS; j++) {
+            unsigned long long s = acc[t].w[j];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) red[wave][t * GKR_ACC_WORDS + j] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NEV * GKR_ACC_WORDS) {
+        unsigned long long s = 0;
+#pragma unroll
+        for (int w = 0; w < GKR_BLOCK / 64; w++) s += red[w][threadIdx.x];
+        a.partials[(size_t)blockIdx.x * (NEV * GKR_ACC_WORDS) + threadIdx.x] = s;
+    }
+}
+
+// sum the per-block partials: out[k] = sum_b partials[b][k],  k < nwords
+__global__ void __launch_bounds__(GKR_BLOCK) k_reduce_partials(const unsigned long long* __restrict__ partials,
+                                                               unsigned long long* __restrict__ out, int nblocks,
+                                                               int nwords) {
+    __shared__ unsigned long long red[GKR_BLOCK];
+    for (int k = blockIdx.x; k < nwords; k += gridDim.x) {
+        unsigned long long s = 0;
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partials[(size_t)b * nwords + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = GKR_BLOCK / 2; off >= 1; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = red[0];
+        __syncthreads();
+    }
+}
+
+// gather element 0 of up to 5 tables into a small AoS buffer (finalClaims, sumcheck/prover.go:79-86)
+struct Gather0Args {
+    CPlanes t[GKR_MAX_ARITY + 1];
+    int ntab;
+    uint4* out;  // AoS: 2 x uint4 per element
+};
+__global__ void k_gather0(Gather0Args a) {
+    const int t = threadIdx.x;
+    if (t < a.ntab) {
+        a.out[2 * t] = a.t[t].lo[0];
+        a.out[2 * t + 1] = a.t[t].hi[0];
+    }
+}

@@ -1,0 +1,256 @@
+"""Python mirror of the reference's Go API for the hot path, over the C ABI of libgkrhip.so
+(include/gkrhip.h).  Names and argument meaning follow the Go functions they stand for:
+
+    fold(table, r)                    (*MultiLin).Fold            poly/multilin.go:19-23
+    evaluate(table, coords)           MultiLin.Evaluate           poly/multilin.go:59-66
+    folded_eq_table(q, mult=None)     poly.FoldedEqTable          poly/eq.go:41-59
+    gate_eval_batch(gate, ark, xs)    Gate.EvalBatch              circuit/gates.go:16
+    sumcheck_prove(X, qPrimes, claims, gate, ark)   sumcheck.Prove   sumcheck/prover.go:46-90
+    gkr_prove_mimc(in0, in1, qPrime)  Assign + gkr.Prove on examples.MimcCircuit (gkr/prover.go:21-47)
+    MimcSession                       resident assignment, repeated Prove (benchmarks)
+
+Field-element arrays are numpy uint64 arrays of shape (n, 4): the memory image of a Go
+`[]fr.Element`.  Errors raise GkrHipError (the reference panics).  There is no CPU fallback: if the
+library or a gfx950 GPU is missing, the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+GATE_IDENTITY, GATE_CIPHER = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgkrhip.so")
+_lib = None
+
+# every symbol include/gkrhip.h declares: (restype, argtypes)
+_P, _SZ, _I, _U64, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_double
+ABI = {
+    "gkrhip_init": (_I, [_I]),
+    "gkrhip_shutdown": (None, []),
+    "gkrhip_device_count": (_I, []),
+    "gkrhip_last_error": (C.c_char_p, []),
+    "gkrhip_version": (C.c_char_p, []),
+    "gkrhip_device_synchronize": (_I, []),
+    "gkrhip_fold": (_I, [_P, _SZ, _P]),
+    "gkrhip_evaluate": (_I, [_P, _P, _SZ, _P, _I]),
+    "gkrhip_eq_table": (_I, [_P, _P, _I, _P]),
+    "gkrhip_gate_eval_batch": (_I, [_I, _P, _P, _P, _I, _SZ]),
+    "gkrhip_sumcheck_prove": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "gkrhip_mimc_proof_len": (_SZ, [_I]),
+    "gkrhip_gkr_prove_mimc": (_I, [_I, _P, _P, _P, _P, _P]),
+    "gkrhip_mimc_session_create": (_I, [C.POINTER(_P), _I]),
+    "gkrhip_mimc_session_load_inputs": (_I, [_P, _P, _P]),
+    "gkrhip_mimc_session_synth_inputs": (_I, [_P, _U64, _U64]),
+    "gkrhip_mimc_session_assign": (_I, [_P]),
+    "gkrhip_mimc_session_prove": (_I, [_P, _P, _P]),
+    "gkrhip_mimc_session_outputs": (_I, [_P, _P]),
+    "gkrhip_mimc_session_evaluate_layer": (_I, [_P, _I, _P, _P]),
+    "gkrhip_mimc_session_destroy": (None, [_P]),
+    "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D)]),
+    "gkrhip_profile_reset": (_I, [_SZ]),
+    "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
+}
+
+
+class GkrHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _SO
+
+
+def load():
+    """Load libgkrhip.so (no GPU needed for loading; compute calls need a gfx950 device)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise GkrHipError("libgkrhip.so not built: run `python __graft_entry__.py` (or gkr-mimc_amd/build.py); "
+                          "there is no CPU fallback")
+    lib = C.CDLL(_SO)
+    for name, (res, args) in ABI.items():
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise GkrHipError(load().gkrhip_last_error().decode() or "gkrhip error %d" % rc)
+
+
+def init(device=0):
+    _check(load().gkrhip_init(int(device)))
+
+
+def shutdown():
+    load().gkrhip_shutdown()
+
+
+def device_count():
+    return load().gkrhip_device_count()
+
+
+def synchronize():
+    _check(load().gkrhip_device_synchronize())
+
+
+def _fr(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 4
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def fold(table, r):
+    """(*MultiLin).Fold(r): returns the folded table (len n/2); the input array is not modified."""
+    t = np.array(_fr(table), copy=True)
+    _check(load().gkrhip_fold(_ptr(t), t.shape[0], _ptr(_fr(r))))
+    return t[: t.shape[0] // 2].copy()
+
+
+def evaluate(table, coords):
+    table, coords = _fr(table), _fr(coords).reshape(-1, 4)
+    out = np.zeros((1, 4), np.uint64)
+    _check(load().gkrhip_evaluate(_ptr(out), _ptr(table), table.shape[0], _ptr(coords) if coords.shape[0] else None,
+                                  coords.shape[0]))
+    return out
+
+
+def folded_eq_table(q, mult=None):
+    q = _fr(q).reshape(-1, 4)
+    bN = q.shape[0]
+    out = np.zeros((1 << bN, 4), np.uint64)
+    m = None if mult is None else _fr(mult)
+    _check(load().gkrhip_eq_table(_ptr(out), _ptr(q) if bN else None, bN, _ptr(m)))
+    return out
+
+
+def gate_eval_batch(gate, ark, xs):
+    xs = [_fr(x) for x in xs]
+    n = xs[0].shape[0]
+    res = np.zeros((n, 4), np.uint64)
+    arr = (C.c_void_p * len(xs))(*[x.ctypes.data for x in xs])
+    a = None if ark is None else _fr(ark)
+    _check(load().gkrhip_gate_eval_batch(gate, _ptr(a), _ptr(res), arr, len(xs), n))
+    return res
+
+
+def gate_degree(gate):
+    return 7 if gate == GATE_CIPHER else 1
+
+
+def sumcheck_prove(X, q_primes, claims, gate, ark=None):
+    """sumcheck.Prove(X, qPrimes, claims, gate) -> (proof[bN][deg+2], challenges[bN], finalClaims)."""
+    X = [_fr(x) for x in X]
+    q_primes = _fr(q_primes)
+    assert q_primes.ndim == 3
+    nq, bN = q_primes.shape[0], q_primes.shape[1]
+    claims = _fr(claims).reshape(-1, 4)
+    nc = gate_degree(gate) + 2
+    proof = np.zeros((max(bN * nc, 1), 4), np.uint64)
+    chal = np.zeros((max(bN, 1), 4), np.uint64)
+    final = np.zeros((len(X) + 1, 4), np.uint64)
+    for i, x in enumerate(X):
+        if x.shape[0] != 1 << bN:  # sumcheck/prover.go:52-56
+            raise GkrHipError("inconsistent sizes : bn is %d but table %d has size %d" % (bN, i, x.shape[0]))
+    arr = (C.c_void_p * len(X))(*[x.ctypes.data for x in X])
+    a = None if ark is None else _fr(ark)
+    _check(load().gkrhip_sumcheck_prove(gate, _ptr(a), len(X), bN, arr, _ptr(q_primes) if bN else None, nq,
+                                        _ptr(claims) if claims.shape[0] else None, claims.shape[0],
+                                        _ptr(proof), _ptr(chal), _ptr(final)))
+    return proof[: bN * nc].reshape(bN, nc, 4), chal[:bN], final
+
+
+def mimc_proof_len(bN):
+    return load().gkrhip_mimc_proof_len(bN)
+
+
+def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True):
+    """Circuit.Assign(in0, in1) + gkr.Prove(MimcCircuit, a, qPrime); returns (flat proof, outputs)."""
+    in0, in1 = _fr(in0), _fr(in1)
+    n = in0.shape[0]
+    bN = n.bit_length() - 1
+    assert n == 1 << bN and in1.shape[0] == n
+    q_prime = _fr(q_prime).reshape(-1, 4)
+    assert q_prime.shape[0] == bN
+    flat = np.zeros((mimc_proof_len(bN), 4), np.uint64)
+    outs = np.zeros((n, 4), np.uint64) if want_outputs else None
+    _check(load().gkrhip_gkr_prove_mimc(bN, _ptr(in0), _ptr(in1), _ptr(q_prime) if bN else None, _ptr(flat), _ptr(outs)))
+    return flat, outs
+
+
+class MimcSession:
+    """Resident MiMC assignment on the GPU; prove() can be repeated."""
+
+    def __init__(self, bN):
+        self.bN = bN
+        self._h = C.c_void_p()
+        _check(load().gkrhip_mimc_session_create(C.byref(self._h), bN))
+
+    def load_inputs(self, in0, in1):
+        in0, in1 = _fr(in0), _fr(in1)
+        assert in0.shape[0] == 1 << self.bN and in1.shape[0] == 1 << self.bN
+        _check(load().gkrhip_mimc_session_load_inputs(self._h, _ptr(in0), _ptr(in1)))
+
+    def synth_inputs(self, stride=1, offset=0):
+        _check(load().gkrhip_mimc_session_synth_inputs(self._h, stride, offset))
+
+    def assign(self):
+        _check(load().gkrhip_mimc_session_assign(self._h))
+
+    def prove(self, q_prime):
+        q_prime = _fr(q_prime).reshape(-1, 4)
+        flat = np.zeros((mimc_proof_len(self.bN), 4), np.uint64)
+        _check(load().gkrhip_mimc_session_prove(self._h, _ptr(q_prime) if self.bN else None, _ptr(flat)))
+        return flat
+
+    def outputs(self):
+        out = np.zeros((1 << self.bN, 4), np.uint64)
+        _check(load().gkrhip_mimc_session_outputs(self._h, _ptr(out)))
+        return out
+
+    def evaluate_layer(self, layer, coords):
+        coords = _fr(coords).reshape(-1, 4)
+        out = np.zeros((1, 4), np.uint64)
+        _check(load().gkrhip_mimc_session_evaluate_layer(self._h, layer, _ptr(coords) if self.bN else None, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            load().gkrhip_mimc_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bench_fold(n, ntab=1, warmup=3, iters=20):
+    ms = C.c_double(0)
+    _check(load().gkrhip_bench_fold(n, ntab, warmup, iters, C.byref(ms)))
+    return ms.value
+
+
+def profile_reset(min_n):
+    _check(load().gkrhip_profile_reset(min_n))
+
+
+def profile_get():
+    fl, pl = C.c_uint64(0), C.c_uint64(0)
+    fm, fb, pm, pmm = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    _check(load().gkrhip_profile_get(C.byref(fl), C.byref(fm), C.byref(fb), C.byref(pl), C.byref(pm), C.byref(pmm)))
+    return {"fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
+            "peval_launches": pl.value, "peval_ms": pm.value, "peval_modmuls": pmm.value}

@@ -1,0 +1,104 @@
+/* gkrhip.h -- C ABI of libgkrhip.so: the MI355X (gfx950) GKR/sumcheck prover for batched MiMC7/BN254.
+ *
+ * Drop-in boundary for the hot path of Consensys/gkr-mimc (citations are file:line in that
+ * repository).  The reference has no FFI layer: the path sits behind plain Go functions, so each
+ * entry point below names the Go function whose body a cgo shim replaces (see INTEGRATION.md for
+ * the shim).  Every `uint64_t*` field-element array is the memory image of a Go `[]fr.Element`
+ * (gnark-crypto, [4]uint64 little-endian Montgomery limbs, canonical), so `unsafe.Pointer(&s[0])`
+ * passes with no conversion on the Go side.  Host input buffers are read-only to the library unless
+ * stated; outputs are written into caller-allocated buffers.
+ *
+ * All functions return 0 on success and a non-zero code otherwise; gkrhip_last_error() describes
+ * the last failure of the calling process (the reference panics on the prover side,
+ * sumcheck/prover.go:54,114; the Go shim turns non-zero into panic).  Calls block until the result
+ * is in host memory.  One context per process, guarded by a mutex (the reference's Prove is called
+ * from one goroutine and blocks, sumcheck/prover.go:46-90).
+ *
+ * There is NO CPU fallback: every table-sized operation runs in HIP kernels on the selected GPU and
+ * gkrhip_init() fails loudly when no gfx950 device is usable.  The host only performs the
+ * inherently serial scalar work (Fiat-Shamir MiMC hashing of <= 91 elements, 9x9 interpolation).
+ */
+#ifndef GKRHIP_H
+#define GKRHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKRHIP_GATE_IDENTITY 0 /* circuit/gates/copy.go:9-32   : xs[0],              Degree 1 */
+#define GKRHIP_GATE_CIPHER 1   /* circuit/gates/cipher.go:11-70: (xs[0]+xs[1]+Ark)^7, Degree 7 */
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int gkrhip_init(int device_ordinal);      /* idempotent; selects the GPU, creates the stream/arena */
+void gkrhip_shutdown(void);
+int gkrhip_device_count(void);
+const char *gkrhip_last_error(void);
+const char *gkrhip_version(void);
+int gkrhip_device_synchronize(void);
+
+/* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
+/* (*MultiLin).Fold(r), poly/multilin.go:19-23: in place on `table` (n elements, n a power of two >= 2);
+ * the folded table is the first n/2 elements (the Go shim re-slices to [:mid]). */
+int gkrhip_fold(uint64_t *table, size_t n, const uint64_t r[4]);
+/* MultiLin.Evaluate(coordinates), poly/multilin.go:59-66 (table untouched). */
+int gkrhip_evaluate(uint64_t out[4], const uint64_t *table, size_t n, const uint64_t *coords, int ncoords);
+/* poly.FoldedEqTable(preallocated, qPrime, multiplier...), poly/eq.go:41-59; mult may be NULL. Also the
+ * result of any sequence of poly.ChunkOfEqTable calls covering the table (poly/eq.go:62-89). */
+int gkrhip_eq_table(uint64_t *out, const uint64_t *q, int bN, const uint64_t *mult_or_null);
+
+/* ---- circuit.Gate (circuit/gates.go:9-21) ---------------------------------------------------- */
+/* Gate.EvalBatch(res, xs...) / Layer.Evaluate, circuit/circuit.go:48-64. */
+int gkrhip_gate_eval_batch(int gate, const uint64_t *ark_or_null, uint64_t *res, const uint64_t *const *xs,
+                           int arity, size_t n);
+
+/* ---- sumcheck.Prove (sumcheck/prover.go:46-90) ------------------------------------------------ */
+/* X[k], k < arity: tables of 2^bN elements (NOT modified; the reference consumes them).
+ * qprimes: nq*bN elements; claims: nclaims elements (may be 0: top GKR layer).
+ * proof: bN*(Degree+2) coefficients, round-major, low->high (poly.InterpolateOnRange order);
+ * challenges: bN; final_claims: arity+1 = [Eq[0], X_1[0], ...] after the last fold. */
+int gkrhip_sumcheck_prove(int gate, const uint64_t *ark_or_null, int arity, int bN, const uint64_t *const *X,
+                          const uint64_t *qprimes, int nq, const uint64_t *claims, int nclaims,
+                          uint64_t *proof, uint64_t *challenges, uint64_t *final_claims);
+
+/* ---- gkr.Prove for examples.MimcCircuit (gkr/prover.go:21-47, examples/mimc.go:10-37) --------- */
+/* Number of field elements of the flat proof, = GkrProverHint.NbOutputs (prover/gadget/hints.go:76-116):
+ * 822*bN + 183 + 184*bN. */
+size_t gkrhip_mimc_proof_len(int bN);
+/* Circuit.Assign(in0,in1) (circuit/assignment.go:12-32) + gkr.Prove, as GkrProverHint.Call does
+ * (prover/gadget/hints.go:220-222).  flat: gkrhip_mimc_proof_len(bN) elements in GkrProofToVec order
+ * (hints.go:236-271) kept as Montgomery limbs; outputs_or_null: 2^bN elements = assignment[93]. */
+int gkrhip_gkr_prove_mimc(int bN, const uint64_t *in0, const uint64_t *in1, const uint64_t *qprime,
+                          uint64_t *flat, uint64_t *outputs_or_null);
+
+/* Resident session: the assignment stays in HBM, Prove can be repeated (it never mutates the
+ * assignment).  This is what the benchmark times (gkr/gkr_test.go:99-105 excludes Assign). */
+typedef struct gkrhip_mimc_session gkrhip_mimc_session;
+int gkrhip_mimc_session_create(gkrhip_mimc_session **out, int bN);
+int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session *s, const uint64_t *in0, const uint64_t *in1);
+/* inputs = common.RandomFrArray(2^bN) for both (common/common.go:49-55), generated on the device;
+ * index_stride/index_offset select the shard i = j*stride + offset (1, 0 for the whole hypercube). */
+int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session *s, uint64_t index_stride, uint64_t index_offset);
+int gkrhip_mimc_session_assign(gkrhip_mimc_session *s);
+int gkrhip_mimc_session_prove(gkrhip_mimc_session *s, const uint64_t *qprime, uint64_t *flat);
+int gkrhip_mimc_session_outputs(gkrhip_mimc_session *s, uint64_t *outputs);
+/* MultiLin.Evaluate of an assignment layer at `coords` on the device (verifier helper, gkr/verifier.go:36,120-132). */
+int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session *s, int layer, const uint64_t *coords, uint64_t out[4]);
+void gkrhip_mimc_session_destroy(gkrhip_mimc_session *s);
+
+/* ---- measurement hooks ------------------------------------------------------------------------ */
+/* Device-resident fold micro-benchmark (shape of BenchmarkFolding, poly/multilin_test.go:55-78):
+ * ntab tables of n elements (table[i] = Montgomery(i)), r = 5, `iters` timed out-of-place folds after
+ * `warmup`; *avg_ms = mean kernel time from HIP events on the library's stream. */
+int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double *avg_ms);
+/* Per-kernel accounting of the calling process since the last reset: HIP-event time of every fold
+ * launch whose input table has >= min_n elements. */
+int gkrhip_profile_reset(size_t min_n);
+int gkrhip_profile_get(uint64_t *fold_launches, double *fold_ms, double *fold_bytes,
+                       uint64_t *peval_launches, double *peval_ms, double *peval_modmuls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKRHIP_H */

@@ -1,0 +1,64 @@
+// CPU unit test of the generated Montgomery column schedule (portable branch of fr_bn254.h) against
+// the C oracle (tests/ may link oracle/).  Exercises the carry-out-of-first-product case with
+// limbs of 0xFFFFFFFF, boundary values and random values, for canonical and lazy (< 2q) inputs.
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include "../../gkr-mimc_amd/csrc/fr_bn254.h"
+#include "../../oracle/gkr_oracle.h"
+
+static u64 rng_state = 0x9e3779b97f4a7c15ULL;
+static u64 rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static const u32 Q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
+static bool lt_q(const Fr& a) {
+    for (int j = 7; j >= 0; j--) { if (a.v[j] < Q[j]) return true; if (a.v[j] > Q[j]) return false; }
+    return false;
+}
+static Fr canon(Fr a) { while (!lt_q(a)) { u32 br = 0; for (int j = 0; j < 8; j++) a.v[j] = fr_subb(a.v[j], Q[j], br, &br); } return a; }
+static Fr gen(int mode) {
+    Fr a;
+    for (int j = 0; j < 8; j++) {
+        u64 r = rnd();
+        switch (mode) {
+            case 0: a.v[j] = (u32)r; break;
+            case 1: a.v[j] = 0xFFFFFFFFu; break;
+            case 2: a.v[j] = (r & 1) ? 0xFFFFFFFFu : (u32)(r >> 32); break;
+            case 3: a.v[j] = (r & 3) ? 0xFFFFFFFFu : 0u; break;
+            default: a.v[j] = 0; break;
+        }
+    }
+    a.v[7] &= 0x3FFFFFFFu;          // < 2^254
+    return a;
+}
+int main() {
+    long bad = 0, n = 0;
+    Fr qm1; for (int j = 0; j < 8; j++) qm1.v[j] = Q[j]; qm1.v[0] -= 1;
+    for (int it = 0; it < 400000; it++) {
+        Fr a = canon(gen(it % 5)), b = canon(gen((it / 5) % 5));
+        if (it == 0) { a = qm1; b = qm1; }
+        if (it == 1) { a = qm1; b = fr_one(); }
+        ofr_t oa, ob, oc; memcpy(&oa, &a, 32); memcpy(&ob, &b, 32);
+        oracle_fr_mul(&oc, &oa, &ob);
+        Fr c = fr_mul(a, b);
+        if (memcmp(&c, &oc, 32)) bad++;
+        oracle_fr_add(&oc, &oa, &ob); c = fr_add(a, b); if (memcmp(&c, &oc, 32)) bad++;
+        oracle_fr_sub(&oc, &oa, &ob); c = fr_sub(a, b); if (memcmp(&c, &oc, 32)) bad++;
+        // lazy inputs: (a+q)*(b+q) raw must still reduce to the same canonical product
+        if (it % 4 == 0) {
+            Fr aq, bq; u32 cy = 0; for (int j = 0; j < 8; j++) aq.v[j] = fr_addc(a.v[j], Q[j], cy, &cy);
+            cy = 0; for (int j = 0; j < 8; j++) bq.v[j] = fr_addc(b.v[j], Q[j], cy, &cy);
+            oracle_fr_mul(&oc, &oa, &ob);
+            c = fr_reduce_once(fr_mont_mul_raw(aq, bq));
+            if (memcmp(&c, &oc, 32)) bad++;
+        }
+        // x^7
+        if (it % 8 == 0) {
+            ofr_t t; oracle_fr_mul(&t, &oa, &oa); oracle_fr_mul(&t, &t, &oa); oracle_fr_mul(&t, &t, &t); oracle_fr_mul(&t, &t, &oa);
+            c = fr_pow7(a); if (memcmp(&c, &t, 32)) bad++;
+        }
+        n++;
+    }
+    printf("cases=%ld bad=%ld\n", n, bad);
+    return bad ? 1 : 0;
+}

@@ -1,0 +1,72 @@
+"""CPU tests of the boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/gkrhip.h declares; the generated Montgomery schedule (portable branch) matches the oracle;
+the product never references oracle/."""
+import importlib
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gk():
+    b = importlib.import_module("gkr-mimc_amd.build")
+    b.build()
+    return importlib.import_module("gkr-mimc_amd")
+
+
+def test_library_exports_every_declared_symbol(gk):
+    hdr = open(os.path.join(ROOT, "include", "gkrhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gkrhip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = gk.prover.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(gk.prover.ABI), declared ^ set(gk.prover.ABI)
+
+
+def test_no_gpu_fails_loudly(gk):
+    if gk.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(gk.prover.GkrHipError):
+        gk.init(0)
+    import numpy as np
+    with pytest.raises(gk.prover.GkrHipError):
+        gk.fold(np.zeros((4, 4), np.uint64), np.zeros((1, 4), np.uint64))
+
+
+def test_proof_len(gk):
+    for bn in (0, 1, 5, 24):
+        assert gk.mimc_proof_len(bn) == 822 * bn + 183 + 184 * bn
+
+
+def test_montgomery_schedule_portable_branch(tmp_path):
+    """fr_bn254.h + fr_mont_gen.inc (host branch, identical column schedule to the device asm) vs oracle."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    exe = str(tmp_path / "test_fr")
+    subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_fr_schedule.cpp"),
+                           "-L" + os.path.join(ROOT, "oracle"), "-lgkr_oracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-fopenmp"])
+    out = subprocess.check_output([exe]).decode()
+    assert "bad=0" in out, out
+
+
+def test_generated_schedule_is_current():
+    inc = os.path.join(ROOT, "gkr-mimc_amd", "csrc", "fr_mont_gen.inc")
+    before = open(inc).read()
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_mont_asm.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before
+
+
+def test_product_does_not_reference_oracle():
+    pkg = os.path.join(ROOT, "gkr-mimc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".inc", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for bad in ("gkr_oracle", "coracle", "pyoracle", "libgkr_oracle"):
+                    assert bad not in txt, (f, bad)
