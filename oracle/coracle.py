@@ -21,9 +21,32 @@ def build():
     subprocess.check_call(["make", "-C", _here, "-s"])
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (a container can
+    see 256 logical CPUs while being allowed a handful; OpenMP would then oversubscribe badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def _load():
     if not os.path.exists(_SO):
         build()
+    # libgomp reads these when it is first loaded: sleep instead of spinning at barriers
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("OMP_PROC_BIND", "false")
     lib = C.CDLL(_SO)
     P = C.c_void_p
     sig = {
@@ -64,6 +87,7 @@ def _load():
 
 
 lib = _load()
+lib.oracle_set_num_threads(int(os.environ.get("GKR_ORACLE_THREADS", min(usable_cpus(), 64))))
 
 
 def fr(n=1):
