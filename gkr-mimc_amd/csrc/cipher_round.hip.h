@@ -1,0 +1,231 @@
+// cipher_round.hip.h -- the single-point cipher-gate sumcheck round (the 91 MiMC layers), one launch
+// per round:  fold(r_{k-1}) of both tables + the round's sums + cross-block reduction + hand-off to
+// the host, replacing the reference's dispatchPartialEvals / dispatchFolding pair
+// (sumcheck/prover.go:70-76,148-190; sumcheck/algo.go:46-51,54-205).
+//
+// Same polynomial, cheaper evaluation.  With one evaluation point q, after k folds the reference's
+// bookkeeping table is Eq_k(x) = c_k * eq(q[k:], x), c_k = prod_{i<k} eq(q_i, r_i), so the round
+// message is
+//     P_k(t) = c_k * eq(q_k, t) * S_k(t),     S_k(t) = sum_x W_k(x) * (u(x) + t*d(x))^7,
+//     W_k = eq(q[k+1:], .),  u = K_lo + S_lo + ark,  d = (K_hi - K_lo) + (S_hi - S_lo)
+// (K = key table, S = state table, pairs (x, x+mid), gate (K+S+ark)^7: circuit/gates/cipher.go:32-41).
+// The device returns the 8 monomial sums M_j = sum_x W_k(x) u^(7-j) d^j (23 multiplications per pair
+// instead of the 45 of evaluating at t = 0..8); the host multiplies by the binomials, by the linear
+// factor and by c_k, which yields exactly the coefficients poly.InterpolateOnRange produces from the
+// reference's nine evaluations (a polynomial of degree <= 8 is determined by them), hence the same
+// Fiat-Shamir challenges and the same transcript.  The Eq table is never materialised or folded:
+// W_k factorises over index bits into a per-thread factor Wt (low bits) and a per-iteration factor
+// Wj (high bits), both read from tiny "suffix pyramids" of eq tables.
+#pragma once
+#include "kernels.hip.h"
+
+#define GKR_CR_NSUM 8                          // M_0 .. M_7
+#define GKR_CR_WORDS (GKR_CR_NSUM * GKR_ACC_WORDS)
+
+// ------------------------------------------------------------------------------------------------
+// suffix pyramid: level s (s = 0..max_level) is the table eq(q[nc-s .. nc-1], .) of 2^s entries,
+// stored at element offset 2^s - 1.  Thread idx computes the running product over its low bits
+// (LSB <-> q[nc-1]) and writes level s when idx < 2^s.  max_level muls per thread, no dependencies
+// between threads (poly/eq.go:41-59 computes the same values by doubling).
+// ------------------------------------------------------------------------------------------------
+struct PyramidArgs {
+    Planes out;
+    const Fr* q;      // nc coordinates
+    int nc, max_level;
+    Fr seed;          // level-0 value (1, or the multiplier)
+};
+__global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)1 << a.max_level)) return;
+    const Fr one = fr_one();
+    Fr cur = a.seed;
+    if (idx == 0) st_fr(a.out.lo, a.out.hi, 0, cur);
+    for (int s = 1; s <= a.max_level; s++) {
+        const Fr qc = a.q[a.nc - s];
+        const bool bit = (idx >> (s - 1)) & 1;
+        const Fr f = bit ? qc : fr_sub(one, qc);
+        cur = fr_mul(cur, f);
+        if (idx < ((size_t)1 << s)) st_fr(a.out.lo, a.out.hi, (((size_t)1 << s) - 1) + idx, cur);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the round kernel
+// ------------------------------------------------------------------------------------------------
+struct CipherRoundArgs {
+    CPlanes k_src, s_src;  // FOLD: previous round's tables (4P elements); else this round's (2P)
+    Planes k_dst, s_dst;   // FOLD: folded tables (2P elements) are written here (may alias src)
+    CPlanes wt;            // per-thread factor: 2^g entries (pointer already at the level)
+    CPlanes wj;            // per-iteration factor: P >> g entries (HAS_WJ only)
+    size_t P;              // index pairs this round
+    unsigned g;            // log2(threads)
+    Fr r;                  // previous round's challenge (FOLD)
+    Fr ark;
+    unsigned long long* partials;   // [gridDim.x][GKR_CR_WORDS]
+    unsigned int* counter;          // arrival counter, zero at launch, reset by the last block
+    unsigned long long* host_out;   // host-mapped: GKR_CR_WORDS sums, then 8 x u64 x 4 tail elements
+    unsigned int* host_flag;        // host-mapped: set to `seq` when host_out is complete
+    unsigned int seq;
+};
+
+// a += x as an un-reduced 288-bit integer (x < 2^256).  One opaque carry chain: keeps hipcc from
+// widening the nine accumulator words to 64-bit pairs and from sinking all eight accumulations to
+// the end of the loop body (both of which spill).
+__device__ __forceinline__ void acc_add_raw(Acc9& a, const Fr& x) {
+    asm volatile(
+        "v_add_co_u32 %0, vcc, %0, %9\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %16, vcc\n\t"
+        "v_addc_co_u32 %8, vcc, 0, %8, vcc"
+        : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.w[4]), "+v"(a.w[5]), "+v"(a.w[6]),
+          "+v"(a.w[7]), "+v"(a.w[8])
+        : "v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]), "v"(x.v[4]), "v"(x.v[5]), "v"(x.v[6]), "v"(x.v[7])
+        : "vcc");
+}
+
+template <bool FOLD, bool HAS_WJ>
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a) {
+    __shared__ unsigned long long red[GKR_BLOCK / 64][GKR_CR_WORDS];
+    __shared__ unsigned int s_last;
+    Acc9 acc[GKR_CR_NSUM];
+#pragma unroll
+    for (int t = 0; t < GKR_CR_NSUM; t++)
+#pragma unroll
+        for (int j = 0; j < GKR_ACC_WORDS; j++) acc[t].w[j] = 0;
+
+    const size_t P = a.P;
+    const size_t threads = (size_t)1 << a.g;
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid < threads) {
+        const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
+        const Fr ark = a.ark;
+        const size_t iters = P >> a.g;
+        for (size_t j = 0; j < iters; j++) {
+            const size_t x = j * threads + gtid;
+            Fr klo, khi, slo, shi;
+            if (FOLD) {
+                // previous round's tables have 4P entries and pair (y, y+2P); this round pairs (x, x+P)
+                const Fr r = a.r;
+                const Fr k0 = ld_fr(a.k_src.lo, a.k_src.hi, x), k2 = ld_fr(a.k_src.lo, a.k_src.hi, x + 2 * P);
+                const Fr k1 = ld_fr(a.k_src.lo, a.k_src.hi, x + P), k3 = ld_fr(a.k_src.lo, a.k_src.hi, x + 3 * P);
+                const Fr s0 = ld_fr(a.s_src.lo, a.s_src.hi, x), s2 = ld_fr(a.s_src.lo, a.s_src.hi, x + 2 * P);
+                const Fr s1 = ld_fr(a.s_src.lo, a.s_src.hi, x + P), s3 = ld_fr(a.s_src.lo, a.s_src.hi, x + 3 * P);
+                klo = fr_add(k0, fr_mul(fr_sub(k2, k0), r));   // poly/multilin.go:32-34
+                khi = fr_add(k1, fr_mul(fr_sub(k3, k1), r));
+                slo = fr_add(s0, fr_mul(fr_sub(s2, s0), r));
+                shi = fr_add(s1, fr_mul(fr_sub(s3, s1), r));
+                st_fr(a.k_dst.lo, a.k_dst.hi, x, klo);
+                st_fr(a.k_dst.lo, a.k_dst.hi, x + P, khi);
+                st_fr(a.s_dst.lo, a.s_dst.hi, x, slo);
+                st_fr(a.s_dst.lo, a.s_dst.hi, x + P, shi);
+            } else {
+                klo = ld_fr(a.k_src.lo, a.k_src.hi, x);
+                khi = ld_fr(a.k_src.lo, a.k_src.hi, x + P);
+                slo = ld_fr(a.s_src.lo, a.s_src.hi, x);
+                shi = ld_fr(a.s_src.lo, a.s_src.hi, x + P);
+            }
+            const Fr u = fr_add(fr_add(klo, slo), ark);
+            const Fr d = fr_add(fr_sub(khi, klo), fr_sub(shi, slo));
+            Fr W = wt;
+            if (HAS_WJ) W = fr_mont_mul_raw(ld_fr(a.wj.lo, a.wj.hi, j), wt);
+            // all products below are lazy Montgomery products in [0, 2q).  The scheduling barriers keep
+            // hipcc from interleaving the independent products (which only raises register pressure:
+            // the kernel is VALU-bound and each product already saturates the issue slot).
+#define GKR_SB() __builtin_amdgcn_sched_barrier(0)
+            const Fr p = fr_mont_mul_raw(u, u);  GKR_SB();
+            const Fr r2 = fr_mont_mul_raw(d, d); GKR_SB();
+            const Fr A = fr_mont_mul_raw(p, u);  GKR_SB();   // u^3
+            const Fr B = fr_mont_mul_raw(p, d);  GKR_SB();   // u^2 d
+            const Fr C = fr_mont_mul_raw(u, r2); GKR_SB();   // u d^2
+            const Fr D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
+            const Fr v = fr_mont_mul_raw(W, u);  GKR_SB();
+            const Fr w = fr_mont_mul_raw(W, d);  GKR_SB();
+            Fr t;
+            t = fr_mont_mul_raw(A, A); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[0], t); GKR_SB();  // W u^7
+            t = fr_mont_mul_raw(A, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[1], t); GKR_SB();  // W u^6 d
+            t = fr_mont_mul_raw(B, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[2], t); GKR_SB();  // W u^5 d^2
+            t = fr_mont_mul_raw(A, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[3], t); GKR_SB();  // W u^4 d^3
+            t = fr_mont_mul_raw(C, C); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[4], t); GKR_SB();  // W u^3 d^4
+            t = fr_mont_mul_raw(C, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[5], t); GKR_SB();  // W u^2 d^5
+            const Fr D2 = fr_mont_mul_raw(D, D); GKR_SB();                                                             // d^6
+            t = fr_mont_mul_raw(v, D2); GKR_SB(); acc_add_raw(acc[6], t); GKR_SB();                                      // W u d^6
+            t = fr_mont_mul_raw(w, D2); GKR_SB(); acc_add_raw(acc[7], t); GKR_SB();                                      // W d^7
+#undef GKR_SB
+            if (P == 1) {
+                // last round: hand the two remaining entries of each table to the host, which applies
+                // the final fold (two scalar multiplications) to obtain finalClaims (prover.go:79-86)
+                unsigned long long* tail = a.host_out + GKR_CR_WORDS;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    tail[0 + l] = (unsigned long long)klo.v[2 * l] | ((unsigned long long)klo.v[2 * l + 1] << 32);
+                    tail[4 + l] = (unsigned long long)khi.v[2 * l] | ((unsigned long long)khi.v[2 * l + 1] << 32);
+                    tail[8 + l] = (unsigned long long)slo.v[2 * l] | ((unsigned long long)slo.v[2 * l + 1] << 32);
+                    tail[12 + l] = (unsigned long long)shi.v[2 * l] | ((unsigned long long)shi.v[2 * l + 1] << 32);
+                }
+            }
+        }
+    }
+
+    // ---- wave -> block reduction of the limb words (exact integer sums).  Each 32-bit word is summed
+    // over the wave as two 16-bit halves (sums < 2^22 fit 32-bit cross-lane adds), recombined by lane 0.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < GKR_CR_NSUM; t++) {
+#pragma unroll
+        for (int j = 0; j < GKR_ACC_WORDS; j++) {
+            u32 lo = acc[t].w[j] & 0xffffu, hi = acc[t].w[j] >> 16;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                lo += __shfl_xor(lo, off, 64);
+                hi += __shfl_xor(hi, off, 64);
+            }
+            if (lane == 0) red[wave][t * GKR_ACC_WORDS + j] = (unsigned long long)lo + ((unsigned long long)hi << 16);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GKR_CR_WORDS) {
+        unsigned long long s = 0;
+#pragma unroll
+        for (int w = 0; w < GKR_BLOCK / 64; w++) s += red[w][threadIdx.x];
+        a.partials[(size_t)blockIdx.x * GKR_CR_WORDS + threadIdx.x] = s;
+    }
+
+    // ---- last-arriving block sums the block partials and publishes to the host
+    // (agent-scope release by lane 0 after the block's stores have drained; acquire before re-reading)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = atomicAdd(a.counter, 1u);
+        const unsigned int last = (prev == gridDim.x - 1) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {
+        if (threadIdx.x < 3 * GKR_CR_WORDS) {   // three strided passes over the blocks, combined through LDS
+            const unsigned int w = threadIdx.x % GKR_CR_WORDS, part = threadIdx.x / GKR_CR_WORDS;
+            unsigned long long s = 0;
+            for (unsigned int b = part; b < gridDim.x; b += 3) s += a.partials[(size_t)b * GKR_CR_WORDS + w];
+            red[part][w] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < GKR_CR_WORDS) a.host_out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *a.counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}

@@ -131,10 +131,58 @@ static inline E pow7(const E& x) {  // hash/poseidon.go:129-135
     return mul(t, x);
 }
 
+// Lazy Montgomery product: no final conditional subtraction.  For x < 2^256 - q the running value stays
+// below x + q, so it fits four limbs; the result is < x*y/2^256 + q.
+static inline E mul_lazy(const E& x, const E& y) {
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#define HFR_ROW(yi)                                        \
+    {                                                      \
+        u128 a = (u128)x.l[0] * (yi) + t0;                 \
+        u64 lo0 = (u64)a;                                  \
+        a = (u128)x.l[1] * (yi) + t1 + (u64)(a >> 64);     \
+        u64 lo1 = (u64)a;                                  \
+        a = (u128)x.l[2] * (yi) + t2 + (u64)(a >> 64);     \
+        u64 lo2 = (u64)a;                                  \
+        a = (u128)x.l[3] * (yi) + t3 + (u64)(a >> 64);     \
+        u64 lo3 = (u64)a;                                  \
+        u64 hi = (u64)(a >> 64);                           \
+        u64 m = lo0 * QINV;                                \
+        a = (u128)m * Q[0] + lo0;                          \
+        a = (u128)m * Q[1] + lo1 + (u64)(a >> 64);         \
+        t0 = (u64)a;                                       \
+        a = (u128)m * Q[2] + lo2 + (u64)(a >> 64);         \
+        t1 = (u64)a;                                       \
+        a = (u128)m * Q[3] + lo3 + (u64)(a >> 64);         \
+        t2 = (u64)a;                                       \
+        t3 = hi + (u64)(a >> 64);                          \
+    }
+    HFR_ROW(y.l[0])
+    HFR_ROW(y.l[1])
+    HFR_ROW(y.l[2])
+    HFR_ROW(y.l[3])
+#undef HFR_ROW
+    E r = {{t0, t1, t2, t3}};
+    return r;
+}
+
 // hash/mimc.go:31-39
 static inline E mimc_keyed_permutation(const E& x, const E& key) {
+    // Fiat-Shamir is the serial floor of the prover (one hash of the round polynomial per round,
+    // 9 x 91 x^7 in a dependent chain), so this is written for latency: the round keys key+Ark_i do not
+    // depend on the state and are hoisted; x^7 = x^3 * x^4 has multiplicative depth 3 instead of the
+    // reference's sq-mul-sq-mul depth 4 (same value); the inner products are lazy (s < 2q:
+    // s2 < 1.76q, s3 < 1.67q, s4 < 1.59q, s7 < 1.51q before the single conditional subtraction).
+    E kc[MIMC_ROUNDS];
+    for (int i = 0; i < MIMC_ROUNDS; i++) kc[i] = add(key, ARKS[i]);
     E res = x;
-    for (int i = 0; i < MIMC_ROUNDS; i++) res = pow7(add(add(res, key), ARKS[i]));
+    for (int i = 0; i < MIMC_ROUNDS; i++) {
+        const E s = add(res, kc[i]);
+        const E s2 = mul_lazy(s, s);
+        const E s3 = mul_lazy(s2, s);
+        const E s4 = mul_lazy(s2, s2);
+        res = mul_lazy(s3, s4);
+        if (geq_q(res.l)) sub_q(res.l);
+    }
     return res;
 }
 // hash/mimc.go:11-28,43-49 : state <- state + (Perm_state(x) + state) + x

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #include <algorithm>
@@ -16,6 +18,7 @@
 #include "../../include/gkrhip.h"
 #include "fr_host.h"
 #include "kernels.hip.h"
+#include "cipher_round.hip.h"
 
 using hfr::E;
 
@@ -52,6 +55,15 @@ struct Ctx {
     size_t d_q_cap = 0;
     int max_grid = 2048;
     int n_cu = 256;
+    // fused cipher round (cipher_round.hip.h)
+    unsigned long long* h_round = nullptr;     // host-mapped: GKR_CR_WORDS sums + 16 tail words
+    unsigned long long* d_round = nullptr;     // device view of h_round
+    unsigned int* h_flag = nullptr;            // host-mapped completion flag
+    unsigned int* d_flag = nullptr;
+    unsigned int* d_counter = nullptr;         // block arrival counter
+    unsigned int seq = 0;
+    int g_max = 17;                            // log2(max threads of the round kernel)
+    bool force_generic = false;
     hfr::Lagrange* lag = nullptr;
     Profile prof;
     std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
@@ -108,6 +120,16 @@ int ctx_init(int dev) {
     HIPCHK(hipHostMalloc(&g.h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
     HIPCHK(hipMalloc(&g.d_small, sizeof(uint4) * 2 * 8));
     HIPCHK(hipHostMalloc(&g.h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&g.h_round, sizeof(unsigned long long) * (GKR_CR_WORDS + 16), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&g.d_round, g.h_round, 0));
+    HIPCHK(hipHostMalloc(&g.h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&g.d_flag, g.h_flag, 0));
+    *g.h_flag = 0;
+    g.seq = 0;
+    HIPCHK(hipMalloc(&g.d_counter, 64));
+    HIPCHK(hipMemset(g.d_counter, 0, 64));
+    if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
     g.lag = new hfr::Lagrange();
     g.device = dev;
     g.ready = true;
@@ -347,6 +369,152 @@ int build_eq(DevTable* eq, const E* qprimes, int nq, int bN, const E* seeds) {
     return 0;
 }
 
+// ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
+inline E limbs9_to_fr(const unsigned long long* w) {
+    hfr::u64 lanes[8];
+    for (int j = 0; j < 8; j++) lanes[j] = w[j];
+    const E lo = hfr::reduce_limbsplit(lanes);
+    const E hv = {{w[8], 0, 0, 0}};                  // w[8] * 2^256 mod q
+    return hfr::add(lo, hfr::mul(hv, hfr::R2));
+}
+
+int wait_flag(unsigned int seq) {
+    volatile unsigned int* f = g.h_flag;
+    unsigned long spins = 0;
+    while (*f != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {              // ~ every millisecond-ish: make sure the GPU is alive
+            hipError_t e = hipStreamQuery(g.stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
+            if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
+        }
+    }
+    __sync_synchronize();
+    return 0;
+}
+
+template <bool FOLD, bool HAS_WJ>
+void launch_cipher_round(const CipherRoundArgs& a, int grid) {
+    hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+}
+
+int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable* S, const E* q, const E& mult, E* proof,
+                         E* challenges, E* final_claims) {
+    const size_t n = (size_t)1 << bN;
+    const int gT = std::min(g.g_max, bN - 1);          // threads of round 0 = 2^gT
+    const int m = bN - 1 - gT;                         // log2(iterations of round 0)
+    // coordinates -> device
+    if ((size_t)bN > g.d_q_cap) {
+        if (g.d_q) HIPCHK(hipFree(g.d_q));
+        HIPCHK(hipMalloc(&g.d_q, sizeof(Fr) * std::max(bN, 64)));
+        g.d_q_cap = std::max(bN, 64);
+    }
+    std::vector<Fr> stage(bN);
+    for (int i = 0; i < bN; i++) stage[i] = to_dev(q[i]);
+    HIPCHK(hipMemcpyAsync(g.d_q, stage.data(), sizeof(Fr) * bN, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    // suffix pyramids
+    DevTable pyrT, pyrU, ks, ss;
+    CHK(table_alloc(&pyrT, (size_t)2 << gT));
+    CHK(table_alloc(&pyrU, (size_t)2 << std::max(m, 0)));
+    CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
+    CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
+    PyramidArgs pa;
+    pa.out = pyrT.planes();
+    pa.q = g.d_q;
+    pa.nc = bN;
+    pa.max_level = gT;
+    pa.seed = to_dev(hfr::ONE);
+    hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, g.stream, pa);
+    if (m > 0) {
+        pa.out = pyrU.planes();
+        pa.nc = bN - gT;                               // q[0 .. bN-gT-1]; level L = eq(q[nc-L .. nc-1], .)
+        pa.max_level = m;
+        hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << m, 1 << 20)), dim3(GKR_BLOCK), 0, g.stream, pa);
+    }
+    HIPCHK(hipGetLastError());
+
+    static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
+    E c = mult;                                         // c_k = mult * prod_{i<k} eq(q_i, r_i)
+    E r_prev = hfr::ZERO;
+    for (int k = 0; k < bN; k++) {
+        const size_t P = n >> (k + 1);
+        const int gk = std::min(g.g_max, bN - 1 - k);
+        const int lj = bN - 1 - k - gk;                // log2(iterations)
+        CipherRoundArgs a;
+        memset(&a, 0, sizeof a);
+        const bool fold = k > 0;
+        a.k_src = (k <= 1 ? K : &ks)->cplanes();
+        a.s_src = (k <= 1 ? S : &ss)->cplanes();
+        a.k_dst = ks.planes();
+        a.s_dst = ss.planes();
+        const size_t offT = ((size_t)1 << gk) - 1;
+        a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
+        if (lj > 0) {
+            const size_t offU = ((size_t)1 << lj) - 1;
+            a.wj = CPlanes{pyrU.base + offU, pyrU.base + pyrU.cap + offU};
+        }
+        a.P = P;
+        a.g = (unsigned)gk;
+        a.r = to_dev(r_prev);
+        a.ark = to_dev(ark);
+        a.partials = g.d_partials;
+        a.counter = g.d_counter;
+        a.host_out = g.d_round;
+        a.host_flag = g.d_flag;
+        a.seq = ++g.seq;
+        const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
+        const bool timed = 2 * P >= g.prof.min_n;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            e0 = prof_event();
+            e1 = prof_event();
+            HIPCHK(hipEventRecord(e0, g.stream));
+        }
+        if (fold) {
+            if (lj > 0) launch_cipher_round<true, true>(a, grid);
+            else launch_cipher_round<true, false>(a, grid);
+        } else {
+            if (lj > 0) launch_cipher_round<false, true>(a, grid);
+            else launch_cipher_round<false, false>(a, grid);
+        }
+        HIPCHK(hipGetLastError());
+        if (timed) {
+            HIPCHK(hipEventRecord(e1, g.stream));
+            g.prof.peval_ev.emplace_back(e0, e1);
+            g.prof.peval_launches++;
+            g.prof.peval_modmuls += (23.0 + (lj > 0 ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
+        }
+        CHK(wait_flag(a.seq));
+        // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
+        E sp[8];
+        for (int j = 0; j < 8; j++)
+            sp[j] = hfr::mul(limbs9_to_fr(g.h_round + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j]));
+        const E a0 = hfr::mul(c, hfr::sub(hfr::ONE, q[k]));
+        const E a1 = hfr::mul(c, hfr::sub(hfr::add(q[k], q[k]), hfr::ONE));
+        E* co = proof + (size_t)k * 9;
+        co[0] = hfr::mul(a0, sp[0]);
+        for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, sp[j]), hfr::mul(a1, sp[j - 1]));
+        co[8] = hfr::mul(a1, sp[7]);
+        const E r = hfr::mimc_hash(co, 9);
+        challenges[k] = r;
+        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
+        r_prev = r;
+    }
+    // final fold of the two remaining entries of each table (tail written by the P == 1 launch)
+    E tail[4];
+    memcpy(tail, g.h_round + GKR_CR_WORDS, sizeof tail);
+    final_claims[0] = c;
+    final_claims[1] = hfr::add(tail[0], hfr::mul(hfr::sub(tail[1], tail[0]), r_prev));
+    final_claims[2] = hfr::add(tail[2], hfr::mul(hfr::sub(tail[3], tail[2]), r_prev));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    table_release(&pyrT);
+    table_release(&pyrU);
+    table_release(&ks);
+    table_release(&ss);
+    return 0;
+}
+
 int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }
 
 // sumcheck.Prove on device-resident tables (sumcheck/prover.go:46-90).  X is read-only.
@@ -372,6 +540,9 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
         }
         nq_used = nq;
     }
+    if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !g.force_generic)
+        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, hfr::ONE, proof, challenges, final_claims);
+
     DevTable eq;
     CHK(table_alloc(&eq, n));
     CHK(build_eq(&eq, qprimes, nq_used, bN, seeds.data()));
@@ -655,6 +826,9 @@ void gkrhip_shutdown(void) {
     (void)hipHostFree(g.h_sums);
     (void)hipFree(g.d_small);
     (void)hipHostFree(g.h_small);
+    (void)hipHostFree(g.h_round);
+    (void)hipHostFree(g.h_flag);
+    (void)hipFree(g.d_counter);
     if (g.d_q) (void)hipFree(g.d_q);
     g.d_q = nullptr;
     g.d_q_cap = 0;

@@ -1,0 +1,39 @@
+"""Helper run in a subprocess by the GPU tests with different GKRHIP_* environment settings (they are
+read once, at library initialisation): compares sumcheck.Prove / gkr.Prove on the GPU against the
+oracle for a list of sizes and prints CASE-OK."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import coracle as c  # noqa: E402
+
+
+def main():
+    sizes = [int(x) for x in sys.argv[1].split(",")]
+    gk = importlib.import_module("gkr-mimc_amd")
+    gk.init(0)
+    for bn in sizes:
+        n = 1 << bn
+        rng = np.random.default_rng(bn)
+        X = [c.random_fr_array(n), c.from_ints([int(v) for v in rng.integers(0, 1 << 62, n)])]
+        ark = c.from_u64(145646)
+        qs = c.random_fr_array(bn).reshape(1, bn, 4)
+        claims = c.evaluation(c.GATE_CIPHER, ark, qs, c.fr(0), X)
+        got = gk.sumcheck_prove(X, qs, claims, gk.GATE_CIPHER, ark)
+        want = c.sumcheck_prove(c.GATE_CIPHER, ark, X, qs, claims)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), ("sumcheck", bn)
+        i0, qp = c.random_fr_array(n), c.random_fr_array(bn)
+        flat, outs = gk.gkr_prove_mimc(i0, X[1], qp)
+        oflat, oouts, _ = c.gkr_prove_mimc(bn, i0, X[1], qp)
+        assert np.array_equal(flat, oflat) and np.array_equal(outs, oouts), ("gkr", bn)
+    print("CASE-OK", sizes)
+
+
+if __name__ == "__main__":
+    main()

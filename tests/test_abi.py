@@ -55,6 +55,17 @@ def test_montgomery_schedule_portable_branch(tmp_path):
     assert "bad=0" in out, out
 
 
+def test_host_scalar_code_vs_oracle(tmp_path):
+    """fr_host.h (Fiat-Shamir MiMC hash written for latency, interpolation, limb-split reduction) vs oracle."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    exe = str(tmp_path / "test_host")
+    subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_host_fr.cpp"),
+                           "-L" + os.path.join(ROOT, "oracle"), "-lgkr_oracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-fopenmp"])
+    out = subprocess.check_output([exe]).decode()
+    assert "bad=0" in out, out
+
+
 def test_generated_schedule_is_current():
     inc = os.path.join(ROOT, "gkr-mimc_amd", "csrc", "fr_mont_gen.inc")
     before = open(inc).read()

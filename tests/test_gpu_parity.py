@@ -228,6 +228,29 @@ def test_sumcheck_cipher_bn20_vs_oracle(gk):
     assert np.array_equal(proof, oproof) and np.array_equal(chal, ochal) and np.array_equal(final, ofinal)
 
 
+def _run_case(env, sizes):
+    import os, subprocess, sys
+    e = dict(os.environ)
+    e.update(env)
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "gpu_case.py"), sizes], env=e, capture_output=True,
+                         text=True, timeout=1200)
+    assert out.returncode == 0 and "CASE-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_generic_partial_eval_path(gk):
+    """The reference-shaped evaluator (t = 0..8, Eq table folded) stays available and bit-identical:
+    GKRHIP_GENERIC=1 routes cipher layers through k_partial_eval + k_fold instead of k_cipher_round."""
+    _run_case({"GKRHIP_GENERIC": "1"}, "1,2,5,9,12")
+
+
+def test_round_kernel_small_thread_budget(gk):
+    """GKRHIP_GMAX=8 caps the round kernel at 256 threads so the per-iteration eq factor (Wj), the
+    multi-iteration loop and the multi-block hand-off are exercised at small sizes."""
+    _run_case({"GKRHIP_GMAX": "8"}, "1,3,8,9,10,13")
+    _run_case({"GKRHIP_GMAX": "10"}, "11,12,14")
+
+
 # ---------------------------------------------------------------- gkr.Prove (MimcCircuit)
 def test_gkr_golden(gk):
     for e in load("gkr_mimc.json"):
