@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def cpu_baseline(target_seconds=12.0):
+def cpu_baseline(target_seconds=40.0):
     """Time the CPU oracle (C restatement, OpenMP over the host cores) on a bounded sample of the same
     workload: gkr.Prove of 2^b MiMC hashes with RandomFrArray inputs; b grows until a run takes
     >= target_seconds/4 (each +1 doubles the work)."""
@@ -130,6 +130,10 @@ def main():
                                "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
                                "modmul_per_s": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
                                "bound": "integer VALU (no MFMA: modular arithmetic)"}
+    if prof.get("rounds"):
+        out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
+                                         ("host_hash_ms", "host_wait_ms", "host_launch_ms", "host_other_ms")}
+        out["host_split_ms_per_step"]["rounds"] = prof["rounds"] / args.steps
     if rank == 0 and not args.no_cpu_baseline and (dist is None or world == 1):
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -34,7 +34,15 @@ struct DevTable {
     CPlanes cplanes() const { return CPlanes{base, base + cap}; }
 };
 
+static inline double now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 struct Profile {
+    double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
+    uint64_t rounds = 0;
     size_t min_n = (size_t)1 << 62;
     uint64_t fold_launches = 0, peval_launches = 0;
     double fold_bytes = 0, peval_modmuls = 0;
@@ -471,6 +479,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
             e1 = prof_event();
             HIPCHK(hipEventRecord(e0, g.stream));
         }
+        const double t_l0 = now_ms();
         if (fold) {
             if (lj > 0) launch_cipher_round<true, true>(a, grid);
             else launch_cipher_round<true, false>(a, grid);
@@ -485,7 +494,9 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
             g.prof.peval_launches++;
             g.prof.peval_modmuls += (23.0 + (lj > 0 ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
+        const double t_l1 = now_ms();
         CHK(wait_flag(a.seq));
+        const double t_w = now_ms();
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         E sp[8];
         for (int j = 0; j < 8; j++)
@@ -496,10 +507,17 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
         co[0] = hfr::mul(a0, sp[0]);
         for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, sp[j]), hfr::mul(a1, sp[j - 1]));
         co[8] = hfr::mul(a1, sp[7]);
+        const double t_h0 = now_ms();
         const E r = hfr::mimc_hash(co, 9);
+        const double t_h1 = now_ms();
         challenges[k] = r;
         c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
         r_prev = r;
+        g.prof.host_launch_ms += t_l1 - t_l0;
+        g.prof.host_wait_ms += t_w - t_l1;
+        g.prof.host_other_ms += t_h0 - t_w;
+        g.prof.host_hash_ms += t_h1 - t_h0;
+        g.prof.rounds++;
     }
     // final fold of the two remaining entries of each table (tail written by the P == 1 launch)
     E tail[4];
@@ -1097,6 +1115,8 @@ int gkrhip_profile_reset(size_t min_n) {
     g.prof.peval_ev.clear();
     g.prof.fold_launches = g.prof.peval_launches = 0;
     g.prof.fold_bytes = g.prof.peval_modmuls = 0;
+    g.prof.host_hash_ms = g.prof.host_wait_ms = g.prof.host_launch_ms = g.prof.host_other_ms = 0;
+    g.prof.rounds = 0;
     g.prof.min_n = min_n == 0 ? ((size_t)1 << 62) : min_n;
     return 0;
 }
@@ -1123,6 +1143,16 @@ int gkrhip_profile_get(uint64_t* fold_launches, double* fold_ms, double* fold_by
     if (peval_launches) *peval_launches = g.prof.peval_launches;
     if (peval_ms) *peval_ms = pm;
     if (peval_modmuls) *peval_modmuls = g.prof.peval_modmuls;
+    return 0;
+}
+
+int gkrhip_profile_host(uint64_t* rounds, double* hash_ms, double* wait_ms, double* launch_ms, double* other_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (rounds) *rounds = g.prof.rounds;
+    if (hash_ms) *hash_ms = g.prof.host_hash_ms;
+    if (wait_ms) *wait_ms = g.prof.host_wait_ms;
+    if (launch_ms) *launch_ms = g.prof.host_launch_ms;
+    if (other_ms) *other_ms = g.prof.host_other_ms;
     return 0;
 }
 

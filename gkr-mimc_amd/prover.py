@@ -53,6 +53,7 @@ ABI = {
     "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D)]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
+    "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
 }
 
 
@@ -252,5 +253,9 @@ def profile_get():
     fl, pl = C.c_uint64(0), C.c_uint64(0)
     fm, fb, pm, pmm = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
     _check(load().gkrhip_profile_get(C.byref(fl), C.byref(fm), C.byref(fb), C.byref(pl), C.byref(pm), C.byref(pmm)))
+    r, hh, hw, hl, ho = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    _check(load().gkrhip_profile_host(C.byref(r), C.byref(hh), C.byref(hw), C.byref(hl), C.byref(ho)))
     return {"fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
-            "peval_launches": pl.value, "peval_ms": pm.value, "peval_modmuls": pmm.value}
+            "peval_launches": pl.value, "peval_ms": pm.value, "peval_modmuls": pmm.value,
+            "rounds": r.value, "host_hash_ms": hh.value, "host_wait_ms": hw.value, "host_launch_ms": hl.value,
+            "host_other_ms": ho.value}

@@ -98,6 +98,10 @@ int gkrhip_profile_reset(size_t min_n);
 int gkrhip_profile_get(uint64_t *fold_launches, double *fold_ms, double *fold_bytes,
                        uint64_t *peval_launches, double *peval_ms, double *peval_modmuls);
 
+/* Host-side wall-clock split of the fused cipher rounds since the last reset: Fiat-Shamir hashing,
+ * waiting for the round kernel, launching, other scalar work (all in ms), and the number of rounds. */
+int gkrhip_profile_host(uint64_t *rounds, double *hash_ms, double *wait_ms, double *launch_ms, double *other_ms);
+
 #ifdef __cplusplus
 }
 #endif
