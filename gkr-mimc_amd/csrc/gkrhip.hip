@@ -4,6 +4,13 @@
 // with every table-sized step replaced by a HIP kernel from kernels.hip.h.  Nothing here includes,
 // links or calls anything under oracle/.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,6 +79,7 @@ struct Ctx {
     unsigned int seq = 0;
     int g_max = 17;                            // log2(max threads of the round kernel)
     bool force_generic = false;
+    bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
     Profile prof;
     std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
@@ -138,6 +146,7 @@ int ctx_init(int dev) {
     HIPCHK(hipMemset(g.d_counter, 0, 64));
     if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
+    if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
     g.lag = new hfr::Lagrange();
     g.device = dev;
     g.ready = true;
@@ -276,10 +285,160 @@ int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t m
     return 0;
 }
 
+// ---- collective over the ranks of one node (RCCL over xGMI), loaded lazily -----------------------------
+// The only exchange of the path: an exact integer sum of limb-split lanes (u64), a handful of words per
+// round.  world == 1: no-ops.  RCCL is dlopen()ed on gkrhip_comm_init so that single-GPU use neither
+// links nor loads it.
+struct Coll {
+    int world = 1, rank = 0, gamma = 0;
+    void* dl = nullptr;
+    ncclComm_t comm = nullptr;
+    decltype(&ncclGetUniqueId) p_get_id = nullptr;
+    decltype(&ncclCommInitRank) p_init = nullptr;
+    decltype(&ncclAllReduce) p_allreduce = nullptr;
+    decltype(&ncclCommDestroy) p_destroy = nullptr;
+    decltype(&ncclGetErrorString) p_errstr = nullptr;
+    unsigned long long* d_buf = nullptr;   // device staging: lanes / gathered elements
+    unsigned long long* h_buf = nullptr;   // pinned mirror
+    size_t buf_words = 0;
+    // host shared-memory transport (processes of one node without RCCL, e.g. several ranks time-sharing
+    // one GPU in the tests): same call sites, sums formed on the host
+    struct ShmHdr {
+        std::atomic<unsigned> arrive, gen;
+    }* shm = nullptr;
+    unsigned long long* shm_slots = nullptr;
+    size_t shm_bytes = 0;
+    unsigned long long* h_tmp = nullptr;
+};
+Coll gc;
+const size_t kShmSlotWords = 8192;
+
+void shm_barrier() {
+    const unsigned gen = gc.shm->gen.load(std::memory_order_acquire);
+    if (gc.shm->arrive.fetch_add(1, std::memory_order_acq_rel) == (unsigned)gc.world - 1) {
+        gc.shm->arrive.store(0, std::memory_order_relaxed);
+        gc.shm->gen.fetch_add(1, std::memory_order_release);
+    } else {
+        while (gc.shm->gen.load(std::memory_order_acquire) == gen) __builtin_ia32_pause();
+    }
+}
+
+int coll_load() {
+    if (gc.dl) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        gc.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (gc.dl) break;
+    }
+    if (!gc.dl) return fail("cannot load RCCL (librccl.so.1): %s", dlerror());
+    gc.p_get_id = (decltype(gc.p_get_id))dlsym(gc.dl, "ncclGetUniqueId");
+    gc.p_init = (decltype(gc.p_init))dlsym(gc.dl, "ncclCommInitRank");
+    gc.p_allreduce = (decltype(gc.p_allreduce))dlsym(gc.dl, "ncclAllReduce");
+    gc.p_destroy = (decltype(gc.p_destroy))dlsym(gc.dl, "ncclCommDestroy");
+    gc.p_errstr = (decltype(gc.p_errstr))dlsym(gc.dl, "ncclGetErrorString");
+    if (!gc.p_get_id || !gc.p_init || !gc.p_allreduce || !gc.p_destroy || !gc.p_errstr)
+        return fail("RCCL library lacks a required symbol");
+    return 0;
+}
+int coll_buffers(size_t words) {
+    if (words <= gc.buf_words) return 0;
+    if (gc.d_buf) (void)hipFree(gc.d_buf);
+    if (gc.h_buf) (void)hipHostFree(gc.h_buf);
+    HIPCHK(hipMalloc(&gc.d_buf, sizeof(unsigned long long) * words));
+    HIPCHK(hipHostMalloc(&gc.h_buf, sizeof(unsigned long long) * words, hipHostMallocDefault));
+    gc.buf_words = words;
+    return 0;
+}
+#define NCCLCHK(x)                                                                             \
+    do {                                                                                       \
+        ncclResult_t _r = (x);                                                                 \
+        if (_r != ncclSuccess) return fail("%s failed: %s", #x, gc.p_errstr ? gc.p_errstr(_r) : "?"); \
+    } while (0)
+
+// in-place sum over ranks of n u64 lanes in device memory, on the library's stream
+int coll_allreduce(unsigned long long* d, int n) {
+    if (gc.comm) {
+        NCCLCHK(gc.p_allreduce(d, d, (size_t)n, ncclUint64, ncclSum, gc.comm, g.stream));
+        return 0;
+    }
+    if (gc.shm) {
+        if ((size_t)n > kShmSlotWords) return fail("shm all-reduce of %d words exceeds the slot", n);
+        if (!gc.h_tmp) HIPCHK(hipHostMalloc(&gc.h_tmp, sizeof(unsigned long long) * kShmSlotWords, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(gc.h_tmp, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        memcpy(gc.shm_slots + (size_t)gc.rank * kShmSlotWords, gc.h_tmp, sizeof(unsigned long long) * n);
+        shm_barrier();
+        for (int i = 0; i < n; i++) {
+            unsigned long long s = 0;
+            for (int r = 0; r < gc.world; r++) s += gc.shm_slots[(size_t)r * kShmSlotWords + i];
+            gc.h_tmp[i] = s;
+        }
+        shm_barrier();
+        HIPCHK(hipMemcpyAsync(d, gc.h_tmp, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        return 0;
+    }
+    return 0;
+}
+// all-gather of `cnt` field elements per rank (host values): rank g's elements land in out[g*cnt ..].
+// Implemented as an all-reduce of a zero-padded buffer (one contributor per slot: the sum is exact).
+int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
+    out.assign((size_t)gc.world * cnt, hfr::ZERO);
+    if (gc.world == 1 && !g.force_collective) {
+        for (int i = 0; i < cnt; i++) out[i] = mine[i];
+        return 0;
+    }
+    const size_t words = (size_t)gc.world * cnt * 4;
+    CHK(coll_buffers(std::max<size_t>(words, 256)));
+    memset(gc.h_buf, 0, words * 8);
+    memcpy(gc.h_buf + (size_t)gc.rank * cnt * 4, mine, (size_t)cnt * 32);
+    HIPCHK(hipMemcpyAsync(gc.d_buf, gc.h_buf, words * 8, hipMemcpyHostToDevice, g.stream));
+    CHK(coll_allreduce(gc.d_buf, (int)words));
+    HIPCHK(hipMemcpyAsync(gc.h_buf, gc.d_buf, words * 8, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out.data(), gc.h_buf, words * 8);
+    return 0;
+}
+
+// eq(q_tail, bits(rank)) with the table convention (q_tail[0] <-> most significant bit): the weight of
+// shard `rank` when the hypercube is sharded on its gamma lowest index bits (poly/eq.go:74-88 uses the same
+// factorisation for chunks).
+E shard_seed(const E* q_tail, int gamma, int rank) {
+    E r = hfr::ONE;
+    for (int i = 0; i < gamma; i++) {
+        const bool bit = (rank >> (gamma - 1 - i)) & 1;
+        r = hfr::mul(r, bit ? q_tail[i] : hfr::sub(hfr::ONE, q_tail[i]));
+    }
+    return r;
+}
+
+inline E limbs9_to_fr(const unsigned long long* w) {
+    hfr::u64 lanes[8];
+    for (int j = 0; j < 8; j++) lanes[j] = w[j];
+    const E lo = hfr::reduce_limbsplit(lanes);
+    const E hv = {{w[8], 0, 0, 0}};                  // w[8] * 2^256 mod q
+    return hfr::add(lo, hfr::mul(hv, hfr::R2));
+}
+
+// gather element 0 of up to 5 device tables to the host
+int gather0(const DevTable* const* t, int ntab, E* out) {
+    Gather0Args ga;
+    memset(&ga, 0, sizeof ga);
+    for (int i = 0; i < ntab; i++) ga.t[i] = t[i]->cplanes();
+    ga.ntab = ntab;
+    ga.out = g.d_small;
+    hipLaunchKernelGGL(k_gather0, dim3(1), dim3(64), 0, g.stream, ga);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g.h_small, g.d_small, 32 * ntab, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out, g.h_small, 32 * ntab);
+    return 0;
+}
+
 // evals[t] (t < nev) for the current round.  Launches the partial evaluation, the block reduction,
-// copies the limb-split sums to the host and reduces them mod q.
+// (all-reduces the limb-split sums across ranks,) copies them to the host and reduces them mod q.
 int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, E* evals,
-                  int nev) {
+                  int nev, bool collective) {
     int nblocks = 0;
     const bool timed = 2 * mid >= g.prof.min_n;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -307,55 +466,57 @@ int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const
     const int nwords = nev * GKR_ACC_WORDS;
     hipLaunchKernelGGL(k_reduce_partials, dim3(nwords), dim3(GKR_BLOCK), 0, g.stream, g.d_partials, g.d_sums, nblocks, nwords);
     HIPCHK(hipGetLastError());
+    if (collective) CHK(coll_allreduce(g.d_sums, nwords));
     HIPCHK(hipMemcpyAsync(g.h_sums, g.d_sums, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    for (int t = 0; t < nev; t++) {
-        // 9 lanes: fold lane 8 (the 2^256 column) into the 8-lane reducer
-        const unsigned long long* w = g.h_sums + (size_t)t * GKR_ACC_WORDS;
-        hfr::u64 lanes[8];
-        for (int j = 0; j < 8; j++) lanes[j] = w[j];
-        E lo = hfr::reduce_limbsplit(lanes);
-        E hv = {{w[8], 0, 0, 0}};                 // w[8] * 2^256 mod q
-        evals[t] = hfr::add(lo, hfr::mul(hv, hfr::R2));
-    }
+    for (int t = 0; t < nev; t++) evals[t] = limbs9_to_fr(g.h_sums + (size_t)t * GKR_ACC_WORDS);
     return 0;
 }
 
-// Build Eq = sum_j seed_j * eq(q_j, .) over 2^bN entries (poly/eq.go:41-59 + sumcheck/prover.go:102-144).
-int build_eq(DevTable* eq, const E* qprimes, int nq, int bN, const E* seeds) {
-    const size_t n = (size_t)1 << bN;
-    const int nhi = bN / 2, nlo = bN - nhi;
+int stage_coords(const E* coords, size_t n) {
+    if (n > g.d_q_cap) {
+        if (g.d_q) HIPCHK(hipFree(g.d_q));
+        g.d_q_cap = std::max<size_t>(n, 256);
+        HIPCHK(hipMalloc(&g.d_q, sizeof(Fr) * g.d_q_cap));
+    }
+    if (n == 0) return 0;
+    std::vector<Fr> stage(n);
+    for (size_t i = 0; i < n; i++) stage[i] = to_dev(coords[i]);
+    HIPCHK(hipMemcpyAsync(g.d_q, stage.data(), sizeof(Fr) * n, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));  // `stage` is pageable host memory
+    return 0;
+}
+
+// Build Eq = sum_j seed_j * eq(q_j[0:m], .) over 2^m entries (poly/eq.go:41-59 + sumcheck/prover.go:102-144).
+// qprimes holds nq points of q_stride coordinates each; only the first m coordinates of each are used.
+int build_eq(DevTable* eq, const E* qprimes, int nq, int q_stride, int m, const E* seeds) {
+    const size_t n = (size_t)1 << m;
+    const int nhi = m / 2, nlo = m - nhi;
     const size_t shi = (size_t)1 << nhi, slo = (size_t)1 << nlo;
     // stage coordinates + seeds (+ the constant one for the lo tables)
-    const size_t nfr = (size_t)nq * bN + 2 * (size_t)nq;
-    if (nfr > g.d_q_cap) {
-        if (g.d_q) HIPCHK(hipFree(g.d_q));
-        HIPCHK(hipMalloc(&g.d_q, sizeof(Fr) * nfr));
-        g.d_q_cap = nfr;
-    }
-    std::vector<Fr> stage(nfr);
-    for (size_t i = 0; i < (size_t)nq * bN; i++) stage[i] = to_dev(qprimes[i]);
+    const size_t ncoord = (size_t)nq * q_stride;
+    std::vector<E> stage(ncoord + 2 * (size_t)nq);
+    for (size_t i = 0; i < ncoord; i++) stage[i] = qprimes[i];
     for (int j = 0; j < nq; j++) {
-        stage[(size_t)nq * bN + j] = to_dev(seeds[j]);
-        stage[(size_t)nq * bN + nq + j] = to_dev(hfr::ONE);
+        stage[ncoord + j] = seeds[j];
+        stage[ncoord + nq + j] = hfr::ONE;
     }
-    HIPCHK(hipMemcpyAsync(g.d_q, stage.data(), sizeof(Fr) * nfr, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));  // `stage` is pageable host memory
+    CHK(stage_coords(stage.data(), stage.size()));
 
     DevTable thi, tlo;
     CHK(table_alloc(&thi, shi * nq));
     CHK(table_alloc(&tlo, slo * nq));
     EqSmallArgs s;
     s.q = g.d_q;
-    s.q_stride = bN;
+    s.q_stride = q_stride;
     s.out = thi.planes();
-    s.seeds = g.d_q + (size_t)nq * bN;
+    s.seeds = g.d_q + ncoord;
     s.nbits = nhi;
     s.q_off = 0;
     s.tab_stride = shi;
     hipLaunchKernelGGL(k_eq_small, dim3(nq), dim3(1024), 0, g.stream, s);
     s.out = tlo.planes();
-    s.seeds = g.d_q + (size_t)nq * bN + nq;
+    s.seeds = g.d_q + ncoord + nq;
     s.nbits = nlo;
     s.q_off = nhi;
     s.tab_stride = slo;
@@ -378,20 +539,12 @@ int build_eq(DevTable* eq, const E* qprimes, int nq, int bN, const E* seeds) {
 }
 
 // ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
-inline E limbs9_to_fr(const unsigned long long* w) {
-    hfr::u64 lanes[8];
-    for (int j = 0; j < 8; j++) lanes[j] = w[j];
-    const E lo = hfr::reduce_limbsplit(lanes);
-    const E hv = {{w[8], 0, 0, 0}};                  // w[8] * 2^256 mod q
-    return hfr::add(lo, hfr::mul(hv, hfr::R2));
-}
-
 int wait_flag(unsigned int seq) {
     volatile unsigned int* f = g.h_flag;
     unsigned long spins = 0;
     while (*f != seq) {
         __builtin_ia32_pause();
-        if ((++spins & 0xfffff) == 0) {              // ~ every millisecond-ish: make sure the GPU is alive
+        if ((++spins & 0xfffff) == 0) {              // every ~millisecond: make sure the GPU is alive
             hipError_t e = hipStreamQuery(g.stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
             if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
@@ -406,49 +559,45 @@ void launch_cipher_round(const CipherRoundArgs& a, int grid) {
     hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
 }
 
-int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable* S, const E* q, const E& mult, E* proof,
-                         E* challenges, E* final_claims) {
-    const size_t n = (size_t)1 << bN;
-    const int gT = std::min(g.g_max, bN - 1);          // threads of round 0 = 2^gT
-    const int m = bN - 1 - gT;                         // log2(iterations of round 0)
-    // coordinates -> device
-    if ((size_t)bN > g.d_q_cap) {
-        if (g.d_q) HIPCHK(hipFree(g.d_q));
-        HIPCHK(hipMalloc(&g.d_q, sizeof(Fr) * std::max(bN, 64)));
-        g.d_q_cap = std::max(bN, 64);
-    }
-    std::vector<Fr> stage(bN);
-    for (int i = 0; i < bN; i++) stage[i] = to_dev(q[i]);
-    HIPCHK(hipMemcpyAsync(g.d_q, stage.data(), sizeof(Fr) * bN, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    // suffix pyramids
+// The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
+// q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
+// monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
+// eq(q_k, r_k) of every round, proof/chal hold m rounds, tail = the two remaining entries of each table
+// (K_lo, K_hi, S_lo, S_hi) and r_last the last challenge (the caller applies the final fold).
+int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, const E* q, const E& seed, bool collective,
+                  E& c, E* proof, E* chal, E tail[4], E& r_last) {
+    const size_t n = (size_t)1 << m;
+    const int gT = std::min(g.g_max, m - 1);           // threads of round 0 = 2^gT
+    const int mU = m - 1 - gT;                         // log2(iterations of round 0)
+    CHK(stage_coords(q, (size_t)m));
     DevTable pyrT, pyrU, ks, ss;
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
-    CHK(table_alloc(&pyrU, (size_t)2 << std::max(m, 0)));
+    CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
     CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
     CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
     PyramidArgs pa;
     pa.out = pyrT.planes();
     pa.q = g.d_q;
-    pa.nc = bN;
+    pa.nc = m;
     pa.max_level = gT;
-    pa.seed = to_dev(hfr::ONE);
+    pa.seed = to_dev(seed);
     hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, g.stream, pa);
-    if (m > 0) {
+    if (mU > 0) {
         pa.out = pyrU.planes();
-        pa.nc = bN - gT;                               // q[0 .. bN-gT-1]; level L = eq(q[nc-L .. nc-1], .)
-        pa.max_level = m;
-        hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << m, 1 << 20)), dim3(GKR_BLOCK), 0, g.stream, pa);
+        pa.nc = m - gT;                                // q[0 .. m-gT-1]; level L = eq(q[nc-L .. nc-1], .)
+        pa.max_level = mU;
+        pa.seed = to_dev(hfr::ONE);
+        hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << mU, 1 << 20)), dim3(GKR_BLOCK), 0, g.stream, pa);
     }
     HIPCHK(hipGetLastError());
+    if (collective) CHK(coll_buffers(256));
 
     static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
-    E c = mult;                                         // c_k = mult * prod_{i<k} eq(q_i, r_i)
     E r_prev = hfr::ZERO;
-    for (int k = 0; k < bN; k++) {
+    for (int k = 0; k < m; k++) {
         const size_t P = n >> (k + 1);
-        const int gk = std::min(g.g_max, bN - 1 - k);
-        const int lj = bN - 1 - k - gk;                // log2(iterations)
+        const int gk = std::min(g.g_max, m - 1 - k);
+        const int lj = m - 1 - k - gk;                 // log2(iterations)
         CipherRoundArgs a;
         memset(&a, 0, sizeof a);
         const bool fold = k > 0;
@@ -468,7 +617,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
         a.ark = to_dev(ark);
         a.partials = g.d_partials;
         a.counter = g.d_counter;
-        a.host_out = g.d_round;
+        a.host_out = collective ? gc.d_buf : g.d_round;      // sharded: sums stay on the device for the all-reduce
         a.host_flag = g.d_flag;
         a.seq = ++g.seq;
         const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
@@ -495,12 +644,23 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
             g.prof.peval_modmuls += (23.0 + (lj > 0 ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
         const double t_l1 = now_ms();
-        CHK(wait_flag(a.seq));
+        const unsigned long long* words = g.h_round;
+        if (collective) {
+            // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are
+            // rank-local and are copied as they are
+            CHK(coll_allreduce(gc.d_buf, GKR_CR_WORDS));
+            HIPCHK(hipMemcpyAsync(gc.h_buf, gc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
+                                  hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+            words = gc.h_buf;
+        } else {
+            CHK(wait_flag(a.seq));
+        }
         const double t_w = now_ms();
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         E sp[8];
         for (int j = 0; j < 8; j++)
-            sp[j] = hfr::mul(limbs9_to_fr(g.h_round + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j]));
+            sp[j] = hfr::mul(limbs9_to_fr(words + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j]));
         const E a0 = hfr::mul(c, hfr::sub(hfr::ONE, q[k]));
         const E a1 = hfr::mul(c, hfr::sub(hfr::add(q[k], q[k]), hfr::ONE));
         E* co = proof + (size_t)k * 9;
@@ -510,21 +670,17 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
         const double t_h0 = now_ms();
         const E r = hfr::mimc_hash(co, 9);
         const double t_h1 = now_ms();
-        challenges[k] = r;
+        chal[k] = r;
         c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
         r_prev = r;
+        if (k == m - 1) memcpy(tail, words + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
         g.prof.host_launch_ms += t_l1 - t_l0;
         g.prof.host_wait_ms += t_w - t_l1;
         g.prof.host_other_ms += t_h0 - t_w;
         g.prof.host_hash_ms += t_h1 - t_h0;
         g.prof.rounds++;
     }
-    // final fold of the two remaining entries of each table (tail written by the P == 1 launch)
-    E tail[4];
-    memcpy(tail, g.h_round + GKR_CR_WORDS, sizeof tail);
-    final_claims[0] = c;
-    final_claims[1] = hfr::add(tail[0], hfr::mul(hfr::sub(tail[1], tail[0]), r_prev));
-    final_claims[2] = hfr::add(tail[2], hfr::mul(hfr::sub(tail[3], tail[2]), r_prev));
+    r_last = r_prev;
     HIPCHK(hipStreamSynchronize(g.stream));
     table_release(&pyrT);
     table_release(&pyrU);
@@ -533,56 +689,85 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     return 0;
 }
 
+inline E fold2(const E& lo, const E& hi, const E& r) { return hfr::add(lo, hfr::mul(hfr::sub(hi, lo), r)); }
+
+// host elements -> a small device table (boundary helper for the gathered shard tables)
+int small_table(DevTable* t, const std::vector<E>& v) {
+    CHK(table_alloc(t, v.size()));
+    return upload_table(t, (const uint64_t*)v.data(), v.size());
+}
+
+// sumcheck.Prove for the cipher gate with one evaluation point.  bN is the GLOBAL number of variables; K and
+// S are this rank's shard (2^(bN-gamma) entries, indices = rank mod world).  Phase 1: the bN-gamma local
+// rounds (sums all-reduced); then one element per table per rank is all-gathered and the last gamma
+// rounds run redundantly on every rank (phase 2).
+int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable* S, const E* q, E* proof, E* challenges,
+                         E* final_claims) {
+    const int gamma = gc.gamma, m1 = bN - gamma;
+    if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
+    E c = hfr::ONE, tail[4], r_last, kv, sv;
+    if (m1 >= 1) {
+        const E seed = gamma ? shard_seed(q + m1, gamma, gc.rank) : hfr::ONE;
+        CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || g.force_collective, c, proof, challenges, tail, r_last));
+        kv = fold2(tail[0], tail[1], r_last);
+        sv = fold2(tail[2], tail[3], r_last);
+    } else {
+        const DevTable* t[2] = {K, S};
+        E v[2];
+        CHK(gather0(t, 2, v));
+        kv = v[0];
+        sv = v[1];
+    }
+    if (gamma > 0) {
+        const E mine[2] = {kv, sv};
+        std::vector<E> all;
+        CHK(coll_allgather(mine, 2, all));
+        std::vector<E> k2(gc.world), s2(gc.world);
+        for (int r = 0; r < gc.world; r++) {
+            k2[r] = all[2 * r];
+            s2[r] = all[2 * r + 1];
+        }
+        DevTable K2, S2;
+        CHK(small_table(&K2, k2));
+        CHK(small_table(&S2, s2));
+        CHK(cipher_rounds(ark, gamma, &K2, &S2, q + m1, hfr::ONE, false, c, proof + (size_t)9 * m1, challenges + m1, tail,
+                          r_last));
+        kv = fold2(tail[0], tail[1], r_last);
+        sv = fold2(tail[2], tail[3], r_last);
+        table_release(&K2);
+        table_release(&S2);
+    }
+    final_claims[0] = c;
+    final_claims[1] = kv;
+    final_claims[2] = sv;
+    return 0;
+}
+
 int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }
 
-// sumcheck.Prove on device-resident tables (sumcheck/prover.go:46-90).  X is read-only.
-// proof: bN*(deg+2), challenges: bN, final: arity+1.
-int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
-                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims) {
-    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
-    if (nq < 1) return fail("need at least one evaluation point");
-    if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
-        return fail("provided a multi-instance %d but the number of claims does not match %d", nq, nclaims);
-    const size_t n = (size_t)1 << bN;
+// The reference-shaped rounds (sumcheck/prover.go:70-76) over an Eq table and `arity` tables of 2^m entries:
+// partial evaluation at t = 0..deg+1, interpolation, Fiat-Shamir, fold.  eq is folded in place, X is
+// read-only (round 0 folds into scratch).  On return `last` = [Eq[0], X_1[0], ...] of this rank.
+int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const DevTable* const* X, bool collective,
+                   E* proof, E* chal, E* last) {
+    const size_t n = (size_t)1 << m;
     const int nev = gate_degree(gate) + 2;
-
-    // ---- makeEqTable (prover.go:102-144)
-    std::vector<E> seeds(nq, hfr::ONE);
-    int nq_used = 1;
-    if (nclaims >= 1) {
-        const E rho = hfr::mimc_hash(claims, (size_t)nclaims);  // computed even when unused, as the reference
-        E m = rho;
-        for (int j = 1; j < nq; j++) {
-            seeds[j] = m;
-            m = hfr::mul(m, rho);
-        }
-        nq_used = nq;
-    }
-    if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !g.force_generic)
-        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, hfr::ONE, proof, challenges, final_claims);
-
-    DevTable eq;
-    CHK(table_alloc(&eq, n));
-    CHK(build_eq(&eq, qprimes, nq_used, bN, seeds.data()));
-
     DevTable scratch[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) CHK(table_alloc(&scratch[k], std::max<size_t>(n / 2, 1)));
-
-    const DevTable* cur[GKR_MAX_ARITY];
+    const DevTable* cur[GKR_MAX_ARITY + 1];
     for (int k = 0; k < arity; k++) cur[k] = X[k];
-
-    for (int k = 0; k < bN; k++) {  // prover.go:70-76
+    for (int k = 0; k < m; k++) {
         const size_t mid = n >> (k + 1);
         E evals[GKR_MAX_EVALS];
-        CHK(partial_evals(gate, arity, &eq, cur, mid, ark, evals, nev));
+        CHK(partial_evals(gate, arity, eq, cur, mid, ark, evals, nev, collective));
         E* coeffs = proof + (size_t)k * nev;
         g.lag->interpolate(coeffs, evals, nev);
         const E r = hfr::mimc_hash(coeffs, (size_t)nev);
-        challenges[k] = r;
+        chal[k] = r;
         const DevTable* src[GKR_MAX_ARITY + 1];
         const DevTable* dst[GKR_MAX_ARITY + 1];
-        src[0] = &eq;
-        dst[0] = &eq;
+        src[0] = eq;
+        dst[0] = eq;
         for (int t = 0; t < arity; t++) {
             src[1 + t] = cur[t];
             dst[1 + t] = &scratch[t];
@@ -590,22 +775,69 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
         CHK(launch_fold(src, dst, arity + 1, mid, r));
         for (int t = 0; t < arity; t++) cur[t] = &scratch[t];
     }
-
-    // finalClaims (prover.go:79-86)
-    Gather0Args ga;
-    memset(&ga, 0, sizeof ga);
-    ga.t[0] = eq.cplanes();
-    for (int t = 0; t < arity; t++) ga.t[1 + t] = cur[t]->cplanes();
-    ga.ntab = arity + 1;
-    ga.out = g.d_small;
-    hipLaunchKernelGGL(k_gather0, dim3(1), dim3(64), 0, g.stream, ga);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(g.h_small, g.d_small, 32 * (arity + 1), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    memcpy(final_claims, g.h_small, 32 * (arity + 1));
-
-    table_release(&eq);
+    const DevTable* all[GKR_MAX_ARITY + 1];
+    all[0] = eq;
+    for (int t = 0; t < arity; t++) all[1 + t] = cur[t];
+    CHK(gather0(all, arity + 1, last));   // finalClaims (prover.go:79-86)
     for (int k = 0; k < arity; k++) table_release(&scratch[k]);
+    return 0;
+}
+
+// sumcheck.Prove on device-resident tables (sumcheck/prover.go:46-90).  bN = GLOBAL number of variables;
+// X = this rank's shards (read-only).  proof: bN*(deg+2), challenges: bN, final: arity+1.
+int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
+                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims) {
+    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    if (nq < 1) return fail("need at least one evaluation point");
+    if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
+        return fail("provided a multi-instance %d but the number of claims does not match %d", nq, nclaims);
+    const int gamma = gc.gamma, m1 = bN - gamma;
+    if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
+    const int nev = gate_degree(gate) + 2;
+
+    // ---- makeEqTable (prover.go:102-144)
+    std::vector<E> seeds(nq, hfr::ONE);
+    int nq_used = 1;
+    if (nclaims >= 1) {
+        const E rho = hfr::mimc_hash(claims, (size_t)nclaims);  // computed even when unused, as the reference
+        E mlt = rho;
+        for (int j = 1; j < nq; j++) {
+            seeds[j] = mlt;
+            mlt = hfr::mul(mlt, rho);
+        }
+        nq_used = nq;
+    }
+    if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !g.force_generic)
+        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims);
+
+    // phase 1: this rank's shard; Eq_local = sum_j seed_j * eq(q_j tail, rank) * eq(q_j[0:m1], .)
+    if (gamma > 0)
+        for (int j = 0; j < nq_used; j++) seeds[j] = hfr::mul(seeds[j], shard_seed(qprimes + (size_t)j * bN + m1, gamma, gc.rank));
+    DevTable eq;
+    CHK(table_alloc(&eq, (size_t)1 << m1));
+    CHK(build_eq(&eq, qprimes, nq_used, bN, m1, seeds.data()));
+    E last[GKR_MAX_ARITY + 1];
+    CHK(generic_rounds(gate, ark, arity, m1, &eq, X, gamma > 0 || g.force_collective, proof, challenges, last));
+    table_release(&eq);
+    if (gamma > 0) {
+        // phase 2: one entry per table per rank -> tables over the gamma shard bits, same rounds on every rank
+        std::vector<E> all;
+        CHK(coll_allgather(last, arity + 1, all));
+        std::vector<std::vector<E>> cols(arity + 1, std::vector<E>(gc.world));
+        for (int r = 0; r < gc.world; r++)
+            for (int t = 0; t <= arity; t++) cols[t][r] = all[(size_t)r * (arity + 1) + t];
+        DevTable eq2, x2[GKR_MAX_ARITY];
+        const DevTable* X2[GKR_MAX_ARITY];
+        CHK(small_table(&eq2, cols[0]));
+        for (int t = 0; t < arity; t++) {
+            CHK(small_table(&x2[t], cols[1 + t]));
+            X2[t] = &x2[t];
+        }
+        CHK(generic_rounds(gate, ark, arity, gamma, &eq2, X2, false, proof + (size_t)nev * m1, challenges + m1, last));
+        table_release(&eq2);
+        for (int t = 0; t < arity; t++) table_release(&x2[t]);
+    }
+    for (int t = 0; t <= arity; t++) final_claims[t] = last[t];
     return 0;
 }
 
@@ -629,30 +861,37 @@ int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, 
     return 0;
 }
 
-// MultiLin.Evaluate on a device table (poly/multilin.go:59-66): fold chain into scratch.
-int evaluate_dev(const DevTable* t, size_t n, const E* coords, int nc, E* out) {
-    if (((size_t)1 << nc) != n) return fail("Evaluate: table has %zu elements but %d coordinates were given", n, nc);
+// MultiLin.Evaluate (poly/multilin.go:59-66) of a table of 2^nc entries: fold chain into scratch.  The
+// table is this rank's shard of 2^(nc-gamma) entries; the shard values are all-gathered and the last gamma
+// coordinates are applied to the gathered (<= world-entry) table.
+int evaluate_dev(const DevTable* t, int nc, const E* coords, E* out) {
+    const int gamma = gc.gamma, m1 = nc - gamma;
+    if (m1 < 0) return fail("Evaluate: %d coordinates for a table sharded over 2^%d ranks", nc, gamma);
+    const size_t n = (size_t)1 << m1;
     DevTable s;
     CHK(table_alloc(&s, std::max<size_t>(n / 2, 1)));
     const DevTable* cur = t;
-    for (int k = 0; k < nc; k++) {
+    for (int k = 0; k < m1; k++) {
         const size_t mid = n >> (k + 1);
         const DevTable* src[1] = {cur};
         const DevTable* dst[1] = {&s};
         CHK(launch_fold(src, dst, 1, mid, coords[k]));
         cur = &s;
     }
-    Gather0Args ga;
-    memset(&ga, 0, sizeof ga);
-    ga.t[0] = cur->cplanes();
-    ga.ntab = 1;
-    ga.out = g.d_small;
-    hipLaunchKernelGGL(k_gather0, dim3(1), dim3(64), 0, g.stream, ga);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(g.h_small, g.d_small, 32, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    memcpy(out, g.h_small, 32);
+    E v;
+    CHK(gather0(&cur, 1, &v));
     table_release(&s);
+    if (gamma > 0) {
+        std::vector<E> all;
+        CHK(coll_allgather(&v, 1, all));
+        for (int k = 0; k < gamma; k++) {           // <= world scalar folds
+            const size_t mid = all.size() / 2;
+            for (size_t i = 0; i < mid; i++) all[i] = fold2(all[i], all[i + mid], coords[m1 + k]);
+            all.resize(mid);
+        }
+        v = all[0];
+    }
+    *out = v;
     return 0;
 }
 
@@ -822,6 +1061,22 @@ int session_prove(gkrhip_mimc_session* s, const E* qprime, E* flat) {  // gkr/pr
 
 }  // namespace
 
+// Host-buffer entry points (Fold, Evaluate, FoldedEqTable, EvalBatch, sumcheck.Prove on host tables) always
+// run un-sharded on this process's GPU, whatever communicator is installed; only sessions shard.
+struct LocalOnly {
+    int world, rank, gamma;
+    LocalOnly() : world(gc.world), rank(gc.rank), gamma(gc.gamma) {
+        gc.world = 1;
+        gc.rank = 0;
+        gc.gamma = 0;
+    }
+    ~LocalOnly() {
+        gc.world = world;
+        gc.rank = rank;
+        gc.gamma = gamma;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -896,11 +1151,13 @@ int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint
     std::lock_guard<std::mutex> lk(g_mu);
     CHK(ensure_ctx());
     if (n < 1 || (n & (n - 1))) return fail("Evaluate: table length %zu is not a power of two", n);
+    if (((size_t)1 << ncoords) != n) return fail("Evaluate: table has %zu elements but %d coordinates were given", n, ncoords);
+    LocalOnly lo;
     DevTable t;
     CHK(table_alloc(&t, n));
     CHK(upload_table(&t, table, n));
     E res;
-    CHK(evaluate_dev(&t, n, (const E*)coords, ncoords, &res));
+    CHK(evaluate_dev(&t, ncoords, (const E*)coords, &res));
     memcpy(out, res.l, 32);
     table_release(&t);
     return 0;
@@ -915,7 +1172,7 @@ int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mu
     CHK(table_alloc(&t, n));
     E seed = hfr::ONE;
     if (mult_or_null) memcpy(seed.l, mult_or_null, 32);
-    CHK(build_eq(&t, (const E*)q, 1, bN, &seed));
+    CHK(build_eq(&t, (const E*)q, 1, bN, bN, &seed));
     CHK(download_table(&t, out, n));
     table_release(&t);
     return 0;
@@ -951,6 +1208,7 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int 
     if (bN < 0 || bN > 30) return fail("bN %d out of range", bN);
     if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
     const size_t n = (size_t)1 << bN;
+    LocalOnly lo;
     DevTable tabs[GKR_MAX_ARITY];
     const DevTable* X_[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) {
@@ -971,10 +1229,12 @@ size_t gkrhip_mimc_proof_len(int bN) { return (size_t)822 * bN + 183 + (size_t)1
 int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     std::lock_guard<std::mutex> lk(g_mu);
     CHK(ensure_ctx());
-    if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
+    if (bN < 0 || bN > 32) return fail("bN %d out of range", bN);
+    if (bN < gc.gamma) return fail("bN %d is smaller than log2(world) = %d", bN, gc.gamma);
+    if (bN - gc.gamma > 28) return fail("a shard of 2^%d entries does not fit one GPU", bN - gc.gamma);
     gkrhip_mimc_session* s = new gkrhip_mimc_session();
-    s->bN = bN;
-    s->n = (size_t)1 << bN;
+    s->bN = bN;                                   // global number of variables
+    s->n = (size_t)1 << (bN - gc.gamma);          // entries of this rank's shard
     s->c = mimc_circuit();
     const int rc = session_alloc(s);
     if (rc != 0) {
@@ -1035,7 +1295,7 @@ int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session* s, int layer, const 
     if (layer < 0 || layer >= (int)s->c.size()) return fail("layer %d out of range", layer);
     if (!s->assigned && layer >= 2) return fail("session is not assigned");
     E res;
-    CHK(evaluate_dev(session_table(s, layer), s->n, (const E*)coords, s->bN, &res));
+    CHK(evaluate_dev(session_table(s, layer), s->bN, (const E*)coords, &res));
     memcpy(out, res.l, 32);
     return 0;
 }
@@ -1143,6 +1403,139 @@ int gkrhip_profile_get(uint64_t* fold_launches, double* fold_ms, double* fold_by
     if (peval_launches) *peval_launches = g.prof.peval_launches;
     if (peval_ms) *peval_ms = pm;
     if (peval_modmuls) *peval_modmuls = g.prof.peval_modmuls;
+    return 0;
+}
+
+int gkrhip_comm_unique_id(uint8_t out[128]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(coll_load());
+    ncclUniqueId id;
+    NCCLCHK(gc.p_get_id(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out, &id, 128);
+    return 0;
+}
+
+int gkrhip_comm_init(int world, int rank, const uint8_t id_bytes[128]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
+        return fail("comm_init: world %d must be a power of two and 0 <= rank %d < world", world, rank);
+    if (gc.comm) return fail("communicator already initialised");
+    int gamma = 0;
+    while ((1 << gamma) < world) gamma++;
+    if (world > 1 || id_bytes) {
+        CHK(coll_load());
+        ncclUniqueId id;
+        memcpy(&id, id_bytes, 128);
+        NCCLCHK(gc.p_init(&gc.comm, world, id, rank));
+        CHK(coll_buffers(4096));
+    }
+    gc.world = world;
+    gc.rank = rank;
+    gc.gamma = gamma;
+    return 0;
+}
+
+int gkrhip_comm_init_shm(int world, int rank, const char* name) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    CHK(ensure_ctx());
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
+        return fail("comm_init_shm: world %d must be a power of two and 0 <= rank %d < world", world, rank);
+    if (gc.comm || gc.shm) return fail("communicator already initialised");
+    const size_t bytes = 4096 + sizeof(unsigned long long) * kShmSlotWords * world;
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(name, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return fail("shm_open/ftruncate(%s) failed", name);
+    } else {
+        for (int tries = 0; tries < 20000; tries++) {   // wait for rank 0 to create and size the segment
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            usleep(1000);
+        }
+        if (fd < 0) return fail("shm segment %s did not appear", name);
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail("mmap of %s failed", name);
+    gc.shm = (Coll::ShmHdr*)p;
+    gc.shm_slots = (unsigned long long*)((char*)p + 4096);
+    gc.shm_bytes = bytes;
+    CHK(coll_buffers(4096));
+    int gamma = 0;
+    while ((1 << gamma) < world) gamma++;
+    gc.world = world;
+    gc.rank = rank;
+    gc.gamma = gamma;
+    shm_barrier();   // everybody mapped (the segment is zero-filled by ftruncate)
+    return 0;
+}
+
+int gkrhip_comm_destroy(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (gc.comm) {
+        (void)hipStreamSynchronize(g.stream);
+        (void)gc.p_destroy(gc.comm);
+        gc.comm = nullptr;
+    }
+    if (gc.shm) {
+        munmap((void*)gc.shm, gc.shm_bytes);
+        gc.shm = nullptr;
+        gc.shm_slots = nullptr;
+    }
+    gc.world = 1;
+    gc.rank = 0;
+    gc.gamma = 0;
+    return 0;
+}
+
+int gkrhip_comm_info(int* world, int* rank) {
+    if (world) *world = gc.world;
+    if (rank) *rank = gc.rank;
+    return 0;
+}
+
+/* host-only scalar helpers of the sharded protocol (no GPU needed; used by the CPU multi-process tests) */
+int gkrhip_host_shard_seed(uint64_t out[4], const uint64_t* q_tail, int gamma, int rank) {
+    const E r = shard_seed((const E*)q_tail, gamma, rank);
+    memcpy(out, r.l, 32);
+    return 0;
+}
+int gkrhip_host_limbsplit_reduce(uint64_t out[4], const uint64_t* lanes, int nlanes) {
+    if (nlanes != 8 && nlanes != 9) return fail("limbsplit_reduce: 8 or 9 lanes");
+    unsigned long long w[9] = {0};
+    for (int i = 0; i < nlanes; i++) w[i] = lanes[i];
+    const E r = limbs9_to_fr(w);
+    memcpy(out, r.l, 32);
+    return 0;
+}
+int gkrhip_host_mimc_hash(uint64_t out[4], const uint64_t* in, size_t n) {
+    const E r = hfr::mimc_hash((const E*)in, n);
+    memcpy(out, r.l, 32);
+    return 0;
+}
+/* coefficients (9) of the cipher round polynomial from the 8 monomial sums M_j, the running constant c and
+ * the round's coordinate q_k:  c * ((1-q_k) + (2 q_k - 1) t) * sum_j C(7,j) M_j t^j */
+int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t* M, const uint64_t c_[4], const uint64_t qk_[4]) {
+    static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
+    E c, qk, sp[8], co[9];
+    memcpy(c.l, c_, 32);
+    memcpy(qk.l, qk_, 32);
+    for (int j = 0; j < 8; j++) {
+        E mj;
+        memcpy(mj.l, M + 4 * j, 32);
+        sp[j] = hfr::mul(mj, hfr::from_u64(binom7[j]));
+    }
+    const E a0 = hfr::mul(c, hfr::sub(hfr::ONE, qk));
+    const E a1 = hfr::mul(c, hfr::sub(hfr::add(qk, qk), hfr::ONE));
+    co[0] = hfr::mul(a0, sp[0]);
+    for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, sp[j]), hfr::mul(a1, sp[j - 1]));
+    co[8] = hfr::mul(a1, sp[7]);
+    memcpy(out, co, sizeof co);
     return 0;
 }
 

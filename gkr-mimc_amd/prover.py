@@ -50,6 +50,15 @@ ABI = {
     "gkrhip_mimc_session_outputs": (_I, [_P, _P]),
     "gkrhip_mimc_session_evaluate_layer": (_I, [_P, _I, _P, _P]),
     "gkrhip_mimc_session_destroy": (None, [_P]),
+    "gkrhip_comm_unique_id": (_I, [_P]),
+    "gkrhip_comm_init": (_I, [_I, _I, _P]),
+    "gkrhip_comm_init_shm": (_I, [_I, _I, C.c_char_p]),
+    "gkrhip_comm_destroy": (_I, []),
+    "gkrhip_comm_info": (_I, [C.POINTER(_I), C.POINTER(_I)]),
+    "gkrhip_host_shard_seed": (_I, [_P, _P, _I, _I]),
+    "gkrhip_host_limbsplit_reduce": (_I, [_P, _P, _I]),
+    "gkrhip_host_mimc_hash": (_I, [_P, _P, _SZ]),
+    "gkrhip_host_cipher_round_coeffs": (_I, [_P, _P, _P, _P]),
     "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D)]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
@@ -197,14 +206,21 @@ class MimcSession:
     def __init__(self, bN):
         self.bN = bN
         self._h = C.c_void_p()
+        w, r = C.c_int(1), C.c_int(0)
+        load().gkrhip_comm_info(C.byref(w), C.byref(r))
+        self.world, self.rank = w.value, r.value
+        self.local_n = (1 << bN) // self.world
         _check(load().gkrhip_mimc_session_create(C.byref(self._h), bN))
 
     def load_inputs(self, in0, in1):
         in0, in1 = _fr(in0), _fr(in1)
-        assert in0.shape[0] == 1 << self.bN and in1.shape[0] == 1 << self.bN
+        assert in0.shape[0] == self.local_n and in1.shape[0] == self.local_n
         _check(load().gkrhip_mimc_session_load_inputs(self._h, _ptr(in0), _ptr(in1)))
 
-    def synth_inputs(self, stride=1, offset=0):
+    def synth_inputs(self, stride=None, offset=None):
+        """RandomFrArray inputs generated on the device; defaults to this rank's shard."""
+        stride = self.world if stride is None else stride
+        offset = self.rank if offset is None else offset
         _check(load().gkrhip_mimc_session_synth_inputs(self._h, stride, offset))
 
     def assign(self):
@@ -217,7 +233,7 @@ class MimcSession:
         return flat
 
     def outputs(self):
-        out = np.zeros((1 << self.bN, 4), np.uint64)
+        out = np.zeros((self.local_n, 4), np.uint64)
         _check(load().gkrhip_mimc_session_outputs(self._h, _ptr(out)))
         return out
 
@@ -237,6 +253,53 @@ class MimcSession:
             self.close()
         except Exception:
             pass
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (call on rank 0, broadcast to the other ranks)."""
+    buf = np.zeros(128, np.uint8)
+    _check(load().gkrhip_comm_unique_id(_ptr(buf)))
+    return buf
+
+
+def comm_init(world, rank, unique_id):
+    uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
+    _check(load().gkrhip_comm_init(world, rank, _ptr(uid)))
+
+
+def comm_init_shm(world, rank, name):
+    _check(load().gkrhip_comm_init_shm(world, rank, name.encode()))
+
+
+def comm_destroy():
+    _check(load().gkrhip_comm_destroy())
+
+
+def host_shard_seed(q_tail, rank):
+    q_tail = _fr(q_tail).reshape(-1, 4)
+    out = np.zeros((1, 4), np.uint64)
+    _check(load().gkrhip_host_shard_seed(_ptr(out), _ptr(q_tail) if q_tail.shape[0] else None, q_tail.shape[0], rank))
+    return out
+
+
+def host_limbsplit_reduce(lanes):
+    lanes = np.ascontiguousarray(lanes, dtype=np.uint64)
+    out = np.zeros((1, 4), np.uint64)
+    _check(load().gkrhip_host_limbsplit_reduce(_ptr(out), _ptr(lanes), lanes.shape[0]))
+    return out
+
+
+def host_mimc_hash(arr):
+    arr = _fr(arr).reshape(-1, 4)
+    out = np.zeros((1, 4), np.uint64)
+    _check(load().gkrhip_host_mimc_hash(_ptr(out), _ptr(arr), arr.shape[0]))
+    return out
+
+
+def host_cipher_round_coeffs(M, c, qk):
+    out = np.zeros((9, 4), np.uint64)
+    _check(load().gkrhip_host_cipher_round_coeffs(_ptr(out), _ptr(_fr(M)), _ptr(_fr(c)), _ptr(_fr(qk))))
+    return out
 
 
 def bench_fold(n, ntab=1, warmup=3, iters=20):

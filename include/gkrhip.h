@@ -87,6 +87,34 @@ int gkrhip_mimc_session_outputs(gkrhip_mimc_session *s, uint64_t *outputs);
 int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session *s, int layer, const uint64_t *coords, uint64_t out[4]);
 void gkrhip_mimc_session_destroy(gkrhip_mimc_session *s);
 
+/* ---- multi-GPU: one process per GPU, hypercube sharded on its log2(world) LOWEST index bits ------------
+ * Rank g holds T_g[j] = T[j*world + g] of every table (a dense table over the top bN - log2(world)
+ * variables), so all local rounds pair (j, j+mid) exactly as on one GPU and no table data crosses xGMI.
+ * Per round the ranks all-reduce (RCCL ncclSum over ncclUint64) the limb-split partial sums -- an exact
+ * integer sum; a plain sum of packed 4x64-bit limbs would be wrong -- and every rank hashes the same
+ * coefficients.  After the local rounds one element per table per rank is gathered and the last
+ * log2(world) rounds run redundantly on every rank.  RCCL is dlopen()ed here, not linked.
+ * Bootstrap: rank 0 calls gkrhip_comm_unique_id, the 128 bytes are broadcast by the launcher
+ * (torch.distributed in bench.py), every rank calls gkrhip_comm_init after gkrhip_init(local GPU).
+ * Once installed, sessions take the GLOBAL bN; load/synth inputs and outputs are this rank's shard
+ * (synth: index_stride = world, index_offset = rank).  Host-buffer entry points stay un-sharded. */
+int gkrhip_comm_unique_id(uint8_t out[128]);
+int gkrhip_comm_init(int world, int rank, const uint8_t unique_id[128]);
+/* Same protocol over a POSIX shared-memory segment `name` (rank 0 creates it): the sums are formed on the
+ * host.  For processes of one node that cannot form an RCCL communicator -- in particular several ranks
+ * time-sharing ONE GPU, which is how the sharded driver is tested on single-GPU machines. */
+int gkrhip_comm_init_shm(int world, int rank, const char *name);
+int gkrhip_comm_destroy(void);
+int gkrhip_comm_info(int *world, int *rank);
+
+/* Host-only scalar pieces of the sharded protocol (no GPU needed): the shard weight eq(q_tail, bits(rank))
+ * (q_tail[0] <-> most significant rank bit), the reduction of 8 or 9 limb-split u64 lanes to an element,
+ * Fiat-Shamir, and the round coefficients from the eight monomial sums. */
+int gkrhip_host_shard_seed(uint64_t out[4], const uint64_t *q_tail, int gamma, int rank);
+int gkrhip_host_limbsplit_reduce(uint64_t out[4], const uint64_t *lanes, int nlanes);
+int gkrhip_host_mimc_hash(uint64_t out[4], const uint64_t *in, size_t n);
+int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t *M, const uint64_t c[4], const uint64_t qk[4]);
+
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 /* Device-resident fold micro-benchmark (shape of BenchmarkFolding, poly/multilin_test.go:55-78):
  * ntab tables of n elements (table[i] = Montgomery(i)), r = 5, `iters` timed out-of-place folds after

@@ -333,3 +333,48 @@ def test_gkr_bn18_vs_oracle_and_bn20_verified(gk):
     bad = flat.copy()
     bad[12345, 1] ^= np.uint64(4)
     assert c.gkr_verify_mimc(bn, bad, i0, i0, outs, qp) != 0
+
+
+# ---------------------------------------------------------------- sharded prover (multi-process, one GPU)
+def _run_shards(mode, world, sizes, env=None):
+    import os, subprocess, sys, uuid
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
+    e = dict(os.environ)
+    e.update(env or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), mode, str(world), str(r), name,
+                               sizes], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=1500)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    try:
+        os.unlink("/dev/shm" + name)
+    except OSError:
+        pass
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "SHARD-OK" in out, "rank %d:\n%s" % (r, out[-3000:])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_prover_matches_oracle(gk, world):
+    """shard on the lowest index bits; bN from log2(world) (no local round at all) upwards."""
+    g = world.bit_length() - 1
+    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10})))
+
+
+def test_sharded_prover_generic_path_and_small_budget(gk):
+    _run_shards("shm", 2, "3,6,9", {"GKRHIP_GENERIC": "1"})
+    _run_shards("shm", 4, "4,9,11", {"GKRHIP_GMAX": "8"})
+
+
+def test_rccl_plumbing_world1(gk):
+    """RCCL is dlopen()ed, a 1-rank communicator is created and every round's sums go through
+    ncclAllReduce (GKRHIP_FORCE_COLLECTIVE): the call sequence of the multi-GPU path on the one GPU we have."""
+    _run_shards("rccl", 1, "1,2,5,9", {"GKRHIP_FORCE_COLLECTIVE": "1"})
