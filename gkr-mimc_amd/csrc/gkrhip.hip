@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -319,7 +320,11 @@ void shm_barrier() {
         gc.shm->arrive.store(0, std::memory_order_relaxed);
         gc.shm->gen.fetch_add(1, std::memory_order_release);
     } else {
-        while (gc.shm->gen.load(std::memory_order_acquire) == gen) __builtin_ia32_pause();
+        unsigned spins = 0;
+        while (gc.shm->gen.load(std::memory_order_acquire) == gen) {
+            __builtin_ia32_pause();
+            if (++spins > 2000) sched_yield();   // ranks may outnumber the cores the cgroup allows
+        }
     }
 }
 

@@ -340,7 +340,7 @@ def _run_shards(mode, world, sizes, env=None):
     import os, subprocess, sys, uuid
     here = os.path.dirname(os.path.abspath(__file__))
     name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
-    e = dict(os.environ)
+    e = dict(os.environ, GKR_ORACLE_THREADS="2")
     e.update(env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), mode, str(world), str(r), name,
                                sizes], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -366,7 +366,7 @@ def _run_shards(mode, world, sizes, env=None):
 def test_sharded_prover_matches_oracle(gk, world):
     """shard on the lowest index bits; bN from log2(world) (no local round at all) upwards."""
     g = world.bit_length() - 1
-    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10})))
+    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10} if world < 8 else {3, 4, 8})))
 
 
 def test_sharded_prover_generic_path_and_small_budget(gk):
