@@ -88,8 +88,11 @@ __device__ __forceinline__ void acc_add_raw(Acc9& a, const Fr& x) {
         : "vcc");
 }
 
-template <bool FOLD, bool HAS_WJ>
-__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a) {
+// LAT = latency variant for the small rounds (at most one wave per SIMD is resident, so nothing hides the
+// ~10-cycle dependent-issue latency of a single multiplication chain): no scheduling barriers, so hipcc
+// interleaves the independent products of the monomial schedule, and a 512-VGPR budget.
+template <bool FOLD, bool HAS_WJ, bool LAT>
+__device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     __shared__ unsigned long long red[GKR_BLOCK / 64][GKR_CR_WORDS];
     __shared__ unsigned int s_last;
     Acc9 acc[GKR_CR_NSUM];
@@ -115,10 +118,20 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a
                 const Fr k1 = ld_fr(a.k_src.lo, a.k_src.hi, x + P), k3 = ld_fr(a.k_src.lo, a.k_src.hi, x + 3 * P);
                 const Fr s0 = ld_fr(a.s_src.lo, a.s_src.hi, x), s2 = ld_fr(a.s_src.lo, a.s_src.hi, x + 2 * P);
                 const Fr s1 = ld_fr(a.s_src.lo, a.s_src.hi, x + P), s3 = ld_fr(a.s_src.lo, a.s_src.hi, x + 3 * P);
+                if (LAT) {
+                    Fr f0, f1, f2, f3;
+                    fr_mont_mul2_raw(f0, f1, fr_sub(k2, k0), r, fr_sub(k3, k1), r);
+                    fr_mont_mul2_raw(f2, f3, fr_sub(s2, s0), r, fr_sub(s3, s1), r);
+                    klo = fr_add(k0, fr_reduce_once(f0));
+                    khi = fr_add(k1, fr_reduce_once(f1));
+                    slo = fr_add(s0, fr_reduce_once(f2));
+                    shi = fr_add(s1, fr_reduce_once(f3));
+                } else {
                 klo = fr_add(k0, fr_mul(fr_sub(k2, k0), r));   // poly/multilin.go:32-34
                 khi = fr_add(k1, fr_mul(fr_sub(k3, k1), r));
                 slo = fr_add(s0, fr_mul(fr_sub(s2, s0), r));
                 shi = fr_add(s1, fr_mul(fr_sub(s3, s1), r));
+                }
                 st_fr(a.k_dst.lo, a.k_dst.hi, x, klo);
                 st_fr(a.k_dst.lo, a.k_dst.hi, x + P, khi);
                 st_fr(a.s_dst.lo, a.s_dst.hi, x, slo);
@@ -136,25 +149,49 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a
             // all products below are lazy Montgomery products in [0, 2q).  The scheduling barriers keep
             // hipcc from interleaving the independent products (which only raises register pressure:
             // the kernel is VALU-bound and each product already saturates the issue slot).
-#define GKR_SB() __builtin_amdgcn_sched_barrier(0)
-            const Fr p = fr_mont_mul_raw(u, u);  GKR_SB();
-            const Fr r2 = fr_mont_mul_raw(d, d); GKR_SB();
-            const Fr A = fr_mont_mul_raw(p, u);  GKR_SB();   // u^3
-            const Fr B = fr_mont_mul_raw(p, d);  GKR_SB();   // u^2 d
-            const Fr C = fr_mont_mul_raw(u, r2); GKR_SB();   // u d^2
-            const Fr D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
-            const Fr v = fr_mont_mul_raw(W, u);  GKR_SB();
-            const Fr w = fr_mont_mul_raw(W, d);  GKR_SB();
-            Fr t;
+#define GKR_SB() do { if (!LAT) __builtin_amdgcn_sched_barrier(0); } while (0)
+            Fr p, r2, A, B, C, D, v, w, t, t2, D2;
+            if (LAT) {
+                // latency variant: products issued in independent pairs with interleaved instruction streams
+                fr_mont_mul2_raw(p, r2, u, u, d, d);
+                fr_mont_mul2_raw(A, B, p, u, p, d);          // u^3, u^2 d
+                fr_mont_mul2_raw(C, D, u, r2, r2, d);        // u d^2, d^3
+                fr_mont_mul2_raw(v, w, W, u, W, d);
+                fr_mont_mul2_raw(t, t2, A, A, A, B);
+                fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                acc_add_raw(acc[0], t);                      // W u^7
+                acc_add_raw(acc[1], t2);                     // W u^6 d
+                fr_mont_mul2_raw(t, t2, B, B, A, D);
+                fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                acc_add_raw(acc[2], t);                      // W u^5 d^2
+                acc_add_raw(acc[3], t2);                     // W u^4 d^3
+                fr_mont_mul2_raw(t, t2, C, C, C, D);
+                fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                acc_add_raw(acc[4], t);                      // W u^3 d^4
+                acc_add_raw(acc[5], t2);                     // W u^2 d^5
+                D2 = fr_mont_mul_raw(D, D);                  // d^6
+                fr_mont_mul2_raw(t, t2, v, D2, w, D2);
+                acc_add_raw(acc[6], t);                      // W u d^6
+                acc_add_raw(acc[7], t2);                     // W d^7
+            } else {
+            p = fr_mont_mul_raw(u, u);  GKR_SB();
+            r2 = fr_mont_mul_raw(d, d); GKR_SB();
+            A = fr_mont_mul_raw(p, u);  GKR_SB();   // u^3
+            B = fr_mont_mul_raw(p, d);  GKR_SB();   // u^2 d
+            C = fr_mont_mul_raw(u, r2); GKR_SB();   // u d^2
+            D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
+            v = fr_mont_mul_raw(W, u);  GKR_SB();
+            w = fr_mont_mul_raw(W, d);  GKR_SB();
             t = fr_mont_mul_raw(A, A); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[0], t); GKR_SB();  // W u^7
             t = fr_mont_mul_raw(A, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[1], t); GKR_SB();  // W u^6 d
             t = fr_mont_mul_raw(B, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[2], t); GKR_SB();  // W u^5 d^2
             t = fr_mont_mul_raw(A, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[3], t); GKR_SB();  // W u^4 d^3
             t = fr_mont_mul_raw(C, C); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[4], t); GKR_SB();  // W u^3 d^4
             t = fr_mont_mul_raw(C, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[5], t); GKR_SB();  // W u^2 d^5
-            const Fr D2 = fr_mont_mul_raw(D, D); GKR_SB();                                                             // d^6
+            D2 = fr_mont_mul_raw(D, D); GKR_SB();                                                                      // d^6
             t = fr_mont_mul_raw(v, D2); GKR_SB(); acc_add_raw(acc[6], t); GKR_SB();                                      // W u d^6
             t = fr_mont_mul_raw(w, D2); GKR_SB(); acc_add_raw(acc[7], t); GKR_SB();                                      // W d^7
+            }
 #undef GKR_SB
             if (P == 1) {
                 // last round: hand the two remaining entries of each table to the host, which applies
@@ -228,4 +265,13 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a
             __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+template <bool FOLD, bool HAS_WJ>
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a) {
+    cipher_round_body<FOLD, HAS_WJ, false>(a);
+}
+template <bool FOLD, bool HAS_WJ>
+__global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(CipherRoundArgs a) {
+    cipher_round_body<FOLD, HAS_WJ, true>(a);
 }

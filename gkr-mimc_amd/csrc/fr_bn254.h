@@ -120,6 +120,16 @@ FR_HD Fr fr_mont_mul_raw(const Fr& a, const Fr& b) {
     return r;
 }
 
+// two independent lazy products at once (instruction streams interleaved on the device: fr_mont2_gen.inc)
+FR_HD void fr_mont_mul2_raw(Fr& r0, Fr& r1, const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_mont2_gen.inc"
+#else
+    r0 = fr_mont_mul_raw(a0, b0);
+    r1 = fr_mont_mul_raw(a1, b1);
+#endif
+}
+
 // canonical product
 FR_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_reduce_once(fr_mont_mul_raw(a, b)); }
 FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_mul_raw(a, a)); }

@@ -80,6 +80,7 @@ struct Ctx {
     unsigned int seq = 0;
     int g_max = 17;                            // log2(max threads of the round kernel)
     bool force_generic = false;
+    int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
     Profile prof;
@@ -147,6 +148,7 @@ int ctx_init(int dev) {
     HIPCHK(hipMemset(g.d_counter, 0, 64));
     if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
+    if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
     g.lag = new hfr::Lagrange();
     g.device = dev;
@@ -560,8 +562,9 @@ int wait_flag(unsigned int seq) {
 }
 
 template <bool FOLD, bool HAS_WJ>
-void launch_cipher_round(const CipherRoundArgs& a, int grid) {
-    hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
+    if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+    else hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
 }
 
 // The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
@@ -634,12 +637,14 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             HIPCHK(hipEventRecord(e0, g.stream));
         }
         const double t_l0 = now_ms();
+        // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
+        const bool lat = g.lat_mode == 2 || (g.lat_mode == 1 && lj == 0);
         if (fold) {
-            if (lj > 0) launch_cipher_round<true, true>(a, grid);
-            else launch_cipher_round<true, false>(a, grid);
+            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat);
+            else launch_cipher_round<true, false>(a, grid, lat);
         } else {
-            if (lj > 0) launch_cipher_round<false, true>(a, grid);
-            else launch_cipher_round<false, false>(a, grid);
+            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat);
+            else launch_cipher_round<false, false>(a, grid, lat);
         }
         HIPCHK(hipGetLastError());
         if (timed) {

@@ -251,6 +251,13 @@ def test_round_kernel_small_thread_budget(gk):
     _run_case({"GKRHIP_GMAX": "10"}, "11,12,14")
 
 
+def test_round_kernel_variants(gk):
+    """The throughput kernel everywhere (GKRHIP_LAT=0) and the interleaved-pair kernel everywhere
+    (GKRHIP_LAT=2, with and without the per-iteration eq factor) give the same transcript."""
+    _run_case({"GKRHIP_LAT": "0"}, "1,4,9,12")
+    _run_case({"GKRHIP_LAT": "2", "GKRHIP_GMAX": "8"}, "1,4,9,12,13")
+
+
 # ---------------------------------------------------------------- gkr.Prove (MimcCircuit)
 def test_gkr_golden(gk):
     for e in load("gkr_mimc.json"):

@@ -114,7 +114,109 @@ def gen_mul():
     return dev + dfin, host + fin
 
 
+# ------------------------------------------------------------------------------------------------
+# mul2: two independent products with their instruction streams interleaved one-for-one, so that a wave
+# that is alone on its SIMD (the small sumcheck rounds) still has an independent instruction to issue
+# while the previous MAD/ADDC of the other chain is in flight.  Chain X carries in VCC, chain Y in a
+# scratch SGPR pair (VOP3 forms of v_mad_u64_u32 / v_addc_co_u32 take any SGPR pair for the carry).
+# ------------------------------------------------------------------------------------------------
+def cexpr2(o, ch):
+    k, i = o
+    if k == "q":
+        return "FRQ%d" % i
+    return {"a": "a%d.v[%d]", "b": "b%d.v[%d]", "m": "m%d_%d"}[k] % (ch, i)
+
+
+def emit_asm2(products, pos0):
+    ops = []          # (operand, chain) ; q operands are shared (chain None)
+    def key(o, ch):
+        return (o, None) if o[0] == "q" else (o, ch)
+    for x, y in products:
+        for ch in (0, 1):
+            for o in (x, y):
+                if key(o, ch) not in ops:
+                    ops.append(key(o, ch))
+    base = 5      # %0 acc0, %1 ovf0, %2 acc1, %3 ovf1, %4 sgpr carry pair of chain 1
+    names = {k: "%%%d" % (base + n) for n, k in enumerate(ops)}
+    lines = []
+    inits = False
+    for k, (x, y) in enumerate(products):
+        pos = pos0 + k
+        lines.append("v_mad_u64_u32 %%0, vcc, %s, %s, %%0" % (names[key(x, 0)], names[key(y, 0)]))
+        lines.append("v_mad_u64_u32 %%2, %%4, %s, %s, %%2" % (names[key(x, 1)], names[key(y, 1)]))
+        if pos == 0:
+            lines.append("v_addc_co_u32_e64 %1, vcc, 0, 0, vcc")
+            lines.append("v_addc_co_u32_e64 %3, %4, 0, 0, %4")
+            inits = True
+        else:
+            lines.append("v_addc_co_u32_e32 %1, vcc, 0, %1, vcc")
+            lines.append("v_addc_co_u32_e64 %3, %4, 0, %3, %4")
+    ovf = '"=&v"(ovf0), "+v"(acc1), "=&v"(ovf1)' if inits else '"+v"(ovf0), "+v"(acc1), "+v"(ovf1)'
+    ins = ", ".join('"%s"(%s)' % ("s" if o[0] == "q" else "v", cexpr2(o, ch)) for (o, ch) in ops)
+    body = '"' + '\\n\\t"\n        "'.join(lines) + '"'
+    assert len(ops) + base <= 30, len(ops)
+    return '    asm(%s\n        : "+v"(acc0), %s, "=&s"(sc)\n        : %s\n        : "vcc");\n' % (body, ovf, ins)
+
+
+def split2(products, limit=30):
+    chunks, cur = [], []
+    for p in products:
+        trial = cur + [p]
+        ops = set()
+        for x, y in trial:
+            for o in (x, y):
+                if o[0] == "q":
+                    ops.add((o, None))
+                else:
+                    ops.add((o, 0))
+                    ops.add((o, 1))
+        if len(ops) + 5 > limit and cur:
+            chunks.append(cur)
+            cur = [p]
+        else:
+            cur = trial
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
+def gen_mul2():
+    dev = ("    u64 acc0 = (u64)a0.v[0] * b0.v[0], acc1 = (u64)a1.v[0] * b1.v[0];\n"
+           "    u32 ovf0, ovf1;\n    unsigned long long sc;\n")
+    for c in range(2 * NL - 1):
+        prods = []
+        lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
+        if c > 0:
+            for i in range(lo_i, hi_i + 1):
+                prods.append((("a", i), ("b", c - i)))
+        for i in range(lo_i, hi_i + 1):
+            if c < NL and i == c:
+                continue
+            prods.append((("m", i), ("q", c - i)))
+        pos = 0
+        for ch in split2(prods):
+            dev += emit_asm2(ch, pos)
+            pos += len(ch)
+        if c < NL:
+            dev += "    const u32 m0_%d = (u32)acc0 * FR_QINV32, m1_%d = (u32)acc1 * FR_QINV32;\n" % (c, c)
+            dev += emit_asm2([(("m", c), ("q", 0))], pos)
+        else:
+            dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r0.v[%d]) : "v"((u32)acc0));\n' % (c - NL)
+            dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r1.v[%d]) : "v"((u32)acc1));\n' % (c - NL)
+        dev += "    acc0 = (acc0 >> 32) | ((u64)ovf0 << 32);\n    acc1 = (acc1 >> 32) | ((u64)ovf1 << 32);\n"
+    dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r0.v[%d]) : "v"((u32)acc0));\n' % (NL - 1)
+    dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r1.v[%d]) : "v"((u32)acc1));\n' % (NL - 1)
+    return dev
+
+
 def main():
+    out2 = os.path.join(os.path.dirname(OUT), "fr_mont2_gen.inc")
+    with open(out2, "w") as f:
+        f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Device body of fr_mont_mul2_raw() in fr_bn254.h:\n"
+                "// two independent lazy Montgomery products r0 = a0*b0/2^256, r1 = a1*b1/2^256 (both in [0, 2q)) with\n"
+                "// their instruction streams interleaved (chain 0 carries in VCC, chain 1 in the SGPR pair `sc`).\n")
+        f.write(gen_mul2())
+    print("wrote", out2)
     dev, host = gen_mul()
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Body of fr_mont_mul_raw() in fr_bn254.h:\n"
