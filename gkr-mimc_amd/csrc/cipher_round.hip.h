@@ -93,7 +93,7 @@ __device__ __forceinline__ void acc_add_raw(Acc9& a, const Fr& x) {
 // interleaves the independent products of the monomial schedule, and a 512-VGPR budget.
 template <bool FOLD, bool HAS_WJ, bool LAT>
 __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
-    __shared__ unsigned long long red[GKR_BLOCK / 64][GKR_CR_WORDS];
+    __shared__ unsigned long long red[3][GKR_CR_WORDS];
     __shared__ unsigned int s_last;
     Acc9 acc[GKR_CR_NSUM];
 #pragma unroll
@@ -208,29 +208,8 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
         }
     }
 
-    // ---- wave -> block reduction of the limb words (exact integer sums).  Each 32-bit word is summed
-    // over the wave as two 16-bit halves (sums < 2^22 fit 32-bit cross-lane adds), recombined by lane 0.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int t = 0; t < GKR_CR_NSUM; t++) {
-#pragma unroll
-        for (int j = 0; j < GKR_ACC_WORDS; j++) {
-            u32 lo = acc[t].w[j] & 0xffffu, hi = acc[t].w[j] >> 16;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                lo += __shfl_xor(lo, off, 64);
-                hi += __shfl_xor(hi, off, 64);
-            }
-            if (lane == 0) red[wave][t * GKR_ACC_WORDS + j] = (unsigned long long)lo + ((unsigned long long)hi << 16);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < GKR_CR_WORDS) {
-        unsigned long long s = 0;
-#pragma unroll
-        for (int w = 0; w < GKR_BLOCK / 64; w++) s += red[w][threadIdx.x];
-        a.partials[(size_t)blockIdx.x * GKR_CR_WORDS + threadIdx.x] = s;
-    }
+    // ---- block reduction of the limb words (exact integer sums), one partial per block
+    block_reduce_acc<GKR_CR_NSUM, 18>(acc, a.partials + (size_t)blockIdx.x * GKR_CR_WORDS);
 
     // ---- last-arriving block sums the block partials and publishes to the host
     // (agent-scope release by lane 0 after the block's stores have drained; acquire before re-reading)

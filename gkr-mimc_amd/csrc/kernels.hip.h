@@ -190,6 +190,45 @@ __device__ __forceinline__ void acc_add(Acc9& a, const Fr& x) {
     a.w[8] += c;
 }
 
+// Block reduction of NS un-reduced accumulators (NS*9 32-bit words per lane) to NS*9 exact 64-bit integer
+// sums, through LDS: the lanes store CH words at a time transposed ([word][lane], row stride 257 words so
+// that the column readers fall on different banks), then 4*CH threads each add the 64 lanes of one wave
+// for one word.  (A cross-lane butterfly needs 6 dependent ds_bpermute round trips per word; hipcc
+// serialises them, ~20 us per launch for 72 words -- more than the arithmetic of a small round.)
+template <int NS, int CH>
+__device__ __forceinline__ void block_reduce_acc(const Acc9 (&acc)[NS], unsigned long long* __restrict__ out) {
+    constexpr int NW = NS * GKR_ACC_WORDS;
+    static_assert(NW % CH == 0 && CH * 4 <= GKR_BLOCK, "chunking");
+    __shared__ u32 tr[CH][GKR_BLOCK + 1];
+    __shared__ unsigned long long red[GKR_BLOCK / 64][NW];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < NW / CH; p++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int wi = p * CH + c;
+            tr[c][tid] = acc[wi / GKR_ACC_WORDS].w[wi % GKR_ACC_WORDS];
+        }
+        __syncthreads();
+        if (tid < CH * 4) {
+            const int c = tid % CH, q = tid / CH;
+            unsigned long long s = 0;
+#pragma unroll 16
+            for (int i = 0; i < 64; i++) s += tr[c][q * 64 + ((i + 8 * q) & 63)];
+            red[q][p * CH + c] = s;
+        }
+        __syncthreads();
+    }
+    if (tid < NW) {
+        unsigned long long s = 0;
+#pragma unroll
+        for (int q = 0; q < GKR_BLOCK / 64; q++) s += red[q][tid];
+        out[tid] = s;
+    }
+}
+
 struct PartialEvalArgs {
     CPlanes eq;
     CPlanes x[GKR_MAX_ARITY];
@@ -200,7 +239,6 @@ struct PartialEvalArgs {
 
 template <int GATE, int ARITY, int NEV>
 __global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a) {
-    __shared__ unsigned long long red[GKR_BLOCK / 64][NEV * GKR_ACC_WORDS];
     Acc9 acc[NEV];
 #pragma unroll
     for (int t = 0; t < NEV; t++)
@@ -234,25 +272,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a
         }
     }
 
-    // wave reduction of the limb words as 64-bit integer sums
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int t = 0; t < NEV; t++) {
-#pragma unroll
-        for (int j = 0; j < GKR_ACC_WORDS; j++) {
-            unsigned long long s = acc[t].w[j];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (lane == 0) red[wave][t * GKR_ACC_WORDS + j] = s;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < NEV * GKR_ACC_WORDS) {
-        unsigned long long s = 0;
-#pragma unroll
-        for (int w = 0; w < GKR_BLOCK / 64; w++) s += red[w][threadIdx.x];
-        a.partials[(size_t)blockIdx.x * (NEV * GKR_ACC_WORDS) + threadIdx.x] = s;
-    }
+    block_reduce_acc<NEV, (NEV == 9 ? 27 : 27)>(acc, a.partials + (size_t)blockIdx.x * (NEV * GKR_ACC_WORDS));
 }
 
 // sum the per-block partials: out[k] = sum_b partials[b][k],  k < nwords
