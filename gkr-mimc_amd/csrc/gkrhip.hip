@@ -130,7 +130,7 @@ int ctx_init(int dev) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail("device %d is %s; libgkrhip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
     g.n_cu = prop.multiProcessorCount;
-    g.max_grid = g.n_cu * 8;
+    g.max_grid = g.n_cu * 32;   // streaming kernels: 8192 workgroups measured best for the fold (profiles/)
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&g.d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
@@ -149,6 +149,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.max_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
     g.lag = new hfr::Lagrange();
     g.device = dev;
@@ -262,7 +263,15 @@ int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab
         e1 = prof_event();
         HIPCHK(hipEventRecord(e0, g.stream));
     }
-    hipLaunchKernelGGL(k_fold, dim3(grid_for(mid, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, a);
+    const dim3 grid(grid_for(mid, g.max_grid)), block(GKR_BLOCK);
+    switch (ntab) {
+        case 1: hipLaunchKernelGGL(k_fold<1>, grid, block, 0, g.stream, a); break;
+        case 2: hipLaunchKernelGGL(k_fold<2>, grid, block, 0, g.stream, a); break;
+        case 3: hipLaunchKernelGGL(k_fold<3>, grid, block, 0, g.stream, a); break;
+        case 4: hipLaunchKernelGGL(k_fold<4>, grid, block, 0, g.stream, a); break;
+        case 5: hipLaunchKernelGGL(k_fold<5>, grid, block, 0, g.stream, a); break;
+        default: return fail("fold of %d tables not supported", ntab);
+    }
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(e1, g.stream));

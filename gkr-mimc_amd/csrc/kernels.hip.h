@@ -68,14 +68,33 @@ struct FoldArgs {
     size_t mid;
     Fr r;
 };
+// NTAB is a template parameter so that all 2*NTAB*2 plane loads of an index are issued before the first
+// multiplication (more bytes in flight per wave); the data is touched once, hence the non-temporal hints.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Fr ld_fr_nt(const uint4* __restrict__ lo, const uint4* __restrict__ hi, size_t i) {
+    const u32x4 a = __builtin_nontemporal_load((const u32x4*)(lo + i)), b = __builtin_nontemporal_load((const u32x4*)(hi + i));
+    Fr r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+__device__ __forceinline__ void st_fr_nt(uint4* __restrict__ lo, uint4* __restrict__ hi, size_t i, const Fr& x) {
+    const u32x4 a = {x.v[0], x.v[1], x.v[2], x.v[3]}, b = {x.v[4], x.v[5], x.v[6], x.v[7]};
+    __builtin_nontemporal_store(a, (u32x4*)(lo + i));
+    __builtin_nontemporal_store(b, (u32x4*)(hi + i));
+}
+template <int NTAB>
 __global__ void __launch_bounds__(GKR_BLOCK) k_fold(FoldArgs a) {
     const Fr r = a.r;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.mid; i += (size_t)gridDim.x * blockDim.x) {
-        for (int t = 0; t < a.ntab; t++) {
-            const Fr lo = ld_fr(a.src[t].lo, a.src[t].hi, i);
-            const Fr hi = ld_fr(a.src[t].lo, a.src[t].hi, i + a.mid);
-            const Fr d = fr_mul(fr_sub(hi, lo), r);
-            st_fr(a.dst[t].lo, a.dst[t].hi, i, fr_add(lo, d));
+        Fr lo[NTAB], hi[NTAB];
+#pragma unroll
+        for (int t = 0; t < NTAB; t++) {
+            lo[t] = ld_fr_nt(a.src[t].lo, a.src[t].hi, i);
+            hi[t] = ld_fr_nt(a.src[t].lo, a.src[t].hi, i + a.mid);
+        }
+#pragma unroll
+        for (int t = 0; t < NTAB; t++) {
+            const Fr d = fr_mul(fr_sub(hi[t], lo[t]), r);
+            st_fr_nt(a.dst[t].lo, a.dst[t].hi, i, fr_add(lo[t], d));
         }
     }
 }
