@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bn", type=int, default=24, help="log2 of the number of MiMC hashes per proof (per job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=2,
+                    help="independent proofs in flight (each on its own resident session/lane/stream); 1 = strictly "
+                         "one proof at a time.  Only un-sharded (1 GPU) runs can overlap proofs.")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,10 +83,35 @@ def main():
     # weak scaling: every GPU holds a 2^bn shard, the job proves 2^(bn + log2 N) hashes in ONE proof
     bn = args.bn + gamma
     # RandomFrArray(bN) as qPrime (gkr/gkr_test.go:93-95): element i = (i*i) ^ 0xf45c9df123f, Montgomery form.
-    s = gk.MimcSession(bn)
-    s.synth_inputs()            # block = initstate = RandomFrArray(2^bN), generated in HBM
-    s.assign()                  # Circuit.Assign: outside the timer, as BenchmarkGkr
+    import threading
+    nconc = 1 if (dist is not None and world > 1) else max(1, min(args.concurrent, args.steps))
+    sessions = []
+    for _ in range(nconc):
+        s = gk.MimcSession(bn)
+        s.synth_inputs()        # block = initstate = RandomFrArray(2^bN), generated in HBM
+        s.assign()              # Circuit.Assign: outside the timer, as BenchmarkGkr
+        sessions.append(s)
     qprime = random_fr_array_np(bn)
+    last = [None] * nconc
+
+    def run_steps(total):
+        """`total` full proofs; with nconc > 1 they are dealt round-robin to nconc sessions that prove
+        concurrently (one host thread each; ctypes releases the GIL inside the library)."""
+        if nconc == 1:
+            for _ in range(total):
+                last[0] = sessions[0].prove(qprime)
+            return
+        counts = [total // nconc + (1 if k < total % nconc else 0) for k in range(nconc)]
+
+        def work(k):
+            for _ in range(counts[k]):
+                last[k] = sessions[k].prove(qprime)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(nconc)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
 
     def sync_all():
         gk.synchronize()
@@ -92,15 +120,20 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
-        s.prove(qprime)
+    run_steps(max(args.warmup, 1 if nconc > 1 and args.warmup else 0))
+    # single-proof latency (one proof alone on the GPU), reported beside the throughput figure
+    sync_all()
+    tl = time.perf_counter()
+    last[0] = sessions[0].prove(qprime)
+    sync_all()
+    latency_ms = 1e3 * (time.perf_counter() - tl)
     gk.profile_reset(1 << args.bn)   # HIP-event accounting of the round-0 fold / partial-eval launches
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        flat = s.prove(qprime)
+    run_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
+    flat = last[0]
     prof = gk.profile_get()
     gk.profile_reset(0)
     if dist is not None:
@@ -126,7 +159,8 @@ def main():
         "config": {"workload": "gkr.Prove(MimcCircuit): ONE proof of 2^%d MiMC hashes, hypercube sharded on its low "
                                "index bits over %d GPU(s) (2^%d-entry shard per GPU), inputs RandomFrArray, "
                                "assignment resident in HBM" % (bn, max(world, 1) if dist is not None else 1, args.bn),
-                   "bN": bn, "bN_per_gpu": args.bn, "proof_elements": int(flat.shape[0])},
+                   "bN": bn, "bN_per_gpu": args.bn, "proof_elements": int(flat.shape[0]),
+                   "concurrent_proofs": nconc, "single_proof_latency_ms": latency_ms},
     }
     if prof["fold_launches"]:
         avg_ms = prof["fold_ms"] / prof["fold_launches"]
@@ -149,7 +183,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    s.close()
+    for s in sessions:
+        s.close()
     if dist is not None:
         gk.comm_destroy()
         dist.destroy_process_group()

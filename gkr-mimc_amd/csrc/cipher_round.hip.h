@@ -58,7 +58,7 @@ struct CipherRoundArgs {
     CPlanes wt;            // per-thread factor: 2^g entries (pointer already at the level)
     CPlanes wj;            // per-iteration factor: P >> g entries (HAS_WJ only)
     size_t P;              // index pairs this round
-    unsigned g;            // log2(threads)
+    unsigned lg_threads;   // log2(threads)
     Fr r;                  // previous round's challenge (FOLD)
     Fr ark;
     unsigned long long* partials;   // [gridDim.x][GKR_CR_WORDS]
@@ -102,12 +102,12 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
         for (int j = 0; j < GKR_ACC_WORDS; j++) acc[t].w[j] = 0;
 
     const size_t P = a.P;
-    const size_t threads = (size_t)1 << a.g;
+    const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr ark = a.ark;
-        const size_t iters = P >> a.g;
+        const size_t iters = P >> a.lg_threads;
         for (size_t j = 0; j < iters; j++) {
             const size_t x = j * threads + gtid;
             Fr klo, khi, slo, shi;

@@ -84,11 +84,27 @@ struct Ctx {
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
     Profile prof;
-    std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
+    std::mutex mu;                             // serialises the calls that use this lane
 };
 
-Ctx g;
-std::mutex g_mu;
+// A Ctx is a "lane": one stream plus every buffer a proof in flight needs exclusively.  g0 is the default
+// lane (host-buffer entry points, sharded sessions); each un-sharded session owns a lane of its own, so
+// independent sessions can prove concurrently from different host threads (one proof's Fiat-Shamir hashing
+// and small latency-bound rounds then overlap another proof's big rounds).
+Ctx g0;
+thread_local Ctx* g_cur = &g0;
+#define g (*g_cur)
+struct UseLane {
+    Ctx* prev;
+    explicit UseLane(Ctx* l) : prev(g_cur) { g_cur = l; }
+    ~UseLane() { g_cur = prev; }
+};
+std::mutex g_lanes_mu;
+std::vector<Ctx*> g_lanes;                     // every lane, for profile aggregation
+struct Pool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
+} g_pool;
 thread_local std::string g_err;
 
 int fail(const char* fmt, ...) {
@@ -113,6 +129,7 @@ int fail(const char* fmt, ...) {
     } while (0)
 
 const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
+int lane_alloc();
 
 int ctx_init(int dev) {
     if (g.ready) {
@@ -131,6 +148,24 @@ int ctx_init(int dev) {
         return fail("device %d is %s; libgkrhip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
     g.n_cu = prop.multiProcessorCount;
     g.max_grid = g.n_cu * 32;   // streaming kernels: 8192 workgroups measured best for the fold (profiles/)
+    if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
+    if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.max_grid = std::max(64, atoi(e));
+    if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
+    g.lag = new hfr::Lagrange();
+    g.device = dev;
+    CHK(lane_alloc());
+    {
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        g_lanes.push_back(&g);
+    }
+    g.ready = true;
+    return 0;
+}
+
+// stream + buffers of the current lane
+int lane_alloc() {
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&g.d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
@@ -146,31 +181,74 @@ int ctx_init(int dev) {
     g.seq = 0;
     HIPCHK(hipMalloc(&g.d_counter, 64));
     HIPCHK(hipMemset(g.d_counter, 0, 64));
-    if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
-    if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
-    if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
-    if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.max_grid = std::max(64, atoi(e));
-    if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
-    g.lag = new hfr::Lagrange();
-    g.device = dev;
-    g.ready = true;
     return 0;
+}
+void lane_free() {
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipFree(g.d_partials);
+    (void)hipFree(g.d_sums);
+    (void)hipHostFree(g.h_sums);
+    (void)hipFree(g.d_small);
+    (void)hipHostFree(g.h_small);
+    (void)hipHostFree(g.h_round);
+    (void)hipHostFree(g.h_flag);
+    (void)hipFree(g.d_counter);
+    if (g.d_q) (void)hipFree(g.d_q);
+    g.d_q = nullptr;
+    g.d_q_cap = 0;
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+}
+// a new lane configured like the default one
+Ctx* lane_create() {
+    Ctx* l = new Ctx();
+    l->device = g0.device;
+    l->n_cu = g0.n_cu;
+    l->max_grid = g0.max_grid;
+    l->g_max = g0.g_max;
+    l->force_generic = g0.force_generic;
+    l->lat_mode = g0.lat_mode;
+    l->force_collective = g0.force_collective;
+    l->lag = g0.lag;
+    l->prof.min_n = g0.prof.min_n;
+    UseLane u(l);
+    if (lane_alloc() != 0) {
+        delete l;
+        return nullptr;
+    }
+    l->ready = true;
+    std::lock_guard<std::mutex> lk(g_lanes_mu);
+    g_lanes.push_back(l);
+    return l;
+}
+void lane_destroy(Ctx* l) {
+    {
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        g_lanes.erase(std::remove(g_lanes.begin(), g_lanes.end(), l), g_lanes.end());
+    }
+    UseLane u(l);
+    lane_free();
+    delete l;
 }
 
 int ensure_ctx() {
-    if (!g.ready) return ctx_init(-1);
-    HIPCHK(hipSetDevice(g.device));
+    if (!g0.ready) {
+        UseLane u(&g0);
+        CHK(ctx_init(-1));
+    }
+    HIPCHK(hipSetDevice(g0.device));
     return 0;
 }
 
 // ---- device table arena (replaces poly/pool.go:69-126; no 2^24 cap) ---------------------------------
 int table_alloc(DevTable* t, size_t cap) {
     if (cap == 0) cap = 1;
-    for (size_t i = 0; i < g.free_list.size(); i++) {
-        if (g.free_list[i].first == cap) {
-            t->base = g.free_list[i].second;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (size_t i = 0; i < g_pool.free_list.size(); i++) {
+        if (g_pool.free_list[i].first == cap) {
+            t->base = g_pool.free_list[i].second;
             t->cap = cap;
-            g.free_list.erase(g.free_list.begin() + i);
+            g_pool.free_list.erase(g_pool.free_list.begin() + i);
             return 0;
         }
     }
@@ -178,8 +256,8 @@ int table_alloc(DevTable* t, size_t cap) {
     hipError_t e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
     if (e != hipSuccess) {
         // drop the cache and retry once
-        for (auto& f : g.free_list) (void)hipFree(f.second);
-        g.free_list.clear();
+        for (auto& f : g_pool.free_list) (void)hipFree(f.second);
+        g_pool.free_list.clear();
         e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
         if (e != hipSuccess) return fail("hipMalloc of a %zu-element table failed: %s", cap, hipGetErrorString(e));
     }
@@ -188,7 +266,10 @@ int table_alloc(DevTable* t, size_t cap) {
     return 0;
 }
 void table_release(DevTable* t) {
-    if (t->base) g.free_list.emplace_back(t->cap, t->base);
+    if (t->base) {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool.free_list.emplace_back(t->cap, t->base);
+    }
     t->base = nullptr;
     t->cap = 0;
 }
@@ -629,7 +710,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             a.wj = CPlanes{pyrU.base + offU, pyrU.base + pyrU.cap + offU};
         }
         a.P = P;
-        a.g = (unsigned)gk;
+        a.lg_threads = (unsigned)gk;
         a.r = to_dev(r_prev);
         a.ark = to_dev(ark);
         a.partials = g.d_partials;
@@ -982,6 +1063,7 @@ struct gkrhip_mimc_session {
     std::vector<DevTable> a;     // assignment; identity layers alias their input (no storage)
     std::vector<int> alias;      // alias[l] = layer whose table layer l shares, or l
     bool have_inputs = false, assigned = false;
+    Ctx* lane = nullptr;         // &g0 for sharded sessions, otherwise a lane of its own
 };
 
 namespace {
@@ -1102,29 +1184,26 @@ struct LocalOnly {
 extern "C" {
 
 int gkrhip_init(int device_ordinal) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
+    UseLane u(&g0);
     return ctx_init(device_ordinal);
 }
 
 void gkrhip_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.ready) return;
+    std::lock_guard<std::mutex> lk(g0.mu);
+    if (!g0.ready) return;
+    UseLane u(&g0);
     (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
-    for (auto& f : g.free_list) (void)hipFree(f.second);
-    g.free_list.clear();
-    (void)hipFree(g.d_partials);
-    (void)hipFree(g.d_sums);
-    (void)hipHostFree(g.h_sums);
-    (void)hipFree(g.d_small);
-    (void)hipHostFree(g.h_small);
-    (void)hipHostFree(g.h_round);
-    (void)hipHostFree(g.h_flag);
-    (void)hipFree(g.d_counter);
-    if (g.d_q) (void)hipFree(g.d_q);
-    g.d_q = nullptr;
-    g.d_q_cap = 0;
-    (void)hipStreamDestroy(g.stream);
+    lane_free();
+    {
+        std::lock_guard<std::mutex> pl(g_pool.mu);
+        for (auto& f : g_pool.free_list) (void)hipFree(f.second);
+        g_pool.free_list.clear();
+    }
+    {
+        std::lock_guard<std::mutex> ll(g_lanes_mu);
+        g_lanes.erase(std::remove(g_lanes.begin(), g_lanes.end(), &g0), g_lanes.end());
+    }
     delete g.lag;
     g.lag = nullptr;
     g.ready = false;
@@ -1141,14 +1220,14 @@ const char* gkrhip_last_error(void) { return g_err.c_str(); }
 const char* gkrhip_version(void) { return "gkrhip 0.1 (gfx950)"; }
 
 int gkrhip_device_synchronize(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
 
 int gkrhip_fold(uint64_t* table, size_t n, const uint64_t r[4]) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (n < 2 || (n & (n - 1))) return fail("Fold: table length %zu is not a power of two >= 2", n);
     DevTable t, o;
@@ -1167,7 +1246,7 @@ int gkrhip_fold(uint64_t* table, size_t n, const uint64_t r[4]) {
 }
 
 int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint64_t* coords, int ncoords) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (n < 1 || (n & (n - 1))) return fail("Evaluate: table length %zu is not a power of two", n);
     if (((size_t)1 << ncoords) != n) return fail("Evaluate: table has %zu elements but %d coordinates were given", n, ncoords);
@@ -1183,7 +1262,7 @@ int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint
 }
 
 int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mult_or_null) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (bN < 0 || bN > 30) return fail("eq table: bN %d out of range", bN);
     DevTable t;
@@ -1199,7 +1278,7 @@ int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mu
 
 int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res, const uint64_t* const* xs, int arity,
                            size_t n) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
     DevTable in[GKR_MAX_ARITY], out;
@@ -1222,7 +1301,7 @@ int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res,
 int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int bN, const uint64_t* const* X,
                           const uint64_t* qprimes, int nq, const uint64_t* claims, int nclaims, uint64_t* proof,
                           uint64_t* challenges, uint64_t* final_claims) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (bN < 0 || bN > 30) return fail("bN %d out of range", bN);
     if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
@@ -1246,7 +1325,7 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int 
 size_t gkrhip_mimc_proof_len(int bN) { return (size_t)822 * bN + 183 + (size_t)184 * bN; }
 
 int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (bN < 0 || bN > 32) return fail("bN %d out of range", bN);
     if (bN < gc.gamma) return fail("bN %d is smaller than log2(world) = %d", bN, gc.gamma);
@@ -1255,9 +1334,17 @@ int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     s->bN = bN;                                   // global number of variables
     s->n = (size_t)1 << (bN - gc.gamma);          // entries of this rank's shard
     s->c = mimc_circuit();
+    // collectives are issued from one stream in one order on every rank: sharded sessions share the default lane
+    const bool shared = gc.comm || gc.shm || g0.force_collective;
+    s->lane = shared ? &g0 : lane_create();
+    if (!s->lane) {
+        delete s;
+        return fail("cannot create a lane for the session: %s", g_err.c_str());
+    }
     const int rc = session_alloc(s);
     if (rc != 0) {
         for (auto& t : s->a) table_free(&t);
+        if (s->lane != &g0) lane_destroy(s->lane);
         delete s;
         return rc;
     }
@@ -1265,9 +1352,16 @@ int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     return 0;
 }
 
+// session entry points run on the session's lane: they take that lane's mutex only, so sessions with lanes
+// of their own proceed concurrently
+#define SESSION_ENTER(s)                                  \
+    if (!(s) || !(s)->lane) return fail("null session");   \
+    HIPCHK(hipSetDevice(g0.device));                      \
+    std::lock_guard<std::mutex> lk((s)->lane->mu);        \
+    UseLane ul((s)->lane)
+
 int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session* s, const uint64_t* in0, const uint64_t* in1) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
+    SESSION_ENTER(s);
     CHK(upload_table(&s->a[0], in0, s->n));
     CHK(upload_table(&s->a[1], in1, s->n));
     s->have_inputs = true;
@@ -1276,8 +1370,7 @@ int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session* s, const uint64_t* in0,
 }
 
 int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session* s, uint64_t index_stride, uint64_t index_offset) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
+    SESSION_ENTER(s);
     for (int l = 0; l < 2; l++) {
         hipLaunchKernelGGL(k_random_fr_array, dim3(grid_for(s->n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream,
                            s->a[l].planes(), s->n, (unsigned long long)index_stride, (unsigned long long)index_offset);
@@ -1290,27 +1383,23 @@ int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session* s, uint64_t index_stri
 }
 
 int gkrhip_mimc_session_assign(gkrhip_mimc_session* s) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
+    SESSION_ENTER(s);
     return session_assign(s);
 }
 
 int gkrhip_mimc_session_prove(gkrhip_mimc_session* s, const uint64_t* qprime, uint64_t* flat) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
+    SESSION_ENTER(s);
     return session_prove(s, (const E*)qprime, (E*)flat);
 }
 
 int gkrhip_mimc_session_outputs(gkrhip_mimc_session* s, uint64_t* outputs) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
+    SESSION_ENTER(s);
     if (!s->assigned) return fail("session is not assigned");
     return download_table(session_table(s, (int)s->c.size() - 1), outputs, s->n);
 }
 
 int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session* s, int layer, const uint64_t* coords, uint64_t out[4]) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
+    SESSION_ENTER(s);
     if (layer < 0 || layer >= (int)s->c.size()) return fail("layer %d out of range", layer);
     if (!s->assigned && layer >= 2) return fail("session is not assigned");
     E res;
@@ -1321,9 +1410,16 @@ int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session* s, int layer, const 
 
 void gkrhip_mimc_session_destroy(gkrhip_mimc_session* s) {
     if (!s) return;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g.ready) (void)hipSetDevice(g.device);
-    for (auto& t : s->a) table_free(&t);
+    if (g0.ready) (void)hipSetDevice(g0.device);
+    if (s->lane) {
+        {
+            std::lock_guard<std::mutex> lk(s->lane->mu);
+            UseLane ul(s->lane);
+            (void)hipStreamSynchronize(g.stream);
+            for (auto& t : s->a) table_free(&t);
+        }
+        if (s->lane != &g0) lane_destroy(s->lane);
+    }
     delete s;
 }
 
@@ -1340,7 +1436,7 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
 }
 
 int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (n < 2 || (n & (n - 1)) || ntab < 1 || ntab > GKR_MAX_ARITY + 1) return fail("bench_fold: bad arguments");
     std::vector<DevTable> src(ntab), dst(ntab);
@@ -1379,54 +1475,81 @@ int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms)
 }
 
 int gkrhip_profile_reset(size_t min_n) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
-    HIPCHK(hipStreamSynchronize(g.stream));
-    for (auto& p : g.prof.fold_ev) {
-        g.prof.pool.push_back(p.first);
-        g.prof.pool.push_back(p.second);
+    {
+        std::lock_guard<std::mutex> lk(g0.mu);
+        CHK(ensure_ctx());
     }
-    for (auto& p : g.prof.peval_ev) {
-        g.prof.pool.push_back(p.first);
-        g.prof.pool.push_back(p.second);
+    std::vector<Ctx*> lanes;
+    {
+        std::lock_guard<std::mutex> ll(g_lanes_mu);
+        lanes = g_lanes;
     }
-    g.prof.fold_ev.clear();
-    g.prof.peval_ev.clear();
-    g.prof.fold_launches = g.prof.peval_launches = 0;
-    g.prof.fold_bytes = g.prof.peval_modmuls = 0;
-    g.prof.host_hash_ms = g.prof.host_wait_ms = g.prof.host_launch_ms = g.prof.host_other_ms = 0;
-    g.prof.rounds = 0;
-    g.prof.min_n = min_n == 0 ? ((size_t)1 << 62) : min_n;
+    for (Ctx* l : lanes) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        UseLane u(l);
+        HIPCHK(hipStreamSynchronize(g.stream));
+        for (auto& p : g.prof.fold_ev) {
+            g.prof.pool.push_back(p.first);
+            g.prof.pool.push_back(p.second);
+        }
+        for (auto& p : g.prof.peval_ev) {
+            g.prof.pool.push_back(p.first);
+            g.prof.pool.push_back(p.second);
+        }
+        g.prof.fold_ev.clear();
+        g.prof.peval_ev.clear();
+        g.prof.fold_launches = g.prof.peval_launches = 0;
+        g.prof.fold_bytes = g.prof.peval_modmuls = 0;
+        g.prof.host_hash_ms = g.prof.host_wait_ms = g.prof.host_launch_ms = g.prof.host_other_ms = 0;
+        g.prof.rounds = 0;
+        g.prof.min_n = min_n == 0 ? ((size_t)1 << 62) : min_n;
+    }
     return 0;
 }
 
 int gkrhip_profile_get(uint64_t* fold_launches, double* fold_ms, double* fold_bytes, uint64_t* peval_launches,
                        double* peval_ms, double* peval_modmuls) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    CHK(ensure_ctx());
-    HIPCHK(hipStreamSynchronize(g.stream));
-    double fm = 0, pm = 0;
-    for (auto& p : g.prof.fold_ev) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
-        fm += ms;
+    {
+        std::lock_guard<std::mutex> lk(g0.mu);
+        CHK(ensure_ctx());
     }
-    for (auto& p : g.prof.peval_ev) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
-        pm += ms;
+    double fm = 0, pm = 0, fb = 0, pmm = 0;
+    uint64_t fl = 0, pl = 0;
+    std::vector<Ctx*> lanes;
+    {
+        std::lock_guard<std::mutex> ll(g_lanes_mu);
+        lanes = g_lanes;
     }
-    if (fold_launches) *fold_launches = g.prof.fold_launches;
+    for (Ctx* l : lanes) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        UseLane u(l);
+        HIPCHK(hipStreamSynchronize(g.stream));
+        for (auto& p : g.prof.fold_ev) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+            fm += ms;
+        }
+        for (auto& p : g.prof.peval_ev) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+            pm += ms;
+        }
+        fl += g.prof.fold_launches;
+        pl += g.prof.peval_launches;
+        fb += g.prof.fold_bytes;
+        pmm += g.prof.peval_modmuls;
+    }
+    if (fold_launches) *fold_launches = fl;
     if (fold_ms) *fold_ms = fm;
-    if (fold_bytes) *fold_bytes = g.prof.fold_bytes;
-    if (peval_launches) *peval_launches = g.prof.peval_launches;
+    if (fold_bytes) *fold_bytes = fb;
+    if (peval_launches) *peval_launches = pl;
     if (peval_ms) *peval_ms = pm;
-    if (peval_modmuls) *peval_modmuls = g.prof.peval_modmuls;
+    if (peval_modmuls) *peval_modmuls = pmm;
     return 0;
 }
 
 int gkrhip_comm_unique_id(uint8_t out[128]) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(coll_load());
     ncclUniqueId id;
     NCCLCHK(gc.p_get_id(&id));
@@ -1436,7 +1559,7 @@ int gkrhip_comm_unique_id(uint8_t out[128]) {
 }
 
 int gkrhip_comm_init(int world, int rank, const uint8_t id_bytes[128]) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
         return fail("comm_init: world %d must be a power of two and 0 <= rank %d < world", world, rank);
@@ -1457,7 +1580,7 @@ int gkrhip_comm_init(int world, int rank, const uint8_t id_bytes[128]) {
 }
 
 int gkrhip_comm_init_shm(int world, int rank, const char* name) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
         return fail("comm_init_shm: world %d must be a power of two and 0 <= rank %d < world", world, rank);
@@ -1495,7 +1618,7 @@ int gkrhip_comm_init_shm(int world, int rank, const char* name) {
 }
 
 int gkrhip_comm_destroy(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g0.mu);
     if (gc.comm) {
         (void)hipStreamSynchronize(g.stream);
         (void)gc.p_destroy(gc.comm);
@@ -1559,12 +1682,26 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t* M, const u
 }
 
 int gkrhip_profile_host(uint64_t* rounds, double* hash_ms, double* wait_ms, double* launch_ms, double* other_ms) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (rounds) *rounds = g.prof.rounds;
-    if (hash_ms) *hash_ms = g.prof.host_hash_ms;
-    if (wait_ms) *wait_ms = g.prof.host_wait_ms;
-    if (launch_ms) *launch_ms = g.prof.host_launch_ms;
-    if (other_ms) *other_ms = g.prof.host_other_ms;
+    uint64_t r = 0;
+    double h = 0, w = 0, l_ = 0, o = 0;
+    std::vector<Ctx*> lanes;
+    {
+        std::lock_guard<std::mutex> ll(g_lanes_mu);
+        lanes = g_lanes;
+    }
+    for (Ctx* l : lanes) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        r += l->prof.rounds;
+        h += l->prof.host_hash_ms;
+        w += l->prof.host_wait_ms;
+        l_ += l->prof.host_launch_ms;
+        o += l->prof.host_other_ms;
+    }
+    if (rounds) *rounds = r;
+    if (hash_ms) *hash_ms = h;
+    if (wait_ms) *wait_ms = w;
+    if (launch_ms) *launch_ms = l_;
+    if (other_ms) *other_ms = o;
     return 0;
 }
 
