@@ -52,8 +52,8 @@ def main():
     ap.add_argument("--bn", type=int, default=24, help="log2 of the number of MiMC hashes per proof (per job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrent", type=int, default=2,
-                    help="independent proofs in flight (each on its own resident session/lane/stream); 1 = strictly "
-                         "one proof at a time.  Only un-sharded (1 GPU) runs can overlap proofs.")
+                    help="independent proofs in flight (each on its own resident session/lane/stream and, when "
+                         "sharded, its own communicator); 1 = strictly one proof at a time")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,19 +72,19 @@ def main():
     gk.init(local_rank)
 
     import numpy as np
+    nconc = max(1, min(args.concurrent, args.steps))
     if dist is not None:
-        # install the library's own RCCL communicator (the per-round all-reduce of the limb-split sums lives
-        # inside the C++ round loop); torch.distributed only carries the 128-byte unique id, the barriers and
-        # the max-over-ranks of the timing
-        box = [gk.comm_unique_id().tobytes() if rank == 0 else None]
+        # install the library's own RCCL communicators, one per lane (the per-round all-reduce of the limb-split
+        # sums lives inside the C++ round loop); torch.distributed only carries the 128-byte unique ids, the
+        # barriers and the max-over-ranks of the timing
+        box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        gk.comm_init(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy())
+        gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
     gamma = (world.bit_length() - 1) if dist is not None else 0
     # weak scaling: every GPU holds a 2^bn shard, the job proves 2^(bn + log2 N) hashes in ONE proof
     bn = args.bn + gamma
     # RandomFrArray(bN) as qPrime (gkr/gkr_test.go:93-95): element i = (i*i) ^ 0xf45c9df123f, Montgomery form.
     import threading
-    nconc = 1 if (dist is not None and world > 1) else max(1, min(args.concurrent, args.steps))
     sessions = []
     for _ in range(nconc):
         s = gk.MimcSession(bn)

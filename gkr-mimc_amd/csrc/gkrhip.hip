@@ -58,6 +58,22 @@ struct Profile {
     std::vector<hipEvent_t> pool;
 };
 
+// per-lane state of the collective (one communicator / shared-memory segment per lane: the lanes of a rank
+// issue their collectives independently, lane k pairing with lane k of the other ranks)
+struct ShmHdr {
+    std::atomic<unsigned> arrive, gen;
+};
+struct LaneColl {
+    ncclComm_t comm = nullptr;
+    ShmHdr* shm = nullptr;
+    unsigned long long* shm_slots = nullptr;
+    size_t shm_bytes = 0;
+    unsigned long long* d_buf = nullptr;   // device staging: lanes / gathered elements
+    unsigned long long* h_buf = nullptr;   // pinned mirror
+    unsigned long long* h_tmp = nullptr;
+    size_t buf_words = 0;
+};
+
 struct Ctx {
     bool ready = false;
     int device = -1;
@@ -84,6 +100,7 @@ struct Ctx {
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
     Profile prof;
+    LaneColl lc;
     std::mutex mu;                             // serialises the calls that use this lane
 };
 
@@ -385,35 +402,27 @@ int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t m
 struct Coll {
     int world = 1, rank = 0, gamma = 0;
     void* dl = nullptr;
-    ncclComm_t comm = nullptr;
     decltype(&ncclGetUniqueId) p_get_id = nullptr;
     decltype(&ncclCommInitRank) p_init = nullptr;
     decltype(&ncclAllReduce) p_allreduce = nullptr;
     decltype(&ncclCommDestroy) p_destroy = nullptr;
     decltype(&ncclGetErrorString) p_errstr = nullptr;
-    unsigned long long* d_buf = nullptr;   // device staging: lanes / gathered elements
-    unsigned long long* h_buf = nullptr;   // pinned mirror
-    size_t buf_words = 0;
-    // host shared-memory transport (processes of one node without RCCL, e.g. several ranks time-sharing
-    // one GPU in the tests): same call sites, sums formed on the host
-    struct ShmHdr {
-        std::atomic<unsigned> arrive, gen;
-    }* shm = nullptr;
-    unsigned long long* shm_slots = nullptr;
-    size_t shm_bytes = 0;
-    unsigned long long* h_tmp = nullptr;
+    // per-lane: LaneColl (RCCL communicator, or the host shared-memory transport used by processes of one
+    // node without RCCL, e.g. several ranks time-sharing one GPU in the tests)
+    std::vector<Ctx*> lanes;               // the lanes that carry a communicator (lane 0 = default lane)
+    size_t next_lane = 0;
 };
 Coll gc;
 const size_t kShmSlotWords = 8192;
 
 void shm_barrier() {
-    const unsigned gen = gc.shm->gen.load(std::memory_order_acquire);
-    if (gc.shm->arrive.fetch_add(1, std::memory_order_acq_rel) == (unsigned)gc.world - 1) {
-        gc.shm->arrive.store(0, std::memory_order_relaxed);
-        gc.shm->gen.fetch_add(1, std::memory_order_release);
+    const unsigned gen = g.lc.shm->gen.load(std::memory_order_acquire);
+    if (g.lc.shm->arrive.fetch_add(1, std::memory_order_acq_rel) == (unsigned)gc.world - 1) {
+        g.lc.shm->arrive.store(0, std::memory_order_relaxed);
+        g.lc.shm->gen.fetch_add(1, std::memory_order_release);
     } else {
         unsigned spins = 0;
-        while (gc.shm->gen.load(std::memory_order_acquire) == gen) {
+        while (g.lc.shm->gen.load(std::memory_order_acquire) == gen) {
             __builtin_ia32_pause();
             if (++spins > 2000) sched_yield();   // ranks may outnumber the cores the cgroup allows
         }
@@ -438,12 +447,12 @@ int coll_load() {
     return 0;
 }
 int coll_buffers(size_t words) {
-    if (words <= gc.buf_words) return 0;
-    if (gc.d_buf) (void)hipFree(gc.d_buf);
-    if (gc.h_buf) (void)hipHostFree(gc.h_buf);
-    HIPCHK(hipMalloc(&gc.d_buf, sizeof(unsigned long long) * words));
-    HIPCHK(hipHostMalloc(&gc.h_buf, sizeof(unsigned long long) * words, hipHostMallocDefault));
-    gc.buf_words = words;
+    if (words <= g.lc.buf_words) return 0;
+    if (g.lc.d_buf) (void)hipFree(g.lc.d_buf);
+    if (g.lc.h_buf) (void)hipHostFree(g.lc.h_buf);
+    HIPCHK(hipMalloc(&g.lc.d_buf, sizeof(unsigned long long) * words));
+    HIPCHK(hipHostMalloc(&g.lc.h_buf, sizeof(unsigned long long) * words, hipHostMallocDefault));
+    g.lc.buf_words = words;
     return 0;
 }
 #define NCCLCHK(x)                                                                             \
@@ -454,24 +463,24 @@ int coll_buffers(size_t words) {
 
 // in-place sum over ranks of n u64 lanes in device memory, on the library's stream
 int coll_allreduce(unsigned long long* d, int n) {
-    if (gc.comm) {
-        NCCLCHK(gc.p_allreduce(d, d, (size_t)n, ncclUint64, ncclSum, gc.comm, g.stream));
+    if (g.lc.comm) {
+        NCCLCHK(gc.p_allreduce(d, d, (size_t)n, ncclUint64, ncclSum, g.lc.comm, g.stream));
         return 0;
     }
-    if (gc.shm) {
+    if (g.lc.shm) {
         if ((size_t)n > kShmSlotWords) return fail("shm all-reduce of %d words exceeds the slot", n);
-        if (!gc.h_tmp) HIPCHK(hipHostMalloc(&gc.h_tmp, sizeof(unsigned long long) * kShmSlotWords, hipHostMallocDefault));
-        HIPCHK(hipMemcpyAsync(gc.h_tmp, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, g.stream));
+        if (!g.lc.h_tmp) HIPCHK(hipHostMalloc(&g.lc.h_tmp, sizeof(unsigned long long) * kShmSlotWords, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(g.lc.h_tmp, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
-        memcpy(gc.shm_slots + (size_t)gc.rank * kShmSlotWords, gc.h_tmp, sizeof(unsigned long long) * n);
+        memcpy(g.lc.shm_slots + (size_t)gc.rank * kShmSlotWords, g.lc.h_tmp, sizeof(unsigned long long) * n);
         shm_barrier();
         for (int i = 0; i < n; i++) {
             unsigned long long s = 0;
-            for (int r = 0; r < gc.world; r++) s += gc.shm_slots[(size_t)r * kShmSlotWords + i];
-            gc.h_tmp[i] = s;
+            for (int r = 0; r < gc.world; r++) s += g.lc.shm_slots[(size_t)r * kShmSlotWords + i];
+            g.lc.h_tmp[i] = s;
         }
         shm_barrier();
-        HIPCHK(hipMemcpyAsync(d, gc.h_tmp, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d, g.lc.h_tmp, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
         return 0;
     }
@@ -487,13 +496,13 @@ int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     }
     const size_t words = (size_t)gc.world * cnt * 4;
     CHK(coll_buffers(std::max<size_t>(words, 256)));
-    memset(gc.h_buf, 0, words * 8);
-    memcpy(gc.h_buf + (size_t)gc.rank * cnt * 4, mine, (size_t)cnt * 32);
-    HIPCHK(hipMemcpyAsync(gc.d_buf, gc.h_buf, words * 8, hipMemcpyHostToDevice, g.stream));
-    CHK(coll_allreduce(gc.d_buf, (int)words));
-    HIPCHK(hipMemcpyAsync(gc.h_buf, gc.d_buf, words * 8, hipMemcpyDeviceToHost, g.stream));
+    memset(g.lc.h_buf, 0, words * 8);
+    memcpy(g.lc.h_buf + (size_t)gc.rank * cnt * 4, mine, (size_t)cnt * 32);
+    HIPCHK(hipMemcpyAsync(g.lc.d_buf, g.lc.h_buf, words * 8, hipMemcpyHostToDevice, g.stream));
+    CHK(coll_allreduce(g.lc.d_buf, (int)words));
+    HIPCHK(hipMemcpyAsync(g.lc.h_buf, g.lc.d_buf, words * 8, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    memcpy(out.data(), gc.h_buf, words * 8);
+    memcpy(out.data(), g.lc.h_buf, words * 8);
     return 0;
 }
 
@@ -715,7 +724,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.ark = to_dev(ark);
         a.partials = g.d_partials;
         a.counter = g.d_counter;
-        a.host_out = collective ? gc.d_buf : g.d_round;      // sharded: sums stay on the device for the all-reduce
+        a.host_out = collective ? g.lc.d_buf : g.d_round;      // sharded: sums stay on the device for the all-reduce
         a.host_flag = g.d_flag;
         a.seq = ++g.seq;
         const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
@@ -748,11 +757,11 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         if (collective) {
             // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are
             // rank-local and are copied as they are
-            CHK(coll_allreduce(gc.d_buf, GKR_CR_WORDS));
-            HIPCHK(hipMemcpyAsync(gc.h_buf, gc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
+            CHK(coll_allreduce(g.lc.d_buf, GKR_CR_WORDS));
+            HIPCHK(hipMemcpyAsync(g.lc.h_buf, g.lc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
                                   hipMemcpyDeviceToHost, g.stream));
             HIPCHK(hipStreamSynchronize(g.stream));
-            words = gc.h_buf;
+            words = g.lc.h_buf;
         } else {
             CHK(wait_flag(a.seq));
         }
@@ -1335,7 +1344,7 @@ int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     s->n = (size_t)1 << (bN - gc.gamma);          // entries of this rank's shard
     s->c = mimc_circuit();
     // collectives are issued from one stream in one order on every rank: sharded sessions share the default lane
-    const bool shared = gc.comm || gc.shm || g0.force_collective;
+    const bool shared = g.lc.comm || g.lc.shm || g0.force_collective;
     s->lane = shared ? &g0 : lane_create();
     if (!s->lane) {
         delete s;
@@ -1344,7 +1353,7 @@ int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     const int rc = session_alloc(s);
     if (rc != 0) {
         for (auto& t : s->a) table_free(&t);
-        if (s->lane != &g0) lane_destroy(s->lane);
+        if (s->lane != &g0 && gc.lanes.empty()) lane_destroy(s->lane);
         delete s;
         return rc;
     }
@@ -1418,7 +1427,9 @@ void gkrhip_mimc_session_destroy(gkrhip_mimc_session* s) {
             (void)hipStreamSynchronize(g.stream);
             for (auto& t : s->a) table_free(&t);
         }
-        if (s->lane != &g0) lane_destroy(s->lane);
+        bool owned = s->lane != &g0;
+        for (Ctx* l : gc.lanes) owned = owned && l != s->lane;   // communicator lanes outlive their sessions
+        if (owned) lane_destroy(s->lane);
     }
     delete s;
 }
@@ -1558,33 +1569,17 @@ int gkrhip_comm_unique_id(uint8_t out[128]) {
     return 0;
 }
 
-int gkrhip_comm_init(int world, int rank, const uint8_t id_bytes[128]) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
-    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
-        return fail("comm_init: world %d must be a power of two and 0 <= rank %d < world", world, rank);
-    if (gc.comm) return fail("communicator already initialised");
-    int gamma = 0;
-    while ((1 << gamma) < world) gamma++;
-    if (world > 1 || id_bytes) {
-        CHK(coll_load());
-        ncclUniqueId id;
-        memcpy(&id, id_bytes, 128);
-        NCCLCHK(gc.p_init(&gc.comm, world, id, rank));
-        CHK(coll_buffers(4096));
+// lane k of the communicator set: lane 0 is the default lane, further lanes are created on demand
+static Ctx* comm_lane(int k) {
+    while ((int)gc.lanes.size() <= k) {
+        Ctx* l = gc.lanes.empty() ? &g0 : lane_create();
+        if (!l) return nullptr;
+        gc.lanes.push_back(l);
     }
-    gc.world = world;
-    gc.rank = rank;
-    gc.gamma = gamma;
-    return 0;
+    return gc.lanes[k];
 }
 
-int gkrhip_comm_init_shm(int world, int rank, const char* name) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
-    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
-        return fail("comm_init_shm: world %d must be a power of two and 0 <= rank %d < world", world, rank);
-    if (gc.comm || gc.shm) return fail("communicator already initialised");
+static int shm_attach(int world, int rank, const char* name) {   // on the current lane
     const size_t bytes = 4096 + sizeof(unsigned long long) * kShmSlotWords * world;
     int fd = -1;
     if (rank == 0) {
@@ -1604,31 +1599,100 @@ int gkrhip_comm_init_shm(int world, int rank, const char* name) {
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) return fail("mmap of %s failed", name);
-    gc.shm = (Coll::ShmHdr*)p;
-    gc.shm_slots = (unsigned long long*)((char*)p + 4096);
-    gc.shm_bytes = bytes;
+    g.lc.shm = (ShmHdr*)p;
+    g.lc.shm_slots = (unsigned long long*)((char*)p + 4096);
+    g.lc.shm_bytes = bytes;
     CHK(coll_buffers(4096));
+    return 0;
+}
+
+static int comm_common(int world, int rank, int nlanes) {
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
+        return fail("comm_init: world %d must be a power of two and 0 <= rank %d < world", world, rank);
+    if (nlanes < 1 || nlanes > 8) return fail("comm_init: 1..8 lanes");
+    if (!gc.lanes.empty()) return fail("communicator already initialised");
+    return 0;
+}
+static void comm_set(int world, int rank) {
     int gamma = 0;
     while ((1 << gamma) < world) gamma++;
     gc.world = world;
     gc.rank = rank;
     gc.gamma = gamma;
-    shm_barrier();   // everybody mapped (the segment is zero-filled by ftruncate)
+}
+
+int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /* nlanes x 128 */) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    CHK(comm_common(world, rank, nlanes));
+    CHK(coll_load());
+    for (int k = 0; k < nlanes; k++) {
+        Ctx* l = comm_lane(k);
+        if (!l) return fail("cannot create lane %d: %s", k, g_err.c_str());
+        UseLane u(l);
+        ncclUniqueId id;
+        memcpy(&id, ids + (size_t)128 * k, 128);
+        NCCLCHK(gc.p_init(&g.lc.comm, world, id, rank));
+        CHK(coll_buffers(4096));
+    }
+    comm_set(world, rank);
     return 0;
 }
 
+int gkrhip_comm_init(int world, int rank, const uint8_t id_bytes[128]) {
+    if (world == 1 && !id_bytes) {   // explicit single-GPU mode without a communicator
+        std::lock_guard<std::mutex> lk(g0.mu);
+        CHK(ensure_ctx());
+        comm_set(1, 0);
+        return 0;
+    }
+    return gkrhip_comm_init_lanes(world, rank, 1, id_bytes);
+}
+
+int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char* name) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    CHK(comm_common(world, rank, nlanes));
+    for (int k = 0; k < nlanes; k++) {
+        Ctx* l = comm_lane(k);
+        if (!l) return fail("cannot create lane %d: %s", k, g_err.c_str());
+        UseLane u(l);
+        char nm[256];
+        snprintf(nm, sizeof nm, "%s_%d", name, k);
+        CHK(shm_attach(world, rank, nm));
+    }
+    comm_set(world, rank);
+    for (int k = 0; k < nlanes; k++) {
+        UseLane u(gc.lanes[k]);
+        shm_barrier();   // everybody mapped (the segments are zero-filled by ftruncate)
+    }
+    return 0;
+}
+
+int gkrhip_comm_init_shm(int world, int rank, const char* name) { return gkrhip_comm_init_shm_lanes(world, rank, 1, name); }
+
 int gkrhip_comm_destroy(void) {
     std::lock_guard<std::mutex> lk(g0.mu);
-    if (gc.comm) {
-        (void)hipStreamSynchronize(g.stream);
-        (void)gc.p_destroy(gc.comm);
-        gc.comm = nullptr;
+    for (Ctx* l : gc.lanes) {
+        {
+            std::unique_lock<std::mutex> ll;
+            if (l != &g0) ll = std::unique_lock<std::mutex>(l->mu);   // g0.mu is already held
+            UseLane u(l);
+            (void)hipStreamSynchronize(g.stream);
+            if (g.lc.comm) {
+                (void)gc.p_destroy(g.lc.comm);
+                g.lc.comm = nullptr;
+            }
+            if (g.lc.shm) {
+                munmap((void*)g.lc.shm, g.lc.shm_bytes);
+                g.lc.shm = nullptr;
+                g.lc.shm_slots = nullptr;
+            }
+        }
+        if (l != &g0) lane_destroy(l);
     }
-    if (gc.shm) {
-        munmap((void*)gc.shm, gc.shm_bytes);
-        gc.shm = nullptr;
-        gc.shm_slots = nullptr;
-    }
+    gc.lanes.clear();
+    gc.next_lane = 0;
     gc.world = 1;
     gc.rank = 0;
     gc.gamma = 0;

@@ -53,6 +53,8 @@ ABI = {
     "gkrhip_comm_unique_id": (_I, [_P]),
     "gkrhip_comm_init": (_I, [_I, _I, _P]),
     "gkrhip_comm_init_shm": (_I, [_I, _I, C.c_char_p]),
+    "gkrhip_comm_init_lanes": (_I, [_I, _I, _I, _P]),
+    "gkrhip_comm_init_shm_lanes": (_I, [_I, _I, _I, C.c_char_p]),
     "gkrhip_comm_destroy": (_I, []),
     "gkrhip_comm_info": (_I, [C.POINTER(_I), C.POINTER(_I)]),
     "gkrhip_host_shard_seed": (_I, [_P, _P, _I, _I]),
@@ -269,6 +271,16 @@ def comm_init(world, rank, unique_id):
 
 def comm_init_shm(world, rank, name):
     _check(load().gkrhip_comm_init_shm(world, rank, name.encode()))
+
+
+def comm_init_lanes(world, rank, unique_ids):
+    """unique_ids: (nlanes, 128) uint8 -- one RCCL unique id per lane."""
+    ids = np.ascontiguousarray(unique_ids, dtype=np.uint8).reshape(-1, 128)
+    _check(load().gkrhip_comm_init_lanes(world, rank, ids.shape[0], _ptr(ids)))
+
+
+def comm_init_shm_lanes(world, rank, nlanes, name):
+    _check(load().gkrhip_comm_init_shm_lanes(world, rank, nlanes, name.encode()))
 
 
 def comm_destroy():

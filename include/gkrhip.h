@@ -104,6 +104,13 @@ int gkrhip_comm_init(int world, int rank, const uint8_t unique_id[128]);
  * host.  For processes of one node that cannot form an RCCL communicator -- in particular several ranks
  * time-sharing ONE GPU, which is how the sharded driver is tested on single-GPU machines. */
 int gkrhip_comm_init_shm(int world, int rank, const char *name);
+/* Several lanes per rank (1..8): lane k owns its own stream, buffers and communicator (unique id k /
+ * segment `name`_k) and pairs with lane k of the other ranks, so `nlanes` independent proofs can be in
+ * flight at once (session i runs on lane i mod nlanes: create the sessions in the same order on every
+ * rank).  One proof's Fiat-Shamir hashing, all-reduce latency and small rounds then overlap another's
+ * big rounds. */
+int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t *unique_ids /* nlanes x 128 */);
+int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char *name);
 int gkrhip_comm_destroy(void);
 int gkrhip_comm_info(int *world, int *rank);
 

@@ -15,15 +15,50 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import coracle as c  # noqa: E402
 
 
+def concurrent(gk, world, rank, sizes, nlanes):
+    """nlanes sessions (session k on lane k on every rank) proving concurrently from nlanes host threads."""
+    import threading
+    for bn in sizes:
+        n = 1 << bn
+        i0, qp = c.random_fr_array(n), c.random_fr_array(bn)
+        want = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)[0]
+        ss = []
+        for _ in range(nlanes):
+            s = gk.MimcSession(bn)
+            s.synth_inputs()
+            s.assign()
+            ss.append(s)
+        got = [[None, None] for _ in range(nlanes)]
+
+        def work(k):
+            for rep in range(2):
+                got[k][rep] = ss[k].prove(qp)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(nlanes)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for k in range(nlanes):
+            for rep in range(2):
+                assert np.array_equal(got[k][rep], want), ("lanes", bn, rank, k, rep)
+            ss[k].close()
+    gk.comm_destroy()
+    print("SHARD-OK rank %d/%d lanes=%d %s" % (rank, world, nlanes, sizes))
+
+
 def main():
     mode, world, rank, name = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     sizes = [int(x) for x in sys.argv[5].split(",")]
     gk = importlib.import_module("gkr-mimc_amd")
     gk.init(0)
+    nlanes = int(os.environ.get("GKR_TEST_LANES", "1"))
     if mode == "shm":
-        gk.comm_init_shm(world, rank, name)
+        gk.comm_init_shm_lanes(world, rank, nlanes, name)
     else:
-        gk.comm_init(1, 0, gk.comm_unique_id())
+        gk.comm_init_lanes(1, 0, np.stack([gk.comm_unique_id() for _ in range(nlanes)]))
+    if nlanes > 1:
+        return concurrent(gk, world, rank, sizes, nlanes)
     for bn in sizes:
         n = 1 << bn
         i0 = c.random_fr_array(n)

@@ -412,6 +412,12 @@ def test_sharded_prover_generic_path_and_small_budget(gk):
     _run_shards("shm", 4, "4,9,11", {"GKRHIP_GMAX": "8"})
 
 
+def test_sharded_prover_concurrent_lanes(gk):
+    """Two lanes per rank, each with its own collective channel, two proofs in flight per rank."""
+    _run_shards("shm", 2, "4,9,11", {"GKR_TEST_LANES": "2"})
+    _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
+
+
 def test_rccl_plumbing_world1(gk):
     """RCCL is dlopen()ed, a 1-rank communicator is created and every round's sums go through
     ncclAllReduce (GKRHIP_FORCE_COLLECTIVE): the call sequence of the multi-GPU path on the one GPU we have."""
