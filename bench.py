@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bn", type=int, default=24, help="log2 of the number of MiMC hashes per proof (per job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrent", type=int, default=2,
+    ap.add_argument("--concurrent", type=int, default=3,
                     help="independent proofs in flight (each on its own resident session/lane/stream and, when "
                          "sharded, its own communicator); 1 = strictly one proof at a time")
     args = ap.parse_args()

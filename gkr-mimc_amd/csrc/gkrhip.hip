@@ -1343,9 +1343,10 @@ int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     s->bN = bN;                                   // global number of variables
     s->n = (size_t)1 << (bN - gc.gamma);          // entries of this rank's shard
     s->c = mimc_circuit();
-    // collectives are issued from one stream in one order on every rank: sharded sessions share the default lane
-    const bool shared = g.lc.comm || g.lc.shm || g0.force_collective;
-    s->lane = shared ? &g0 : lane_create();
+    // with a communicator installed, session i runs on communicator lane i mod nlanes (lane k pairs with lane k
+    // of the peers: create the sessions in the same order on every rank); otherwise it gets a lane of its own
+    if (!gc.lanes.empty()) s->lane = gc.lanes[gc.next_lane++ % gc.lanes.size()];
+    else s->lane = g0.force_collective ? &g0 : lane_create();
     if (!s->lane) {
         delete s;
         return fail("cannot create a lane for the session: %s", g_err.c_str());
