@@ -10,7 +10,9 @@
 //     W_k = eq(q[k+1:], .),  u = K_lo + S_lo + ark,  d = (K_hi - K_lo) + (S_hi - S_lo)
 // (K = key table, S = state table, pairs (x, x+mid), gate (K+S+ark)^7: circuit/gates/cipher.go:32-41).
 // The device returns the 8 monomial sums M_j = sum_x W_k(x) u^(7-j) d^j (23 multiplications per pair
-// instead of the 45 of evaluating at t = 0..8); the host multiplies by the binomials, by the linear
+// instead of the 45 of evaluating at t = 0..8; 21 when the round's claim P_k(0)+P_k(1) is known to the
+// host, which then derives c_k*M_0 from it instead -- only inside gkr.Prove, where every claim is the
+// previous round's P(r) and therefore consistent by construction); the host multiplies by the binomials, by the linear
 // factor and by c_k, which yields exactly the coefficients poly.InterpolateOnRange produces from the
 // reference's nine evaluations (a polynomial of degree <= 8 is determined by them), hence the same
 // Fiat-Shamir challenges and the same transcript.  The Eq table is never materialised or folded:
@@ -66,6 +68,7 @@ struct CipherRoundArgs {
     unsigned long long* host_out;   // host-mapped: GKR_CR_WORDS sums, then 8 x u64 x 4 tail elements
     unsigned int* host_flag;        // host-mapped: set to `seq` when host_out is complete
     unsigned int seq;
+    unsigned int need_m0;           // 0: M_0 is derived by the host from the running claim (2 products fewer)
 };
 
 // a += x as an un-reduced 288-bit integer (x < 2^256).  One opaque carry chain: keeps hipcc from
@@ -157,9 +160,13 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
                 fr_mont_mul2_raw(A, B, p, u, p, d);          // u^3, u^2 d
                 fr_mont_mul2_raw(C, D, u, r2, r2, d);        // u d^2, d^3
                 fr_mont_mul2_raw(v, w, W, u, W, d);
-                fr_mont_mul2_raw(t, t2, A, A, A, B);
-                fr_mont_mul2_raw(t, t2, v, t, v, t2);
-                acc_add_raw(acc[0], t);                      // W u^7
+                if (a.need_m0) {
+                    fr_mont_mul2_raw(t, t2, A, A, A, B);
+                    fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                    acc_add_raw(acc[0], t);                  // W u^7
+                } else {
+                    t2 = fr_mont_mul_raw(v, fr_mont_mul_raw(A, B));
+                }
                 acc_add_raw(acc[1], t2);                     // W u^6 d
                 fr_mont_mul2_raw(t, t2, B, B, A, D);
                 fr_mont_mul2_raw(t, t2, v, t, v, t2);
@@ -182,7 +189,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
             D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
             v = fr_mont_mul_raw(W, u);  GKR_SB();
             w = fr_mont_mul_raw(W, d);  GKR_SB();
-            t = fr_mont_mul_raw(A, A); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[0], t); GKR_SB();  // W u^7
+            if (a.need_m0) { t = fr_mont_mul_raw(A, A); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[0], t); GKR_SB(); }  // W u^7
             t = fr_mont_mul_raw(A, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[1], t); GKR_SB();  // W u^6 d
             t = fr_mont_mul_raw(B, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[2], t); GKR_SB();  // W u^5 d^2
             t = fr_mont_mul_raw(A, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[3], t); GKR_SB();  // W u^4 d^3

@@ -96,6 +96,7 @@ struct Ctx {
     unsigned int seq = 0;
     int g_max = 17;                            // log2(max threads of the round kernel)
     bool force_generic = false;
+    bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
@@ -168,6 +169,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) g.claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.max_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
     g.lag = new hfr::Lagrange();
@@ -225,6 +227,7 @@ Ctx* lane_create() {
     l->g_max = g0.g_max;
     l->force_generic = g0.force_generic;
     l->lat_mode = g0.lat_mode;
+    l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->lag = g0.lag;
     l->prof.min_n = g0.prof.min_n;
@@ -672,7 +675,8 @@ void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
 // eq(q_k, r_k) of every round, proof/chal hold m rounds, tail = the two remaining entries of each table
 // (K_lo, K_hi, S_lo, S_hi) and r_last the last challenge (the caller applies the final fold).
 int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, const E* q, const E& seed, bool collective,
-                  E& c, E* proof, E* chal, E tail[4], E& r_last) {
+                  E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
+                  bool* claim_known) {
     const size_t n = (size_t)1 << m;
     const int gT = std::min(g.g_max, m - 1);           // threads of round 0 = 2^gT
     const int mU = m - 1 - gT;                         // log2(iterations of round 0)
@@ -727,6 +731,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.host_out = collective ? g.lc.d_buf : g.d_round;      // sharded: sums stay on the device for the all-reduce
         a.host_flag = g.d_flag;
         a.seq = ++g.seq;
+        const bool derive_m0 = claim && *claim_known;
+        a.need_m0 = derive_m0 ? 0u : 1u;
         const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
         const bool timed = 2 * P >= g.prof.min_n;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -750,7 +756,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             HIPCHK(hipEventRecord(e1, g.stream));
             g.prof.peval_ev.emplace_back(e0, e1);
             g.prof.peval_launches++;
-            g.prof.peval_modmuls += (23.0 + (lj > 0 ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
+            g.prof.peval_modmuls += ((derive_m0 ? 21.0 : 23.0) + (lj > 0 ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
         const double t_l1 = now_ms();
         const unsigned long long* words = g.h_round;
@@ -767,21 +773,32 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         const double t_w = now_ms();
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
-        E sp[8];
-        for (int j = 0; j < 8; j++)
-            sp[j] = hfr::mul(limbs9_to_fr(words + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j]));
-        const E a0 = hfr::mul(c, hfr::sub(hfr::ONE, q[k]));
-        const E a1 = hfr::mul(c, hfr::sub(hfr::add(q[k], q[k]), hfr::ONE));
+        // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
+        // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
+        E csp[8];
+        for (int j = derive_m0 ? 1 : 0; j < 8; j++)
+            csp[j] = hfr::mul(c, hfr::mul(limbs9_to_fr(words + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j])));
+        if (derive_m0) {
+            E rest = csp[1];
+            for (int j = 2; j < 8; j++) rest = hfr::add(rest, csp[j]);
+            csp[0] = hfr::sub(*claim, hfr::mul(q[k], rest));
+        }
+        const E a0 = hfr::sub(hfr::ONE, q[k]);
+        const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
         E* co = proof + (size_t)k * 9;
-        co[0] = hfr::mul(a0, sp[0]);
-        for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, sp[j]), hfr::mul(a1, sp[j - 1]));
-        co[8] = hfr::mul(a1, sp[7]);
+        co[0] = hfr::mul(a0, csp[0]);
+        for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, csp[j]), hfr::mul(a1, csp[j - 1]));
+        co[8] = hfr::mul(a1, csp[7]);
         const double t_h0 = now_ms();
         const E r = hfr::mimc_hash(co, 9);
         const double t_h1 = now_ms();
         chal[k] = r;
         c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
         r_prev = r;
+        if (claim) {   // next round's claim = P_k(r_k)
+            *claim = hfr::eval_univariate(co, 9, r);
+            *claim_known = true;
+        }
         if (k == m - 1) memcpy(tail, words + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
         g.prof.host_launch_ms += t_l1 - t_l0;
         g.prof.host_wait_ms += t_w - t_l1;
@@ -811,13 +828,18 @@ int small_table(DevTable* t, const std::vector<E>& v) {
 // rounds (sums all-reduced); then one element per table per rank is all-gathered and the last gamma
 // rounds run redundantly on every rank (phase 2).
 int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable* S, const E* q, E* proof, E* challenges,
-                         E* final_claims) {
+                         E* final_claims, const E* trusted_claim, bool track_claim) {
     const int gamma = gc.gamma, m1 = bN - gamma;
     if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
     E c = hfr::ONE, tail[4], r_last, kv, sv;
+    // running claim: known from the start when the caller vouches for it, otherwise from round 1 on
+    E claim = trusted_claim ? *trusted_claim : hfr::ZERO;
+    bool claim_known = trusted_claim != nullptr;
+    E* claim_p = track_claim ? &claim : nullptr;
     if (m1 >= 1) {
         const E seed = gamma ? shard_seed(q + m1, gamma, gc.rank) : hfr::ONE;
-        CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || g.force_collective, c, proof, challenges, tail, r_last));
+        CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || g.force_collective, c, proof, challenges, tail, r_last,
+                          claim_p, &claim_known));
         kv = fold2(tail[0], tail[1], r_last);
         sv = fold2(tail[2], tail[3], r_last);
     } else {
@@ -840,7 +862,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
         CHK(small_table(&K2, k2));
         CHK(small_table(&S2, s2));
         CHK(cipher_rounds(ark, gamma, &K2, &S2, q + m1, hfr::ONE, false, c, proof + (size_t)9 * m1, challenges + m1, tail,
-                          r_last));
+                          r_last, claim_p, &claim_known));
         kv = fold2(tail[0], tail[1], r_last);
         sv = fold2(tail[2], tail[3], r_last);
         table_release(&K2);
@@ -894,8 +916,12 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
 
 // sumcheck.Prove on device-resident tables (sumcheck/prover.go:46-90).  bN = GLOBAL number of variables;
 // X = this rank's shards (read-only).  proof: bN*(deg+2), challenges: bN, final: arity+1.
+// trust_claims: the caller guarantees that `claims` are the true sums (gkr.Prove: every claim is a previous
+// sumcheck's output).  The single-point cipher path then derives one monomial sum per round from the running
+// claim instead of computing it.  Entry points that take claims from outside never set it: for them the
+// output must be the reference's whatever the claims are (they only feed Fiat-Shamir there).
 int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
-                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims) {
+                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims, bool trust_claims = false) {
     if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
     if (nq < 1) return fail("need at least one evaluation point");
     if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
@@ -917,7 +943,8 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
         nq_used = nq;
     }
     if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !g.force_generic)
-        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims);
+        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims,
+                                    (trust_claims && nclaims == 1) ? &claims[0] : nullptr, trust_claims && g.claim_trick);
 
     // phase 1: this rank's shard; Eq_local = sum_j seed_j * eq(q_j tail, rank) * eq(q_j[0:m1], .)
     if (gamma > 0)
@@ -1135,7 +1162,7 @@ int session_prove(gkrhip_mimc_session* s, const E* qprime, E* flat) {  // gkr/pr
         const int nq = layer == L - 1 ? 1 : (int)lay.out.size();
         const int ncl = has_claims[layer] ? (int)lay.out.size() : 0;
         CHK(sumcheck_prove_dev(lay.gate, lay.ark, arity, bN, X, qps[layer].data(), nq, claims[layer].data(), ncl,
-                               sc[layer].data(), next_q.data(), fin));
+                               sc[layer].data(), next_q.data(), fin, /*trust_claims=*/true));
         for (int i = 1; i <= arity; i++) {  // updateWithSumcheck, prover.go:66-90
             const int inp = lay.in[i - 1];
             const std::vector<int>& o = c[inp].out;

@@ -255,6 +255,7 @@ def test_round_kernel_variants(gk):
     """The throughput kernel everywhere (GKRHIP_LAT=0) and the interleaved-pair kernel everywhere
     (GKRHIP_LAT=2, with and without the per-iteration eq factor) give the same transcript."""
     _run_case({"GKRHIP_LAT": "0"}, "1,4,9,12")
+    _run_case({"GKRHIP_CLAIM_TRICK": "0"}, "1,2,7,12")   # all eight monomial sums computed on the device
     _run_case({"GKRHIP_LAT": "2", "GKRHIP_GMAX": "8"}, "1,4,9,12,13")
 
 
