@@ -47,11 +47,11 @@ def cpu_baseline(target_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--bn", type=int, default=24, help="log2 of the number of MiMC hashes per proof (per job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrent", type=int, default=3,
+    ap.add_argument("--concurrent", type=int, default=4,
                     help="independent proofs in flight (each on its own resident session/lane/stream and, when "
                          "sharded, its own communicator); 1 = strictly one proof at a time")
     args = ap.parse_args()
@@ -72,7 +72,14 @@ def main():
     gk.init(local_rank)
 
     import numpy as np
-    nconc = max(1, min(args.concurrent, args.steps))
+    # every proof in flight keeps its own resident assignment (93 tables of 2^bn elements) plus scratch
+    free_b, _total_b = gk.mem_info()
+    per_session = 96 * 32 * (1 << args.bn)
+    nconc = max(1, min(args.concurrent, args.steps, int(0.85 * free_b // per_session)))
+    if dist is not None:
+        t = torch.tensor([nconc], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)     # same number of lanes on every rank
+        nconc = int(t.item())
     if dist is not None:
         # install the library's own RCCL communicators, one per lane (the per-round all-reduce of the limb-split
         # sums lives inside the C++ round loop); torch.distributed only carries the 128-byte unique ids, the

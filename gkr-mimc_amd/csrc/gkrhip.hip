@@ -1255,10 +1255,25 @@ int gkrhip_device_count(void) {
 const char* gkrhip_last_error(void) { return g_err.c_str(); }
 const char* gkrhip_version(void) { return "gkrhip 0.1 (gfx950)"; }
 
+int gkrhip_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
 int gkrhip_device_synchronize(void) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
-    HIPCHK(hipStreamSynchronize(g.stream));
+    std::vector<Ctx*> lanes;
+    {
+        std::lock_guard<std::mutex> ll(g_lanes_mu);
+        lanes = g_lanes;
+    }
+    for (Ctx* l : lanes) HIPCHK(hipStreamSynchronize(l->stream));
     return 0;
 }
 

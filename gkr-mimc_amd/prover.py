@@ -35,6 +35,7 @@ ABI = {
     "gkrhip_last_error": (C.c_char_p, []),
     "gkrhip_version": (C.c_char_p, []),
     "gkrhip_device_synchronize": (_I, []),
+    "gkrhip_mem_info": (_I, [C.POINTER(_SZ), C.POINTER(_SZ)]),
     "gkrhip_fold": (_I, [_P, _SZ, _P]),
     "gkrhip_evaluate": (_I, [_P, _P, _SZ, _P, _I]),
     "gkrhip_eq_table": (_I, [_P, _P, _I, _P]),
@@ -108,6 +109,12 @@ def shutdown():
 
 def device_count():
     return load().gkrhip_device_count()
+
+
+def mem_info():
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    _check(load().gkrhip_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def synchronize():

@@ -36,7 +36,8 @@ void gkrhip_shutdown(void);
 int gkrhip_device_count(void);
 const char *gkrhip_last_error(void);
 const char *gkrhip_version(void);
-int gkrhip_device_synchronize(void);
+int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
+int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 
 /* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
 /* (*MultiLin).Fold(r), poly/multilin.go:19-23: in place on `table` (n elements, n a power of two >= 2);
