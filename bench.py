@@ -173,9 +173,16 @@ def main():
         avg_ms = prof["fold_ms"] / prof["fold_launches"]
         bytes_per_launch = prof["fold_bytes"] / prof["fold_launches"]
         ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        try:   # PMC pass of this very workload (tools/pmc_bench.sh), committed under profiles/
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fold_traffic.json")))
+            if pm.get("bn") == args.bn:
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": "k_fold (round-0 instance fold, 2^%d-element tables)" % args.bn,
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "launches": prof["fold_launches"], "avg_launch_ms": avg_ms,
+                           "traffic": traffic, "launches": prof["fold_launches"], "avg_launch_ms": avg_ms,
                            "algorithmic_bytes_per_launch": bytes_per_launch}
     if prof["peval_launches"]:
         out["partial_eval"] = {"kernel": "k_partial_eval (round 0)", "launches": prof["peval_launches"],
