@@ -293,6 +293,22 @@ def test_gkr_vs_oracle(gk, bn):
     assert c.gkr_verify_mimc(bn, flat, i0, i1, outs, qp) == 0
 
 
+@pytest.mark.parametrize("bn", [20, 22, 24])
+def test_gkr_baseline_sizes_match_oracle_digest(gk, bn):
+    """BASELINE configs 2 and 3 (bN = 20, 24) and bN = 22: the full transcript and the output table equal the
+    C oracle's, through SHA-256 digests the oracle produced on the host CPU (158 s for bN = 24 on 16 cores;
+    tests/golden/gen_big_digests.py).  Inputs are generated on the device (RandomFrArray)."""
+    want = [e for e in load("gkr_mimc_big_digests.json") if e["bn"] == bn][0]
+    s = gk.MimcSession(bn)
+    s.synth_inputs()
+    s.assign()
+    flat = s.prove(c.random_fr_array(bn))
+    assert flat.shape[0] == want["n_elements"]
+    assert hashlib.sha256(flat.astype("<u8").tobytes()).hexdigest() == want["sha256_flat"]
+    assert hashlib.sha256(s.outputs().astype("<u8").tobytes()).hexdigest() == want["sha256_outputs"]
+    s.close()
+
+
 def test_gkr_session_repeatable_and_claims_consistent(gk):
     """Prove never mutates the resident assignment; every input-layer claim equals
     Evaluate(layer table, point) (gkr/gkr_test.go:35-44) computed on the device."""
