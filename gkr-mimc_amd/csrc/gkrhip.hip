@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1486,6 +1487,145 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
     if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
     if (rc == 0 && outputs_or_null) rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
     gkrhip_mimc_session_destroy(s);
+    return rc;
+}
+
+// ---- wire-format helpers (prover/gadget/hints.go) ---------------------------------------------------------
+static int convert_inplace(uint64_t* data, size_t n, const E& factor) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    if (n == 0) return 0;
+    uint4* d = nullptr;
+    HIPCHK(hipMalloc(&d, 32 * n));
+    HIPCHK(hipMemcpyAsync(d, data, 32 * n, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_convert_aos, dim3(grid_for(n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, d, n, to_dev(factor));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(data, d, 32 * n, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipFree(d));
+    return 0;
+}
+int gkrhip_to_regular(uint64_t* data, size_t n) {
+    const E one = {{1, 0, 0, 0}};
+    return convert_inplace(data, n, one);
+}
+int gkrhip_from_regular(uint64_t* data, size_t n) { return convert_inplace(data, n, hfr::R2); }
+
+int gkrhip_mimc_permutation_batch(uint64_t* out, const uint64_t* x, const uint64_t* key, size_t n) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    if (n == 0) return 0;
+    DevTable tx, tk, to;
+    CHK(table_alloc(&tx, n));
+    CHK(table_alloc(&tk, n));
+    CHK(table_alloc(&to, n));
+    CHK(upload_table(&tx, x, n));
+    CHK(upload_table(&tk, key, n));
+    hipLaunchKernelGGL(k_mimc_permutation, dim3(grid_for(n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream, tx.cplanes(),
+                       tk.cplanes(), to.planes(), n);
+    HIPCHK(hipGetLastError());
+    CHK(download_table(&to, out, n));
+    table_release(&tx);
+    table_release(&tk);
+    table_release(&to);
+    return 0;
+}
+
+// ---- gkr.Verify (gkr/verifier.go:15-132, sumcheck/verifier.go:28-65) on a flat proof.  The O(N) parts --
+// MultiLin.Evaluate of the output table and of the two input tables -- run on the device through `eval`;
+// the rest is scalar work on <= 822*bN + 183 + 184*bN elements.  Returns 0 = accepted, > 0 = rejected.
+static int verify_flat(const Circuit& c, int bN, const E* flat, const E* qprime,
+                       const std::function<int(int, const E*, E*)>& eval) {
+    const int L = (int)c.size();
+    std::vector<const E*> sc(L, nullptr), claims(L), qps(L);
+    size_t cur = 0;
+    for (int l = 0; l < L; l++)
+        if (c[l].gate >= 0) {
+            sc[l] = flat + cur;
+            cur += (size_t)bN * (gate_degree(c[l].gate) + 2);
+        }
+    for (int l = 0; l < L; l++) {
+        claims[l] = flat + cur;
+        cur += c[l].out.size();
+    }
+    for (int l = 0; l < L; l++) {
+        qps[l] = flat + cur;
+        cur += (l == L - 1 ? 1 : c[l].out.size()) * bN;
+    }
+    if (memcmp(qprime, qps[L - 1], (size_t)bN * sizeof(E)) != 0) return 1;   // verifier.go:25-30
+    E top;
+    CHK(eval(L - 1, qprime, &top));                                        // verifier.go:36
+    std::vector<E> next_q(std::max(bN, 1));
+    for (int layer = L - 1; layer >= 0; layer--) {
+        if (c[layer].gate < 0) break;
+        const E* cl = layer == L - 1 ? &top : claims[layer];
+        const int ncl = layer == L - 1 ? 1 : (int)c[layer].out.size();
+        const int nc = gate_degree(c[layer].gate) + 2;
+        // sumcheck.Verify
+        const E recomb = hfr::mimc_hash(cl, (size_t)ncl);
+        E expected = hfr::eval_univariate(cl, ncl, recomb);
+        for (int i = 0; i < bN; i++) {
+            const E* p = sc[layer] + (size_t)i * nc;
+            const E s01 = hfr::add(hfr::eval_univariate(p, nc, hfr::ZERO), hfr::eval_univariate(p, nc, hfr::ONE));
+            if (s01 != expected) return 10 + layer;
+            next_q[i] = hfr::mimc_hash(p, (size_t)nc);
+            expected = hfr::eval_univariate(p, nc, next_q[i]);
+        }
+        // testSumcheck (verifier.go:61-117)
+        E sub[GKR_MAX_ARITY];
+        for (size_t k = 0; k < c[layer].in.size(); k++) {
+            const int inp = c[layer].in[k];
+            const std::vector<int>& o = c[inp].out;
+            const size_t r_at = (size_t)(std::lower_bound(o.begin(), o.end(), layer) - o.begin());
+            if (memcmp(qps[inp] + r_at * bN, next_q.data(), (size_t)bN * sizeof(E)) != 0) return 1000 + layer;
+            sub[k] = claims[inp][r_at];
+        }
+        E gate_val;
+        if (c[layer].gate == GKRHIP_GATE_CIPHER) gate_val = hfr::pow7(hfr::add(hfr::add(sub[1], c[layer].ark), sub[0]));
+        else gate_val = sub[0];
+        std::vector<E> eqs(ncl);
+        for (int i = 0; i < ncl; i++) eqs[i] = hfr::eval_eq(qps[layer] + (size_t)i * bN, next_q.data(), bN);
+        const E eq_eval = hfr::eval_univariate(eqs.data(), ncl, recomb);
+        if (hfr::mul(gate_val, eq_eval) != expected) return 2000 + layer;
+    }
+    for (int l = 0; l < L && c[l].gate < 0; l++) {   // testInitialRound (verifier.go:120-132)
+        E actual;
+        CHK(eval(l, qps[l], &actual));
+        if (actual != claims[l][0]) return 3000 + l;
+    }
+    return 0;
+}
+
+int gkrhip_gkr_verify_mimc(int bN, const uint64_t* flat, const uint64_t* in0, const uint64_t* in1, const uint64_t* outputs,
+                           const uint64_t* qprime) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    LocalOnly lo;
+    if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
+    const size_t n = (size_t)1 << bN;
+    const Circuit c = mimc_circuit();
+    DevTable t[3];
+    const uint64_t* host[3] = {in0, in1, outputs};
+    for (int i = 0; i < 3; i++) {
+        CHK(table_alloc(&t[i], n));
+        CHK(upload_table(&t[i], host[i], n));
+    }
+    auto eval = [&](int layer, const E* pt, E* out) -> int {
+        const DevTable* tab = layer == 0 ? &t[0] : layer == 1 ? &t[1] : &t[2];
+        return evaluate_dev(tab, bN, pt, out);
+    };
+    const int rc = verify_flat(c, bN, (const E*)flat, (const E*)qprime, eval);
+    for (int i = 0; i < 3; i++) table_release(&t[i]);
+    if (rc > 0) fail("gkr.Verify rejected the proof (code %d)", rc);
+    return rc;
+}
+
+int gkrhip_mimc_session_verify(gkrhip_mimc_session* s, const uint64_t* qprime, const uint64_t* flat) {
+    SESSION_ENTER(s);
+    if (!s->assigned) return fail("session is not assigned");
+    auto eval = [&](int layer, const E* pt, E* out) -> int { return evaluate_dev(session_table(s, layer), s->bN, pt, out); };
+    const int rc = verify_flat(s->c, s->bN, (const E*)flat, (const E*)qprime, eval);
+    if (rc > 0) fail("gkr.Verify rejected the proof (code %d)", rc);
     return rc;
 }
 

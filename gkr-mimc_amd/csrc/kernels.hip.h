@@ -326,3 +326,47 @@ __global__ void k_gather0(Gather0Args a) {
         a.out[2 * t + 1] = a.t[t].hi[0];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// wire-format helpers of the production caller (prover/gadget/hints.go)
+// ------------------------------------------------------------------------------------------------
+// bulk Montgomery <-> regular conversion on the boundary (AoS) layout: x <- x * factor / 2^256 mod q.
+// factor = 1 (as a plain integer): fr.Element.FromMont / ToBigIntRegular (hints.go:141,231-268);
+// factor = R^2: SetBigInt of a reduced value (hints.go:136-137,202-205).
+__global__ void __launch_bounds__(GKR_BLOCK) k_convert_aos(uint4* __restrict__ data, size_t n, Fr factor) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 a = data[2 * i], b = data[2 * i + 1];
+        const Fr x = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+        const Fr y = fr_mul(x, factor);
+        data[2 * i] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+        data[2 * i + 1] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+    }
+}
+
+// hash.Arks (hash/ark.go:232-336), Montgomery limbs
+struct ArkLimbs {
+    unsigned long long l[4];
+};
+__device__ __constant__ ArkLimbs d_arks[100] = {
+#include "arks_bn254.inc"
+};
+__device__ __forceinline__ Fr ark_fr(int i) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        r.v[2 * k] = (u32)d_arks[i].l[k];
+        r.v[2 * k + 1] = (u32)(d_arks[i].l[k] >> 32);
+    }
+    return r;
+}
+// batched hash.MimcKeyedPermutation(x[i], key[i]) (hash/mimc.go:31-39): the body of HashHint.Call
+// (hints.go:134-145), which the solver invokes once per hash
+__global__ void __launch_bounds__(GKR_BLOCK) k_mimc_permutation(CPlanes x, CPlanes key, Planes out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr res = ld_fr(x.lo, x.hi, i);
+        const Fr k = ld_fr(key.lo, key.hi, i);
+#pragma unroll 1
+        for (int r = 0; r < 91; r++) res = fr_pow7(fr_add(fr_add(res, k), ark_fr(r)));
+        st_fr(out.lo, out.hi, i, res);
+    }
+}

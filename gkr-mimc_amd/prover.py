@@ -51,6 +51,11 @@ ABI = {
     "gkrhip_mimc_session_outputs": (_I, [_P, _P]),
     "gkrhip_mimc_session_evaluate_layer": (_I, [_P, _I, _P, _P]),
     "gkrhip_mimc_session_destroy": (None, [_P]),
+    "gkrhip_gkr_verify_mimc": (_I, [_I, _P, _P, _P, _P, _P]),
+    "gkrhip_mimc_session_verify": (_I, [_P, _P, _P]),
+    "gkrhip_to_regular": (_I, [_P, _SZ]),
+    "gkrhip_from_regular": (_I, [_P, _SZ]),
+    "gkrhip_mimc_permutation_batch": (_I, [_P, _P, _P, _SZ]),
     "gkrhip_comm_unique_id": (_I, [_P]),
     "gkrhip_comm_init": (_I, [_I, _I, _P]),
     "gkrhip_comm_init_shm": (_I, [_I, _I, C.c_char_p]),
@@ -209,6 +214,38 @@ def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True):
     return flat, outs
 
 
+def gkr_verify_mimc(flat, in0, in1, outputs, q_prime):
+    """gkr.Verify(MimcCircuit, proof, inputs, outputs, qPrime): True if accepted, False if rejected."""
+    in0, in1, outputs, flat = _fr(in0), _fr(in1), _fr(outputs), _fr(flat)
+    bN = in0.shape[0].bit_length() - 1
+    q_prime = _fr(q_prime).reshape(-1, 4)
+    rc = load().gkrhip_gkr_verify_mimc(bN, _ptr(flat), _ptr(in0), _ptr(in1), _ptr(outputs), _ptr(q_prime) if bN else None)
+    if rc < 0:
+        _check(rc)
+    return rc == 0
+
+
+def to_regular(arr):
+    """Montgomery limbs -> regular value limbs (fr.Element.ToBigIntRegular for a whole slice)."""
+    a = np.array(_fr(arr), copy=True)
+    _check(load().gkrhip_to_regular(_ptr(a), a.reshape(-1, 4).shape[0]))
+    return a
+
+
+def from_regular(arr):
+    a = np.array(_fr(arr), copy=True)
+    _check(load().gkrhip_from_regular(_ptr(a), a.reshape(-1, 4).shape[0]))
+    return a
+
+
+def mimc_permutation_batch(x, key):
+    """hash.MimcKeyedPermutation(x[i], key[i]) for every i (HashHint.Call for a batch)."""
+    x, key = _fr(x), _fr(key)
+    out = np.zeros_like(x)
+    _check(load().gkrhip_mimc_permutation_batch(_ptr(out), _ptr(x), _ptr(key), x.shape[0]))
+    return out
+
+
 class MimcSession:
     """Resident MiMC assignment on the GPU; prove() can be repeated."""
 
@@ -245,6 +282,14 @@ class MimcSession:
         out = np.zeros((self.local_n, 4), np.uint64)
         _check(load().gkrhip_mimc_session_outputs(self._h, _ptr(out)))
         return out
+
+    def verify(self, q_prime, flat):
+        """gkr.Verify against the resident inputs/outputs: True if accepted."""
+        q_prime = _fr(q_prime).reshape(-1, 4)
+        rc = load().gkrhip_mimc_session_verify(self._h, _ptr(q_prime) if self.bN else None, _ptr(_fr(flat)))
+        if rc < 0:
+            _check(rc)
+        return rc == 0
 
     def evaluate_layer(self, layer, coords):
         coords = _fr(coords).reshape(-1, 4)

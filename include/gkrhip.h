@@ -88,6 +88,23 @@ int gkrhip_mimc_session_outputs(gkrhip_mimc_session *s, uint64_t *outputs);
 int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session *s, int layer, const uint64_t *coords, uint64_t out[4]);
 void gkrhip_mimc_session_destroy(gkrhip_mimc_session *s);
 
+/* ---- gkr.Verify (gkr/verifier.go:15-132): native verifier; MultiLin.Evaluate of the output and input tables
+ * runs on the device, the rest is scalar host work.  Returns 0 = accepted, > 0 = rejected (code in
+ * gkrhip_last_error), < 0 = error.  The session form uses the resident assignment (inputs = layers 0, 1;
+ * outputs = layer 93), so it also checks proofs of sizes whose tables never lived on the host. */
+int gkrhip_gkr_verify_mimc(int bN, const uint64_t *flat, const uint64_t *in0, const uint64_t *in1,
+                           const uint64_t *outputs, const uint64_t *qprime);
+int gkrhip_mimc_session_verify(gkrhip_mimc_session *s, const uint64_t *qprime, const uint64_t *flat);
+
+/* ---- wire format of the production caller (prover/gadget/hints.go) -------------------------------------
+ * Bulk conversions, in place, between fr.Element's Montgomery limbs and the regular value as 4 little-endian
+ * u64 limbs (what ToBigIntRegular / SetBigInt exchange with big.Int; hints.go:136-141,202-205,236-271), and
+ * the body of HashHint.Call for a whole batch: out[i] = hash.MimcKeyedPermutation(x[i], key[i])
+ * (hints.go:134-145, hash/mimc.go:31-39; the solver calls it once per hash). */
+int gkrhip_to_regular(uint64_t *data, size_t n);
+int gkrhip_from_regular(uint64_t *data, size_t n);
+int gkrhip_mimc_permutation_batch(uint64_t *out, const uint64_t *x, const uint64_t *key, size_t n);
+
 /* ---- multi-GPU: one process per GPU, hypercube sharded on its log2(world) LOWEST index bits ------------
  * Rank g holds T_g[j] = T[j*world + g] of every table (a dense table over the top bN - log2(world)
  * variables), so all local rounds pair (j, j+mid) exactly as on one GPU and no table data crosses xGMI.

@@ -390,6 +390,67 @@ def test_gkr_bn18_vs_oracle_and_bn20_verified(gk):
     assert c.gkr_verify_mimc(bn, bad, i0, i0, outs, qp) != 0
 
 
+# ---------------------------------------------------------------- verifier and wire-format helpers
+@pytest.mark.parametrize("bn", [0, 1, 3, 8, 13])
+def test_native_verifier_agrees_with_oracle(gk, bn):
+    """gkr.Verify (gkr/verifier.go): accepts the prover's output, rejects every single-element corruption we
+    try, and agrees with the oracle's restated verifier."""
+    i0 = c.random_fr_array(1 << bn)
+    i1 = nasty(1 << bn, bn + 40) if bn else c.from_u64(5)
+    qp = c.random_fr_array(bn)
+    flat, outs = gk.gkr_prove_mimc(i0, i1, qp)
+    assert gk.gkr_verify_mimc(flat, i0, i1, outs, qp)
+    assert c.gkr_verify_mimc(bn, flat, i0, i1, outs, qp) == 0
+    rng = np.random.default_rng(bn)
+    if bn:
+        for pos in rng.integers(0, flat.shape[0], 6):
+            bad = flat.copy()
+            bad[pos, int(rng.integers(0, 4))] ^= np.uint64(1 << int(rng.integers(0, 60)))
+            ours = gk.gkr_verify_mimc(bad, i0, i1, outs, qp)
+            theirs = c.gkr_verify_mimc(bn, bad, i0, i1, outs, qp) == 0
+            assert ours == theirs and not ours
+    bad_out = outs.copy()
+    bad_out[0, 0] ^= np.uint64(2)
+    assert not gk.gkr_verify_mimc(flat, i0, i1, bad_out, qp)
+    bad_in = i1.copy()
+    bad_in[-1, 1] ^= np.uint64(8)
+    assert not gk.gkr_verify_mimc(flat, i0, bad_in, outs, qp)
+
+
+def test_session_verify_full_size(gk):
+    """BASELINE config 3 size: the bN = 24 proof is accepted by gkr.Verify run against the resident tables,
+    and a corrupted transcript is rejected."""
+    bn = 24
+    s = gk.MimcSession(bn)
+    s.synth_inputs()
+    s.assign()
+    qp = c.random_fr_array(bn)
+    flat = s.prove(qp)
+    assert s.verify(qp, flat)
+    bad = flat.copy()
+    bad[777, 2] ^= np.uint64(1)
+    assert not s.verify(qp, bad)
+    s.close()
+
+
+def test_wire_format_helpers(gk):
+    # ToBigIntRegular / SetBigInt for a slice (prover/gadget/hints.go:202-205,236-271)
+    vals = [0, 1, 12, o.Q - 1, 1 << 200, 1808205620575546259657963589762746470347087906694759866517376279978241663265]
+    mont = c.from_ints(vals)
+    reg = gk.to_regular(mont)
+    assert [sum(int(reg[i, k]) << (64 * k) for k in range(4)) for i in range(len(vals))] == vals
+    assert np.array_equal(gk.from_regular(reg), mont)
+    big = nasty(1 << 12, 77)
+    assert c.to_ints(gk.from_regular(gk.to_regular(big))) == c.to_ints(big)
+    # HashHint.Call for a batch: MimcKeyedPermutation(block, state)  (hints.go:134-145)
+    x, key = nasty(300, 5), c.random_fr_array(300)
+    got = gk.mimc_permutation_batch(x, key)
+    for i in (0, 1, 2, 17, 299):
+        assert np.array_equal(got[i], c.mimc_keyed_permutation(x[i:i + 1], key[i:i + 1])[0])
+    for e in load("kat.json")["mimc_perm"]:
+        assert fr_to_hex(gk.mimc_permutation_batch(hex_to_fr(e["x"]), hex_to_fr(e["key"]))) == [e["out"]]
+
+
 # ---------------------------------------------------------------- sharded prover (multi-process, one GPU)
 def _run_shards(mode, world, sizes, env=None):
     import os, subprocess, sys, uuid
