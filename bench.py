@@ -129,11 +129,13 @@ def main():
 
     run_steps(max(args.warmup, 1 if nconc > 1 and args.warmup else 0))
     # single-proof latency (one proof alone on the GPU), reported beside the throughput figure
+    gk.profile_reset(1 << args.bn)
     sync_all()
     tl = time.perf_counter()
     last[0] = sessions[0].prove(qprime)
     sync_all()
     latency_ms = 1e3 * (time.perf_counter() - tl)
+    solo = gk.profile_get()          # the same launches with no other proof in flight
     gk.profile_reset(1 << args.bn)   # HIP-event accounting of the round-0 fold / partial-eval launches
     sync_all()
     t0 = time.perf_counter()
@@ -183,7 +185,24 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_fold (round-0 instance fold, 2^%d-element tables)" % args.bn,
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "launches": prof["fold_launches"], "avg_launch_ms": avg_ms,
-                           "algorithmic_bytes_per_launch": bytes_per_launch}
+                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "measured": "HIP events on the launching stream around the fold launches of full-size tables "
+                                       "inside the K timed steps; with %d proofs in flight the other lanes' VALU-bound "
+                                       "kernels share the CUs, so the launch duration includes waiting for CU slots" % nconc}
+        if solo["fold_launches"]:
+            sms = solo["fold_ms"] / solo["fold_launches"]
+            sb = solo["fold_bytes"] / solo["fold_launches"]
+            out["roofline"]["solo"] = {"achieved": sb / (sms * 1e-3) / 1e9, "frac": sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "avg_launch_ms": sms, "launches": solo["fold_launches"],
+                                       "measured": "same launches, same events, during the single-proof pass "
+                                                   "(one proof alone on the GPU) that precedes the K timed steps"}
+    if rank == 0:
+        # the same kernel alone on the GPU (micro-benchmark of BenchmarkFolding's shape, poly/multilin_test.go:55-78)
+        ms3 = gk.bench_fold(1 << args.bn, ntab=3, warmup=2, iters=10)
+        out["fold_alone"] = {"tables": 3, "elements_per_table": 1 << args.bn, "ms": ms3,
+                             "GB_per_s": 96.0 * 3 * (1 << (args.bn - 1)) / (ms3 * 1e-3) / 1e9,
+                             "note": "k_fold with no other kernel running; roofline.achieved is measured inside the "
+                                     "timed region, where the other lanes' kernels share the GPU"}
     if prof["peval_launches"]:
         out["partial_eval"] = {"kernel": "k_partial_eval (round 0)", "launches": prof["peval_launches"],
                                "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],

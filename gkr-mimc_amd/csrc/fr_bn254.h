@@ -35,6 +35,16 @@ struct Fr {
 #define FRQ7 0x30644e72u
 #define FR_QINV32 0xefffffffu  // -q^-1 mod 2^32
 
+// Copy of a finished limb out of the 64-bit accumulator pair into a register of its own.  Without a real
+// move hipcc keeps every result limb in the low half of its own 64-bit register tuple (twice the VGPRs);
+// an identity v_mov_b32_dpp is a move the compiler schedules itself (an inline-asm v_mov would cost a
+// padding s_nop per statement).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FR_LIMB_COPY(x) ((u32)__builtin_amdgcn_mov_dpp((int)(x), 0xE4, 0xF, 0xF, false))
+#else
+#define FR_LIMB_COPY(x) (x)
+#endif
+
 // portable multiply-accumulate into the 96-bit column accumulator (host branch of the schedule)
 #define FR_MADC(acc, ovf, x, y)              \
     do {                                     \

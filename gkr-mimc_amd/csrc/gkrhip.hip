@@ -87,6 +87,8 @@ struct Ctx {
     Fr* d_q = nullptr;                         // qPrime coordinates + seeds staging
     size_t d_q_cap = 0;
     int max_grid = 2048;
+    int fold_grid = 1 << 20;                   // workgroups cap of the fold: one element per lane up to 2^28 outputs
+    bool fold_split = true;                    // one single-table launch per table instead of a fused launch
     int n_cu = 256;
     // fused cipher round (cipher_round.hip.h)
     unsigned long long* h_round = nullptr;     // host-mapped: GKR_CR_WORDS sums + 16 tail words
@@ -171,7 +173,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) g.claim_trick = atoi(e) != 0;
-    if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.max_grid = std::max(64, atoi(e));
+    if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
     g.lag = new hfr::Lagrange();
     g.device = dev;
@@ -225,6 +227,8 @@ Ctx* lane_create() {
     l->device = g0.device;
     l->n_cu = g0.n_cu;
     l->max_grid = g0.max_grid;
+    l->fold_grid = g0.fold_grid;
+    l->fold_split = g0.fold_split;
     l->g_max = g0.g_max;
     l->force_generic = g0.force_generic;
     l->lat_mode = g0.lat_mode;
@@ -365,14 +369,29 @@ int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab
         e1 = prof_event();
         HIPCHK(hipEventRecord(e0, g.stream));
     }
-    const dim3 grid(grid_for(mid, g.max_grid)), block(GKR_BLOCK);
-    switch (ntab) {
-        case 1: hipLaunchKernelGGL(k_fold<1>, grid, block, 0, g.stream, a); break;
-        case 2: hipLaunchKernelGGL(k_fold<2>, grid, block, 0, g.stream, a); break;
-        case 3: hipLaunchKernelGGL(k_fold<3>, grid, block, 0, g.stream, a); break;
-        case 4: hipLaunchKernelGGL(k_fold<4>, grid, block, 0, g.stream, a); break;
-        case 5: hipLaunchKernelGGL(k_fold<5>, grid, block, 0, g.stream, a); break;
-        default: return fail("fold of %d tables not supported", ntab);
+    // one single-table launch per table, one element per lane: measured (interleaved A/B in one process,
+    // profiles/r01_fold_variants.txt) 6.4-6.6 TB/s on 2^24/2^25-element tables, against 5.7-6.1 TB/s for a
+    // fused three-table launch and 4.6-5.8 TB/s for grid-stride loops over 8192 workgroups
+    const dim3 grid(grid_for(mid, g.fold_grid)), block(GKR_BLOCK);
+    if (!g.fold_split) {
+        switch (ntab) {
+            case 1: hipLaunchKernelGGL(k_fold<1>, grid, block, 0, g.stream, a); break;
+            case 2: hipLaunchKernelGGL(k_fold<2>, grid, block, 0, g.stream, a); break;
+            case 3: hipLaunchKernelGGL(k_fold<3>, grid, block, 0, g.stream, a); break;
+            case 4: hipLaunchKernelGGL(k_fold<4>, grid, block, 0, g.stream, a); break;
+            case 5: hipLaunchKernelGGL(k_fold<5>, grid, block, 0, g.stream, a); break;
+            default: return fail("fold of %d tables not supported", ntab);
+        }
+    } else
+    for (int t = 0; t < ntab; t++) {
+        FoldArgs one;
+        memset(&one, 0, sizeof one);
+        one.src[0] = a.src[t];
+        one.dst[0] = a.dst[t];
+        one.ntab = 1;
+        one.mid = mid;
+        one.r = a.r;
+        hipLaunchKernelGGL(k_fold<1>, grid, block, 0, g.stream, one);
     }
     HIPCHK(hipGetLastError());
     if (timed) {
@@ -1255,6 +1274,25 @@ int gkrhip_device_count(void) {
 
 const char* gkrhip_last_error(void) { return g_err.c_str(); }
 const char* gkrhip_version(void) { return "gkrhip 0.1 (gfx950)"; }
+
+int gkrhip_set_option(const char* key, long value) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    std::vector<Ctx*> lanes;
+    {
+        std::lock_guard<std::mutex> ll(g_lanes_mu);
+        lanes = g_lanes;
+    }
+    for (Ctx* l : lanes) {
+        if (!strcmp(key, "fold_grid")) l->fold_grid = (int)std::max(64L, value);
+        else if (!strcmp(key, "fold_split")) l->fold_split = value != 0;
+        else if (!strcmp(key, "g_max")) l->g_max = (int)std::max(8L, std::min(20L, value));
+        else if (!strcmp(key, "lat_mode")) l->lat_mode = (int)value;
+        else if (!strcmp(key, "claim_trick")) l->claim_trick = value != 0;
+        else return fail("unknown option %s", key);
+    }
+    return 0;
+}
 
 int gkrhip_mem_info(size_t* free_bytes, size_t* total_bytes) {
     std::lock_guard<std::mutex> lk(g0.mu);

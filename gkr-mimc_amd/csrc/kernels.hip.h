@@ -84,17 +84,24 @@ __device__ __forceinline__ void st_fr_nt(uint4* __restrict__ lo, uint4* __restri
 template <int NTAB>
 __global__ void __launch_bounds__(GKR_BLOCK) k_fold(FoldArgs a) {
     const Fr r = a.r;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.mid; i += (size_t)gridDim.x * blockDim.x) {
-        Fr lo[NTAB], hi[NTAB];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // tables outermost: each table is an independent stream, and one table at a time keeps the register
+    // footprint (hence the occupancy) of the single-table kernel; two indices per iteration so that four
+    // 1 KiB loads per wave are in flight before the first product
 #pragma unroll
-        for (int t = 0; t < NTAB; t++) {
-            lo[t] = ld_fr_nt(a.src[t].lo, a.src[t].hi, i);
-            hi[t] = ld_fr_nt(a.src[t].lo, a.src[t].hi, i + a.mid);
+    for (int t = 0; t < NTAB; t++) {
+        const CPlanes src = a.src[t];
+        const Planes dst = a.dst[t];
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + stride < a.mid; i += 2 * stride) {
+            const Fr lo0 = ld_fr_nt(src.lo, src.hi, i), hi0 = ld_fr_nt(src.lo, src.hi, i + a.mid);
+            const Fr lo1 = ld_fr_nt(src.lo, src.hi, i + stride), hi1 = ld_fr_nt(src.lo, src.hi, i + stride + a.mid);
+            st_fr_nt(dst.lo, dst.hi, i, fr_add(lo0, fr_mul(fr_sub(hi0, lo0), r)));
+            st_fr_nt(dst.lo, dst.hi, i + stride, fr_add(lo1, fr_mul(fr_sub(hi1, lo1), r)));
         }
-#pragma unroll
-        for (int t = 0; t < NTAB; t++) {
-            const Fr d = fr_mul(fr_sub(hi[t], lo[t]), r);
-            st_fr_nt(a.dst[t].lo, a.dst[t].hi, i, fr_add(lo[t], d));
+        if (i < a.mid) {
+            const Fr lo0 = ld_fr_nt(src.lo, src.hi, i), hi0 = ld_fr_nt(src.lo, src.hi, i + a.mid);
+            st_fr_nt(dst.lo, dst.hi, i, fr_add(lo0, fr_mul(fr_sub(hi0, lo0), r)));
         }
     }
 }

@@ -36,6 +36,7 @@ ABI = {
     "gkrhip_version": (C.c_char_p, []),
     "gkrhip_device_synchronize": (_I, []),
     "gkrhip_mem_info": (_I, [C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "gkrhip_set_option": (_I, [C.c_char_p, C.c_long]),
     "gkrhip_fold": (_I, [_P, _SZ, _P]),
     "gkrhip_evaluate": (_I, [_P, _P, _SZ, _P, _I]),
     "gkrhip_eq_table": (_I, [_P, _P, _I, _P]),
@@ -114,6 +115,10 @@ def shutdown():
 
 def device_count():
     return load().gkrhip_device_count()
+
+
+def set_option(key, value):
+    _check(load().gkrhip_set_option(key.encode(), int(value)))
 
 
 def mem_info():

@@ -38,6 +38,9 @@ const char *gkrhip_last_error(void);
 const char *gkrhip_version(void);
 int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
 int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
+ * "g_max", "lat_mode", "claim_trick" -- applied to every existing lane */
+int gkrhip_set_option(const char *key, long value);
 
 /* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
 /* (*MultiLin).Fold(r), poly/multilin.go:19-23: in place on `table` (n elements, n a power of two >= 2);

@@ -105,12 +105,12 @@ def gen_mul():
             host += "    r.v[%d] = (u32)acc;\n" % (c - NL)
             # device: copy the finished limb out of the accumulator pair with an explicit move, otherwise
             # hipcc keeps every result limb in the low half of its own 64-bit register tuple (2x VGPRs)
-            dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r.v[%d]) : "v"((u32)acc));\n' % (c - NL)
+            dev += '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (c - NL)
         sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
         dev += sh
         host += sh
     fin = "    r.v[%d] = (u32)acc;\n" % (NL - 1)
-    dfin = '    asm("v_mov_b32 %%0, %%1" : "=v"(r.v[%d]) : "v"((u32)acc));\n' % (NL - 1)
+    dfin = '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (NL - 1)
     return dev + dfin, host + fin
 
 
@@ -201,11 +201,11 @@ def gen_mul2():
             dev += "    const u32 m0_%d = (u32)acc0 * FR_QINV32, m1_%d = (u32)acc1 * FR_QINV32;\n" % (c, c)
             dev += emit_asm2([(("m", c), ("q", 0))], pos)
         else:
-            dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r0.v[%d]) : "v"((u32)acc0));\n' % (c - NL)
-            dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r1.v[%d]) : "v"((u32)acc1));\n' % (c - NL)
+            dev += '    r0.v[%d] = FR_LIMB_COPY((u32)acc0);\n' % (c - NL)
+            dev += '    r1.v[%d] = FR_LIMB_COPY((u32)acc1);\n' % (c - NL)
         dev += "    acc0 = (acc0 >> 32) | ((u64)ovf0 << 32);\n    acc1 = (acc1 >> 32) | ((u64)ovf1 << 32);\n"
-    dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r0.v[%d]) : "v"((u32)acc0));\n' % (NL - 1)
-    dev += '    asm("v_mov_b32 %%0, %%1" : "=v"(r1.v[%d]) : "v"((u32)acc1));\n' % (NL - 1)
+    dev += '    r0.v[%d] = FR_LIMB_COPY((u32)acc0);\n' % (NL - 1)
+    dev += '    r1.v[%d] = FR_LIMB_COPY((u32)acc1);\n' % (NL - 1)
     return dev
 
 
