@@ -582,6 +582,8 @@ int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const
         CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 1, 3>(eq, x, mid, ark, &nblocks)));
     } else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) {
         CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 2, 3>(eq, x, mid, ark, &nblocks)));
+    } else if (gate == GKRHIP_GATE_ADD && arity == 2) {
+        CHK((launch_partial_eval_t<GKR_GATE_ADD, 2, 3>(eq, x, mid, ark, &nblocks)));
     } else {
         return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
     }
@@ -894,7 +896,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     return 0;
 }
 
-int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }
+int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }   // cipher.go:68-70; copy.go:30-32; add: linear
 
 // The reference-shaped rounds (sumcheck/prover.go:70-76) over an Eq table and `arity` tables of 2^m entries:
 // partial evaluation at t = 0..deg+1, interpolation, Fiat-Shamir, fold.  eq is folded in place, X is
@@ -1012,6 +1014,7 @@ int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, 
     if (gate == GKRHIP_GATE_CIPHER && arity == 2) launch_gate_eval<GKR_GATE_CIPHER, 2>(a);
     else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) launch_gate_eval<GKR_GATE_IDENTITY, 1>(a);
     else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) launch_gate_eval<GKR_GATE_IDENTITY, 2>(a);
+    else if (gate == GKRHIP_GATE_ADD && arity == 2) launch_gate_eval<GKR_GATE_ADD, 2>(a);
     else return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1097,6 +1100,99 @@ Circuit mimc_circuit() {  // examples/mimc.go:10-37
     return c;
 }
 
+// circuit from a flat description (circuit/circuit.go:11-44: In given, Out computed by BuildCircuit)
+int circuit_from_layers(const gkrhip_layer* layers, int n, Circuit* out) {
+    if (n < 2 || n > 4096) return fail("circuit: %d layers", n);
+    Circuit c(n);
+    bool seen_gate = false;
+    for (int l = 0; l < n; l++) {
+        const gkrhip_layer& d = layers[l];
+        if (d.gate < 0) {
+            if (seen_gate) return fail("circuit: input layer %d after a gate layer", l);
+            if (d.n_in != 0) return fail("circuit: input layer %d has inputs", l);
+            continue;
+        }
+        seen_gate = true;
+        if (d.gate != GKRHIP_GATE_IDENTITY && d.gate != GKRHIP_GATE_CIPHER && d.gate != GKRHIP_GATE_ADD)
+            return fail("circuit: layer %d has unknown gate %d", l, d.gate);
+        const int want = d.gate == GKRHIP_GATE_IDENTITY ? 1 : 2;
+        if (d.n_in != want) return fail("circuit: layer %d: gate %d takes %d inputs, got %d", l, d.gate, want, d.n_in);
+        c[l].gate = d.gate;
+        memcpy(c[l].ark.l, d.ark, 32);
+        if (!hfr::is_canonical(c[l].ark)) return fail("circuit: layer %d: Ark is not a canonical element", l);
+        for (int k = 0; k < d.n_in; k++) {
+            if (d.in[k] < 0 || d.in[k] >= l) return fail("circuit: layer %d reads layer %d (must be an earlier layer)", l, d.in[k]);
+            c[l].in.push_back(d.in[k]);
+        }
+    }
+    if (c[0].gate >= 0) return fail("circuit: no input layer");
+    if (c[n - 1].gate < 0) return fail("circuit: the last layer must be a gate layer (the output)");
+    for (int l = 0; l < n; l++)
+        for (int p : c[l].in) c[p].out.push_back(l);
+    for (int l = 0; l < n; l++) {
+        if (c[l].gate < 0 && c[l].out.size() > 1)   // circuit/circuit.go:36-41
+            return fail("Layer %d is an input layer but has %zu outputs", l, c[l].out.size());
+        if (l < n - 1 && c[l].out.empty()) return fail("circuit: layer %d feeds nothing (only the last layer may)", l);
+    }
+    *out = c;
+    return 0;
+}
+
+// Build-defined circuit of one GMiMC (t = 2) compression, out = GMimcT2.UpdateInplace([s0,s1],[b0,b1])[0]
+// (hash/gmimc.go:52-65): inputs 0..3 = s0, s1, b0, b1; per round one add layer x' = y + b1 + Ark_i and one
+// cipher layer y' = (b0 + x + Ark_i)^7; explicit copy layers for the multi-use inputs; feed-forward by two add
+// layers with Ark = 0; layers that do not reach the output are pruned.
+std::vector<gkrhip_layer> gmimc_t2_layers() {
+    struct Tmp {
+        int gate, n_in, in[2];
+        E ark;
+    };
+    std::vector<Tmp> L;
+    auto add = [&](int gate, int a, int b, const E& ark) {
+        Tmp t;
+        t.gate = gate;
+        t.n_in = gate < 0 ? 0 : (gate == GKRHIP_GATE_IDENTITY ? 1 : 2);
+        t.in[0] = a;
+        t.in[1] = b;
+        t.ark = ark;
+        L.push_back(t);
+        return (int)L.size() - 1;
+    };
+    for (int i = 0; i < 4; i++) add(-1, 0, 0, hfr::ZERO);
+    const int cs0 = add(GKRHIP_GATE_IDENTITY, 0, 0, hfr::ZERO);
+    const int cb0 = add(GKRHIP_GATE_IDENTITY, 2, 0, hfr::ZERO);
+    const int cb1 = add(GKRHIP_GATE_IDENTITY, 3, 0, hfr::ZERO);
+    int x = cs0, y = 1;
+    for (int i = 0; i < hfr::MIMC_ROUNDS; i++) {
+        const int nx = add(GKRHIP_GATE_ADD, y, cb1, hfr::ARKS[i]);
+        const int ny = add(GKRHIP_GATE_CIPHER, cb0, x, hfr::ARKS[i]);
+        x = nx;
+        y = ny;
+    }
+    const int t1 = add(GKRHIP_GATE_ADD, x, cs0, hfr::ZERO);
+    add(GKRHIP_GATE_ADD, t1, cb0, hfr::ZERO);
+    std::vector<char> need(L.size(), 0);
+    need.back() = 1;
+    for (int l = (int)L.size() - 1; l >= 0; l--)
+        if (need[l])
+            for (int k = 0; k < L[l].n_in; k++) need[L[l].in[k]] = 1;
+    for (int i = 0; i < 4; i++) need[i] = 1;
+    std::vector<int> ren(L.size(), -1);
+    std::vector<gkrhip_layer> out;
+    for (size_t l = 0; l < L.size(); l++) {
+        if (!need[l]) continue;
+        ren[l] = (int)out.size();
+        gkrhip_layer d;
+        memset(&d, 0, sizeof d);
+        d.gate = L[l].gate;
+        d.n_in = L[l].n_in;
+        for (int k = 0; k < d.n_in; k++) d.in[k] = ren[L[l].in[k]];
+        memcpy(d.ark, L[l].ark.l, 32);
+        out.push_back(d);
+    }
+    return out;
+}
+
 size_t proof_len(const Circuit& c, int bN) {  // hints.go:76-116
     size_t sc = 0, cl = 0, qp = 0;
     for (const Layer& l : c) {
@@ -1112,19 +1208,20 @@ size_t proof_len(const Circuit& c, int bN) {  // hints.go:76-116
 // ------------------------------------------------------------------------------------------------
 // resident session
 // ------------------------------------------------------------------------------------------------
-struct gkrhip_mimc_session {
+struct gkrhip_session {
     int bN = 0;
     size_t n = 0;
     Circuit c;
     std::vector<DevTable> a;     // assignment; identity layers alias their input (no storage)
     std::vector<int> alias;      // alias[l] = layer whose table layer l shares, or l
     bool have_inputs = false, assigned = false;
+    unsigned long long inputs_loaded = 0;
     Ctx* lane = nullptr;         // &g0 for sharded sessions, otherwise a lane of its own
 };
 
 namespace {
 
-int session_alloc(gkrhip_mimc_session* s) {
+int session_alloc(gkrhip_session* s) {
     const size_t L = s->c.size();
     s->a.assign(L, DevTable());
     s->alias.resize(L);
@@ -1140,9 +1237,9 @@ int session_alloc(gkrhip_mimc_session* s) {
     }
     return 0;
 }
-const DevTable* session_table(const gkrhip_mimc_session* s, int l) { return &s->a[s->alias[l]]; }
+const DevTable* session_table(const gkrhip_session* s, int l) { return &s->a[s->alias[l]]; }
 
-int session_assign(gkrhip_mimc_session* s) {  // circuit/assignment.go:12-32
+int session_assign(gkrhip_session* s) {  // circuit/assignment.go:12-32
     if (!s->have_inputs) return fail("session has no inputs");
     for (size_t l = 0; l < s->c.size(); l++) {
         const Layer& lay = s->c[l];
@@ -1156,7 +1253,7 @@ int session_assign(gkrhip_mimc_session* s) {  // circuit/assignment.go:12-32
     return 0;
 }
 
-int session_prove(gkrhip_mimc_session* s, const E* qprime, E* flat) {  // gkr/prover.go:21-91
+int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.go:21-91
     if (!s->assigned) return fail("session is not assigned");
     const Circuit& c = s->c;
     const int L = (int)c.size(), bN = s->bN;
@@ -1414,16 +1511,46 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int 
 
 size_t gkrhip_mimc_proof_len(int bN) { return (size_t)822 * bN + 183 + (size_t)184 * bN; }
 
-int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
+static int session_create_for(gkrhip_session** out, const Circuit& circ, int bN);
+
+int gkrhip_mimc_session_create(gkrhip_session** out, int bN) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
+    return session_create_for(out, mimc_circuit(), bN);
+}
+
+int gkrhip_session_create(gkrhip_session** out, const gkrhip_layer* layers, int n_layers, int bN) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    Circuit c;
+    CHK(circuit_from_layers(layers, n_layers, &c));
+    return session_create_for(out, c, bN);
+}
+
+int gkrhip_gmimc_t2_circuit(gkrhip_layer* layers_out, int capacity) {
+    const std::vector<gkrhip_layer> v = gmimc_t2_layers();
+    if (layers_out) {
+        if (capacity < (int)v.size()) return fail("gmimc_t2_circuit: capacity %d < %zu layers", capacity, v.size());
+        memcpy(layers_out, v.data(), v.size() * sizeof(gkrhip_layer));
+    }
+    return (int)v.size();
+}
+
+size_t gkrhip_session_proof_len(const gkrhip_session* s) { return s ? proof_len(s->c, s->bN) : 0; }
+int gkrhip_session_num_inputs(const gkrhip_session* s) {
+    int n = 0;
+    while (s && n < (int)s->c.size() && s->c[n].gate < 0) n++;
+    return n;
+}
+
+static int session_create_for(gkrhip_session** out, const Circuit& circ, int bN) {
     if (bN < 0 || bN > 32) return fail("bN %d out of range", bN);
     if (bN < gc.gamma) return fail("bN %d is smaller than log2(world) = %d", bN, gc.gamma);
     if (bN - gc.gamma > 28) return fail("a shard of 2^%d entries does not fit one GPU", bN - gc.gamma);
-    gkrhip_mimc_session* s = new gkrhip_mimc_session();
+    gkrhip_session* s = new gkrhip_session();
     s->bN = bN;                                   // global number of variables
     s->n = (size_t)1 << (bN - gc.gamma);          // entries of this rank's shard
-    s->c = mimc_circuit();
+    s->c = circ;
     // with a communicator installed, session i runs on communicator lane i mod nlanes (lane k pairs with lane k
     // of the peers: create the sessions in the same order on every rank); otherwise it gets a lane of its own
     if (!gc.lanes.empty()) s->lane = gc.lanes[gc.next_lane++ % gc.lanes.size()];
@@ -1451,8 +1578,10 @@ int gkrhip_mimc_session_create(gkrhip_mimc_session** out, int bN) {
     std::lock_guard<std::mutex> lk((s)->lane->mu);        \
     UseLane ul((s)->lane)
 
-int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session* s, const uint64_t* in0, const uint64_t* in1) {
+int gkrhip_mimc_session_load_inputs(gkrhip_session* s, const uint64_t* in0, const uint64_t* in1) {
     SESSION_ENTER(s);
+    if (s->c.size() < 2 || s->c[0].gate >= 0 || s->c[1].gate >= 0 || (s->c.size() > 2 && s->c[2].gate < 0))
+        return fail("load_inputs: the circuit does not have exactly two input layers");
     CHK(upload_table(&s->a[0], in0, s->n));
     CHK(upload_table(&s->a[1], in1, s->n));
     s->have_inputs = true;
@@ -1460,9 +1589,24 @@ int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session* s, const uint64_t* in0,
     return 0;
 }
 
-int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session* s, uint64_t index_stride, uint64_t index_offset) {
+int gkrhip_session_load_input(gkrhip_session* s, int input_index, const uint64_t* table) {
     SESSION_ENTER(s);
-    for (int l = 0; l < 2; l++) {
+    if (input_index < 0 || input_index >= (int)s->c.size() || s->c[input_index].gate >= 0)
+        return fail("layer %d is not an input layer", input_index);
+    CHK(upload_table(&s->a[input_index], table, s->n));
+    s->inputs_loaded |= 1ull << (input_index & 63);
+    int n_in = 0;
+    while (n_in < (int)s->c.size() && s->c[n_in].gate < 0) n_in++;
+    s->have_inputs = s->inputs_loaded == ((n_in >= 64) ? ~0ull : ((1ull << n_in) - 1));
+    s->assigned = false;
+    return 0;
+}
+
+int gkrhip_mimc_session_synth_inputs(gkrhip_session* s, uint64_t index_stride, uint64_t index_offset) {
+    SESSION_ENTER(s);
+    int n_in = 0;
+    while (n_in < (int)s->c.size() && s->c[n_in].gate < 0) n_in++;
+    for (int l = 0; l < n_in; l++) {
         hipLaunchKernelGGL(k_random_fr_array, dim3(grid_for(s->n, g.max_grid)), dim3(GKR_BLOCK), 0, g.stream,
                            s->a[l].planes(), s->n, (unsigned long long)index_stride, (unsigned long long)index_offset);
         HIPCHK(hipGetLastError());
@@ -1473,23 +1617,23 @@ int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session* s, uint64_t index_stri
     return 0;
 }
 
-int gkrhip_mimc_session_assign(gkrhip_mimc_session* s) {
+int gkrhip_mimc_session_assign(gkrhip_session* s) {
     SESSION_ENTER(s);
     return session_assign(s);
 }
 
-int gkrhip_mimc_session_prove(gkrhip_mimc_session* s, const uint64_t* qprime, uint64_t* flat) {
+int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_t* flat) {
     SESSION_ENTER(s);
     return session_prove(s, (const E*)qprime, (E*)flat);
 }
 
-int gkrhip_mimc_session_outputs(gkrhip_mimc_session* s, uint64_t* outputs) {
+int gkrhip_mimc_session_outputs(gkrhip_session* s, uint64_t* outputs) {
     SESSION_ENTER(s);
     if (!s->assigned) return fail("session is not assigned");
     return download_table(session_table(s, (int)s->c.size() - 1), outputs, s->n);
 }
 
-int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session* s, int layer, const uint64_t* coords, uint64_t out[4]) {
+int gkrhip_mimc_session_evaluate_layer(gkrhip_session* s, int layer, const uint64_t* coords, uint64_t out[4]) {
     SESSION_ENTER(s);
     if (layer < 0 || layer >= (int)s->c.size()) return fail("layer %d out of range", layer);
     if (!s->assigned && layer >= 2) return fail("session is not assigned");
@@ -1499,7 +1643,7 @@ int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session* s, int layer, const 
     return 0;
 }
 
-void gkrhip_mimc_session_destroy(gkrhip_mimc_session* s) {
+void gkrhip_mimc_session_destroy(gkrhip_session* s) {
     if (!s) return;
     if (g0.ready) (void)hipSetDevice(g0.device);
     if (s->lane) {
@@ -1518,7 +1662,7 @@ void gkrhip_mimc_session_destroy(gkrhip_mimc_session* s) {
 
 int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
                           uint64_t* outputs_or_null) {
-    gkrhip_mimc_session* s = nullptr;
+    gkrhip_session* s = nullptr;
     CHK(gkrhip_mimc_session_create(&s, bN));
     int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
     if (rc == 0) rc = gkrhip_mimc_session_assign(s);
@@ -1620,6 +1764,7 @@ static int verify_flat(const Circuit& c, int bN, const E* flat, const E* qprime,
         }
         E gate_val;
         if (c[layer].gate == GKRHIP_GATE_CIPHER) gate_val = hfr::pow7(hfr::add(hfr::add(sub[1], c[layer].ark), sub[0]));
+        else if (c[layer].gate == GKRHIP_GATE_ADD) gate_val = hfr::add(hfr::add(sub[0], sub[1]), c[layer].ark);
         else gate_val = sub[0];
         std::vector<E> eqs(ncl);
         for (int i = 0; i < ncl; i++) eqs[i] = hfr::eval_eq(qps[layer] + (size_t)i * bN, next_q.data(), bN);
@@ -1658,7 +1803,7 @@ int gkrhip_gkr_verify_mimc(int bN, const uint64_t* flat, const uint64_t* in0, co
     return rc;
 }
 
-int gkrhip_mimc_session_verify(gkrhip_mimc_session* s, const uint64_t* qprime, const uint64_t* flat) {
+int gkrhip_mimc_session_verify(gkrhip_session* s, const uint64_t* qprime, const uint64_t* flat) {
     SESSION_ENTER(s);
     if (!s->assigned) return fail("session is not assigned");
     auto eval = [&](int layer, const E* pt, E* out) -> int { return evaluate_dev(session_table(s, layer), s->bN, pt, out); };

@@ -18,7 +18,7 @@
 #define GKR_MAX_EVALS 9   // cipher gate: degree 8 -> 9 evaluation points (sumcheck/prover.go:95, algo.go:57)
 #define GKR_ACC_WORDS 9   // un-reduced 288-bit lane accumulators
 
-enum { GKR_GATE_IDENTITY = 0, GKR_GATE_CIPHER = 1 };
+enum { GKR_GATE_IDENTITY = 0, GKR_GATE_CIPHER = 1, GKR_GATE_ADD = 2 };
 
 struct Planes {
     uint4* lo;
@@ -172,6 +172,8 @@ template <int GATE>
 __device__ __forceinline__ Fr gate_eval(const Fr* x, const Fr& ark) {
     if (GATE == GKR_GATE_CIPHER) {
         return fr_pow7(fr_add(fr_add(x[1], ark), x[0]));
+    } else if (GATE == GKR_GATE_ADD) {
+        return fr_add(fr_add(x[0], x[1]), ark);   // build-defined linear gate (GMiMC's non-S-box branches)
     } else {
         return x[0];
     }

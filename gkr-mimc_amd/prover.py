@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-GATE_IDENTITY, GATE_CIPHER = 0, 1
+GATE_IDENTITY, GATE_CIPHER, GATE_ADD = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libgkrhip.so")
@@ -52,6 +52,11 @@ ABI = {
     "gkrhip_mimc_session_outputs": (_I, [_P, _P]),
     "gkrhip_mimc_session_evaluate_layer": (_I, [_P, _I, _P, _P]),
     "gkrhip_mimc_session_destroy": (None, [_P]),
+    "gkrhip_session_create": (_I, [C.POINTER(_P), _P, _I, _I]),
+    "gkrhip_session_load_input": (_I, [_P, _I, _P]),
+    "gkrhip_session_proof_len": (_SZ, [_P]),
+    "gkrhip_session_num_inputs": (_I, [_P]),
+    "gkrhip_gmimc_t2_circuit": (_I, [_P, _I]),
     "gkrhip_gkr_verify_mimc": (_I, [_I, _P, _P, _P, _P, _P]),
     "gkrhip_mimc_session_verify": (_I, [_P, _P, _P]),
     "gkrhip_to_regular": (_I, [_P, _SZ]),
@@ -251,17 +256,47 @@ def mimc_permutation_batch(x, key):
     return out
 
 
-class MimcSession:
-    """Resident MiMC assignment on the GPU; prove() can be repeated."""
+class LayerDesc(C.Structure):
+    _fields_ = [("gate", C.c_int), ("n_in", C.c_int), ("in_", C.c_int * 2), ("ark", C.c_uint64 * 4)]
 
-    def __init__(self, bN):
+
+def gmimc_t2_circuit():
+    """The library's GMiMC (t = 2) circuit description as a list of (gate, [inputs], ark limbs)."""
+    n = load().gkrhip_gmimc_t2_circuit(None, 0)
+    arr = (LayerDesc * n)()
+    assert load().gkrhip_gmimc_t2_circuit(C.cast(arr, C.c_void_p), n) == n
+    return [(l.gate, [l.in_[k] for k in range(l.n_in)], [int(v) for v in l.ark]) for l in arr]
+
+
+class MimcSession:
+    """Resident assignment on the GPU (examples.MimcCircuit, or any circuit given as `layers` =
+    [(gate, [inputs], ark limbs or None), ...]); prove() can be repeated."""
+
+    def __init__(self, bN, layers=None):
         self.bN = bN
         self._h = C.c_void_p()
         w, r = C.c_int(1), C.c_int(0)
         load().gkrhip_comm_info(C.byref(w), C.byref(r))
         self.world, self.rank = w.value, r.value
         self.local_n = (1 << bN) // self.world
-        _check(load().gkrhip_mimc_session_create(C.byref(self._h), bN))
+        if layers is None:
+            _check(load().gkrhip_mimc_session_create(C.byref(self._h), bN))
+        else:
+            arr = (LayerDesc * len(layers))()
+            for i, (gate, ins, ark) in enumerate(layers):
+                arr[i].gate, arr[i].n_in = gate, len(ins)
+                for k, v in enumerate(ins):
+                    arr[i].in_[k] = v
+                for k in range(4):
+                    arr[i].ark[k] = 0 if ark is None else int(ark[k])
+            _check(load().gkrhip_session_create(C.byref(self._h), C.cast(arr, C.c_void_p), len(layers), bN))
+        self.proof_len = load().gkrhip_session_proof_len(self._h)
+        self.num_inputs = load().gkrhip_session_num_inputs(self._h)
+
+    def load_input(self, index, table):
+        table = _fr(table)
+        assert table.shape[0] == self.local_n
+        _check(load().gkrhip_session_load_input(self._h, index, _ptr(table)))
 
     def load_inputs(self, in0, in1):
         in0, in1 = _fr(in0), _fr(in1)
@@ -279,7 +314,7 @@ class MimcSession:
 
     def prove(self, q_prime):
         q_prime = _fr(q_prime).reshape(-1, 4)
-        flat = np.zeros((mimc_proof_len(self.bN), 4), np.uint64)
+        flat = np.zeros((self.proof_len, 4), np.uint64)
         _check(load().gkrhip_mimc_session_prove(self._h, _ptr(q_prime) if self.bN else None, _ptr(flat)))
         return flat
 

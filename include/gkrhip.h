@@ -29,6 +29,8 @@ extern "C" {
 
 #define GKRHIP_GATE_IDENTITY 0 /* circuit/gates/copy.go:9-32   : xs[0],              Degree 1 */
 #define GKRHIP_GATE_CIPHER 1   /* circuit/gates/cipher.go:11-70: (xs[0]+xs[1]+Ark)^7, Degree 7 */
+#define GKRHIP_GATE_ADD 2      /* build-defined (no such circuit.Gate in the reference): xs[0]+xs[1]+Ark, Degree 1;
+                                * the non-S-box branches of a GMiMC round (hash/gmimc.go:52-58) */
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 int gkrhip_init(int device_ordinal);      /* idempotent; selects the GPU, creates the stream/arena */
@@ -78,7 +80,8 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t *in0, const uint64_t *in1, cons
 
 /* Resident session: the assignment stays in HBM, Prove can be repeated (it never mutates the
  * assignment).  This is what the benchmark times (gkr/gkr_test.go:99-105 excludes Assign). */
-typedef struct gkrhip_mimc_session gkrhip_mimc_session;
+typedef struct gkrhip_session gkrhip_session;
+typedef gkrhip_session gkrhip_mimc_session;   /* a session over examples.MimcCircuit */
 int gkrhip_mimc_session_create(gkrhip_mimc_session **out, int bN);
 int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session *s, const uint64_t *in0, const uint64_t *in1);
 /* inputs = common.RandomFrArray(2^bN) for both (common/common.go:49-55), generated on the device;
@@ -90,6 +93,28 @@ int gkrhip_mimc_session_outputs(gkrhip_mimc_session *s, uint64_t *outputs);
 /* MultiLin.Evaluate of an assignment layer at `coords` on the device (verifier helper, gkr/verifier.go:36,120-132). */
 int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session *s, int layer, const uint64_t *coords, uint64_t out[4]);
 void gkrhip_mimc_session_destroy(gkrhip_mimc_session *s);
+
+/* ---- gkr.Prove on any layered circuit (circuit/circuit.go:11-44) built from the gates above ----------------
+ * A layer is described by its gate, its Ark and the layers it reads (circuit.Layer.In); input layers
+ * (gate = -1) come first; Out is computed as BuildCircuit does, with its rule that an input layer has at most
+ * one consumer (multi-use tables need an explicit identity layer, as examples/mimc.go:20).  The last layer is
+ * the output layer.  Every gkrhip_mimc_session_* entry point accepts such a session (load_inputs needs
+ * exactly two input layers; synth_inputs fills every input layer); the flat proof is in GkrProofToVec order
+ * for that circuit and has gkrhip_session_proof_len elements. */
+typedef struct {
+    int gate;          /* -1 input layer, else GKRHIP_GATE_* */
+    int n_in;          /* 0 for inputs, 1 for IDENTITY, 2 for CIPHER / ADD */
+    int in[2];
+    uint64_t ark[4];   /* Montgomery limbs; ignored for IDENTITY and inputs */
+} gkrhip_layer;
+int gkrhip_session_create(gkrhip_session **out, const gkrhip_layer *layers, int n_layers, int bN);
+int gkrhip_session_load_input(gkrhip_session *s, int input_index, const uint64_t *table);
+size_t gkrhip_session_proof_len(const gkrhip_session *s);
+int gkrhip_session_num_inputs(const gkrhip_session *s);
+/* The build-defined circuit of one GMiMC (t = 2) compression, out = GMimcT2.UpdateInplace([s0,s1],[b0,b1])[0]
+ * (hash/gmimc.go:52-65; BASELINE config 5): input layers 0..3 = s0, s1, b0, b1.  Returns the number of
+ * layers (100); fills layers_out when it is not NULL. */
+int gkrhip_gmimc_t2_circuit(gkrhip_layer *layers_out, int capacity);
 
 /* ---- gkr.Verify (gkr/verifier.go:15-132): native verifier; MultiLin.Evaluate of the output and input tables
  * runs on the device, the rest is scalar host work.  Returns 0 = accepted, > 0 = rejected (code in

@@ -260,6 +260,23 @@ class IdentityGate:
         return 1
 
 
+class AddGate:
+    """Build-defined linear gate xs[0] + xs[1] + Ark (Degree 1): the non-S-box branches of a GMiMC round,
+    state[j] += block[j] + Ark (hash/poseidon.go:146-151 as used by hash/gmimc.go:52-58).  The reference has
+    no such circuit.Gate; it is pinned only through hash.GMimcHasher's outputs."""
+
+    kind = "add"
+
+    def __init__(self, ark):
+        self.ark = ark % Q
+
+    def eval(self, *xs):
+        return (xs[0] + xs[1] + self.ark) % Q
+
+    def degree(self):
+        return 1
+
+
 class Layer:
     def __init__(self, In, gate=None):
         self.In = list(In)
@@ -304,6 +321,38 @@ def mimc_circuit():
         inp = 1 if i == 0 else i + 2
         c[i + 3] = Layer([2, inp], CipherGate(ARKS[i]))
     return build_circuit(c)
+
+
+def gmimc_t2_circuit():
+    """Build-defined GKR circuit for one GMiMC (t = 2) compression (hash/gmimc.go:52-65):
+        out = GMimcT2.UpdateInplace(state = [s0, s1], block = [b0, b1])[0]
+    Inputs: layers 0..3 = s0, s1, b0, b1.  A round maps the state (x, y) to (y + b1 + Ark_i, (x + b0 + Ark_i)^7)
+    (add keys and Ark to every branch, S-box on branch 0, rotate left): one AddGate layer and one CipherGate
+    layer per round, multi-use inputs behind explicit copy layers (as examples/mimc.go:20 does for the key).
+    The feed-forward out = x_91 + s0 + b0 is two AddGate layers with Ark = 0.  Layers that do not reach the
+    output (the last S-box, the add before it) are pruned, so the last layer is the only one without consumers."""
+    L = [Layer([]), Layer([]), Layer([]), Layer([])]      # 0: s0, 1: s1, 2: b0, 3: b1
+    L.append(Layer([0], IdentityGate()))                  # 4: copy of s0 (round 0 and the feed-forward)
+    L.append(Layer([2], IdentityGate()))                  # 5: copy of b0
+    L.append(Layer([3], IdentityGate()))                  # 6: copy of b1
+    x, y = 4, 1
+    for i in range(MIMC_ROUNDS):
+        L.append(Layer([y, 6], AddGate(ARKS[i])))         # x' = y + b1 + Ark_i
+        nx = len(L) - 1
+        L.append(Layer([5, x], CipherGate(ARKS[i])))      # y' = (b0 + x + Ark_i)^7
+        ny = len(L) - 1
+        x, y = nx, ny
+    L.append(Layer([x, 4], AddGate(0)))                   # x_91 + s0
+    L.append(Layer([len(L) - 1, 5], AddGate(0)))          # ... + b0
+    # prune layers that do not reach the output, keep the order
+    need = {len(L) - 1}
+    for l in range(len(L) - 1, -1, -1):
+        if l in need:
+            need.update(L[l].In)
+    need.update(range(4))
+    keep = [l for l in range(len(L)) if l in need]
+    ren = {l: k for k, l in enumerate(keep)}
+    return build_circuit([Layer([ren[p] for p in L[l].In], L[l].gate) for l in keep])
 
 
 def assign(c, *inps):

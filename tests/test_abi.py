@@ -39,6 +39,27 @@ def test_no_gpu_fails_loudly(gk):
         gk.fold(np.zeros((4, 4), np.uint64), np.zeros((1, 4), np.uint64))
 
 
+def test_gmimc_circuit_description_matches_oracle(gk):
+    """The library's build-defined GMiMC (t = 2) circuit (BASELINE config 5) is layer for layer the circuit the
+    Python oracle proves, and that circuit computes hash.GMimcHasher's compression (checked in pyoracle)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as o
+    lib_c = gk.gmimc_t2_circuit()
+    ref_c = o.gmimc_t2_circuit()
+    assert len(lib_c) == len(ref_c) == 100
+    kinds = {None: -1, "identity": gk.GATE_IDENTITY, "cipher": gk.GATE_CIPHER, "add": gk.GATE_ADD}
+    for (gate, ins, ark), lay in zip(lib_c, ref_c):
+        assert gate == kinds[lay.gate.kind if lay.gate else None]
+        assert ins == lay.In
+        if gate in (gk.GATE_CIPHER, gk.GATE_ADD):
+            assert ark == o.to_mont_limbs(lay.gate.ark)
+    # the circuit is the compression function of the reference's hasher
+    ins = [[5], [7], [11], [13]]
+    a = o.assign(ref_c, *ins)
+    assert a[-1][0] == o.gmimc_update([5, 7], [11, 13])[0]
+
+
 def test_proof_len(gk):
     for bn in (0, 1, 5, 24):
         assert gk.mimc_proof_len(bn) == 822 * bn + 183 + 184 * bn

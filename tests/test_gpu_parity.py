@@ -390,6 +390,63 @@ def test_gkr_bn18_vs_oracle_and_bn20_verified(gk):
     assert c.gkr_verify_mimc(bn, bad, i0, i0, outs, qp) != 0
 
 
+# ---------------------------------------------------------------- generic circuits: GMiMC (BASELINE config 5)
+def _gmimc_inputs(n):
+    return [o.random_fr_array(n), [(3 * i * i + 7) % o.Q for i in range(n)], [(i * i * i * 5 + 1) % o.Q for i in range(n)],
+            [o.mimc_hash([i]) for i in range(n)]]
+
+
+@pytest.mark.parametrize("bn", [0, 1, 3, 5])
+def test_gmimc_circuit_vs_oracle(gk, bn):
+    """gkr.Prove on the build-defined GMiMC (t = 2) circuit (add, cipher and copy layers): the transcript equals
+    the Python oracle's, the outputs equal hash.GMimcHasher's compression of every instance."""
+    n = 1 << bn
+    ins = _gmimc_inputs(n)
+    circ = o.gmimc_t2_circuit()
+    a = o.assign(circ, *ins)
+    qp = o.random_fr_array(bn)
+    want = o.gkr_proof_to_vec(o.gkr_prove(circ, a, qp))
+    s = gk.MimcSession(bn, layers=gk.gmimc_t2_circuit())
+    assert s.num_inputs == 4 and s.proof_len == len(want)
+    for k in range(4):
+        s.load_input(k, c.from_ints(ins[k]))
+    s.assign()
+    flat = s.prove(c.from_ints(qp))
+    assert c.to_ints(flat) == want
+    assert c.to_ints(s.outputs()) == [o.gmimc_update([ins[0][k], ins[1][k]], [ins[2][k], ins[3][k]])[0] for k in range(n)]
+    assert s.verify(c.from_ints(qp), flat)
+    s.close()
+
+
+def test_gmimc_circuit_larger_sizes(gk):
+    """bN = 10: outputs equal the reference hasher on every instance; bN = 14 and 22 (BASELINE config 5): the
+    native gkr.Verify accepts the proof against the resident tables and rejects a corrupted one."""
+    bn = 10
+    n = 1 << bn
+    ins = _gmimc_inputs(n)
+    s = gk.MimcSession(bn, layers=gk.gmimc_t2_circuit())
+    for k in range(4):
+        s.load_input(k, c.from_ints(ins[k]))
+    s.assign()
+    assert c.to_ints(s.outputs()) == [o.gmimc_update([ins[0][k], ins[1][k]], [ins[2][k], ins[3][k]])[0] for k in range(n)]
+    qp = c.random_fr_array(bn)
+    flat = s.prove(qp)
+    assert s.verify(qp, flat)
+    s.close()
+    for bn in (14, 22):
+        s = gk.MimcSession(bn, layers=gk.gmimc_t2_circuit())
+        s.synth_inputs()
+        s.assign()
+        qp = c.random_fr_array(bn)
+        flat = s.prove(qp)
+        assert np.array_equal(flat, s.prove(qp))
+        assert s.verify(qp, flat)
+        bad = flat.copy()
+        bad[len(bad) // 2, 0] ^= np.uint64(1)
+        assert not s.verify(qp, bad)
+        s.close()
+
+
 # ---------------------------------------------------------------- verifier and wire-format helpers
 @pytest.mark.parametrize("bn", [0, 1, 3, 8, 13])
 def test_native_verifier_agrees_with_oracle(gk, bn):
