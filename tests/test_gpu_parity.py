@@ -212,6 +212,33 @@ def test_sumcheck_does_not_mutate_inputs_and_checks_sizes(gk):
         gk.sumcheck_prove(Xm, qs_m, claims_m[:2], gk.GATE_IDENTITY)
 
 
+def test_sumcheck_output_does_not_depend_on_claims_being_true(gk):
+    """In the reference the claims only feed Fiat-Shamir (sumcheck/prover.go:36-37,128): a caller may pass any
+    values.  sumcheck.Prove through the C ABI therefore never derives a round sum from the claim (that shortcut
+    is internal to gkr.Prove): with false claims the output still equals the oracle's, and for a single point it
+    equals the output with the true claim."""
+    X, claims, qs, ark = _cipher_instance(8)
+    bogus = c.mimc_hash(claims)
+    got = gk.sumcheck_prove(X, qs, bogus, gk.GATE_CIPHER, ark)
+    want = c.sumcheck_prove(c.GATE_CIPHER, ark, X, qs, bogus)
+    true = gk.sumcheck_prove(X, qs, claims, gk.GATE_CIPHER, ark)
+    for a, b, t in zip(got, want, true):
+        assert np.array_equal(a, b) and np.array_equal(a, t)
+    Xm, claims_m, qs_m = _multi_instance(7, 5)
+    bogus_m = np.concatenate([c.mimc_hash(claims_m[i:i + 1]) for i in range(5)])
+    got = gk.sumcheck_prove(Xm, qs_m, bogus_m, gk.GATE_IDENTITY)
+    want = c.sumcheck_prove(c.GATE_IDENTITY, None, Xm, qs_m, bogus_m)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # degenerate evaluation points (coordinates 0 and 1) exercise the eq-weight corner cases
+    qz = c.from_ints([0, 1, 0, 1, 1, 0, 5, 0]).reshape(1, 8, 4)
+    cl = c.evaluation(c.GATE_CIPHER, ark, qz, c.fr(0), X)
+    got = gk.sumcheck_prove(X, qz, cl, gk.GATE_CIPHER, ark)
+    want = c.sumcheck_prove(c.GATE_CIPHER, ark, X, qz, cl)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 def test_sumcheck_cipher_bn20_vs_oracle(gk):
     """BASELINE config 2 size (bN = 20) on the reference's benchmark instance shape
     (sumcheck/prover_test.go:96-109: L[i]=R[i]=i, ark=145646)."""
