@@ -14,7 +14,7 @@ import numpy as np
 _here = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_here, "libgkr_oracle.so")
 
-GATE_IDENTITY, GATE_CIPHER = 0, 1
+GATE_IDENTITY, GATE_CIPHER, GATE_ADD = 0, 1, 2
 
 
 def build():
@@ -76,6 +76,9 @@ def _load():
         "oracle_mimc_proof_len": (C.c_size_t, [C.c_int]),
         "oracle_gkr_prove_mimc": (C.c_int, [C.c_int, P, P, P, P, P, P]),
         "oracle_gkr_verify_mimc": (C.c_int, [C.c_int, P, P, P, P, P]),
+        "oracle_circuit_proof_len": (C.c_size_t, [P, C.c_int, C.c_int]),
+        "oracle_gkr_prove_circuit": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
+        "oracle_gkr_verify_circuit": (C.c_int, [P, C.c_int, C.c_int, P, P, C.c_int, P, P]),
         "oracle_num_threads": (C.c_int, []),
         "oracle_set_num_threads": (None, [C.c_int]),
     }
@@ -270,3 +273,45 @@ def gkr_verify_mimc(bN, flat, in0, in1, outputs, qprime):
     return lib.oracle_gkr_verify_mimc(bN, _p(np.ascontiguousarray(flat)), _p(np.ascontiguousarray(in0)),
                                       _p(np.ascontiguousarray(in1)), _p(np.ascontiguousarray(outputs)),
                                       _p(qprime) if bN else None)
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("gate", C.c_int), ("n_in", C.c_int), ("in_", C.c_int * 2), ("ark", C.c_uint64 * 4)]
+
+
+def circuit_descs(pycircuit):
+    """pyoracle circuit (list of Layer) -> C array of oracle_layer_desc."""
+    import pyoracle as o
+    kinds = {"identity": GATE_IDENTITY, "cipher": GATE_CIPHER, "add": GATE_ADD}
+    arr = (LayerDesc * len(pycircuit))()
+    for i, lay in enumerate(pycircuit):
+        arr[i].gate = -1 if lay.gate is None else kinds[lay.gate.kind]
+        arr[i].n_in = len(lay.In)
+        for k, v in enumerate(lay.In):
+            arr[i].in_[k] = v
+        limbs = o.to_mont_limbs(getattr(lay.gate, "ark", 0)) if lay.gate is not None else [0, 0, 0, 0]
+        for k in range(4):
+            arr[i].ark[k] = limbs[k]
+    return arr
+
+
+def gkr_prove_circuit(descs, bN, inputs, qprime):
+    n_layers = len(descs)
+    flat = fr(lib.oracle_circuit_proof_len(C.cast(descs, C.c_void_p), n_layers, bN))
+    outs = fr(1 << bN)
+    secs = C.c_double(0.0)
+    ins = [np.ascontiguousarray(x) for x in inputs]
+    qprime = np.ascontiguousarray(qprime).reshape(-1, 4)
+    rc = lib.oracle_gkr_prove_circuit(C.cast(descs, C.c_void_p), n_layers, bN, _ptr_array(ins), len(ins),
+                                      _p(qprime) if bN else None, _p(flat), _p(outs), C.byref(secs))
+    if rc != 0:
+        raise RuntimeError("oracle_gkr_prove_circuit rc=%d" % rc)
+    return flat, outs, secs.value
+
+
+def gkr_verify_circuit(descs, bN, flat, inputs, outputs, qprime):
+    ins = [np.ascontiguousarray(x) for x in inputs]
+    qprime = np.ascontiguousarray(qprime).reshape(-1, 4)
+    return lib.oracle_gkr_verify_circuit(C.cast(descs, C.c_void_p), len(descs), bN, _p(np.ascontiguousarray(flat)),
+                                         _ptr_array(ins), len(ins), _p(np.ascontiguousarray(outputs)),
+                                         _p(qprime) if bN else None)

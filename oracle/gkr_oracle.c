@@ -334,11 +334,14 @@ static inline void gate_eval(int gate, const ofr_t *ark, ofr_t *res, const ofr_t
         fr_mul(res, res, &tmp);
         fr_mul(res, res, res);
         fr_mul(res, res, &tmp);
+    } else if (gate == ORACLE_GATE_ADD) { /* build-defined: xs[0] + xs[1] + Ark (GMiMC's linear branches, hash/gmimc.go:52-58) */
+        fr_add(res, xs[0], xs[1]);
+        fr_add(res, res, ark);
     } else { /* circuit/gates/copy.go:20-22 */
         *res = *xs[0];
     }
 }
-static int gate_degree(int gate) { return gate == ORACLE_GATE_CIPHER ? 7 : 1; } /* cipher.go:68-70, copy.go:30-32 */
+static int gate_degree(int gate) { return gate == ORACLE_GATE_CIPHER ? 7 : 1; } /* cipher.go:68-70, copy.go:30-32; add: linear */
 
 void oracle_gate_eval_batch(int gate, const ofr_t *ark, ofr_t *res, const ofr_t *const *xs, int arity, size_t n) {
     /* cipher.go:25-42 / copy.go:15-17 */
@@ -351,6 +354,11 @@ void oracle_gate_eval_batch(int gate, const ofr_t *ark, ofr_t *res, const ofr_t 
             fr_mul(&res[i], &res[i], &tmp);
             fr_mul(&res[i], &res[i], &res[i]);
             fr_mul(&res[i], &res[i], &tmp);
+        }
+    } else if (gate == ORACLE_GATE_ADD) {
+        for (size_t i = 0; i < n; i++) {
+            fr_add(&res[i], &xs[0][i], &xs[1][i]);
+            fr_add(&res[i], &res[i], ark);
         }
     } else {
         (void)arity;
@@ -596,40 +604,76 @@ void oracle_evaluation(ofr_t *out, int gate, const ofr_t *ark, const ofr_t *qpri
     *out = res;
 }
 
-/* ---- MimcCircuit (examples/mimc.go:10-37) + gkr ---------------------------------------------------- */
-#define N_LAYERS 94
+/* ---- circuits (circuit/circuit.go:11-44), MimcCircuit (examples/mimc.go:10-37), gkr ---------------------- */
 typedef struct {
     int n_in, in[2];
-    int n_out, out[91];
+    int n_out, *out;
     int gate; /* -1 = input layer */
     ofr_t ark;
 } layer_t;
 
-static void mimc_circuit(layer_t *c) {
-    memset(c, 0, sizeof(layer_t) * N_LAYERS);
-    c[0].gate = -1;
-    c[1].gate = -1;
-    c[2].gate = ORACLE_GATE_IDENTITY;
-    c[2].n_in = 1;
-    c[2].in[0] = 0;
+/* BuildCircuit (circuit/circuit.go:28-44) from a flat description; returns NULL on a malformed circuit */
+static layer_t *build_circuit(const oracle_layer_desc *d, int n) {
+    layer_t *c = (layer_t *)calloc((size_t)n, sizeof(layer_t));
+    for (int l = 0; l < n; l++) {
+        c[l].gate = d[l].gate;
+        c[l].n_in = d[l].gate < 0 ? 0 : d[l].n_in;
+        c[l].in[0] = d[l].in[0];
+        c[l].in[1] = d[l].in[1];
+        c[l].ark = d[l].ark;
+        c[l].out = (int *)calloc((size_t)n, sizeof(int));
+        for (int k = 0; k < c[l].n_in; k++)
+            if (c[l].in[k] < 0 || c[l].in[k] >= l) goto bad;
+    }
+    for (int l = 0; l < n; l++)
+        for (int k = 0; k < c[l].n_in; k++) {
+            layer_t *p = &c[c[l].in[k]];
+            p->out[p->n_out++] = l;
+        }
+    for (int l = 0; l < n; l++)
+        if (c[l].gate < 0 && c[l].n_out > 1) goto bad; /* :36-41 */
+    return c;
+bad:
+    for (int l = 0; l < n; l++) free(c[l].out);
+    free(c);
+    return NULL;
+}
+static void free_circuit(layer_t *c, int n) {
+    for (int l = 0; l < n; l++) free(c[l].out);
+    free(c);
+}
+
+#define MIMC_LAYERS 94
+static void mimc_descs(oracle_layer_desc *d) { /* examples/mimc.go:10-37 */
+    memset(d, 0, sizeof(oracle_layer_desc) * MIMC_LAYERS);
+    d[0].gate = -1;
+    d[1].gate = -1;
+    d[2].gate = ORACLE_GATE_IDENTITY;
+    d[2].n_in = 1;
+    d[2].in[0] = 0;
     for (int i = 0; i < 91; i++) {
-        layer_t *l = &c[i + 3];
+        oracle_layer_desc *l = &d[i + 3];
         l->gate = ORACLE_GATE_CIPHER;
         l->ark = ARKS[i];
         l->n_in = 2;
         l->in[0] = 2;
         l->in[1] = i == 0 ? 1 : i + 2;
     }
-    for (int l = 0; l < N_LAYERS; l++) /* BuildCircuit circuit/circuit.go:28-44 */
-        for (int k = 0; k < c[l].n_in; k++) {
-            layer_t *p = &c[c[l].in[k]];
-            p->out[p->n_out++] = l;
-        }
 }
 
-size_t oracle_mimc_proof_len(int bN) { /* hints.go:76-116 */
-    return (size_t)822 * bN + 183 + (size_t)184 * bN;
+size_t oracle_circuit_proof_len(const oracle_layer_desc *d, int n, int bN) { /* hints.go:76-116 */
+    layer_t *c = build_circuit(d, n);
+    if (!c) return 0;
+    size_t sc = 0, cl = 0, qp = 0;
+    for (int l = 0; l < n; l++) {
+        if (c[l].gate >= 0) sc += (size_t)bN * (gate_degree(c[l].gate) + 2);
+        cl += (size_t)c[l].n_out;
+        qp += (size_t)bN * c[l].n_out;
+    }
+    free_circuit(c, n);
+    return sc + cl + qp + bN;
 }
+size_t oracle_mimc_proof_len(int bN) { return (size_t)822 * bN + 183 + (size_t)184 * bN; }
 
 static double now_s(void) {
     struct timespec ts;
@@ -643,17 +687,16 @@ static int out_index(const layer_t *p, int layer) { /* sort.SearchInts on the so
     return -1;
 }
 
-int oracle_gkr_prove_mimc(int bN, const ofr_t *in0, const ofr_t *in1, const ofr_t *qprime, ofr_t *flat_out,
-                          ofr_t *outputs_out, double *prove_seconds) {
-    static layer_t c[N_LAYERS];
-    mimc_circuit(c);
+int oracle_gkr_prove_circuit(const oracle_layer_desc *desc, int NL, int bN, const ofr_t *const *inputs, int n_inputs,
+                             const ofr_t *qprime, ofr_t *flat_out, ofr_t *outputs_out, double *prove_seconds) {
+    layer_t *c = build_circuit(desc, NL);
+    if (!c) return -5;
     size_t n = (size_t)1 << bN;
     /* Assign: circuit/assignment.go:12-32 */
-    ofr_t **a = (ofr_t **)calloc(N_LAYERS, sizeof(ofr_t *));
-    for (int l = 0; l < N_LAYERS; l++) a[l] = (ofr_t *)malloc(n * sizeof(ofr_t));
-    memcpy(a[0], in0, n * sizeof(ofr_t));
-    memcpy(a[1], in1, n * sizeof(ofr_t));
-    for (int l = 2; l < N_LAYERS; l++) {
+    ofr_t **a = (ofr_t **)calloc((size_t)NL, sizeof(ofr_t *));
+    for (int l = 0; l < NL; l++) a[l] = (ofr_t *)malloc(n * sizeof(ofr_t));
+    for (int l = 0; l < n_inputs; l++) memcpy(a[l], inputs[l], n * sizeof(ofr_t));
+    for (int l = n_inputs; l < NL; l++) {
         const ofr_t *xs[2] = {a[c[l].in[0]], c[l].n_in > 1 ? a[c[l].in[1]] : NULL};
         size_t blk = 4096;
 #pragma omp parallel for schedule(static)
@@ -663,22 +706,21 @@ int oracle_gkr_prove_mimc(int bN, const ofr_t *in0, const ofr_t *in1, const ofr_
             oracle_gate_eval_batch(c[l].gate, &c[l].ark, a[l] + b, ys, c[l].n_in, e - b);
         }
     }
-    if (outputs_out) memcpy(outputs_out, a[N_LAYERS - 1], n * sizeof(ofr_t));
+    if (outputs_out) memcpy(outputs_out, a[NL - 1], n * sizeof(ofr_t));
 
     /* Prove: gkr/prover.go:21-91 */
     double t0 = now_s();
-    ofr_t *claims[N_LAYERS], *qprimes[N_LAYERS], *sc[N_LAYERS];
-    int has_claims[N_LAYERS];
-    for (int l = 0; l < N_LAYERS; l++) {
+    ofr_t **claims = (ofr_t **)calloc((size_t)NL, sizeof(ofr_t *)), **qprimes = (ofr_t **)calloc((size_t)NL, sizeof(ofr_t *)),
+          **sc = (ofr_t **)calloc((size_t)NL, sizeof(ofr_t *));
+    int *has_claims = (int *)calloc((size_t)NL, sizeof(int));
+    for (int l = 0; l < NL; l++) {
         int slots = c[l].n_out > 0 ? c[l].n_out : 1;
         claims[l] = (ofr_t *)calloc((size_t)slots, sizeof(ofr_t));
         qprimes[l] = (ofr_t *)calloc((size_t)slots * (bN > 0 ? bN : 1), sizeof(ofr_t));
-        sc[l] = NULL;
-        has_claims[l] = 0;
     }
-    memcpy(qprimes[N_LAYERS - 1], qprime, (size_t)bN * sizeof(ofr_t));
+    memcpy(qprimes[NL - 1], qprime, (size_t)bN * sizeof(ofr_t));
     int rc = 0;
-    for (int layer = N_LAYERS - 1; layer >= 0 && rc == 0; layer--) {
+    for (int layer = NL - 1; layer >= 0 && rc == 0; layer--) {
         if (c[layer].gate < 0) break;
         int arity = c[layer].n_in;
         ofr_t *X[2] = {NULL, NULL};
@@ -697,10 +739,10 @@ int oracle_gkr_prove_mimc(int bN, const ofr_t *in0, const ofr_t *in1, const ofr_
         sc[layer] = (ofr_t *)calloc((size_t)(bN > 0 ? bN : 1) * nc, sizeof(ofr_t));
         ofr_t *next_q = (ofr_t *)calloc((size_t)(bN > 0 ? bN : 1), sizeof(ofr_t));
         ofr_t final[3];
-        int nq = layer == N_LAYERS - 1 ? 1 : c[layer].n_out;
+        int nq = layer == NL - 1 ? 1 : c[layer].n_out;
         int ncl = has_claims[layer] ? c[layer].n_out : 0;
-        rc = oracle_sumcheck_prove(c[layer].gate, &c[layer].ark, arity, bN, X, qprimes[layer], nq, claims[layer],
-                                   ncl, sc[layer], next_q, final);
+        rc = oracle_sumcheck_prove(c[layer].gate, &c[layer].ark, arity, bN, X, qprimes[layer], nq, claims[layer], ncl,
+                                   sc[layer], next_q, final);
         for (int i = 1; i <= arity && rc == 0; i++) { /* updateWithSumcheck :66-90 */
             int inp = c[layer].in[i - 1];
             int w = out_index(&c[inp], layer);
@@ -718,66 +760,81 @@ int oracle_gkr_prove_mimc(int bN, const ofr_t *in0, const ofr_t *in1, const ofr_
     /* GkrProofToVec order: hints.go:236-271 */
     size_t cur = 0;
     if (rc == 0) {
-        for (int l = 0; l < N_LAYERS; l++)
+        for (int l = 0; l < NL; l++)
             if (sc[l]) {
                 size_t cnt = (size_t)bN * (gate_degree(c[l].gate) + 2);
                 memcpy(flat_out + cur, sc[l], cnt * sizeof(ofr_t));
                 cur += cnt;
             }
-        for (int l = 0; l < N_LAYERS; l++) {
+        for (int l = 0; l < NL; l++) {
             memcpy(flat_out + cur, claims[l], (size_t)c[l].n_out * sizeof(ofr_t));
             cur += (size_t)c[l].n_out;
         }
-        for (int l = 0; l < N_LAYERS; l++) {
-            size_t slots = l == N_LAYERS - 1 ? 1 : (size_t)c[l].n_out;
+        for (int l = 0; l < NL; l++) {
+            size_t slots = l == NL - 1 ? 1 : (size_t)c[l].n_out;
             memcpy(flat_out + cur, qprimes[l], slots * bN * sizeof(ofr_t));
             cur += slots * bN;
         }
-        if (cur != oracle_mimc_proof_len(bN)) rc = -4;
+        if (cur != oracle_circuit_proof_len(desc, NL, bN)) rc = -4;
     }
-    for (int l = 0; l < N_LAYERS; l++) {
+    for (int l = 0; l < NL; l++) {
         free(a[l]);
         free(claims[l]);
         free(qprimes[l]);
         free(sc[l]);
     }
     free(a);
+    free(claims);
+    free(qprimes);
+    free(sc);
+    free(has_claims);
+    free_circuit(c, NL);
     return rc;
 }
 
-int oracle_gkr_verify_mimc(int bN, const ofr_t *flat, const ofr_t *in0, const ofr_t *in1, const ofr_t *outputs,
-                           const ofr_t *qprime) { /* gkr/verifier.go:15-132 */
-    static layer_t c[N_LAYERS];
-    mimc_circuit(c);
+int oracle_gkr_prove_mimc(int bN, const ofr_t *in0, const ofr_t *in1, const ofr_t *qprime, ofr_t *flat_out,
+                          ofr_t *outputs_out, double *prove_seconds) {
+    oracle_layer_desc d[MIMC_LAYERS];
+    mimc_descs(d);
+    const ofr_t *ins[2] = {in0, in1};
+    return oracle_gkr_prove_circuit(d, MIMC_LAYERS, bN, ins, 2, qprime, flat_out, outputs_out, prove_seconds);
+}
+
+int oracle_gkr_verify_circuit(const oracle_layer_desc *desc, int NL, int bN, const ofr_t *flat, const ofr_t *const *inputs,
+                              int n_inputs, const ofr_t *outputs, const ofr_t *qprime) { /* gkr/verifier.go:15-132 */
+    layer_t *c = build_circuit(desc, NL);
+    if (!c) return -5;
     size_t n = (size_t)1 << bN;
     /* locate the three sections of the flat proof */
-    const ofr_t *sc[N_LAYERS], *claims[N_LAYERS], *qps[N_LAYERS];
+    const ofr_t **sc = (const ofr_t **)calloc((size_t)NL, sizeof(ofr_t *)), **claims = (const ofr_t **)calloc((size_t)NL, sizeof(ofr_t *)),
+                **qps = (const ofr_t **)calloc((size_t)NL, sizeof(ofr_t *));
     size_t cur = 0;
-    for (int l = 0; l < N_LAYERS; l++) {
-        sc[l] = NULL;
+    int max_out = 1;
+    for (int l = 0; l < NL; l++) {
+        if (c[l].n_out > max_out) max_out = c[l].n_out;
         if (c[l].gate >= 0) {
             sc[l] = flat + cur;
             cur += (size_t)bN * (gate_degree(c[l].gate) + 2);
         }
     }
-    for (int l = 0; l < N_LAYERS; l++) {
+    for (int l = 0; l < NL; l++) {
         claims[l] = flat + cur;
         cur += (size_t)c[l].n_out;
     }
-    for (int l = 0; l < N_LAYERS; l++) {
+    for (int l = 0; l < NL; l++) {
         qps[l] = flat + cur;
-        cur += (l == N_LAYERS - 1 ? 1 : (size_t)c[l].n_out) * bN;
+        cur += (l == NL - 1 ? 1 : (size_t)c[l].n_out) * bN;
     }
-    if (memcmp(qprime, qps[N_LAYERS - 1], (size_t)bN * sizeof(ofr_t)) != 0) return -10; /* :25-30 */
-    ofr_t top_claim;
-    oracle_evaluate(&top_claim, outputs, n, qprime, bN); /* :36 */
-
-    ofr_t *next_q = (ofr_t *)calloc((size_t)(bN > 0 ? bN : 1), sizeof(ofr_t));
     int rc = 0;
-    for (int layer = N_LAYERS - 1; layer >= 0 && rc == 0; layer--) {
+    ofr_t *next_q = (ofr_t *)calloc((size_t)(bN > 0 ? bN : 1), sizeof(ofr_t));
+    ofr_t *tmp_evals = (ofr_t *)calloc((size_t)max_out, sizeof(ofr_t));
+    ofr_t top_claim;
+    if (memcmp(qprime, qps[NL - 1], (size_t)bN * sizeof(ofr_t)) != 0) { rc = -10; goto done; } /* :25-30 */
+    oracle_evaluate(&top_claim, outputs, n, qprime, bN); /* :36 */
+    for (int layer = NL - 1; layer >= 0 && rc == 0; layer--) {
         if (c[layer].gate < 0) break;
-        const ofr_t *cl = layer == N_LAYERS - 1 ? &top_claim : claims[layer];
-        int ncl = layer == N_LAYERS - 1 ? 1 : c[layer].n_out;
+        const ofr_t *cl = layer == NL - 1 ? &top_claim : claims[layer];
+        int ncl = layer == NL - 1 ? 1 : c[layer].n_out;
         int nc = gate_degree(c[layer].gate) + 2;
         ofr_t next_claim, recomb;
         if (oracle_sumcheck_verify(cl, ncl, sc[layer], bN, nc, next_q, &next_claim, &recomb) != 0) {
@@ -792,20 +849,32 @@ int oracle_gkr_verify_mimc(int bN, const ofr_t *flat, const ofr_t *in0, const of
             sub[k] = &claims[inp][r_at];
         }
         if (rc) break;
-        ofr_t expected, eq_eval, tmp_evals[91];
+        ofr_t expected, eq_eval;
         gate_eval(c[layer].gate, &c[layer].ark, &expected, sub);
         for (int i = 0; i < ncl; i++) oracle_eval_eq(&tmp_evals[i], qps[layer] + (size_t)i * bN, next_q, bN);
         oracle_eval_univariate(&eq_eval, tmp_evals, ncl, &recomb);
         fr_mul(&expected, &expected, &eq_eval);
         if (!fr_eq(&expected, &next_claim)) rc = -22 - layer * 10;
     }
-    free(next_q);
-    if (rc) return rc;
-    const ofr_t *ins[2] = {in0, in1};
-    for (int l = 0; l < 2; l++) { /* testInitialRound :120-132 */
+    for (int l = 0; l < n_inputs && rc == 0; l++) { /* testInitialRound :120-132 */
         ofr_t actual;
-        oracle_evaluate(&actual, ins[l], n, qps[l], bN);
-        if (!fr_eq(&actual, &claims[l][0])) return -30 - l;
+        oracle_evaluate(&actual, inputs[l], n, qps[l], bN);
+        if (!fr_eq(&actual, &claims[l][0])) rc = -30 - l;
     }
-    return 0;
+done:
+    free(next_q);
+    free(tmp_evals);
+    free(sc);
+    free(claims);
+    free(qps);
+    free_circuit(c, NL);
+    return rc;
+}
+
+int oracle_gkr_verify_mimc(int bN, const ofr_t *flat, const ofr_t *in0, const ofr_t *in1, const ofr_t *outputs,
+                           const ofr_t *qprime) {
+    oracle_layer_desc d[MIMC_LAYERS];
+    mimc_descs(d);
+    const ofr_t *ins[2] = {in0, in1};
+    return oracle_gkr_verify_circuit(d, MIMC_LAYERS, bN, flat, ins, 2, outputs, qprime);
 }

@@ -29,7 +29,13 @@ extern "C" {
 
 typedef struct { uint64_t l[4]; } ofr_t; /* Montgomery limbs, little-endian */
 
-enum { ORACLE_GATE_IDENTITY = 0, ORACLE_GATE_CIPHER = 1 };
+enum { ORACLE_GATE_IDENTITY = 0, ORACLE_GATE_CIPHER = 1, ORACLE_GATE_ADD = 2 /* build-defined: xs[0]+xs[1]+Ark */ };
+
+/* one layer of a circuit (circuit/circuit.go:11-23): gate = -1 for input layers (which come first) */
+typedef struct {
+    int gate, n_in, in[2];
+    ofr_t ark;
+} oracle_layer_desc;
 
 /* fr helpers */
 void oracle_fr_from_u64(ofr_t *out, uint64_t v);                 /* fr.Element.SetUint64 */
@@ -77,7 +83,7 @@ void oracle_evaluation(ofr_t *out, int gate, const ofr_t *ark, const ofr_t *qpri
                        const ofr_t *claims, int nclaims, const ofr_t *const *X, int arity);
 
 /* examples/mimc.go + circuit/assignment.go + gkr/prover.go.
- * size of the flat proof (prover/gadget/hints.go:76-116) for MimcCircuit: 822*bN + 183 + 185*bN. */
+ * size of the flat proof (prover/gadget/hints.go:76-116) for MimcCircuit: 822*bN + 183 + 184*bN. */
 size_t oracle_mimc_proof_len(int bN);
 /* Assign + Prove on inputs in0,in1 (2^bN each, untouched).  flat_out: oracle_mimc_proof_len(bN)
  * elements in GkrProofToVec order (hints.go:236-271) but kept as Montgomery limbs.
@@ -88,6 +94,13 @@ int oracle_gkr_prove_mimc(int bN, const ofr_t *in0, const ofr_t *in1, const ofr_
 /* gkr/verifier.go:15-132 on a flat proof. Returns 0 if accepted, else a negative code. */
 int oracle_gkr_verify_mimc(int bN, const ofr_t *flat, const ofr_t *in0, const ofr_t *in1,
                            const ofr_t *outputs, const ofr_t *qprime);
+
+/* the same for any layered circuit over the gates above (inputs: the n_inputs leading input layers) */
+size_t oracle_circuit_proof_len(const oracle_layer_desc *layers, int n_layers, int bN);
+int oracle_gkr_prove_circuit(const oracle_layer_desc *layers, int n_layers, int bN, const ofr_t *const *inputs,
+                             int n_inputs, const ofr_t *qprime, ofr_t *flat_out, ofr_t *outputs_out, double *prove_seconds);
+int oracle_gkr_verify_circuit(const oracle_layer_desc *layers, int n_layers, int bN, const ofr_t *flat,
+                              const ofr_t *const *inputs, int n_inputs, const ofr_t *outputs, const ofr_t *qprime);
 
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);

@@ -445,6 +445,26 @@ def test_gmimc_circuit_vs_oracle(gk, bn):
     s.close()
 
 
+@pytest.mark.parametrize("bn", [8, 12, 14])
+def test_gmimc_circuit_vs_c_oracle(gk, bn):
+    """Full-transcript equality with the C oracle's generic-circuit prover at sizes Python cannot reach."""
+    n = 1 << bn
+    circ = o.gmimc_t2_circuit()
+    descs = c.circuit_descs(circ)
+    ins = [c.random_fr_array(n), nasty(n, bn + 1), c.from_ints([int(v) for v in np.random.default_rng(bn).integers(0, 1 << 62, n)]),
+           nasty(n, bn + 2)]
+    qp = c.random_fr_array(bn)
+    want, wouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+    s = gk.MimcSession(bn, layers=gk.gmimc_t2_circuit())
+    for k in range(4):
+        s.load_input(k, ins[k])
+    s.assign()
+    flat = s.prove(qp)
+    assert np.array_equal(flat, want) and np.array_equal(s.outputs(), wouts)
+    assert c.gkr_verify_circuit(descs, bn, flat, ins, wouts, qp) == 0
+    s.close()
+
+
 def test_gmimc_circuit_larger_sizes(gk):
     """bN = 10: outputs equal the reference hasher on every instance; bN = 14 and 22 (BASELINE config 5): the
     native gkr.Verify accepts the proof against the resident tables and rejects a corrupted one."""

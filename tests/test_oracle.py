@@ -197,3 +197,26 @@ def test_mimc_circuit_is_mimc():
     circ = o.mimc_circuit()
     for lay in circ:  # TestCircuitForm :44-53
         assert lay.Out == sorted(lay.Out)
+
+
+@pytest.mark.parametrize("bn", [0, 1, 3, 5])
+def test_gmimc_circuit_c_oracle_vs_python_oracle(bn):
+    """BASELINE config 5: the build-defined GMiMC (t = 2) circuit.  The C oracle's generic-circuit prover agrees
+    with the Python oracle, its verifier accepts, and the outputs are hash.GMimcHasher's compression."""
+    n = 1 << bn
+    circ = o.gmimc_t2_circuit()
+    ins = [o.random_fr_array(n), [(3 * i * i + 7) % o.Q for i in range(n)], [(i * i * i * 5 + 1) % o.Q for i in range(n)],
+           [o.mimc_hash([i]) for i in range(n)]]
+    a = o.assign(circ, *ins)
+    qp = o.random_fr_array(bn)
+    want = o.gkr_proof_to_vec(o.gkr_prove(circ, a, qp))
+    descs = c.circuit_descs(circ)
+    cins = [c.from_ints(x) for x in ins]
+    flat, outs, _ = c.gkr_prove_circuit(descs, bn, cins, c.from_ints(qp))
+    assert c.to_ints(flat) == want
+    assert c.to_ints(outs) == [o.gmimc_update([ins[0][k], ins[1][k]], [ins[2][k], ins[3][k]])[0] for k in range(n)]
+    assert c.gkr_verify_circuit(descs, bn, flat, cins, outs, c.from_ints(qp)) == 0
+    if bn:
+        bad = flat.copy()
+        bad[3, 0] ^= np.uint64(1)
+        assert c.gkr_verify_circuit(descs, bn, bad, cins, outs, c.from_ints(qp)) != 0
