@@ -93,7 +93,6 @@ def main():
     gamma = (world.bit_length() - 1) if dist is not None else 0
     # weak scaling: every GPU holds a 2^bn shard, the job proves 2^(bn + log2 N) hashes in ONE proof
     bn = args.bn + gamma
-    # RandomFrArray(bN) as qPrime (gkr/gkr_test.go:93-95): element i = (i*i) ^ 0xf45c9df123f, Montgomery form.
     import threading
     sessions = []
     layers = gk.gmimc_t2_circuit() if args.circuit == "gmimc" else None
@@ -102,7 +101,7 @@ def main():
         s.synth_inputs()        # block = initstate = RandomFrArray(2^bN), generated in HBM
         s.assign()              # Circuit.Assign: outside the timer, as BenchmarkGkr
         sessions.append(s)
-    qprime = random_fr_array_np(bn)
+    qprime = random_fr_array_np(bn)   # qPrime = RandomFrArray(bN), as gkr/gkr_test.go:93-95
     last = [None] * nconc
 
     def run_steps(total):
@@ -210,10 +209,11 @@ def main():
         ms3 = gk.bench_fold(1 << args.bn, ntab=3, warmup=2, iters=10)
         out["fold_alone"] = {"tables": 3, "elements_per_table": 1 << args.bn, "ms": ms3,
                              "GB_per_s": 96.0 * 3 * (1 << (args.bn - 1)) / (ms3 * 1e-3) / 1e9,
-                             "note": "k_fold with no other kernel running; roofline.achieved is measured inside the "
-                                     "timed region, where the other lanes' kernels share the GPU"}
+                             "note": "device-resident micro-benchmark of the same kernel (gkrhip_bench_fold): three "
+                                     "tables, no other kernel running"}
     if prof["peval_launches"]:
-        out["partial_eval"] = {"kernel": "k_partial_eval (round 0)", "launches": prof["peval_launches"],
+        out["partial_eval"] = {"kernel": "k_cipher_round / k_partial_eval launches on full-size tables (round 0 of a layer)",
+                               "launches": prof["peval_launches"],
                                "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
                                "modmul_per_s": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
                                "bound": "integer VALU (no MFMA: modular arithmetic)"}
