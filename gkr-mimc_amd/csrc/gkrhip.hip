@@ -97,7 +97,7 @@ struct Ctx {
     unsigned int* d_flag = nullptr;
     unsigned int* d_counter = nullptr;         // block arrival counter
     unsigned int seq = 0;
-    int g_max = 17;                            // log2(max threads of the round kernel)
+    int g_max = 16;                            // log2(max threads of the round kernel): 16 measured best with 4 proofs in flight (17 for one proof alone)
     bool force_generic = false;
     bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
