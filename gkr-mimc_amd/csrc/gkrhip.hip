@@ -1651,7 +1651,10 @@ void gkrhip_mimc_session_destroy(gkrhip_session* s) {
             std::lock_guard<std::mutex> lk(s->lane->mu);
             UseLane ul(s->lane);
             (void)hipStreamSynchronize(g.stream);
-            for (auto& t : s->a) table_free(&t);
+            // back to the arena, not to the driver: the next session of the same size (one-shot calls from the
+            // hint, one per proof) reuses the buffers instead of paying ~1 s of hipMalloc/hipFree for 50 GB;
+            // table_alloc drops the cache when an allocation fails
+            for (auto& t : s->a) table_release(&t);
         }
         bool owned = s->lane != &g0;
         for (Ctx* l : gc.lanes) owned = owned && l != s->lane;   // communicator lanes outlive their sessions
