@@ -91,6 +91,43 @@ __device__ __forceinline__ void acc_add_raw(Acc9& a, const Fr& x) {
         : "vcc");
 }
 
+// last-arriving block sums the block partials and publishes them to the host (agent-scope release by lane 0
+// after the block's stores have drained; acquire before re-reading)
+__device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, unsigned long long (*red)[GKR_CR_WORDS] /* [3] */,
+                                                     unsigned int* s_last) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = atomicAdd(a.counter, 1u);
+        const unsigned int last = (prev == gridDim.x - 1) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last) {
+        if (threadIdx.x < 3 * GKR_CR_WORDS) {   // three strided passes over the blocks, combined through LDS
+            const unsigned int w = threadIdx.x % GKR_CR_WORDS, part = threadIdx.x / GKR_CR_WORDS;
+            unsigned long long s = 0;
+            for (unsigned int b = part; b < gridDim.x; b += 3) s += a.partials[(size_t)b * GKR_CR_WORDS + w];
+            red[part][w] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < GKR_CR_WORDS) a.host_out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *a.counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // LAT = latency variant for the small rounds (at most one wave per SIMD is resident, so nothing hides the
 // ~10-cycle dependent-issue latency of a single multiplication chain): no scheduling barriers, so hipcc
 // interleaves the independent products of the monomial schedule, and a 512-VGPR budget.
@@ -217,40 +254,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
 
     // ---- block reduction of the limb words (exact integer sums), one partial per block
     block_reduce_acc<GKR_CR_NSUM, 18>(acc, a.partials + (size_t)blockIdx.x * GKR_CR_WORDS);
-
-    // ---- last-arriving block sums the block partials and publishes to the host
-    // (agent-scope release by lane 0 after the block's stores have drained; acquire before re-reading)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int prev = atomicAdd(a.counter, 1u);
-        const unsigned int last = (prev == gridDim.x - 1) ? 1u : 0u;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (s_last) {
-        if (threadIdx.x < 3 * GKR_CR_WORDS) {   // three strided passes over the blocks, combined through LDS
-            const unsigned int w = threadIdx.x % GKR_CR_WORDS, part = threadIdx.x / GKR_CR_WORDS;
-            unsigned long long s = 0;
-            for (unsigned int b = part; b < gridDim.x; b += 3) s += a.partials[(size_t)b * GKR_CR_WORDS + w];
-            red[part][w] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < GKR_CR_WORDS) a.host_out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x];
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            *a.counter = 0;
-            __threadfence_system();
-            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    cipher_round_publish(a, red, &s_last);
 }
 
 template <bool FOLD, bool HAS_WJ>
@@ -260,4 +264,154 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a
 template <bool FOLD, bool HAS_WJ>
 __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(CipherRoundArgs a) {
     cipher_round_body<FOLD, HAS_WJ, true>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deferred-reduction variant for the large rounds (several pairs per lane, M_0 derived from the claim).
+// The seven products W u^(7-j) d^j that only feed the sums M_1..M_7 are accumulated as plain 512-bit
+// integers (fr_mac_wide: 79 limb products instead of the 136 of a Montgomery product) into 17-limb
+// accumulators, and each lane reduces its seven sums once, after the loop (fr_redc_wide).  Four wide
+// accumulators live in VGPRs; three live in LDS (17 words per lane, read and written back around their
+// MAC), which keeps the kernel inside the 256-VGPR budget of two waves per SIMD.  The LDS region is
+// reused by the block reduction afterwards.
+// ------------------------------------------------------------------------------------------------
+#define GKR_WIDE_LDS 3
+struct WideShared {
+    union {
+        struct {
+            uint4 q[GKR_WIDE_LDS][4][GKR_BLOCK];
+            u32 w[GKR_WIDE_LDS][GKR_BLOCK];
+        } acc;
+        u32 tr[18][GKR_BLOCK + 1];
+    };
+    unsigned long long red[GKR_BLOCK / 64][GKR_CR_WORDS];
+};
+
+__device__ __forceinline__ void wide_lds_load(u32 (&T)[FR_WIDE_LIMBS], const WideShared& sh, int slot) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint4 x = sh.acc.q[slot][c][threadIdx.x];
+        T[4 * c] = x.x; T[4 * c + 1] = x.y; T[4 * c + 2] = x.z; T[4 * c + 3] = x.w;
+    }
+    T[16] = sh.acc.w[slot][threadIdx.x];
+}
+__device__ __forceinline__ void wide_lds_store(WideShared& sh, int slot, const u32 (&T)[FR_WIDE_LIMBS]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) sh.acc.q[slot][c][threadIdx.x] = make_uint4(T[4 * c], T[4 * c + 1], T[4 * c + 2], T[4 * c + 3]);
+    sh.acc.w[slot][threadIdx.x] = T[16];
+}
+
+// WT_LATE (rounds with many pairs per lane): the per-lane weight Wt is the same for every pair of a lane, so
+// it multiplies the lane's seven reduced sums once after the loop instead of every pair's weight inside it.
+template <bool FOLD, bool WT_LATE>
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
+    __shared__ WideShared sh;
+    __shared__ unsigned int s_last;
+    u32 R[GKR_CR_NSUM - 1 - GKR_WIDE_LDS][FR_WIDE_LIMBS];     // M_4 .. M_7
+#pragma unroll
+    for (int t = 0; t < GKR_CR_NSUM - 1 - GKR_WIDE_LDS; t++)
+#pragma unroll
+        for (int j = 0; j < FR_WIDE_LIMBS; j++) R[t][j] = 0;
+    {
+        u32 Z[FR_WIDE_LIMBS];
+#pragma unroll
+        for (int j = 0; j < FR_WIDE_LIMBS; j++) Z[j] = 0;
+#pragma unroll
+        for (int s = 0; s < GKR_WIDE_LDS; s++) wide_lds_store(sh, s, Z);   // each lane touches only its own column
+    }
+
+    const size_t P = a.P;
+    const size_t threads = (size_t)1 << a.lg_threads;
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid < threads) {
+        const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
+        const Fr ark = a.ark;
+        const size_t iters = P >> a.lg_threads;
+        for (size_t j = 0; j < iters; j++) {
+            const size_t x = j * threads + gtid;
+            Fr klo, khi, slo, shi;
+            if (FOLD) {
+                const Fr r = a.r;
+                const Fr k0 = ld_fr(a.k_src.lo, a.k_src.hi, x), k2 = ld_fr(a.k_src.lo, a.k_src.hi, x + 2 * P);
+                const Fr k1 = ld_fr(a.k_src.lo, a.k_src.hi, x + P), k3 = ld_fr(a.k_src.lo, a.k_src.hi, x + 3 * P);
+                const Fr s0 = ld_fr(a.s_src.lo, a.s_src.hi, x), s2 = ld_fr(a.s_src.lo, a.s_src.hi, x + 2 * P);
+                const Fr s1 = ld_fr(a.s_src.lo, a.s_src.hi, x + P), s3 = ld_fr(a.s_src.lo, a.s_src.hi, x + 3 * P);
+                klo = fr_add(k0, fr_mul(fr_sub(k2, k0), r));   // poly/multilin.go:32-34
+                khi = fr_add(k1, fr_mul(fr_sub(k3, k1), r));
+                slo = fr_add(s0, fr_mul(fr_sub(s2, s0), r));
+                shi = fr_add(s1, fr_mul(fr_sub(s3, s1), r));
+                st_fr(a.k_dst.lo, a.k_dst.hi, x, klo);
+                st_fr(a.k_dst.lo, a.k_dst.hi, x + P, khi);
+                st_fr(a.s_dst.lo, a.s_dst.hi, x, slo);
+                st_fr(a.s_dst.lo, a.s_dst.hi, x + P, shi);
+            } else {
+                klo = ld_fr(a.k_src.lo, a.k_src.hi, x);
+                khi = ld_fr(a.k_src.lo, a.k_src.hi, x + P);
+                slo = ld_fr(a.s_src.lo, a.s_src.hi, x);
+                shi = ld_fr(a.s_src.lo, a.s_src.hi, x + P);
+            }
+            const Fr u = fr_add(fr_add(klo, slo), ark);
+            const Fr d = fr_add(fr_sub(khi, klo), fr_sub(shi, slo));
+            Fr W = ld_fr(a.wj.lo, a.wj.hi, j);
+            if (!WT_LATE) W = fr_mont_mul_raw(W, wt);
+#define GKR_SB() __builtin_amdgcn_sched_barrier(0)
+            Fr p, r2, A, B, C, D, v, w, t, D2;
+            u32 T[FR_WIDE_LIMBS];
+            p = fr_mont_mul_raw(u, u);  GKR_SB();
+            r2 = fr_mont_mul_raw(d, d); GKR_SB();
+            A = fr_mont_mul_raw(p, u);  GKR_SB();   // u^3
+            B = fr_mont_mul_raw(p, d);  GKR_SB();   // u^2 d
+            C = fr_mont_mul_raw(u, r2); GKR_SB();   // u d^2
+            D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
+            v = fr_mont_mul_raw(W, u);  GKR_SB();
+            w = fr_mont_mul_raw(W, d);  GKR_SB();
+            // the LDS-resident sums are fetched before the product that precedes their MAC
+            wide_lds_load(T, sh, 0); t = fr_mont_mul_raw(A, B); GKR_SB(); fr_mac_wide(T, v, t); GKR_SB(); wide_lds_store(sh, 0, T); GKR_SB();  // W u^6 d
+            wide_lds_load(T, sh, 1); t = fr_mont_mul_raw(B, B); GKR_SB(); fr_mac_wide(T, v, t); GKR_SB(); wide_lds_store(sh, 1, T); GKR_SB();  // W u^5 d^2
+            wide_lds_load(T, sh, 2); t = fr_mont_mul_raw(A, D); GKR_SB(); fr_mac_wide(T, v, t); GKR_SB(); wide_lds_store(sh, 2, T); GKR_SB();  // W u^4 d^3
+            t = fr_mont_mul_raw(C, C); GKR_SB(); fr_mac_wide(R[0], v, t); GKR_SB();   // W u^3 d^4
+            t = fr_mont_mul_raw(C, D); GKR_SB(); fr_mac_wide(R[1], v, t); GKR_SB();   // W u^2 d^5
+            D2 = fr_mont_mul_raw(D, D); GKR_SB();                                     // d^6
+            fr_mac_wide(R[2], v, D2); GKR_SB();                                       // W u d^6
+            fr_mac_wide(R[3], w, D2); GKR_SB();                                       // W d^7
+#undef GKR_SB
+        }
+    }
+
+    // ---- one Montgomery reduction per sum and lane, then the usual exact block reduction
+    Acc9 acc[GKR_CR_NSUM];
+#pragma unroll
+    for (int j = 0; j < GKR_ACC_WORDS; j++) acc[0].w[j] = 0;      // M_0: derived by the host from the claim
+    // s = lo + top*2^256 (9 limbs) times Wt, as a Montgomery product: s*Wt/2^256 = mont(lo, Wt) + top*Wt
+    Fr wtl = fr_zero();
+    if (WT_LATE && gtid < threads) wtl = ld_fr(a.wt.lo, a.wt.hi, gtid);
+    auto finish = [&](Acc9& dst, const u32 (&T)[FR_WIDE_LIMBS]) {
+        fr_redc_wide(dst.w, T);
+        if (WT_LATE) {
+            Fr lo;
+#pragma unroll
+            for (int j = 0; j < 8; j++) lo.v[j] = dst.w[j];
+            const u32 top = dst.w[8];
+            const Fr m = fr_mont_mul_raw(lo, wtl);                  // < 2q
+            u64 c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c += (u64)top * wtl.v[j] + m.v[j];
+                dst.w[j] = (u32)c;
+                c >>= 32;
+            }
+            dst.w[8] = (u32)c;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < GKR_WIDE_LDS; s++) {
+        u32 T[FR_WIDE_LIMBS];
+        wide_lds_load(T, sh, s);
+        finish(acc[1 + s], T);
+    }
+#pragma unroll
+    for (int t = 0; t < GKR_CR_NSUM - 1 - GKR_WIDE_LDS; t++) finish(acc[1 + GKR_WIDE_LDS + t], R[t]);
+    __syncthreads();                                                // tr aliases the LDS accumulators
+    block_reduce_acc_buf<GKR_CR_NSUM, 18>(acc, a.partials + (size_t)blockIdx.x * GKR_CR_WORDS, sh.tr, sh.red);
+    cipher_round_publish(a, sh.red, &s_last);
 }

@@ -140,6 +140,41 @@ FR_HD void fr_mont_mul2_raw(Fr& r0, Fr& r1, const Fr& a0, const Fr& b0, const Fr
 #endif
 }
 
+// ---- deferred reduction for products that only feed a sum -----------------------------------------
+// A (17 limbs, un-reduced, < 2^542) += a*b as a plain integer product (fr_mac_wide_gen.inc); the sum of
+// many such products is reduced ONCE by fr_redc_wide instead of once per product.
+#define FR_WIDE_LIMBS 17
+FR_HD void fr_mac_wide(u32 (&A)[FR_WIDE_LIMBS], const Fr& a, const Fr& b) {
+#include "fr_mac_wide_gen.inc"
+}
+// Montgomery reduction of the wide sum: out (9 limbs, un-reduced) == A / 2^256 (mod q), out < A/2^256 + q.
+// With A < 2^542 the result fits the 9-limb accumulators the block reduction sums exactly.
+FR_HD void fr_redc_wide(u32 (&out)[9], const u32 (&A)[FR_WIDE_LIMBS]) {
+    const u32 q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
+    u32 T[FR_WIDE_LIMBS];
+#pragma unroll
+    for (int j = 0; j < FR_WIDE_LIMBS; j++) T[j] = A[j];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 m = T[i] * FR_QINV32;
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)m * q[j] + T[i + j];      // < 2^64: (2^32-1)^2 + 2*(2^32-1)
+            T[i + j] = (u32)c;
+            c >>= 32;
+        }
+#pragma unroll
+        for (int j = i + 8; j < FR_WIDE_LIMBS; j++) {
+            c += T[j];
+            T[j] = (u32)c;
+            c >>= 32;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) out[j] = T[8 + j];
+}
+
 // canonical product
 FR_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_reduce_once(fr_mont_mul_raw(a, b)); }
 FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_mul_raw(a, a)); }

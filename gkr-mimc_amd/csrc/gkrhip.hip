@@ -101,6 +101,8 @@ struct Ctx {
     bool force_generic = false;
     bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
+    int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
+    int wt_late_lj = 4;                        // ... and from 2^4 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
     Profile prof;
@@ -172,6 +174,8 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_GMAX")) g.g_max = std::max(8, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_GENERIC")) g.force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) g.lat_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_WIDE")) g.wide_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_WT_LATE_LJ")) g.wt_late_lj = atoi(e);
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) g.claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) g.fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) g.force_collective = atoi(e) != 0;
@@ -232,6 +236,8 @@ Ctx* lane_create() {
     l->g_max = g0.g_max;
     l->force_generic = g0.force_generic;
     l->lat_mode = g0.lat_mode;
+    l->wide_mode = g0.wide_mode;
+    l->wt_late_lj = g0.wt_late_lj;
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->lag = g0.lag;
@@ -766,7 +772,17 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_l0 = now_ms();
         // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
         const bool lat = g.lat_mode == 2 || (g.lat_mode == 1 && lj == 0);
-        if (fold) {
+        const bool wide = g.wide_mode && lj > 0 && derive_m0 && !lat;
+        const bool late = wide && lj >= g.wt_late_lj;  // the lane weight multiplies the sums after the loop: 8 products per lane
+        if (wide) {
+            if (fold) {
+                if (late) hipLaunchKernelGGL((k_cipher_round_wide<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+                else hipLaunchKernelGGL((k_cipher_round_wide<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+            } else {
+                if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+                else hipLaunchKernelGGL((k_cipher_round_wide<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, g.stream, a);
+            }
+        } else if (fold) {
             if (lj > 0) launch_cipher_round<true, true>(a, grid, lat);
             else launch_cipher_round<true, false>(a, grid, lat);
         } else {
@@ -778,7 +794,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             HIPCHK(hipEventRecord(e1, g.stream));
             g.prof.peval_ev.emplace_back(e0, e1);
             g.prof.peval_launches++;
-            g.prof.peval_modmuls += ((derive_m0 ? 21.0 : 23.0) + (lj > 0 ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
+            g.prof.peval_modmuls += ((derive_m0 ? 21.0 : 23.0) + (lj > 0 && !late ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
         const double t_l1 = now_ms();
         const unsigned long long* words = g.h_round;
@@ -1385,6 +1401,8 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "fold_split")) l->fold_split = value != 0;
         else if (!strcmp(key, "g_max")) l->g_max = (int)std::max(8L, std::min(20L, value));
         else if (!strcmp(key, "lat_mode")) l->lat_mode = (int)value;
+        else if (!strcmp(key, "wide_mode")) l->wide_mode = (int)value;
+        else if (!strcmp(key, "wt_late_lj")) l->wt_late_lj = (int)value;
         else if (!strcmp(key, "claim_trick")) l->claim_trick = value != 0;
         else return fail("unknown option %s", key);
     }

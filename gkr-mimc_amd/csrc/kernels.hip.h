@@ -224,11 +224,11 @@ __device__ __forceinline__ void acc_add(Acc9& a, const Fr& x) {
 // for one word.  (A cross-lane butterfly needs 6 dependent ds_bpermute round trips per word; hipcc
 // serialises them, ~20 us per launch for 72 words -- more than the arithmetic of a small round.)
 template <int NS, int CH>
-__device__ __forceinline__ void block_reduce_acc(const Acc9 (&acc)[NS], unsigned long long* __restrict__ out) {
+__device__ __forceinline__ void block_reduce_acc_buf(const Acc9 (&acc)[NS], unsigned long long* __restrict__ out,
+                                                     u32 (*tr)[GKR_BLOCK + 1] /* [CH] */,
+                                                     unsigned long long (*red)[NS * GKR_ACC_WORDS] /* [GKR_BLOCK/64] */) {
     constexpr int NW = NS * GKR_ACC_WORDS;
     static_assert(NW % CH == 0 && CH * 4 <= GKR_BLOCK, "chunking");
-    __shared__ u32 tr[CH][GKR_BLOCK + 1];
-    __shared__ unsigned long long red[GKR_BLOCK / 64][NW];
     const int tid = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < NW / CH; p++) {
@@ -255,6 +255,12 @@ __device__ __forceinline__ void block_reduce_acc(const Acc9 (&acc)[NS], unsigned
         for (int q = 0; q < GKR_BLOCK / 64; q++) s += red[q][tid];
         out[tid] = s;
     }
+}
+template <int NS, int CH>
+__device__ __forceinline__ void block_reduce_acc(const Acc9 (&acc)[NS], unsigned long long* __restrict__ out) {
+    __shared__ u32 tr[CH][GKR_BLOCK + 1];
+    __shared__ unsigned long long red[GKR_BLOCK / 64][NS * GKR_ACC_WORDS];
+    block_reduce_acc_buf<NS, CH>(acc, out, tr, red);
 }
 
 struct PartialEvalArgs {

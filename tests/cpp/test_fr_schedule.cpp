@@ -59,6 +59,41 @@ int main() {
         }
         n++;
     }
+    // deferred reduction: sum_k a_k*b_k accumulated wide (lazy operands < 2q, carry-corner limbs), reduced once,
+    // must equal the sum of the individual Montgomery products
+    for (int it = 0; it < 20000; it++) {
+        u32 A[FR_WIDE_LIMBS] = {0};
+        ofr_t sum; memset(&sum, 0, sizeof sum);
+        const int terms = 1 + (int)(rnd() % 40);
+        for (int k = 0; k < terms; k++) {
+            Fr a = canon(gen((it + k) % 5)), b = canon(gen((it / 5 + k) % 5));
+            if (it == 0) { a = qm1; b = qm1; }
+            ofr_t oa, ob, oc; memcpy(&oa, &a, 32); memcpy(&ob, &b, 32);
+            oracle_fr_mul(&oc, &oa, &ob); oracle_fr_add(&sum, &sum, &oc);
+            if ((it + k) & 1) {   // lazy representatives a+q, b+q
+                u32 cy = 0; for (int j = 0; j < 8; j++) a.v[j] = fr_addc(a.v[j], Q[j], cy, &cy);
+                cy = 0; for (int j = 0; j < 8; j++) b.v[j] = fr_addc(b.v[j], Q[j], cy, &cy);
+            }
+            fr_mac_wide(A, a, b);
+        }
+        if (it == 1) {            // saturated accumulator below the 2^542 bound: REDC must still fit 9 limbs
+            for (int j = 0; j < 16; j++) A[j] = 0xFFFFFFFFu;
+            A[16] = 0x3FFFu;
+        }
+        u32 out[9]; fr_redc_wide(out, A);
+        if (it == 1) { n++; if (out[8] > 0x3FFFFFFFu) bad++; continue; }
+        // out (288 bits) mod q == sum
+        Fr lo; for (int j = 0; j < 8; j++) lo.v[j] = out[j];
+        // value = lo + out[8]*2^256: fold the top limb with the Montgomery constant 2^256 mod q = fr_one()
+        ofr_t acc; Fr lc = canon(lo); memcpy(&acc, &lc, 32);
+        ofr_t one_m; Fr o1 = fr_one(); memcpy(&one_m, &o1, 32);   // regular value 2^256 mod q, as plain limbs
+        // top * (2^256 mod q) mod q by double-and-add on plain residues
+        ofr_t addend = one_m, topacc; memset(&topacc, 0, sizeof topacc);
+        for (u32 t = out[8]; t; t >>= 1) { if (t & 1) oracle_fr_add(&topacc, &topacc, &addend); oracle_fr_add(&addend, &addend, &addend); }
+        oracle_fr_add(&acc, &acc, &topacc);
+        if (memcmp(&acc, &sum, 32)) bad++;
+        n++;
+    }
     printf("cases=%ld bad=%ld\n", n, bad);
     return bad ? 1 : 0;
 }

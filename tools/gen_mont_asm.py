@@ -25,7 +25,9 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 def cexpr(o):
     k, i = o
-    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d"}[k] % i
+    if k == "one":
+        return "1u"
+    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]"}[k] % i
 
 
 def emit_asm(products, pos0):
@@ -33,9 +35,10 @@ def emit_asm(products, pos0):
     ops = []
     for x, y in products:
         for o in (x, y):
-            if o not in ops:
+            if o not in ops and o[0] != "one":
                 ops.append(o)
     names = {o: "%%%d" % (2 + n) for n, o in enumerate(ops)}
+    names[("one", 0)] = "1"          # inline constant
     lines = []
     inits = False
     for k, (x, y) in enumerate(products):
@@ -209,7 +212,44 @@ def gen_mul2():
     return dev
 
 
+# ------------------------------------------------------------------------------------------------
+# wide multiply-accumulate: A (17 limbs, un-reduced) += a*b as a plain 512-bit product -- no Montgomery
+# reduction.  Used for the products that only feed a sum: the sum is reduced once per thread instead of
+# once per product (half of a multiplication's limb products are its reduction).  Column c adds the
+# accumulator limb A[c] with one more MAD (x1), so the cost is 64+15 MAD/ADDC pairs against 136.
+# ------------------------------------------------------------------------------------------------
+def gen_mac_wide():
+    dev = host = "    u64 acc = (u64)a.v[0] * b.v[0] + A[0];\n    u32 ovf;\n"
+    dev += "    A[0] = FR_LIMB_COPY((u32)acc);\n    acc >>= 32;\n"
+    host += "    A[0] = (u32)acc;\n    acc >>= 32;\n"
+    for c in range(1, 2 * NL - 1):
+        lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
+        prods = [(("A", c), ("one", 0))]
+        for i in range(lo_i, hi_i + 1):
+            prods.append((("a", i), ("b", c - i)))
+        pos = 0
+        for ch in split(prods, pos):
+            dev += emit_asm(ch, pos)
+            host += emit_portable(ch, pos)
+            pos += len(ch)
+        dev += "    A[%d] = FR_LIMB_COPY((u32)acc);\n" % c
+        host += "    A[%d] = (u32)acc;\n" % c
+        sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
+        dev += sh
+        host += sh
+    fin = ("    acc += ((u64)A[16] << 32) | A[15];\n"
+           "    A[15] = (u32)acc;\n    A[16] = (u32)(acc >> 32);\n")
+    return dev + fin, host + fin
+
+
 def main():
+    outw = os.path.join(os.path.dirname(OUT), "fr_mac_wide_gen.inc")
+    dev, host = gen_mac_wide()
+    with open(outw, "w") as f:
+        f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Body of fr_mac_wide() in fr_bn254.h:\n"
+                "// A (17 x u32 limbs, un-reduced) += a*b as a plain 512-bit integer product.\n")
+        f.write("#if defined(__HIP_DEVICE_COMPILE__)\n" + dev + "#else\n" + host + "#endif\n")
+    print("wrote", outw)
     out2 = os.path.join(os.path.dirname(OUT), "fr_mont2_gen.inc")
     with open(out2, "w") as f:
         f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Device body of fr_mont_mul2_raw() in fr_bn254.h:\n"
