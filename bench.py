@@ -47,14 +47,14 @@ def cpu_baseline(target_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bn", type=int, default=24, help="log2 of the number of MiMC hashes per proof (per job)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--circuit", choices=["mimc", "gmimc"], default="mimc",
                     help="mimc: examples.MimcCircuit (the headline metric); gmimc: the build-defined GMiMC t=2 circuit "
                          "(BASELINE config 5, quoted at --bn 22)")
-    ap.add_argument("--concurrent", type=int, default=4,
+    ap.add_argument("--concurrent", type=int, default=5,
                     help="independent proofs in flight (each on its own resident session/lane/stream and, when "
                          "sharded, its own communicator); 1 = strictly one proof at a time")
     args = ap.parse_args()
@@ -79,6 +79,8 @@ def main():
     free_b, _total_b = gk.mem_info()
     per_session = (96 if args.circuit == "mimc" else 104) * 32 * (1 << args.bn)
     nconc = max(1, min(args.concurrent, args.steps, int(0.85 * free_b // per_session)))
+    if nconc > 1 and args.steps % nconc and args.steps % (nconc - 1) == 0:
+        nconc -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
     if dist is not None:
         t = torch.tensor([nconc], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # same number of lanes on every rank

@@ -175,6 +175,31 @@ FR_HD void fr_redc_wide(u32 (&out)[9], const u32 (&A)[FR_WIDE_LIMBS]) {
     for (int j = 0; j < 9; j++) out[j] = T[8 + j];
 }
 
+// canonical residue of a 9-limb value below 16q (a wide sum of at most 64 products after fr_redc_wide:
+// 64*q^2/2^256 + q < 13.2q): conditional subtraction of 8q, 4q, 2q, q
+FR_HD Fr fr_canon_lt16q(const u32 (&w)[9]) {
+    const u32 q[9] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7, 0u};
+    u32 x[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) x[j] = w[j];
+#pragma unroll
+    for (int s = 3; s >= 0; s--) {
+        u32 d[9];
+        u32 br = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const u32 qs = s ? ((q[j] << s) | (j ? (q[j - 1] >> (32 - s)) : 0u)) : q[j];
+            d[j] = fr_subb(x[j], qs, br, &br);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) x[j] = br ? x[j] : d[j];
+    }
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = x[j];
+    return r;
+}
+
 // canonical product
 FR_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_reduce_once(fr_mont_mul_raw(a, b)); }
 FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_mul_raw(a, a)); }

@@ -155,11 +155,22 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_eq_expand(EqExpandArgs a) {
     const size_t mask = ((size_t)1 << a.nlo) - 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t ih = i >> a.nlo, il = i & mask;
-        Fr acc = fr_mul(ld_fr(a.thi.lo, a.thi.hi, ih), ld_fr(a.tlo.lo, a.tlo.hi, il));
-        for (int j = 1; j < a.nclaims; j++) {
-            const Fr h = ld_fr(a.thi.lo, a.thi.hi, (size_t)j * a.hi_stride + ih);
-            const Fr l = ld_fr(a.tlo.lo, a.tlo.hi, (size_t)j * a.lo_stride + il);
-            acc = fr_add(acc, fr_mul(h, l));
+        // dot product over the claims with deferred reduction: plain 512-bit products accumulate in 17 limbs and
+        // are reduced once per 64 claims (fr_mac_wide / fr_redc_wide) instead of once per product
+        Fr acc = fr_zero();
+        for (int j0 = 0; j0 < a.nclaims; j0 += 64) {
+            u32 T[FR_WIDE_LIMBS];
+#pragma unroll
+            for (int w = 0; w < FR_WIDE_LIMBS; w++) T[w] = 0;
+            const int j1 = min(j0 + 64, a.nclaims);
+            for (int j = j0; j < j1; j++) {
+                const Fr h = ld_fr(a.thi.lo, a.thi.hi, (size_t)j * a.hi_stride + ih);
+                const Fr l = ld_fr(a.tlo.lo, a.tlo.hi, (size_t)j * a.lo_stride + il);
+                fr_mac_wide(T, h, l);
+            }
+            u32 red[9];
+            fr_redc_wide(red, T);
+            acc = fr_add(acc, fr_canon_lt16q(red));
         }
         st_fr(a.out.lo, a.out.hi, i, acc);
     }

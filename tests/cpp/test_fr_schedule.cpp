@@ -64,7 +64,7 @@ int main() {
     for (int it = 0; it < 20000; it++) {
         u32 A[FR_WIDE_LIMBS] = {0};
         ofr_t sum; memset(&sum, 0, sizeof sum);
-        const int terms = 1 + (int)(rnd() % 40);
+        const int terms = 1 + (int)(rnd() % 64);
         for (int k = 0; k < terms; k++) {
             Fr a = canon(gen((it + k) % 5)), b = canon(gen((it / 5 + k) % 5));
             if (it == 0) { a = qm1; b = qm1; }
@@ -92,6 +92,10 @@ int main() {
         for (u32 t = out[8]; t; t >>= 1) { if (t & 1) oracle_fr_add(&topacc, &topacc, &addend); oracle_fr_add(&addend, &addend, &addend); }
         oracle_fr_add(&acc, &acc, &topacc);
         if (memcmp(&acc, &sum, 32)) bad++;
+        if (terms <= 64) {        // the canonicalisation used by k_eq_expand (value < 16q)
+            Fr cn = fr_canon_lt16q(out);
+            if (memcmp(&cn, &sum, 32)) bad++;
+        }
         n++;
     }
     printf("cases=%ld bad=%ld\n", n, bad);

@@ -286,6 +286,30 @@ def test_round_kernel_variants(gk):
     _run_case({"GKRHIP_LAT": "2", "GKRHIP_GMAX": "8"}, "1,4,9,12,13")
 
 
+def test_round_kernel_deferred_reduction_variants(gk):
+    """The deferred-reduction round kernel (wide LDS/VGPR accumulators, one reduction per lane and sum) against the
+    oracle with the lane weight applied after the loop from 2 pairs per lane on, never, and with the kernel
+    switched off (every product reduced) -- the same transcript each time."""
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "1"}, "9,10,12,14")
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "99"}, "9,10,13")
+    _run_case({"GKRHIP_GMAX": "9", "GKRHIP_WIDE": "0"}, "10,12,13")
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_LAT": "0", "GKRHIP_WT_LATE_LJ": "3"}, "11,15")
+
+
+def test_round_kernel_deferred_reduction_carry_corners(gk):
+    """Tables made of the carry-corner values (limbs of 0xFFFFFFFF, q-1, 0, 1) through gkr.Prove with a small
+    thread budget, so that every lane accumulates many wide products of extreme operands."""
+    gk.set_option("g_max", 8)
+    try:
+        for bn in (10, 13):
+            i0, i1, qp = nasty(1 << bn, 3 * bn), nasty(1 << bn, 5 * bn + 1), c.random_fr_array(bn)
+            flat, outs = gk.gkr_prove_mimc(i0, i1, qp)
+            oflat, oouts, _ = c.gkr_prove_mimc(bn, i0, i1, qp)
+            assert np.array_equal(flat, oflat) and np.array_equal(outs, oouts)
+    finally:
+        gk.set_option("g_max", 16)
+
+
 # ---------------------------------------------------------------- gkr.Prove (MimcCircuit)
 def test_gkr_golden(gk):
     for e in load("gkr_mimc.json"):
