@@ -89,9 +89,30 @@ def main():
         # install the library's own RCCL communicators, one per lane (the per-round all-reduce of the limb-split
         # sums lives inside the C++ round loop); torch.distributed only carries the 128-byte unique ids, the
         # barriers and the max-over-ranks of the timing
-        box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
+        transport, err = "rccl", ""
+        try:
+            box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
+        except Exception as e:      # noqa: BLE001 -- reported below, never silent
+            box, err = [None], str(e)
         dist.broadcast_object_list(box, src=0)
-        gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
+        ok = 0
+        if box[0] is not None:
+            try:
+                gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+        t = torch.tensor([ok], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            # RCCL communicators could not be created on some rank: the same call sites run over the library's
+            # host shared-memory transport (single node only) and the JSON line says so
+            gk.comm_destroy()
+            dist.barrier()
+            gk.comm_init_shm_lanes(world, rank, nconc, "/gkrhip_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+            transport = "host shared memory (RCCL communicator init failed: %s)" % (err or "on another rank")
+            if rank == 0:
+                print("bench.py: " + transport, file=sys.stderr)
     gamma = (world.bit_length() - 1) if dist is not None else 0
     # weak scaling: every GPU holds a 2^bn shard, the job proves 2^(bn + log2 N) hashes in ONE proof
     bn = args.bn + gamma
@@ -177,6 +198,8 @@ def main():
                    "bN": bn, "bN_per_gpu": args.bn, "proof_elements": int(flat.shape[0]),
                    "concurrent_proofs": nconc, "single_proof_latency_ms": latency_ms},
     }
+    if dist is not None:
+        out["config"]["per_round_exchange"] = transport + ": all-reduce of 72 limb-split u64 lanes per sumcheck round"
     if solo["fold_launches"]:
         # The fold launches on full-size tables, timed with HIP events on the launching stream.  Primary figure:
         # the single-proof pass (one proof alone on the GPU) that bench.py runs between the warm-up and the K timed
@@ -213,12 +236,27 @@ def main():
                              "GB_per_s": 96.0 * 3 * (1 << (args.bn - 1)) / (ms3 * 1e-3) / 1e9,
                              "note": "device-resident micro-benchmark of the same kernel (gkrhip_bench_fold): three "
                                      "tables, no other kernel running"}
-    if prof["peval_launches"]:
-        out["partial_eval"] = {"kernel": "k_cipher_round / k_partial_eval launches on full-size tables (round 0 of a layer)",
-                               "launches": prof["peval_launches"],
-                               "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
-                               "modmul_per_s": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
-                               "bound": "integer VALU (no MFMA: modular arithmetic)"}
+    if solo["peval_launches"]:
+        # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit), so it is
+        # priced in field products per second against an instruction-issue ceiling: one Montgomery product is 136
+        # v_mad_u64_u32 + 136 v_addc_co_u32 + 8 v_mul_lo_u32 + moves = 1158 cycles per wave measured in isolation at
+        # full occupancy (profiles/r01_ubench_instruction_rates.txt) -> 2.4 GHz x 1024 SIMDs x 64 lanes / 1158
+        ceiling = 2.4e9 * 1024 * 64 / 1158.0
+        rate = solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3)
+        out["partial_eval"] = {"kernel": "k_cipher_round_wide (round 0 of a cipher layer: 2^%d index pairs, 21 field products "
+                                         "per pair, 7 of them accumulated with deferred reduction)" % (args.bn - 1),
+                               "bound": "integer VALU (no MFMA: modular arithmetic)",
+                               "launches": solo["peval_launches"],
+                               "avg_launch_ms": solo["peval_ms"] / solo["peval_launches"],
+                               "modmul_per_s": rate, "ceiling_modmul_per_s": ceiling, "frac": rate / ceiling,
+                               "ceiling_assumption": "every product a full Montgomery product at the measured isolated "
+                                                     "rate of 1158 cycles per wave; deferred-reduction products count as products",
+                               "measured": "HIP events around the round-0 launches of the single-proof pass"}
+        if prof["peval_launches"]:
+            out["partial_eval"]["in_timed_region"] = {
+                "launches": prof["peval_launches"], "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
+                "modmul_per_s_per_launch": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
+                "note": "launch durations with %d proofs in flight overlap the other lanes' kernels" % nconc}
     if prof.get("rounds"):
         out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
                                          ("host_hash_ms", "host_wait_ms", "host_launch_ms", "host_other_ms")}
