@@ -1,0 +1,392 @@
+// host_ctx.hip.h -- lanes (per-proof contexts), the device table arena, boundary copies, profiling events and
+// kernel launch wrappers of the host drivers.  Included by gkrhip.hip inside its anonymous namespace.
+#pragma once
+
+struct DevTable {
+    uint4* base = nullptr;
+    size_t cap = 0;  // elements per plane
+    Planes planes() const { return Planes{base, base + cap}; }
+    CPlanes cplanes() const { return CPlanes{base, base + cap}; }
+};
+
+static inline double now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+struct Profile {
+    double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
+    uint64_t rounds = 0;
+    size_t min_n = (size_t)1 << 62;
+    uint64_t fold_launches = 0, peval_launches = 0;
+    double fold_bytes = 0, peval_modmuls = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fold_ev, peval_ev;
+    std::vector<hipEvent_t> pool;
+};
+
+// per-lane state of the collective (one communicator / shared-memory segment per lane: the lanes of a rank
+// issue their collectives independently, lane k pairing with lane k of the other ranks)
+struct ShmHdr {
+    std::atomic<unsigned> arrive, gen;
+};
+struct LaneColl {
+    ncclComm_t comm = nullptr;
+    ShmHdr* shm = nullptr;
+    unsigned long long* shm_slots = nullptr;
+    size_t shm_bytes = 0;
+    unsigned long long* d_buf = nullptr;   // device staging: lanes / gathered elements
+    unsigned long long* h_buf = nullptr;   // pinned mirror
+    unsigned long long* h_tmp = nullptr;
+    size_t buf_words = 0;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums
+    unsigned long long* d_sums = nullptr;      // reduced sums (device)
+    unsigned long long* h_sums = nullptr;      // pinned
+    uint4* d_small = nullptr;                  // gather buffer (AoS)
+    uint4* h_small = nullptr;                  // pinned
+    Fr* d_q = nullptr;                         // qPrime coordinates + seeds staging
+    size_t d_q_cap = 0;
+    int max_grid = 2048;
+    int fold_grid = 1 << 20;                   // workgroups cap of the fold: one element per lane up to 2^28 outputs
+    bool fold_split = true;                    // one single-table launch per table instead of a fused launch
+    int n_cu = 256;
+    // fused cipher round (cipher_round.hip.h)
+    unsigned long long* h_round = nullptr;     // host-mapped: GKR_CR_WORDS sums + 16 tail words
+    unsigned long long* d_round = nullptr;     // device view of h_round
+    unsigned int* h_flag = nullptr;            // host-mapped completion flag
+    unsigned int* d_flag = nullptr;
+    unsigned int* d_counter = nullptr;         // block arrival counter
+    unsigned int seq = 0;
+    int g_max = 16;                            // log2(max threads of the round kernel): 16 measured best with 4 proofs in flight (17 for one proof alone)
+    bool force_generic = false;
+    bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
+    int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
+    int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
+    int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
+    bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
+    hfr::Lagrange* lag = nullptr;
+    Profile prof;
+    LaneColl lc;
+    std::mutex mu;                             // serialises the calls that use this lane
+};
+
+// A Ctx is a "lane": one stream plus every buffer a proof in flight needs exclusively.  g0 is the default
+// lane (host-buffer entry points, sharded sessions); each un-sharded session owns a lane of its own, so
+// independent sessions can prove concurrently from different host threads (one proof's Fiat-Shamir hashing
+// and small latency-bound rounds then overlap another proof's big rounds).
+Ctx g0;
+thread_local Ctx* g_cur = &g0;
+// the lane (stream, hand-off buffers, counters, communicator) the calling thread currently works on
+static inline Ctx& cx() { return *g_cur; }
+struct UseLane {
+    Ctx* prev;
+    explicit UseLane(Ctx* l) : prev(g_cur) { g_cur = l; }
+    ~UseLane() { g_cur = prev; }
+};
+std::mutex g_lanes_mu;
+std::vector<Ctx*> g_lanes;                     // every lane, for profile aggregation
+struct Pool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
+} g_pool;
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIPCHK(x)                                                                                 \
+    do {                                                                                          \
+        hipError_t _e = (x);                                                                      \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)                  \
+    do {                        \
+        int _r = (x);           \
+        if (_r != 0) return _r; \
+    } while (0)
+
+const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
+int lane_alloc();
+
+int ctx_init(int dev) {
+    if (cx().ready) {
+        if (dev >= 0 && dev != cx().device) return fail("gkrhip already initialised on device %d", cx().device);
+        return 0;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail("no HIP device available (%s): libgkrhip has no CPU fallback", hipGetErrorString(e));
+    if (dev < 0) dev = 0;
+    if (dev >= n) return fail("device ordinal %d out of range (%d devices)", dev, n);
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("device %d is %s; libgkrhip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+    cx().n_cu = prop.multiProcessorCount;
+    cx().max_grid = cx().n_cu * 32;   // streaming kernels: 8192 workgroups measured best for the fold (profiles/)
+    if (const char* e = getenv("GKRHIP_GMAX")) cx().g_max = std::max(8, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_GENERIC")) cx().force_generic = atoi(e) != 0;
+    if (const char* e = getenv("GKRHIP_LAT")) cx().lat_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_WIDE")) cx().wide_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_WT_LATE_LJ")) cx().wt_late_lj = atoi(e);
+    if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
+    if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
+    if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
+    cx().lag = new hfr::Lagrange();
+    cx().device = dev;
+    CHK(lane_alloc());
+    {
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        g_lanes.push_back(&cx());
+    }
+    cx().ready = true;
+    return 0;
+}
+
+// stream + buffers of the current lane
+int lane_alloc() {
+    HIPCHK(hipStreamCreateWithFlags(&cx().stream, hipStreamNonBlocking));
+    const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
+    HIPCHK(hipMalloc(&cx().d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
+    HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));
+    HIPCHK(hipHostMalloc(&cx().h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&cx().d_small, sizeof(uint4) * 2 * 8));
+    HIPCHK(hipHostMalloc(&cx().h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&cx().h_round, sizeof(unsigned long long) * (GKR_CR_WORDS + 16), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_round, cx().h_round, 0));
+    HIPCHK(hipHostMalloc(&cx().h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_flag, cx().h_flag, 0));
+    *cx().h_flag = 0;
+    cx().seq = 0;
+    HIPCHK(hipMalloc(&cx().d_counter, 64));
+    HIPCHK(hipMemset(cx().d_counter, 0, 64));
+    return 0;
+}
+void lane_free() {
+    (void)hipStreamSynchronize(cx().stream);
+    (void)hipFree(cx().d_partials);
+    (void)hipFree(cx().d_sums);
+    (void)hipHostFree(cx().h_sums);
+    (void)hipFree(cx().d_small);
+    (void)hipHostFree(cx().h_small);
+    (void)hipHostFree(cx().h_round);
+    (void)hipHostFree(cx().h_flag);
+    (void)hipFree(cx().d_counter);
+    if (cx().d_q) (void)hipFree(cx().d_q);
+    cx().d_q = nullptr;
+    cx().d_q_cap = 0;
+    (void)hipStreamDestroy(cx().stream);
+    cx().stream = nullptr;
+}
+// a new lane configured like the default one
+Ctx* lane_create() {
+    Ctx* l = new Ctx();
+    l->device = g0.device;
+    l->n_cu = g0.n_cu;
+    l->max_grid = g0.max_grid;
+    l->fold_grid = g0.fold_grid;
+    l->fold_split = g0.fold_split;
+    l->g_max = g0.g_max;
+    l->force_generic = g0.force_generic;
+    l->lat_mode = g0.lat_mode;
+    l->wide_mode = g0.wide_mode;
+    l->wt_late_lj = g0.wt_late_lj;
+    l->claim_trick = g0.claim_trick;
+    l->force_collective = g0.force_collective;
+    l->lag = g0.lag;
+    l->prof.min_n = g0.prof.min_n;
+    UseLane u(l);
+    if (lane_alloc() != 0) {
+        delete l;
+        return nullptr;
+    }
+    l->ready = true;
+    std::lock_guard<std::mutex> lk(g_lanes_mu);
+    g_lanes.push_back(l);
+    return l;
+}
+void lane_destroy(Ctx* l) {
+    {
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        g_lanes.erase(std::remove(g_lanes.begin(), g_lanes.end(), l), g_lanes.end());
+    }
+    UseLane u(l);
+    lane_free();
+    delete l;
+}
+
+int ensure_ctx() {
+    if (!g0.ready) {
+        UseLane u(&g0);
+        CHK(ctx_init(-1));
+    }
+    HIPCHK(hipSetDevice(g0.device));
+    return 0;
+}
+
+// ---- device table arena (replaces poly/pool.go:69-126; no 2^24 cap) ---------------------------------
+int table_alloc(DevTable* t, size_t cap) {
+    if (cap == 0) cap = 1;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (size_t i = 0; i < g_pool.free_list.size(); i++) {
+        if (g_pool.free_list[i].first == cap) {
+            t->base = g_pool.free_list[i].second;
+            t->cap = cap;
+            g_pool.free_list.erase(g_pool.free_list.begin() + i);
+            return 0;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& f : g_pool.free_list) (void)hipFree(f.second);
+        g_pool.free_list.clear();
+        e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
+        if (e != hipSuccess) return fail("hipMalloc of a %zu-element table failed: %s", cap, hipGetErrorString(e));
+    }
+    t->base = (uint4*)p;
+    t->cap = cap;
+    return 0;
+}
+void table_release(DevTable* t) {
+    if (t->base) {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool.free_list.emplace_back(t->cap, t->base);
+    }
+    t->base = nullptr;
+    t->cap = 0;
+}
+void table_free(DevTable* t) {
+    if (t->base) (void)hipFree(t->base);
+    t->base = nullptr;
+    t->cap = 0;
+}
+
+inline int grid_for(size_t n, int cap_blocks) {
+    size_t b = (n + GKR_BLOCK - 1) / GKR_BLOCK;
+    if (b < 1) b = 1;
+    return (int)std::min<size_t>(b, (size_t)cap_blocks);
+}
+
+inline Fr to_dev(const E& e) {
+    Fr r;
+    memcpy(r.v, e.l, 32);
+    return r;
+}
+
+// ---- boundary copies -----------------------------------------------------------------------------
+// host AoS -> device planes.  Staged through a device AoS buffer and transposed by k_aos_to_planes.
+int upload_table(DevTable* t, const uint64_t* host_aos, size_t n) {
+    uint4* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, 32 * n));
+    HIPCHK(hipMemcpyAsync(stage, host_aos, 32 * n, hipMemcpyHostToDevice, cx().stream));
+    hipLaunchKernelGGL(k_aos_to_planes, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    HIPCHK(hipFree(stage));
+    return 0;
+}
+int download_table(const DevTable* t, uint64_t* host_aos, size_t n) {
+    uint4* stage = nullptr;
+    HIPCHK(hipMalloc(&stage, 32 * n));
+    hipLaunchKernelGGL(k_planes_to_aos, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->cplanes(), stage, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_aos, stage, 32 * n, hipMemcpyDeviceToHost, cx().stream));
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    HIPCHK(hipFree(stage));
+    return 0;
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+hipEvent_t prof_event() {
+    if (!cx().prof.pool.empty()) {
+        hipEvent_t e = cx().prof.pool.back();
+        cx().prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// ---- kernel launch wrappers ------------------------------------------------------------------------
+int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab, size_t mid, const E& r) {
+    FoldArgs a;
+    memset(&a, 0, sizeof a);
+    for (int t = 0; t < ntab; t++) {
+        a.src[t] = src[t]->cplanes();
+        a.dst[t] = dst[t]->planes();
+    }
+    a.ntab = ntab;
+    a.mid = mid;
+    a.r = to_dev(r);
+    const bool timed = 2 * mid >= cx().prof.min_n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        e0 = prof_event();
+        e1 = prof_event();
+        HIPCHK(hipEventRecord(e0, cx().stream));
+    }
+    // one single-table launch per table, one element per lane: measured (interleaved A/B in one process,
+    // profiles/r01_fold_variants.txt) 6.4-6.6 TB/s on 2^24/2^25-element tables, against 5.7-6.1 TB/s for a
+    // fused three-table launch and 4.6-5.8 TB/s for grid-stride loops over 8192 workgroups
+    const dim3 grid(grid_for(mid, cx().fold_grid)), block(GKR_BLOCK);
+    if (!cx().fold_split) {
+        switch (ntab) {
+            case 1: hipLaunchKernelGGL(k_fold<1>, grid, block, 0, cx().stream, a); break;
+            case 2: hipLaunchKernelGGL(k_fold<2>, grid, block, 0, cx().stream, a); break;
+            case 3: hipLaunchKernelGGL(k_fold<3>, grid, block, 0, cx().stream, a); break;
+            case 4: hipLaunchKernelGGL(k_fold<4>, grid, block, 0, cx().stream, a); break;
+            case 5: hipLaunchKernelGGL(k_fold<5>, grid, block, 0, cx().stream, a); break;
+            default: return fail("fold of %d tables not supported", ntab);
+        }
+    } else
+    for (int t = 0; t < ntab; t++) {
+        FoldArgs one;
+        memset(&one, 0, sizeof one);
+        one.src[0] = a.src[t];
+        one.dst[0] = a.dst[t];
+        one.ntab = 1;
+        one.mid = mid;
+        one.r = a.r;
+        hipLaunchKernelGGL(k_fold<1>, grid, block, 0, cx().stream, one);
+    }
+    HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(e1, cx().stream));
+        cx().prof.fold_ev.emplace_back(e0, e1);
+        cx().prof.fold_launches++;
+        cx().prof.fold_bytes += 96.0 * ntab * (double)mid;
+    }
+    return 0;
+}
+
+template <int GATE, int ARITY, int NEV>
+int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, int* nblocks) {
+    PartialEvalArgs a;
+    memset(&a, 0, sizeof a);
+    a.eq = eq->cplanes();
+    for (int k = 0; k < ARITY; k++) a.x[k] = x[k]->cplanes();
+    a.mid = mid;
+    a.ark = to_dev(ark);
+    a.partials = cx().d_partials;
+    const int grid = grid_for(mid, kPartialBlocks);
+    hipLaunchKernelGGL((k_partial_eval<GATE, ARITY, NEV>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+    *nblocks = grid;
+    return 0;
+}

@@ -1,0 +1,421 @@
+// host_sumcheck.hip.h -- sumcheck.Prove on device tables (sumcheck/prover.go:46-144): the fused single-point
+// cipher rounds, the reference-shaped generic rounds, Evaluate.  Included by gkrhip.hip inside its anonymous namespace.
+#pragma once
+// ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
+int wait_flag(unsigned int seq) {
+    volatile unsigned int* f = cx().h_flag;
+    unsigned long spins = 0;
+    while (*f != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0) {              // every ~millisecond: make sure the GPU is alive
+            hipError_t e = hipStreamQuery(cx().stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
+            if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
+        }
+    }
+    __sync_synchronize();
+    return 0;
+}
+
+template <bool FOLD, bool HAS_WJ>
+void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
+    if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+    else hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+}
+
+// The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
+// q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
+// monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
+// eq(q_k, r_k) of every round, proof/chal hold m rounds, tail = the two remaining entries of each table
+// (K_lo, K_hi, S_lo, S_hi) and r_last the last challenge (the caller applies the final fold).
+int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, const E* q, const E& seed, bool collective,
+                  E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
+                  bool* claim_known) {
+    const size_t n = (size_t)1 << m;
+    const int gT = std::min(cx().g_max, m - 1);           // threads of round 0 = 2^gT
+    const int mU = m - 1 - gT;                         // log2(iterations of round 0)
+    CHK(stage_coords(q, (size_t)m));
+    DevTable pyrT, pyrU, ks, ss;
+    CHK(table_alloc(&pyrT, (size_t)2 << gT));
+    CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
+    CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
+    CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
+    PyramidArgs pa;
+    pa.out = pyrT.planes();
+    pa.q = cx().d_q;
+    pa.nc = m;
+    pa.max_level = gT;
+    pa.seed = to_dev(seed);
+    hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
+    if (mU > 0) {
+        pa.out = pyrU.planes();
+        pa.nc = m - gT;                                // q[0 .. m-gT-1]; level L = eq(q[nc-L .. nc-1], .)
+        pa.max_level = mU;
+        pa.seed = to_dev(hfr::ONE);
+        hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << mU, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
+    }
+    HIPCHK(hipGetLastError());
+    if (collective) CHK(coll_buffers(256));
+
+    static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
+    E r_prev = hfr::ZERO;
+    for (int k = 0; k < m; k++) {
+        const size_t P = n >> (k + 1);
+        const int gk = std::min(cx().g_max, m - 1 - k);
+        const int lj = m - 1 - k - gk;                 // log2(iterations)
+        CipherRoundArgs a;
+        memset(&a, 0, sizeof a);
+        const bool fold = k > 0;
+        a.k_src = (k <= 1 ? K : &ks)->cplanes();
+        a.s_src = (k <= 1 ? S : &ss)->cplanes();
+        a.k_dst = ks.planes();
+        a.s_dst = ss.planes();
+        const size_t offT = ((size_t)1 << gk) - 1;
+        a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
+        if (lj > 0) {
+            const size_t offU = ((size_t)1 << lj) - 1;
+            a.wj = CPlanes{pyrU.base + offU, pyrU.base + pyrU.cap + offU};
+        }
+        a.P = P;
+        a.lg_threads = (unsigned)gk;
+        a.r = to_dev(r_prev);
+        a.ark = to_dev(ark);
+        a.partials = cx().d_partials;
+        a.counter = cx().d_counter;
+        a.host_out = collective ? cx().lc.d_buf : cx().d_round;      // sharded: sums stay on the device for the all-reduce
+        a.host_flag = cx().d_flag;
+        a.seq = ++cx().seq;
+        const bool derive_m0 = claim && *claim_known;
+        a.need_m0 = derive_m0 ? 0u : 1u;
+        const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
+        const bool timed = 2 * P >= cx().prof.min_n;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            e0 = prof_event();
+            e1 = prof_event();
+            HIPCHK(hipEventRecord(e0, cx().stream));
+        }
+        const double t_l0 = now_ms();
+        // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
+        const bool lat = cx().lat_mode == 2 || (cx().lat_mode == 1 && lj == 0);
+        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat;
+        const bool late = wide && lj >= cx().wt_late_lj;  // the lane weight multiplies the sums after the loop: 8 products per lane
+        if (wide) {
+            if (fold) {
+                if (late) hipLaunchKernelGGL((k_cipher_round_wide<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+                else hipLaunchKernelGGL((k_cipher_round_wide<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            } else {
+                if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+                else hipLaunchKernelGGL((k_cipher_round_wide<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            }
+        } else if (fold) {
+            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat);
+            else launch_cipher_round<true, false>(a, grid, lat);
+        } else {
+            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat);
+            else launch_cipher_round<false, false>(a, grid, lat);
+        }
+        HIPCHK(hipGetLastError());
+        if (timed) {
+            HIPCHK(hipEventRecord(e1, cx().stream));
+            cx().prof.peval_ev.emplace_back(e0, e1);
+            cx().prof.peval_launches++;
+            cx().prof.peval_modmuls += ((derive_m0 ? 21.0 : 23.0) + (lj > 0 && !late ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
+        }
+        const double t_l1 = now_ms();
+        const unsigned long long* words = cx().h_round;
+        if (collective) {
+            // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are
+            // rank-local and are copied as they are
+            CHK(coll_allreduce(cx().lc.d_buf, GKR_CR_WORDS));
+            HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
+                                  hipMemcpyDeviceToHost, cx().stream));
+            HIPCHK(hipStreamSynchronize(cx().stream));
+            words = cx().lc.h_buf;
+        } else {
+            CHK(wait_flag(a.seq));
+        }
+        const double t_w = now_ms();
+        // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
+        // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
+        // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
+        E csp[8];
+        for (int j = derive_m0 ? 1 : 0; j < 8; j++)
+            csp[j] = hfr::mul(c, hfr::mul(limbs9_to_fr(words + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j])));
+        if (derive_m0) {
+            E rest = csp[1];
+            for (int j = 2; j < 8; j++) rest = hfr::add(rest, csp[j]);
+            csp[0] = hfr::sub(*claim, hfr::mul(q[k], rest));
+        }
+        const E a0 = hfr::sub(hfr::ONE, q[k]);
+        const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
+        E* co = proof + (size_t)k * 9;
+        co[0] = hfr::mul(a0, csp[0]);
+        for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, csp[j]), hfr::mul(a1, csp[j - 1]));
+        co[8] = hfr::mul(a1, csp[7]);
+        const double t_h0 = now_ms();
+        const E r = hfr::mimc_hash(co, 9);
+        const double t_h1 = now_ms();
+        chal[k] = r;
+        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
+        r_prev = r;
+        if (claim) {   // next round's claim = P_k(r_k)
+            *claim = hfr::eval_univariate(co, 9, r);
+            *claim_known = true;
+        }
+        if (k == m - 1) memcpy(tail, words + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
+        cx().prof.host_launch_ms += t_l1 - t_l0;
+        cx().prof.host_wait_ms += t_w - t_l1;
+        cx().prof.host_other_ms += t_h0 - t_w;
+        cx().prof.host_hash_ms += t_h1 - t_h0;
+        cx().prof.rounds++;
+    }
+    r_last = r_prev;
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    table_release(&pyrT);
+    table_release(&pyrU);
+    table_release(&ks);
+    table_release(&ss);
+    return 0;
+}
+
+inline E fold2(const E& lo, const E& hi, const E& r) { return hfr::add(lo, hfr::mul(hfr::sub(hi, lo), r)); }
+
+// host elements -> a small device table (boundary helper for the gathered shard tables)
+int small_table(DevTable* t, const std::vector<E>& v) {
+    CHK(table_alloc(t, v.size()));
+    return upload_table(t, (const uint64_t*)v.data(), v.size());
+}
+
+// sumcheck.Prove for the cipher gate with one evaluation point.  bN is the GLOBAL number of variables; K and
+// S are this rank's shard (2^(bN-gamma) entries, indices = rank mod world).  Phase 1: the bN-gamma local
+// rounds (sums all-reduced); then one element per table per rank is all-gathered and the last gamma
+// rounds run redundantly on every rank (phase 2).
+int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable* S, const E* q, E* proof, E* challenges,
+                         E* final_claims, const E* trusted_claim, bool track_claim) {
+    const int gamma = gc.gamma, m1 = bN - gamma;
+    if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
+    E c = hfr::ONE, tail[4], r_last, kv, sv;
+    // running claim: known from the start when the caller vouches for it, otherwise from round 1 on
+    E claim = trusted_claim ? *trusted_claim : hfr::ZERO;
+    bool claim_known = trusted_claim != nullptr;
+    E* claim_p = track_claim ? &claim : nullptr;
+    if (m1 >= 1) {
+        const E seed = gamma ? shard_seed(q + m1, gamma, gc.rank) : hfr::ONE;
+        CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last,
+                          claim_p, &claim_known));
+        kv = fold2(tail[0], tail[1], r_last);
+        sv = fold2(tail[2], tail[3], r_last);
+    } else {
+        const DevTable* t[2] = {K, S};
+        E v[2];
+        CHK(gather0(t, 2, v));
+        kv = v[0];
+        sv = v[1];
+    }
+    if (gamma > 0) {
+        const E mine[2] = {kv, sv};
+        std::vector<E> all;
+        CHK(coll_allgather(mine, 2, all));
+        std::vector<E> k2(gc.world), s2(gc.world);
+        for (int r = 0; r < gc.world; r++) {
+            k2[r] = all[2 * r];
+            s2[r] = all[2 * r + 1];
+        }
+        DevTable K2, S2;
+        CHK(small_table(&K2, k2));
+        CHK(small_table(&S2, s2));
+        CHK(cipher_rounds(ark, gamma, &K2, &S2, q + m1, hfr::ONE, false, c, proof + (size_t)9 * m1, challenges + m1, tail,
+                          r_last, claim_p, &claim_known));
+        kv = fold2(tail[0], tail[1], r_last);
+        sv = fold2(tail[2], tail[3], r_last);
+        table_release(&K2);
+        table_release(&S2);
+    }
+    final_claims[0] = c;
+    final_claims[1] = kv;
+    final_claims[2] = sv;
+    return 0;
+}
+
+int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }   // cipher.go:68-70; copy.go:30-32; add: linear
+
+// The reference-shaped rounds (sumcheck/prover.go:70-76) over an Eq table and `arity` tables of 2^m entries:
+// partial evaluation at t = 0..deg+1, interpolation, Fiat-Shamir, fold.  eq is folded in place, X is
+// read-only (round 0 folds into scratch).  On return `last` = [Eq[0], X_1[0], ...] of this rank.
+int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const DevTable* const* X, bool collective,
+                   E* proof, E* chal, E* last) {
+    const size_t n = (size_t)1 << m;
+    const int nev = gate_degree(gate) + 2;
+    DevTable scratch[GKR_MAX_ARITY];
+    for (int k = 0; k < arity; k++) CHK(table_alloc(&scratch[k], std::max<size_t>(n / 2, 1)));
+    const DevTable* cur[GKR_MAX_ARITY + 1];
+    for (int k = 0; k < arity; k++) cur[k] = X[k];
+    for (int k = 0; k < m; k++) {
+        const size_t mid = n >> (k + 1);
+        E evals[GKR_MAX_EVALS];
+        CHK(partial_evals(gate, arity, eq, cur, mid, ark, evals, nev, collective));
+        E* coeffs = proof + (size_t)k * nev;
+        cx().lag->interpolate(coeffs, evals, nev);
+        const E r = hfr::mimc_hash(coeffs, (size_t)nev);
+        chal[k] = r;
+        const DevTable* src[GKR_MAX_ARITY + 1];
+        const DevTable* dst[GKR_MAX_ARITY + 1];
+        src[0] = eq;
+        dst[0] = eq;
+        for (int t = 0; t < arity; t++) {
+            src[1 + t] = cur[t];
+            dst[1 + t] = &scratch[t];
+        }
+        CHK(launch_fold(src, dst, arity + 1, mid, r));
+        for (int t = 0; t < arity; t++) cur[t] = &scratch[t];
+    }
+    const DevTable* all[GKR_MAX_ARITY + 1];
+    all[0] = eq;
+    for (int t = 0; t < arity; t++) all[1 + t] = cur[t];
+    CHK(gather0(all, arity + 1, last));   // finalClaims (prover.go:79-86)
+    for (int k = 0; k < arity; k++) table_release(&scratch[k]);
+    return 0;
+}
+
+// sumcheck.Prove on device-resident tables (sumcheck/prover.go:46-90).  bN = GLOBAL number of variables;
+// X = this rank's shards (read-only).  proof: bN*(deg+2), challenges: bN, final: arity+1.
+// trust_claims: the caller guarantees that `claims` are the true sums (gkr.Prove: every claim is a previous
+// sumcheck's output).  The single-point cipher path then derives one monomial sum per round from the running
+// claim instead of computing it.  Entry points that take claims from outside never set it: for them the
+// output must be the reference's whatever the claims are (they only feed Fiat-Shamir there).
+int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
+                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims, bool trust_claims = false) {
+    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    if (nq < 1) return fail("need at least one evaluation point");
+    if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
+        return fail("provided a multi-instance %d but the number of claims does not match %d", nq, nclaims);
+    const int gamma = gc.gamma, m1 = bN - gamma;
+    if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
+    const int nev = gate_degree(gate) + 2;
+
+    // ---- makeEqTable (prover.go:102-144)
+    std::vector<E> seeds(nq, hfr::ONE);
+    int nq_used = 1;
+    if (nclaims >= 1) {
+        const E rho = hfr::mimc_hash(claims, (size_t)nclaims);  // computed even when unused, as the reference
+        E mlt = rho;
+        for (int j = 1; j < nq; j++) {
+            seeds[j] = mlt;
+            mlt = hfr::mul(mlt, rho);
+        }
+        nq_used = nq;
+    }
+    if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !cx().force_generic)
+        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims,
+                                    (trust_claims && nclaims == 1) ? &claims[0] : nullptr, trust_claims && cx().claim_trick);
+
+    // phase 1: this rank's shard; Eq_local = sum_j seed_j * eq(q_j tail, rank) * eq(q_j[0:m1], .)
+    if (gamma > 0)
+        for (int j = 0; j < nq_used; j++) seeds[j] = hfr::mul(seeds[j], shard_seed(qprimes + (size_t)j * bN + m1, gamma, gc.rank));
+    DevTable eq;
+    CHK(table_alloc(&eq, (size_t)1 << m1));
+    CHK(build_eq(&eq, qprimes, nq_used, bN, m1, seeds.data()));
+    E last[GKR_MAX_ARITY + 1];
+    CHK(generic_rounds(gate, ark, arity, m1, &eq, X, gamma > 0 || cx().force_collective, proof, challenges, last));
+    table_release(&eq);
+    if (gamma > 0) {
+        // phase 2: one entry per table per rank -> tables over the gamma shard bits, same rounds on every rank
+        std::vector<E> all;
+        CHK(coll_allgather(last, arity + 1, all));
+        std::vector<std::vector<E>> cols(arity + 1, std::vector<E>(gc.world));
+        for (int r = 0; r < gc.world; r++)
+            for (int t = 0; t <= arity; t++) cols[t][r] = all[(size_t)r * (arity + 1) + t];
+        DevTable eq2, x2[GKR_MAX_ARITY];
+        const DevTable* X2[GKR_MAX_ARITY];
+        CHK(small_table(&eq2, cols[0]));
+        for (int t = 0; t < arity; t++) {
+            CHK(small_table(&x2[t], cols[1 + t]));
+            X2[t] = &x2[t];
+        }
+        CHK(generic_rounds(gate, ark, arity, gamma, &eq2, X2, false, proof + (size_t)nev * m1, challenges + m1, last));
+        table_release(&eq2);
+        for (int t = 0; t < arity; t++) table_release(&x2[t]);
+    }
+    for (int t = 0; t <= arity; t++) final_claims[t] = last[t];
+    return 0;
+}
+
+template <int GATE, int ARITY>
+void launch_gate_eval(const AssignArgs& a) {
+    hipLaunchKernelGGL((k_gate_eval_batch<GATE, ARITY>), dim3(grid_for(a.n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, a);
+}
+int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, const DevTable* out, size_t n) {
+    AssignArgs a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < arity; k++) a.in[k] = in[k]->cplanes();
+    a.out = out->planes();
+    a.arity = arity;
+    a.n = n;
+    a.ark = to_dev(ark);
+    if (gate == GKRHIP_GATE_CIPHER && arity == 2) launch_gate_eval<GKR_GATE_CIPHER, 2>(a);
+    else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) launch_gate_eval<GKR_GATE_IDENTITY, 1>(a);
+    else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) launch_gate_eval<GKR_GATE_IDENTITY, 2>(a);
+    else if (gate == GKRHIP_GATE_ADD && arity == 2) launch_gate_eval<GKR_GATE_ADD, 2>(a);
+    else return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// MultiLin.Evaluate (poly/multilin.go:59-66) of a table of 2^nc entries: fold chain into scratch.  The
+// table is this rank's shard of 2^(nc-gamma) entries; the shard values are all-gathered and the last gamma
+// coordinates are applied to the gathered (<= world-entry) table.
+int evaluate_dev(const DevTable* t, int nc, const E* coords, E* out) {
+    const int gamma = gc.gamma, m1 = nc - gamma;
+    if (m1 < 0) return fail("Evaluate: %d coordinates for a table sharded over 2^%d ranks", nc, gamma);
+    const size_t n = (size_t)1 << m1;
+    DevTable s;
+    CHK(table_alloc(&s, std::max<size_t>(n / 2, 1)));
+    const DevTable* cur = t;
+    for (int k = 0; k < m1; k++) {
+        const size_t mid = n >> (k + 1);
+        const DevTable* src[1] = {cur};
+        const DevTable* dst[1] = {&s};
+        CHK(launch_fold(src, dst, 1, mid, coords[k]));
+        cur = &s;
+    }
+    E v;
+    CHK(gather0(&cur, 1, &v));
+    table_release(&s);
+    if (gamma > 0) {
+        std::vector<E> all;
+        CHK(coll_allgather(&v, 1, all));
+        for (int k = 0; k < gamma; k++) {           // <= world scalar folds
+            const size_t mid = all.size() / 2;
+            for (size_t i = 0; i < mid; i++) all[i] = fold2(all[i], all[i + mid], coords[m1 + k]);
+            all.resize(mid);
+        }
+        v = all[0];
+    }
+    *out = v;
+    return 0;
+}
+
+// synthetic inputs: element j = Montgomery(((i*i) mod 2^64) ^ 0xf45c9df123f), i = j*stride + offset
+__global__ void __launch_bounds__(GKR_BLOCK) k_random_fr_array(Planes out, size_t n, unsigned long long stride,
+                                                               unsigned long long offset) {
+    const Fr r2 = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long i = (unsigned long long)j * stride + offset;
+        const unsigned long long v = (i * i) ^ 0xf45c9df123fULL;
+        Fr x = fr_zero();
+        x.v[0] = (u32)v;
+        x.v[1] = (u32)(v >> 32);
+        st_fr(out.lo, out.hi, j, fr_mul(x, r2));
+    }
+}
+// table[i] = Montgomery(i)  (BenchmarkFolding's table, poly/multilin_test.go:60-63)
+__global__ void __launch_bounds__(GKR_BLOCK) k_iota(Planes out, size_t n) {
+    const Fr r2 = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        Fr x = fr_zero();
+        x.v[0] = (u32)j;
+        x.v[1] = (u32)((unsigned long long)j >> 32);
+        st_fr(out.lo, out.hi, j, fr_mul(x, r2));
+    }
+}
