@@ -128,6 +128,15 @@ __device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, u
     }
 }
 
+// sharded prover: after the all-reduce the summed words go to the host the same way (host-mapped buffer + flag)
+__global__ void __launch_bounds__(128) k_publish_words(const unsigned long long* __restrict__ src, unsigned long long* host_dst,
+                                                       int n, unsigned int* host_flag, unsigned int seq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) host_dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // LAT = latency variant for the small rounds (at most one wave per SIMD is resident, so nothing hides the
 // ~10-cycle dependent-issue latency of a single multiplication chain): no scheduling barriers, so hipcc
 // interleaves the independent products of the monomial schedule, and a 512-VGPR budget.

@@ -83,7 +83,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.partials = cx().d_partials;
         a.counter = cx().d_counter;
         a.host_out = collective ? cx().lc.d_buf : cx().d_round;      // sharded: sums stay on the device for the all-reduce
-        a.host_flag = cx().d_flag;
+        // sharded: the kernel's own completion flag lands in a spare word of the exchange buffer (the host is
+        // signalled after the all-reduce instead)
+        a.host_flag = collective ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
         a.seq = ++cx().seq;
         const bool derive_m0 = claim && *claim_known;
         a.need_m0 = derive_m0 ? 0u : 1u;
@@ -128,10 +130,19 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are
             // rank-local and are copied as they are
             CHK(coll_allreduce(cx().lc.d_buf, GKR_CR_WORDS));
-            HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
-                                  hipMemcpyDeviceToHost, cx().stream));
-            HIPCHK(hipStreamSynchronize(cx().stream));
-            words = cx().lc.h_buf;
+            if (cx().lc.comm) {
+                // RCCL: the reduced words reach the host like the un-sharded ones (host-mapped buffer + flag the host
+                // polls): no copy engine round trip and no stream synchronisation per round
+                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round,
+                                   GKR_CR_WORDS + 16, cx().d_flag, a.seq);
+                HIPCHK(hipGetLastError());
+                CHK(wait_flag(a.seq));
+            } else {
+                HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
+                                      hipMemcpyDeviceToHost, cx().stream));
+                HIPCHK(hipStreamSynchronize(cx().stream));
+                words = cx().lc.h_buf;
+            }
         } else {
             CHK(wait_flag(a.seq));
         }
