@@ -628,3 +628,19 @@ def test_rccl_plumbing_world1(gk):
     """RCCL is dlopen()ed, a 1-rank communicator is created and every round's sums go through
     ncclAllReduce (GKRHIP_FORCE_COLLECTIVE): the call sequence of the multi-GPU path on the one GPU we have."""
     _run_shards("rccl", 1, "1,2,5,9", {"GKRHIP_FORCE_COLLECTIVE": "1"})
+
+
+# ---------------------------------------------------------------- compiled caller (what a cgo shim does)
+def test_cpp_abi_harness(gk, tmp_path):
+    """tests/cpp/test_abi_gkr.cpp: the reference's TestGKR (gkr/gkr_test.go:14-78) and the poly / sumcheck entry
+    points driven from compiled code through include/gkrhip.h, checked against the oracle library."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s"])
+    exe = str(tmp_path / "test_abi_gkr")
+    lib, orc = os.path.join(root, "gkr-mimc_amd"), os.path.join(root, "oracle")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "test_abi_gkr.cpp"),
+                           "-L" + lib, "-lgkrhip", "-L" + orc, "-lgkr_oracle", "-Wl,-rpath," + lib, "-Wl,-rpath," + orc,
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-fopenmp"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "abi-harness fails=0" in out.stdout, out.stdout + out.stderr
