@@ -91,6 +91,7 @@ int session_assign(gkrhip_session* s) {  // circuit/assignment.go:12-32
 
 int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.go:21-91
     if (!s->assigned) return fail("session is not assigned");
+    ProofInFlight in_flight;
     const Circuit& c = s->c;
     const int L = (int)c.size(), bN = s->bN;
     std::vector<std::vector<E>> claims(L), qps(L), sc(L);

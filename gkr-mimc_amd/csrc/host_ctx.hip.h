@@ -68,6 +68,7 @@ struct Ctx {
     bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
+    int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     hfr::Lagrange* lag = nullptr;
@@ -88,6 +89,11 @@ struct UseLane {
     Ctx* prev;
     explicit UseLane(Ctx* l) : prev(g_cur) { g_cur = l; }
     ~UseLane() { g_cur = prev; }
+};
+std::atomic<int> g_proofs_in_flight{0};          // gkr.Prove calls currently running (any lane)
+struct ProofInFlight {
+    ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
+    ~ProofInFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }
 };
 std::mutex g_lanes_mu;
 std::vector<Ctx*> g_lanes;                     // every lane, for profile aggregation
@@ -143,6 +149,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_LAT")) cx().lat_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WIDE")) cx().wide_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WT_LATE_LJ")) cx().wt_late_lj = atoi(e);
+    if (const char* e = getenv("GKRHIP_SOLO_BOOST")) cx().solo_boost = atoi(e);
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
@@ -205,6 +212,7 @@ Ctx* lane_create() {
     l->lat_mode = g0.lat_mode;
     l->wide_mode = g0.wide_mode;
     l->wt_late_lj = g0.wt_late_lj;
+    l->solo_boost = g0.solo_boost;
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->lag = g0.lag;

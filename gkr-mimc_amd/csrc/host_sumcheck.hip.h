@@ -32,12 +32,20 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
                   E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
                   bool* claim_known) {
     const size_t n = (size_t)1 << m;
-    const int gT = std::min(cx().g_max, m - 1);           // threads of round 0 = 2^gT
-    const int mU = m - 1 - gT;                         // log2(iterations of round 0)
+    // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the
+    // other lanes' kernels fill the second wave slot.  A proof that is alone on the GPU gets twice the threads for
+    // the rounds that still have two pairs per lane (two workgroups per CU instead of a lone wave per SIMD).
+    const bool solo = cx().solo_boost && !collective && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    const int g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
+    auto threads_log2 = [&](int k) {                   // k = round
+        const int rem = m - 1 - k;                     // log2(pairs of the round)
+        return rem >= g_big + 1 ? g_big : std::min(cx().g_max, rem);
+    };
+    const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
     CHK(stage_coords(q, (size_t)m));
-    DevTable pyrT, pyrU, ks, ss;
+    DevTable pyrT, pyrU[2], ks, ss;                    // pyrU[0]: split at g_max threads, pyrU[1]: at g_big
+    const int gsplit[2] = {std::min(cx().g_max, m - 1), g_big};
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
-    CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
     CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
     CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
     PyramidArgs pa;
@@ -47,12 +55,16 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     pa.max_level = gT;
     pa.seed = to_dev(seed);
     hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
-    if (mU > 0) {
-        pa.out = pyrU.planes();
-        pa.nc = m - gT;                                // q[0 .. m-gT-1]; level L = eq(q[nc-L .. nc-1], .)
-        pa.max_level = mU;
-        pa.seed = to_dev(hfr::ONE);
-        hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << mU, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
+    for (int v = 0; v < (g_big != gsplit[0] ? 2 : 1); v++) {
+        const int mU = m - 1 - gsplit[v];              // log2(iterations of round 0 at this split)
+        CHK(table_alloc(&pyrU[v], (size_t)2 << std::max(mU, 0)));
+        if (mU > 0) {
+            pa.out = pyrU[v].planes();
+            pa.nc = m - gsplit[v];                     // q[0 .. m-g-1]; level L = eq(q[nc-L .. nc-1], .)
+            pa.max_level = mU;
+            pa.seed = to_dev(hfr::ONE);
+            hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << mU, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
+        }
     }
     HIPCHK(hipGetLastError());
     if (collective) CHK(coll_buffers(256));
@@ -61,7 +73,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     E r_prev = hfr::ZERO;
     for (int k = 0; k < m; k++) {
         const size_t P = n >> (k + 1);
-        const int gk = std::min(cx().g_max, m - 1 - k);
+        const int gk = threads_log2(k);
         const int lj = m - 1 - k - gk;                 // log2(iterations)
         CipherRoundArgs a;
         memset(&a, 0, sizeof a);
@@ -73,8 +85,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const size_t offT = ((size_t)1 << gk) - 1;
         a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
         if (lj > 0) {
+            const DevTable& pu = pyrU[gk == gsplit[0] ? 0 : 1];
             const size_t offU = ((size_t)1 << lj) - 1;
-            a.wj = CPlanes{pyrU.base + offU, pyrU.base + pyrU.cap + offU};
+            a.wj = CPlanes{pu.base + offU, pu.base + pu.cap + offU};
         }
         a.P = P;
         a.lg_threads = (unsigned)gk;
@@ -184,7 +197,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
     table_release(&pyrT);
-    table_release(&pyrU);
+    table_release(&pyrU[0]);
+    if (pyrU[1].base) table_release(&pyrU[1]);
     table_release(&ks);
     table_release(&ss);
     return 0;

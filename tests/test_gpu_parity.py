@@ -294,6 +294,8 @@ def test_round_kernel_deferred_reduction_variants(gk):
     _run_case({"GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "99"}, "9,10,13")
     _run_case({"GKRHIP_GMAX": "9", "GKRHIP_WIDE": "0"}, "10,12,13")
     _run_case({"GKRHIP_GMAX": "8", "GKRHIP_LAT": "0", "GKRHIP_WT_LATE_LJ": "3"}, "11,15")
+    # a proof alone on the GPU doubles the threads of its big rounds (two eq-weight splits in one sumcheck); off:
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_SOLO_BOOST": "0"}, "10,11,12")
 
 
 def test_round_kernel_deferred_reduction_carry_corners(gk):
