@@ -18,15 +18,41 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob("$OUT/%s/*/*counter_collection.csv" % c)
     vals = []
     for r in csv.DictReader(open(fs[0])):
-        if r.get("Kernel_Name", "").startswith("void k_fold<2>") and r.get("Counter_Name") == c:
+        if r.get("Kernel_Name", "").startswith("void k_fold<") and r.get("Counter_Name") == c:
             vals.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     big = [v for g, v in vals if g == max(g for g, _ in vals)]
-    top = sorted(big)[-3:]            # the round-0 launches (largest tables) of the proofs in the run
-    res[c + "_KB_per_round0_fold_launch"] = sum(top) / len(top)
+    # the launches on the largest tables (round 0 of the identity layer: one single-table launch per table of the
+    # instance, T = 2 tables, plus the fold_alone micro-benchmark on tables of the same size): average per launch x T
+    res[c + "_KB_per_round0_fold_launch"] = 2 * sum(big) / len(big)
     res[c + "_dispatches_seen"] = len(vals)
 # gfx950: FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM)
 res["traffic_bytes_per_launch"] = (2 * res["FETCH_SIZE_KB_per_round0_fold_launch"] + res["WRITE_SIZE_KB_per_round0_fold_launch"]) * 1024
-res["algorithmic_bytes_per_launch"] = 96 * 2 * (1 << ($BN - 1))
+res["algorithmic_bytes_per_launch"] = 96 * 2 * (1 << ($BN - 1))   # the two table launches of the instance fold
+res["note"] = "k_fold<1>: one launch per table; figures are per instance fold (2 tables), as bench.py's roofline.algorithmic_bytes_per_launch"
 json.dump(res, open("$OUT/summary.json", "w"), indent=1)
 print(json.dumps(res))
+PY
+
+# VALU-side counters of the round kernels (one more pass, SQ block only)
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/SQ -- python3 $ROOT/bench.py --bn $BN --steps 1 --warmup 0 --concurrent 1 --no-cpu-baseline > $OUT/SQ.log 2>&1
+python3 - <<PY
+import csv, glob, json, collections
+fs = glob.glob("$OUT/SQ/*/*counter_collection.csv")
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for r in csv.DictReader(open(fs[0])):
+    k = r.get("Kernel_Name", "")
+    if "k_cipher_round" in k or "k_fold" in k:
+        key = (k.split("(")[0], int(r["Grid_Size"]))
+        agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVES": cnt[key] += 1
+rows = []
+for key in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0))[:8]:
+    a = agg[key]
+    rows.append({"kernel": key[0], "grid_threads": key[1], "dispatches": cnt[key], **{c: a[c] for c in sorted(a)},
+                 "valu_active_fraction_of_wave_cycles": a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"] if a.get("SQ_WAVE_CYCLES") else None,
+                 "valu_insts_per_wave": a["SQ_INSTS_VALU"] / a["SQ_WAVES"] if a.get("SQ_WAVES") else None})
+json.dump({"bn": $BN, "command": "bench.py --bn $BN --steps 1 --warmup 0 --concurrent 1 --no-cpu-baseline", "kernels": rows}, open("$OUT/sq_summary.json", "w"), indent=1)
+print(json.dumps(rows[:3]))
 PY
