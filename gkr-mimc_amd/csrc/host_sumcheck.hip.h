@@ -35,7 +35,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the
     // other lanes' kernels fill the second wave slot.  A proof that is alone on the GPU gets twice the threads for
     // the rounds that still have two pairs per lane (two workgroups per CU instead of a lone wave per SIMD).
-    const bool solo = cx().solo_boost && !collective && g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    const bool solo = cx().solo_boost && !collective &&
+                      (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
     const int g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
     auto threads_log2 = [&](int k) {                   // k = round
         const int rem = m - 1 - k;                     // log2(pairs of the round)
