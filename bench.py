@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--concurrent", type=int, default=5,
                     help="independent proofs in flight (each on its own resident session/lane/stream and, when "
                          "sharded, its own communicator); 1 = strictly one proof at a time")
+    ap.add_argument("--mem-fraction", type=float, default=0.85,
+                    help="share of the free HBM the resident sessions may take (caps --concurrent)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,7 +80,7 @@ def main():
     # every proof in flight keeps its own resident assignment (93 tables of 2^bn elements) plus scratch
     free_b, _total_b = gk.mem_info()
     per_session = (96 if args.circuit == "mimc" else 104) * 32 * (1 << args.bn)
-    nconc = max(1, min(args.concurrent, args.steps, int(0.85 * free_b // per_session)))
+    nconc = max(1, min(args.concurrent, args.steps, int(args.mem_fraction * free_b // per_session)))
     if nconc > 1 and args.steps % nconc and args.steps % (nconc - 1) == 0:
         nconc -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
     if dist is not None:

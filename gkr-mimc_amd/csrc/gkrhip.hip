@@ -520,7 +520,7 @@ static int convert_inplace(uint64_t* data, size_t n, const E& factor) {
     CHK(ensure_ctx());
     if (n == 0) return 0;
     uint4* d = nullptr;
-    HIPCHK(hipMalloc(&d, 32 * n));
+    CHK(staging_alloc(&d, 32 * n));
     HIPCHK(hipMemcpyAsync(d, data, 32 * n, hipMemcpyHostToDevice, cx().stream));
     hipLaunchKernelGGL(k_convert_aos, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d, n, to_dev(factor));
     HIPCHK(hipGetLastError());

@@ -271,6 +271,22 @@ int table_alloc(DevTable* t, size_t cap) {
     t->cap = cap;
     return 0;
 }
+// large transient buffers (boundary staging): same policy as the arena -- on failure give the cached tables
+// back to the driver and retry once
+int staging_alloc(uint4** p, size_t bytes) {
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(g_pool.mu);
+            for (auto& f : g_pool.free_list) (void)hipFree(f.second);
+            g_pool.free_list.clear();
+        }
+        e = hipMalloc((void**)p, bytes);
+        if (e != hipSuccess) return fail("hipMalloc of a %zu-byte staging buffer failed: %s", bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
 void table_release(DevTable* t) {
     if (t->base) {
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -301,7 +317,7 @@ inline Fr to_dev(const E& e) {
 // host AoS -> device planes.  Staged through a device AoS buffer and transposed by k_aos_to_planes.
 int upload_table(DevTable* t, const uint64_t* host_aos, size_t n) {
     uint4* stage = nullptr;
-    HIPCHK(hipMalloc(&stage, 32 * n));
+    CHK(staging_alloc(&stage, 32 * n));
     HIPCHK(hipMemcpyAsync(stage, host_aos, 32 * n, hipMemcpyHostToDevice, cx().stream));
     hipLaunchKernelGGL(k_aos_to_planes, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n);
     HIPCHK(hipGetLastError());
@@ -311,7 +327,7 @@ int upload_table(DevTable* t, const uint64_t* host_aos, size_t n) {
 }
 int download_table(const DevTable* t, uint64_t* host_aos, size_t n) {
     uint4* stage = nullptr;
-    HIPCHK(hipMalloc(&stage, 32 * n));
+    CHK(staging_alloc(&stage, 32 * n));
     hipLaunchKernelGGL(k_planes_to_aos, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->cplanes(), stage, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_aos, stage, 32 * n, hipMemcpyDeviceToHost, cx().stream));
