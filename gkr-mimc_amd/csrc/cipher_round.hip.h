@@ -199,51 +199,51 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
             // hipcc from interleaving the independent products (which only raises register pressure:
             // the kernel is VALU-bound and each product already saturates the issue slot).
 #define GKR_SB() do { if (!LAT) __builtin_amdgcn_sched_barrier(0); } while (0)
-            Fr p, r2, A, B, C, D, v, w, t, t2, D2;
+            // Monomials through a 2 x 4 product table: {W u^4, W d^4} x {u^3, u^2 d, u d^2, d^3} gives all eight
+            // W u^(7-j) d^j with ten products in front of the final ones (u^2, d^2; the four cubics; u^4, d^4; W.).
+            Fr p, r2, A, B, C, D, U4, D4, X0, X1, t, t2;
             if (LAT) {
                 // latency variant: products issued in independent pairs with interleaved instruction streams
                 fr_mont_mul2_raw(p, r2, u, u, d, d);
                 fr_mont_mul2_raw(A, B, p, u, p, d);          // u^3, u^2 d
                 fr_mont_mul2_raw(C, D, u, r2, r2, d);        // u d^2, d^3
-                fr_mont_mul2_raw(v, w, W, u, W, d);
+                fr_mont_mul2_raw(U4, D4, p, p, r2, r2);      // u^4, d^4
+                fr_mont_mul2_raw(X0, X1, W, U4, W, D4);
                 if (a.need_m0) {
-                    fr_mont_mul2_raw(t, t2, A, A, A, B);
-                    fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                    fr_mont_mul2_raw(t, t2, X0, A, X0, B);
                     acc_add_raw(acc[0], t);                  // W u^7
                 } else {
-                    t2 = fr_mont_mul_raw(v, fr_mont_mul_raw(A, B));
+                    t2 = fr_mont_mul_raw(X0, B);
                 }
                 acc_add_raw(acc[1], t2);                     // W u^6 d
-                fr_mont_mul2_raw(t, t2, B, B, A, D);
-                fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                fr_mont_mul2_raw(t, t2, X0, C, X0, D);
                 acc_add_raw(acc[2], t);                      // W u^5 d^2
                 acc_add_raw(acc[3], t2);                     // W u^4 d^3
-                fr_mont_mul2_raw(t, t2, C, C, C, D);
-                fr_mont_mul2_raw(t, t2, v, t, v, t2);
+                fr_mont_mul2_raw(t, t2, X1, A, X1, B);
                 acc_add_raw(acc[4], t);                      // W u^3 d^4
                 acc_add_raw(acc[5], t2);                     // W u^2 d^5
-                D2 = fr_mont_mul_raw(D, D);                  // d^6
-                fr_mont_mul2_raw(t, t2, v, D2, w, D2);
+                fr_mont_mul2_raw(t, t2, X1, C, X1, D);
                 acc_add_raw(acc[6], t);                      // W u d^6
                 acc_add_raw(acc[7], t2);                     // W d^7
             } else {
-            p = fr_mont_mul_raw(u, u);  GKR_SB();
-            r2 = fr_mont_mul_raw(d, d); GKR_SB();
-            A = fr_mont_mul_raw(p, u);  GKR_SB();   // u^3
-            B = fr_mont_mul_raw(p, d);  GKR_SB();   // u^2 d
-            C = fr_mont_mul_raw(u, r2); GKR_SB();   // u d^2
-            D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
-            v = fr_mont_mul_raw(W, u);  GKR_SB();
-            w = fr_mont_mul_raw(W, d);  GKR_SB();
-            if (a.need_m0) { t = fr_mont_mul_raw(A, A); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[0], t); GKR_SB(); }  // W u^7
-            t = fr_mont_mul_raw(A, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[1], t); GKR_SB();  // W u^6 d
-            t = fr_mont_mul_raw(B, B); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[2], t); GKR_SB();  // W u^5 d^2
-            t = fr_mont_mul_raw(A, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[3], t); GKR_SB();  // W u^4 d^3
-            t = fr_mont_mul_raw(C, C); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[4], t); GKR_SB();  // W u^3 d^4
-            t = fr_mont_mul_raw(C, D); GKR_SB(); t = fr_mont_mul_raw(v, t); GKR_SB(); acc_add_raw(acc[5], t); GKR_SB();  // W u^2 d^5
-            D2 = fr_mont_mul_raw(D, D); GKR_SB();                                                                      // d^6
-            t = fr_mont_mul_raw(v, D2); GKR_SB(); acc_add_raw(acc[6], t); GKR_SB();                                      // W u d^6
-            t = fr_mont_mul_raw(w, D2); GKR_SB(); acc_add_raw(acc[7], t); GKR_SB();                                      // W d^7
+            p = fr_mont_mul_raw(u, u);   GKR_SB();
+            r2 = fr_mont_mul_raw(d, d);  GKR_SB();
+            A = fr_mont_mul_raw(p, u);   GKR_SB();   // u^3
+            B = fr_mont_mul_raw(p, d);   GKR_SB();   // u^2 d
+            C = fr_mont_mul_raw(u, r2);  GKR_SB();   // u d^2
+            D = fr_mont_mul_raw(r2, d);  GKR_SB();   // d^3
+            U4 = fr_mont_mul_raw(p, p);  GKR_SB();   // u^4
+            D4 = fr_mont_mul_raw(r2, r2); GKR_SB();  // d^4
+            X0 = fr_mont_mul_raw(W, U4); GKR_SB();
+            X1 = fr_mont_mul_raw(W, D4); GKR_SB();
+            if (a.need_m0) { t = fr_mont_mul_raw(X0, A); GKR_SB(); acc_add_raw(acc[0], t); GKR_SB(); }  // W u^7
+            t = fr_mont_mul_raw(X0, B); GKR_SB(); acc_add_raw(acc[1], t); GKR_SB();  // W u^6 d
+            t = fr_mont_mul_raw(X0, C); GKR_SB(); acc_add_raw(acc[2], t); GKR_SB();  // W u^5 d^2
+            t = fr_mont_mul_raw(X0, D); GKR_SB(); acc_add_raw(acc[3], t); GKR_SB();  // W u^4 d^3
+            t = fr_mont_mul_raw(X1, A); GKR_SB(); acc_add_raw(acc[4], t); GKR_SB();  // W u^3 d^4
+            t = fr_mont_mul_raw(X1, B); GKR_SB(); acc_add_raw(acc[5], t); GKR_SB();  // W u^2 d^5
+            t = fr_mont_mul_raw(X1, C); GKR_SB(); acc_add_raw(acc[6], t); GKR_SB();  // W u d^6
+            t = fr_mont_mul_raw(X1, D); GKR_SB(); acc_add_raw(acc[7], t); GKR_SB();  // W d^7
             }
 #undef GKR_SB
             if (P == 1) {
@@ -364,25 +364,28 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             Fr W = ld_fr(a.wj.lo, a.wj.hi, j);
             if (!WT_LATE) W = fr_mont_mul_raw(W, wt);
 #define GKR_SB() __builtin_amdgcn_sched_barrier(0)
-            Fr p, r2, A, B, C, D, v, w, t, D2;
+            Fr p, r2, A, B, C, D, U4, D4, X0, X1;
             u32 T[FR_WIDE_LIMBS];
-            p = fr_mont_mul_raw(u, u);  GKR_SB();
-            r2 = fr_mont_mul_raw(d, d); GKR_SB();
-            A = fr_mont_mul_raw(p, u);  GKR_SB();   // u^3
-            B = fr_mont_mul_raw(p, d);  GKR_SB();   // u^2 d
-            C = fr_mont_mul_raw(u, r2); GKR_SB();   // u d^2
-            D = fr_mont_mul_raw(r2, d); GKR_SB();   // d^3
-            v = fr_mont_mul_raw(W, u);  GKR_SB();
-            w = fr_mont_mul_raw(W, d);  GKR_SB();
-            // the LDS-resident sums are fetched before the product that precedes their MAC
-            wide_lds_load(T, sh, 0); t = fr_mont_mul_raw(A, B); GKR_SB(); fr_mac_wide(T, v, t); GKR_SB(); wide_lds_store(sh, 0, T); GKR_SB();  // W u^6 d
-            wide_lds_load(T, sh, 1); t = fr_mont_mul_raw(B, B); GKR_SB(); fr_mac_wide(T, v, t); GKR_SB(); wide_lds_store(sh, 1, T); GKR_SB();  // W u^5 d^2
-            wide_lds_load(T, sh, 2); t = fr_mont_mul_raw(A, D); GKR_SB(); fr_mac_wide(T, v, t); GKR_SB(); wide_lds_store(sh, 2, T); GKR_SB();  // W u^4 d^3
-            t = fr_mont_mul_raw(C, C); GKR_SB(); fr_mac_wide(R[0], v, t); GKR_SB();   // W u^3 d^4
-            t = fr_mont_mul_raw(C, D); GKR_SB(); fr_mac_wide(R[1], v, t); GKR_SB();   // W u^2 d^5
-            D2 = fr_mont_mul_raw(D, D); GKR_SB();                                     // d^6
-            fr_mac_wide(R[2], v, D2); GKR_SB();                                       // W u d^6
-            fr_mac_wide(R[3], w, D2); GKR_SB();                                       // W d^7
+            // ordered for short lifetimes: u^2 and its dependants first, then d^2 and its dependants
+            p = fr_mont_mul_raw(u, u);    GKR_SB();
+            U4 = fr_mont_mul_raw(p, p);   GKR_SB();   // u^4
+            X0 = fr_mont_mul_raw(W, U4);  GKR_SB();
+            A = fr_mont_mul_raw(p, u);    GKR_SB();   // u^3
+            B = fr_mont_mul_raw(p, d);    GKR_SB();   // u^2 d
+            r2 = fr_mont_mul_raw(d, d);   GKR_SB();
+            D4 = fr_mont_mul_raw(r2, r2); GKR_SB();   // d^4
+            X1 = fr_mont_mul_raw(W, D4);  GKR_SB();
+            C = fr_mont_mul_raw(u, r2);   GKR_SB();   // u d^2
+            D = fr_mont_mul_raw(r2, d);   GKR_SB();   // d^3
+            // {W u^4, W d^4} x {u^3, u^2 d, u d^2, d^3}: the seven closing products are wide MACs; the LDS-resident
+            // sums are fetched ahead of their MAC
+            wide_lds_load(T, sh, 0); fr_mac_wide(T, X0, B); GKR_SB(); wide_lds_store(sh, 0, T); GKR_SB();  // W u^6 d
+            wide_lds_load(T, sh, 1); fr_mac_wide(T, X0, C); GKR_SB(); wide_lds_store(sh, 1, T); GKR_SB();  // W u^5 d^2
+            wide_lds_load(T, sh, 2); fr_mac_wide(T, X0, D); GKR_SB(); wide_lds_store(sh, 2, T); GKR_SB();  // W u^4 d^3
+            fr_mac_wide(R[0], X1, A); GKR_SB();   // W u^3 d^4
+            fr_mac_wide(R[1], X1, B); GKR_SB();   // W u^2 d^5
+            fr_mac_wide(R[2], X1, C); GKR_SB();   // W u d^6
+            fr_mac_wide(R[3], X1, D); GKR_SB();   // W d^7
 #undef GKR_SB
         }
     }

@@ -136,7 +136,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             HIPCHK(hipEventRecord(e1, cx().stream));
             cx().prof.peval_ev.emplace_back(e0, e1);
             cx().prof.peval_launches++;
-            cx().prof.peval_modmuls += ((derive_m0 ? 21.0 : 23.0) + (lj > 0 && !late ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
+            cx().prof.peval_modmuls += ((derive_m0 ? 17.0 : 18.0) + (lj > 0 && !late ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
