@@ -63,7 +63,7 @@ struct CipherRoundArgs {
     unsigned lg_threads;   // log2(threads)
     Fr r;                  // previous round's challenge (FOLD)
     Fr ark;
-    unsigned long long* partials;   // [gridDim.x][GKR_CR_WORDS]
+    unsigned long long* partials;   // [GKR_CR_WORDS] accumulator shared by the blocks (atomic adds); zero at launch, reset by the last block
     unsigned int* counter;          // arrival counter, zero at launch, reset by the last block
     unsigned long long* host_out;   // host-mapped: GKR_CR_WORDS sums, then 8 x u64 x 4 tail elements
     unsigned int* host_flag;        // host-mapped: set to `seq` when host_out is complete
@@ -91,10 +91,9 @@ __device__ __forceinline__ void acc_add_raw(Acc9& a, const Fr& x) {
         : "vcc");
 }
 
-// last-arriving block sums the block partials and publishes them to the host (agent-scope release by lane 0
-// after the block's stores have drained; acquire before re-reading)
-__device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, unsigned long long (*red)[GKR_CR_WORDS] /* [3] */,
-                                                     unsigned int* s_last) {
+// every block has added its sums into the shared accumulator; the last-arriving block publishes it to the host
+// (agent-scope release by lane 0 after the block's atomics have drained; acquire before re-reading)
+__device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, unsigned int* s_last) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -110,14 +109,10 @@ __device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, u
     }
     __syncthreads();
     if (*s_last) {
-        if (threadIdx.x < 3 * GKR_CR_WORDS) {   // three strided passes over the blocks, combined through LDS
-            const unsigned int w = threadIdx.x % GKR_CR_WORDS, part = threadIdx.x / GKR_CR_WORDS;
-            unsigned long long s = 0;
-            for (unsigned int b = part; b < gridDim.x; b += 3) s += a.partials[(size_t)b * GKR_CR_WORDS + w];
-            red[part][w] = s;
+        if (threadIdx.x < GKR_CR_WORDS) {
+            a.host_out[threadIdx.x] = __hip_atomic_load(a.partials + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.partials[threadIdx.x] = 0;            // ready for the next launch on this lane
         }
-        __syncthreads();
-        if (threadIdx.x < GKR_CR_WORDS) a.host_out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x];
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -142,7 +137,6 @@ __global__ void __launch_bounds__(128) k_publish_words(const unsigned long long*
 // interleaves the independent products of the monomial schedule, and a 512-VGPR budget.
 template <bool FOLD, bool HAS_WJ, bool LAT>
 __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
-    __shared__ unsigned long long red[3][GKR_CR_WORDS];
     __shared__ unsigned int s_last;
     Acc9 acc[GKR_CR_NSUM];
 #pragma unroll
@@ -262,8 +256,8 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     }
 
     // ---- block reduction of the limb words (exact integer sums), one partial per block
-    block_reduce_acc<GKR_CR_NSUM, 18>(acc, a.partials + (size_t)blockIdx.x * GKR_CR_WORDS);
-    cipher_round_publish(a, red, &s_last);
+    block_reduce_acc<GKR_CR_NSUM, 18, true>(acc, a.partials);
+    cipher_round_publish(a, &s_last);
 }
 
 template <bool FOLD, bool HAS_WJ>
@@ -424,6 +418,6 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
 #pragma unroll
     for (int t = 0; t < GKR_CR_NSUM - 1 - GKR_WIDE_LDS; t++) finish(acc[1 + GKR_WIDE_LDS + t], R[t]);
     __syncthreads();                                                // tr aliases the LDS accumulators
-    block_reduce_acc_buf<GKR_CR_NSUM, 18>(acc, a.partials + (size_t)blockIdx.x * GKR_CR_WORDS, sh.tr, sh.red);
-    cipher_round_publish(a, sh.red, &s_last);
+    block_reduce_acc_buf<GKR_CR_NSUM, 18, true>(acc, a.partials, sh.tr, sh.red);
+    cipher_round_publish(a, &s_last);
 }

@@ -45,7 +45,8 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
-    unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums
+    unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums (reference-shaped evaluator)
+    unsigned long long* d_racc = nullptr;      // GKR_CR_WORDS-word accumulator of the fused round kernels (zero between launches)
     unsigned long long* d_sums = nullptr;      // reduced sums (device)
     unsigned long long* h_sums = nullptr;      // pinned
     uint4* d_small = nullptr;                  // gather buffer (AoS)
@@ -170,6 +171,8 @@ int lane_alloc() {
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&cx().d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
     HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));
+    HIPCHK(hipMalloc(&cx().d_racc, sizeof(unsigned long long) * GKR_CR_WORDS));
+    HIPCHK(hipMemset(cx().d_racc, 0, sizeof(unsigned long long) * GKR_CR_WORDS));
     HIPCHK(hipHostMalloc(&cx().h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
     HIPCHK(hipMalloc(&cx().d_small, sizeof(uint4) * 2 * 8));
     HIPCHK(hipHostMalloc(&cx().h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));
@@ -186,6 +189,7 @@ int lane_alloc() {
 void lane_free() {
     (void)hipStreamSynchronize(cx().stream);
     (void)hipFree(cx().d_partials);
+    (void)hipFree(cx().d_racc);
     (void)hipFree(cx().d_sums);
     (void)hipHostFree(cx().h_sums);
     (void)hipFree(cx().d_small);

@@ -68,6 +68,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
     }
     HIPCHK(hipGetLastError());
+    // the shared accumulator and the arrival counter are zero between launches; make sure of it after a failed call
+    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * GKR_CR_WORDS, cx().stream));
+    HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     if (collective) CHK(coll_buffers(256));
 
     static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
@@ -94,7 +97,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.lg_threads = (unsigned)gk;
         a.r = to_dev(r_prev);
         a.ark = to_dev(ark);
-        a.partials = cx().d_partials;
+        a.partials = cx().d_racc;
         a.counter = cx().d_counter;
         a.host_out = collective ? cx().lc.d_buf : cx().d_round;      // sharded: sums stay on the device for the all-reduce
         // sharded: the kernel's own completion flag lands in a spare word of the exchange buffer (the host is

@@ -234,7 +234,9 @@ __device__ __forceinline__ void acc_add(Acc9& a, const Fr& x) {
 // that the column readers fall on different banks), then 4*CH threads each add the 64 lanes of one wave
 // for one word.  (A cross-lane butterfly needs 6 dependent ds_bpermute round trips per word; hipcc
 // serialises them, ~20 us per launch for 72 words -- more than the arithmetic of a small round.)
-template <int NS, int CH>
+// ATOMIC: the block adds its NW sums into one global accumulator (`out`, NW words shared by all blocks; exact
+// integer adds commute) instead of writing a per-block partial
+template <int NS, int CH, bool ATOMIC = false>
 __device__ __forceinline__ void block_reduce_acc_buf(const Acc9 (&acc)[NS], unsigned long long* __restrict__ out,
                                                      u32 (*tr)[GKR_BLOCK + 1] /* [CH] */,
                                                      unsigned long long (*red)[NS * GKR_ACC_WORDS] /* [GKR_BLOCK/64] */) {
@@ -264,14 +266,18 @@ __device__ __forceinline__ void block_reduce_acc_buf(const Acc9 (&acc)[NS], unsi
         unsigned long long s = 0;
 #pragma unroll
         for (int q = 0; q < GKR_BLOCK / 64; q++) s += red[q][tid];
-        out[tid] = s;
+        if (ATOMIC) {
+            if (s) (void)__hip_atomic_fetch_add(out + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            out[tid] = s;
+        }
     }
 }
-template <int NS, int CH>
+template <int NS, int CH, bool ATOMIC = false>
 __device__ __forceinline__ void block_reduce_acc(const Acc9 (&acc)[NS], unsigned long long* __restrict__ out) {
     __shared__ u32 tr[CH][GKR_BLOCK + 1];
     __shared__ unsigned long long red[GKR_BLOCK / 64][NS * GKR_ACC_WORDS];
-    block_reduce_acc_buf<NS, CH>(acc, out, tr, red);
+    block_reduce_acc_buf<NS, CH, ATOMIC>(acc, out, tr, red);
 }
 
 struct PartialEvalArgs {
