@@ -219,12 +219,17 @@ def gen_mul2():
 # accumulator limb A[c] with one more MAD (x1), so the cost is 64+15 MAD/ADDC pairs against 136.
 # ------------------------------------------------------------------------------------------------
 def gen_mac_wide():
-    dev = host = "    u64 acc = (u64)a.v[0] * b.v[0] + A[0];\n    u32 ovf;\n"
-    dev += "    A[0] = FR_LIMB_COPY((u32)acc);\n    acc >>= 32;\n"
-    host += "    A[0] = (u32)acc;\n    acc >>= 32;\n"
+    """Device: the plain product a*b column by column (64 MAD/ADDC pairs, as in the multiplication without its
+    Montgomery half); every finished limb is added straight into the accumulator limb by ONE carry-chained
+    add whose carry lives in an SGPR pair (VCC belongs to the column arithmetic).  Host: same columns, u64."""
+    dev = "    u64 acc = (u64)a.v[0] * b.v[0];\n    u32 ovf;\n    unsigned long long sc;\n"
+    dev += '    asm("v_add_co_u32_e64 %0, %1, %0, %2" : "+v"(A[0]), "=&s"(sc) : "v"((u32)acc));\n'
+    dev += "    acc >>= 32;\n"
+    host = "    u64 acc = (u64)a.v[0] * b.v[0];\n    u32 ovf;\n    u64 cy;\n"
+    host += "    cy = (u64)A[0] + (u32)acc;\n    A[0] = (u32)cy;\n    cy >>= 32;\n    acc >>= 32;\n"
     for c in range(1, 2 * NL - 1):
         lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
-        prods = [(("A", c), ("one", 0))]
+        prods = []
         for i in range(lo_i, hi_i + 1):
             prods.append((("a", i), ("b", c - i)))
         pos = 0
@@ -232,14 +237,16 @@ def gen_mac_wide():
             dev += emit_asm(ch, pos)
             host += emit_portable(ch, pos)
             pos += len(ch)
-        dev += "    A[%d] = FR_LIMB_COPY((u32)acc);\n" % c
-        host += "    A[%d] = (u32)acc;\n" % c
+        dev += '    asm("v_addc_co_u32_e64 %%0, %%1, %%0, %%2, %%1" : "+v"(A[%d]), "+s"(sc) : "v"((u32)acc));\n' % c
+        host += "    cy += (u64)A[%d] + (u32)acc;\n    A[%d] = (u32)cy;\n    cy >>= 32;\n" % (c, c)
         sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
         dev += sh
         host += sh
-    fin = ("    acc += ((u64)A[16] << 32) | A[15];\n"
-           "    A[15] = (u32)acc;\n    A[16] = (u32)(acc >> 32);\n")
-    return dev + fin, host + fin
+    # the last column's carry (acc < 2^32 now) and the chain carry go into limbs 15 and 16
+    dev += '    asm("v_addc_co_u32_e64 %0, %1, %0, %2, %1" : "+v"(A[15]), "+s"(sc) : "v"((u32)acc));\n'
+    dev += '    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(A[16]), "+s"(sc));\n'
+    host += "    cy += (u64)A[15] + (u32)acc;\n    A[15] = (u32)cy;\n    cy >>= 32;\n    A[16] += (u32)cy;\n"
+    return dev, host
 
 
 def main():
