@@ -62,6 +62,7 @@ struct CipherRoundArgs {
     size_t P;              // index pairs this round
     unsigned lg_threads;   // log2(threads)
     Fr r;                  // previous round's challenge (FOLD)
+    Fr r_lo;               // r * 2^-128 mod q: with r, the split images fr_mul_const2_raw takes
     Fr ark;
     unsigned long long* partials;   // [GKR_CR_WORDS] accumulator shared by the blocks (atomic adds); zero at launch, reset by the last block
     unsigned int* counter;          // arrival counter, zero at launch, reset by the last block
@@ -170,10 +171,12 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
                     slo = fr_add(s0, fr_reduce_once(f2));
                     shi = fr_add(s1, fr_reduce_once(f3));
                 } else {
-                klo = fr_add(k0, fr_mul(fr_sub(k2, k0), r));   // poly/multilin.go:32-34
-                khi = fr_add(k1, fr_mul(fr_sub(k3, k1), r));
-                slo = fr_add(s0, fr_mul(fr_sub(s2, s0), r));
-                shi = fr_add(s1, fr_mul(fr_sub(s3, s1), r));
+                // poly/multilin.go:32-34; the challenge is a launch-wide constant: 96-product multiplication, < 3q
+                const Fr ra = a.r_lo;
+                klo = fr_reduce_lt4q(fr_add_raw(k0, fr_mul_const2_raw(fr_sub(k2, k0), ra, r)));
+                khi = fr_reduce_lt4q(fr_add_raw(k1, fr_mul_const2_raw(fr_sub(k3, k1), ra, r)));
+                slo = fr_reduce_lt4q(fr_add_raw(s0, fr_mul_const2_raw(fr_sub(s2, s0), ra, r)));
+                shi = fr_reduce_lt4q(fr_add_raw(s1, fr_mul_const2_raw(fr_sub(s3, s1), ra, r)));
                 }
                 st_fr(a.k_dst.lo, a.k_dst.hi, x, klo);
                 st_fr(a.k_dst.lo, a.k_dst.hi, x + P, khi);
@@ -339,10 +342,12 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
                 const Fr k1 = ld_fr(a.k_src.lo, a.k_src.hi, x + P), k3 = ld_fr(a.k_src.lo, a.k_src.hi, x + 3 * P);
                 const Fr s0 = ld_fr(a.s_src.lo, a.s_src.hi, x), s2 = ld_fr(a.s_src.lo, a.s_src.hi, x + 2 * P);
                 const Fr s1 = ld_fr(a.s_src.lo, a.s_src.hi, x + P), s3 = ld_fr(a.s_src.lo, a.s_src.hi, x + 3 * P);
-                klo = fr_add(k0, fr_mul(fr_sub(k2, k0), r));   // poly/multilin.go:32-34
-                khi = fr_add(k1, fr_mul(fr_sub(k3, k1), r));
-                slo = fr_add(s0, fr_mul(fr_sub(s2, s0), r));
-                shi = fr_add(s1, fr_mul(fr_sub(s3, s1), r));
+                // poly/multilin.go:32-34; the challenge is a launch-wide constant: 96-product multiplication, < 3q
+                const Fr ra = a.r_lo;
+                klo = fr_reduce_lt4q(fr_add_raw(k0, fr_mul_const2_raw(fr_sub(k2, k0), ra, r)));
+                khi = fr_reduce_lt4q(fr_add_raw(k1, fr_mul_const2_raw(fr_sub(k3, k1), ra, r)));
+                slo = fr_reduce_lt4q(fr_add_raw(s0, fr_mul_const2_raw(fr_sub(s2, s0), ra, r)));
+                shi = fr_reduce_lt4q(fr_add_raw(s1, fr_mul_const2_raw(fr_sub(s3, s1), ra, r)));
                 st_fr(a.k_dst.lo, a.k_dst.hi, x, klo);
                 st_fr(a.k_dst.lo, a.k_dst.hi, x + P, khi);
                 st_fr(a.s_dst.lo, a.s_dst.hi, x, slo);

@@ -200,6 +200,42 @@ FR_HD Fr fr_canon_lt16q(const u32 (&w)[9]) {
     return r;
 }
 
+// Product with a launch-wide constant c (the fold challenge of a round), c given by the host as the pair
+// ca = c * 2^-128 mod q, cb = c (both canonical, Montgomery form like every element):
+//     a * c / 2^256 == (a_lo * ca + a_hi * cb) / 2^128  (mod q),   a = a_lo + 2^128 a_hi,
+// so four Montgomery steps suffice (96 limb products instead of 128).  a canonical; result < 3q.
+FR_HD Fr fr_mul_const2_raw(const Fr& a, const Fr& ca, const Fr& cb) {
+    Fr r;
+#include "fr_mulc2_gen.inc"
+    return r;
+}
+// a + b without reduction (the caller knows the bound of the sum)
+FR_HD Fr fr_add_raw(const Fr& a, const Fr& b) {
+    Fr s;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s.v[j] = fr_addc(a.v[j], b.v[j], c, &c);
+    return s;
+}
+// canonical residue of t < 4q (< 2^256): subtract 2q, then q, when they fit
+FR_HD Fr fr_reduce_lt4q(const Fr& t) {
+    const u32 q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
+    Fr x = t;
+#pragma unroll
+    for (int s = 1; s >= 0; s--) {
+        u32 dd[8];
+        u32 br = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 qs = s ? ((q[j] << 1) | (j ? (q[j - 1] >> 31) : 0u)) : q[j];
+            dd[j] = fr_subb(x.v[j], qs, br, &br);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) x.v[j] = br ? x.v[j] : dd[j];
+    }
+    return x;
+}
+
 // canonical product
 FR_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_reduce_once(fr_mont_mul_raw(a, b)); }
 FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_mul_raw(a, a)); }

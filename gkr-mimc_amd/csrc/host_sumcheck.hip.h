@@ -96,6 +96,10 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.P = P;
         a.lg_threads = (unsigned)gk;
         a.r = to_dev(r_prev);
+        {
+            const E two128 = {{0, 0, 1, 0}};                 // the plain integer 2^128: mul divides by 2^256
+            a.r_lo = to_dev(hfr::mul(r_prev, two128));       // r * 2^-128 (fr_mul_const2_raw's second image)
+        }
         a.ark = to_dev(ark);
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;

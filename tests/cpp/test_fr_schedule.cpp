@@ -98,6 +98,26 @@ int main() {
         }
         n++;
     }
+    // multiplication by a launch-wide constant through the split images (ca = c * 2^-128, cb = c): the fold product
+    {
+        ofr_t two128; memset(&two128, 0, sizeof two128); two128.l[2] = 1;      // the plain integer 2^128 as limbs
+        for (int it = 0; it < 200000; it++) {
+            Fr a = canon(gen(it % 5)), c = canon(gen((it / 5) % 5)), k0 = canon(gen((it / 25) % 5));
+            if (it == 0) { a = qm1; c = qm1; k0 = qm1; }
+            ofr_t oa, oc, oca, want; memcpy(&oa, &a, 32); memcpy(&oc, &c, 32);
+            oracle_fr_mul(&oca, &oc, &two128);                                  // c * 2^128 / 2^256 = c * 2^-128
+            Fr ca; memcpy(&ca, &oca, 32);
+            oracle_fr_mul(&want, &oa, &oc);
+            Fr raw = fr_mul_const2_raw(a, ca, c);
+            // raw < 3q; k0 + raw < 4q reduces to k0 + a*c
+            ofr_t ok0, sum; memcpy(&ok0, &k0, 32); oracle_fr_add(&sum, &ok0, &want);
+            Fr t; u32 cy = 0; for (int j = 0; j < 8; j++) t.v[j] = fr_addc(k0.v[j], raw.v[j], cy, &cy);
+            if (cy) bad++;
+            Fr got = fr_reduce_lt4q(t);
+            if (memcmp(&got, &sum, 32)) bad++;
+            n++;
+        }
+    }
     printf("cases=%ld bad=%ld\n", n, bad);
     return bad ? 1 : 0;
 }

@@ -27,7 +27,7 @@ def cexpr(o):
     k, i = o
     if k == "one":
         return "1u"
-    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]"}[k] % i
+    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]", "ca": "ca.v[%d]", "cb": "cb.v[%d]"}[k] % i
 
 
 def emit_asm(products, pos0):
@@ -50,7 +50,7 @@ def emit_asm(products, pos0):
         else:
             lines.append("v_addc_co_u32_e32 %1, vcc, 0, %1, vcc")
     ovf = '"=&v"(ovf)' if inits else '"+v"(ovf)'
-    ins = ", ".join('"%s"(%s)' % ("s" if o[0] == "q" else "v", cexpr(o)) for o in ops)
+    ins = ", ".join('"%s"(%s)' % ("s" if o[0] in ("q", "ca", "cb") else "v", cexpr(o)) for o in ops)
     body = '"' + '\\n\\t"\n        "'.join(lines) + '"'
     assert len(ops) + 2 <= 30
     return '    asm(%s\n        : "+v"(acc), %s\n        : %s\n        : "vcc");\n' % (body, ovf, ins)
@@ -249,7 +249,63 @@ def gen_mac_wide():
     return dev, host
 
 
+# ------------------------------------------------------------------------------------------------
+# multiplication by a launch-wide constant c (the fold challenge): with x = x_lo + 2^128 x_hi and the two
+# host-prepared images ca = c * 2^-128 mod q, cb = c (both uniform, in SGPRs),
+#     x * c / 2^256  ==  (x_lo * ca + x_hi * cb) / 2^128   (mod q)
+# so only FOUR Montgomery steps are needed: 32 + 32 + 32 limb products instead of 64 + 64.  Result < 3q.
+# ------------------------------------------------------------------------------------------------
+def gen_mul_const2():
+    H = NL // 2
+    dev = host = "    u64 acc = (u64)a.v[0] * ca.v[0];\n    u32 ovf;\n"
+    ncol = H + NL - 1            # columns 0 .. 10 carry products; limbs H .. H+7 are the result
+    for c in range(ncol):
+        prods = []
+        for i in range(H):
+            j = c - i
+            if 0 <= j < NL:
+                if not (c == 0 and i == 0):
+                    prods.append((("a", i), ("ca", j)))
+                prods.append((("a", H + i), ("cb", j)))
+        for i in range(H):
+            j = c - i
+            if 0 <= j < NL and not (c < H and i == c):
+                prods.append((("m", i), ("q", j)))
+        pos = 0
+        # column 0 starts from the exact product a0*ca0: its first listed product must use the carry-tracking form
+        first = True
+        for ch in split(prods, pos):
+            if c == 0 and first:
+                dev += emit_asm(ch, 0)
+                host += emit_portable(ch, 0)
+            else:
+                dev += emit_asm(ch, pos if pos else (0 if c else 1))
+                host += emit_portable(ch, pos if pos else (0 if c else 1))
+            first = False
+            pos += len(ch)
+        if c < H:
+            t = "    const u32 m%d = (u32)acc * FR_QINV32;\n" % c
+            dev += t + emit_asm([(("m", c), ("q", 0))], max(pos, 1))
+            host += t + emit_portable([(("m", c), ("q", 0))], max(pos, 1))
+        else:
+            host += "    r.v[%d] = (u32)acc;\n" % (c - H)
+            dev += '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (c - H)
+        sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
+        dev += sh
+        host += sh
+    fin = "    r.v[%d] = (u32)acc;\n" % (NL - 1)
+    dfin = '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (NL - 1)
+    return dev + dfin, host + fin
+
+
 def main():
+    outc = os.path.join(os.path.dirname(OUT), "fr_mulc2_gen.inc")
+    dev, host = gen_mul_const2()
+    with open(outc, "w") as f:
+        f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Body of fr_mul_const2() in fr_bn254.h:\n"
+                "// r = (a_lo * ca + a_hi * cb) / 2^128 mod q with four Montgomery steps; r < 3q.\n")
+        f.write("#if defined(__HIP_DEVICE_COMPILE__)\n" + dev + "#else\n" + host + "#endif\n")
+    print("wrote", outc)
     outw = os.path.join(os.path.dirname(OUT), "fr_mac_wide_gen.inc")
     dev, host = gen_mac_wide()
     with open(outw, "w") as f:
