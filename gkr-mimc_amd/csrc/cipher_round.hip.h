@@ -32,6 +32,7 @@
 // ------------------------------------------------------------------------------------------------
 struct PyramidArgs {
     Planes out;
+    Planes out2;      // optional (lo == nullptr: none): every entry times 2^-128, the second image fr_mul_const2_raw takes
     const Fr* q;      // nc coordinates
     int nc, max_level;
     Fr seed;          // level-0 value (1, or the multiplier)
@@ -40,14 +41,21 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) 
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ((size_t)1 << a.max_level)) return;
     const Fr one = fr_one();
+    const Fr two128 = {{0u, 0u, 0u, 0u, 1u, 0u, 0u, 0u}};   // the plain integer 2^128: a Montgomery product with it divides by 2^128
     Fr cur = a.seed;
-    if (idx == 0) st_fr(a.out.lo, a.out.hi, 0, cur);
+    if (idx == 0) {
+        st_fr(a.out.lo, a.out.hi, 0, cur);
+        if (a.out2.lo) st_fr(a.out2.lo, a.out2.hi, 0, fr_mul(cur, two128));
+    }
     for (int s = 1; s <= a.max_level; s++) {
         const Fr qc = a.q[a.nc - s];
         const bool bit = (idx >> (s - 1)) & 1;
         const Fr f = bit ? qc : fr_sub(one, qc);
         cur = fr_mul(cur, f);
-        if (idx < ((size_t)1 << s)) st_fr(a.out.lo, a.out.hi, (((size_t)1 << s) - 1) + idx, cur);
+        if (idx < ((size_t)1 << s)) {
+            st_fr(a.out.lo, a.out.hi, (((size_t)1 << s) - 1) + idx, cur);
+            if (a.out2.lo) st_fr(a.out2.lo, a.out2.hi, (((size_t)1 << s) - 1) + idx, fr_mul(cur, two128));
+        }
     }
 }
 
@@ -59,6 +67,7 @@ struct CipherRoundArgs {
     Planes k_dst, s_dst;   // FOLD: folded tables (2P elements) are written here (may alias src)
     CPlanes wt;            // per-thread factor: 2^g entries (pointer already at the level)
     CPlanes wj;            // per-iteration factor: P >> g entries (HAS_WJ only)
+    CPlanes wj2;           // the same entries times 2^-128 (k_cipher_round_wide with late lane weights)
     size_t P;              // index pairs this round
     unsigned lg_threads;   // log2(threads)
     Fr r;                  // previous round's challenge (FOLD)
@@ -360,20 +369,23 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             }
             const Fr u = fr_add(fr_add(klo, slo), ark);
             const Fr d = fr_add(fr_sub(khi, klo), fr_sub(shi, slo));
-            Fr W = ld_fr(a.wj.lo, a.wj.hi, j);
-            if (!WT_LATE) W = fr_mont_mul_raw(W, wt);
+            Fr W = ld_fr(a.wj.lo, a.wj.hi, j);            // the same element for every lane of the launch
+            Fr W2 = W;
+            if (WT_LATE) W2 = ld_fr(a.wj2.lo, a.wj2.hi, j);
+            else W = fr_mont_mul_raw(W, wt);
 #define GKR_SB() __builtin_amdgcn_sched_barrier(0)
             Fr p, r2, A, B, C, D, U4, D4, X0, X1;
             u32 T[FR_WIDE_LIMBS];
             // ordered for short lifetimes: u^2 and its dependants first, then d^2 and its dependants
             p = fr_mont_mul_raw(u, u);    GKR_SB();
             U4 = fr_mont_mul_raw(p, p);   GKR_SB();   // u^4
-            X0 = fr_mont_mul_raw(W, U4);  GKR_SB();
+            // with late lane weights W is uniform over the launch's lanes: 96-product multiplication (< 3q)
+            X0 = WT_LATE ? fr_mul_const2_raw(U4, W2, W) : fr_mont_mul_raw(W, U4);  GKR_SB();
             A = fr_mont_mul_raw(p, u);    GKR_SB();   // u^3
             B = fr_mont_mul_raw(p, d);    GKR_SB();   // u^2 d
             r2 = fr_mont_mul_raw(d, d);   GKR_SB();
             D4 = fr_mont_mul_raw(r2, r2); GKR_SB();   // d^4
-            X1 = fr_mont_mul_raw(W, D4);  GKR_SB();
+            X1 = WT_LATE ? fr_mul_const2_raw(D4, W2, W) : fr_mont_mul_raw(W, D4);  GKR_SB();
             C = fr_mont_mul_raw(u, r2);   GKR_SB();   // u d^2
             D = fr_mont_mul_raw(r2, d);   GKR_SB();   // d^3
             // {W u^4, W d^4} x {u^3, u^2 d, u d^2, d^3}: the seven closing products are wide MACs; the LDS-resident

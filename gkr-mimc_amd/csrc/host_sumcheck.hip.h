@@ -44,7 +44,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     };
     const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
     CHK(stage_coords(q, (size_t)m));
-    DevTable pyrT, pyrU[2], ks, ss;                    // pyrU[0]: split at g_max threads, pyrU[1]: at g_big
+    DevTable pyrT, pyrU[2], pyrU2[2], ks, ss;          // pyrU[0]: split at g_max threads, pyrU[1]: at g_big; pyrU2: times 2^-128
     const int gsplit[2] = {std::min(cx().g_max, m - 1), g_big};
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
     CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
@@ -55,12 +55,15 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     pa.nc = m;
     pa.max_level = gT;
     pa.seed = to_dev(seed);
+    pa.out2 = Planes{nullptr, nullptr};
     hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
     for (int v = 0; v < (g_big != gsplit[0] ? 2 : 1); v++) {
         const int mU = m - 1 - gsplit[v];              // log2(iterations of round 0 at this split)
         CHK(table_alloc(&pyrU[v], (size_t)2 << std::max(mU, 0)));
+        CHK(table_alloc(&pyrU2[v], (size_t)2 << std::max(mU, 0)));
         if (mU > 0) {
             pa.out = pyrU[v].planes();
+            pa.out2 = pyrU2[v].planes();
             pa.nc = m - gsplit[v];                     // q[0 .. m-g-1]; level L = eq(q[nc-L .. nc-1], .)
             pa.max_level = mU;
             pa.seed = to_dev(hfr::ONE);
@@ -92,6 +95,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             const DevTable& pu = pyrU[gk == gsplit[0] ? 0 : 1];
             const size_t offU = ((size_t)1 << lj) - 1;
             a.wj = CPlanes{pu.base + offU, pu.base + pu.cap + offU};
+            const DevTable& pu2 = pyrU2[gk == gsplit[0] ? 0 : 1];
+            a.wj2 = CPlanes{pu2.base + offU, pu2.base + pu2.cap + offU};
         }
         a.P = P;
         a.lg_threads = (unsigned)gk;
@@ -205,8 +210,10 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
     table_release(&pyrT);
-    table_release(&pyrU[0]);
-    if (pyrU[1].base) table_release(&pyrU[1]);
+    for (int v = 0; v < 2; v++) {
+        if (pyrU[v].base) table_release(&pyrU[v]);
+        if (pyrU2[v].base) table_release(&pyrU2[v]);
+    }
     table_release(&ks);
     table_release(&ss);
     return 0;
