@@ -239,25 +239,32 @@ def main():
                              "note": "device-resident micro-benchmark of the same kernel (gkrhip_bench_fold): three "
                                      "tables, no other kernel running"}
     if solo["peval_launches"]:
-        # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit), so it is
-        # priced in field products per second against an instruction-issue ceiling: one Montgomery product is 136
-        # v_mad_u64_u32 + 136 v_addc_co_u32 + 8 v_mul_lo_u32 + moves = 1158 cycles per wave measured in isolation at
-        # full occupancy (profiles/r01_ubench_instruction_rates.txt) -> 2.4 GHz x 1024 SIMDs x 64 lanes / 1158
-        ceiling = 2.4e9 * 1024 * 64 / 1158.0
-        rate = solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3)
-        out["partial_eval"] = {"kernel": "k_cipher_round_wide (round 0 of a cipher layer: 2^%d index pairs, 21 field products "
-                                         "per pair, 7 of them accumulated with deferred reduction)" % (args.bn - 1),
-                               "bound": "integer VALU (no MFMA: modular arithmetic)",
-                               "launches": solo["peval_launches"],
-                               "avg_launch_ms": solo["peval_ms"] / solo["peval_launches"],
-                               "modmul_per_s": rate, "ceiling_modmul_per_s": ceiling, "frac": rate / ceiling,
-                               "ceiling_assumption": "every product a full Montgomery product at the measured isolated "
-                                                     "rate of 1158 cycles per wave; deferred-reduction products count as products",
+        # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit) and runs
+        # at the vector issue rate, so it is priced against an instruction-issue ceiling: the round-0 loop body is
+        # 3950 vector instructions per index pair (3591 half-rate: v_mad_u64_u32 / carries at 4.3 cycles per wave, 359
+        # at 2.4; tools/isa_loop_count.py, rates from profiles/r01_ubench_*.txt) = 16303 issue cycles per pair and
+        # wave; 1024 SIMDs x 64 lanes share the pairs; nominal clock 2.4 GHz (the sustained clock under this load is
+        # nearer 2.1 GHz, profiles/r01_v8_pmc_round_kernel_sq.json)
+        pairs = float(1 << (args.bn - 1))
+        issue_cycles_per_pair = 16303.0
+        ceiling_ms = pairs / (1024 * 64) * issue_cycles_per_pair / 2.4e9 * 1e3
+        avg_ms = solo["peval_ms"] / solo["peval_launches"]
+        out["partial_eval"] = {"kernel": "k_cipher_round_wide (round 0 of a cipher layer: 2^%d index pairs; per pair 10 field products, "
+                                         "2 of them by a launch-wide constant, and 7 multiply-accumulates with deferred "
+                                         "reduction)" % (args.bn - 1),
+                               "bound": "integer VALU issue (no MFMA: modular arithmetic)",
+                               "launches": solo["peval_launches"], "avg_launch_ms": avg_ms,
+                               "ceiling_ms": ceiling_ms, "frac": ceiling_ms / avg_ms,
+                               "vector_instructions_per_pair": 3950, "issue_cycles_per_pair": issue_cycles_per_pair,
+                               "field_products_per_s": solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3),
+                               "ceiling_assumption": "every vector instruction of the loop body at its measured issue cost "
+                                                     "(4.3 / 2.4 cycles per wave), two waves per SIMD keeping the port "
+                                                     "busy, 2.4 GHz",
                                "measured": "HIP events around the round-0 launches of the single-proof pass"}
         if prof["peval_launches"]:
             out["partial_eval"]["in_timed_region"] = {
                 "launches": prof["peval_launches"], "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
-                "modmul_per_s_per_launch": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
+                "field_products_per_s_per_launch": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
                 "note": "launch durations with %d proofs in flight overlap the other lanes' kernels" % nconc}
     if prof.get("rounds"):
         out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
