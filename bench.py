@@ -241,12 +241,12 @@ def main():
     if solo["peval_launches"]:
         # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit) and runs
         # at the vector issue rate, so it is priced against an instruction-issue ceiling: the round-0 loop body is
-        # 3950 vector instructions per index pair (3591 half-rate: v_mad_u64_u32 / carries at 4.3 cycles per wave, 359
-        # at 2.4; tools/isa_loop_count.py, rates from profiles/r01_ubench_*.txt) = 16303 issue cycles per pair and
+        # 3903 vector instructions per index pair (3566 half-rate: v_mad_u64_u32 / carries at 4.3 cycles per wave, 337
+        # at 2.4; tools/isa_loop_count.py, rates from profiles/r01_ubench_*.txt) = 16143 issue cycles per pair and
         # wave; 1024 SIMDs x 64 lanes share the pairs; nominal clock 2.4 GHz (the sustained clock under this load is
         # nearer 2.1 GHz, profiles/r01_v8_pmc_round_kernel_sq.json)
         pairs = float(1 << (args.bn - 1))
-        issue_cycles_per_pair = 16303.0
+        issue_cycles_per_pair = 16143.0
         ceiling_ms = pairs / (1024 * 64) * issue_cycles_per_pair / 2.4e9 * 1e3
         avg_ms = solo["peval_ms"] / solo["peval_launches"]
         out["partial_eval"] = {"kernel": "k_cipher_round_wide (round 0 of a cipher layer: 2^%d index pairs; per pair 10 field products, "
@@ -255,7 +255,7 @@ def main():
                                "bound": "integer VALU issue (no MFMA: modular arithmetic)",
                                "launches": solo["peval_launches"], "avg_launch_ms": avg_ms,
                                "ceiling_ms": ceiling_ms, "frac": ceiling_ms / avg_ms,
-                               "vector_instructions_per_pair": 3950, "issue_cycles_per_pair": issue_cycles_per_pair,
+                               "vector_instructions_per_pair": 3903, "issue_cycles_per_pair": issue_cycles_per_pair,
                                "field_products_per_s": solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3),
                                "ceiling_assumption": "every vector instruction of the loop body at its measured issue cost "
                                                      "(4.3 / 2.4 cycles per wave), two waves per SIMD keeping the port "

@@ -197,11 +197,13 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
                 slo = ld_fr(a.s_src.lo, a.s_src.hi, x);
                 shi = ld_fr(a.s_src.lo, a.s_src.hi, x + P);
             }
-            const Fr u = fr_add(fr_add(klo, slo), ark);
-            const Fr d = fr_add(fr_sub(khi, klo), fr_sub(shi, slo));
+            // lazy sums: u < 3q, d < 2q.  The product chain is closed below 3q (a*b/2^256 + q < 2.7q for a, b < 3q),
+            // so neither is reduced
+            const Fr u = fr_add_raw(fr_add_raw(klo, slo), ark);
+            const Fr d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));
             Fr W = wt;
             if (HAS_WJ) W = fr_mont_mul_raw(ld_fr(a.wj.lo, a.wj.hi, j), wt);
-            // all products below are lazy Montgomery products in [0, 2q).  The scheduling barriers keep
+            // all products below are lazy Montgomery products (below 3q).  The scheduling barriers keep
             // hipcc from interleaving the independent products (which only raises register pressure:
             // the kernel is VALU-bound and each product already saturates the issue slot).
 #define GKR_SB() do { if (!LAT) __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -367,8 +369,10 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
                 slo = ld_fr(a.s_src.lo, a.s_src.hi, x);
                 shi = ld_fr(a.s_src.lo, a.s_src.hi, x + P);
             }
-            const Fr u = fr_add(fr_add(klo, slo), ark);
-            const Fr d = fr_add(fr_sub(khi, klo), fr_sub(shi, slo));
+            // lazy sums: u < 3q, d < 2q.  The product chain is closed below 3q (a*b/2^256 + q < 2.7q for a, b < 3q),
+            // so neither is reduced
+            const Fr u = fr_add_raw(fr_add_raw(klo, slo), ark);
+            const Fr d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));
             Fr W = ld_fr(a.wj.lo, a.wj.hi, j);            // the same element for every lane of the launch
             Fr W2 = W;
             if (WT_LATE) W2 = ld_fr(a.wj2.lo, a.wj2.hi, j);

@@ -123,7 +123,8 @@ FR_HD Fr fr_sub(const Fr& a, const Fr& b) {
 
 FR_HD Fr fr_dbl(const Fr& a) { return fr_add(a, a); }
 
-// Montgomery product a*b/2^256 mod q, result in [0, 2q)  (inputs < 2q is enough: 4q^2 + q*2^256 < 2q*2^256)
+// Montgomery product a*b/2^256 mod q, result < a*b/2^256 + q: in [0, 2q) for inputs < 2q (4q^2 + q*2^256 < 2q*2^256),
+// below 2.7q for inputs < 3q (q/2^256 = 0.189) -- any inputs whose result stays below 2^256 = 5.29q are exact
 FR_HD Fr fr_mont_mul_raw(const Fr& a, const Fr& b) {
     Fr r;
 #include "fr_mont_gen.inc"
