@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--concurrent", type=int, default=5,
                     help="independent proofs in flight (each on its own resident session/lane/stream and, when "
                          "sharded, its own communicator); 1 = strictly one proof at a time")
+    ap.add_argument("--exchange", choices=["auto", "rccl", "shm"], default="auto",
+                    help="transport of the per-round 576-byte sum of the sharded prover: rccl = ncclAllReduce on the lane's "
+                         "stream; shm = the ranks add the words on the host through POSIX shared memory (one node); auto = "
+                         "shm when every rank is on this node, else rccl")
     ap.add_argument("--mem-fraction", type=float, default=0.85,
                     help="share of the free HBM the resident sessions may take (caps --concurrent)")
     args = ap.parse_args()
@@ -91,30 +95,39 @@ def main():
         # install the library's own RCCL communicators, one per lane (the per-round all-reduce of the limb-split
         # sums lives inside the C++ round loop); torch.distributed only carries the 128-byte unique ids, the
         # barriers and the max-over-ranks of the timing
+        one_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
+        use_shm = args.exchange == "shm" or (args.exchange == "auto" and one_node)
+        shm_name = "/gkrhip_bench_%s" % os.environ.get("MASTER_PORT", "0")
         transport, err = "rccl", ""
-        try:
-            box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
-        except Exception as e:      # noqa: BLE001 -- reported below, never silent
-            box, err = [None], str(e)
-        dist.broadcast_object_list(box, src=0)
-        ok = 0
-        if box[0] is not None:
+        if use_shm:
+            # 576 bytes per round: the round kernel hands its sums to the host as in the un-sharded case and the ranks add
+            # them through shared memory -- no collective kernel has to queue behind the compute-bound rounds
+            gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
+            transport = "host shared memory (one node)"
+        else:
             try:
-                gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
-                ok = 1
-            except Exception as e:  # noqa: BLE001
-                err = str(e)
-        t = torch.tensor([ok], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0:
-            # RCCL communicators could not be created on some rank: the same call sites run over the library's
-            # host shared-memory transport (single node only) and the JSON line says so
-            gk.comm_destroy()
-            dist.barrier()
-            gk.comm_init_shm_lanes(world, rank, nconc, "/gkrhip_bench_%s" % os.environ.get("MASTER_PORT", "0"))
-            transport = "host shared memory (RCCL communicator init failed: %s)" % (err or "on another rank")
-            if rank == 0:
-                print("bench.py: " + transport, file=sys.stderr)
+                box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
+            except Exception as e:      # noqa: BLE001 -- reported below, never silent
+                box, err = [None], str(e)
+            dist.broadcast_object_list(box, src=0)
+            ok = 0
+            if box[0] is not None:
+                try:
+                    gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
+                    ok = 1
+                except Exception as e:  # noqa: BLE001
+                    err = str(e)
+            t = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                # RCCL communicators could not be created on some rank: the same call sites run over the library's
+                # host shared-memory transport (single node only) and the JSON line says so
+                gk.comm_destroy()
+                dist.barrier()
+                gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
+                transport = "host shared memory (RCCL communicator init failed: %s)" % (err or "on another rank")
+                if rank == 0:
+                    print("bench.py: " + transport, file=sys.stderr)
     gamma = (world.bit_length() - 1) if dist is not None else 0
     # weak scaling: every GPU holds a 2^bn shard, the job proves 2^(bn + log2 N) hashes in ONE proof
     bn = args.bn + gamma

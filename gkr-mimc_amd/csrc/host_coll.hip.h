@@ -93,6 +93,20 @@ int coll_allreduce(unsigned long long* d, int n) {
     }
     return 0;
 }
+// The same sum over ranks for words that are already on the host (the round kernel's host-mapped hand-off):
+// slot write, barrier, sum, barrier.  No device round trip at all.
+int shm_allreduce_host(unsigned long long* words, int n) {
+    if ((size_t)n > kShmSlotWords) return fail("shm all-reduce of %d words exceeds the slot", n);
+    memcpy(cx().lc.shm_slots + (size_t)gc.rank * kShmSlotWords, words, sizeof(unsigned long long) * n);
+    shm_barrier();
+    for (int i = 0; i < n; i++) {
+        unsigned long long s = 0;
+        for (int r = 0; r < gc.world; r++) s += cx().lc.shm_slots[(size_t)r * kShmSlotWords + i];
+        words[i] = s;
+    }
+    shm_barrier();
+    return 0;
+}
 // all-gather of `cnt` field elements per rank (host values): rank g's elements land in out[g*cnt ..].
 // Implemented as an all-reduce of a zero-padded buffer (one contributor per slot: the sum is exact).
 int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {

@@ -108,10 +108,13 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.ark = to_dev(ark);
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;
-        a.host_out = collective ? cx().lc.d_buf : cx().d_round;      // sharded: sums stay on the device for the all-reduce
-        // sharded: the kernel's own completion flag lands in a spare word of the exchange buffer (the host is
-        // signalled after the all-reduce instead)
-        a.host_flag = collective ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
+        // Sharded over RCCL: the sums stay on the device for the all-reduce and the kernel's own completion flag lands
+        // in a spare word of the exchange buffer (the host is signalled after the all-reduce).  Sharded over the host
+        // shared-memory transport: the kernel hands its local sums to the host as in the un-sharded case and the
+        // ranks add them on the host (576 bytes per round: no extra kernel has to queue behind the big rounds).
+        const bool on_device = collective && cx().lc.comm;
+        a.host_out = on_device ? cx().lc.d_buf : cx().d_round;
+        a.host_flag = on_device ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
         a.seq = ++cx().seq;
         const bool derive_m0 = claim && *claim_known;
         a.need_m0 = derive_m0 ? 0u : 1u;
@@ -152,33 +155,30 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
-        if (collective) {
-            // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are
-            // rank-local and are copied as they are
+        unsigned long long summed[GKR_CR_WORDS];
+        if (on_device) {
+            // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are rank-local.
+            // The reduced words reach the host like the un-sharded ones (host-mapped buffer + flag the host polls)
             CHK(coll_allreduce(cx().lc.d_buf, GKR_CR_WORDS));
-            if (cx().lc.comm) {
-                // RCCL: the reduced words reach the host like the un-sharded ones (host-mapped buffer + flag the host
-                // polls): no copy engine round trip and no stream synchronisation per round
-                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round,
-                                   GKR_CR_WORDS + 16, cx().d_flag, a.seq);
-                HIPCHK(hipGetLastError());
-                CHK(wait_flag(a.seq));
-            } else {
-                HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, sizeof(unsigned long long) * (GKR_CR_WORDS + 16),
-                                      hipMemcpyDeviceToHost, cx().stream));
-                HIPCHK(hipStreamSynchronize(cx().stream));
-                words = cx().lc.h_buf;
-            }
+            hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round,
+                               GKR_CR_WORDS + 16, cx().d_flag, a.seq);
+            HIPCHK(hipGetLastError());
+            CHK(wait_flag(a.seq));
         } else {
             CHK(wait_flag(a.seq));
+            if (collective && cx().lc.shm) {
+                memcpy(summed, cx().h_round, sizeof summed);
+                CHK(shm_allreduce_host(summed, GKR_CR_WORDS));
+            }
         }
+        const unsigned long long* sums = (collective && !on_device && cx().lc.shm) ? summed : words;
         const double t_w = now_ms();
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
         // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
         E csp[8];
         for (int j = derive_m0 ? 1 : 0; j < 8; j++)
-            csp[j] = hfr::mul(c, hfr::mul(limbs9_to_fr(words + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j])));
+            csp[j] = hfr::mul(c, hfr::mul(limbs9_to_fr(sums + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j])));
         if (derive_m0) {
             E rest = csp[1];
             for (int j = 2; j < 8; j++) rest = hfr::add(rest, csp[j]);
