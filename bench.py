@@ -97,7 +97,9 @@ def main():
         # barriers and the max-over-ranks of the timing
         one_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
         use_shm = args.exchange == "shm" or (args.exchange == "auto" and one_node)
-        shm_name = "/gkrhip_bench_%s" % os.environ.get("MASTER_PORT", "0")
+        tag = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
+        dist.broadcast_object_list(tag, src=0)        # a name no earlier run can have left behind
+        shm_name = "/gkrhip_bench_%s" % tag[0]
         transport, err = "rccl", ""
         if use_shm:
             # 576 bytes per round: the round kernel hands its sums to the host as in the un-sharded case and the ranks add

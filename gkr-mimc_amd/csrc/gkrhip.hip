@@ -791,7 +791,8 @@ static int shm_attach(int world, int rank, const char* name) {   // on the curre
     const size_t bytes = 4096 + sizeof(unsigned long long) * kShmSlotWords * world;
     int fd = -1;
     if (rank == 0) {
-        fd = shm_open(name, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        (void)shm_unlink(name);                        // a leftover of a crashed run; names should be unique per run anyway
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return fail("shm_open/ftruncate(%s) failed", name);
     } else {
         for (int tries = 0; tries < 20000; tries++) {   // wait for rank 0 to create and size the segment
@@ -873,6 +874,13 @@ int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char* name
     for (int k = 0; k < nlanes; k++) {
         UseLane u(gc.lanes[k]);
         shm_barrier();   // everybody mapped (the segments are zero-filled by ftruncate)
+    }
+    if (rank == 0) {     // every rank holds its mapping: the names can go (nothing is left behind in /dev/shm)
+        for (int k = 0; k < nlanes; k++) {
+            char nm[256];
+            snprintf(nm, sizeof nm, "%s_%d", name, k);
+            (void)shm_unlink(nm);
+        }
     }
     return 0;
 }
