@@ -28,11 +28,8 @@ void shm_barrier() {
         cx().lc.shm->arrive.store(0, std::memory_order_relaxed);
         cx().lc.shm->gen.fetch_add(1, std::memory_order_release);
     } else {
-        unsigned spins = 0;
-        while (cx().lc.shm->gen.load(std::memory_order_acquire) == gen) {
-            __builtin_ia32_pause();
-            if (++spins > 2000) sched_yield();   // ranks may outnumber the cores the cgroup allows
-        }
+        Waiter w;
+        while (cx().lc.shm->gen.load(std::memory_order_acquire) == gen) w.step();
     }
 }
 

@@ -91,6 +91,49 @@ struct UseLane {
     explicit UseLane(Ctx* l) : prev(g_cur) { g_cur = l; }
     ~UseLane() { g_cur = prev; }
 };
+// ---- how host threads wait (for the round kernel's flag, for the other ranks) -------------------------------
+// Spinning is the lowest-latency wait and is what un-sharded runs use: a handful of lanes on a many-core host.
+// A sharded run has (ranks on this node) x (lanes) waiting threads; when they outnumber the CPUs the container may
+// use (affinity mask and cgroup quota), spinning starves the threads that hash and burns the quota, so the wait
+// spins only briefly and then sleeps in short steps.  GKRHIP_WAIT_SPIN_US overrides (-1 = always spin).
+inline int usable_cpus() {
+    cpu_set_t set;
+    int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {        // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return std::max(n, 1);
+}
+std::atomic<int> g_wait_spin_us{-1};            // -1: spin; otherwise spin this long, then sleep in 20 us steps
+std::atomic<int> g_wait_ranks{1};               // ranks assumed to share this host (set with the communicator)
+inline void wait_policy_update(int waiting_threads) {
+    if (const char* e = getenv("GKRHIP_WAIT_SPIN_US")) {
+        g_wait_spin_us.store(atoi(e), std::memory_order_relaxed);
+        return;
+    }
+    g_wait_spin_us.store(usable_cpus() >= waiting_threads + 2 ? -1 : 25, std::memory_order_relaxed);
+}
+struct Waiter {                                 // one per wait: call step() in the polling loop
+    unsigned long spins = 0;
+    double t0 = 0;
+    inline void step() {
+        __builtin_ia32_pause();
+        if ((++spins & 127) != 0) return;
+        const int lim = g_wait_spin_us.load(std::memory_order_relaxed);
+        if (lim < 0) return;
+        if (t0 == 0) { t0 = now_ms(); return; }
+        if ((now_ms() - t0) * 1e3 > lim) {
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+};
 std::atomic<int> g_proofs_in_flight{0};          // gkr.Prove calls currently running (any lane)
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
@@ -229,6 +272,7 @@ Ctx* lane_create() {
     l->ready = true;
     std::lock_guard<std::mutex> lk(g_lanes_mu);
     g_lanes.push_back(l);
+    wait_policy_update(g_wait_ranks.load() * (int)g_lanes.size());   // one waiting host thread per lane and rank
     return l;
 }
 void lane_destroy(Ctx* l) {

@@ -5,9 +5,10 @@
 int wait_flag(unsigned int seq) {
     volatile unsigned int* f = cx().h_flag;
     unsigned long spins = 0;
+    Waiter w;
     while (*f != seq) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xfffff) == 0) {              // every ~millisecond: make sure the GPU is alive
+        w.step();
+        if ((++spins & 0xfffff) == 0) {              // every now and then: make sure the GPU is alive
             hipError_t e = hipStreamQuery(cx().stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
             if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
