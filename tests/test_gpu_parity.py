@@ -646,3 +646,13 @@ def test_cpp_abi_harness(gk, tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-fopenmp"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "abi-harness fails=0" in out.stdout, out.stdout + out.stderr
+
+
+def test_soak_lanes_deterministic(gk):
+    """tools/stress.py for 20 s: 14 lanes proving sizes 2^9..2^20 concurrently; every proof is byte-identical to the
+    first of its size and verifies (races in the hand-off flags or the atomic accumulation would show up here)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "20"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "mismatches: []" in out.stdout, out.stdout + out.stderr
