@@ -22,6 +22,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gkrhip.h"
@@ -508,8 +509,30 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
     CHK(gkrhip_mimc_session_create(&s, bN));
     int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
     if (rc == 0) rc = gkrhip_mimc_session_assign(s);
+    // The output table is final once the assignment is: its download (transposition + 2^bN x 32 bytes over PCIe into
+    // pageable memory) runs on the default lane's stream from a second host thread while this thread proves.
+    int rc_out = 0;
+    std::string err_out;
+    std::thread dl;
+    if (rc == 0 && outputs_or_null && s->lane != &g0) {
+        dl = std::thread([&]() {
+            std::lock_guard<std::mutex> lk(g0.mu);
+            UseLane u(&g0);
+            rc_out = hipSetDevice(g0.device) == hipSuccess ? download_table(session_table(s, (int)s->c.size() - 1), outputs_or_null, s->n)
+                                                           : fail("hipSetDevice failed");
+            if (rc_out) err_out = g_err;
+        });
+    }
     if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
-    if (rc == 0 && outputs_or_null) rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
+    if (dl.joinable()) {
+        dl.join();
+        if (rc == 0 && rc_out) {
+            g_err = err_out;
+            rc = rc_out;
+        }
+    } else if (rc == 0 && outputs_or_null) {
+        rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
+    }
     gkrhip_mimc_session_destroy(s);
     return rc;
 }
