@@ -102,3 +102,9 @@ def test_product_does_not_reference_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for bad in ("gkr_oracle", "coracle", "pyoracle", "libgkr_oracle"):
                     assert bad not in txt, (f, bad)
+
+
+def test_header_is_plain_c():
+    """include/gkrhip.h is what a cgo preamble includes: it must be valid C99 on its own."""
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "gkrhip.h")])
