@@ -9,10 +9,11 @@
 //     P_k(t) = c_k * eq(q_k, t) * S_k(t),     S_k(t) = sum_x W_k(x) * (u(x) + t*d(x))^7,
 //     W_k = eq(q[k+1:], .),  u = K_lo + S_lo + ark,  d = (K_hi - K_lo) + (S_hi - S_lo)
 // (K = key table, S = state table, pairs (x, x+mid), gate (K+S+ark)^7: circuit/gates/cipher.go:32-41).
-// The device returns the 8 monomial sums M_j = sum_x W_k(x) u^(7-j) d^j (23 multiplications per pair
-// instead of the 45 of evaluating at t = 0..8; 21 when the round's claim P_k(0)+P_k(1) is known to the
-// host, which then derives c_k*M_0 from it instead -- only inside gkr.Prove, where every claim is the
-// previous round's P(r) and therefore consistent by construction); the host multiplies by the binomials, by the linear
+// The device returns the 8 monomial sums M_j = sum_x W_k(x) u^(7-j) d^j, read off the 2 x 4 product table
+// {W u^4, W d^4} x {u^3, u^2 d, u d^2, d^3} (18 multiplications per pair instead of the 45 of evaluating at
+// t = 0..8; 17 when the round's claim P_k(0)+P_k(1) is known to the host, which then derives c_k*M_0 from it
+// instead -- only inside gkr.Prove, where every claim is the previous round's P(r) and therefore consistent by
+// construction); the host multiplies by the binomials, by the linear
 // factor and by c_k, which yields exactly the coefficients poly.InterpolateOnRange produces from the
 // reference's nine evaluations (a polynomial of degree <= 8 is determined by them), hence the same
 // Fiat-Shamir challenges and the same transcript.  The Eq table is never materialised or folded:
