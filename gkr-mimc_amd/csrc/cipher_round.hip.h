@@ -102,36 +102,8 @@ __device__ __forceinline__ void acc_add_raw(Acc9& a, const Fr& x) {
         : "vcc");
 }
 
-// every block has added its sums into the shared accumulator; the last-arriving block publishes it to the host
-// (agent-scope release by lane 0 after the block's atomics have drained; acquire before re-reading)
 __device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, unsigned int* s_last) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int prev = atomicAdd(a.counter, 1u);
-        const unsigned int last = (prev == gridDim.x - 1) ? 1u : 0u;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *s_last = last;
-    }
-    __syncthreads();
-    if (*s_last) {
-        if (threadIdx.x < GKR_CR_WORDS) {
-            a.host_out[threadIdx.x] = __hip_atomic_load(a.partials + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.partials[threadIdx.x] = 0;            // ready for the next launch on this lane
-        }
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            *a.counter = 0;
-            __threadfence_system();
-            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    publish_sums(a.partials, a.counter, a.host_out, a.host_flag, a.seq, GKR_CR_WORDS, s_last);
 }
 
 // sharded prover: after the all-reduce the summed words go to the host the same way (host-mapped buffer + flag)

@@ -164,6 +164,7 @@ int gather0(const DevTable* const* t, int ntab, E* out) {
 int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, E* evals,
                   int nev, bool collective) {
     int nblocks = 0;
+    const bool direct = !collective;      // un-sharded: the kernel hands the sums to the host itself
     const bool timed = 2 * mid >= cx().prof.min_n;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
@@ -172,13 +173,13 @@ int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const
         HIPCHK(hipEventRecord(e0, cx().stream));
     }
     if (gate == GKRHIP_GATE_CIPHER && arity == 2) {
-        CHK((launch_partial_eval_t<GKR_GATE_CIPHER, 2, 9>(eq, x, mid, ark, &nblocks)));
+        CHK((launch_partial_eval_t<GKR_GATE_CIPHER, 2, 9>(eq, x, mid, ark, &nblocks, direct)));
     } else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) {
-        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 1, 3>(eq, x, mid, ark, &nblocks)));
+        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 1, 3>(eq, x, mid, ark, &nblocks, direct)));
     } else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) {
-        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 2, 3>(eq, x, mid, ark, &nblocks)));
+        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 2, 3>(eq, x, mid, ark, &nblocks, direct)));
     } else if (gate == GKRHIP_GATE_ADD && arity == 2) {
-        CHK((launch_partial_eval_t<GKR_GATE_ADD, 2, 3>(eq, x, mid, ark, &nblocks)));
+        CHK((launch_partial_eval_t<GKR_GATE_ADD, 2, 3>(eq, x, mid, ark, &nblocks, direct)));
     } else {
         return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
     }
@@ -190,6 +191,11 @@ int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const
         cx().prof.peval_modmuls += (gate == GKRHIP_GATE_CIPHER ? 45.0 : 3.0) * (double)mid;
     }
     const int nwords = nev * GKR_ACC_WORDS;
+    if (direct) {
+        CHK(wait_flag(cx().seq));
+        for (int t = 0; t < nev; t++) evals[t] = limbs9_to_fr(cx().h_round + (size_t)t * GKR_ACC_WORDS);
+        return 0;
+    }
     hipLaunchKernelGGL(k_reduce_partials, dim3(nwords), dim3(GKR_BLOCK), 0, cx().stream, cx().d_partials, cx().d_sums, nblocks, nwords);
     HIPCHK(hipGetLastError());
     if (collective) CHK(coll_allreduce(cx().d_sums, nwords));

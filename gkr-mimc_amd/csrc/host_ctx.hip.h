@@ -169,6 +169,7 @@ int fail(const char* fmt, ...) {
     } while (0)
 
 const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
+const int kRaccWords = 128;       // shared accumulator / host hand-off buffer: 72 (fused rounds) or up to 81 (nine evaluations) + 16 tail words
 int lane_alloc();
 
 int ctx_init(int dev) {
@@ -214,12 +215,12 @@ int lane_alloc() {
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&cx().d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
     HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));
-    HIPCHK(hipMalloc(&cx().d_racc, sizeof(unsigned long long) * GKR_CR_WORDS));
-    HIPCHK(hipMemset(cx().d_racc, 0, sizeof(unsigned long long) * GKR_CR_WORDS));
+    HIPCHK(hipMalloc(&cx().d_racc, sizeof(unsigned long long) * kRaccWords));
+    HIPCHK(hipMemset(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords));
     HIPCHK(hipHostMalloc(&cx().h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
     HIPCHK(hipMalloc(&cx().d_small, sizeof(uint4) * 2 * 8));
     HIPCHK(hipHostMalloc(&cx().h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(&cx().h_round, sizeof(unsigned long long) * (GKR_CR_WORDS + 16), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostMalloc(&cx().h_round, sizeof(unsigned long long) * kRaccWords, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_round, cx().h_round, 0));
     HIPCHK(hipHostMalloc(&cx().h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_flag, cx().h_flag, 0));
@@ -418,7 +419,7 @@ int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab
     // profiles/r01_fold_variants.txt) 6.4-6.6 TB/s on 2^24/2^25-element tables, against 5.7-6.1 TB/s for a
     // fused three-table launch and 4.6-5.8 TB/s for grid-stride loops over 8192 workgroups
     const dim3 grid(grid_for(mid, cx().fold_grid)), block(GKR_BLOCK);
-    if (!cx().fold_split) {
+    if (!cx().fold_split || mid < ((size_t)1 << 19)) {      // small tables are launch-bound: one launch for all of them
         switch (ntab) {
             case 1: hipLaunchKernelGGL(k_fold<1>, grid, block, 0, cx().stream, a); break;
             case 2: hipLaunchKernelGGL(k_fold<2>, grid, block, 0, cx().stream, a); break;
@@ -449,7 +450,7 @@ int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab
 }
 
 template <int GATE, int ARITY, int NEV>
-int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, int* nblocks) {
+int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, int* nblocks, bool direct) {
     PartialEvalArgs a;
     memset(&a, 0, sizeof a);
     a.eq = eq->cplanes();
@@ -457,8 +458,32 @@ int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t m
     a.mid = mid;
     a.ark = to_dev(ark);
     a.partials = cx().d_partials;
+    if (direct) {            // sums straight to the host (host-mapped buffer + flag), no reduction kernel, no copy
+        a.racc = cx().d_racc;
+        a.counter = cx().d_counter;
+        a.host_out = cx().d_round;
+        a.host_flag = cx().d_flag;
+        a.seq = ++cx().seq;
+    }
     const int grid = grid_for(mid, kPartialBlocks);
     hipLaunchKernelGGL((k_partial_eval<GATE, ARITY, NEV>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
     *nblocks = grid;
+    return 0;
+}
+
+// wait for the sequence number a kernel of this lane publishes with its hand-off (host-mapped flag)
+int wait_flag(unsigned int seq) {
+    volatile unsigned int* f = cx().h_flag;
+    unsigned long spins = 0;
+    Waiter w;
+    while (*f != seq) {
+        w.step();
+        if ((++spins & 0xfffff) == 0) {              // every now and then: make sure the GPU is alive
+            hipError_t e = hipStreamQuery(cx().stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
+            if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
+        }
+    }
+    __sync_synchronize();
     return 0;
 }

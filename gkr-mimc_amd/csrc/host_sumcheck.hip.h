@@ -2,22 +2,6 @@
 // cipher rounds, the reference-shaped generic rounds, Evaluate.  Included by gkrhip.hip inside its anonymous namespace.
 #pragma once
 // ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
-int wait_flag(unsigned int seq) {
-    volatile unsigned int* f = cx().h_flag;
-    unsigned long spins = 0;
-    Waiter w;
-    while (*f != seq) {
-        w.step();
-        if ((++spins & 0xfffff) == 0) {              // every now and then: make sure the GPU is alive
-            hipError_t e = hipStreamQuery(cx().stream);
-            if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
-            if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
-        }
-    }
-    __sync_synchronize();
-    return 0;
-}
-
 template <bool FOLD, bool HAS_WJ>
 void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
     if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
@@ -73,7 +57,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     }
     HIPCHK(hipGetLastError());
     // the shared accumulator and the arrival counter are zero between launches; make sure of it after a failed call
-    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * GKR_CR_WORDS, cx().stream));
+    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
     HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     if (collective) CHK(coll_buffers(256));
 
@@ -288,6 +272,9 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
                    E* proof, E* chal, E* last) {
     const size_t n = (size_t)1 << m;
     const int nev = gate_degree(gate) + 2;
+    // the shared accumulator and the arrival counter are zero between launches; make sure of it after a failed call
+    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+    HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     DevTable scratch[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) CHK(table_alloc(&scratch[k], std::max<size_t>(n / 2, 1)));
     const DevTable* cur[GKR_MAX_ARITY + 1];

@@ -280,12 +280,53 @@ __device__ __forceinline__ void block_reduce_acc(const Acc9 (&acc)[NS], unsigned
     block_reduce_acc_buf<NS, CH, ATOMIC>(acc, out, tr, red);
 }
 
+// Every block has added its sums into the shared accumulator `racc` (nwords words, zero at launch); the
+// last-arriving block hands them to the host (host-mapped buffer, then the sequence flag the host polls) and resets
+// accumulator and arrival counter for the next launch of the lane.  Agent-scope release by lane 0 after the block's
+// atomics have drained; acquire before re-reading.
+__device__ __forceinline__ void publish_sums(unsigned long long* racc, unsigned int* counter, unsigned long long* host_out,
+                                             unsigned int* host_flag, unsigned int seq, int nwords, unsigned int* s_last) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = atomicAdd(counter, 1u);
+        const unsigned int last = (prev == gridDim.x - 1) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last) {
+        if ((int)threadIdx.x < nwords) {
+            host_out[threadIdx.x] = __hip_atomic_load(racc + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            racc[threadIdx.x] = 0;
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 struct PartialEvalArgs {
     CPlanes eq;
     CPlanes x[GKR_MAX_ARITY];
     size_t mid;
     Fr ark;
-    unsigned long long* partials;  // [gridDim.x][NEV][9]
+    unsigned long long* partials;  // [gridDim.x][NEV][9]   (host_flag == nullptr: separate reduction kernel)
+    // host_flag != nullptr: the sums go straight to the host, as the fused round kernels hand theirs over
+    unsigned long long* racc;      // NEV*9-word accumulator shared by the blocks
+    unsigned int* counter;
+    unsigned long long* host_out;
+    unsigned int* host_flag;
+    unsigned int seq;
 };
 
 template <int GATE, int ARITY, int NEV>
@@ -323,7 +364,13 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a
         }
     }
 
-    block_reduce_acc<NEV, (NEV == 9 ? 27 : 27)>(acc, a.partials + (size_t)blockIdx.x * (NEV * GKR_ACC_WORDS));
+    if (a.host_flag) {
+        __shared__ unsigned int s_last;
+        block_reduce_acc<NEV, 27, true>(acc, a.racc);
+        publish_sums(a.racc, a.counter, a.host_out, a.host_flag, a.seq, NEV * GKR_ACC_WORDS, &s_last);
+    } else {
+        block_reduce_acc<NEV, 27>(acc, a.partials + (size_t)blockIdx.x * (NEV * GKR_ACC_WORDS));
+    }
 }
 
 // sum the per-block partials: out[k] = sum_b partials[b][k],  k < nwords
