@@ -1,0 +1,42 @@
+"""The bench.py output contract, checked on the committed line of the last GPU run (profiles/): every key the
+driver reads is there, with the meaning BASELINE.json gives it."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_bn24_default.json")))
+    assert files, "no committed bench line"
+    return json.loads(open(files[-1]).read().strip().splitlines()[-1])
+
+
+def test_bench_line_contract():
+    d = _latest()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["data"] == "synthetic" and "bN=24" in d["metric"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - (1 << 24) * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6     # whole-job throughput
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1
+    assert r["traffic"] is None or abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1) < 0.05   # no wasted re-reads
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_defaults_finish_quickly():
+    """No flags = N=1 and a K/W that finish within minutes (10 steps of one 2^24-hash proof each, ~0.25 s per step)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
