@@ -38,8 +38,7 @@ struct PyramidArgs {
     int nc, max_level;
     Fr seed;          // level-0 value (1, or the multiplier)
 };
-__global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, size_t idx) {
     if (idx >= ((size_t)1 << a.max_level)) return;
     const Fr one = fr_one();
     const Fr two128 = {{0u, 0u, 0u, 0u, 1u, 0u, 0u, 0u}};   // the plain integer 2^128: a Montgomery product with it divides by 2^128
@@ -58,6 +57,18 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) 
             if (a.out2.lo) st_fr(a.out2.lo, a.out2.hi, (((size_t)1 << s) - 1) + idx, fr_mul(cur, two128));
         }
     }
+}
+__global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
+    eq_suffix_pyramid_body(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// up to three pyramids of a layer in one launch (blockIdx.y selects; unused slots have max_level < 0)
+struct PyramidArgs3 {
+    PyramidArgs p[3];
+};
+__global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a) {
+    const PyramidArgs& p = a.p[blockIdx.y];
+    if (p.max_level < 0) return;
+    eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

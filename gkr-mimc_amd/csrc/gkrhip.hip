@@ -853,7 +853,6 @@ static void comm_set(int world, int rank) {
     gc.gamma = gamma;
     // every rank (taken to be on this node) runs one waiting host thread per lane
     g_wait_ranks.store(world);
-    wait_policy_update(world * (int)std::max<size_t>(gc.lanes.size(), 1));
 }
 
 int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /* nlanes x 128 */) {

@@ -46,6 +46,7 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums (reference-shaped evaluator)
+    bool racc_dirty = false;                   // a call that uses d_racc / d_counter is under way or failed half-way
     unsigned long long* d_racc = nullptr;      // GKR_CR_WORDS-word accumulator of the fused round kernels (zero between launches)
     unsigned long long* d_sums = nullptr;      // reduced sums (device)
     unsigned long long* h_sums = nullptr;      // pinned
@@ -110,14 +111,21 @@ inline int usable_cpus() {
     }
     return std::max(n, 1);
 }
-std::atomic<int> g_wait_spin_us{-1};            // -1: spin; otherwise spin this long, then sleep in 20 us steps
+std::atomic<int> g_wait_override{-2};           // GKRHIP_WAIT_SPIN_US (-2: not set; -1: always spin; n: spin n us, then sleep)
 std::atomic<int> g_wait_ranks{1};               // ranks assumed to share this host (set with the communicator)
-inline void wait_policy_update(int waiting_threads) {
-    if (const char* e = getenv("GKRHIP_WAIT_SPIN_US")) {
-        g_wait_spin_us.store(atoi(e), std::memory_order_relaxed);
-        return;
-    }
-    g_wait_spin_us.store(usable_cpus() >= waiting_threads + 2 ? -1 : 25, std::memory_order_relaxed);
+std::atomic<int> g_proofs_in_flight{0};          // gkr.Prove calls currently running in this process (any lane)
+inline int wait_spin_limit_us() {
+    static const int cpus = usable_cpus();
+    static const bool init = [] {
+        if (const char* e = getenv("GKRHIP_WAIT_SPIN_US")) g_wait_override.store(atoi(e), std::memory_order_relaxed);
+        return true;
+    }();
+    (void)init;
+    const int ov = g_wait_override.load(std::memory_order_relaxed);
+    if (ov > -2) return ov;
+    // one waiting host thread per proof in flight and rank
+    const int waiting = g_wait_ranks.load(std::memory_order_relaxed) * std::max(1, g_proofs_in_flight.load(std::memory_order_relaxed));
+    return cpus >= waiting + 2 ? -1 : 25;
 }
 struct Waiter {                                 // one per wait: call step() in the polling loop
     unsigned long spins = 0;
@@ -125,7 +133,7 @@ struct Waiter {                                 // one per wait: call step() in 
     inline void step() {
         __builtin_ia32_pause();
         if ((++spins & 127) != 0) return;
-        const int lim = g_wait_spin_us.load(std::memory_order_relaxed);
+        const int lim = wait_spin_limit_us();
         if (lim < 0) return;
         if (t0 == 0) { t0 = now_ms(); return; }
         if ((now_ms() - t0) * 1e3 > lim) {
@@ -134,7 +142,6 @@ struct Waiter {                                 // one per wait: call step() in 
         }
     }
 };
-std::atomic<int> g_proofs_in_flight{0};          // gkr.Prove calls currently running (any lane)
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
     ~ProofInFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -273,7 +280,6 @@ Ctx* lane_create() {
     l->ready = true;
     std::lock_guard<std::mutex> lk(g_lanes_mu);
     g_lanes.push_back(l);
-    wait_policy_update(g_wait_ranks.load() * (int)g_lanes.size());   // one waiting host thread per lane and rank
     return l;
 }
 void lane_destroy(Ctx* l) {

@@ -34,31 +34,41 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
     CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
     CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
-    PyramidArgs pa;
-    pa.out = pyrT.planes();
-    pa.q = cx().d_q;
-    pa.nc = m;
-    pa.max_level = gT;
-    pa.seed = to_dev(seed);
-    pa.out2 = Planes{nullptr, nullptr};
-    hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
+    // the per-lane pyramid (over all of q) and the per-iteration pyramids (one per thread split) in ONE launch
+    PyramidArgs3 pa3;
+    memset(&pa3, 0, sizeof pa3);
+    for (int v = 0; v < 3; v++) pa3.p[v].max_level = -1;
+    pa3.p[0].out = pyrT.planes();
+    pa3.p[0].out2 = Planes{nullptr, nullptr};
+    pa3.p[0].q = cx().d_q;
+    pa3.p[0].nc = m;
+    pa3.p[0].max_level = gT;
+    pa3.p[0].seed = to_dev(seed);
+    int widest = gT;
     for (int v = 0; v < (g_big != gsplit[0] ? 2 : 1); v++) {
         const int mU = m - 1 - gsplit[v];              // log2(iterations of round 0 at this split)
         CHK(table_alloc(&pyrU[v], (size_t)2 << std::max(mU, 0)));
         CHK(table_alloc(&pyrU2[v], (size_t)2 << std::max(mU, 0)));
         if (mU > 0) {
+            PyramidArgs& pa = pa3.p[1 + v];
             pa.out = pyrU[v].planes();
             pa.out2 = pyrU2[v].planes();
+            pa.q = cx().d_q;
             pa.nc = m - gsplit[v];                     // q[0 .. m-g-1]; level L = eq(q[nc-L .. nc-1], .)
             pa.max_level = mU;
             pa.seed = to_dev(hfr::ONE);
-            hipLaunchKernelGGL(k_eq_suffix_pyramid, dim3(grid_for((size_t)1 << mU, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, pa);
+            widest = std::max(widest, mU);
         }
     }
+    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 3), dim3(GKR_BLOCK), 0, cx().stream, pa3);
     HIPCHK(hipGetLastError());
-    // the shared accumulator and the arrival counter are zero between launches; make sure of it after a failed call
-    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
-    HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+    // the shared accumulator and the arrival counter are zero between launches (the last workgroup of every launch
+    // resets them); only a call that failed half-way can leave them dirty
+    if (cx().racc_dirty) {
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+    }
+    cx().racc_dirty = true;                            // until this call has run to its end
     if (collective) CHK(coll_buffers(256));
 
     static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
@@ -194,6 +204,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     }
     r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
+    cx().racc_dirty = false;
     table_release(&pyrT);
     for (int v = 0; v < 2; v++) {
         if (pyrU[v].base) table_release(&pyrU[v]);
@@ -272,9 +283,11 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
                    E* proof, E* chal, E* last) {
     const size_t n = (size_t)1 << m;
     const int nev = gate_degree(gate) + 2;
-    // the shared accumulator and the arrival counter are zero between launches; make sure of it after a failed call
-    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
-    HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+    if (cx().racc_dirty) {   // see cipher_rounds
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+    }
+    cx().racc_dirty = true;
     DevTable scratch[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) CHK(table_alloc(&scratch[k], std::max<size_t>(n / 2, 1)));
     const DevTable* cur[GKR_MAX_ARITY + 1];
@@ -302,6 +315,7 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
     all[0] = eq;
     for (int t = 0; t < arity; t++) all[1 + t] = cur[t];
     CHK(gather0(all, arity + 1, last));   // finalClaims (prover.go:79-86)
+    cx().racc_dirty = false;
     for (int k = 0; k < arity; k++) table_release(&scratch[k]);
     return 0;
 }
