@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libgkrhip.so")
 SRC = os.path.join(HERE, "csrc", "gkrhip.hip")
 DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("gkrhip.hip", "host_ctx.hip.h", "host_coll.hip.h", "host_sumcheck.hip.h", "host_circuit.hip.h", "kernels.hip.h", "cipher_round.hip.h", "fr_bn254.h", "fr_mont_gen.inc", "fr_mont2_gen.inc", "fr_mac_wide_gen.inc", "fr_mulc2_gen.inc", "fr_host.h", "arks_bn254.inc")] + \
+        ("gkrhip.hip", "host_ctx.hip.h", "host_coll.hip.h", "host_sumcheck.hip.h", "host_circuit.hip.h", "kernels.hip.h", "cipher_round.hip.h", "linear_round.hip.h", "fr_bn254.h", "fr_mont_gen.inc", "fr_mont2_gen.inc", "fr_mac_wide_gen.inc", "fr_mulc2_gen.inc", "fr_host.h", "arks_bn254.inc")] + \
        [os.path.join(os.path.dirname(HERE), "include", "gkrhip.h")]
 
 

@@ -29,6 +29,7 @@
 #include "fr_host.h"
 #include "kernels.hip.h"
 #include "cipher_round.hip.h"
+#include "linear_round.hip.h"
 
 using hfr::E;
 

@@ -274,6 +274,121 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     return 0;
 }
 
+// ---- single-point sumcheck of a linear gate: one fused launch per round (linear_round.hip.h) ------------------
+// Tables X[0..arity) of 2^m entries (m >= 1), coordinates q[0:m].  On return: c has absorbed eq(q_k, r_k) of every
+// round, proof/chal hold m rounds of 3 coefficients, finals[t] = X_t folded on every challenge.
+int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* const* X, const E* q, E& c, E* proof, E* chal,
+                  E* finals, E* claim /* running claim, or nullptr */, bool* claim_known) {
+    const size_t n = (size_t)1 << m;
+    const int gT = std::min(cx().g_max, m - 1);
+    const int mU = m - 1 - gT;
+    CHK(stage_coords(q, (size_t)m));
+    DevTable pyrT, pyrU, scratch[2];
+    CHK(table_alloc(&pyrT, (size_t)2 << gT));
+    CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
+    for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
+    PyramidArgs3 pa3;
+    memset(&pa3, 0, sizeof pa3);
+    for (int v = 0; v < 3; v++) pa3.p[v].max_level = -1;
+    pa3.p[0].out = pyrT.planes();
+    pa3.p[0].q = cx().d_q;
+    pa3.p[0].nc = m;
+    pa3.p[0].max_level = gT;
+    pa3.p[0].seed = to_dev(hfr::ONE);
+    if (mU > 0) {
+        pa3.p[1].out = pyrU.planes();
+        pa3.p[1].q = cx().d_q;
+        pa3.p[1].nc = m - gT;
+        pa3.p[1].max_level = mU;
+        pa3.p[1].seed = to_dev(hfr::ONE);
+    }
+    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(gT, mU), 1 << 20), 3), dim3(GKR_BLOCK), 0,
+                       cx().stream, pa3);
+    HIPCHK(hipGetLastError());
+    if (cx().racc_dirty) {   // see cipher_rounds
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+    }
+    cx().racc_dirty = true;
+    const E two128 = {{0, 0, 1, 0}};
+    E r_prev = hfr::ZERO;
+    for (int k = 0; k < m; k++) {
+        const size_t P = n >> (k + 1);
+        const int gk = std::min(cx().g_max, m - 1 - k);
+        const int lj = m - 1 - k - gk;
+        LinearRoundArgs a;
+        memset(&a, 0, sizeof a);
+        const bool fold = k > 0;
+        for (int t = 0; t < arity; t++) {
+            a.src[t] = (k <= 1 ? X[t] : &scratch[t])->cplanes();
+            a.dst[t] = scratch[t].planes();
+        }
+        const size_t offT = ((size_t)1 << gk) - 1;
+        a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
+        if (lj > 0) {
+            const size_t offU = ((size_t)1 << lj) - 1;
+            a.wj = CPlanes{pyrU.base + offU, pyrU.base + pyrU.cap + offU};
+        }
+        a.P = P;
+        a.lg_threads = (unsigned)gk;
+        a.r = to_dev(r_prev);
+        a.r_lo = to_dev(hfr::mul(r_prev, two128));
+        a.ark = to_dev(gate == GKRHIP_GATE_ADD ? ark : hfr::ZERO);
+        a.arity = arity;
+        a.gate_inputs = gate == GKRHIP_GATE_ADD ? 2 : 1;
+        a.racc = cx().d_racc;
+        a.counter = cx().d_counter;
+        a.host_out = cx().d_round;
+        a.host_flag = cx().d_flag;
+        a.seq = ++cx().seq;
+        const bool derive_m0 = claim && *claim_known;
+        a.need_m0 = derive_m0 ? 0u : 1u;
+        const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
+        if (fold) {
+            if (lj > 0) hipLaunchKernelGGL((k_linear_round<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else hipLaunchKernelGGL((k_linear_round<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+        } else {
+            if (lj > 0) hipLaunchKernelGGL((k_linear_round<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else hipLaunchKernelGGL((k_linear_round<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+        }
+        HIPCHK(hipGetLastError());
+        CHK(wait_flag(a.seq));
+        const unsigned long long* words = cx().h_round;
+        // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
+        const E cm1 = hfr::mul(c, limbs9_to_fr(words + GKR_ACC_WORDS));
+        const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, limbs9_to_fr(words));
+        const E a0 = hfr::sub(hfr::ONE, q[k]);
+        const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
+        E* co = proof + (size_t)k * 3;
+        co[0] = hfr::mul(a0, cm0);
+        co[1] = hfr::add(hfr::mul(a0, cm1), hfr::mul(a1, cm0));
+        co[2] = hfr::mul(a1, cm1);
+        const E r = hfr::mimc_hash(co, 3);
+        chal[k] = r;
+        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
+        r_prev = r;
+        if (claim) {
+            *claim = hfr::eval_univariate(co, 3, r);
+            *claim_known = true;
+        }
+        if (k == m - 1) {
+            for (int t = 0; t < arity; t++) {
+                E lo, hi;
+                memcpy(&lo, words + GKR_LR_WORDS + 8 * t, sizeof(E));
+                memcpy(&hi, words + GKR_LR_WORDS + 8 * t + 4, sizeof(E));
+                finals[t] = fold2(lo, hi, r);
+            }
+        }
+        cx().prof.rounds++;
+    }
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    cx().racc_dirty = false;
+    table_release(&pyrT);
+    table_release(&pyrU);
+    for (int t = 0; t < arity; t++) table_release(&scratch[t]);
+    return 0;
+}
+
 int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }   // cipher.go:68-70; copy.go:30-32; add: linear
 
 // The reference-shaped rounds (sumcheck/prover.go:70-76) over an Eq table and `arity` tables of 2^m entries:
@@ -351,6 +466,18 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
     if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !cx().force_generic)
         return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims,
                                     (trust_claims && nclaims == 1) ? &claims[0] : nullptr, trust_claims && cx().claim_trick);
+
+    // single-point linear layers (identity, add) of an un-sharded prover: fused rounds, no Eq table
+    if ((gate == GKRHIP_GATE_IDENTITY || (gate == GKRHIP_GATE_ADD && arity == 2)) && nq_used == 1 && bN >= 1 && gamma == 0 &&
+        !cx().force_generic && !cx().force_collective) {
+        E c = hfr::ONE;
+        E claim = (trust_claims && nclaims == 1) ? claims[0] : hfr::ZERO;
+        bool claim_known = trust_claims && nclaims == 1;
+        CHK(linear_rounds(gate, ark, arity, bN, X, qprimes, c, proof, challenges, final_claims + 1,
+                          (trust_claims && cx().claim_trick) ? &claim : nullptr, &claim_known));
+        final_claims[0] = c;
+        return 0;
+    }
 
     // phase 1: this rank's shard; Eq_local = sum_j seed_j * eq(q_j tail, rank) * eq(q_j[0:m1], .)
     if (gamma > 0)

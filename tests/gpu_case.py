@@ -15,8 +15,27 @@ import coracle as c  # noqa: E402
 
 def main():
     sizes = [int(x) for x in sys.argv[1].split(",")]
+    circuit = sys.argv[2] if len(sys.argv) > 2 else "mimc"
     gk = importlib.import_module("gkr-mimc_amd")
     gk.init(0)
+    if circuit == "gmimc":      # the build-defined GMiMC (t = 2) circuit: cipher, add and identity layers
+        import pyoracle as o
+        layers = gk.gmimc_t2_circuit()
+        descs = c.circuit_descs(o.gmimc_t2_circuit())
+        for bn in sizes:
+            n = 1 << bn
+            ins = [c.random_fr_array(n) if i % 2 == 0 else c.from_ints([(7 * j * j + i) % 1000003 for j in range(n)]) for i in range(4)]
+            qp = c.random_fr_array(bn)
+            s = gk.MimcSession(bn, layers=layers)
+            for i, t in enumerate(ins):
+                s.load_input(i, t)
+            s.assign()
+            flat = s.prove(qp)
+            oflat, _oouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+            assert np.array_equal(flat, oflat), ("gmimc", bn)
+            s.close()
+        print("CASE-OK", sizes)
+        return
     for bn in sizes:
         n = 1 << bn
         rng = np.random.default_rng(bn)

@@ -180,6 +180,23 @@ def test_sumcheck_multi_identity_vs_oracle(gk, bn):
     assert np.array_equal(recomb, c.mimc_hash(claims))
 
 
+@pytest.mark.parametrize("bn", [1, 2, 3, 6, 9, 10, 13, 17, 18])
+def test_sumcheck_linear_gates_single_point_vs_oracle(gk, bn):
+    """One evaluation point and a linear gate (identity with one and with two tables, the add gate): the fused
+    linear rounds (linear_round.hip.h) against the oracle; carry-corner tables; the claim is false on purpose for
+    the add gate (the transcript does not depend on it)."""
+    n = 1 << bn
+    q = c.random_fr_array(bn).reshape(1, bn, 4)
+    A, B = nasty(n, bn + 40), c.random_fr_array(n)
+    ark = c.from_u64(3 * bn + 1)
+    for gate, X, a, cl in ((gk.GATE_IDENTITY, [A], None, c.evaluation(c.GATE_IDENTITY, None, q, c.fr(0), [A])),
+                           (gk.GATE_IDENTITY, [B, A], None, c.evaluation(c.GATE_IDENTITY, None, q, c.fr(0), [B, A])),
+                           (gk.GATE_ADD, [A, B], ark, c.from_u64(77))):
+        proof, chal, final = gk.sumcheck_prove(X, q, cl, gate, a)
+        oproof, ochal, ofinal = c.sumcheck_prove(gate, a, X, q, cl)
+        assert np.array_equal(proof, oproof) and np.array_equal(chal, ochal) and np.array_equal(final, ofinal), gate
+
+
 def test_sumcheck_91_claims(gk):
     # shape of MiMC layer 2 / BenchmarkMultiIdentity (sumcheck/prover_test.go:111-125) at bn = 10
     X, claims, qs = _multi_instance(10, 91)
@@ -255,12 +272,12 @@ def test_sumcheck_cipher_bn20_vs_oracle(gk):
     assert np.array_equal(proof, oproof) and np.array_equal(chal, ochal) and np.array_equal(final, ofinal)
 
 
-def _run_case(env, sizes):
+def _run_case(env, sizes, circuit="mimc"):
     import os, subprocess, sys
     e = dict(os.environ)
     e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, "gpu_case.py"), sizes], env=e, capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(here, "gpu_case.py"), sizes, circuit], env=e, capture_output=True,
                          text=True, timeout=1200)
     assert out.returncode == 0 and "CASE-OK" in out.stdout, out.stdout + out.stderr
 
@@ -269,6 +286,8 @@ def test_generic_partial_eval_path(gk):
     """The reference-shaped evaluator (t = 0..8, Eq table folded) stays available and bit-identical:
     GKRHIP_GENERIC=1 routes cipher layers through k_partial_eval + k_fold instead of k_cipher_round."""
     _run_case({"GKRHIP_GENERIC": "1"}, "1,2,5,9,12")
+    _run_case({"GKRHIP_GMAX": "8"}, "9,11", circuit="gmimc")       # fused linear rounds with several pairs per lane
+    _run_case({"GKRHIP_GENERIC": "1"}, "3,8", circuit="gmimc")     # the same circuit through the reference-shaped rounds
 
 
 def test_round_kernel_small_thread_budget(gk):
