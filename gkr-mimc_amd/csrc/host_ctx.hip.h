@@ -70,6 +70,7 @@ struct Ctx {
     bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
+    int g_lin = 0;                             // GKRHIP_GLIN: log2(max threads) of the linear-gate round kernel when above g_max (measured: no gain)
     int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
@@ -196,12 +197,13 @@ int ctx_init(int dev) {
         return fail("device %d is %s; libgkrhip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
     cx().n_cu = prop.multiProcessorCount;
     cx().max_grid = cx().n_cu * 32;   // streaming kernels: 8192 workgroups measured best for the fold (profiles/)
-    if (const char* e = getenv("GKRHIP_GMAX")) cx().g_max = std::max(8, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_GMAX")) cx().g_max = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_GENERIC")) cx().force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) cx().lat_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WIDE")) cx().wide_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WT_LATE_LJ")) cx().wt_late_lj = atoi(e);
     if (const char* e = getenv("GKRHIP_SOLO_BOOST")) cx().solo_boost = atoi(e);
+    if (const char* e = getenv("GKRHIP_GLIN")) cx().g_lin = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
@@ -268,6 +270,7 @@ Ctx* lane_create() {
     l->wide_mode = g0.wide_mode;
     l->wt_late_lj = g0.wt_late_lj;
     l->solo_boost = g0.solo_boost;
+    l->g_lin = g0.g_lin;
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->lag = g0.lag;

@@ -280,7 +280,9 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
 int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* const* X, const E* q, E& c, E* proof, E* chal,
                   E* finals, E* claim /* running claim, or nullptr */, bool* claim_known) {
     const size_t n = (size_t)1 << m;
-    const int gT = std::min(cx().g_max, m - 1);
+    // HBM-bound rounds with a few dozen registers per lane: many more lanes than the compute-bound cipher rounds
+    const int g_lin = std::max(cx().g_max, cx().g_lin);
+    const int gT = std::min(g_lin, m - 1);
     const int mU = m - 1 - gT;
     CHK(stage_coords(q, (size_t)m));
     DevTable pyrT, pyrU, scratch[2];
@@ -314,7 +316,7 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
     E r_prev = hfr::ZERO;
     for (int k = 0; k < m; k++) {
         const size_t P = n >> (k + 1);
-        const int gk = std::min(cx().g_max, m - 1 - k);
+        const int gk = std::min(g_lin, m - 1 - k);
         const int lj = m - 1 - k - gk;
         LinearRoundArgs a;
         memset(&a, 0, sizeof a);
