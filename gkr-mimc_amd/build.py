@@ -21,7 +21,10 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO, SRC]
+    # host side: BMI2/ADX (mulx, adcx/adox) for the Fiat-Shamir hash's dependent multiplication chain (-16..20 % latency);
+    # gkrhip_init refuses a CPU without them
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xarch_host", "-mbmi2", "-Xarch_host", "-madx",
+           "-o", SO, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -176,6 +176,10 @@ struct LocalOnly {
 extern "C" {
 
 int gkrhip_init(int device_ordinal) {
+#if defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__)
+    if (!__builtin_cpu_supports("bmi2") || !__builtin_cpu_supports("adx"))
+        return fail("this build of libgkrhip.so needs a host CPU with BMI2 and ADX (every x86-64 server CPU since 2015)");
+#endif
     std::lock_guard<std::mutex> lk(g0.mu);
     UseLane u(&g0);
     return ctx_init(device_ordinal);
