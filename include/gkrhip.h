@@ -41,7 +41,8 @@ const char *gkrhip_version(void);
 int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
 int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
- * "g_max", "lat_mode", "claim_trick" -- applied to every existing lane */
+ * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick" -- applied to every existing lane (DESIGN.md,
+ * "Runtime switches", lists the environment variables read at gkrhip_init) */
 int gkrhip_set_option(const char *key, long value);
 
 /* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
@@ -146,9 +147,11 @@ int gkrhip_mimc_permutation_batch(uint64_t *out, const uint64_t *x, const uint64
  * (synth: index_stride = world, index_offset = rank).  Host-buffer entry points stay un-sharded. */
 int gkrhip_comm_unique_id(uint8_t out[128]);
 int gkrhip_comm_init(int world, int rank, const uint8_t unique_id[128]);
-/* Same protocol over a POSIX shared-memory segment `name` (rank 0 creates it): the sums are formed on the
- * host.  For processes of one node that cannot form an RCCL communicator -- in particular several ranks
- * time-sharing ONE GPU, which is how the sharded driver is tested on single-GPU machines. */
+/* Same protocol with the exchange on the host: the round kernels hand their 576-byte sums to the host as in the
+ * un-sharded case and the ranks add them through a POSIX shared-memory segment `name` (rank 0 creates it and
+ * unlinks it once every rank has mapped it; use a name no earlier run can have left behind).  For the ranks of ONE
+ * node this is the faster transport (no collective kernel queues behind the compute-bound rounds: DESIGN.md section 6);
+ * it is also how several ranks time-share one GPU in the tests. */
 int gkrhip_comm_init_shm(int world, int rank, const char *name);
 /* Several lanes per rank (1..8): lane k owns its own stream, buffers and communicator (unique id k /
  * segment `name`_k) and pairs with lane k of the other ranks, so `nlanes` independent proofs can be in
