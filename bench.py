@@ -83,7 +83,7 @@ def main():
     import numpy as np
     # every proof in flight keeps its own resident assignment (93 tables of 2^bn elements) plus scratch
     free_b, _total_b = gk.mem_info()
-    per_session = (96 if args.circuit == "mimc" else 104) * 32 * (1 << args.bn)
+    per_session = (94.25 if args.circuit == "mimc" else 104) * 32 * (1 << args.bn)   # 93 tables + two half-size scratch tables + pyramids
     nconc = max(1, min(args.concurrent, args.steps, int(args.mem_fraction * free_b // per_session)))
     if nconc > 1 and args.steps % nconc and args.steps % (nconc - 1) == 0:
         nconc -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
