@@ -154,21 +154,24 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
 
 }  // namespace
 
-// Host-buffer entry points (Fold, Evaluate, FoldedEqTable, EvalBatch, sumcheck.Prove on host tables) always
-// run un-sharded on this process's GPU, whatever communicator is installed; only sessions shard.
-struct LocalOnly {
-    int world, rank, gamma;
-    LocalOnly() : world(gc.world), rank(gc.rank), gamma(gc.gamma) {
-        gc.world = 1;
-        gc.rank = 0;
-        gc.gamma = 0;
+// Visit every lane with its mutex held.  Lock order: default lane (g0.mu) -> lane list -> the lane.  A lane in
+// the middle of a proof keeps its mutex for the whole proof, so the visit waits for proofs in flight; holding the
+// lane list keeps a concurrent session destroy from freeing a lane under the visitor.
+namespace {
+template <class F>
+int for_each_lane(F&& fn) {
+    std::lock_guard<std::mutex> lk0(g0.mu);
+    CHK(ensure_ctx());
+    std::lock_guard<std::mutex> ll(g_lanes_mu);
+    for (Ctx* l : g_lanes) {
+        std::unique_lock<std::mutex> lk;
+        if (l != &g0) lk = std::unique_lock<std::mutex>(l->mu);
+        UseLane u(l);
+        CHK(fn(l));
     }
-    ~LocalOnly() {
-        gc.world = world;
-        gc.rank = rank;
-        gc.gamma = gamma;
-    }
-};
+    return 0;
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -191,6 +194,7 @@ void gkrhip_shutdown(void) {
     UseLane u(&g0);
     (void)hipSetDevice(cx().device);
     lane_free();
+    lane_pool_drain();
     {
         std::lock_guard<std::mutex> pl(g_pool.mu);
         for (auto& f : g_pool.free_list) (void)hipFree(f.second);
@@ -216,14 +220,11 @@ const char* gkrhip_last_error(void) { return g_err.c_str(); }
 const char* gkrhip_version(void) { return "gkrhip 0.1 (gfx950)"; }
 
 int gkrhip_set_option(const char* key, long value) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
-    std::vector<Ctx*> lanes;
-    {
-        std::lock_guard<std::mutex> ll(g_lanes_mu);
-        lanes = g_lanes;
-    }
-    for (Ctx* l : lanes) {
+    static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail"};
+    bool known = false;
+    for (const char* k : keys) known = known || !strcmp(key, k);
+    if (!known) return fail("unknown option %s", key);
+    return for_each_lane([&](Ctx* l) {
         if (!strcmp(key, "fold_grid")) l->fold_grid = (int)std::max(64L, value);
         else if (!strcmp(key, "fold_split")) l->fold_split = value != 0;
         else if (!strcmp(key, "g_max")) l->g_max = (int)std::max(8L, std::min(20L, value));
@@ -231,9 +232,9 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "wide_mode")) l->wide_mode = (int)value;
         else if (!strcmp(key, "wt_late_lj")) l->wt_late_lj = (int)value;
         else if (!strcmp(key, "claim_trick")) l->claim_trick = value != 0;
-        else return fail("unknown option %s", key);
-    }
-    return 0;
+        else if (!strcmp(key, "host_tail")) l->host_tail = (int)std::max(0L, std::min(6L, value));
+        return 0;
+    });
 }
 
 int gkrhip_mem_info(size_t* free_bytes, size_t* total_bytes) {
@@ -247,22 +248,17 @@ int gkrhip_mem_info(size_t* free_bytes, size_t* total_bytes) {
 }
 
 int gkrhip_device_synchronize(void) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
-    std::vector<Ctx*> lanes;
-    {
-        std::lock_guard<std::mutex> ll(g_lanes_mu);
-        lanes = g_lanes;
-    }
-    for (Ctx* l : lanes) HIPCHK(hipStreamSynchronize(l->stream));
-    return 0;
+    return for_each_lane([&](Ctx* l) {
+        HIPCHK(hipStreamSynchronize(l->stream));
+        return 0;
+    });
 }
 
 int gkrhip_fold(uint64_t* table, size_t n, const uint64_t r[4]) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (n < 2 || (n & (n - 1))) return fail("Fold: table length %zu is not a power of two >= 2", n);
-    DevTable t, o;
+    ScopedTable t, o;
     CHK(table_alloc(&t, n));
     CHK(table_alloc(&o, n / 2));
     CHK(upload_table(&t, table, n));
@@ -283,7 +279,7 @@ int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint
     if (n < 1 || (n & (n - 1))) return fail("Evaluate: table length %zu is not a power of two", n);
     if (((size_t)1 << ncoords) != n) return fail("Evaluate: table has %zu elements but %d coordinates were given", n, ncoords);
     LocalOnly lo;
-    DevTable t;
+    ScopedTable t;
     CHK(table_alloc(&t, n));
     CHK(upload_table(&t, table, n));
     E res;
@@ -297,7 +293,7 @@ int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mu
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (bN < 0 || bN > 30) return fail("eq table: bN %d out of range", bN);
-    DevTable t;
+    ScopedTable t;
     const size_t n = (size_t)1 << bN;
     CHK(table_alloc(&t, n));
     E seed = hfr::ONE;
@@ -313,7 +309,8 @@ int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res,
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
-    DevTable in[GKR_MAX_ARITY], out;
+    if (n < 1) return fail("EvalBatch: empty tables");
+    ScopedTable in[GKR_MAX_ARITY], out;
     const DevTable* inp[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) {
         CHK(table_alloc(&in[k], n));
@@ -339,7 +336,7 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int 
     if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
     const size_t n = (size_t)1 << bN;
     LocalOnly lo;
-    DevTable tabs[GKR_MAX_ARITY];
+    ScopedTable tabs[GKR_MAX_ARITY];
     const DevTable* X_[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) {
         CHK(table_alloc(&tabs[k], n));
@@ -469,7 +466,9 @@ int gkrhip_mimc_session_assign(gkrhip_session* s) {
 
 int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_t* flat) {
     SESSION_ENTER(s);
-    return session_prove(s, (const E*)qprime, (E*)flat);
+    const int rc = session_prove(s, (const E*)qprime, (E*)flat);
+    if (rc != 0) shm_abort();     // a sharded proof that fails on this rank must not leave the peers waiting
+    return rc;
 }
 
 int gkrhip_mimc_session_outputs(gkrhip_session* s, uint64_t* outputs) {
@@ -515,14 +514,19 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
     int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
     if (rc == 0) rc = gkrhip_mimc_session_assign(s);
     // The output table is final once the assignment is: its download (transposition + 2^bN x 32 bytes over PCIe into
-    // pageable memory) runs on the default lane's stream from a second host thread while this thread proves.
+    // pageable memory) runs on a lane of its own from a second host thread while this thread proves.
     int rc_out = 0;
     std::string err_out;
     std::thread dl;
+    Ctx* dl_lane = nullptr;
     if (rc == 0 && outputs_or_null && s->lane != &g0) {
+        std::lock_guard<std::mutex> lk(g0.mu);
+        dl_lane = lane_create();
+    }
+    if (dl_lane) {
         dl = std::thread([&]() {
-            std::lock_guard<std::mutex> lk(g0.mu);
-            UseLane u(&g0);
+            std::lock_guard<std::mutex> lk(dl_lane->mu);
+            UseLane u(dl_lane);
             rc_out = hipSetDevice(g0.device) == hipSuccess ? download_table(session_table(s, (int)s->c.size() - 1), outputs_or_null, s->n)
                                                            : fail("hipSetDevice failed");
             if (rc_out) err_out = g_err;
@@ -531,6 +535,7 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
     if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
     if (dl.joinable()) {
         dl.join();
+        lane_destroy(dl_lane);
         if (rc == 0 && rc_out) {
             g_err = err_out;
             rc = rc_out;
@@ -567,7 +572,7 @@ int gkrhip_mimc_permutation_batch(uint64_t* out, const uint64_t* x, const uint64
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (n == 0) return 0;
-    DevTable tx, tk, to;
+    ScopedTable tx, tk, to;
     CHK(table_alloc(&tx, n));
     CHK(table_alloc(&tk, n));
     CHK(table_alloc(&to, n));
@@ -657,7 +662,7 @@ int gkrhip_gkr_verify_mimc(int bN, const uint64_t* flat, const uint64_t* in0, co
     if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
     const size_t n = (size_t)1 << bN;
     const Circuit c = mimc_circuit();
-    DevTable t[3];
+    ScopedTable t[3];
     const uint64_t* host[3] = {in0, in1, outputs};
     for (int i = 0; i < 3; i++) {
         CHK(table_alloc(&t[i], n));
@@ -722,70 +727,36 @@ int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms)
 }
 
 int gkrhip_profile_reset(size_t min_n) {
-    {
-        std::lock_guard<std::mutex> lk(g0.mu);
-        CHK(ensure_ctx());
-    }
-    std::vector<Ctx*> lanes;
-    {
-        std::lock_guard<std::mutex> ll(g_lanes_mu);
-        lanes = g_lanes;
-    }
-    for (Ctx* l : lanes) {
-        std::lock_guard<std::mutex> lk(l->mu);
-        UseLane u(l);
-        HIPCHK(hipStreamSynchronize(cx().stream));
-        for (auto& p : cx().prof.fold_ev) {
-            cx().prof.pool.push_back(p.first);
-            cx().prof.pool.push_back(p.second);
-        }
-        for (auto& p : cx().prof.peval_ev) {
-            cx().prof.pool.push_back(p.first);
-            cx().prof.pool.push_back(p.second);
-        }
-        cx().prof.fold_ev.clear();
-        cx().prof.peval_ev.clear();
-        cx().prof.fold_launches = cx().prof.peval_launches = 0;
-        cx().prof.fold_bytes = cx().prof.peval_modmuls = 0;
-        cx().prof.host_hash_ms = cx().prof.host_wait_ms = cx().prof.host_launch_ms = cx().prof.host_other_ms = 0;
-        cx().prof.rounds = 0;
-        cx().prof.min_n = min_n == 0 ? ((size_t)1 << 62) : min_n;
-    }
-    return 0;
+    return for_each_lane([&](Ctx* l) {
+        HIPCHK(hipStreamSynchronize(l->stream));
+        prof_clear(l->prof);
+        l->prof.min_n = min_n == 0 ? ((size_t)1 << 62) : min_n;
+        return 0;
+    });
 }
 
 int gkrhip_profile_get(uint64_t* fold_launches, double* fold_ms, double* fold_bytes, uint64_t* peval_launches,
                        double* peval_ms, double* peval_modmuls) {
-    {
-        std::lock_guard<std::mutex> lk(g0.mu);
-        CHK(ensure_ctx());
-    }
     double fm = 0, pm = 0, fb = 0, pmm = 0;
     uint64_t fl = 0, pl = 0;
-    std::vector<Ctx*> lanes;
-    {
-        std::lock_guard<std::mutex> ll(g_lanes_mu);
-        lanes = g_lanes;
-    }
-    for (Ctx* l : lanes) {
-        std::lock_guard<std::mutex> lk(l->mu);
-        UseLane u(l);
-        HIPCHK(hipStreamSynchronize(cx().stream));
-        for (auto& p : cx().prof.fold_ev) {
+    CHK(for_each_lane([&](Ctx* l) {
+        HIPCHK(hipStreamSynchronize(l->stream));
+        for (auto& p : l->prof.fold_ev) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
             fm += ms;
         }
-        for (auto& p : cx().prof.peval_ev) {
+        for (auto& p : l->prof.peval_ev) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
             pm += ms;
         }
-        fl += cx().prof.fold_launches;
-        pl += cx().prof.peval_launches;
-        fb += cx().prof.fold_bytes;
-        pmm += cx().prof.peval_modmuls;
-    }
+        fl += l->prof.fold_launches;
+        pl += l->prof.peval_launches;
+        fb += l->prof.fold_bytes;
+        pmm += l->prof.peval_modmuls;
+        return 0;
+    }));
     if (fold_launches) *fold_launches = fl;
     if (fold_ms) *fold_ms = fm;
     if (fold_bytes) *fold_bytes = fb;
@@ -818,25 +789,47 @@ static Ctx* comm_lane(int k) {
 static int shm_attach(int world, int rank, const char* name) {   // on the current lane
     const size_t bytes = 4096 + sizeof(unsigned long long) * kShmSlotWords * world;
     int fd = -1;
+    const double t_start = now_ms();
     if (rank == 0) {
         (void)shm_unlink(name);                        // a leftover of a crashed run; names should be unique per run anyway
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return fail("shm_open/ftruncate(%s) failed", name);
     } else {
-        for (int tries = 0; tries < 20000; tries++) {   // wait for rank 0 to create and size the segment
+        for (;;) {   // wait for rank 0 to create and size the segment
             fd = shm_open(name, O_RDWR, 0600);
             struct stat st;
             if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
             if (fd >= 0) close(fd);
             fd = -1;
+            if (now_ms() - t_start > coll_timeout_ms()) return fail("shm segment %s did not appear", name);
             usleep(1000);
         }
-        if (fd < 0) return fail("shm segment %s did not appear", name);
     }
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) return fail("mmap of %s failed", name);
-    cx().lc.shm = (ShmHdr*)p;
+    ShmHdr* h = (ShmHdr*)p;
+    // rank 0 stamps the (zero-filled) segment with its creation time, last of all; peers accept only a segment that
+    // was stamped within the time-out window, so the leftover of an earlier run under the same name is refused
+    // instead of being waited on
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    if (rank == 0) {
+        h->magic.store(kShmMagic ^ (unsigned long long)ts.tv_sec, std::memory_order_release);
+    } else {
+        for (;;) {
+            const unsigned long long m = h->magic.load(std::memory_order_acquire);
+            clock_gettime(CLOCK_REALTIME, &ts);
+            const long long age = (long long)ts.tv_sec - (long long)(m ^ kShmMagic);
+            if (m != 0 && age >= -5 && age * 1e3 <= coll_timeout_ms() + 5e3) break;
+            if (now_ms() - t_start > coll_timeout_ms()) {
+                munmap(p, bytes);
+                return fail("shm segment %s is stale or was never initialised by rank 0", name);
+            }
+            usleep(1000);
+        }
+    }
+    cx().lc.shm = h;
     cx().lc.shm_slots = (unsigned long long*)((char*)p + 4096);
     cx().lc.shm_bytes = bytes;
     CHK(coll_buffers(4096));
@@ -903,7 +896,7 @@ int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char* name
     comm_set(world, rank);
     for (int k = 0; k < nlanes; k++) {
         UseLane u(gc.lanes[k]);
-        shm_barrier();   // everybody mapped (the segments are zero-filled by ftruncate)
+        CHK(shm_barrier());   // everybody mapped (the segments are zero-filled by ftruncate)
     }
     if (rank == 0) {     // every rank holds its mapping: the names can go (nothing is left behind in /dev/shm)
         for (int k = 0; k < nlanes; k++) {
@@ -930,12 +923,13 @@ int gkrhip_comm_destroy(void) {
                 cx().lc.comm = nullptr;
             }
             if (cx().lc.shm) {
+                cx().lc.shm->abort.store(1, std::memory_order_release);   // a peer still waiting here fails instead of hanging
                 munmap((void*)cx().lc.shm, cx().lc.shm_bytes);
                 cx().lc.shm = nullptr;
                 cx().lc.shm_slots = nullptr;
             }
         }
-        if (l != &g0) lane_destroy(l);
+        if (l != &g0) lane_destroy(l, /*pool=*/false);
     }
     gc.lanes.clear();
     gc.next_lane = 0;
@@ -994,19 +988,14 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t* M, const u
 int gkrhip_profile_host(uint64_t* rounds, double* hash_ms, double* wait_ms, double* launch_ms, double* other_ms) {
     uint64_t r = 0;
     double h = 0, w = 0, l_ = 0, o = 0;
-    std::vector<Ctx*> lanes;
-    {
-        std::lock_guard<std::mutex> ll(g_lanes_mu);
-        lanes = g_lanes;
-    }
-    for (Ctx* l : lanes) {
-        std::lock_guard<std::mutex> lk(l->mu);
+    CHK(for_each_lane([&](Ctx* l) {
         r += l->prof.rounds;
         h += l->prof.host_hash_ms;
         w += l->prof.host_wait_ms;
         l_ += l->prof.host_launch_ms;
         o += l->prof.host_other_ms;
-    }
+        return 0;
+    }));
     if (rounds) *rounds = r;
     if (hash_ms) *hash_ms = h;
     if (wait_ms) *wait_ms = w;

@@ -22,15 +22,70 @@ struct Coll {
 Coll gc;
 const size_t kShmSlotWords = 8192;
 
-void shm_barrier() {
-    const unsigned gen = cx().lc.shm->gen.load(std::memory_order_acquire);
-    if (cx().lc.shm->arrive.fetch_add(1, std::memory_order_acq_rel) == (unsigned)gc.world - 1) {
-        cx().lc.shm->arrive.store(0, std::memory_order_relaxed);
-        cx().lc.shm->gen.fetch_add(1, std::memory_order_release);
-    } else {
-        Waiter w;
-        while (cx().lc.shm->gen.load(std::memory_order_acquire) == gen) w.step();
+// The shard a call works on.  Sessions shard over the installed communicator; the host-buffer entry points (Fold,
+// Evaluate, FoldedEqTable, EvalBatch, sumcheck.Prove on host tables, the one-shot verifier) always run un-sharded
+// on this process's GPU.  They say so with a LocalOnly scope on their own thread -- the process-wide communicator
+// state is never rewritten, so a sharded proof in flight on another lane (another thread) is not disturbed.
+struct ShardView {
+    int world, rank, gamma;
+};
+thread_local int g_local_only = 0;
+struct LocalOnly {
+    LocalOnly() { g_local_only++; }
+    ~LocalOnly() { g_local_only--; }
+};
+inline ShardView shard_view() {
+    if (g_local_only) return ShardView{1, 0, 0};
+    return ShardView{gc.world, gc.rank, gc.gamma};
+}
+
+// How long a rank waits for its peers (barrier of the shared-memory transport, completion of an RCCL all-reduce)
+// before it gives up with an error: GKRHIP_COLL_TIMEOUT_S, default 300 s.  Ranks reach the first exchange of a proof
+// at different times (seconds apart when one of them was still assigning), but never minutes.
+inline double coll_timeout_ms() {
+    static const double t = [] {
+        const char* e = getenv("GKRHIP_COLL_TIMEOUT_S");
+        const double s = e ? atof(e) : 300.0;
+        return (s > 0 ? s : 300.0) * 1e3;
+    }();
+    return t;
+}
+
+// Barrier over the ranks of the lane's shared-memory segment.  Fails (instead of waiting for ever) when a peer has
+// raised the segment's abort word -- every error return of a sharded call and gkrhip_comm_destroy raise it -- or when
+// the peers do not arrive within the deadline; the rank that times out raises the abort word itself.
+int shm_barrier() {
+    ShmHdr* h = cx().lc.shm;
+    const unsigned world = (unsigned)shard_view().world;
+    const unsigned gen = h->gen.load(std::memory_order_acquire);
+    if (h->abort.load(std::memory_order_acquire)) return fail("sharded prover: a peer rank failed or left (abort word set)");
+    if (h->arrive.fetch_add(1, std::memory_order_acq_rel) == world - 1) {
+        h->arrive.store(0, std::memory_order_relaxed);
+        h->gen.fetch_add(1, std::memory_order_release);
+        return 0;
     }
+    Waiter w;
+    unsigned long spins = 0;
+    double t0 = 0;
+    while (h->gen.load(std::memory_order_acquire) == gen) {
+        w.step();
+        if ((++spins & 0xffff) != 0) continue;
+        if (h->abort.load(std::memory_order_acquire)) {
+            // a peer that leaves after the barrier completed raises the word too: the generation decides
+            if (h->gen.load(std::memory_order_acquire) != gen) break;
+            return fail("sharded prover: a peer rank failed or left (abort word set)");
+        }
+        if (t0 == 0) t0 = now_ms();
+        else if (now_ms() - t0 > coll_timeout_ms()) {
+            h->abort.store(1, std::memory_order_release);
+            return fail("sharded prover: timed out after %.0f s waiting for the other ranks", coll_timeout_ms() * 1e-3);
+        }
+    }
+    return 0;
+}
+// raise the abort word of the current lane's segment (error paths of sharded calls)
+inline void shm_abort() {
+    if (cx().lc.shm) cx().lc.shm->abort.store(1, std::memory_order_release);
 }
 
 int coll_load() {
@@ -76,46 +131,76 @@ int coll_allreduce(unsigned long long* d, int n) {
         if (!cx().lc.h_tmp) HIPCHK(hipHostMalloc(&cx().lc.h_tmp, sizeof(unsigned long long) * kShmSlotWords, hipHostMallocDefault));
         HIPCHK(hipMemcpyAsync(cx().lc.h_tmp, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, cx().stream));
         HIPCHK(hipStreamSynchronize(cx().stream));
-        memcpy(cx().lc.shm_slots + (size_t)gc.rank * kShmSlotWords, cx().lc.h_tmp, sizeof(unsigned long long) * n);
-        shm_barrier();
+        memcpy(cx().lc.shm_slots + (size_t)shard_view().rank * kShmSlotWords, cx().lc.h_tmp, sizeof(unsigned long long) * n);
+        CHK(shm_barrier());
         for (int i = 0; i < n; i++) {
             unsigned long long s = 0;
-            for (int r = 0; r < gc.world; r++) s += cx().lc.shm_slots[(size_t)r * kShmSlotWords + i];
+            for (int r = 0; r < shard_view().world; r++) s += cx().lc.shm_slots[(size_t)r * kShmSlotWords + i];
             cx().lc.h_tmp[i] = s;
         }
-        shm_barrier();
+        CHK(shm_barrier());
         HIPCHK(hipMemcpyAsync(d, cx().lc.h_tmp, sizeof(unsigned long long) * n, hipMemcpyHostToDevice, cx().stream));
         HIPCHK(hipStreamSynchronize(cx().stream));
         return 0;
     }
     return 0;
 }
+// The all-reduced words (device memory, lc.d_buf) reach the host like the un-sharded round sums: host-mapped buffer,
+// then the sequence flag the host polls.  GKRHIP_RCCL_PUBLISH=0: a one-block copy kernel (it has to find a free
+// workgroup slot behind the compute-bound rounds of the other lanes); 1: a copy + a stream memory operation
+// (hipStreamWriteValue32), both executed by the command processor / SDMA without occupying a CU.
+int coll_publish(int nwords, unsigned int seq) {
+    static const int mode = [] {
+        const char* e = getenv("GKRHIP_RCCL_PUBLISH");
+        return e ? atoi(e) : 0;
+    }();
+    if (mode == 1) {
+        HIPCHK(hipMemcpyAsync(cx().h_round, cx().lc.d_buf, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, cx().stream));
+        HIPCHK(hipStreamWriteValue32(cx().stream, cx().d_flag, seq, 0));
+        return 0;
+    }
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round, nwords, cx().d_flag, seq);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // The same sum over ranks for words that are already on the host (the round kernel's host-mapped hand-off):
 // slot write, barrier, sum, barrier.  No device round trip at all.
 int shm_allreduce_host(unsigned long long* words, int n) {
     if ((size_t)n > kShmSlotWords) return fail("shm all-reduce of %d words exceeds the slot", n);
-    memcpy(cx().lc.shm_slots + (size_t)gc.rank * kShmSlotWords, words, sizeof(unsigned long long) * n);
-    shm_barrier();
+    const ShardView v = shard_view();
+    memcpy(cx().lc.shm_slots + (size_t)v.rank * kShmSlotWords, words, sizeof(unsigned long long) * n);
+    CHK(shm_barrier());
     for (int i = 0; i < n; i++) {
         unsigned long long s = 0;
-        for (int r = 0; r < gc.world; r++) s += cx().lc.shm_slots[(size_t)r * kShmSlotWords + i];
+        for (int r = 0; r < v.world; r++) s += cx().lc.shm_slots[(size_t)r * kShmSlotWords + i];
         words[i] = s;
     }
-    shm_barrier();
+    CHK(shm_barrier());
     return 0;
 }
 // all-gather of `cnt` field elements per rank (host values): rank g's elements land in out[g*cnt ..].
 // Implemented as an all-reduce of a zero-padded buffer (one contributor per slot: the sum is exact).
 int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
-    out.assign((size_t)gc.world * cnt, hfr::ZERO);
-    if (gc.world == 1 && !cx().force_collective) {
+    const ShardView v = shard_view();
+    out.assign((size_t)v.world * cnt, hfr::ZERO);
+    if (v.world == 1 && !cx().force_collective) {
         for (int i = 0; i < cnt; i++) out[i] = mine[i];
         return 0;
     }
-    const size_t words = (size_t)gc.world * cnt * 4;
+    const size_t words = (size_t)v.world * cnt * 4;
+    if (cx().lc.shm && !cx().lc.comm) {
+        // host transport: every rank writes its elements into its slot and reads the others' -- no device round trip
+        if ((size_t)cnt * 4 > kShmSlotWords) return fail("shm all-gather of %d elements exceeds the slot", cnt);
+        memcpy(cx().lc.shm_slots + (size_t)v.rank * kShmSlotWords, mine, (size_t)cnt * 32);
+        CHK(shm_barrier());
+        for (int r = 0; r < v.world; r++) memcpy(&out[(size_t)r * cnt], cx().lc.shm_slots + (size_t)r * kShmSlotWords, (size_t)cnt * 32);
+        CHK(shm_barrier());
+        return 0;
+    }
     CHK(coll_buffers(std::max<size_t>(words, 256)));
     memset(cx().lc.h_buf, 0, words * 8);
-    memcpy(cx().lc.h_buf + (size_t)gc.rank * cnt * 4, mine, (size_t)cnt * 32);
+    memcpy(cx().lc.h_buf + (size_t)v.rank * cnt * 4, mine, (size_t)cnt * 32);
     HIPCHK(hipMemcpyAsync(cx().lc.d_buf, cx().lc.h_buf, words * 8, hipMemcpyHostToDevice, cx().stream));
     CHK(coll_allreduce(cx().lc.d_buf, (int)words));
     HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, words * 8, hipMemcpyDeviceToHost, cx().stream));
@@ -235,7 +320,7 @@ int build_eq(DevTable* eq, const E* qprimes, int nq, int q_stride, int m, const 
     }
     CHK(stage_coords(stage.data(), stage.size()));
 
-    DevTable thi, tlo;
+    ScopedTable thi, tlo;
     CHK(table_alloc(&thi, shi * nq));
     CHK(table_alloc(&tlo, slo * nq));
     EqSmallArgs s;

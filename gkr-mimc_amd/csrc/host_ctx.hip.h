@@ -25,11 +25,31 @@ struct Profile {
     std::vector<hipEvent_t> pool;
 };
 
+inline void prof_clear(Profile& p) {              // events go back to the lane's event pool
+    for (auto& e : p.fold_ev) {
+        p.pool.push_back(e.first);
+        p.pool.push_back(e.second);
+    }
+    for (auto& e : p.peval_ev) {
+        p.pool.push_back(e.first);
+        p.pool.push_back(e.second);
+    }
+    p.fold_ev.clear();
+    p.peval_ev.clear();
+    p.fold_launches = p.peval_launches = 0;
+    p.fold_bytes = p.peval_modmuls = 0;
+    p.host_hash_ms = p.host_wait_ms = p.host_launch_ms = p.host_other_ms = 0;
+    p.rounds = 0;
+}
+
 // per-lane state of the collective (one communicator / shared-memory segment per lane: the lanes of a rank
 // issue their collectives independently, lane k pairing with lane k of the other ranks)
 struct ShmHdr {
     std::atomic<unsigned> arrive, gen;
+    std::atomic<unsigned> abort;             // set by a rank that fails (or leaves): peers stop waiting and fail too
+    std::atomic<unsigned long long> magic;   // kShmMagic ^ creation time (s): written last by rank 0; peers refuse anything else
 };
+const unsigned long long kShmMagic = 0x676b726869700000ull;   // "gkrhip"
 struct LaneColl {
     ncclComm_t comm = nullptr;
     ShmHdr* shm = nullptr;
@@ -39,6 +59,8 @@ struct LaneColl {
     unsigned long long* h_buf = nullptr;   // pinned mirror
     unsigned long long* h_tmp = nullptr;
     size_t buf_words = 0;
+    unsigned int* h_cflag = nullptr;       // host-mapped completion word of the RCCL path (written by a stream memory operation)
+    unsigned int* d_cflag = nullptr;
 };
 
 struct Ctx {
@@ -54,6 +76,8 @@ struct Ctx {
     uint4* h_small = nullptr;                  // pinned
     Fr* d_q = nullptr;                         // qPrime coordinates + seeds staging
     size_t d_q_cap = 0;
+    unsigned int* h_bad = nullptr;             // host-mapped: set by k_aos_to_planes when an uploaded element is >= q
+    unsigned int* d_bad = nullptr;
     int max_grid = 2048;
     int fold_grid = 1 << 20;                   // workgroups cap of the fold: one element per lane up to 2^28 outputs
     bool fold_split = true;                    // one single-table launch per table instead of a fused launch
@@ -74,6 +98,7 @@ struct Ctx {
     int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
+    int host_tail = 0;                         // GKRHIP_HOST_TAIL: log2 of the pairs from which the last rounds run on the host (0: never)
     hfr::Lagrange* lag = nullptr;
     Profile prof;
     LaneColl lc;
@@ -207,6 +232,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
+    if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = std::max(0, std::min(6, atoi(e)));
     cx().lag = new hfr::Lagrange();
     cx().device = dev;
     CHK(lane_alloc());
@@ -237,6 +263,9 @@ int lane_alloc() {
     cx().seq = 0;
     HIPCHK(hipMalloc(&cx().d_counter, 64));
     HIPCHK(hipMemset(cx().d_counter, 0, 64));
+    HIPCHK(hipHostMalloc(&cx().h_bad, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_bad, cx().h_bad, 0));
+    *cx().h_bad = 0;
     return 0;
 }
 void lane_free() {
@@ -253,12 +282,25 @@ void lane_free() {
     if (cx().d_q) (void)hipFree(cx().d_q);
     cx().d_q = nullptr;
     cx().d_q_cap = 0;
+    if (cx().h_bad) (void)hipHostFree(cx().h_bad);
+    cx().h_bad = cx().d_bad = nullptr;
+    // the exchange buffers of a communicator lane
+    if (cx().lc.d_buf) (void)hipFree(cx().lc.d_buf);
+    if (cx().lc.h_buf) (void)hipHostFree(cx().lc.h_buf);
+    if (cx().lc.h_tmp) (void)hipHostFree(cx().lc.h_tmp);
+    if (cx().lc.h_cflag) (void)hipHostFree(cx().lc.h_cflag);
+    cx().lc.d_buf = cx().lc.h_buf = cx().lc.h_tmp = nullptr;
+    cx().lc.h_cflag = cx().lc.d_cflag = nullptr;
+    cx().lc.buf_words = 0;
     (void)hipStreamDestroy(cx().stream);
     cx().stream = nullptr;
 }
-// a new lane configured like the default one
-Ctx* lane_create() {
-    Ctx* l = new Ctx();
+// Lanes that lost their session wait here for the next one (the hint-shaped one-shot calls create a session per
+// call: stream, pinned hand-off buffers and counters are reused instead of re-created every time).
+std::mutex g_lane_pool_mu;
+std::vector<Ctx*> g_lane_pool;
+const size_t kLanePoolMax = 16;
+void lane_configure(Ctx* l) {
     l->device = g0.device;
     l->n_cu = g0.n_cu;
     l->max_grid = g0.max_grid;
@@ -273,8 +315,25 @@ Ctx* lane_create() {
     l->g_lin = g0.g_lin;
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
+    l->host_tail = g0.host_tail;
     l->lag = g0.lag;
     l->prof.min_n = g0.prof.min_n;
+}
+// a new lane configured like the default one
+Ctx* lane_create() {
+    {
+        std::lock_guard<std::mutex> lk(g_lane_pool_mu);
+        if (!g_lane_pool.empty()) {
+            Ctx* l = g_lane_pool.back();
+            g_lane_pool.pop_back();
+            lane_configure(l);
+            std::lock_guard<std::mutex> ll(g_lanes_mu);
+            g_lanes.push_back(l);
+            return l;
+        }
+    }
+    Ctx* l = new Ctx();
+    lane_configure(l);
     UseLane u(l);
     if (lane_alloc() != 0) {
         delete l;
@@ -285,14 +344,32 @@ Ctx* lane_create() {
     g_lanes.push_back(l);
     return l;
 }
-void lane_destroy(Ctx* l) {
+void lane_destroy(Ctx* l, bool pool = true) {
     {
         std::lock_guard<std::mutex> lk(g_lanes_mu);
         g_lanes.erase(std::remove(g_lanes.begin(), g_lanes.end(), l), g_lanes.end());
     }
     UseLane u(l);
+    if (pool && !l->lc.comm && !l->lc.shm) {
+        (void)hipStreamSynchronize(l->stream);
+        prof_clear(l->prof);
+        std::lock_guard<std::mutex> lk(g_lane_pool_mu);
+        if (g_lane_pool.size() < kLanePoolMax) {
+            g_lane_pool.push_back(l);
+            return;
+        }
+    }
     lane_free();
     delete l;
+}
+void lane_pool_drain() {
+    std::lock_guard<std::mutex> lk(g_lane_pool_mu);
+    for (Ctx* l : g_lane_pool) {
+        UseLane u(l);
+        lane_free();
+        delete l;
+    }
+    g_lane_pool.clear();
 }
 
 int ensure_ctx() {
@@ -371,26 +448,52 @@ inline Fr to_dev(const E& e) {
     return r;
 }
 
+// A DevTable that goes back to the arena when it leaves scope, so that an early error return strands nothing.  A
+// table that is still held at that point belongs to a call that failed half-way: the lane's stream is drained first
+// (kernels may still be using the buffer, and the arena hands it to the next caller).
+struct ScopedTable : DevTable {
+    ScopedTable() = default;
+    ScopedTable(const ScopedTable&) = delete;
+    ScopedTable& operator=(const ScopedTable&) = delete;
+    ~ScopedTable() {
+        if (base) {
+            (void)hipStreamSynchronize(cx().stream);
+            table_release(this);
+        }
+    }
+};
+
 // ---- boundary copies -----------------------------------------------------------------------------
-// host AoS -> device planes.  Staged through a device AoS buffer and transposed by k_aos_to_planes.
+// The device image of a host AoS table (32 bytes per element) has the size of a table, so the staging buffers come
+// from the table arena and go back to it: the hint-shaped one-shot entry points, which move the same sizes every
+// call, pay no hipMalloc/hipFree per call.
+// host AoS -> device planes.  Staged through a device AoS buffer and transposed by k_aos_to_planes, which also
+// checks the fr.Element invariant the lazy-reduction bounds of the round kernels rely on (every element < q).
 int upload_table(DevTable* t, const uint64_t* host_aos, size_t n) {
-    uint4* stage = nullptr;
-    CHK(staging_alloc(&stage, 32 * n));
+    ScopedTable st;
+    CHK(table_alloc(&st, n));
+    uint4* stage = st.base;
     HIPCHK(hipMemcpyAsync(stage, host_aos, 32 * n, hipMemcpyHostToDevice, cx().stream));
-    hipLaunchKernelGGL(k_aos_to_planes, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n);
+    hipLaunchKernelGGL(k_aos_to_planes, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n,
+                       cx().d_bad);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(cx().stream));
-    HIPCHK(hipFree(stage));
+    if (*(volatile unsigned int*)cx().h_bad) {
+        *cx().h_bad = 0;
+        return fail("input table holds an element that is not a canonical fr.Element (limbs >= q)");
+    }
+    table_release(&st);
     return 0;
 }
 int download_table(const DevTable* t, uint64_t* host_aos, size_t n) {
-    uint4* stage = nullptr;
-    CHK(staging_alloc(&stage, 32 * n));
+    ScopedTable st;
+    CHK(table_alloc(&st, n));
+    uint4* stage = st.base;
     hipLaunchKernelGGL(k_planes_to_aos, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->cplanes(), stage, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_aos, stage, 32 * n, hipMemcpyDeviceToHost, cx().stream));
     HIPCHK(hipStreamSynchronize(cx().stream));
-    HIPCHK(hipFree(stage));
+    table_release(&st);
     return 0;
 }
 
@@ -481,16 +584,23 @@ int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t m
 }
 
 // wait for the sequence number a kernel of this lane publishes with its hand-off (host-mapped flag)
-int wait_flag(unsigned int seq) {
-    volatile unsigned int* f = cx().h_flag;
+// `f` defaults to the lane's round flag; deadline_ms > 0 bounds the wait (collective paths: a peer that died or a
+// collective that cannot make progress must surface as an error, never as a hang)
+int wait_flag(unsigned int seq, volatile unsigned int* f = nullptr, double deadline_ms = 0) {
+    if (!f) f = cx().h_flag;
     unsigned long spins = 0;
     Waiter w;
+    double t0 = 0;
     while (*f != seq) {
         w.step();
         if ((++spins & 0xfffff) == 0) {              // every now and then: make sure the GPU is alive
             hipError_t e = hipStreamQuery(cx().stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
             if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
+            if (deadline_ms > 0) {
+                if (t0 == 0) t0 = now_ms();
+                else if (now_ms() - t0 > deadline_ms) return fail("timed out after %.0f s waiting for the per-round exchange", deadline_ms * 1e-3);
+            }
         }
     }
     __sync_synchronize();

@@ -29,7 +29,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     };
     const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
     CHK(stage_coords(q, (size_t)m));
-    DevTable pyrT, pyrU[2], pyrU2[2], ks, ss;          // pyrU[0]: split at g_max threads, pyrU[1]: at g_big; pyrU2: times 2^-128
+    ScopedTable pyrT, pyrU[2], pyrU2[2], ks, ss;          // pyrU[0]: split at g_max threads, pyrU[1]: at g_big; pyrU2: times 2^-128
     const int gsplit[2] = {std::min(cx().g_max, m - 1), g_big};
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
     CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
@@ -155,10 +155,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are rank-local.
             // The reduced words reach the host like the un-sharded ones (host-mapped buffer + flag the host polls)
             CHK(coll_allreduce(cx().lc.d_buf, GKR_CR_WORDS));
-            hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round,
-                               GKR_CR_WORDS + 16, cx().d_flag, a.seq);
-            HIPCHK(hipGetLastError());
-            CHK(wait_flag(a.seq));
+            CHK(coll_publish(GKR_CR_WORDS + 16, a.seq));
+            CHK(wait_flag(a.seq, nullptr, coll_timeout_ms()));
         } else {
             CHK(wait_flag(a.seq));
             if (collective && cx().lc.shm) {
@@ -229,7 +227,8 @@ int small_table(DevTable* t, const std::vector<E>& v) {
 // rounds run redundantly on every rank (phase 2).
 int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable* S, const E* q, E* proof, E* challenges,
                          E* final_claims, const E* trusted_claim, bool track_claim) {
-    const int gamma = gc.gamma, m1 = bN - gamma;
+    const ShardView shard = shard_view();
+    const int gamma = shard.gamma, m1 = bN - gamma;
     if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
     E c = hfr::ONE, tail[4], r_last, kv, sv;
     // running claim: known from the start when the caller vouches for it, otherwise from round 1 on
@@ -237,7 +236,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     bool claim_known = trusted_claim != nullptr;
     E* claim_p = track_claim ? &claim : nullptr;
     if (m1 >= 1) {
-        const E seed = gamma ? shard_seed(q + m1, gamma, gc.rank) : hfr::ONE;
+        const E seed = gamma ? shard_seed(q + m1, gamma, shard.rank) : hfr::ONE;
         CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last,
                           claim_p, &claim_known));
         kv = fold2(tail[0], tail[1], r_last);
@@ -253,12 +252,12 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
         const E mine[2] = {kv, sv};
         std::vector<E> all;
         CHK(coll_allgather(mine, 2, all));
-        std::vector<E> k2(gc.world), s2(gc.world);
-        for (int r = 0; r < gc.world; r++) {
+        std::vector<E> k2(shard.world), s2(shard.world);
+        for (int r = 0; r < shard.world; r++) {
             k2[r] = all[2 * r];
             s2[r] = all[2 * r + 1];
         }
-        DevTable K2, S2;
+        ScopedTable K2, S2;
         CHK(small_table(&K2, k2));
         CHK(small_table(&S2, s2));
         CHK(cipher_rounds(ark, gamma, &K2, &S2, q + m1, hfr::ONE, false, c, proof + (size_t)9 * m1, challenges + m1, tail,
@@ -285,7 +284,7 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
     const int gT = std::min(g_lin, m - 1);
     const int mU = m - 1 - gT;
     CHK(stage_coords(q, (size_t)m));
-    DevTable pyrT, pyrU, scratch[2];
+    ScopedTable pyrT, pyrU, scratch[2];
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
     CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
     for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
@@ -405,7 +404,7 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     }
     cx().racc_dirty = true;
-    DevTable scratch[GKR_MAX_ARITY];
+    ScopedTable scratch[GKR_MAX_ARITY];
     for (int k = 0; k < arity; k++) CHK(table_alloc(&scratch[k], std::max<size_t>(n / 2, 1)));
     const DevTable* cur[GKR_MAX_ARITY + 1];
     for (int k = 0; k < arity; k++) cur[k] = X[k];
@@ -449,7 +448,8 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
     if (nq < 1) return fail("need at least one evaluation point");
     if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
         return fail("provided a multi-instance %d but the number of claims does not match %d", nq, nclaims);
-    const int gamma = gc.gamma, m1 = bN - gamma;
+    const ShardView shard = shard_view();
+    const int gamma = shard.gamma, m1 = bN - gamma;
     if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
     const int nev = gate_degree(gate) + 2;
 
@@ -483,8 +483,8 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
 
     // phase 1: this rank's shard; Eq_local = sum_j seed_j * eq(q_j tail, rank) * eq(q_j[0:m1], .)
     if (gamma > 0)
-        for (int j = 0; j < nq_used; j++) seeds[j] = hfr::mul(seeds[j], shard_seed(qprimes + (size_t)j * bN + m1, gamma, gc.rank));
-    DevTable eq;
+        for (int j = 0; j < nq_used; j++) seeds[j] = hfr::mul(seeds[j], shard_seed(qprimes + (size_t)j * bN + m1, gamma, shard.rank));
+    ScopedTable eq;
     CHK(table_alloc(&eq, (size_t)1 << m1));
     CHK(build_eq(&eq, qprimes, nq_used, bN, m1, seeds.data()));
     E last[GKR_MAX_ARITY + 1];
@@ -494,10 +494,10 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
         // phase 2: one entry per table per rank -> tables over the gamma shard bits, same rounds on every rank
         std::vector<E> all;
         CHK(coll_allgather(last, arity + 1, all));
-        std::vector<std::vector<E>> cols(arity + 1, std::vector<E>(gc.world));
-        for (int r = 0; r < gc.world; r++)
+        std::vector<std::vector<E>> cols(arity + 1, std::vector<E>(shard.world));
+        for (int r = 0; r < shard.world; r++)
             for (int t = 0; t <= arity; t++) cols[t][r] = all[(size_t)r * (arity + 1) + t];
-        DevTable eq2, x2[GKR_MAX_ARITY];
+        ScopedTable eq2, x2[GKR_MAX_ARITY];
         const DevTable* X2[GKR_MAX_ARITY];
         CHK(small_table(&eq2, cols[0]));
         for (int t = 0; t < arity; t++) {
@@ -537,10 +537,10 @@ int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, 
 // table is this rank's shard of 2^(nc-gamma) entries; the shard values are all-gathered and the last gamma
 // coordinates are applied to the gathered (<= world-entry) table.
 int evaluate_dev(const DevTable* t, int nc, const E* coords, E* out) {
-    const int gamma = gc.gamma, m1 = nc - gamma;
+    const int gamma = shard_view().gamma, m1 = nc - gamma;
     if (m1 < 0) return fail("Evaluate: %d coordinates for a table sharded over 2^%d ranks", nc, gamma);
     const size_t n = (size_t)1 << m1;
-    DevTable s;
+    ScopedTable s;
     CHK(table_alloc(&s, std::max<size_t>(n / 2, 1)));
     const DevTable* cur = t;
     for (int k = 0; k < m1; k++) {

@@ -42,11 +42,23 @@ __device__ __forceinline__ void st_fr(uint4* __restrict__ lo, uint4* __restrict_
 // ------------------------------------------------------------------------------------------------
 // boundary: Go []fr.Element (AoS, 32 B per element) <-> limb planes
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GKR_BLOCK) k_aos_to_planes(const uint4* __restrict__ aos, Planes out, size_t n) {
+// `bad` (host-mapped word) is set when an element is not below q: gnark-crypto keeps fr.Element canonical and the
+// lazy-reduction bounds of the round kernels (u < 3q, d < 2q, fold results < 4q) assume exactly that of table entries
+__global__ void __launch_bounds__(GKR_BLOCK) k_aos_to_planes(const uint4* __restrict__ aos, Planes out, size_t n,
+                                                             unsigned int* bad) {
+    const u32 q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
+    bool any_bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        out.lo[i] = aos[2 * i];
-        out.hi[i] = aos[2 * i + 1];
+        const uint4 a = aos[2 * i], b = aos[2 * i + 1];
+        out.lo[i] = a;
+        out.hi[i] = b;
+        const u32 v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        u32 br = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) (void)fr_subb(v[j], q[j], br, &br);
+        any_bad |= br == 0;                           // no borrow: v >= q
     }
+    if (any_bad) atomicOr(bad, 1u);
 }
 __global__ void __launch_bounds__(GKR_BLOCK) k_planes_to_aos(CPlanes in, uint4* __restrict__ aos, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -220,3 +220,74 @@ def test_gmimc_circuit_c_oracle_vs_python_oracle(bn):
         bad = flat.copy()
         bad[3, 0] ^= np.uint64(1)
         assert c.gkr_verify_circuit(descs, bn, bad, cins, outs, c.from_ints(qp)) != 0
+
+
+def test_survey_appendix_b():
+    """values of an independent restatement of the reference (written by a different
+    session, KAT-anchored and verifier-accepted) -- the only second reading of the algorithm this repository
+    has, asserted here on BOTH oracles.  Inputs follow sumcheck/testing.go:11-57 and gkr/gkr_test.go:23-25."""
+    Q = o.Q
+    # common.RandomFrArray(4); poly.FoldedEqTable([2,3]); fold([0,1,2,3], 5)
+    rfa4 = [16792413999679, 16792413999678, 16792413999675, 16792413999670]
+    assert o.random_fr_array(4) == rfa4 and c.to_ints(c.random_fr_array(4)) == rfa4
+    eq23 = [2, (-3) % Q, (-4) % Q, 6]
+    assert o.folded_eq_table([2, 3]) == eq23 and c.to_ints(c.folded_eq_table(c.from_ints([2, 3]))) == eq23
+    assert o.fold([0, 1, 2, 3], 5) == [10, 11]
+
+    # InitializeCipherGateInstance(2)  (sumcheck/testing.go:11-26)
+    X, claims, qs, gate = o.initialize_cipher_gate_instance(2)
+    assert qs == [[16792413999679, 16792413999678]]
+    assert claims == [6210164148622235469085091026862563128838641017496921984]
+    round0 = [21888242871839275184561835838863618971897026818209516123207594011953420612865,
+              75362930075014142017900484743430457352086602784186311477888,
+              12419049195478414334940816557593184013274926150706173184,
+              852695088970139060850731351704017254582492295811584,
+              31224423234359380840366957119592272582448808960,
+              643155849042919484885696612437680723589120,
+              7065388620329840615834319386742878208,
+              32340315080560337413961102483456,
+              550253821941465088]
+    chal = [7683915157646553957972751715506210273774041546390922002351511344957472092635,
+            10056654415683796759942491034232422885846793423765035913409411941319351042801]
+    final = [12560110031309288988337635978213296499715689218361145289462178438943874440404,
+             3536241859137629453641588719987568344846512116130845574414230444658486732454,
+             3536241859137629453641588719987568344846512116130845574414230444658486732454]
+    proof, ch, fin = o.sumcheck_prove([list(x) for x in X], qs, claims, gate)
+    assert proof[0] == round0 and ch == chal and fin == final
+    cp, cc, cf = c.sumcheck_prove(c.GATE_CIPHER, c.from_u64(145646), [c.from_ints(x) for x in X],
+                                  c.from_ints(qs[0]).reshape(1, 2, 4), c.from_ints(claims))
+    assert c.to_ints(cp[0]) == round0 and c.to_ints(cc) == chal and c.to_ints(cf) == final
+
+    # InitializeMultiInstance(2, 3)  (sumcheck/testing.go:28-57)
+    X, claims, qs, gate = o.initialize_multi_instance(2, 3)
+    assert qs == [[0, 0], [1, 2], [2, 4]] and claims == [0, 4, 8]
+    chal = [21366438619878141333539650973972889481318660075116115520302585625232830162408,
+            15050161346558720454461840747952731668813985870593406549855952370501809100848]
+    fin01 = [6923648215444982917282612078813725970844542082510533916261334677738104788671,
+             14006552842636452677048331205383960454354577219993568903064715247815852434430]
+    _, ch, fin = o.sumcheck_prove([list(x) for x in X], qs, claims, gate)
+    assert ch == chal and fin[:2] == fin01
+    _, cc, cf = c.sumcheck_prove(c.GATE_IDENTITY, None, [c.from_ints(x) for x in X],
+                                 np.stack([c.from_ints(q) for q in qs]), c.from_ints(claims))
+    assert c.to_ints(cc) == chal and c.to_ints(cf)[:2] == fin01
+
+    # gkr.Prove(MimcCircuit), bN = 1, inputs = qPrime = RandomFrArray
+    circ = o.mimc_circuit()
+    inp = o.random_fr_array(2)
+    a = o.assign(circ, inp, list(inp))
+    pr = o.gkr_prove(circ, a, o.random_fr_array(1))
+    sc93 = [8603423878151217347612283315717020960620926714233984240685120503134163518679,
+            6225796057942586806576531527479361841449264046497628497844748636862076955978]
+    cl0 = [10987504763916727291808773442712990250720948185337753863556565714056923793942]
+    cl1 = [4802317624173645157770282518706233816660915781471186570068121738487279260555]
+    assert pr.sumcheck_proofs[93][0][:2] == sc93 and pr.claims[0] == cl0 and pr.claims[1] == cl1
+    i0 = c.random_fr_array(2)
+    flat, _, _ = c.gkr_prove_mimc(1, i0, i0.copy(), c.random_fr_array(1))
+    ints = c.to_ints(flat)
+    # flat = GkrProofToVec order: layer 2 (identity, 3 coeffs) then 91 cipher layers of 9 coeffs; claims follow
+    assert ints[3 + 90 * 9: 3 + 90 * 9 + 2] == sc93
+    assert ints[822] == cl0[0] and ints[823] == cl1[0]
+    assert ints == o.gkr_proof_to_vec(pr)
+    # proof sizes (coeffs / claims / point coordinates), hints.go:76-116
+    for bn, sizes in ((0, (0, 183, 0)), (1, (822, 183, 184)), (3, (2466, 183, 552)), (5, (4110, 183, 920))):
+        assert c.mimc_proof_len(bn) == sum(sizes) and o.nb_outputs(circ, bn) == sum(sizes)
