@@ -4,9 +4,13 @@ examples.MimcCircuit, assignment excluded from the timer as BenchmarkGkr does,
 gkr/gkr_test.go:99-105), plus the fold kernel's achieved HBM bandwidth and the CPU oracle timed
 beside it.
 
-    python bench.py --gpus N --steps K --warmup W [--bn B]
+    python bench.py --gpus N --steps K --warmup W [--bn B] [--weak] [--exchange rccl|shm]
 
-N = 1: one process, GPU 0.  N > 1: launched by torch.distributed.run, one rank per GPU.
+N = 1: one process, GPU 0, bN = 24 (BASELINE config 3, the size the metric is quoted on).
+N > 1: launched by torch.distributed.run, one rank per GPU; ONE proof of 2^26 hashes (BASELINE config 4 at
+N = 8: a 2^23-entry shard per GPU) sharded on the low index bits, the per-round sum of the round-polynomial
+words all-reduced with RCCL (north_star's transport); the same run over the host shared-memory exchange is
+reported beside it.  --weak keeps 2^bn entries per GPU instead (total 2^(bn + log2 N)).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -14,12 +18,18 @@ import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+NOMINAL_GHZ = 2.4         # MI355X engine clock (MI355X_MICROARCH.md)
+HALF_RATE_CYCLES = 4.3    # v_mad_u64_u32 / carries / v_mul_lo_u32 per wave and SIMD (profiles/r01_ubench_instruction_rates.txt)
+FULL_RATE_CYCLES = 2.4
+N_SIMD = 1024             # 256 CUs x 4 SIMDs
+BN_TOTAL_MULTI = 26       # BASELINE config 4
 
 
 def cpu_baseline(target_seconds=40.0):
@@ -39,265 +49,13 @@ def cpu_baseline(target_seconds=40.0):
             break
         b += 2 if secs < target_seconds / 16 else 1
     b, secs = best
-    return {"value": (1 << b) / secs, "unit": "MiMC hashes GKR-proved/s", "cores": coracle.lib.oracle_num_threads(),
-            "kind": "port", "sample": "gkr.Prove of 2^%d hashes (RandomFrArray inputs), %.2f s, C restatement "
-                                      "of the reference algorithm (not the Go binary)" % (b, secs)}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--bn", type=int, default=24, help="log2 of the number of MiMC hashes per proof (per job)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--circuit", choices=["mimc", "gmimc"], default="mimc",
-                    help="mimc: examples.MimcCircuit (the headline metric); gmimc: the build-defined GMiMC t=2 circuit "
-                         "(BASELINE config 5, quoted at --bn 22)")
-    ap.add_argument("--concurrent", type=int, default=5,
-                    help="independent proofs in flight (each on its own resident session/lane/stream and, when "
-                         "sharded, its own communicator); 1 = strictly one proof at a time")
-    ap.add_argument("--exchange", choices=["auto", "rccl", "shm"], default="auto",
-                    help="transport of the per-round 576-byte sum of the sharded prover: rccl = ncclAllReduce on the lane's "
-                         "stream; shm = the ranks add the words on the host through POSIX shared memory (one node); auto = "
-                         "shm when every rank is on this node, else rccl")
-    ap.add_argument("--mem-fraction", type=float, default=0.85,
-                    help="share of the free HBM the resident sessions may take (caps --concurrent)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if args.gpus > 1 or world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()
-        rank = dist.get_rank()
-
-    gk = importlib.import_module("gkr-mimc_amd")
-    gk.init(local_rank)
-
-    import numpy as np
-    # every proof in flight keeps its own resident assignment (93 tables of 2^bn elements) plus scratch
-    free_b, _total_b = gk.mem_info()
-    per_session = (94.25 if args.circuit == "mimc" else 104) * 32 * (1 << args.bn)   # 93 tables + two half-size scratch tables + pyramids
-    nconc = max(1, min(args.concurrent, args.steps, int(args.mem_fraction * free_b // per_session)))
-    if nconc > 1 and args.steps % nconc and args.steps % (nconc - 1) == 0:
-        nconc -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
-    if dist is not None:
-        t = torch.tensor([nconc], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)     # same number of lanes on every rank
-        nconc = int(t.item())
-    if dist is not None:
-        # install the library's own RCCL communicators, one per lane (the per-round all-reduce of the limb-split
-        # sums lives inside the C++ round loop); torch.distributed only carries the 128-byte unique ids, the
-        # barriers and the max-over-ranks of the timing
-        one_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
-        use_shm = args.exchange == "shm" or (args.exchange == "auto" and one_node)
-        tag = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
-        dist.broadcast_object_list(tag, src=0)        # a name no earlier run can have left behind
-        shm_name = "/gkrhip_bench_%s" % tag[0]
-        transport, err = "rccl", ""
-        if use_shm:
-            # 576 bytes per round: the round kernel hands its sums to the host as in the un-sharded case and the ranks add
-            # them through shared memory -- no collective kernel has to queue behind the compute-bound rounds
-            gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
-            transport = "host shared memory (one node)"
-        else:
-            try:
-                box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
-            except Exception as e:      # noqa: BLE001 -- reported below, never silent
-                box, err = [None], str(e)
-            dist.broadcast_object_list(box, src=0)
-            ok = 0
-            if box[0] is not None:
-                try:
-                    gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
-                    ok = 1
-                except Exception as e:  # noqa: BLE001
-                    err = str(e)
-            t = torch.tensor([ok], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 0:
-                # RCCL communicators could not be created on some rank: the same call sites run over the library's
-                # host shared-memory transport (single node only) and the JSON line says so
-                gk.comm_destroy()
-                dist.barrier()
-                gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
-                transport = "host shared memory (RCCL communicator init failed: %s)" % (err or "on another rank")
-                if rank == 0:
-                    print("bench.py: " + transport, file=sys.stderr)
-    gamma = (world.bit_length() - 1) if dist is not None else 0
-    # weak scaling: every GPU holds a 2^bn shard, the job proves 2^(bn + log2 N) hashes in ONE proof
-    bn = args.bn + gamma
-    import threading
-    sessions = []
-    layers = gk.gmimc_t2_circuit() if args.circuit == "gmimc" else None
-    for _ in range(nconc):
-        s = gk.MimcSession(bn, layers=layers)
-        s.synth_inputs()        # block = initstate = RandomFrArray(2^bN), generated in HBM
-        s.assign()              # Circuit.Assign: outside the timer, as BenchmarkGkr
-        sessions.append(s)
-    qprime = random_fr_array_np(bn)   # qPrime = RandomFrArray(bN), as gkr/gkr_test.go:93-95
-    last = [None] * nconc
-
-    def run_steps(total):
-        """`total` full proofs; with nconc > 1 they are dealt round-robin to nconc sessions that prove
-        concurrently (one host thread each; ctypes releases the GIL inside the library)."""
-        if nconc == 1:
-            for _ in range(total):
-                last[0] = sessions[0].prove(qprime)
-            return
-        counts = [total // nconc + (1 if k < total % nconc else 0) for k in range(nconc)]
-
-        def work(k):
-            for _ in range(counts[k]):
-                last[k] = sessions[k].prove(qprime)
-
-        ths = [threading.Thread(target=work, args=(k,)) for k in range(nconc)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-
-    def sync_all():
-        gk.synchronize()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    run_steps(max(args.warmup, 1 if nconc > 1 and args.warmup else 0))
-    # single-proof latency (one proof alone on the GPU), reported beside the throughput figure
-    gk.profile_reset(1 << args.bn)
-    sync_all()
-    tl = time.perf_counter()
-    last[0] = sessions[0].prove(qprime)
-    sync_all()
-    latency_ms = 1e3 * (time.perf_counter() - tl)
-    solo = gk.profile_get()          # the same launches with no other proof in flight
-    gk.profile_reset(1 << args.bn)   # HIP-event accounting of the round-0 fold / partial-eval launches
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    flat = last[0]
-    prof = gk.profile_get()
-    gk.profile_reset(0)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    hashes = float(1 << bn) * args.steps
-    out = {
-        "metric": ("MiMC hashes GKR-proved/sec at bN=%d" if args.circuit == "mimc" else
-                   "GMiMC(t=2) compressions GKR-proved/sec at bN=%d") % bn,
-        "value": hashes / dt,
-        "unit": "hashes/s",
-        "n_gpus": world if dist is not None else 1,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u32x8 (BN254-Fr Montgomery, 256-bit integer)",
-        "data": "synthetic",
-        "config": {"workload": "gkr.Prove(MimcCircuit): ONE proof of 2^%d MiMC hashes, hypercube sharded on its low "
-                               "index bits over %d GPU(s) (2^%d-entry shard per GPU), inputs RandomFrArray, "
-                               "assignment resident in HBM" % (bn, max(world, 1) if dist is not None else 1, args.bn),
-                   "bN": bn, "bN_per_gpu": args.bn, "proof_elements": int(flat.shape[0]),
-                   "concurrent_proofs": nconc, "single_proof_latency_ms": latency_ms},
-    }
-    if dist is not None:
-        out["config"]["per_round_exchange"] = transport + ": all-reduce of 72 limb-split u64 lanes per sumcheck round"
-    if solo["fold_launches"]:
-        # The fold launches on full-size tables, timed with HIP events on the launching stream.  Primary figure:
-        # the single-proof pass (one proof alone on the GPU) that bench.py runs between the warm-up and the K timed
-        # steps -- the kernel's own speed.  Inside the K timed steps the other lanes' VALU-bound kernels hold the
-        # CUs, so an HBM-bound launch mostly waits for CU slots; that figure is reported under in_timed_region.
-        traffic = None
-        try:   # PMC pass of this very workload (tools/pmc_bench.sh), committed under profiles/
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fold_traffic.json")))
-            if pm.get("bn") == args.bn:
-                traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            pass
-        sms = solo["fold_ms"] / solo["fold_launches"]
-        sb = solo["fold_bytes"] / solo["fold_launches"]
-        ach = sb / (sms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_fold (round-0 instance fold, 2^%d-element tables)" % args.bn,
-                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "launches": solo["fold_launches"], "avg_launch_ms": sms,
-                           "algorithmic_bytes_per_launch": sb,
-                           "measured": "HIP events on the launching stream around the fold launches of full-size tables "
-                                       "during the single-proof pass of this run (one proof alone on the GPU)"}
-        if prof["fold_launches"]:
-            avg_ms = prof["fold_ms"] / prof["fold_launches"]
-            bpl = prof["fold_bytes"] / prof["fold_launches"]
-            out["roofline"]["in_timed_region"] = {
-                "achieved": bpl / (avg_ms * 1e-3) / 1e9, "frac": bpl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_ms": avg_ms, "launches": prof["fold_launches"],
-                "measured": "same launches and events inside the K timed steps with %d proofs in flight: the launch "
-                            "duration includes waiting for CU slots held by the other lanes' VALU-bound kernels" % nconc}
-    if rank == 0:
-        # the same kernel alone on the GPU (micro-benchmark of BenchmarkFolding's shape, poly/multilin_test.go:55-78)
-        ms3 = gk.bench_fold(1 << args.bn, ntab=3, warmup=2, iters=10)
-        out["fold_alone"] = {"tables": 3, "elements_per_table": 1 << args.bn, "ms": ms3,
-                             "GB_per_s": 96.0 * 3 * (1 << (args.bn - 1)) / (ms3 * 1e-3) / 1e9,
-                             "note": "device-resident micro-benchmark of the same kernel (gkrhip_bench_fold): three "
-                                     "tables, no other kernel running"}
-    if solo["peval_launches"]:
-        # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit) and runs
-        # at the vector issue rate, so it is priced against an instruction-issue ceiling: the round-0 loop body is
-        # 3903 vector instructions per index pair (3566 half-rate: v_mad_u64_u32 / carries at 4.3 cycles per wave, 337
-        # at 2.4; tools/isa_loop_count.py, rates from profiles/r01_ubench_*.txt) = 16143 issue cycles per pair and
-        # wave; 1024 SIMDs x 64 lanes share the pairs; nominal clock 2.4 GHz (the sustained clock under this load is
-        # nearer 2.1 GHz, profiles/r01_v8_pmc_round_kernel_sq.json)
-        pairs = float(1 << (args.bn - 1))
-        issue_cycles_per_pair = 16143.0
-        ceiling_ms = pairs / (1024 * 64) * issue_cycles_per_pair / 2.4e9 * 1e3
-        avg_ms = solo["peval_ms"] / solo["peval_launches"]
-        out["partial_eval"] = {"kernel": "k_cipher_round_wide (round 0 of a cipher layer: 2^%d index pairs; per pair 10 field products, "
-                                         "2 of them by a launch-wide constant, and 7 multiply-accumulates with deferred "
-                                         "reduction)" % (args.bn - 1),
-                               "bound": "integer VALU issue (no MFMA: modular arithmetic)",
-                               "launches": solo["peval_launches"], "avg_launch_ms": avg_ms,
-                               "ceiling_ms": ceiling_ms, "frac": ceiling_ms / avg_ms,
-                               "vector_instructions_per_pair": 3903, "issue_cycles_per_pair": issue_cycles_per_pair,
-                               "field_products_per_s": solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3),
-                               "ceiling_assumption": "every vector instruction of the loop body at its measured issue cost "
-                                                     "(4.3 / 2.4 cycles per wave), two waves per SIMD keeping the port "
-                                                     "busy, 2.4 GHz",
-                               "measured": "HIP events around the round-0 launches of the single-proof pass"}
-        if args.circuit != "mimc":       # the launch mix of other circuits differs (linear layers): no ceiling claimed
-            for k in ("ceiling_ms", "frac", "vector_instructions_per_pair", "issue_cycles_per_pair", "ceiling_assumption"):
-                out["partial_eval"].pop(k, None)
-            out["partial_eval"]["kernel"] = "round-0 launches of the circuit's layers (cipher and linear)"
-        if prof["peval_launches"]:
-            out["partial_eval"]["in_timed_region"] = {
-                "launches": prof["peval_launches"], "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
-                "field_products_per_s_per_launch": prof["peval_modmuls"] / (prof["peval_ms"] * 1e-3),
-                "note": "launch durations with %d proofs in flight overlap the other lanes' kernels" % nconc}
-    if prof.get("rounds"):
-        out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
-                                         ("host_hash_ms", "host_wait_ms", "host_launch_ms", "host_other_ms")}
-        out["host_split_ms_per_step"]["rounds"] = prof["rounds"] / args.steps
-    if rank == 0 and not args.no_cpu_baseline and (dist is None or world == 1) and args.circuit == "mimc":
-        out["cpu_baseline"] = cpu_baseline()
-    if rank == 0:
-        print(json.dumps(out))
-    for s in sessions:
-        s.close()
-    if dist is not None:
-        gk.comm_destroy()
-        dist.destroy_process_group()
+    cores = coracle.lib.oracle_num_threads()
+    muls = 4555.0 * (1 << b)          # field multiplications of gkr.Prove per hash (SURVEY 8a totals)
+    return {"value": (1 << b) / secs, "unit": "MiMC hashes GKR-proved/s", "cores": cores,
+            "kind": "port", "ns_per_field_mul_per_core": secs * cores / muls * 1e9,
+            "sample": "gkr.Prove of 2^%d hashes (RandomFrArray inputs), %.2f s, C restatement of the reference "
+                      "algorithm built with -O3 -march=x86-64-v3 -madx (portable unsigned __int128 CIOS product; not the Go "
+                      "binary, whose gnark-crypto amd64 assembly is ~1.5-2x faster per multiplication)" % (b, secs)}
 
 
 def random_fr_array_np(n):
@@ -311,6 +69,345 @@ def random_fr_array_np(n):
         for k in range(4):
             out[i, k] = (m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
     return out
+
+
+class Job:
+    """nconc resident sessions (one lane each) of the same circuit and size, proving concurrently."""
+
+    def __init__(self, gk, bn, nconc, layers):
+        self.gk, self.bn, self.nconc = gk, bn, nconc
+        self.sessions = []
+        for _ in range(nconc):
+            s = gk.MimcSession(bn, layers=layers)
+            s.synth_inputs()        # block = initstate = RandomFrArray(2^bN), generated in HBM (this rank's shard)
+            s.assign()              # Circuit.Assign: outside the timer, as BenchmarkGkr
+            self.sessions.append(s)
+        self.qprime = random_fr_array_np(bn)   # qPrime = RandomFrArray(bN), as gkr/gkr_test.go:93-95
+        self.last = [None] * nconc
+        self.errors = []
+
+    def run_steps(self, total):
+        """`total` full proofs; with nconc > 1 they are dealt round-robin to nconc sessions that prove
+        concurrently (one host thread each; ctypes releases the GIL inside the library)."""
+        if self.nconc == 1:
+            for _ in range(total):
+                self.last[0] = self.sessions[0].prove(self.qprime)
+            return
+        counts = [total // self.nconc + (1 if k < total % self.nconc else 0) for k in range(self.nconc)]
+
+        def work(k):
+            try:
+                for _ in range(counts[k]):
+                    self.last[k] = self.sessions[k].prove(self.qprime)
+            except Exception as e:   # noqa: BLE001 -- re-raised on the main thread
+                self.errors.append(e)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(self.nconc)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if self.errors:
+            raise self.errors[0]
+
+    def close(self):
+        for s in self.sessions:
+            s.close()
+        self.sessions = []
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bn", type=int, default=None,
+                    help="log2 of the number of hashes of ONE proof: default 24 on one GPU (BASELINE config 3) and 26 in "
+                         "total on N > 1 GPUs (config 4); with --weak it is the per-GPU shard size (default 23)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: keep 2^bn entries per GPU (total 2^(bn + log2 N))")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-micro", action="store_true", help="skip the sumcheck / fold micro-benchmarks (SURVEY 8d)")
+    ap.add_argument("--circuit", choices=["mimc", "gmimc"], default="mimc",
+                    help="mimc: examples.MimcCircuit (the headline metric); gmimc: the build-defined GMiMC t=2 circuit "
+                         "(BASELINE config 5, quoted at --bn 22)")
+    ap.add_argument("--concurrent", type=int, default=5,
+                    help="independent proofs in flight (each on its own resident session/lane/stream and, when "
+                         "sharded, its own communicator); 1 = strictly one proof at a time")
+    ap.add_argument("--exchange", choices=["rccl", "shm", "auto"], default="rccl",
+                    help="transport of the per-round 576-byte sum of the sharded prover: rccl = ncclAllReduce over xGMI on "
+                         "the lane's stream (the headline transport); shm = the ranks add the words on the host through "
+                         "POSIX shared memory (one node only); auto = rccl")
+    ap.add_argument("--no-shm-beside", action="store_true",
+                    help="N > 1 on one node: do not repeat the timed steps over the shared-memory exchange")
+    ap.add_argument("--mem-fraction", type=float, default=0.85,
+                    help="share of the free HBM the resident sessions may take (caps --concurrent)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if args.gpus > 1 or world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
+        # torch.distributed carries only the bootstrap (128-byte communicator ids), the barriers and the max-over-ranks
+        # of the timing -- over gloo, so that the only RCCL in the process is the one libgkrhip dlopen()s and torch
+        # never initialises the GPU
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        world = dist.get_world_size()
+        rank = dist.get_rank()
+    multi = dist is not None and world > 1
+
+    gk = importlib.import_module("gkr-mimc_amd")
+    gk.init(local_rank)
+
+    import numpy as np
+    gamma = world.bit_length() - 1 if dist is not None else 0
+    if dist is not None and (1 << gamma) != world:
+        raise SystemExit("bench.py: the number of ranks must be a power of two")
+    if not multi:
+        bn = args.bn if args.bn is not None else 24
+    elif args.weak:
+        bn = (args.bn if args.bn is not None else 23) + gamma
+    else:
+        bn = args.bn if args.bn is not None else BN_TOTAL_MULTI
+    bn_gpu = bn - gamma
+    # every proof in flight keeps its own resident assignment (93 tables of 2^bn_gpu elements) plus scratch
+    free_b, _total_b = gk.mem_info()
+    per_session = (94.25 if args.circuit == "mimc" else 104) * 32 * (1 << bn_gpu)   # tables + two half-size scratch tables + pyramids
+    nconc = max(1, min(args.concurrent, args.steps, int(args.mem_fraction * free_b // per_session)))
+    if multi:
+        nconc = min(nconc, 8)                         # one communicator per lane, at most 8
+    if nconc > 1 and args.steps % nconc and args.steps % (nconc - 1) == 0:
+        nconc -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
+    if dist is not None:
+        t = torch.tensor([nconc], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)     # same number of lanes on every rank
+        nconc = int(t.item())
+    layers = gk.gmimc_t2_circuit() if args.circuit == "gmimc" else None
+    one_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
+
+    def install(transport_kind):
+        """Install the library's communicators, one per lane (the per-round all-reduce of the limb-split sums lives
+        inside the C++ round loop).  Returns a description of the transport actually installed."""
+        tag = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
+        dist.broadcast_object_list(tag, src=0)        # a name no earlier run can have left behind
+        shm_name = "/gkrhip_bench_%s" % tag[0]
+        if transport_kind == "shm":
+            gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
+            return "host shared memory (one node)"
+        err = ""
+        try:
+            box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
+        except Exception as e:      # noqa: BLE001 -- reported below, never silent
+            box, err = [None], str(e)
+        dist.broadcast_object_list(box, src=0)
+        ok = 0
+        if box[0] is not None:
+            try:
+                gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+        t = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            return "RCCL ncclAllReduce (ncclUint64, ncclSum) over xGMI, one communicator per lane"
+        if not one_node:
+            raise SystemExit("bench.py: RCCL communicator init failed (%s) and the ranks span several nodes" % err)
+        # RCCL communicators could not be created on some rank: the same call sites run over the library's
+        # host shared-memory transport (single node only) and the JSON line says so
+        gk.comm_destroy()
+        dist.barrier()
+        gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
+        msg = "host shared memory (RCCL communicator init failed: %s)" % (err or "on another rank")
+        if rank == 0:
+            print("bench.py: " + msg, file=sys.stderr)
+        return msg
+
+    def sync_all():
+        gk.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def timed(job, steps):
+        sync_all()
+        t0 = time.perf_counter()
+        job.run_steps(steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    transport = None
+    if dist is not None:
+        transport = install("shm" if args.exchange == "shm" else "rccl")
+    job = Job(gk, bn, nconc, layers)
+    job.run_steps(max(args.warmup, 1 if nconc > 1 and args.warmup else 0))
+    # single-proof latency (one proof alone on the GPU), reported beside the throughput figure
+    gk.profile_reset(1 << bn_gpu)
+    sync_all()
+    tl = time.perf_counter()
+    job.last[0] = job.sessions[0].prove(job.qprime)
+    sync_all()
+    latency_ms = 1e3 * (time.perf_counter() - tl)
+    solo = gk.profile_get()          # the same launches with no other proof in flight
+    gk.profile_reset(1 << bn_gpu)    # HIP-event accounting of the round-0 fold / partial-eval launches
+    dt = timed(job, args.steps)
+    flat = job.last[0]
+    prof = gk.profile_get()
+    gk.profile_reset(0)
+    verified = bool(job.sessions[0].verify(job.qprime, flat))   # native gkr.Verify against the resident tables (outside the timer)
+
+    hashes = float(1 << bn) * args.steps
+    n_gpus = world if dist is not None else 1
+    out = {
+        "metric": ("MiMC hashes GKR-proved/sec at bN=%d" if args.circuit == "mimc" else
+                   "GMiMC(t=2) compressions GKR-proved/sec at bN=%d") % bn,
+        "value": hashes / dt,
+        "unit": "hashes/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak" if (args.weak or not multi) else "strong",
+        "vs_baseline": None,
+        "dtype": "u32x8 (BN254-Fr Montgomery, 256-bit integer)",
+        "data": "synthetic",
+        "config": {"workload": "gkr.Prove(%s): ONE proof of 2^%d hashes (bN_total = %d), hypercube sharded on its low "
+                               "index bits over %d GPU(s) (2^%d-entry shard per GPU), inputs RandomFrArray, "
+                               "assignment resident in HBM%s"
+                               % ("MimcCircuit" if args.circuit == "mimc" else "GMiMC t=2 circuit", bn, bn, n_gpus, bn_gpu,
+                                  ("; per-round exchange: " + transport) if transport else ""),
+                   "bN": bn, "bN_total": bn, "bN_per_gpu": bn_gpu, "proof_elements": int(flat.shape[0]),
+                   "concurrent_proofs": nconc, "single_proof_latency_ms": latency_ms,
+                   "proof_verified_by_native_gkr_verify": verified},
+        "single_proof_latency_ms": latency_ms,
+    }
+    if dist is not None:
+        out["config"]["per_round_exchange"] = transport + ": all-reduce of 72 limb-split u64 lanes per sumcheck round"
+        out["config"]["bootstrap"] = "torch.distributed gloo (ids, barriers, max-over-ranks of the timing); the only RCCL in the process is the one libgkrhip dlopen()s"
+    if solo.get("rounds"):
+        out["single_proof"] = {"latency_ms": latency_ms, "hashes_per_s": float(1 << bn) / (latency_ms * 1e-3),
+                               "rounds": solo["rounds"], "host_hash_ms": solo["host_hash_ms"], "host_wait_ms": solo["host_wait_ms"],
+                               "host_launch_ms": solo["host_launch_ms"], "host_other_ms": solo["host_other_ms"],
+                               "note": "one gkr.Prove alone on the GPU (BenchmarkGkr's shape): the serial chain of rounds -- "
+                                       "Fiat-Shamir hash on the host, then the next round kernel -- is not overlapped with anything; "
+                                       "host_wait_ms is the time the host waited for round kernels (their GPU time plus hand-off latency)"}
+
+    build_info = importlib.import_module("gkr-mimc_amd.build").read_info() or {}
+    if rank == 0:
+        # ---- roofline of the HBM-bound kernel: k_fold<1>, the launch gkr.Prove uses for full-size tables, timed with HIP
+        # events on the launching stream over 20 back-to-back launches on 2^bn_gpu-element tables (out of place,
+        # table[i] = Montgomery(i), r = 5: BenchmarkFolding's shape)
+        iters = 20
+        ms1 = gk.bench_fold(1 << bn_gpu, ntab=1, warmup=3, iters=iters)
+        bytes1 = 96.0 * (1 << (bn_gpu - 1))
+        traffic = None
+        try:   # PMC pass of the same launches (tools/pmc_bench.sh), committed under profiles/
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fold_traffic.json")))
+            if pm.get("bn") == bn_gpu:
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+        ach = bytes1 / (ms1 * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_fold<1> on a 2^%d-element table (2^%d outputs)" % (bn_gpu, bn_gpu - 1),
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic, "launches": iters, "avg_launch_ms": ms1,
+                           "algorithmic_bytes_per_launch": bytes1,
+                           "measured": "HIP events on the launching stream around %d back-to-back launches, nothing else "
+                                       "running (gkrhip_bench_fold); 96 B per output element (SURVEY 8d)" % iters}
+        if solo["fold_launches"]:
+            sms = solo["fold_ms"] / solo["fold_launches"]
+            sb = solo["fold_bytes"] / solo["fold_launches"]
+            out["roofline"]["in_single_proof"] = {
+                "achieved": sb / (sms * 1e-3) / 1e9, "frac": sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": sms,
+                "launches": solo["fold_launches"], "algorithmic_bytes_per_launch": sb,
+                "measured": "the fold launches on full-size tables inside one gkr.Prove alone on the GPU (the key-copy "
+                            "layer's round 0: one launch per table of the instance, timed together)"}
+        if prof["fold_launches"]:
+            avg_ms = prof["fold_ms"] / prof["fold_launches"]
+            bpl = prof["fold_bytes"] / prof["fold_launches"]
+            out["roofline"]["in_timed_region"] = {
+                "achieved": bpl / (avg_ms * 1e-3) / 1e9, "frac": bpl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "avg_launch_ms": avg_ms, "launches": prof["fold_launches"],
+                "measured": "same launches inside the K timed steps with %d proofs in flight: the launch duration includes "
+                            "waiting for CU slots held by the other lanes' VALU-bound kernels" % nconc}
+    loops = build_info.get("round_kernel_loops", {})
+    if solo["peval_launches"] and args.circuit == "mimc" and "round0" in loops:
+        # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit): priced
+        # against instruction-issue ceilings taken from the ISA of THIS build (gkr-mimc_amd/build_info.json)
+        lp = loops["round0"]
+        pairs = float(1 << (bn_gpu - 1))
+        avg_ms = solo["peval_ms"] / solo["peval_launches"]
+        waves_per_simd = pairs / (N_SIMD * 64)
+        issue_cycles = HALF_RATE_CYCLES * lp["half_rate"] + FULL_RATE_CYCLES * lp["full_rate"]
+        ceiling_ms = waves_per_simd * issue_cycles / (NOMINAL_GHZ * 1e9) * 1e3
+        mad_ms = waves_per_simd * HALF_RATE_CYCLES * lp["v_mad_u64_u32"] / (NOMINAL_GHZ * 1e9) * 1e3
+        out["partial_eval"] = {
+            "kernel": "k_cipher_round_wide<false,true> (round 0 of a cipher layer: 2^%d index pairs; per pair 10 field "
+                      "products, 2 of them by a launch-wide constant, and 7 multiply-accumulates with deferred reduction)" % (bn_gpu - 1),
+            "bound": "integer VALU issue (no MFMA: modular arithmetic)",
+            "launches": solo["peval_launches"], "avg_launch_ms": avg_ms,
+            "loop_instructions_per_pair": lp, "issue_cycles_per_pair": issue_cycles,
+            "ceiling_ms": ceiling_ms, "frac": ceiling_ms / avg_ms,
+            "mad_only_ms": mad_ms, "mad_issue_frac": mad_ms / avg_ms,
+            "field_products_per_s": solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3),
+            "ceiling_assumption": "frac: every vector instruction of this build's loop body at its measured issue cost (%.1f / %.1f "
+                                  "cycles per wave), the port never idle, nominal %.1f GHz; mad_issue_frac: the limb products "
+                                  "(v_mad_u64_u32) alone at %.1f cycles -- what a carry-free multiplier would cost -- over the "
+                                  "measured duration" % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ, HALF_RATE_CYCLES),
+            "measured": "HIP events around the round-0 launches of the single-proof pass"}
+        if prof["peval_launches"]:
+            out["partial_eval"]["in_timed_region"] = {
+                "launches": prof["peval_launches"], "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
+                "note": "launch durations with %d proofs in flight overlap the other lanes' kernels" % nconc}
+    if prof.get("rounds"):
+        out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
+                                         ("host_hash_ms", "host_wait_ms", "host_launch_ms", "host_other_ms")}
+        out["host_split_ms_per_step"]["rounds"] = prof["rounds"] / args.steps
+
+    # ---- N > 1 on one node: the same K steps over the host shared-memory exchange, reported beside the RCCL headline
+    if multi and one_node and not args.no_shm_beside and args.exchange != "shm":
+        job.close()
+        gk.comm_destroy()
+        dist.barrier()
+        try:
+            t2 = install("shm")
+            job = Job(gk, bn, nconc, layers)
+            job.run_steps(max(1, min(args.warmup, nconc)))
+            dt2 = timed(job, args.steps)
+            out["config"]["shm_exchange_beside"] = {"value": hashes / dt2, "ms_per_step": 1e3 * dt2 / args.steps, "transport": t2}
+        except Exception as e:   # noqa: BLE001 -- the headline above stands; say why the companion figure is missing
+            out["config"]["shm_exchange_beside"] = {"error": str(e)}
+
+    if rank == 0 and not multi and not args.no_micro and args.circuit == "mimc":
+        # SURVEY 8d micro-benchmarks, shaped like the reference's own (device-resident tables)
+        job.close()
+        micro = {}
+        ms, _ = gk.bench_sumcheck(0, 22, 1, warmup=1, iters=3)
+        micro["sumcheck_cipher_bn22"] = {"ms_per_prove": ms, "index_pairs_per_s": float(1 << 22) / (ms * 1e-3),
+                                         "mirrors": "BenchmarkWithCipherGate, sumcheck/prover_test.go:96-109 (bn = 22, L = R = i, Ark = 145646)"}
+        ms, _ = gk.bench_sumcheck(1, 22, 91, warmup=1, iters=3)
+        micro["sumcheck_multi_identity_91_bn22"] = {"ms_per_prove": ms,
+                                                    "mirrors": "BenchmarkMultiIdentity, sumcheck/prover_test.go:111-125 (bn = 22, 91 instances)"}
+        ms = gk.bench_fold(1 << 25, ntab=1, warmup=2, iters=10)
+        micro["fold_2p25"] = {"ms": ms, "GB_per_s": 96.0 * (1 << 24) / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 96.0 * (1 << 24) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "mirrors": "BenchmarkFolding, poly/multilin_test.go:55-78 (2^25 elements, table[i] = i, r = 5)"}
+        out["micro"] = micro
+    if rank == 0 and not args.no_cpu_baseline and not multi and args.circuit == "mimc":
+        out["cpu_baseline"] = cpu_baseline()
+    out["build"] = {"source_sha256": (build_info.get("source_sha256") or "")[:16], "hipcc": build_info.get("hipcc", "")}
+    if rank == 0:
+        print(json.dumps(out))
+    job.close()
+    if dist is not None:
+        gk.comm_destroy()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

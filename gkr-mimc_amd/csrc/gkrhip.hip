@@ -726,6 +726,63 @@ int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms)
     return 0;
 }
 
+// sumcheck.Prove micro-benchmarks on device-resident tables, shaped like the reference's
+// (sumcheck/prover_test.go:96-125, instances of sumcheck/testing.go:11-57: L = R = [0, 1, 2, ...]):
+//   kind 0  BenchmarkWithCipherGate: CipherGate(ark = 145646), one point q = RandomFrArray(bn)
+//   kind 1  BenchmarkMultiIdentity : IdentityGate on [L, R], `ninstance` points q_i[j] = i*j + i with claims
+//                                    Evaluation(q_i) = L(q_i)
+// The instance is built outside the timer (as the reference does with StopTimer); *avg_ms = wall-clock per Prove,
+// Fiat-Shamir hashing included.  final_claim0 receives finalClaims[0] of the last run (a value to cross-check).
+int gkrhip_bench_sumcheck(int kind, int bn, int ninstance, int warmup, int iters, double* avg_ms, uint64_t final_claim0[4]) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    if (bn < 1 || bn > 28 || iters < 1 || (kind != 0 && kind != 1)) return fail("bench_sumcheck: bad arguments");
+    if (kind == 0) ninstance = 1;
+    if (ninstance < 1 || ninstance > 1024) return fail("bench_sumcheck: 1..1024 instances");
+    LocalOnly lo;
+    const size_t n = (size_t)1 << bn;
+    ScopedTable L, R;
+    CHK(table_alloc(&L, n));
+    CHK(table_alloc(&R, n));
+    for (DevTable* t : {(DevTable*)&L, (DevTable*)&R}) {
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->planes(), n);
+        HIPCHK(hipGetLastError());
+    }
+    const DevTable* X[2] = {&L, &R};
+    const int gate = kind == 0 ? GKRHIP_GATE_CIPHER : GKRHIP_GATE_IDENTITY;
+    const E ark = kind == 0 ? hfr::from_u64(145646) : hfr::ZERO;
+    const int nev = gate_degree(gate) + 2;
+    std::vector<E> qs((size_t)ninstance * bn), claims(ninstance, hfr::ZERO);
+    if (kind == 0) {
+        for (int j = 0; j < bn; j++) qs[j] = hfr::from_u64(((unsigned long long)j * j) ^ 0xf45c9df123fULL);   // common.RandomFrArray
+    } else {
+        for (int i = 0; i < ninstance; i++) {
+            for (int j = 0; j < bn; j++) qs[(size_t)i * bn + j] = hfr::from_u64((unsigned long long)i * j + i);
+            CHK(evaluate_dev(&L, bn, &qs[(size_t)i * bn], &claims[i]));       // Evaluation(identity, q_i) = L(q_i)
+        }
+    }
+    std::vector<E> proof((size_t)bn * nev), chal(bn);
+    E fin[GKR_MAX_ARITY + 1];
+    if (kind == 0) {
+        // the claim of the instance (testing.go:24) = P_0(0) + P_0(1) of an honest first round; a single claim never
+        // enters the transcript (it only seeds the unused recombination challenge, prover.go:121-128)
+        CHK(sumcheck_prove_dev(gate, ark, 2, bn, X, qs.data(), 1, claims.data(), 1, proof.data(), chal.data(), fin));
+        E c01 = hfr::add(proof[0], proof[0]);
+        for (int j = 1; j < nev; j++) c01 = hfr::add(c01, proof[j]);
+        claims[0] = c01;
+    }
+    for (int i = 0; i < warmup; i++)
+        CHK(sumcheck_prove_dev(gate, ark, 2, bn, X, qs.data(), ninstance, claims.data(), ninstance, proof.data(), chal.data(), fin));
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    const double t0 = now_ms();
+    for (int i = 0; i < iters; i++)
+        CHK(sumcheck_prove_dev(gate, ark, 2, bn, X, qs.data(), ninstance, claims.data(), ninstance, proof.data(), chal.data(), fin));
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    *avg_ms = (now_ms() - t0) / iters;
+    if (final_claim0) memcpy(final_claim0, fin[0].l, 32);
+    return 0;
+}
+
 int gkrhip_profile_reset(size_t min_n) {
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));

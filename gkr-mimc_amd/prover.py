@@ -74,6 +74,7 @@ ABI = {
     "gkrhip_host_mimc_hash": (_I, [_P, _P, _SZ]),
     "gkrhip_host_cipher_round_coeffs": (_I, [_P, _P, _P, _P]),
     "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D)]),
+    "gkrhip_bench_sumcheck": (_I, [_I, _I, _I, _I, _I, C.POINTER(_D), _P]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -96,6 +97,11 @@ def load():
     if not os.path.exists(_SO):
         raise GkrHipError("libgkrhip.so not built: run `python __graft_entry__.py` (or gkr-mimc_amd/build.py); "
                           "there is no CPU fallback")
+    from . import build as _build
+    info = _build.read_info()
+    if info is None or info.get("source_sha256") != _build.source_sha():
+        raise GkrHipError("libgkrhip.so was not built from the sources in this tree (build_info.json missing or stale): "
+                          "run `python __graft_entry__.py`; there is no CPU fallback")
     lib = C.CDLL(_SO)
     for name, (res, args) in ABI.items():
         f = getattr(lib, name)
@@ -410,6 +416,14 @@ def bench_fold(n, ntab=1, warmup=3, iters=20):
     ms = C.c_double(0)
     _check(load().gkrhip_bench_fold(n, ntab, warmup, iters, C.byref(ms)))
     return ms.value
+
+
+def bench_sumcheck(kind, bn, ninstance=1, warmup=1, iters=3):
+    """sumcheck.Prove micro-benchmark (kind 0: BenchmarkWithCipherGate, 1: BenchmarkMultiIdentity): (ms per Prove, finalClaims[0])."""
+    ms = C.c_double(0)
+    fin = np.zeros((1, 4), np.uint64)
+    _check(load().gkrhip_bench_sumcheck(kind, bn, ninstance, warmup, iters, C.byref(ms), _ptr(fin)))
+    return ms.value, fin
 
 
 def profile_reset(min_n):

@@ -41,8 +41,9 @@ const char *gkrhip_version(void);
 int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
 int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
- * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick" -- applied to every existing lane (DESIGN.md,
- * "Runtime switches", lists the environment variables read at gkrhip_init) */
+ * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail" -- applied to every existing lane,
+ * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
+ * gkrhip_init) */
 int gkrhip_set_option(const char *key, long value);
 
 /* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
@@ -176,6 +177,13 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t *M, const u
  * ntab tables of n elements (table[i] = Montgomery(i)), r = 5, `iters` timed out-of-place folds after
  * `warmup`; *avg_ms = mean kernel time from HIP events on the library's stream. */
 int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double *avg_ms);
+/* sumcheck.Prove micro-benchmarks on device-resident tables, shaped like the reference's own
+ * (sumcheck/prover_test.go:96-125; instances of sumcheck/testing.go:11-57 with L = R = [0, 1, 2, ...]):
+ * kind 0 = BenchmarkWithCipherGate (CipherGate, Ark = 145646, one point RandomFrArray(bn)); kind 1 =
+ * BenchmarkMultiIdentity (IdentityGate, `ninstance` points q_i[j] = i*j + i with their true claims).  The instance is
+ * built outside the timer; *avg_ms = wall-clock per Prove (Fiat-Shamir hashing included); final_claim0 (may be NULL)
+ * receives finalClaims[0] of the last run. */
+int gkrhip_bench_sumcheck(int kind, int bn, int ninstance, int warmup, int iters, double *avg_ms, uint64_t final_claim0[4]);
 /* Per-kernel accounting of the calling process since the last reset: HIP-event time of every fold
  * launch whose input table has >= min_n elements. */
 int gkrhip_profile_reset(size_t min_n);

@@ -47,6 +47,52 @@ def concurrent(gk, world, rank, sizes, nlanes):
     print("SHARD-OK rank %d/%d lanes=%d %s" % (rank, world, nlanes, sizes))
 
 
+def digests(gk, world, rank, sizes, circuit):
+    """BASELINE sizes: RandomFrArray inputs generated on the device (this rank's shard), transcript SHA-256 against
+    the digest the C oracle produced for the UN-sharded proof (tests/golden/*_big_digests.json)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden",
+                                       "gkr_gmimc_big_digests.json" if circuit == "gmimc" else "gkr_mimc_big_digests.json")))
+    layers = gk.gmimc_t2_circuit() if circuit == "gmimc" else None
+    for bn in sizes:
+        want = [e for e in gold if e["bn"] == bn][0]
+        s = gk.MimcSession(bn, layers=layers)
+        s.synth_inputs()
+        s.assign()
+        qp = c.random_fr_array(bn)
+        flat = s.prove(qp)
+        assert flat.shape[0] == want["n_elements"]
+        assert hashlib.sha256(flat.astype("<u8").tobytes()).hexdigest() == want["sha256_flat"], ("digest", circuit, bn, rank)
+        assert s.verify(qp, flat), ("verify", circuit, bn, rank)
+        s.close()
+    gk.comm_destroy()
+    print("SHARD-OK rank %d/%d digests %s %s" % (rank, world, circuit, sizes))
+
+
+def gmimc_small(gk, world, rank, sizes):
+    """The GMiMC (t = 2) circuit sharded: cipher, add and identity layers against the C oracle's un-sharded transcript."""
+    import pyoracle as o
+    layers = gk.gmimc_t2_circuit()
+    descs = c.circuit_descs(o.gmimc_t2_circuit())
+    for bn in sizes:
+        n = 1 << bn
+        ins = [c.random_fr_array(n) if i % 2 == 0 else c.from_ints([(7 * j * j + i) % 1000003 for j in range(n)]) for i in range(4)]
+        qp = c.random_fr_array(bn)
+        s = gk.MimcSession(bn, layers=layers)
+        for i, t in enumerate(ins):
+            s.load_input(i, t[rank::world].copy())
+        s.assign()
+        flat = s.prove(qp)
+        oflat, oouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+        assert np.array_equal(flat, oflat), ("gmimc transcript", bn, rank)
+        assert np.array_equal(s.outputs(), oouts[rank::world]), ("gmimc outputs", bn, rank)
+        assert s.verify(qp, flat)
+        s.close()
+    gk.comm_destroy()
+    print("SHARD-OK rank %d/%d gmimc %s" % (rank, world, sizes))
+
+
 def main():
     mode, world, rank, name = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     sizes = [int(x) for x in sys.argv[5].split(",")]
@@ -57,6 +103,11 @@ def main():
         gk.comm_init_shm_lanes(world, rank, nlanes, name)
     else:
         gk.comm_init_lanes(1, 0, np.stack([gk.comm_unique_id() for _ in range(nlanes)]))
+    circuit = os.environ.get("GKR_TEST_CIRCUIT", "mimc")
+    if os.environ.get("GKR_TEST_DIGEST"):
+        return digests(gk, world, rank, sizes, circuit)
+    if circuit == "gmimc":
+        return gmimc_small(gk, world, rank, sizes)
     if nlanes > 1:
         return concurrent(gk, world, rank, sizes, nlanes)
     for bn in sizes:

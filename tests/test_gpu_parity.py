@@ -539,6 +539,79 @@ def test_gmimc_circuit_larger_sizes(gk):
         s.close()
 
 
+@pytest.mark.parametrize("bn", [14, 20, 22])
+def test_gmimc_baseline_sizes_match_oracle_digest(gk, bn):
+    """BASELINE config 5 (bN = 22) and two smaller sizes: SHA-256 of the GPU transcript and of the output table
+    against the C oracle's (tests/golden/gkr_gmimc_big_digests.json, tests/golden/gen_big_digests.py gmimc)."""
+    want = [e for e in load("gkr_gmimc_big_digests.json") if e["bn"] == bn][0]
+    s = gk.MimcSession(bn, layers=gk.gmimc_t2_circuit())
+    s.synth_inputs()
+    s.assign()
+    flat = s.prove(c.random_fr_array(bn))
+    assert flat.shape[0] == want["n_elements"]
+    assert hashlib.sha256(flat.astype("<u8").tobytes()).hexdigest() == want["sha256_flat"]
+    assert hashlib.sha256(s.outputs().astype("<u8").tobytes()).hexdigest() == want["sha256_outputs"]
+    s.close()
+
+
+def _split_flat(circ_out_sizes, degs, bn, flat):
+    """flat proof (GkrProofToVec order, hints.go:236-271) -> (claims[layer][slot], qprimes[layer][slot])."""
+    L = len(circ_out_sizes)
+    cur = sum(bn * (d + 2) for d in degs if d is not None)
+    claims, qps = [], []
+    for l in range(L):
+        claims.append(flat[cur:cur + circ_out_sizes[l]])
+        cur += circ_out_sizes[l]
+    for l in range(L):
+        slots = 1 if l == L - 1 else circ_out_sizes[l]
+        qps.append(flat[cur:cur + slots * bn].reshape(slots, bn, 4))
+        cur += slots * bn
+    assert cur == flat.shape[0]
+    return claims, qps
+
+
+def test_gkr_all_claims_equal_evaluate_bn20(gk):
+    """gkr/gkr_test.go:35-44 at BASELINE config 2's size: EVERY claim of the proof (183 of them: 91 on the key
+    copy, one per cipher layer, the two inputs) equals MultiLin.Evaluate of that layer's table at the claim's point,
+    evaluated on the resident (never mutated) assignment."""
+    bn = 20
+    circ = o.mimc_circuit()
+    outs = [len(l.Out) for l in circ]
+    degs = [None if l.gate is None else l.gate.degree() for l in circ]
+    s = gk.MimcSession(bn)
+    s.synth_inputs()
+    s.assign()
+    flat = s.prove(c.random_fr_array(bn))
+    claims, qps = _split_flat(outs, degs, bn, flat)
+    checked = 0
+    for l in range(len(circ) - 1):
+        for w in range(outs[l]):
+            assert np.array_equal(s.evaluate_layer(l, qps[l][w]), claims[l][w:w + 1]), (l, w)
+            checked += 1
+    assert checked == 183
+    s.close()
+
+
+def test_gkr_bn22_accepted_by_oracle_verifier(gk):
+    """The ORACLE's restated gkr.Verify (not the library's own) on the GPU's bN = 22 proof: inputs are regenerated
+    on the host, the output table comes from the device and is itself pinned by the committed digest."""
+    bn = 22
+    want = [e for e in load("gkr_mimc_big_digests.json") if e["bn"] == bn][0]
+    s = gk.MimcSession(bn)
+    s.synth_inputs()
+    s.assign()
+    qp = c.random_fr_array(bn)
+    flat = s.prove(qp)
+    outs = s.outputs()
+    s.close()
+    assert hashlib.sha256(outs.astype("<u8").tobytes()).hexdigest() == want["sha256_outputs"]
+    i0 = c.random_fr_array(1 << bn)
+    assert c.gkr_verify_mimc(bn, flat, i0, i0, outs, qp) == 0
+    bad = flat.copy()
+    bad[12345, 1] ^= np.uint64(4)
+    assert c.gkr_verify_mimc(bn, bad, i0, i0, outs, qp) != 0
+
+
 # ---------------------------------------------------------------- verifier and wire-format helpers
 @pytest.mark.parametrize("bn", [0, 1, 3, 8, 13])
 def test_native_verifier_agrees_with_oracle(gk, bn):
@@ -643,6 +716,23 @@ def test_sharded_prover_concurrent_lanes(gk):
     """Two lanes per rank, each with its own collective channel, two proofs in flight per rank."""
     _run_shards("shm", 2, "4,9,11", {"GKR_TEST_LANES": "2"})
     _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
+
+
+def test_sharded_prover_full_size_digests(gk):
+    """BASELINE config 3's size through the sharded driver: 8 ranks time-sharing the GPU (2^21-entry shards, the
+    per-round exchange over shared memory) at bN = 24, and 2 ranks at bN = 22; the transcript must be the one the C
+    oracle produced for the un-sharded proof (tests/golden/gkr_mimc_big_digests.json)."""
+    _run_shards("shm", 8, "24", {"GKR_TEST_DIGEST": "1"})
+    _run_shards("shm", 2, "22", {"GKR_TEST_DIGEST": "1"})
+
+
+def test_sharded_gmimc_circuit(gk):
+    """BASELINE config 5's circuit sharded (linear layers included): small sizes against the C oracle's un-sharded
+    transcript, bN = 14 and 20 against the committed digests."""
+    _run_shards("shm", 2, "1,2,5,9", {"GKR_TEST_CIRCUIT": "gmimc"})
+    _run_shards("shm", 4, "2,3,8,11", {"GKR_TEST_CIRCUIT": "gmimc"})
+    _run_shards("shm", 4, "14,20", {"GKR_TEST_CIRCUIT": "gmimc", "GKR_TEST_DIGEST": "1"})
+    _run_shards("shm", 2, "3,6,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_GENERIC": "1"})
 
 
 def test_rccl_plumbing_world1(gk):

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box session of the round: parity tests, default bench line, RCCL-path variants at world = 1.
+# Usage (from the repo root, through gpurun):  bash tools/gpu_session.sh <tag> [steps...]
+TAG=${1:-s}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+for step in "$@"; do
+  case $step in
+    tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log ;;
+    bench) timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json ;;
+    bench_hwq8) GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --no-cpu-baseline --no-micro > $OUT/bench_hwq8.json 2> $OUT/bench_hwq8.err ;;
+    rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
+    rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
+    shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+for f in $OUT/bench_*.json; do echo "== $f"; python3 - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(d["value"] / 1e6, "M/s", d["ms_per_step"], "ms/step; latency", d["config"]["single_proof_latency_ms"], d["config"].get("per_round_exchange", ""))
+except Exception as e:
+    print("no json:", e)
+PY
+done
