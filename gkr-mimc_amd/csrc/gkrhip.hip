@@ -38,6 +38,7 @@ using hfr::E;
 // ------------------------------------------------------------------------------------------------
 namespace {
 #include "host_ctx.hip.h"
+#include "host_gates.hip.h"
 #include "host_coll.hip.h"
 #include "host_sumcheck.hip.h"
 #include "host_circuit.hip.h"
@@ -308,7 +309,7 @@ int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res,
                            size_t n) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
-    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    if (arity < 1 || arity > GKR_MAX_ARITY) return fail("arity %d not supported (1..%d)", arity, GKR_MAX_ARITY);
     if (n < 1) return fail("EvalBatch: empty tables");
     ScopedTable in[GKR_MAX_ARITY], out;
     const DevTable* inp[GKR_MAX_ARITY];
@@ -333,7 +334,7 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int 
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (bN < 0 || bN > 30) return fail("bN %d out of range", bN);
-    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    if (arity < 1 || arity > GKR_MAX_ARITY) return fail("arity %d not supported (1..%d)", arity, GKR_MAX_ARITY);
     const size_t n = (size_t)1 << bN;
     LocalOnly lo;
     ScopedTable tabs[GKR_MAX_ARITY];
@@ -376,6 +377,33 @@ int gkrhip_gmimc_t2_circuit(gkrhip_layer* layers_out, int capacity) {
         memcpy(layers_out, v.data(), v.size() * sizeof(gkrhip_layer));
     }
     return (int)v.size();
+}
+
+int gkrhip_gmimc_circuit(int t, gkrhip_layer* layers_out, int capacity, int* input_map_out) {
+    std::vector<gkrhip_layer> v;
+    std::vector<int> map;
+    if (gmimc_layers(t, &v, &map) != 0) return -1;
+    if (input_map_out)
+        for (size_t k = 0; k < map.size(); k++) input_map_out[k] = map[k];
+    if (layers_out) {
+        if (capacity < (int)v.size()) return fail("gmimc_circuit: capacity %d < %zu layers", capacity, v.size());
+        memcpy(layers_out, v.data(), v.size() * sizeof(gkrhip_layer));
+    }
+    return (int)v.size();
+}
+
+int gkrhip_gate_register(const gkrhip_gate_desc* desc, int* gate_id) { return gate_register(desc, gate_id); }
+int gkrhip_gate_lookup(int gate_id, gkrhip_gate_desc* desc_out) {
+    GateDesc g;
+    if (!gate_get(gate_id, &g)) return fail("unknown gate id %d", gate_id);
+    if (desc_out) {
+        memset(desc_out, 0, sizeof *desc_out);
+        strncpy(desc_out->id, g.id.c_str(), sizeof desc_out->id - 1);
+        desc_out->n_in = g.n_in;
+        desc_out->sum_mask = g.mask;
+        desc_out->power = g.power;
+    }
+    return 0;
 }
 
 size_t gkrhip_session_proof_len(const gkrhip_session* s) { return s ? proof_len(s->c, s->bN) : 0; }
@@ -637,10 +665,9 @@ static int verify_flat(const Circuit& c, int bN, const E* flat, const E* qprime,
             if (memcmp(qps[inp] + r_at * bN, next_q.data(), (size_t)bN * sizeof(E)) != 0) return 1000 + layer;
             sub[k] = claims[inp][r_at];
         }
-        E gate_val;
-        if (c[layer].gate == GKRHIP_GATE_CIPHER) gate_val = hfr::pow7(hfr::add(hfr::add(sub[1], c[layer].ark), sub[0]));
-        else if (c[layer].gate == GKRHIP_GATE_ADD) gate_val = hfr::add(hfr::add(sub[0], sub[1]), c[layer].ark);
-        else gate_val = sub[0];
+        GateDesc gd;
+        if (!gate_get(c[layer].gate, &gd)) return fail("verify: unknown gate %d", c[layer].gate);
+        const E gate_val = gate_eval_host(gd, c[layer].gate == GKRHIP_GATE_IDENTITY ? hfr::ZERO : c[layer].ark, sub);
         std::vector<E> eqs(ncl);
         for (int i = 0; i < ncl; i++) eqs[i] = hfr::eval_eq(qps[layer] + (size_t)i * bN, next_q.data(), bN);
         const E eq_eval = hfr::eval_univariate(eqs.data(), ncl, recomb);
@@ -674,6 +701,31 @@ int gkrhip_gkr_verify_mimc(int bN, const uint64_t* flat, const uint64_t* in0, co
     };
     const int rc = verify_flat(c, bN, (const E*)flat, (const E*)qprime, eval);
     for (int i = 0; i < 3; i++) table_release(&t[i]);
+    if (rc > 0) fail("gkr.Verify rejected the proof (code %d)", rc);
+    return rc;
+}
+
+int gkrhip_gkr_verify(const gkrhip_layer* layers, int n_layers, int bN, const uint64_t* flat, const uint64_t* const* inputs,
+                      int n_inputs, const uint64_t* outputs, const uint64_t* qprime) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    LocalOnly lo;
+    if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
+    Circuit c;
+    CHK(circuit_from_layers(layers, n_layers, &c));
+    int n_in = 0;
+    while (n_in < (int)c.size() && c[n_in].gate < 0) n_in++;
+    if (n_inputs != n_in) return fail("gkr.Verify: the circuit has %d input layers, %d tables were given", n_in, n_inputs);
+    const size_t n = (size_t)1 << bN;
+    std::vector<ScopedTable> t(n_in + 1);
+    for (int i = 0; i <= n_in; i++) {
+        CHK(table_alloc(&t[i], n));
+        CHK(upload_table(&t[i], i < n_in ? inputs[i] : outputs, n));
+    }
+    auto eval = [&](int layer, const E* pt, E* out) -> int {
+        return evaluate_dev(layer < n_in ? &t[layer] : &t[n_in], bN, pt, out);
+    };
+    const int rc = verify_flat(c, bN, (const E*)flat, (const E*)qprime, eval);
     if (rc > 0) fail("gkr.Verify rejected the proof (code %d)", rc);
     return rc;
 }

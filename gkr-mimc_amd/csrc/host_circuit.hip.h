@@ -36,10 +36,9 @@ int circuit_from_layers(const gkrhip_layer* layers, int n, Circuit* out) {
             continue;
         }
         seen_gate = true;
-        if (d.gate != GKRHIP_GATE_IDENTITY && d.gate != GKRHIP_GATE_CIPHER && d.gate != GKRHIP_GATE_ADD)
-            return fail("circuit: layer %d has unknown gate %d", l, d.gate);
-        const int want = d.gate == GKRHIP_GATE_IDENTITY ? 1 : 2;
-        if (d.n_in != want) return fail("circuit: layer %d: gate %d takes %d inputs, got %d", l, d.gate, want, d.n_in);
+        GateDesc g;
+        if (!gate_get(d.gate, &g)) return fail("circuit: layer %d has unknown gate %d", l, d.gate);
+        if (d.n_in != g.n_in) return fail("circuit: layer %d: gate %s takes %d inputs, got %d", l, g.id.c_str(), g.n_in, d.n_in);
         c[l].gate = d.gate;
         memcpy(c[l].ark.l, d.ark, 32);
         if (!hfr::is_canonical(c[l].ark)) return fail("circuit: layer %d: Ark is not a canonical element", l);
@@ -61,59 +60,105 @@ int circuit_from_layers(const gkrhip_layer* layers, int n, Circuit* out) {
     return 0;
 }
 
-// Build-defined circuit of one GMiMC (t = 2) compression, out = GMimcT2.UpdateInplace([s0,s1],[b0,b1])[0]
-// (hash/gmimc.go:52-65): inputs 0..3 = s0, s1, b0, b1; per round one add layer x' = y + b1 + Ark_i and one
-// cipher layer y' = (b0 + x + Ark_i)^7; explicit copy layers for the multi-use inputs; feed-forward by two add
-// layers with Ark = 0; layers that do not reach the output are pruned.
-std::vector<gkrhip_layer> gmimc_t2_layers() {
+// Build-defined circuits of one GMiMC compression, out = GMimcT{t}.UpdateInplace(state, block)[0]
+// (hash/gmimc.go:52-65).  The reference has the hasher but no gate or circuit for it; a round
+//     state[j] += block[j] + Ark_i  (all j);   state[0] = state[0]^7;   rotate left
+// is, per wire, one add layer (x + b + Ark_i) for the t-1 linear branches and one cipher layer (b + x + Ark_i)^7 for
+// the S-box branch; inputs used more than once sit behind explicit copy layers (as examples/mimc.go:20 does for the
+// key); layers that do not reach the output are pruned.
+struct GmimcBuilder {
     struct Tmp {
-        int gate, n_in, in[2];
+        int gate, n_in, in[GKRHIP_MAX_GATE_INPUTS];
         E ark;
     };
     std::vector<Tmp> L;
-    auto add = [&](int gate, int a, int b, const E& ark) {
+    int add(int gate, std::initializer_list<int> ins, const E& ark) {
         Tmp t;
+        memset(&t, 0, sizeof t);
         t.gate = gate;
-        t.n_in = gate < 0 ? 0 : (gate == GKRHIP_GATE_IDENTITY ? 1 : 2);
-        t.in[0] = a;
-        t.in[1] = b;
+        t.n_in = (int)ins.size();
+        int k = 0;
+        for (int v : ins) t.in[k++] = v;
         t.ark = ark;
         L.push_back(t);
         return (int)L.size() - 1;
-    };
-    for (int i = 0; i < 4; i++) add(-1, 0, 0, hfr::ZERO);
-    const int cs0 = add(GKRHIP_GATE_IDENTITY, 0, 0, hfr::ZERO);
-    const int cb0 = add(GKRHIP_GATE_IDENTITY, 2, 0, hfr::ZERO);
-    const int cb1 = add(GKRHIP_GATE_IDENTITY, 3, 0, hfr::ZERO);
+    }
+    // prune what does not reach the last layer; kept_inputs (optional) receives the original indices of the input
+    // layers that remain (an input layer without a consumer would have no claim to check, gkr/verifier.go:120-132)
+    std::vector<gkrhip_layer> finish(std::vector<int>* kept_inputs = nullptr) {
+        std::vector<char> need(L.size(), 0);
+        need.back() = 1;
+        for (int l = (int)L.size() - 1; l >= 0; l--)
+            if (need[l])
+                for (int k = 0; k < L[l].n_in; k++) need[L[l].in[k]] = 1;
+        std::vector<int> ren(L.size(), -1);
+        std::vector<gkrhip_layer> out;
+        for (size_t l = 0; l < L.size(); l++) {
+            if (!need[l]) continue;
+            if (L[l].gate < 0 && kept_inputs) kept_inputs->push_back((int)l);
+            ren[l] = (int)out.size();
+            gkrhip_layer d;
+            memset(&d, 0, sizeof d);
+            d.gate = L[l].gate;
+            d.n_in = L[l].n_in;
+            for (int k = 0; k < d.n_in; k++) d.in[k] = ren[L[l].in[k]];
+            memcpy(d.ark, L[l].ark.l, 32);
+            out.push_back(d);
+        }
+        return out;
+    }
+};
+
+// t = 2 with two-input gates only (BASELINE config 5): inputs 0..3 = s0, s1, b0, b1; the feed-forward
+// x_91 + s0 + b0 is two add layers with Ark = 0.
+std::vector<gkrhip_layer> gmimc_t2_layers() {
+    GmimcBuilder B;
+    for (int i = 0; i < 4; i++) B.add(-1, {}, hfr::ZERO);
+    const int cs0 = B.add(GKRHIP_GATE_IDENTITY, {0}, hfr::ZERO);
+    const int cb0 = B.add(GKRHIP_GATE_IDENTITY, {2}, hfr::ZERO);
+    const int cb1 = B.add(GKRHIP_GATE_IDENTITY, {3}, hfr::ZERO);
     int x = cs0, y = 1;
     for (int i = 0; i < hfr::MIMC_ROUNDS; i++) {
-        const int nx = add(GKRHIP_GATE_ADD, y, cb1, hfr::ARKS[i]);
-        const int ny = add(GKRHIP_GATE_CIPHER, cb0, x, hfr::ARKS[i]);
+        const int nx = B.add(GKRHIP_GATE_ADD, {y, cb1}, hfr::ARKS[i]);
+        const int ny = B.add(GKRHIP_GATE_CIPHER, {cb0, x}, hfr::ARKS[i]);
         x = nx;
         y = ny;
     }
-    const int t1 = add(GKRHIP_GATE_ADD, x, cs0, hfr::ZERO);
-    add(GKRHIP_GATE_ADD, t1, cb0, hfr::ZERO);
-    std::vector<char> need(L.size(), 0);
-    need.back() = 1;
-    for (int l = (int)L.size() - 1; l >= 0; l--)
-        if (need[l])
-            for (int k = 0; k < L[l].n_in; k++) need[L[l].in[k]] = 1;
-    for (int i = 0; i < 4; i++) need[i] = 1;
-    std::vector<int> ren(L.size(), -1);
-    std::vector<gkrhip_layer> out;
-    for (size_t l = 0; l < L.size(); l++) {
-        if (!need[l]) continue;
-        ren[l] = (int)out.size();
-        gkrhip_layer d;
-        memset(&d, 0, sizeof d);
-        d.gate = L[l].gate;
-        d.n_in = L[l].n_in;
-        for (int k = 0; k < d.n_in; k++) d.in[k] = ren[L[l].in[k]];
-        memcpy(d.ark, L[l].ark.l, 32);
-        out.push_back(d);
+    const int t1 = B.add(GKRHIP_GATE_ADD, {x, cs0}, hfr::ZERO);
+    B.add(GKRHIP_GATE_ADD, {t1, cb0}, hfr::ZERO);
+    return B.finish();
+}
+
+// any t in {2, 4, 8} (hash/gmimc.go:16-20); the feed-forward is ONE layer of the registered three-input gate "sum3"
+// (state'[0] + state[0] + block[0]).  The reference's round never mixes the branches (every branch gets its own
+// key and Ark added, branch 0 goes through the S-box, the state rotates), so state'[0] depends on ONE initial branch
+// (number 91 mod t) besides the feed-forward operands: the circuit's input layers are exactly the operands that
+// matter, input_map[k] = j for state[j], t + j for block[j] (t = 2: all four; t = 4: 6 of 8; t = 8: 10 of 16).
+int gmimc_layers(int t, std::vector<gkrhip_layer>* out, std::vector<int>* input_map) {
+    if (t != 2 && t != 4 && t != 8) return fail("gmimc circuit: t = %d (2, 4 or 8)", t);
+    gkrhip_gate_desc d;
+    memset(&d, 0, sizeof d);
+    strcpy(d.id, "sum3");
+    d.n_in = 3;
+    d.sum_mask = 7;
+    d.power = 1;
+    int sum3 = -1;
+    CHK(gate_register(&d, &sum3));
+    GmimcBuilder B;
+    for (int i = 0; i < 2 * t; i++) B.add(-1, {}, hfr::ZERO);
+    std::vector<int> st(t), cb(t);
+    const int cs0 = B.add(GKRHIP_GATE_IDENTITY, {0}, hfr::ZERO);      // state[0]: round 0 and the feed-forward
+    for (int j = 0; j < t; j++) st[j] = j == 0 ? cs0 : j;
+    for (int j = 0; j < t; j++) cb[j] = B.add(GKRHIP_GATE_IDENTITY, {t + j}, hfr::ZERO);   // block[j]: every round
+    for (int i = 0; i < hfr::MIMC_ROUNDS; i++) {
+        std::vector<int> nx(t);
+        for (int j = 1; j < t; j++) nx[j - 1] = B.add(GKRHIP_GATE_ADD, {st[j], cb[j]}, hfr::ARKS[i]);
+        nx[t - 1] = B.add(GKRHIP_GATE_CIPHER, {cb[0], st[0]}, hfr::ARKS[i]);
+        st = nx;
     }
-    return out;
+    B.add(sum3, {st[0], cs0, cb[0]}, hfr::ZERO);
+    *out = B.finish(input_map);
+    return 0;
 }
 
 size_t proof_len(const Circuit& c, int bN) {  // hints.go:76-116

@@ -246,7 +246,7 @@ int gather0(const DevTable* const* t, int ntab, E* out) {
 
 // evals[t] (t < nev) for the current round.  Launches the partial evaluation, the block reduction,
 // (all-reduces the limb-split sums across ranks,) copies them to the host and reduces them mod q.
-int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, E* evals,
+int partial_evals(const GateDesc& g, const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, E* evals,
                   int nev, bool collective) {
     int nblocks = 0;
     const bool direct = !collective;      // un-sharded: the kernel hands the sums to the host itself
@@ -257,23 +257,25 @@ int partial_evals(int gate, int arity, const DevTable* eq, const DevTable* const
         e1 = prof_event();
         HIPCHK(hipEventRecord(e0, cx().stream));
     }
-    if (gate == GKRHIP_GATE_CIPHER && arity == 2) {
-        CHK((launch_partial_eval_t<GKR_GATE_CIPHER, 2, 9>(eq, x, mid, ark, &nblocks, direct)));
-    } else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) {
-        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 1, 3>(eq, x, mid, ark, &nblocks, direct)));
-    } else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) {
-        CHK((launch_partial_eval_t<GKR_GATE_IDENTITY, 2, 3>(eq, x, mid, ark, &nblocks, direct)));
-    } else if (gate == GKRHIP_GATE_ADD && arity == 2) {
-        CHK((launch_partial_eval_t<GKR_GATE_ADD, 2, 3>(eq, x, mid, ark, &nblocks, direct)));
-    } else {
-        return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
+#define GKR_PE(P, A) CHK((launch_partial_eval_t<P, A, P + 2>(eq, x, mid, ark, g.mask, &nblocks, direct)))
+    switch (g.power * 10 + g.n_in) {
+        case 11: GKR_PE(1, 1); break;
+        case 12: GKR_PE(1, 2); break;
+        case 13: GKR_PE(1, 3); break;
+        case 14: GKR_PE(1, 4); break;
+        case 71: GKR_PE(7, 1); break;
+        case 72: GKR_PE(7, 2); break;
+        case 73: GKR_PE(7, 3); break;
+        case 74: GKR_PE(7, 4); break;
+        default: return fail("unsupported gate shape (power %d, %d inputs)", g.power, g.n_in);
     }
+#undef GKR_PE
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(e1, cx().stream));
         cx().prof.peval_ev.emplace_back(e0, e1);
         cx().prof.peval_launches++;
-        cx().prof.peval_modmuls += (gate == GKRHIP_GATE_CIPHER ? 45.0 : 3.0) * (double)mid;
+        cx().prof.peval_modmuls += (g.power == 7 ? 45.0 : 3.0) * (double)mid;
     }
     const int nwords = nev * GKR_ACC_WORDS;
     if (direct) {

@@ -561,14 +561,16 @@ int launch_fold(const DevTable* const* src, const DevTable* const* dst, int ntab
     return 0;
 }
 
-template <int GATE, int ARITY, int NEV>
-int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, int* nblocks, bool direct) {
+template <int POWER, int ARITY, int NEV>
+int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, unsigned mask, int* nblocks,
+                          bool direct) {
     PartialEvalArgs a;
     memset(&a, 0, sizeof a);
     a.eq = eq->cplanes();
     for (int k = 0; k < ARITY; k++) a.x[k] = x[k]->cplanes();
     a.mid = mid;
     a.ark = to_dev(ark);
+    a.mask = mask;
     a.partials = cx().d_partials;
     if (direct) {            // sums straight to the host (host-mapped buffer + flag), no reduction kernel, no copy
         a.racc = cx().d_racc;
@@ -578,7 +580,7 @@ int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t m
         a.seq = ++cx().seq;
     }
     const int grid = grid_for(mid, kPartialBlocks);
-    hipLaunchKernelGGL((k_partial_eval<GATE, ARITY, NEV>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+    hipLaunchKernelGGL((k_partial_eval<POWER, ARITY, NEV>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
     *nblocks = grid;
     return 0;
 }

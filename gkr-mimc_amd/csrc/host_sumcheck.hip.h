@@ -8,6 +8,43 @@ void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
     else hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
 }
 
+// ---- hand-off of a fused round's sums ---------------------------------------------------------------------------
+// Un-sharded, or sharded over the host shared-memory transport: the kernel writes its sums and tail words into the
+// lane's host-mapped buffer and raises the lane's flag; with shared memory the ranks then add the sums on the host
+// (576 bytes per round: no extra kernel has to queue behind the big rounds).  Sharded over RCCL: the sums stay on
+// the device for ncclAllReduce, the kernel's own completion flag lands in a spare word of the exchange buffer, and
+// the reduced words reach the host through coll_publish.
+struct RoundTargets {
+    unsigned long long* out;
+    unsigned int* flag;
+    bool on_device;
+};
+inline RoundTargets round_targets(bool collective) {
+    RoundTargets t;
+    t.on_device = collective && cx().lc.comm;
+    t.out = t.on_device ? cx().lc.d_buf : cx().d_round;
+    t.flag = t.on_device ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
+    return t;
+}
+// Wait for round `seq`; on return *sums points at nsum words summed over the ranks (scratch: `summed`, nsum words) and
+// cx().h_round + nsum holds this rank's ntail tail words.
+int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int nsum, int ntail, unsigned long long* summed,
+                  const unsigned long long** sums) {
+    *sums = cx().h_round;
+    if (t.on_device) {
+        CHK(coll_allreduce(cx().lc.d_buf, nsum));     // exact integer sum of limb-split lanes; the tail words are rank-local
+        CHK(coll_publish(nsum + ntail, seq));
+        return wait_flag(seq, nullptr, coll_timeout_ms());
+    }
+    CHK(wait_flag(seq));
+    if (collective && cx().lc.shm) {
+        memcpy(summed, cx().h_round, sizeof(unsigned long long) * nsum);
+        CHK(shm_allreduce_host(summed, nsum));
+        *sums = summed;
+    }
+    return 0;
+}
+
 // The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
 // q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
 // monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
@@ -103,13 +140,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.ark = to_dev(ark);
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;
-        // Sharded over RCCL: the sums stay on the device for the all-reduce and the kernel's own completion flag lands
-        // in a spare word of the exchange buffer (the host is signalled after the all-reduce).  Sharded over the host
-        // shared-memory transport: the kernel hands its local sums to the host as in the un-sharded case and the
-        // ranks add them on the host (576 bytes per round: no extra kernel has to queue behind the big rounds).
-        const bool on_device = collective && cx().lc.comm;
-        a.host_out = on_device ? cx().lc.d_buf : cx().d_round;
-        a.host_flag = on_device ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
+        const RoundTargets tg = round_targets(collective);
+        a.host_out = tg.out;
+        a.host_flag = tg.flag;
         a.seq = ++cx().seq;
         const bool derive_m0 = claim && *claim_known;
         a.need_m0 = derive_m0 ? 0u : 1u;
@@ -151,20 +184,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
         unsigned long long summed[GKR_CR_WORDS];
-        if (on_device) {
-            // sums: all-reduce over ranks (exact integer sum of limb-split lanes); the tail words are rank-local.
-            // The reduced words reach the host like the un-sharded ones (host-mapped buffer + flag the host polls)
-            CHK(coll_allreduce(cx().lc.d_buf, GKR_CR_WORDS));
-            CHK(coll_publish(GKR_CR_WORDS + 16, a.seq));
-            CHK(wait_flag(a.seq, nullptr, coll_timeout_ms()));
-        } else {
-            CHK(wait_flag(a.seq));
-            if (collective && cx().lc.shm) {
-                memcpy(summed, cx().h_round, sizeof summed);
-                CHK(shm_allreduce_host(summed, GKR_CR_WORDS));
-            }
-        }
-        const unsigned long long* sums = (collective && !on_device && cx().lc.shm) ? summed : words;
+        const unsigned long long* sums = nullptr;
+        CHK(round_collect(collective, tg, a.seq, GKR_CR_WORDS, 16, summed, &sums));
         const double t_w = now_ms();
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
@@ -274,17 +295,21 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
 }
 
 // ---- single-point sumcheck of a linear gate: one fused launch per round (linear_round.hip.h) ------------------
-// Tables X[0..arity) of 2^m entries (m >= 1), coordinates q[0:m].  On return: c has absorbed eq(q_k, r_k) of every
-// round, proof/chal hold m rounds of 3 coefficients, finals[t] = X_t folded on every challenge.
-int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* const* X, const E* q, E& c, E* proof, E* chal,
-                  E* finals, E* claim /* running claim, or nullptr */, bool* claim_known) {
+// Tables X[0..arity) of 2^m entries (m >= 1), coordinates q[0:m]; g.mask selects the tables that enter the gate's sum.
+// `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the two sums are added over the
+// ranks before the host reads them.  On return: c has absorbed eq(q_k, r_k) of every round, proof/chal hold m rounds
+// of 3 coefficients, tail[2t], tail[2t+1] = the two remaining entries of table t and r_last the last challenge (the
+// caller applies the final fold).
+int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const* X, const E* q, const E& seed, bool collective,
+                  E& c, E* proof, E* chal, E* tail, E& r_last, E* claim /* running claim, or nullptr */, bool* claim_known) {
     const size_t n = (size_t)1 << m;
+    const int arity = g.n_in;
     // HBM-bound rounds with a few dozen registers per lane: many more lanes than the compute-bound cipher rounds
     const int g_lin = std::max(cx().g_max, cx().g_lin);
     const int gT = std::min(g_lin, m - 1);
     const int mU = m - 1 - gT;
     CHK(stage_coords(q, (size_t)m));
-    ScopedTable pyrT, pyrU, scratch[2];
+    ScopedTable pyrT, pyrU, scratch[GKR_MAX_ARITY];
     CHK(table_alloc(&pyrT, (size_t)2 << gT));
     CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
     for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
@@ -295,7 +320,7 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
     pa3.p[0].q = cx().d_q;
     pa3.p[0].nc = m;
     pa3.p[0].max_level = gT;
-    pa3.p[0].seed = to_dev(hfr::ONE);
+    pa3.p[0].seed = to_dev(seed);
     if (mU > 0) {
         pa3.p[1].out = pyrU.planes();
         pa3.p[1].q = cx().d_q;
@@ -311,6 +336,7 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     }
     cx().racc_dirty = true;
+    if (collective) CHK(coll_buffers(256));
     const E two128 = {{0, 0, 1, 0}};
     E r_prev = hfr::ZERO;
     for (int k = 0; k < m; k++) {
@@ -334,13 +360,14 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
         a.lg_threads = (unsigned)gk;
         a.r = to_dev(r_prev);
         a.r_lo = to_dev(hfr::mul(r_prev, two128));
-        a.ark = to_dev(gate == GKRHIP_GATE_ADD ? ark : hfr::ZERO);
+        a.ark = to_dev(ark);
         a.arity = arity;
-        a.gate_inputs = gate == GKRHIP_GATE_ADD ? 2 : 1;
+        a.sum_mask = g.mask;
         a.racc = cx().d_racc;
         a.counter = cx().d_counter;
-        a.host_out = cx().d_round;
-        a.host_flag = cx().d_flag;
+        const RoundTargets tg = round_targets(collective);
+        a.host_out = tg.out;
+        a.host_flag = tg.flag;
         a.seq = ++cx().seq;
         const bool derive_m0 = claim && *claim_known;
         a.need_m0 = derive_m0 ? 0u : 1u;
@@ -353,11 +380,12 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
             else hipLaunchKernelGGL((k_linear_round<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
         }
         HIPCHK(hipGetLastError());
-        CHK(wait_flag(a.seq));
-        const unsigned long long* words = cx().h_round;
+        unsigned long long summed[GKR_LR_WORDS];
+        const unsigned long long* sums = nullptr;
+        CHK(round_collect(collective, tg, a.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
         // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
-        const E cm1 = hfr::mul(c, limbs9_to_fr(words + GKR_ACC_WORDS));
-        const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, limbs9_to_fr(words));
+        const E cm1 = hfr::mul(c, limbs9_to_fr(sums + GKR_ACC_WORDS));
+        const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, limbs9_to_fr(sums));
         const E a0 = hfr::sub(hfr::ONE, q[k]);
         const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
         E* co = proof + (size_t)k * 3;
@@ -372,16 +400,10 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
             *claim = hfr::eval_univariate(co, 3, r);
             *claim_known = true;
         }
-        if (k == m - 1) {
-            for (int t = 0; t < arity; t++) {
-                E lo, hi;
-                memcpy(&lo, words + GKR_LR_WORDS + 8 * t, sizeof(E));
-                memcpy(&hi, words + GKR_LR_WORDS + 8 * t + 4, sizeof(E));
-                finals[t] = fold2(lo, hi, r);
-            }
-        }
+        if (k == m - 1) memcpy(tail, cx().h_round + GKR_LR_WORDS, (size_t)2 * arity * sizeof(E));   // written by the P == 1 launch
         cx().prof.rounds++;
     }
+    r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
     cx().racc_dirty = false;
     table_release(&pyrT);
@@ -390,15 +412,53 @@ int linear_rounds(int gate, const E& ark, int arity, int m, const DevTable* cons
     return 0;
 }
 
-int gate_degree(int gate) { return gate == GKRHIP_GATE_CIPHER ? 7 : 1; }   // cipher.go:68-70; copy.go:30-32; add: linear
+// sumcheck.Prove for a linear gate with one evaluation point; same two phases as sumcheck_cipher_fast (the local rounds
+// of this rank's shard with the sums added over the ranks, then, when sharded, the gathered per-rank entries and the
+// last gamma rounds on every rank).  No Eq table is built or folded.
+int sumcheck_linear_fast(const GateDesc& g, const E& ark, int bN, const DevTable* const* X, const E* q, E* proof, E* challenges,
+                         E* final_claims, const E* trusted_claim, bool track_claim) {
+    const ShardView shard = shard_view();
+    const int gamma = shard.gamma, m1 = bN - gamma, arity = g.n_in;
+    if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
+    E c = hfr::ONE, tail[2 * GKR_MAX_ARITY], r_last, v[GKR_MAX_ARITY];
+    E claim = trusted_claim ? *trusted_claim : hfr::ZERO;
+    bool claim_known = trusted_claim != nullptr;
+    E* claim_p = track_claim ? &claim : nullptr;
+    if (m1 >= 1) {
+        const E seed = gamma ? shard_seed(q + m1, gamma, shard.rank) : hfr::ONE;
+        CHK(linear_rounds(g, ark, m1, X, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last, claim_p,
+                          &claim_known));
+        for (int t = 0; t < arity; t++) v[t] = fold2(tail[2 * t], tail[2 * t + 1], r_last);
+    } else {
+        CHK(gather0(X, arity, v));
+    }
+    if (gamma > 0) {
+        std::vector<E> all;
+        CHK(coll_allgather(v, arity, all));
+        ScopedTable x2[GKR_MAX_ARITY];
+        const DevTable* X2[GKR_MAX_ARITY];
+        for (int t = 0; t < arity; t++) {
+            std::vector<E> col(shard.world);
+            for (int r = 0; r < shard.world; r++) col[r] = all[(size_t)r * arity + t];
+            CHK(small_table(&x2[t], col));
+            X2[t] = &x2[t];
+        }
+        CHK(linear_rounds(g, ark, gamma, X2, q + m1, hfr::ONE, false, c, proof + (size_t)3 * m1, challenges + m1, tail, r_last,
+                          claim_p, &claim_known));
+        for (int t = 0; t < arity; t++) v[t] = fold2(tail[2 * t], tail[2 * t + 1], r_last);
+    }
+    final_claims[0] = c;
+    for (int t = 0; t < arity; t++) final_claims[1 + t] = v[t];
+    return 0;
+}
 
 // The reference-shaped rounds (sumcheck/prover.go:70-76) over an Eq table and `arity` tables of 2^m entries:
 // partial evaluation at t = 0..deg+1, interpolation, Fiat-Shamir, fold.  eq is folded in place, X is
 // read-only (round 0 folds into scratch).  On return `last` = [Eq[0], X_1[0], ...] of this rank.
-int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const DevTable* const* X, bool collective,
+int generic_rounds(const GateDesc& g, const E& ark, int m, DevTable* eq, const DevTable* const* X, bool collective,
                    E* proof, E* chal, E* last) {
     const size_t n = (size_t)1 << m;
-    const int nev = gate_degree(gate) + 2;
+    const int nev = g.power + 2, arity = g.n_in;
     if (cx().racc_dirty) {   // see cipher_rounds
         HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
@@ -411,7 +471,7 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
     for (int k = 0; k < m; k++) {
         const size_t mid = n >> (k + 1);
         E evals[GKR_MAX_EVALS];
-        CHK(partial_evals(gate, arity, eq, cur, mid, ark, evals, nev, collective));
+        CHK(partial_evals(g, eq, cur, mid, ark, evals, nev, collective));
         E* coeffs = proof + (size_t)k * nev;
         cx().lag->interpolate(coeffs, evals, nev);
         const E r = hfr::mimc_hash(coeffs, (size_t)nev);
@@ -442,16 +502,18 @@ int generic_rounds(int gate, const E& ark, int arity, int m, DevTable* eq, const
 // sumcheck's output).  The single-point cipher path then derives one monomial sum per round from the running
 // claim instead of computing it.  Entry points that take claims from outside never set it: for them the
 // output must be the reference's whatever the claims are (they only feed Fiat-Shamir there).
-int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
+int sumcheck_prove_dev(int gate, const E& ark_in, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
                        const E* claims, int nclaims, E* proof, E* challenges, E* final_claims, bool trust_claims = false) {
-    if (arity < 1 || arity > 2) return fail("arity %d not supported (1..2)", arity);
+    GateDesc g;
+    CHK(gate_resolve(gate, arity, &g));
+    const E ark = gate == GKRHIP_GATE_IDENTITY ? hfr::ZERO : ark_in;   // IdentityGate has no Ark
     if (nq < 1) return fail("need at least one evaluation point");
     if (nclaims != nq && nq > 1)  // sumcheck/prover.go:113-115
         return fail("provided a multi-instance %d but the number of claims does not match %d", nq, nclaims);
     const ShardView shard = shard_view();
     const int gamma = shard.gamma, m1 = bN - gamma;
     if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
-    const int nev = gate_degree(gate) + 2;
+    const int nev = g.power + 2;
 
     // ---- makeEqTable (prover.go:102-144)
     std::vector<E> seeds(nq, hfr::ONE);
@@ -465,21 +527,14 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
         }
         nq_used = nq;
     }
-    if (gate == GKRHIP_GATE_CIPHER && arity == 2 && nq_used == 1 && bN >= 1 && !cx().force_generic)
-        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims,
-                                    (trust_claims && nclaims == 1) ? &claims[0] : nullptr, trust_claims && cx().claim_trick);
-
-    // single-point linear layers (identity, add) of an un-sharded prover: fused rounds, no Eq table
-    if ((gate == GKRHIP_GATE_IDENTITY || (gate == GKRHIP_GATE_ADD && arity == 2)) && nq_used == 1 && bN >= 1 && gamma == 0 &&
-        !cx().force_generic && !cx().force_collective) {
-        E c = hfr::ONE;
-        E claim = (trust_claims && nclaims == 1) ? claims[0] : hfr::ZERO;
-        bool claim_known = trust_claims && nclaims == 1;
-        CHK(linear_rounds(gate, ark, arity, bN, X, qprimes, c, proof, challenges, final_claims + 1,
-                          (trust_claims && cx().claim_trick) ? &claim : nullptr, &claim_known));
-        final_claims[0] = c;
-        return 0;
-    }
+    const E* trusted = (trust_claims && nclaims == 1) ? &claims[0] : nullptr;
+    if (gate_is_cipher2(g) && nq_used == 1 && bN >= 1 && !cx().force_generic)
+        return sumcheck_cipher_fast(ark, bN, X[0], X[1], qprimes, proof, challenges, final_claims, trusted,
+                                    trust_claims && cx().claim_trick);
+    // single-point layers of a linear gate (identity, sums of up to four inputs): fused rounds, no Eq table
+    if (g.power == 1 && nq_used == 1 && bN >= 1 && !cx().force_generic)
+        return sumcheck_linear_fast(g, ark, bN, X, qprimes, proof, challenges, final_claims, trusted,
+                                    trust_claims && cx().claim_trick);
 
     // phase 1: this rank's shard; Eq_local = sum_j seed_j * eq(q_j tail, rank) * eq(q_j[0:m1], .)
     if (gamma > 0)
@@ -488,7 +543,7 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
     CHK(table_alloc(&eq, (size_t)1 << m1));
     CHK(build_eq(&eq, qprimes, nq_used, bN, m1, seeds.data()));
     E last[GKR_MAX_ARITY + 1];
-    CHK(generic_rounds(gate, ark, arity, m1, &eq, X, gamma > 0 || cx().force_collective, proof, challenges, last));
+    CHK(generic_rounds(g, ark, m1, &eq, X, gamma > 0 || cx().force_collective, proof, challenges, last));
     table_release(&eq);
     if (gamma > 0) {
         // phase 2: one entry per table per rank -> tables over the gamma shard bits, same rounds on every rank
@@ -504,7 +559,7 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
             CHK(small_table(&x2[t], cols[1 + t]));
             X2[t] = &x2[t];
         }
-        CHK(generic_rounds(gate, ark, arity, gamma, &eq2, X2, false, proof + (size_t)nev * m1, challenges + m1, last));
+        CHK(generic_rounds(g, ark, gamma, &eq2, X2, false, proof + (size_t)nev * m1, challenges + m1, last));
         table_release(&eq2);
         for (int t = 0; t < arity; t++) table_release(&x2[t]);
     }
@@ -512,23 +567,32 @@ int sumcheck_prove_dev(int gate, const E& ark, int arity, int bN, const DevTable
     return 0;
 }
 
-template <int GATE, int ARITY>
+template <int POWER, int ARITY>
 void launch_gate_eval(const AssignArgs& a) {
-    hipLaunchKernelGGL((k_gate_eval_batch<GATE, ARITY>), dim3(grid_for(a.n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, a);
+    hipLaunchKernelGGL((k_gate_eval_batch<POWER, ARITY>), dim3(grid_for(a.n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, a);
 }
 int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, const DevTable* out, size_t n) {
+    GateDesc g;
+    CHK(gate_resolve(gate, arity, &g));
     AssignArgs a;
     memset(&a, 0, sizeof a);
     for (int k = 0; k < arity; k++) a.in[k] = in[k]->cplanes();
     a.out = out->planes();
     a.arity = arity;
+    a.mask = g.mask;
     a.n = n;
-    a.ark = to_dev(ark);
-    if (gate == GKRHIP_GATE_CIPHER && arity == 2) launch_gate_eval<GKR_GATE_CIPHER, 2>(a);
-    else if (gate == GKRHIP_GATE_IDENTITY && arity == 1) launch_gate_eval<GKR_GATE_IDENTITY, 1>(a);
-    else if (gate == GKRHIP_GATE_IDENTITY && arity == 2) launch_gate_eval<GKR_GATE_IDENTITY, 2>(a);
-    else if (gate == GKRHIP_GATE_ADD && arity == 2) launch_gate_eval<GKR_GATE_ADD, 2>(a);
-    else return fail("unsupported gate/arity combination (gate %d, arity %d)", gate, arity);
+    a.ark = to_dev(gate == GKRHIP_GATE_IDENTITY ? hfr::ZERO : ark);
+    switch (g.power * 10 + g.n_in) {
+        case 11: launch_gate_eval<1, 1>(a); break;
+        case 12: launch_gate_eval<1, 2>(a); break;
+        case 13: launch_gate_eval<1, 3>(a); break;
+        case 14: launch_gate_eval<1, 4>(a); break;
+        case 71: launch_gate_eval<7, 1>(a); break;
+        case 72: launch_gate_eval<7, 2>(a); break;
+        case 73: launch_gate_eval<7, 3>(a); break;
+        case 74: launch_gate_eval<7, 4>(a); break;
+        default: return fail("unsupported gate shape (power %d, %d inputs)", g.power, g.n_in);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

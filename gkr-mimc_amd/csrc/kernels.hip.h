@@ -18,7 +18,6 @@
 #define GKR_MAX_EVALS 9   // cipher gate: degree 8 -> 9 evaluation points (sumcheck/prover.go:95, algo.go:57)
 #define GKR_ACC_WORDS 9   // un-reduced 288-bit lane accumulators
 
-enum { GKR_GATE_IDENTITY = 0, GKR_GATE_CIPHER = 1, GKR_GATE_ADD = 2 };
 
 struct Planes {
     uint4* lo;
@@ -189,35 +188,37 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_eq_expand(EqExpandArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gates (circuit/gates/cipher.go:25-55, circuit/gates/copy.go:15-22)
+// gates (circuit/gates.go:9-21; circuit/gates/cipher.go:25-55, circuit/gates/copy.go:15-22): the descriptor family
+//     Eval(xs...) = (sum of the inputs selected by mask + Ark)^POWER,   POWER = 1 or 7
+// (identity: mask 1, Ark 0, POWER 1; cipher: (xs[0] + xs[1] + Ark)^7).  POWER and ARITY are compile-time (they fix
+// the instruction stream and the register footprint), the mask is a launch-wide runtime value.
 // ------------------------------------------------------------------------------------------------
-template <int GATE>
-__device__ __forceinline__ Fr gate_eval(const Fr* x, const Fr& ark) {
-    if (GATE == GKR_GATE_CIPHER) {
-        return fr_pow7(fr_add(fr_add(x[1], ark), x[0]));
-    } else if (GATE == GKR_GATE_ADD) {
-        return fr_add(fr_add(x[0], x[1]), ark);   // build-defined linear gate (GMiMC's non-S-box branches)
-    } else {
-        return x[0];
-    }
+template <int POWER, int ARITY>
+__device__ __forceinline__ Fr gate_eval(const Fr* x, const Fr& ark, unsigned mask) {
+    Fr s = ark;
+#pragma unroll
+    for (int k = 0; k < ARITY; k++)
+        if ((mask >> k) & 1u) s = fr_add(s, x[k]);
+    return POWER == 7 ? fr_pow7(s) : s;
 }
 
-// layer assignment: out = Gate(in0, in1)   (circuit/circuit.go:48-64 -> Gate.EvalBatch)
+// layer assignment: out = Gate(in0, in1, ...)   (circuit/circuit.go:48-64 -> Gate.EvalBatch)
 struct AssignArgs {
     CPlanes in[GKR_MAX_ARITY];
     Planes out;
     int arity;
+    unsigned mask;
     size_t n;
     Fr ark;
 };
-template <int GATE, int ARITY>
+template <int POWER, int ARITY>
 __global__ void __launch_bounds__(GKR_BLOCK) k_gate_eval_batch(AssignArgs a) {
     const Fr ark = a.ark;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         Fr x[ARITY];
 #pragma unroll
         for (int k = 0; k < ARITY; k++) x[k] = ld_fr(a.in[k].lo, a.in[k].hi, i);
-        st_fr(a.out.lo, a.out.hi, i, gate_eval<GATE>(x, ark));
+        st_fr(a.out.lo, a.out.hi, i, gate_eval<POWER, ARITY>(x, ark, a.mask));
     }
 }
 
@@ -332,6 +333,7 @@ struct PartialEvalArgs {
     CPlanes x[GKR_MAX_ARITY];
     size_t mid;
     Fr ark;
+    unsigned mask;                 // inputs that enter the gate's sum
     unsigned long long* partials;  // [gridDim.x][NEV][9]   (host_flag == nullptr: separate reduction kernel)
     // host_flag != nullptr: the sums go straight to the host, as the fused round kernels hand theirs over
     unsigned long long* racc;      // NEV*9-word accumulator shared by the blocks
@@ -341,7 +343,7 @@ struct PartialEvalArgs {
     unsigned int seq;
 };
 
-template <int GATE, int ARITY, int NEV>
+template <int POWER, int ARITY, int NEV>
 __global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a) {
     Acc9 acc[NEV];
 #pragma unroll
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a
         // compile-time constant (registers, not scratch).  After NEV iterations they are back in place.
 #pragma unroll 1
         for (int t = 0; t < NEV; t++) {
-            acc_add(acc[0], fr_mul(e, gate_eval<GATE>(x, ark)));
+            acc_add(acc[0], fr_mul(e, gate_eval<POWER, ARITY>(x, ark, a.mask)));
             const Acc9 first = acc[0];
 #pragma unroll
             for (int u = 0; u + 1 < NEV; u++) acc[u] = acc[u + 1];

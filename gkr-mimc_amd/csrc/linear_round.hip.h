@@ -1,5 +1,6 @@
-// linear_round.hip.h -- the single-point sumcheck round of a LINEAR gate (identity: xs[0], circuit/gates/copy.go:15-22;
-// the build-defined add gate xs[0]+xs[1]+Ark of the GMiMC circuit), one launch per round: fold(r_{k-1}) of the
+// linear_round.hip.h -- the single-point sumcheck round of a LINEAR gate (power-1 descriptors of the gate table:
+// identity xs[0], circuit/gates/copy.go:15-22; sums of up to four inputs plus Ark, e.g. the add gate of the GMiMC
+// circuits), one launch per round: fold(r_{k-1}) of the
 // layer's tables + the round's sums + hand-off to the host, replacing the reference's dispatchPartialEvals /
 // dispatchFolding pair (sumcheck/prover.go:70-76,148-190) and its folded Eq table for these layers.
 //
@@ -16,15 +17,15 @@
 #define GKR_LR_WORDS (GKR_LR_NSUM * GKR_ACC_WORDS)
 
 struct LinearRoundArgs {
-    CPlanes src[2];        // FOLD: previous round's tables (4P elements); else this round's (2P)
-    Planes dst[2];         // FOLD: folded tables (2P elements)
+    CPlanes src[GKR_MAX_ARITY];   // FOLD: previous round's tables (4P elements); else this round's (2P)
+    Planes dst[GKR_MAX_ARITY];    // FOLD: folded tables (2P elements)
     CPlanes wt, wj;        // eq weights: per lane (2^g entries), per iteration (P >> g entries, HAS_WJ only)
     size_t P;
     unsigned lg_threads;
     Fr r, r_lo;            // previous round's challenge and its image r * 2^-128 (fr_mul_const2_raw)
     Fr ark;                // added once per pair to u (zero for the identity gate)
     int arity;             // tables folded and handed over
-    int gate_inputs;       // leading tables that enter the gate's sum (identity: 1, add: 2)
+    unsigned sum_mask;     // tables that enter the gate's sum (identity: 1; add: 3)
     unsigned long long* racc;
     unsigned int* counter;
     unsigned long long* host_out;   // GKR_LR_WORDS sums, then arity x (lo, hi) tail elements of 4 u64 in the last round
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
                     lo = ld_fr(a.src[t].lo, a.src[t].hi, x);
                     hi = ld_fr(a.src[t].lo, a.src[t].hi, x + P);
                 }
-                if (t < a.gate_inputs) {
+                if ((a.sum_mask >> t) & 1u) {
                     u = fr_add(u, lo);
                     d = fr_add(d, fr_sub(hi, lo));
                 }

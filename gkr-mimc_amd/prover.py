@@ -57,6 +57,10 @@ ABI = {
     "gkrhip_session_proof_len": (_SZ, [_P]),
     "gkrhip_session_num_inputs": (_I, [_P]),
     "gkrhip_gmimc_t2_circuit": (_I, [_P, _I]),
+    "gkrhip_gmimc_circuit": (_I, [_I, _P, _I, _P]),
+    "gkrhip_gate_register": (_I, [_P, C.POINTER(_I)]),
+    "gkrhip_gate_lookup": (_I, [_I, _P]),
+    "gkrhip_gkr_verify": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "gkrhip_gkr_verify_mimc": (_I, [_I, _P, _P, _P, _P, _P]),
     "gkrhip_mimc_session_verify": (_I, [_P, _P, _P]),
     "gkrhip_to_regular": (_I, [_P, _SZ]),
@@ -187,7 +191,9 @@ def gate_eval_batch(gate, ark, xs):
 
 
 def gate_degree(gate):
-    return 7 if gate == GATE_CIPHER else 1
+    if gate in (GATE_IDENTITY, GATE_ADD):
+        return 1
+    return 7 if gate == GATE_CIPHER else gate_lookup(gate)["power"]
 
 
 def sumcheck_prove(X, q_primes, claims, gate, ark=None):
@@ -262,8 +268,45 @@ def mimc_permutation_batch(x, key):
     return out
 
 
+MAX_GATE_INPUTS = 4
+
+
 class LayerDesc(C.Structure):
-    _fields_ = [("gate", C.c_int), ("n_in", C.c_int), ("in_", C.c_int * 2), ("ark", C.c_uint64 * 4)]
+    _fields_ = [("gate", C.c_int), ("n_in", C.c_int), ("in_", C.c_int * MAX_GATE_INPUTS), ("ark", C.c_uint64 * 4)]
+
+
+class GateDesc(C.Structure):
+    _fields_ = [("id", C.c_char * 32), ("n_in", C.c_int), ("sum_mask", C.c_uint), ("power", C.c_int)]
+
+
+def gate_register(gate_id, n_in, sum_mask, power):
+    """Add a gate of the family (sum of the inputs selected by sum_mask + Ark)^power, power 1 or 7, to the library's
+    gate table (the native circuit.Gate plug point); returns its gate id."""
+    d = GateDesc(gate_id.encode(), n_in, sum_mask, power)
+    out = C.c_int(-1)
+    _check(load().gkrhip_gate_register(C.byref(d), C.byref(out)))
+    return out.value
+
+
+def gate_lookup(gate):
+    d = GateDesc()
+    _check(load().gkrhip_gate_lookup(gate, C.byref(d)))
+    return {"id": d.id.decode(), "n_in": d.n_in, "sum_mask": d.sum_mask, "power": d.power}
+
+
+def _layers_to_list(arr):
+    return [(l.gate, [l.in_[k] for k in range(l.n_in)], [int(v) for v in l.ark]) for l in arr]
+
+
+def _layers_from_list(layers):
+    arr = (LayerDesc * len(layers))()
+    for i, (gate, ins, ark) in enumerate(layers):
+        arr[i].gate, arr[i].n_in = gate, len(ins)
+        for k, v in enumerate(ins):
+            arr[i].in_[k] = v
+        for k in range(4):
+            arr[i].ark[k] = 0 if ark is None else int(ark[k])
+    return arr
 
 
 def gmimc_t2_circuit():
@@ -271,7 +314,36 @@ def gmimc_t2_circuit():
     n = load().gkrhip_gmimc_t2_circuit(None, 0)
     arr = (LayerDesc * n)()
     assert load().gkrhip_gmimc_t2_circuit(C.cast(arr, C.c_void_p), n) == n
-    return [(l.gate, [l.in_[k] for k in range(l.n_in)], [int(v) for v in l.ark]) for l in arr]
+    return _layers_to_list(arr)
+
+
+def gmimc_circuit(t):
+    """GMiMC compression circuit for t = 2, 4, 8: (layers, input_map); input layer k is state[j] when
+    input_map[k] = j < t and block[j - t] otherwise."""
+    n = load().gkrhip_gmimc_circuit(t, None, 0, None)
+    if n < 0:
+        _check(n)
+    arr = (LayerDesc * n)()
+    imap = (C.c_int * (2 * t))(*([-1] * (2 * t)))
+    assert load().gkrhip_gmimc_circuit(t, C.cast(arr, C.c_void_p), n, C.cast(imap, C.c_void_p)) == n
+    layers = _layers_to_list(arr)
+    n_in = sum(1 for l in layers if l[0] < 0)
+    return layers, [imap[k] for k in range(n_in)]
+
+
+def gkr_verify(layers, flat, inputs, outputs, q_prime):
+    """gkr.Verify for any circuit of library gates on host tables: True if accepted, False if rejected."""
+    arr = _layers_from_list(layers)
+    inputs = [_fr(x) for x in inputs]
+    outputs, flat = _fr(outputs), _fr(flat)
+    bN = outputs.shape[0].bit_length() - 1
+    q_prime = _fr(q_prime).reshape(-1, 4)
+    ptrs = (C.c_void_p * len(inputs))(*[x.ctypes.data for x in inputs])
+    rc = load().gkrhip_gkr_verify(C.cast(arr, C.c_void_p), len(layers), bN, _ptr(flat), ptrs, len(inputs), _ptr(outputs),
+                                  _ptr(q_prime) if bN else None)
+    if rc < 0:
+        _check(rc)
+    return rc == 0
 
 
 class MimcSession:
@@ -288,13 +360,7 @@ class MimcSession:
         if layers is None:
             _check(load().gkrhip_mimc_session_create(C.byref(self._h), bN))
         else:
-            arr = (LayerDesc * len(layers))()
-            for i, (gate, ins, ark) in enumerate(layers):
-                arr[i].gate, arr[i].n_in = gate, len(ins)
-                for k, v in enumerate(ins):
-                    arr[i].in_[k] = v
-                for k in range(4):
-                    arr[i].ark[k] = 0 if ark is None else int(ark[k])
+            arr = _layers_from_list(layers)
             _check(load().gkrhip_session_create(C.byref(self._h), C.cast(arr, C.c_void_p), len(layers), bN))
         self.proof_len = load().gkrhip_session_proof_len(self._h)
         self.num_inputs = load().gkrhip_session_num_inputs(self._h)

@@ -31,6 +31,27 @@ extern "C" {
 #define GKRHIP_GATE_CIPHER 1   /* circuit/gates/cipher.go:11-70: (xs[0]+xs[1]+Ark)^7, Degree 7 */
 #define GKRHIP_GATE_ADD 2      /* build-defined (no such circuit.Gate in the reference): xs[0]+xs[1]+Ark, Degree 1;
                                 * the non-S-box branches of a GMiMC round (hash/gmimc.go:52-58) */
+#define GKRHIP_MAX_GATE_INPUTS 4
+
+/* ---- circuit.Gate plug point (circuit/gates.go:9-21) ----------------------------------------------------------
+ * The reference's Gate is an interface with variadic inputs (arity = len(Layer.In)) implemented in Go.  Its native
+ * counterpart is a table of gate DESCRIPTORS that the kernels interpret -- no recompilation for a new gate of the
+ * family
+ *     Eval(xs...) = (sum of the inputs selected by sum_mask + Ark)^power,   power = 1 or 7,  1..4 inputs,
+ * with Degree() = power and the layer's Ark supplied per layer (circuit.Layer carries the gate instance; here
+ * gkrhip_layer carries the Ark).  The three built-in ids above are entries 0..2 of the same table
+ * (identity: sum_mask 1, power 1; cipher: two inputs, power 7; add: two inputs, power 1).  A gate outside the
+ * family (e.g. a product of inputs) needs a kernel of its own: gkrhip_gate_register refuses it. */
+typedef struct {
+    char id[32];             /* Gate.ID() (circuit/gates.go:11): unique name */
+    int n_in;                /* number of inputs, 1..GKRHIP_MAX_GATE_INPUTS */
+    unsigned int sum_mask;   /* bit k set: input k enters the sum (IdentityGate over [L, R] returns xs[0]: mask 1) */
+    int power;               /* 1 or 7 */
+} gkrhip_gate_desc;
+/* Adds a descriptor and returns its gate id in *gate_id (>= 3); registering an identical descriptor again returns
+ * the same id.  Thread-safe. */
+int gkrhip_gate_register(const gkrhip_gate_desc *desc, int *gate_id);
+int gkrhip_gate_lookup(int gate_id, gkrhip_gate_desc *desc_out);   /* 0 if gate_id is registered */
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
 int gkrhip_init(int device_ordinal);      /* idempotent; selects the GPU, creates the stream/arena */
@@ -62,7 +83,9 @@ int gkrhip_gate_eval_batch(int gate, const uint64_t *ark_or_null, uint64_t *res,
                            int arity, size_t n);
 
 /* ---- sumcheck.Prove (sumcheck/prover.go:46-90) ------------------------------------------------ */
-/* X[k], k < arity: tables of 2^bN elements (NOT modified; the reference consumes them).
+/* gate: a GKRHIP_GATE_* or registered id; arity must be the gate's number of inputs (IDENTITY also takes two
+ * tables and returns xs[0], as the reference's multi-instance tests do, sumcheck/testing.go:28-57).
+ * X[k], k < arity: tables of 2^bN elements (NOT modified; the reference consumes them).
  * qprimes: nq*bN elements; claims: nclaims elements (may be 0: top GKR layer).
  * proof: bN*(Degree+2) coefficients, round-major, low->high (poly.InterpolateOnRange order);
  * challenges: bN; final_claims: arity+1 = [Eq[0], X_1[0], ...] after the last fold. */
@@ -104,19 +127,30 @@ void gkrhip_mimc_session_destroy(gkrhip_mimc_session *s);
  * exactly two input layers; synth_inputs fills every input layer); the flat proof is in GkrProofToVec order
  * for that circuit and has gkrhip_session_proof_len elements. */
 typedef struct {
-    int gate;          /* -1 input layer, else GKRHIP_GATE_* */
-    int n_in;          /* 0 for inputs, 1 for IDENTITY, 2 for CIPHER / ADD */
-    int in[2];
+    int gate;          /* -1 input layer, else GKRHIP_GATE_* or an id returned by gkrhip_gate_register */
+    int n_in;          /* 0 for inputs, else the gate's number of inputs (len(Layer.In)) */
+    int in[GKRHIP_MAX_GATE_INPUTS];
     uint64_t ark[4];   /* Montgomery limbs; ignored for IDENTITY and inputs */
 } gkrhip_layer;
 int gkrhip_session_create(gkrhip_session **out, const gkrhip_layer *layers, int n_layers, int bN);
 int gkrhip_session_load_input(gkrhip_session *s, int input_index, const uint64_t *table);
 size_t gkrhip_session_proof_len(const gkrhip_session *s);
 int gkrhip_session_num_inputs(const gkrhip_session *s);
+/* gkr.Verify (gkr/verifier.go:15-59) for any such circuit on host tables: inputs[k] = table of input layer k,
+ * outputs = table of the last layer.  0 = accepted, > 0 = rejected, < 0 = error. */
+int gkrhip_gkr_verify(const gkrhip_layer *layers, int n_layers, int bN, const uint64_t *flat, const uint64_t *const *inputs,
+                      int n_inputs, const uint64_t *outputs, const uint64_t *qprime);
 /* The build-defined circuit of one GMiMC (t = 2) compression, out = GMimcT2.UpdateInplace([s0,s1],[b0,b1])[0]
  * (hash/gmimc.go:52-65; BASELINE config 5): input layers 0..3 = s0, s1, b0, b1.  Returns the number of
  * layers (100); fills layers_out when it is not NULL. */
 int gkrhip_gmimc_t2_circuit(gkrhip_layer *layers_out, int capacity);
+/* The same for t = 2, 4 or 8 (hash/gmimc.go:16-20): output = UpdateInplace(state, block)[0].  A round is an add layer per
+ * linear branch and a cipher layer for the S-box branch; the feed-forward state'[0] + state[0] + block[0] is ONE layer of
+ * the registered three-input gate "sum3" (sum_mask 7, power 1).  The reference's round never mixes the branches, so
+ * state'[0] depends on one initial branch (91 mod t) besides the feed-forward operands: the input layers are exactly
+ * the operands that matter and input_map_out (2t ints, may be NULL) names them -- input layer k is state[j] when
+ * input_map_out[k] = j < t, block[j - t] otherwise.  Returns the number of layers. */
+int gkrhip_gmimc_circuit(int t, gkrhip_layer *layers_out, int capacity, int *input_map_out);
 
 /* ---- gkr.Verify (gkr/verifier.go:15-132): native verifier; MultiLin.Evaluate of the output and input tables
  * runs on the device, the rest is scalar host work.  Returns 0 = accepted, > 0 = rejected (code in

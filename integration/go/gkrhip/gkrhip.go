@@ -1,0 +1,280 @@
+//go:build gkrhip
+
+// Package gkrhip is the one cgo package of the MI355X back end: Go-typed wrappers over include/gkrhip.h
+// (libgkrhip.so).  Every []fr.Element is passed as unsafe.Pointer(&s[0]): gnark-crypto's fr.Element is
+// [4]uint64 little-endian Montgomery limbs, canonical, which is exactly the memory image the library reads and
+// writes.  Non-zero return codes become panics carrying gkrhip_last_error(), as the reference's prover side
+// panics (sumcheck/prover.go:54,114; gkr/prover.go:84).
+//
+// STATUS: shipped as source.  The image this library is developed in has no Go toolchain, so this file has not
+// been compiled; the same entry points, with the same argument meaning, are exercised from compiled C++
+// (tests/cpp/test_abi_gkr.cpp) and from Python ctypes (gkr-mimc_amd/prover.py).
+//
+// It imports nothing of gkr-mimc (poly imports this package; circuit imports poly), so the mapping of a
+// circuit.Gate to a library gate lives in the sumcheck shim.
+package gkrhip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../gkr-mimc_amd -lgkrhip -Wl,-rpath,${SRCDIR}/../../../gkr-mimc_amd
+#include <stdlib.h>
+#include "gkrhip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"runtime"
+	"unsafe"
+
+	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
+)
+
+// Library gate ids (include/gkrhip.h).  Further gates come from RegisterGate.
+const (
+	GateIdentity = int(C.GKRHIP_GATE_IDENTITY)
+	GateCipher   = int(C.GKRHIP_GATE_CIPHER)
+	GateAdd      = int(C.GKRHIP_GATE_ADD)
+)
+
+// MaxGateInputs is the largest len(Layer.In) the library's gate descriptors express.
+const MaxGateInputs = int(C.GKRHIP_MAX_GATE_INPUTS)
+
+func must(rc C.int) {
+	if rc != 0 {
+		panic("gkrhip: " + C.GoString(C.gkrhip_last_error()))
+	}
+}
+
+// ptr is the address of the first limb of a slice of field elements (nil for an empty slice).
+func ptr(s []fr.Element) *C.uint64_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+}
+
+func ptr1(e *fr.Element) *C.uint64_t {
+	if e == nil {
+		return nil
+	}
+	return (*C.uint64_t)(unsafe.Pointer(e))
+}
+
+// Init selects the GPU (idempotent).  Every other call initialises device 0 on first use.
+func Init(device int) { must(C.gkrhip_init(C.int(device))) }
+
+// Fold is (*poly.MultiLin).Fold's body: in place, the folded table is table[:len/2] (poly/multilin.go:19-36).
+func Fold(table []fr.Element, r *fr.Element) {
+	must(C.gkrhip_fold(ptr(table), C.size_t(len(table)), ptr1(r)))
+}
+
+// Evaluate is poly.MultiLin.Evaluate (poly/multilin.go:59-66); the table is left untouched.
+func Evaluate(table []fr.Element, coordinates []fr.Element) (res fr.Element) {
+	must(C.gkrhip_evaluate(ptr1(&res), ptr(table), C.size_t(len(table)), ptr(coordinates), C.int(len(coordinates))))
+	return
+}
+
+// EqTable is poly.FoldedEqTable (poly/eq.go:41-59): fills out[:1<<len(qPrime)].
+func EqTable(out []fr.Element, qPrime []fr.Element, multiplier *fr.Element) {
+	must(C.gkrhip_eq_table(ptr(out), ptr(qPrime), C.int(len(qPrime)), ptr1(multiplier)))
+}
+
+// GateDesc describes a gate of the family the kernels evaluate:
+//
+//	out = (sum of the inputs selected by SumMask + Ark)^Power,  Power = 1 or 7
+//
+// (IdentityGate: one input, Power 1; CipherGate: two inputs, Power 7).  Ark is per layer, not part of the gate.
+type GateDesc struct {
+	ID      string // circuit.Gate.ID()
+	NIn     int    // len(Layer.In), 1..MaxGateInputs
+	SumMask uint   // bit k set: input k enters the sum
+	Power   int    // 1 or 7
+}
+
+// RegisterGate adds a gate to the library's registry and returns its id (the same descriptor registered twice
+// yields the same id).
+func RegisterGate(d GateDesc) int {
+	var cd C.gkrhip_gate_desc
+	id := C.CString(d.ID)
+	defer C.free(unsafe.Pointer(id))
+	C.strncpy(&cd.id[0], id, C.size_t(len(cd.id)-1))
+	cd.n_in = C.int(d.NIn)
+	cd.sum_mask = C.uint(d.SumMask)
+	cd.power = C.int(d.Power)
+	var out C.int
+	must(C.gkrhip_gate_register(&cd, &out))
+	return int(out)
+}
+
+// GateEvalBatch is circuit.Gate.EvalBatch (circuit/gates.go:16): res[i] = gate(xs[0][i], xs[1][i], ...).
+func GateEvalBatch(gate int, ark *fr.Element, res []fr.Element, xs ...[]fr.Element) {
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	cx := make([]*C.uint64_t, len(xs))
+	for i := range xs {
+		cx[i] = ptr(xs[i])
+		pin.Pin(&xs[i][0])
+	}
+	must(C.gkrhip_gate_eval_batch(C.int(gate), ptr1(ark), ptr(res), (**C.uint64_t)(unsafe.Pointer(&cx[0])), C.int(len(xs)),
+		C.size_t(len(res))))
+}
+
+// SumcheckProve is sumcheck.Prove's body (sumcheck/prover.go:46-90) on host tables.  X is NOT consumed.
+// proof is round-major: proof[k*(degree+2) : (k+1)*(degree+2)] are the coefficients of round k, low to high.
+func SumcheckProve(gate int, degree int, ark *fr.Element, X [][]fr.Element, qPrimes [][]fr.Element, claims []fr.Element,
+) (proof, challenges, finalClaims []fr.Element) {
+	bN := len(qPrimes[0])
+	flatQ := make([]fr.Element, 0, len(qPrimes)*bN)
+	for _, q := range qPrimes {
+		flatQ = append(flatQ, q...)
+	}
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	cx := make([]*C.uint64_t, len(X))
+	for i := range X {
+		cx[i] = ptr(X[i])
+		pin.Pin(&X[i][0]) // the table pointers sit in Go memory handed to C: pin what they point to
+	}
+	nCoeff := degree + 2
+	proof = make([]fr.Element, bN*nCoeff+1)
+	challenges = make([]fr.Element, bN+1)
+	finalClaims = make([]fr.Element, len(X)+1)
+	must(C.gkrhip_sumcheck_prove(C.int(gate), ptr1(ark), C.int(len(X)), C.int(bN), (**C.uint64_t)(unsafe.Pointer(&cx[0])),
+		ptr(flatQ), C.int(len(qPrimes)), ptr(claims), C.int(len(claims)), ptr(proof), ptr(challenges), ptr(finalClaims)))
+	return proof[:bN*nCoeff], challenges[:bN], finalClaims
+}
+
+// Layer mirrors circuit.Layer for the library: Gate < 0 marks an input layer.
+type Layer struct {
+	Gate int
+	In   []int
+	Ark  fr.Element
+}
+
+// Session is a circuit with its assignment resident on the GPU (gkrhip_session).
+type Session struct {
+	h  *C.gkrhip_session
+	bN int
+}
+
+func cLayers(layers []Layer) []C.gkrhip_layer {
+	cl := make([]C.gkrhip_layer, len(layers))
+	for i, l := range layers {
+		if len(l.In) > MaxGateInputs {
+			panic("gkrhip: a layer has more inputs than the library's gate descriptors express")
+		}
+		cl[i].gate = C.int(l.Gate)
+		cl[i].n_in = C.int(len(l.In))
+		for k, v := range l.In {
+			cl[i].in[k] = C.int(v)
+		}
+		for k := 0; k < 4; k++ {
+			cl[i].ark[k] = C.uint64_t(l.Ark[k])
+		}
+	}
+	return cl
+}
+
+// NewSession builds the circuit on the device (circuit.BuildCircuit's rules are enforced by the library).
+func NewSession(layers []Layer, bN int) *Session {
+	cl := cLayers(layers)
+	s := &Session{bN: bN}
+	must(C.gkrhip_session_create(&s.h, &cl[0], C.int(len(cl)), C.int(bN)))
+	runtime.SetFinalizer(s, func(s *Session) { s.Close() })
+	return s
+}
+
+// LoadInput uploads input layer `index` (2^bN elements).
+func (s *Session) LoadInput(index int, table []fr.Element) {
+	must(C.gkrhip_session_load_input(s.h, C.int(index), ptr(table)))
+}
+
+// Assign is circuit.Circuit.Assign on the device (circuit/assignment.go:12-32).
+func (s *Session) Assign() { must(C.gkrhip_mimc_session_assign(s.h)) }
+
+// ProofLen is GkrProverHint.NbOutputs for this circuit and size (prover/gadget/hints.go:76-116).
+func (s *Session) ProofLen() int { return int(C.gkrhip_session_proof_len(s.h)) }
+
+// Prove is gkr.Prove (gkr/prover.go:21-47); the result is the flat proof in GkrProofToVec order
+// (prover/gadget/hints.go:236-271), still in Montgomery form.  The resident assignment is not consumed.
+func (s *Session) Prove(qPrime []fr.Element) []fr.Element {
+	flat := make([]fr.Element, s.ProofLen())
+	must(C.gkrhip_mimc_session_prove(s.h, ptr(qPrime), ptr(flat)))
+	return flat
+}
+
+// Outputs downloads the assignment of the last layer.
+func (s *Session) Outputs() []fr.Element {
+	out := make([]fr.Element, 1<<s.bN)
+	must(C.gkrhip_mimc_session_outputs(s.h, ptr(out)))
+	return out
+}
+
+// Verify is gkr.Verify against the resident input and output tables (gkr/verifier.go:15-59).
+func (s *Session) Verify(qPrime, flat []fr.Element) error {
+	rc := C.gkrhip_mimc_session_verify(s.h, ptr(qPrime), ptr(flat))
+	if rc > 0 {
+		return errors.New(C.GoString(C.gkrhip_last_error()))
+	}
+	must(rc)
+	return nil
+}
+
+// Close releases the device tables.
+func (s *Session) Close() {
+	if s.h != nil {
+		C.gkrhip_mimc_session_destroy(s.h)
+		s.h = nil
+	}
+}
+
+// Verify is gkr.Verify (gkr/verifier.go:15-59) for any circuit of library gates on host tables: the sumcheck
+// verifiers and the claim bookkeeping run on the host, MultiLin.Evaluate of inputs and outputs on the device.
+func Verify(layers []Layer, bN int, flat []fr.Element, inputs [][]fr.Element, outputs, qPrime []fr.Element) error {
+	cl := cLayers(layers)
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	ci := make([]*C.uint64_t, len(inputs))
+	for i := range inputs {
+		ci[i] = ptr(inputs[i])
+		pin.Pin(&inputs[i][0])
+	}
+	rc := C.gkrhip_gkr_verify(&cl[0], C.int(len(cl)), C.int(bN), ptr(flat), (**C.uint64_t)(unsafe.Pointer(&ci[0])),
+		C.int(len(ci)), ptr(outputs), ptr(qPrime))
+	if rc > 0 {
+		return errors.New(C.GoString(C.gkrhip_last_error()))
+	}
+	must(rc)
+	return nil
+}
+
+// ProveMimc is Circuit.Assign + gkr.Prove for examples.MimcCircuit in one call, what GkrProverHint.Call times
+// (prover/gadget/hints.go:220-222).  outputs may be nil.
+func ProveMimc(bN int, in0, in1, qPrime, outputs []fr.Element) []fr.Element {
+	flat := make([]fr.Element, int(C.gkrhip_mimc_proof_len(C.int(bN))))
+	must(C.gkrhip_gkr_prove_mimc(C.int(bN), ptr(in0), ptr(in1), ptr(qPrime), ptr(flat), ptr(outputs)))
+	return flat
+}
+
+// VerifyMimc is gkr.Verify for examples.MimcCircuit on host tables.
+func VerifyMimc(bN int, flat, in0, in1, outputs, qPrime []fr.Element) error {
+	rc := C.gkrhip_gkr_verify_mimc(C.int(bN), ptr(flat), ptr(in0), ptr(in1), ptr(outputs), ptr(qPrime))
+	if rc > 0 {
+		return errors.New(C.GoString(C.gkrhip_last_error()))
+	}
+	must(rc)
+	return nil
+}
+
+// ToRegular / FromRegular convert a slice in place between Montgomery limbs and the regular value as four
+// little-endian words (what big.Int.SetBits / Bits exchange on amd64): the bulk form of ToBigIntRegular / SetBigInt
+// (prover/gadget/hints.go:202-205,236-271).
+func ToRegular(s []fr.Element)   { must(C.gkrhip_to_regular(ptr(s), C.size_t(len(s)))) }
+func FromRegular(s []fr.Element) { must(C.gkrhip_from_regular(ptr(s), C.size_t(len(s)))) }
+
+// MimcPermutationBatch: out[i] = hash.MimcKeyedPermutation(x[i], key[i]) (hash/mimc.go:31-39), the body of
+// HashHint.Call for a whole batch (prover/gadget/hints.go:134-145).
+func MimcPermutationBatch(out, x, key []fr.Element) {
+	must(C.gkrhip_mimc_permutation_batch(ptr(out), ptr(x), ptr(key), C.size_t(len(x))))
+}

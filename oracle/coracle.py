@@ -14,7 +14,7 @@ import numpy as np
 _here = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_here, "libgkr_oracle.so")
 
-GATE_IDENTITY, GATE_CIPHER, GATE_ADD = 0, 1, 2
+GATE_IDENTITY, GATE_CIPHER, GATE_ADD, GATE_SUM, GATE_SUM_POW7 = 0, 1, 2, 3, 4
 
 
 def build():
@@ -210,8 +210,17 @@ def interpolate_on_range(values):
     return o
 
 
+def gate_eval_batch(gate, ark, xs):
+    """Gate.EvalBatch (circuit/gates.go:16): res[i] = gate(xs[0][i], xs[1][i], ...)."""
+    xs = [np.ascontiguousarray(x) for x in xs]
+    res = fr(xs[0].shape[0])
+    ark = fr() if ark is None else np.ascontiguousarray(ark)
+    lib.oracle_gate_eval_batch(gate, _p(ark), _p(res), _ptr_array(xs), len(xs), xs[0].shape[0])
+    return res
+
+
 def gate_degree(gate):
-    return 7 if gate == GATE_CIPHER else 1
+    return 7 if gate in (GATE_CIPHER, GATE_SUM_POW7) else 1
 
 
 def sumcheck_prove(gate, ark, X, qprimes, claims):
@@ -276,13 +285,13 @@ def gkr_verify_mimc(bN, flat, in0, in1, outputs, qprime):
 
 
 class LayerDesc(C.Structure):
-    _fields_ = [("gate", C.c_int), ("n_in", C.c_int), ("in_", C.c_int * 2), ("ark", C.c_uint64 * 4)]
+    _fields_ = [("gate", C.c_int), ("n_in", C.c_int), ("in_", C.c_int * 4), ("ark", C.c_uint64 * 4)]
 
 
 def circuit_descs(pycircuit):
     """pyoracle circuit (list of Layer) -> C array of oracle_layer_desc."""
     import pyoracle as o
-    kinds = {"identity": GATE_IDENTITY, "cipher": GATE_CIPHER, "add": GATE_ADD}
+    kinds = {"identity": GATE_IDENTITY, "cipher": GATE_CIPHER, "add": GATE_ADD, "sum": GATE_SUM, "sum_pow7": GATE_SUM_POW7}
     arr = (LayerDesc * len(pycircuit))()
     for i, lay in enumerate(pycircuit):
         arr[i].gate = -1 if lay.gate is None else kinds[lay.gate.kind]

@@ -341,7 +341,26 @@ static inline void gate_eval(int gate, const ofr_t *ark, ofr_t *res, const ofr_t
         *res = *xs[0];
     }
 }
-static int gate_degree(int gate) { return gate == ORACLE_GATE_CIPHER ? 7 : 1; } /* cipher.go:68-70, copy.go:30-32; add: linear */
+/* the variadic build-defined gates: the arity is the layer's len(In) */
+static inline void gate_eval_n(int gate, int arity, const ofr_t *ark, ofr_t *res, const ofr_t *const *xs) {
+    if (gate != ORACLE_GATE_SUM && gate != ORACLE_GATE_SUM_POW7) {
+        gate_eval(gate, ark, res, xs);
+        return;
+    }
+    ofr_t s = *ark;
+    for (int k = 0; k < arity; k++) fr_add(&s, &s, xs[k]);
+    if (gate == ORACLE_GATE_SUM) {
+        *res = s;
+    } else { /* same square-and-multiply chain as cipher.go:36-40 */
+        fr_mul(res, &s, &s);
+        fr_mul(res, res, &s);
+        fr_mul(res, res, res);
+        fr_mul(res, res, &s);
+    }
+}
+static int gate_degree(int gate) { /* cipher.go:68-70, copy.go:30-32; add / sum: linear */
+    return gate == ORACLE_GATE_CIPHER || gate == ORACLE_GATE_SUM_POW7 ? 7 : 1;
+}
 
 void oracle_gate_eval_batch(int gate, const ofr_t *ark, ofr_t *res, const ofr_t *const *xs, int arity, size_t n) {
     /* cipher.go:25-42 / copy.go:15-17 */
@@ -360,8 +379,13 @@ void oracle_gate_eval_batch(int gate, const ofr_t *ark, ofr_t *res, const ofr_t 
             fr_add(&res[i], &xs[0][i], &xs[1][i]);
             fr_add(&res[i], &res[i], ark);
         }
+    } else if (gate == ORACLE_GATE_SUM || gate == ORACLE_GATE_SUM_POW7) {
+        for (size_t i = 0; i < n; i++) {
+            const ofr_t *at[ORACLE_MAX_GATE_INPUTS];
+            for (int k = 0; k < arity; k++) at[k] = &xs[k][i];
+            gate_eval_n(gate, arity, ark, &res[i], at);
+        }
     } else {
-        (void)arity;
         memcpy(res, xs[0], n * sizeof(ofr_t));
     }
 }
@@ -596,7 +620,7 @@ void oracle_evaluation(ofr_t *out, int gate, const ofr_t *ark, const ofr_t *qpri
     for (size_t n = 0; n < len; n++) {
         const ofr_t *buf[MAX_ARITY];
         for (int k = 0; k < arity; k++) buf[k] = &X[k][n];
-        gate_eval(gate, ark, &tmp, buf);
+        gate_eval_n(gate, arity, ark, &tmp, buf);
         fr_mul(&tmp, &tmp, &eq[n]);
         fr_add(&res, &res, &tmp);
     }
@@ -606,7 +630,7 @@ void oracle_evaluation(ofr_t *out, int gate, const ofr_t *ark, const ofr_t *qpri
 
 /* ---- circuits (circuit/circuit.go:11-44), MimcCircuit (examples/mimc.go:10-37), gkr ---------------------- */
 typedef struct {
-    int n_in, in[2];
+    int n_in, in[ORACLE_MAX_GATE_INPUTS];
     int n_out, *out;
     int gate; /* -1 = input layer */
     ofr_t ark;
@@ -618,8 +642,8 @@ static layer_t *build_circuit(const oracle_layer_desc *d, int n) {
     for (int l = 0; l < n; l++) {
         c[l].gate = d[l].gate;
         c[l].n_in = d[l].gate < 0 ? 0 : d[l].n_in;
-        c[l].in[0] = d[l].in[0];
-        c[l].in[1] = d[l].in[1];
+        if (c[l].n_in > ORACLE_MAX_GATE_INPUTS) goto bad;
+        for (int k = 0; k < ORACLE_MAX_GATE_INPUTS; k++) c[l].in[k] = d[l].in[k];
         c[l].ark = d[l].ark;
         c[l].out = (int *)calloc((size_t)n, sizeof(int));
         for (int k = 0; k < c[l].n_in; k++)
@@ -697,12 +721,14 @@ int oracle_gkr_prove_circuit(const oracle_layer_desc *desc, int NL, int bN, cons
     for (int l = 0; l < NL; l++) a[l] = (ofr_t *)malloc(n * sizeof(ofr_t));
     for (int l = 0; l < n_inputs; l++) memcpy(a[l], inputs[l], n * sizeof(ofr_t));
     for (int l = n_inputs; l < NL; l++) {
-        const ofr_t *xs[2] = {a[c[l].in[0]], c[l].n_in > 1 ? a[c[l].in[1]] : NULL};
+        const ofr_t *xs[ORACLE_MAX_GATE_INPUTS] = {NULL, NULL, NULL, NULL};
+        for (int k = 0; k < c[l].n_in; k++) xs[k] = a[c[l].in[k]];
         size_t blk = 4096;
 #pragma omp parallel for schedule(static)
         for (size_t s = 0; s < (n + blk - 1) / blk; s++) { /* Layer.Evaluate circuit/circuit.go:48-64 */
             size_t b = s * blk, e = b + blk < n ? b + blk : n;
-            const ofr_t *ys[2] = {xs[0] + b, xs[1] ? xs[1] + b : NULL};
+            const ofr_t *ys[ORACLE_MAX_GATE_INPUTS];
+            for (int k = 0; k < ORACLE_MAX_GATE_INPUTS; k++) ys[k] = xs[k] ? xs[k] + b : NULL;
             oracle_gate_eval_batch(c[l].gate, &c[l].ark, a[l] + b, ys, c[l].n_in, e - b);
         }
     }
@@ -723,8 +749,8 @@ int oracle_gkr_prove_circuit(const oracle_layer_desc *desc, int NL, int bN, cons
     for (int layer = NL - 1; layer >= 0 && rc == 0; layer--) {
         if (c[layer].gate < 0) break;
         int arity = c[layer].n_in;
-        ofr_t *X[2] = {NULL, NULL};
-        int owned[2] = {0, 0};
+        ofr_t *X[ORACLE_MAX_GATE_INPUTS] = {NULL, NULL, NULL, NULL};
+        int owned[ORACLE_MAX_GATE_INPUTS] = {0, 0, 0, 0};
         for (int k = 0; k < arity; k++) { /* InputsOfLayer circuit/assignment.go:35-57 */
             int pos = c[layer].in[k];
             if (c[pos].out[0] == layer) {
@@ -738,7 +764,7 @@ int oracle_gkr_prove_circuit(const oracle_layer_desc *desc, int NL, int bN, cons
         int nc = gate_degree(c[layer].gate) + 2;
         sc[layer] = (ofr_t *)calloc((size_t)(bN > 0 ? bN : 1) * nc, sizeof(ofr_t));
         ofr_t *next_q = (ofr_t *)calloc((size_t)(bN > 0 ? bN : 1), sizeof(ofr_t));
-        ofr_t final[3];
+        ofr_t final[ORACLE_MAX_GATE_INPUTS + 1];
         int nq = layer == NL - 1 ? 1 : c[layer].n_out;
         int ncl = has_claims[layer] ? c[layer].n_out : 0;
         rc = oracle_sumcheck_prove(c[layer].gate, &c[layer].ark, arity, bN, X, qprimes[layer], nq, claims[layer], ncl,
@@ -841,7 +867,7 @@ int oracle_gkr_verify_circuit(const oracle_layer_desc *desc, int NL, int bN, con
             rc = -20 - layer * 10;
             break;
         }
-        const ofr_t *sub[2];
+        const ofr_t *sub[ORACLE_MAX_GATE_INPUTS];
         for (int k = 0; k < c[layer].n_in; k++) { /* testSumcheck :74-93 */
             int inp = c[layer].in[k];
             int r_at = out_index(&c[inp], layer);
@@ -850,7 +876,7 @@ int oracle_gkr_verify_circuit(const oracle_layer_desc *desc, int NL, int bN, con
         }
         if (rc) break;
         ofr_t expected, eq_eval;
-        gate_eval(c[layer].gate, &c[layer].ark, &expected, sub);
+        gate_eval_n(c[layer].gate, c[layer].n_in, &c[layer].ark, &expected, sub);
         for (int i = 0; i < ncl; i++) oracle_eval_eq(&tmp_evals[i], qps[layer] + (size_t)i * bN, next_q, bN);
         oracle_eval_univariate(&eq_eval, tmp_evals, ncl, &recomb);
         fr_mul(&expected, &expected, &eq_eval);

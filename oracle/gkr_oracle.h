@@ -29,11 +29,15 @@ extern "C" {
 
 typedef struct { uint64_t l[4]; } ofr_t; /* Montgomery limbs, little-endian */
 
-enum { ORACLE_GATE_IDENTITY = 0, ORACLE_GATE_CIPHER = 1, ORACLE_GATE_ADD = 2 /* build-defined: xs[0]+xs[1]+Ark */ };
+/* circuit.Gate implementations (circuit/gates.go:9-21).  IDENTITY and CIPHER are the reference's (copy.go, cipher.go);
+ * the others are build-defined members of the same family, variadic as the interface is (arity = len(Layer.In)):
+ * ADD = xs[0]+xs[1]+Ark, SUM = xs[0]+...+xs[arity-1]+Ark (Degree 1), SUM_POW7 = (xs[0]+...+xs[arity-1]+Ark)^7 (Degree 7) */
+enum { ORACLE_GATE_IDENTITY = 0, ORACLE_GATE_CIPHER = 1, ORACLE_GATE_ADD = 2, ORACLE_GATE_SUM = 3, ORACLE_GATE_SUM_POW7 = 4 };
+#define ORACLE_MAX_GATE_INPUTS 4
 
 /* one layer of a circuit (circuit/circuit.go:11-23): gate = -1 for input layers (which come first) */
 typedef struct {
-    int gate, n_in, in[2];
+    int gate, n_in, in[ORACLE_MAX_GATE_INPUTS];
     ofr_t ark;
 } oracle_layer_desc;
 

@@ -277,6 +277,25 @@ class AddGate:
         return 1
 
 
+class SumGate:
+    """Build-defined variadic gate of the same family (circuit.Gate is variadic, circuit/gates.go:16-18; the arity is
+    len(Layer.In)): (xs[0] + ... + xs[n-1] + Ark)^power with power 1 (kind "sum", Degree 1) or 7 (kind "sum_pow7",
+    Degree 7, the square-and-multiply chain of circuit/gates/cipher.go:36-40)."""
+
+    def __init__(self, ark=0, power=1):
+        assert power in (1, 7)
+        self.ark = ark % Q
+        self.power = power
+        self.kind = "sum" if power == 1 else "sum_pow7"
+
+    def eval(self, *xs):
+        s = (sum(xs) + self.ark) % Q
+        return s if self.power == 1 else pow(s, 7, Q)
+
+    def degree(self):
+        return self.power
+
+
 class Layer:
     def __init__(self, In, gate=None):
         self.In = list(In)
@@ -353,6 +372,44 @@ def gmimc_t2_circuit():
     keep = [l for l in range(len(L)) if l in need]
     ren = {l: k for k, l in enumerate(keep)}
     return build_circuit([Layer([ren[p] for p in L[l].In], L[l].gate) for l in keep])
+
+
+def gmimc_circuit(t):
+    """Build-defined GKR circuit for one GMiMC compression with t in (2, 4, 8) (hash/gmimc.go:16-20,52-65):
+        out = GMimcT{t}.UpdateInplace(state, block)[0]
+    Returns (circuit, input_map): input layer k is state[j] when input_map[k] = j < t, block[j - t] otherwise.
+    A round adds block[j] + Ark_i to every branch, sends branch 0 through the S-box and rotates left: per wire an
+    AddGate layer on the linear branches and a CipherGate layer on branch 0.  The branches never mix, so
+    state'[0] depends on ONE initial branch (number 91 mod t), on the block, and -- through the feed-forward
+    state'[0] + state[0] + block[0], ONE layer of the three-input SumGate -- on state[0]: the other state
+    elements are not inputs of the circuit (an input layer without consumers would have no claim,
+    gkr/verifier.go:120-132)."""
+    assert t in (2, 4, 8)
+    L = [Layer([]) for _ in range(2 * t)]
+    L.append(Layer([0], IdentityGate()))
+    cs0 = len(L) - 1
+    st = [cs0] + list(range(1, t))
+    cb = []
+    for j in range(t):
+        L.append(Layer([t + j], IdentityGate()))
+        cb.append(len(L) - 1)
+    for i in range(MIMC_ROUNDS):
+        nx = [None] * t
+        for j in range(1, t):
+            L.append(Layer([st[j], cb[j]], AddGate(ARKS[i])))
+            nx[j - 1] = len(L) - 1
+        L.append(Layer([cb[0], st[0]], CipherGate(ARKS[i])))
+        nx[t - 1] = len(L) - 1
+        st = nx
+    L.append(Layer([st[0], cs0, cb[0]], SumGate(0, 1)))
+    need = {len(L) - 1}
+    for l in range(len(L) - 1, -1, -1):
+        if l in need:
+            need.update(L[l].In)
+    keep = [l for l in range(len(L)) if l in need]
+    ren = {l: k for k, l in enumerate(keep)}
+    input_map = [l for l in keep if l < 2 * t]
+    return build_circuit([Layer([ren[p] for p in L[l].In], L[l].gate) for l in keep]), input_map
 
 
 def assign(c, *inps):

@@ -93,6 +93,30 @@ def gmimc_small(gk, world, rank, sizes):
     print("SHARD-OK rank %d/%d gmimc %s" % (rank, world, sizes))
 
 
+def variadic(gk, world, rank, sizes):
+    """A circuit over registered 1-, 3- and 4-input gates, sharded, against the C oracle's un-sharded transcript."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_parity as T
+    circ, layers = T._variadic_circuit()
+    descs = c.circuit_descs(circ)
+    for bn in sizes:
+        n = 1 << bn
+        ins = [c.random_fr_array(n), T.nasty(n, bn + 5), c.from_ints([(3 * j * j + 1) % 1000003 for j in range(n)]), T.nasty(n, bn + 6)]
+        qp = c.random_fr_array(bn)
+        s = gk.MimcSession(bn, layers=layers)
+        for i, t in enumerate(ins):
+            s.load_input(i, t[rank::world].copy())
+        s.assign()
+        flat = s.prove(qp)
+        oflat, oouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+        assert np.array_equal(flat, oflat), ("variadic transcript", bn, rank)
+        assert np.array_equal(s.outputs(), oouts[rank::world]), ("variadic outputs", bn, rank)
+        assert s.verify(qp, flat)
+        s.close()
+    gk.comm_destroy()
+    print("SHARD-OK rank %d/%d variadic %s" % (rank, world, sizes))
+
+
 def main():
     mode, world, rank, name = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     sizes = [int(x) for x in sys.argv[5].split(",")]
@@ -108,6 +132,8 @@ def main():
         return digests(gk, world, rank, sizes, circuit)
     if circuit == "gmimc":
         return gmimc_small(gk, world, rank, sizes)
+    if circuit == "variadic":
+        return variadic(gk, world, rank, sizes)
     if nlanes > 1:
         return concurrent(gk, world, rank, sizes, nlanes)
     for bn in sizes:

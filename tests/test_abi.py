@@ -60,6 +60,60 @@ def test_gmimc_circuit_description_matches_oracle(gk):
     assert a[-1][0] == o.gmimc_update([5, 7], [11, 13])[0]
 
 
+def test_gmimc_t_circuits_match_oracle(gk):
+    """gkrhip_gmimc_circuit(t) for t = 2, 4, 8 (hash/gmimc.go:16-20) is layer for layer the circuit pyoracle builds
+    independently -- the last layer being the registered three-input gate -- with the same input map, and that circuit
+    computes hash.GMimcHasher's compression on every instance."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as o
+    for t in (2, 4, 8):
+        lib_c, lib_map = gk.gmimc_circuit(t)
+        ref_c, ref_map = o.gmimc_circuit(t)
+        assert lib_map == ref_map and len(lib_c) == len(ref_c)
+        for (gate, ins, ark), lay in zip(lib_c, ref_c):
+            assert ins == lay.In
+            if lay.gate is None:
+                assert gate == -1
+                continue
+            if lay.gate.kind == "sum":
+                d = gk.gate_lookup(gate)
+                assert (d["n_in"], d["sum_mask"], d["power"]) == (len(lay.In), (1 << len(lay.In)) - 1, 1) and gate >= 3
+            else:
+                assert gate == {"identity": gk.GATE_IDENTITY, "cipher": gk.GATE_CIPHER, "add": gk.GATE_ADD}[lay.gate.kind]
+            if lay.gate.kind != "identity":
+                assert ark == o.to_mont_limbs(lay.gate.ark)
+        random.seed(t)
+        state = [[random.randrange(o.Q) for _ in range(3)] for _ in range(t)]
+        block = [[random.randrange(o.Q) for _ in range(3)] for _ in range(t)]
+        a = o.assign(ref_c, *[(state[j] if j < t else block[j - t]) for j in ref_map])
+        for k in range(3):
+            assert a[-1][k] == o.gmimc_update([s[k] for s in state], [b[k] for b in block])[0]
+    # and the compression is the one the committed hash vectors were produced with (kat.json gmimc_hash, all t)
+    from util import hex_to_fr, load
+    import coracle as c
+    for e in load("kat.json")["gmimc_hash"]:
+        msg = c.to_ints(hex_to_fr(e["in"]))
+        assert o.gmimc_hash(msg, e["t"]) == c.to_ints(hex_to_fr(e["out"]))[0]
+
+
+def test_gate_table(gk):
+    """The gate plug point (circuit/gates.go:9-21) as a descriptor table: built-ins, registration, refusals."""
+    assert gk.gate_lookup(gk.GATE_IDENTITY) == {"id": "CopyGate", "n_in": 1, "sum_mask": 1, "power": 1}
+    assert gk.gate_lookup(gk.GATE_CIPHER)["power"] == 7 and gk.gate_lookup(gk.GATE_CIPHER)["n_in"] == 2
+    g = gk.gate_register("test-sum4-pow7", 4, 0b1111, 7)
+    assert g >= 3 and gk.gate_register("test-sum4-pow7", 4, 0b1111, 7) == g          # idempotent
+    assert gk.gate_lookup(g) == {"id": "test-sum4-pow7", "n_in": 4, "sum_mask": 15, "power": 7}
+    assert gk.gate_degree(g) == 7
+    for bad in (("test-mul", 2, 3, 2), ("test-none", 2, 0, 1), ("test-wide", 5, 31, 1), ("test-mask", 2, 4, 1),
+                ("test-sum4-pow7", 3, 7, 1)):          # power 2; empty sum; 5 inputs; mask outside the inputs; ID reused
+        with pytest.raises(gk.prover.GkrHipError):
+            gk.gate_register(*bad)
+    with pytest.raises(gk.prover.GkrHipError):
+        gk.gate_lookup(10 ** 6)
+
+
 def test_proof_len(gk):
     for bn in (0, 1, 5, 24):
         assert gk.mimc_proof_len(bn) == 822 * bn + 183 + 184 * bn

@@ -539,6 +539,107 @@ def test_gmimc_circuit_larger_sizes(gk):
         s.close()
 
 
+# ---------------------------------------------------------------- the gate table (circuit.Gate plug point)
+def _variadic_circuit():
+    """A layered circuit over registered gates of 1, 3 and 4 inputs (the same one tests/test_oracle.py proves with
+    both restatements): returns (pyoracle circuit, library layer list)."""
+    L = [o.Layer([]) for _ in range(4)]
+    L.append(o.Layer([0], o.IdentityGate()))
+    L.append(o.Layer([4, 1, 2], o.SumGate(o.ARKS[0], 7)))
+    L.append(o.Layer([5, 4, 3], o.SumGate(o.ARKS[1], 1)))
+    L.append(o.Layer([6], o.IdentityGate()))
+    L.append(o.Layer([7], o.SumGate(5, 7)))
+    L.append(o.Layer([7, 8, 5, 6], o.SumGate(o.ARKS[2], 7)))
+    circ = o.build_circuit(L)
+    return circ, _library_layers(circ)
+
+
+def _library_layers(circ):
+    def gate_id(lay):
+        g = lay.gate
+        if g is None:
+            return -1
+        if g.kind in ("sum", "sum_pow7"):
+            return importlib.import_module("gkr-mimc_amd").gate_register(
+                "test-%s-%d" % (g.kind, len(lay.In)), len(lay.In), (1 << len(lay.In)) - 1, g.power)
+        return {"identity": 0, "cipher": 1, "add": 2}[g.kind]
+    return [(gate_id(l), list(l.In), None if l.gate is None else o.to_mont_limbs(getattr(l.gate, "ark", 0))) for l in circ]
+
+
+@pytest.mark.parametrize("arity,power", [(1, 7), (3, 1), (3, 7), (4, 1), (4, 7)])
+def test_registered_gates_eval_and_sumcheck_vs_oracle(gk, arity, power):
+    """Gate.EvalBatch and sumcheck.Prove for registered descriptors (variadic gates, circuit/gates.go:16-18) against
+    the C oracle's restated gates: one claim (fused or reference-shaped rounds) and several claims."""
+    gate = gk.gate_register("test-%s-%d" % ("sum" if power == 1 else "sum_pow7", arity), arity, (1 << arity) - 1, power)
+    ogate = c.GATE_SUM if power == 1 else c.GATE_SUM_POW7
+    ark = c.from_ints([o.ARKS[7]])
+    for bn in (1, 4, 9):
+        n = 1 << bn
+        X = [nasty(n, 10 * bn + k) if k % 2 else c.random_fr_array(n) for k in range(arity)]
+        assert np.array_equal(gk.gate_eval_batch(gate, ark, X), c.gate_eval_batch(ogate, ark, X))
+        for nq in (1, 3):
+            qs = np.stack([c.from_ints([(7 * i * j + i + 3) % o.Q for j in range(bn)]) for i in range(nq)])
+            claims = np.concatenate([c.evaluation(ogate, ark, qs[i:i + 1], c.fr(0), X) for i in range(nq)])
+            got = gk.sumcheck_prove(X, qs, claims, gate, ark)
+            want = c.sumcheck_prove(ogate, ark, X, qs, claims)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (arity, power, bn, nq)
+
+
+@pytest.mark.parametrize("bn", [0, 1, 4, 10])
+def test_circuit_of_registered_gates_vs_oracle(gk, bn):
+    """gkr.Prove over a circuit with 1-, 3- and 4-input gates: transcript and outputs equal the C oracle's, the native
+    verifier (session and host-table forms) and the oracle's verifier accept, a corrupted proof is rejected."""
+    circ, layers = _variadic_circuit()
+    descs = c.circuit_descs(circ)
+    n = 1 << bn
+    ins = [c.random_fr_array(n), nasty(n, bn + 5), c.from_ints([(3 * j * j + 1) % 1000003 for j in range(n)]), nasty(n, bn + 6)]
+    qp = c.random_fr_array(bn)
+    want, wouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+    s = gk.MimcSession(bn, layers=layers)
+    for k in range(4):
+        s.load_input(k, ins[k])
+    s.assign()
+    flat = s.prove(qp)
+    assert np.array_equal(flat, want) and np.array_equal(s.outputs(), wouts)
+    assert s.verify(qp, flat)
+    assert gk.gkr_verify(layers, flat, ins, wouts, qp)
+    assert c.gkr_verify_circuit(descs, bn, flat, ins, wouts, qp) == 0
+    if bn:
+        bad = flat.copy()
+        bad[len(bad) // 3, 2] ^= np.uint64(16)
+        assert not gk.gkr_verify(layers, bad, ins, wouts, qp)
+    s.close()
+
+
+@pytest.mark.parametrize("t", [4, 8])
+def test_gmimc_t4_t8_circuits_vs_oracle(gk, t):
+    """GMiMC for t = 4 and 8 (hash/gmimc.go:16-20): the library's circuit (three-input feed-forward gate) against the C
+    oracle's transcript; outputs against the reference hasher's compression on every instance."""
+    layers, imap = gk.gmimc_circuit(t)
+    circ, ref_map = o.gmimc_circuit(t)
+    assert imap == ref_map
+    descs = c.circuit_descs(circ)
+    for bn in (2, 8):
+        n = 1 << bn
+        rng = np.random.default_rng(100 * t + bn)
+        vals = [[int(v) for v in rng.integers(0, 1 << 62, n)] for _ in range(2 * t)]
+        ins = [c.from_ints(vals[j]) for j in imap]
+        qp = c.random_fr_array(bn)
+        want, wouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+        s = gk.MimcSession(bn, layers=layers)
+        for k, tab in enumerate(ins):
+            s.load_input(k, tab)
+        s.assign()
+        flat = s.prove(qp)
+        assert np.array_equal(flat, want) and np.array_equal(s.outputs(), wouts)
+        assert gk.gkr_verify(layers, flat, ins, wouts, qp)
+        if bn == 2:
+            assert c.to_ints(wouts) == [o.gmimc_update([vals[j][k] for j in range(t)], [vals[t + j][k] for j in range(t)])[0]
+                                        for k in range(n)]
+        s.close()
+
+
 @pytest.mark.parametrize("bn", [14, 20, 22])
 def test_gmimc_baseline_sizes_match_oracle_digest(gk, bn):
     """BASELINE config 5 (bN = 22) and two smaller sizes: SHA-256 of the GPU transcript and of the output table
@@ -635,8 +736,21 @@ def test_native_verifier_agrees_with_oracle(gk, bn):
     bad_out[0, 0] ^= np.uint64(2)
     assert not gk.gkr_verify_mimc(flat, i0, i1, bad_out, qp)
     bad_in = i1.copy()
-    bad_in[-1, 1] ^= np.uint64(8)
+    bad_in[0, 1] ^= np.uint64(8)          # still a canonical element
     assert not gk.gkr_verify_mimc(flat, i0, bad_in, outs, qp)
+
+
+def test_non_canonical_input_is_refused(gk):
+    """gnark-crypto keeps fr.Element below q and the round kernels' lazy-reduction bounds rely on it: a table with
+    an element >= q is refused at the boundary instead of yielding silently different sums."""
+    t = c.random_fr_array(8)
+    t[5] = [0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029]   # q itself
+    with pytest.raises(gk.prover.GkrHipError, match="canonical"):
+        gk.fold(t, c.from_u64(5))
+    t[5] = [0xFFFFFFFFFFFFFFFF] * 4
+    with pytest.raises(gk.prover.GkrHipError, match="canonical"):
+        gk.evaluate(t, c.random_fr_array(3))
+    assert np.array_equal(gk.fold(c.random_fr_array(8), c.from_u64(5)), c.fold(c.random_fr_array(8), c.from_u64(5)))
 
 
 def test_session_verify_full_size(gk):
@@ -733,6 +847,10 @@ def test_sharded_gmimc_circuit(gk):
     _run_shards("shm", 4, "2,3,8,11", {"GKR_TEST_CIRCUIT": "gmimc"})
     _run_shards("shm", 4, "14,20", {"GKR_TEST_CIRCUIT": "gmimc", "GKR_TEST_DIGEST": "1"})
     _run_shards("shm", 2, "3,6,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_GENERIC": "1"})
+    # the fused linear rounds through ncclAllReduce (1-rank communicator, every round forced through the collective)
+    _run_shards("rccl", 1, "2,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_FORCE_COLLECTIVE": "1"})
+    # registered 1-, 3- and 4-input gates sharded
+    _run_shards("shm", 4, "2,3,7,10", {"GKR_TEST_CIRCUIT": "variadic"})
 
 
 def test_rccl_plumbing_world1(gk):

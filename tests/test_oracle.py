@@ -291,3 +291,28 @@ def test_survey_appendix_b():
     # proof sizes (coeffs / claims / point coordinates), hints.go:76-116
     for bn, sizes in ((0, (0, 183, 0)), (1, (822, 183, 184)), (3, (2466, 183, 552)), (5, (4110, 183, 920))):
         assert c.mimc_proof_len(bn) == sum(sizes) and o.nb_outputs(circ, bn) == sum(sizes)
+
+
+@pytest.mark.parametrize("bn", [0, 1, 3])
+def test_variadic_gates_c_vs_python(bn):
+    """The build-defined variadic gates (sum / sum^7 over 3 and 4 inputs) in a small layered circuit: the two
+    restatements produce the same transcript, and the restated gkr.Verify accepts it."""
+    n = 1 << bn
+    L = [o.Layer([]) for _ in range(4)]
+    L.append(o.Layer([0], o.IdentityGate()))                       # 4: copy of input 0 (used twice)
+    L.append(o.Layer([4, 1, 2], o.SumGate(o.ARKS[0], 7)))          # 5: (x0 + x1 + x2 + Ark)^7
+    L.append(o.Layer([5, 4, 3], o.SumGate(o.ARKS[1], 1)))          # 6: y + x0 + x3 + Ark
+    L.append(o.Layer([6], o.IdentityGate()))                       # 7: copy (used twice)
+    L.append(o.Layer([7], o.SumGate(5, 7)))                        # 8: one-input power gate
+    L.append(o.Layer([7, 8], o.AddGate(o.ARKS[2])))                # 9
+    circ = o.build_circuit(L)
+    rng = np.random.default_rng(bn)
+    ins = [[int(v) for v in rng.integers(0, 1 << 62, n)] for _ in range(4)]
+    qp = o.random_fr_array(bn)
+    a = o.assign(circ, *ins)
+    pr = o.gkr_prove(circ, a, qp)
+    assert o.gkr_verify(circ, pr, ins, a[-1], qp)
+    descs = c.circuit_descs(circ)
+    cf, cout, _ = c.gkr_prove_circuit(descs, bn, [c.from_ints(x) for x in ins], c.from_ints(qp) if bn else c.fr(0))
+    assert c.to_ints(cf) == o.gkr_proof_to_vec(pr) and c.to_ints(cout) == a[-1]
+    assert c.gkr_verify_circuit(descs, bn, cf, [c.from_ints(x) for x in ins], cout, c.from_ints(qp) if bn else c.fr(0)) == 0
