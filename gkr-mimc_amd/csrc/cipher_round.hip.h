@@ -91,6 +91,8 @@ struct CipherRoundArgs {
     unsigned int* host_flag;        // host-mapped: set to `seq` when host_out is complete
     unsigned int seq;
     unsigned int need_m0;           // 0: M_0 is derived by the host from the running claim (2 products fewer)
+    unsigned long long* tail_tables;   // host-mapped, or nullptr: this round's tables (2P entries of K, then 2P of S, 4 u64
+                                       // each) for the host, which runs the remaining (tiny) rounds itself
 };
 
 // a += x as an un-reduced 288-bit integer (x < 2^256).  One opaque carry chain: keeps hipcc from
@@ -238,6 +240,16 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
             t = fr_mont_mul_raw(X1, D); GKR_SB(); acc_add_raw(acc[7], t); GKR_SB();  // W d^7
             }
 #undef GKR_SB
+            if (a.tail_tables) {
+                unsigned long long* tt = a.tail_tables;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    tt[4 * x + l] = (unsigned long long)klo.v[2 * l] | ((unsigned long long)klo.v[2 * l + 1] << 32);
+                    tt[4 * (x + P) + l] = (unsigned long long)khi.v[2 * l] | ((unsigned long long)khi.v[2 * l + 1] << 32);
+                    tt[4 * (2 * P + x) + l] = (unsigned long long)slo.v[2 * l] | ((unsigned long long)slo.v[2 * l + 1] << 32);
+                    tt[4 * (3 * P + x) + l] = (unsigned long long)shi.v[2 * l] | ((unsigned long long)shi.v[2 * l + 1] << 32);
+                }
+            }
             if (P == 1) {
                 // last round: hand the two remaining entries of each table to the host, which applies
                 // the final fold (two scalar multiplications) to obtain finalClaims (prover.go:79-86)

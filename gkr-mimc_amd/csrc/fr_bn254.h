@@ -54,6 +54,21 @@ struct Fr {
         (acc) = _s;                          \
     } while (0)
 
+// multiply-add whose sum is statically known to stay below 2^64 (tools/gen_mont_asm.py bounds every column): no
+// carry tracking.  -DFR_CHECK_SKIPS (CPU unit tests) counts a wrap-around in fr_skip_overflows.
+#if defined(FR_CHECK_SKIPS) && !defined(__HIP_DEVICE_COMPILE__)
+static long fr_skip_overflows = 0;
+#define FR_MADN(acc, x, y)                         \
+    do {                                           \
+        u64 _p = (u64)(x) * (u64)(y);              \
+        u64 _s = (acc) + _p;                       \
+        if (_s < _p) fr_skip_overflows++;          \
+        (acc) = _s;                                \
+    } while (0)
+#else
+#define FR_MADN(acc, x, y) ((acc) += (u64)(x) * (u64)(y))
+#endif
+
 FR_HD u32 fr_addc(u32 a, u32 b, u32 cin, u32* cout) {
 #if defined(__clang__)
     return __builtin_addc(a, b, cin, cout);
@@ -144,6 +159,8 @@ FR_HD void fr_mont_mul2_raw(Fr& r0, Fr& r1, const Fr& a0, const Fr& b0, const Fr
 // ---- deferred reduction for products that only feed a sum -----------------------------------------
 // A (17 limbs, un-reduced, < 2^542) += a*b as a plain integer product (fr_mac_wide_gen.inc); the sum of
 // many such products is reduced ONCE by fr_redc_wide instead of once per product.
+// PRECONDITION a, b < 3q (lazy Montgomery products or canonical elements at every call site): the generated
+// schedule leaves out the carry instructions that this bound on the top limbs makes unnecessary.
 #define FR_WIDE_LIMBS 17
 FR_HD void fr_mac_wide(u32 (&A)[FR_WIDE_LIMBS], const Fr& a, const Fr& b) {
 #include "fr_mac_wide_gen.inc"
@@ -204,7 +221,8 @@ FR_HD Fr fr_canon_lt16q(const u32 (&w)[9]) {
 // Product with a launch-wide constant c (the fold challenge of a round), c given by the host as the pair
 // ca = c * 2^-128 mod q, cb = c (both canonical, Montgomery form like every element):
 //     a * c / 2^256 == (a_lo * ca + a_hi * cb) / 2^128  (mod q),   a = a_lo + 2^128 a_hi,
-// so four Montgomery steps suffice (96 limb products instead of 128).  a canonical; result < 3q.
+// so four Montgomery steps suffice (96 limb products instead of 128).  PRECONDITION a < 3q, ca and cb canonical
+// (the carry planning of the generated schedule relies on their top limbs); result < 3q.
 FR_HD Fr fr_mul_const2_raw(const Fr& a, const Fr& ca, const Fr& cb) {
     Fr r;
 #include "fr_mulc2_gen.inc"

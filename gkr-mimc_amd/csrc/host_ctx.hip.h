@@ -76,6 +76,8 @@ struct Ctx {
     uint4* h_small = nullptr;                  // pinned
     Fr* d_q = nullptr;                         // qPrime coordinates + seeds staging
     size_t d_q_cap = 0;
+    unsigned long long* h_tail = nullptr;      // host-mapped: the tables of the round after which the host takes over (GKRHIP_HOST_TAIL)
+    unsigned long long* d_tail = nullptr;
     unsigned int* h_bad = nullptr;             // host-mapped: set by k_aos_to_planes when an uploaded element is >= q
     unsigned int* d_bad = nullptr;
     int max_grid = 2048;
@@ -202,6 +204,8 @@ int fail(const char* fmt, ...) {
     } while (0)
 
 const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
+const int kHostTailMax = 6;       // the host can take over from 2^6 pairs on (GKRHIP_HOST_TAIL <= 6)
+const size_t kTailWords = (size_t)4 * 4 * (2 << kHostTailMax);   // two tables of 2P entries, P <= 2^(kHostTailMax+1), 4 u64 each
 const int kRaccWords = 128;       // shared accumulator / host hand-off buffer: 72 (fused rounds) or up to 81 (nine evaluations) + 16 tail words
 int lane_alloc();
 
@@ -263,6 +267,8 @@ int lane_alloc() {
     cx().seq = 0;
     HIPCHK(hipMalloc(&cx().d_counter, 64));
     HIPCHK(hipMemset(cx().d_counter, 0, 64));
+    HIPCHK(hipHostMalloc(&cx().h_tail, kTailWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_tail, cx().h_tail, 0));
     HIPCHK(hipHostMalloc(&cx().h_bad, 64, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_bad, cx().h_bad, 0));
     *cx().h_bad = 0;
@@ -282,6 +288,8 @@ void lane_free() {
     if (cx().d_q) (void)hipFree(cx().d_q);
     cx().d_q = nullptr;
     cx().d_q_cap = 0;
+    if (cx().h_tail) (void)hipHostFree(cx().h_tail);
+    cx().h_tail = cx().d_tail = nullptr;
     if (cx().h_bad) (void)hipHostFree(cx().h_bad);
     cx().h_bad = cx().d_bad = nullptr;
     // the exchange buffers of a communicator lane

@@ -45,6 +45,74 @@ int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int 
     return 0;
 }
 
+inline E fold2(const E& lo, const E& hi, const E& r) { return hfr::add(lo, hfr::mul(hfr::sub(hi, lo), r)); }
+
+// ---- the last rounds of a single-point cipher sumcheck on the host ----------------------------------------------
+// A round of P <= 2^6 pairs is a launch-latency-bound kernel (a lone wave: ~25 us plus ~8 us of launch and hand-off)
+// for a few microseconds of arithmetic, so from GKRHIP_HOST_TAIL pairs on the host runs the rounds itself on the two
+// tables the last device round exported (cipher_round.hip.h, tail_tables): same monomial sums, same coefficients,
+// same transcript.  K and S hold 2^mm entries (table convention: round binds the top index bit); q[0:mm] are the
+// remaining coordinates; seed multiplies every eq weight.  On return K[0], S[0] are the fully folded values.
+void host_cipher_rounds(const E& ark, int mm, std::vector<E>& K, std::vector<E>& S, const E* q, const E& seed, E& c, E* proof,
+                        E* chal, E* claim, bool* claim_known) {
+    static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
+    for (int k = 0; k < mm; k++) {
+        const size_t P = (size_t)1 << (mm - 1 - k);
+        // W(x) = seed * eq(q[k+1 : mm], bits(x)), x < P, by the reference's doubling (poly/eq.go:41-59)
+        std::vector<E> W(P);
+        W[0] = seed;
+        for (int i = 0; i < mm - 1 - k; i++) {
+            const E& qi = q[k + 1 + i];
+            for (size_t t = 0; t < ((size_t)1 << i); t++) {
+                const size_t J = t << (mm - 1 - k - i), JN = J + ((size_t)1 << (mm - 2 - k - i));
+                W[JN] = hfr::mul(qi, W[J]);
+                W[J] = hfr::sub(W[J], W[JN]);
+            }
+        }
+        const bool derive_m0 = claim && *claim_known;
+        E M[8];
+        for (int j = 0; j < 8; j++) M[j] = hfr::ZERO;
+        for (size_t x = 0; x < P; x++) {
+            const E u = hfr::add(hfr::add(K[x], S[x]), ark);
+            const E d = hfr::add(hfr::sub(K[x + P], K[x]), hfr::sub(S[x + P], S[x]));
+            const E u2 = hfr::mul(u, u), d2 = hfr::mul(d, d);
+            const E cub[4] = {hfr::mul(u2, u), hfr::mul(u2, d), hfr::mul(u, d2), hfr::mul(d2, d)};
+            const E x0 = hfr::mul(W[x], hfr::mul(u2, u2)), x1 = hfr::mul(W[x], hfr::mul(d2, d2));
+            for (int j = derive_m0 ? 1 : 0; j < 4; j++) M[j] = hfr::add(M[j], hfr::mul(x0, cub[j]));
+            for (int j = 0; j < 4; j++) M[4 + j] = hfr::add(M[4 + j], hfr::mul(x1, cub[j]));
+        }
+        E csp[8];
+        for (int j = derive_m0 ? 1 : 0; j < 8; j++) csp[j] = hfr::mul(c, hfr::mul(M[j], hfr::from_u64(binom7[j])));
+        if (derive_m0) {
+            E rest = csp[1];
+            for (int j = 2; j < 8; j++) rest = hfr::add(rest, csp[j]);
+            csp[0] = hfr::sub(*claim, hfr::mul(q[k], rest));
+        }
+        const E a0 = hfr::sub(hfr::ONE, q[k]);
+        const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
+        E* co = proof + (size_t)k * 9;
+        co[0] = hfr::mul(a0, csp[0]);
+        for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, csp[j]), hfr::mul(a1, csp[j - 1]));
+        co[8] = hfr::mul(a1, csp[7]);
+        const double t_h0 = now_ms();
+        const E r = hfr::mimc_hash(co, 9);
+        cx().prof.host_hash_ms += now_ms() - t_h0;
+        chal[k] = r;
+        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
+        if (claim) {
+            *claim = hfr::eval_univariate(co, 9, r);
+            *claim_known = true;
+        }
+        for (size_t x = 0; x < P; x++) {   // poly/multilin.go:26-36
+            K[x] = fold2(K[x], K[x + P], r);
+            S[x] = fold2(S[x], S[x + P], r);
+        }
+        K.resize(P);
+        S.resize(P);
+        cx().prof.rounds++;
+    }
+}
+
 // The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
 // q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
 // monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
@@ -110,7 +178,12 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
 
     static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
     E r_prev = hfr::ZERO;
-    for (int k = 0; k < m; k++) {
+    // GKRHIP_HOST_TAIL = h > 0: the device runs the rounds down to 2^(h+1) pairs, exports that round's tables and the
+    // host finishes (un-sharded rounds only: the sharded local rounds exchange device-produced words)
+    const int h_tail = (!collective && cx().host_tail > 0 && m >= cx().host_tail + 2) ? std::min(cx().host_tail, kHostTailMax) : 0;
+    const int k_export = h_tail ? m - 2 - h_tail : -1;      // round whose tables go to the host
+    const int m_dev = h_tail ? k_export + 1 : m;             // rounds on the device
+    for (int k = 0; k < m_dev; k++) {
         const size_t P = n >> (k + 1);
         const int gk = threads_log2(k);
         const int lj = m - 1 - k - gk;                 // log2(iterations)
@@ -140,6 +213,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.ark = to_dev(ark);
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;
+        a.tail_tables = k == k_export ? cx().d_tail : nullptr;
         const RoundTargets tg = round_targets(collective);
         a.host_out = tg.out;
         a.host_flag = tg.flag;
@@ -157,7 +231,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_l0 = now_ms();
         // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
         const bool lat = cx().lat_mode == 2 || (cx().lat_mode == 1 && lj == 0);
-        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat;
+        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat && k != k_export;   // only the plain kernels export
         const bool late = wide && lj >= cx().wt_late_lj;  // the lane weight multiplies the sums after the loop: 8 products per lane
         if (wide) {
             if (fold) {
@@ -215,6 +289,21 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             *claim_known = true;
         }
         if (k == m - 1) memcpy(tail, words + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
+        if (k == k_export) {
+            // the exported tables (2P entries each) folded with this round's challenge are the host's starting point
+            const E* tt = (const E*)cx().h_tail;
+            std::vector<E> Kh(P), Sh(P);
+            for (size_t x = 0; x < P; x++) {
+                Kh[x] = fold2(tt[x], tt[x + P], r);
+                Sh[x] = fold2(tt[2 * P + x], tt[3 * P + x], r);
+            }
+            const int mm = m - 1 - k;                  // variables left
+            host_cipher_rounds(ark, mm, Kh, Sh, q + k + 1, seed, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim, claim_known);
+            // hand back in the shape the device path uses: the caller folds (lo, hi) with r_last
+            tail[0] = tail[1] = Kh[0];
+            tail[2] = tail[3] = Sh[0];
+            r_prev = chal[m - 1];
+        }
         cx().prof.host_launch_ms += t_l1 - t_l0;
         cx().prof.host_wait_ms += t_w - t_l1;
         cx().prof.host_other_ms += t_h0 - t_w;
@@ -233,8 +322,6 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     table_release(&ss);
     return 0;
 }
-
-inline E fold2(const E& lo, const E& hi, const E& r) { return hfr::add(lo, hfr::mul(hfr::sub(hi, lo), r)); }
 
 // host elements -> a small device table (boundary helper for the gathered shard tables)
 int small_table(DevTable* t, const std::vector<E>& v) {
@@ -278,15 +365,22 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
             k2[r] = all[2 * r];
             s2[r] = all[2 * r + 1];
         }
-        ScopedTable K2, S2;
-        CHK(small_table(&K2, k2));
-        CHK(small_table(&S2, s2));
-        CHK(cipher_rounds(ark, gamma, &K2, &S2, q + m1, hfr::ONE, false, c, proof + (size_t)9 * m1, challenges + m1, tail,
-                          r_last, claim_p, &claim_known));
-        kv = fold2(tail[0], tail[1], r_last);
-        sv = fold2(tail[2], tail[3], r_last);
-        table_release(&K2);
-        table_release(&S2);
+        if (cx().host_tail > 0) {
+            // the gathered tables are host data already and the rounds are tiny: no device round trip at all
+            host_cipher_rounds(ark, gamma, k2, s2, q + m1, hfr::ONE, c, proof + (size_t)9 * m1, challenges + m1, claim_p, &claim_known);
+            kv = k2[0];
+            sv = s2[0];
+        } else {
+            ScopedTable K2, S2;
+            CHK(small_table(&K2, k2));
+            CHK(small_table(&S2, s2));
+            CHK(cipher_rounds(ark, gamma, &K2, &S2, q + m1, hfr::ONE, false, c, proof + (size_t)9 * m1, challenges + m1, tail,
+                              r_last, claim_p, &claim_known));
+            kv = fold2(tail[0], tail[1], r_last);
+            sv = fold2(tail[2], tail[3], r_last);
+            table_release(&K2);
+            table_release(&S2);
+        }
     }
     final_claims[0] = c;
     final_claims[1] = kv;

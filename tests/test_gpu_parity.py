@@ -305,6 +305,17 @@ def test_round_kernel_variants(gk):
     _run_case({"GKRHIP_LAT": "2", "GKRHIP_GMAX": "8"}, "1,4,9,12,13")
 
 
+def test_host_tail_rounds(gk):
+    """GKRHIP_HOST_TAIL = h: the device exports the tables of the round with 2^(h+1) pairs and the host runs the last
+    h+1 rounds of every single-point cipher sumcheck itself -- the same transcript for every h, also with the
+    throughput kernel as the exporting round and when the sumcheck is too short to have a device round at all."""
+    for h in ("1", "3", "4", "6"):
+        _run_case({"GKRHIP_HOST_TAIL": h}, "1,2,3,5,8,9,12")
+    _run_case({"GKRHIP_HOST_TAIL": "5", "GKRHIP_LAT": "0"}, "7,8,11")
+    _run_case({"GKRHIP_HOST_TAIL": "2", "GKRHIP_GMAX": "8", "GKRHIP_CLAIM_TRICK": "0"}, "4,10,13")
+    _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "4"})      # sharded: the gathered tail rounds on the host
+
+
 def test_round_kernel_deferred_reduction_variants(gk):
     """The deferred-reduction round kernel (wide LDS/VGPR accumulators, one reduction per lane and sum) against the
     oracle with the lane weight applied after the loop from 2 pairs per lane on, never, and with the kernel

@@ -11,14 +11,49 @@ statement (split only where the 30-operand limit of inline asm would be exceeded
 branch (host compilers) executes the identical schedule with u64 arithmetic; the CPU unit test of
 the schedule exercises it.
 
-acc = (lo,hi) 64-bit pair + ovf word.  Every product can carry out of the 64-bit pair (a shifted-in
-accumulator of up to ~2^37 plus a product of up to 2^64-2^33+1), so every MAD is followed by an
-ADDC; the first ADDC of a column is the e64 form 0 + 0 + carry, which initialises ovf without a
-register zeroing.  Column 0 starts from the exact product a0*b0 (no carry possible).
+acc = (lo,hi) 64-bit pair + ovf word.  A MAD needs its ADDC only when the running column sum can reach
+2^64.  The generator bounds that sum statically -- limbs of a, b and m_i up to 2^32-1 (or the tighter top limb a
+precondition gives), the limbs of q exact -- orders each column's products by their largest possible value and
+leaves the ADDC out for the leading products whose cumulative bound stays below 2^64 (BN254's q has four limbs
+below 2^31, so three of a column's m_i*q_j products usually fit): 33 of the 136 ADDCs of a product disappear.
+The first ADDC a column does execute is the e64 form 0 + 0 + carry, which initialises ovf without a register
+zeroing; a column that needs none hands over acc >> 32.  The portable branch runs the identical schedule
+(FR_MADN = multiply-add without carry tracking; with -DFR_CHECK_SKIPS it counts a wrap-around as a failure, which
+is how the bounds are unit-tested on the CPU).
 """
 import os
 
 NL = 8
+M32 = (1 << 32) - 1
+QL = [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72]
+Q_INT = sum(v << (32 * i) for i, v in enumerate(QL))
+TOP_LT3Q = (3 * Q_INT - 1) >> 224        # largest top limb of a value below 3q
+TOP_LTQ = (Q_INT - 1) >> 224             # ... of a canonical value
+
+
+def opmax(o, bounds):
+    k, i = o
+    if k == "q":
+        return QL[i]
+    if k == "one":
+        return 1
+    return bounds.get((k, i), M32)
+
+
+def plan(t_max, prods, bounds):
+    """Order a column's products (smallest bound first) and decide which need their ADDC.
+    Returns ([(x, y, track)], bound of the column sum)."""
+    items = sorted(prods, key=lambda p: opmax(p[0], bounds) * opmax(p[1], bounds))
+    s, out, tracking = t_max, [], False
+    for x, y in items:
+        pm = opmax(x, bounds) * opmax(y, bounds)
+        if not tracking and s + pm < (1 << 64):
+            out.append((x, y, False))
+        else:
+            tracking = True
+            out.append((x, y, True))
+        s += pm
+    return out, s
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                    "gkr-mimc_amd", "csrc", "fr_mont_gen.inc")
 
@@ -30,47 +65,52 @@ def cexpr(o):
     return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]", "ca": "ca.v[%d]", "cb": "cb.v[%d]"}[k] % i
 
 
-def emit_asm(products, pos0):
-    """One asm statement; pos0 = index of its first product within the column."""
+def emit_asm(products, ovf_live):
+    """One asm statement for [(x, y, track)]; ovf_live = the column's ovf word has been initialised already.
+    Returns (text, ovf_live afterwards)."""
     ops = []
-    for x, y in products:
+    for x, y, _t in products:
         for o in (x, y):
             if o not in ops and o[0] != "one":
                 ops.append(o)
-    names = {o: "%%%d" % (2 + n) for n, o in enumerate(ops)}
+    uses_ovf = any(t for _x, _y, t in products)
+    base = 2 if uses_ovf else 1
+    names = {o: "%%%d" % (base + n) for n, o in enumerate(ops)}
     names[("one", 0)] = "1"          # inline constant
     lines = []
     inits = False
-    for k, (x, y) in enumerate(products):
-        pos = pos0 + k
+    for x, y, track in products:
         lines.append("v_mad_u64_u32 %%0, vcc, %s, %s, %%0" % (names[x], names[y]))
-        if pos == 0:
+        if not track:
+            continue
+        if not ovf_live:
             lines.append("v_addc_co_u32_e64 %1, vcc, 0, 0, vcc")
             inits = True
+            ovf_live = True
         else:
             lines.append("v_addc_co_u32_e32 %1, vcc, 0, %1, vcc")
-    ovf = '"=&v"(ovf)' if inits else '"+v"(ovf)'
+    outs = '"+v"(acc)'
+    if uses_ovf:
+        outs += ', "=&v"(ovf)' if inits else ', "+v"(ovf)'
     ins = ", ".join('"%s"(%s)' % ("s" if o[0] in ("q", "ca", "cb") else "v", cexpr(o)) for o in ops)
     body = '"' + '\\n\\t"\n        "'.join(lines) + '"'
-    assert len(ops) + 2 <= 30
-    return '    asm(%s\n        : "+v"(acc), %s\n        : %s\n        : "vcc");\n' % (body, ovf, ins)
+    assert len(ops) + base <= 30
+    return '    asm(%s\n        : %s\n        : %s\n        : "vcc");\n' % (body, outs, ins), ovf_live
 
 
-def emit_portable(products, pos0):
+def emit_portable(products):
     s = ""
-    for k, (x, y) in enumerate(products):
-        if pos0 + k == 0:
-            s += "    ovf = 0;\n"
-        s += "    FR_MADC(acc, ovf, %s, %s);\n" % (cexpr(x), cexpr(y))
+    for x, y, track in products:
+        s += "    %s(acc, %s%s, %s);\n" % ("FR_MADC" if track else "FR_MADN", "ovf, " if track else "", cexpr(x), cexpr(y))
     return s
 
 
-def split(products, pos0, limit=30):
+def split(products, limit=30):
     chunks, cur = [], []
     for p in products:
         trial = cur + [p]
         ops = set()
-        for x, y in trial:
+        for x, y, _t in trial:
             ops.add(x)
             ops.add(y)
         if len(ops) + 2 > limit and cur:
@@ -83,8 +123,33 @@ def split(products, pos0, limit=30):
     return chunks
 
 
+def column(dev, host, t_max, prods, bounds, last=None):
+    """Emit one column: the planned products, then (optionally) the product `last` that can only be formed once the
+    others are in (m_c * q_0).  Returns (dev, host, bound of the column sum, whether ovf is live)."""
+    planned, s_max = plan(t_max, prods, bounds)
+    live = False
+    host += "    ovf = 0;\n"
+    for ch in split(planned):
+        t, live = emit_asm(ch, live)
+        dev += t
+        host += emit_portable(ch)
+    if last is not None:
+        pm = opmax(last[1], bounds) * opmax(last[2], bounds)
+        track = s_max + pm >= (1 << 64)
+        t = last[0]
+        e, live = emit_asm([(last[1], last[2], track)], live)
+        dev += t + e
+        host += t + emit_portable([(last[1], last[2], track)])
+        s_max += pm
+    if not live:
+        dev += "    ovf = 0;\n"
+    return dev, host, s_max
+
+
 def gen_mul():
+    bounds = {}
     dev = host = "    u64 acc = (u64)a.v[0] * b.v[0];\n    u32 ovf;\n"
+    t_max = M32 * M32
     for c in range(2 * NL - 1):
         prods = []
         lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
@@ -95,16 +160,9 @@ def gen_mul():
             if c < NL and i == c:
                 continue  # m_c * q_0 is added once m_c is known
             prods.append((("m", i), ("q", c - i)))
-        pos = 0
-        for ch in split(prods, pos):
-            dev += emit_asm(ch, pos)
-            host += emit_portable(ch, pos)
-            pos += len(ch)
-        if c < NL:
-            t = "    const u32 m%d = (u32)acc * FR_QINV32;\n" % c
-            dev += t + emit_asm([(("m", c), ("q", 0))], pos)
-            host += t + emit_portable([(("m", c), ("q", 0))], pos)
-        else:
+        last = ("    const u32 m%d = (u32)acc * FR_QINV32;\n" % c, ("m", c), ("q", 0)) if c < NL else None
+        dev, host, s_max = column(dev, host, t_max, prods, bounds, last)
+        if c >= NL:
             host += "    r.v[%d] = (u32)acc;\n" % (c - NL)
             # device: copy the finished limb out of the accumulator pair with an explicit move, otherwise
             # hipcc keeps every result limb in the low half of its own 64-bit register tuple (2x VGPRs)
@@ -112,6 +170,7 @@ def gen_mul():
         sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
         dev += sh
         host += sh
+        t_max = s_max >> 32
     fin = "    r.v[%d] = (u32)acc;\n" % (NL - 1)
     dfin = '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (NL - 1)
     return dev + dfin, host + fin
@@ -130,35 +189,45 @@ def cexpr2(o, ch):
     return {"a": "a%d.v[%d]", "b": "b%d.v[%d]", "m": "m%d_%d"}[k] % (ch, i)
 
 
-def emit_asm2(products, pos0):
+def emit_asm2(products, ovf_live):
     ops = []          # (operand, chain) ; q operands are shared (chain None)
     def key(o, ch):
         return (o, None) if o[0] == "q" else (o, ch)
-    for x, y in products:
+    for x, y, _t in products:
         for ch in (0, 1):
             for o in (x, y):
                 if key(o, ch) not in ops:
                     ops.append(key(o, ch))
-    base = 5      # %0 acc0, %1 ovf0, %2 acc1, %3 ovf1, %4 sgpr carry pair of chain 1
+    uses_ovf = any(t for _x, _y, t in products)
+    # outputs: %0 acc0, [ovf0], acc1, [ovf1], sgpr carry pair of chain 1
+    if uses_ovf:
+        n_acc0, n_ovf0, n_acc1, n_ovf1, n_sc, base = "%0", "%1", "%2", "%3", "%4", 5
+    else:
+        n_acc0, n_ovf0, n_acc1, n_ovf1, n_sc, base = "%0", None, "%1", None, "%2", 3
     names = {k: "%%%d" % (base + n) for n, k in enumerate(ops)}
     lines = []
     inits = False
-    for k, (x, y) in enumerate(products):
-        pos = pos0 + k
-        lines.append("v_mad_u64_u32 %%0, vcc, %s, %s, %%0" % (names[key(x, 0)], names[key(y, 0)]))
-        lines.append("v_mad_u64_u32 %%2, %%4, %s, %s, %%2" % (names[key(x, 1)], names[key(y, 1)]))
-        if pos == 0:
-            lines.append("v_addc_co_u32_e64 %1, vcc, 0, 0, vcc")
-            lines.append("v_addc_co_u32_e64 %3, %4, 0, 0, %4")
+    for x, y, track in products:
+        lines.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (n_acc0, names[key(x, 0)], names[key(y, 0)], n_acc0))
+        lines.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (n_acc1, n_sc, names[key(x, 1)], names[key(y, 1)], n_acc1))
+        if not track:
+            continue
+        if not ovf_live:
+            lines.append("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % n_ovf0)
+            lines.append("v_addc_co_u32_e64 %s, %s, 0, 0, %s" % (n_ovf1, n_sc, n_sc))
             inits = True
+            ovf_live = True
         else:
-            lines.append("v_addc_co_u32_e32 %1, vcc, 0, %1, vcc")
-            lines.append("v_addc_co_u32_e64 %3, %4, 0, %3, %4")
-    ovf = '"=&v"(ovf0), "+v"(acc1), "=&v"(ovf1)' if inits else '"+v"(ovf0), "+v"(acc1), "+v"(ovf1)'
+            lines.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (n_ovf0, n_ovf0))
+            lines.append("v_addc_co_u32_e64 %s, %s, 0, %s, %s" % (n_ovf1, n_sc, n_ovf1, n_sc))
+    if uses_ovf:
+        outs = ('"+v"(acc0), "=&v"(ovf0), "+v"(acc1), "=&v"(ovf1)' if inits else '"+v"(acc0), "+v"(ovf0), "+v"(acc1), "+v"(ovf1)')
+    else:
+        outs = '"+v"(acc0), "+v"(acc1)'
     ins = ", ".join('"%s"(%s)' % ("s" if o[0] == "q" else "v", cexpr2(o, ch)) for (o, ch) in ops)
     body = '"' + '\\n\\t"\n        "'.join(lines) + '"'
     assert len(ops) + base <= 30, len(ops)
-    return '    asm(%s\n        : "+v"(acc0), %s, "=&s"(sc)\n        : %s\n        : "vcc");\n' % (body, ovf, ins)
+    return '    asm(%s\n        : %s, "=&s"(sc)\n        : %s\n        : "vcc");\n' % (body, outs, ins), ovf_live
 
 
 def split2(products, limit=30):
@@ -166,7 +235,7 @@ def split2(products, limit=30):
     for p in products:
         trial = cur + [p]
         ops = set()
-        for x, y in trial:
+        for x, y, _t in trial:
             for o in (x, y):
                 if o[0] == "q":
                     ops.add((o, None))
@@ -184,8 +253,10 @@ def split2(products, limit=30):
 
 
 def gen_mul2():
+    bounds = {}
     dev = ("    u64 acc0 = (u64)a0.v[0] * b0.v[0], acc1 = (u64)a1.v[0] * b1.v[0];\n"
            "    u32 ovf0, ovf1;\n    unsigned long long sc;\n")
+    t_max = M32 * M32
     for c in range(2 * NL - 1):
         prods = []
         lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
@@ -196,17 +267,25 @@ def gen_mul2():
             if c < NL and i == c:
                 continue
             prods.append((("m", i), ("q", c - i)))
-        pos = 0
-        for ch in split2(prods):
-            dev += emit_asm2(ch, pos)
-            pos += len(ch)
+        planned, s_max = plan(t_max, prods, bounds)
+        live = False
+        for ch in split2(planned):
+            t, live = emit_asm2(ch, live)
+            dev += t
         if c < NL:
+            pm = M32 * QL[0]
+            track = s_max + pm >= (1 << 64)
             dev += "    const u32 m0_%d = (u32)acc0 * FR_QINV32, m1_%d = (u32)acc1 * FR_QINV32;\n" % (c, c)
-            dev += emit_asm2([(("m", c), ("q", 0))], pos)
+            t, live = emit_asm2([(("m", c), ("q", 0), track)], live)
+            dev += t
+            s_max += pm
         else:
             dev += '    r0.v[%d] = FR_LIMB_COPY((u32)acc0);\n' % (c - NL)
             dev += '    r1.v[%d] = FR_LIMB_COPY((u32)acc1);\n' % (c - NL)
+        if not live:
+            dev += "    ovf0 = 0;\n    ovf1 = 0;\n"
         dev += "    acc0 = (acc0 >> 32) | ((u64)ovf0 << 32);\n    acc1 = (acc1 >> 32) | ((u64)ovf1 << 32);\n"
+        t_max = s_max >> 32
     dev += '    r0.v[%d] = FR_LIMB_COPY((u32)acc0);\n' % (NL - 1)
     dev += '    r1.v[%d] = FR_LIMB_COPY((u32)acc1);\n' % (NL - 1)
     return dev
@@ -219,29 +298,30 @@ def gen_mul2():
 # accumulator limb A[c] with one more MAD (x1), so the cost is 64+15 MAD/ADDC pairs against 136.
 # ------------------------------------------------------------------------------------------------
 def gen_mac_wide():
-    """Device: the plain product a*b column by column (64 MAD/ADDC pairs, as in the multiplication without its
-    Montgomery half); every finished limb is added straight into the accumulator limb by ONE carry-chained
-    add whose carry lives in an SGPR pair (VCC belongs to the column arithmetic).  Host: same columns, u64."""
+    """Device: the plain product a*b column by column (64 MADs, as in the multiplication without its Montgomery
+    half); every finished limb is added straight into the accumulator limb by ONE carry-chained add whose carry
+    lives in an SGPR pair (VCC belongs to the column arithmetic).  Host: same columns, u64.
+    PRECONDITION a, b < 3q (every call site multiplies lazy Montgomery products or canonical elements): the top
+    limbs are below 2^31.2, so the first product of the columns 7..14 needs no ADDC."""
+    bounds = {("a", NL - 1): TOP_LT3Q, ("b", NL - 1): TOP_LT3Q}
     dev = "    u64 acc = (u64)a.v[0] * b.v[0];\n    u32 ovf;\n    unsigned long long sc;\n"
     dev += '    asm("v_add_co_u32_e64 %0, %1, %0, %2" : "+v"(A[0]), "=&s"(sc) : "v"((u32)acc));\n'
     dev += "    acc >>= 32;\n"
     host = "    u64 acc = (u64)a.v[0] * b.v[0];\n    u32 ovf;\n    u64 cy;\n"
     host += "    cy = (u64)A[0] + (u32)acc;\n    A[0] = (u32)cy;\n    cy >>= 32;\n    acc >>= 32;\n"
+    t_max = (M32 * M32) >> 32
     for c in range(1, 2 * NL - 1):
         lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
         prods = []
         for i in range(lo_i, hi_i + 1):
             prods.append((("a", i), ("b", c - i)))
-        pos = 0
-        for ch in split(prods, pos):
-            dev += emit_asm(ch, pos)
-            host += emit_portable(ch, pos)
-            pos += len(ch)
+        dev, host, s_max = column(dev, host, t_max, prods, bounds)
         dev += '    asm("v_addc_co_u32_e64 %%0, %%1, %%0, %%2, %%1" : "+v"(A[%d]), "+s"(sc) : "v"((u32)acc));\n' % c
         host += "    cy += (u64)A[%d] + (u32)acc;\n    A[%d] = (u32)cy;\n    cy >>= 32;\n" % (c, c)
         sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
         dev += sh
         host += sh
+        t_max = s_max >> 32
     # the last column's carry (acc < 2^32 now) and the chain carry go into limbs 15 and 16
     dev += '    asm("v_addc_co_u32_e64 %0, %1, %0, %2, %1" : "+v"(A[15]), "+s"(sc) : "v"((u32)acc));\n'
     dev += '    asm("v_addc_co_u32_e64 %0, %1, %0, 0, %1" : "+v"(A[16]), "+s"(sc));\n'
@@ -256,9 +336,13 @@ def gen_mac_wide():
 # so only FOUR Montgomery steps are needed: 32 + 32 + 32 limb products instead of 64 + 64.  Result < 3q.
 # ------------------------------------------------------------------------------------------------
 def gen_mul_const2():
+    """PRECONDITION a < 3q; ca, cb canonical (the host and the pyramid kernel store them reduced): the limbs a_7,
+    ca_7, cb_7 are small, which the carry planning uses."""
     H = NL // 2
+    bounds = {("a", NL - 1): TOP_LT3Q, ("ca", NL - 1): TOP_LTQ, ("cb", NL - 1): TOP_LTQ}
     dev = host = "    u64 acc = (u64)a.v[0] * ca.v[0];\n    u32 ovf;\n"
     ncol = H + NL - 1            # columns 0 .. 10 carry products; limbs H .. H+7 are the result
+    t_max = M32 * M32
     for c in range(ncol):
         prods = []
         for i in range(H):
@@ -271,28 +355,15 @@ def gen_mul_const2():
             j = c - i
             if 0 <= j < NL and not (c < H and i == c):
                 prods.append((("m", i), ("q", j)))
-        pos = 0
-        # column 0 starts from the exact product a0*ca0: its first listed product must use the carry-tracking form
-        first = True
-        for ch in split(prods, pos):
-            if c == 0 and first:
-                dev += emit_asm(ch, 0)
-                host += emit_portable(ch, 0)
-            else:
-                dev += emit_asm(ch, pos if pos else (0 if c else 1))
-                host += emit_portable(ch, pos if pos else (0 if c else 1))
-            first = False
-            pos += len(ch)
-        if c < H:
-            t = "    const u32 m%d = (u32)acc * FR_QINV32;\n" % c
-            dev += t + emit_asm([(("m", c), ("q", 0))], max(pos, 1))
-            host += t + emit_portable([(("m", c), ("q", 0))], max(pos, 1))
-        else:
+        last = ("    const u32 m%d = (u32)acc * FR_QINV32;\n" % c, ("m", c), ("q", 0)) if c < H else None
+        dev, host, s_max = column(dev, host, t_max, prods, bounds, last)
+        if c >= H:
             host += "    r.v[%d] = (u32)acc;\n" % (c - H)
             dev += '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (c - H)
         sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
         dev += sh
         host += sh
+        t_max = s_max >> 32
     fin = "    r.v[%d] = (u32)acc;\n" % (NL - 1)
     dfin = '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (NL - 1)
     return dev + dfin, host + fin
