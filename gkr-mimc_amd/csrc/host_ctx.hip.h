@@ -100,7 +100,7 @@ struct Ctx {
     int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
-    int host_tail = 0;                         // GKRHIP_HOST_TAIL: log2 of the pairs from which the last rounds run on the host (0: never)
+    int host_tail = 5;                         // GKRHIP_HOST_TAIL: the rounds with at most 2^h pairs run on the host (0: never); measured: -5 % single-proof latency, +1.5 % throughput
     hfr::Lagrange* lag = nullptr;
     Profile prof;
     LaneColl lc;
@@ -205,7 +205,7 @@ int fail(const char* fmt, ...) {
 
 const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
 const int kHostTailMax = 6;       // the host can take over from 2^6 pairs on (GKRHIP_HOST_TAIL <= 6)
-const size_t kTailWords = (size_t)4 * 4 * (2 << kHostTailMax);   // two tables of 2P entries, P <= 2^(kHostTailMax+1), 4 u64 each
+const size_t kTailWords = (size_t)GKR_MAX_ARITY * 4 * 2 * (2 << kHostTailMax);   // up to four tables of 2P entries, P <= 2^(kHostTailMax+1), 4 u64 each
 const int kRaccWords = 128;       // shared accumulator / host hand-off buffer: 72 (fused rounds) or up to 81 (nine evaluations) + 16 tail words
 int lane_alloc();
 

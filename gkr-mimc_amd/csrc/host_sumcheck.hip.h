@@ -388,6 +388,56 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     return 0;
 }
 
+// The same for a linear gate (host_cipher_rounds' counterpart): T[t] hold 2^mm entries, g.mask selects the tables of the sum.
+void host_linear_rounds(const GateDesc& g, const E& ark, int mm, std::vector<std::vector<E>>& T, const E* q, const E& seed, E& c,
+                        E* proof, E* chal, E* claim, bool* claim_known) {
+    for (int k = 0; k < mm; k++) {
+        const size_t P = (size_t)1 << (mm - 1 - k);
+        std::vector<E> W(P);
+        W[0] = seed;
+        for (int i = 0; i < mm - 1 - k; i++) {
+            const E& qi = q[k + 1 + i];
+            for (size_t t = 0; t < ((size_t)1 << i); t++) {
+                const size_t J = t << (mm - 1 - k - i), JN = J + ((size_t)1 << (mm - 2 - k - i));
+                W[JN] = hfr::mul(qi, W[J]);
+                W[J] = hfr::sub(W[J], W[JN]);
+            }
+        }
+        const bool derive_m0 = claim && *claim_known;
+        E m0 = hfr::ZERO, m1 = hfr::ZERO;
+        for (size_t x = 0; x < P; x++) {
+            E u = ark, d = hfr::ZERO;
+            for (int t = 0; t < g.n_in; t++)
+                if ((g.mask >> t) & 1u) {
+                    u = hfr::add(u, T[t][x]);
+                    d = hfr::add(d, hfr::sub(T[t][x + P], T[t][x]));
+                }
+            if (!derive_m0) m0 = hfr::add(m0, hfr::mul(W[x], u));
+            m1 = hfr::add(m1, hfr::mul(W[x], d));
+        }
+        const E cm1 = hfr::mul(c, m1);
+        const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, m0);
+        const E a0 = hfr::sub(hfr::ONE, q[k]);
+        const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
+        E* co = proof + (size_t)k * 3;
+        co[0] = hfr::mul(a0, cm0);
+        co[1] = hfr::add(hfr::mul(a0, cm1), hfr::mul(a1, cm0));
+        co[2] = hfr::mul(a1, cm1);
+        const E r = hfr::mimc_hash(co, 3);
+        chal[k] = r;
+        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
+        if (claim) {
+            *claim = hfr::eval_univariate(co, 3, r);
+            *claim_known = true;
+        }
+        for (int t = 0; t < g.n_in; t++) {
+            for (size_t x = 0; x < P; x++) T[t][x] = fold2(T[t][x], T[t][x + P], r);
+            T[t].resize(P);
+        }
+        cx().prof.rounds++;
+    }
+}
+
 // ---- single-point sumcheck of a linear gate: one fused launch per round (linear_round.hip.h) ------------------
 // Tables X[0..arity) of 2^m entries (m >= 1), coordinates q[0:m]; g.mask selects the tables that enter the gate's sum.
 // `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the two sums are added over the
@@ -433,7 +483,10 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     if (collective) CHK(coll_buffers(256));
     const E two128 = {{0, 0, 1, 0}};
     E r_prev = hfr::ZERO;
-    for (int k = 0; k < m; k++) {
+    const int h_tail = (!collective && cx().host_tail > 0 && m >= cx().host_tail + 2) ? std::min(cx().host_tail, kHostTailMax) : 0;
+    const int k_export = h_tail ? m - 2 - h_tail : -1;      // see cipher_rounds
+    const int m_dev = h_tail ? k_export + 1 : m;
+    for (int k = 0; k < m_dev; k++) {
         const size_t P = n >> (k + 1);
         const int gk = std::min(g_lin, m - 1 - k);
         const int lj = m - 1 - k - gk;
@@ -459,6 +512,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         a.sum_mask = g.mask;
         a.racc = cx().d_racc;
         a.counter = cx().d_counter;
+        a.tail_tables = k == k_export ? cx().d_tail : nullptr;
         const RoundTargets tg = round_targets(collective);
         a.host_out = tg.out;
         a.host_flag = tg.flag;
@@ -496,6 +550,15 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         }
         if (k == m - 1) memcpy(tail, cx().h_round + GKR_LR_WORDS, (size_t)2 * arity * sizeof(E));   // written by the P == 1 launch
         cx().prof.rounds++;
+        if (k == k_export) {
+            const E* tt = (const E*)cx().h_tail;
+            std::vector<std::vector<E>> Th(arity, std::vector<E>(P));
+            for (int t = 0; t < arity; t++)
+                for (size_t x = 0; x < P; x++) Th[t][x] = fold2(tt[(size_t)t * 2 * P + x], tt[(size_t)t * 2 * P + x + P], r);
+            host_linear_rounds(g, ark, m - 1 - k, Th, q + k + 1, seed, c, proof + (size_t)3 * (k + 1), chal + k + 1, claim, claim_known);
+            for (int t = 0; t < arity; t++) tail[2 * t] = tail[2 * t + 1] = Th[t][0];
+            r_prev = chal[m - 1];
+        }
     }
     r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
@@ -529,17 +592,25 @@ int sumcheck_linear_fast(const GateDesc& g, const E& ark, int bN, const DevTable
     if (gamma > 0) {
         std::vector<E> all;
         CHK(coll_allgather(v, arity, all));
-        ScopedTable x2[GKR_MAX_ARITY];
-        const DevTable* X2[GKR_MAX_ARITY];
-        for (int t = 0; t < arity; t++) {
-            std::vector<E> col(shard.world);
-            for (int r = 0; r < shard.world; r++) col[r] = all[(size_t)r * arity + t];
-            CHK(small_table(&x2[t], col));
-            X2[t] = &x2[t];
+        if (cx().host_tail > 0) {
+            std::vector<std::vector<E>> Th(arity, std::vector<E>(shard.world));
+            for (int t = 0; t < arity; t++)
+                for (int r = 0; r < shard.world; r++) Th[t][r] = all[(size_t)r * arity + t];
+            host_linear_rounds(g, ark, gamma, Th, q + m1, hfr::ONE, c, proof + (size_t)3 * m1, challenges + m1, claim_p, &claim_known);
+            for (int t = 0; t < arity; t++) v[t] = Th[t][0];
+        } else {
+            ScopedTable x2[GKR_MAX_ARITY];
+            const DevTable* X2[GKR_MAX_ARITY];
+            for (int t = 0; t < arity; t++) {
+                std::vector<E> col(shard.world);
+                for (int r = 0; r < shard.world; r++) col[r] = all[(size_t)r * arity + t];
+                CHK(small_table(&x2[t], col));
+                X2[t] = &x2[t];
+            }
+            CHK(linear_rounds(g, ark, gamma, X2, q + m1, hfr::ONE, false, c, proof + (size_t)3 * m1, challenges + m1, tail, r_last,
+                              claim_p, &claim_known));
+            for (int t = 0; t < arity; t++) v[t] = fold2(tail[2 * t], tail[2 * t + 1], r_last);
         }
-        CHK(linear_rounds(g, ark, gamma, X2, q + m1, hfr::ONE, false, c, proof + (size_t)3 * m1, challenges + m1, tail, r_last,
-                          claim_p, &claim_known));
-        for (int t = 0; t < arity; t++) v[t] = fold2(tail[2 * t], tail[2 * t + 1], r_last);
     }
     final_claims[0] = c;
     for (int t = 0; t < arity; t++) final_claims[1 + t] = v[t];

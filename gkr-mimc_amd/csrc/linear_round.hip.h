@@ -32,6 +32,7 @@ struct LinearRoundArgs {
     unsigned int* host_flag;
     unsigned int seq;
     unsigned int need_m0;
+    unsigned long long* tail_tables;   // host-mapped, or nullptr: this round's tables (2P entries per table, 4 u64 each)
 };
 
 template <bool FOLD, bool HAS_WJ>
@@ -65,6 +66,14 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
                 if ((a.sum_mask >> t) & 1u) {
                     u = fr_add(u, lo);
                     d = fr_add(d, fr_sub(hi, lo));
+                }
+                if (a.tail_tables) {   // the host takes over after this round (GKRHIP_HOST_TAIL)
+                    unsigned long long* tt = a.tail_tables + 4 * (size_t)t * 2 * P;
+#pragma unroll
+                    for (int l = 0; l < 4; l++) {
+                        tt[4 * x + l] = (unsigned long long)lo.v[2 * l] | ((unsigned long long)lo.v[2 * l + 1] << 32);
+                        tt[4 * (x + P) + l] = (unsigned long long)hi.v[2 * l] | ((unsigned long long)hi.v[2 * l + 1] << 32);
+                    }
                 }
                 if (P == 1) {   // last round: the two remaining entries of each table go to the host (final fold there)
                     unsigned long long* tail = a.host_out + GKR_LR_WORDS + 8 * t;

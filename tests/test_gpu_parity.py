@@ -309,11 +309,13 @@ def test_host_tail_rounds(gk):
     """GKRHIP_HOST_TAIL = h: the device exports the tables of the round with 2^(h+1) pairs and the host runs the last
     h+1 rounds of every single-point cipher sumcheck itself -- the same transcript for every h, also with the
     throughput kernel as the exporting round and when the sumcheck is too short to have a device round at all."""
-    for h in ("1", "3", "4", "6"):
+    for h in ("0", "1", "3", "6"):     # 0: every round on the device (the default is 5)
         _run_case({"GKRHIP_HOST_TAIL": h}, "1,2,3,5,8,9,12")
+    _run_case({"GKRHIP_HOST_TAIL": "0"}, "2,9", circuit="gmimc")
+    _run_case({"GKRHIP_HOST_TAIL": "3"}, "3,9,11", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "5", "GKRHIP_LAT": "0"}, "7,8,11")
     _run_case({"GKRHIP_HOST_TAIL": "2", "GKRHIP_GMAX": "8", "GKRHIP_CLAIM_TRICK": "0"}, "4,10,13")
-    _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "4"})      # sharded: the gathered tail rounds on the host
+    _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "0"})      # sharded: the gathered tail rounds on the device
 
 
 def test_round_kernel_deferred_reduction_variants(gk):
@@ -829,7 +831,8 @@ def _run_shards(mode, world, sizes, env=None):
 def test_sharded_prover_matches_oracle(gk, world):
     """shard on the lowest index bits; bN from log2(world) (no local round at all) upwards."""
     g = world.bit_length() - 1
-    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10} if world < 8 else {3, 4, 8})))
+    # (8 processes time-sharing one GPU pay a process switch per rank and round, ~70 ms per round: two small sizes)
+    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10} if world < 8 else {3, 6})))
 
 
 def test_sharded_prover_generic_path_and_small_budget(gk):
@@ -847,7 +850,7 @@ def test_sharded_prover_full_size_digests(gk):
     """BASELINE config 3's size through the sharded driver: 8 ranks time-sharing the GPU (2^21-entry shards, the
     per-round exchange over shared memory) at bN = 24, and 2 ranks at bN = 22; the transcript must be the one the C
     oracle produced for the un-sharded proof (tests/golden/gkr_mimc_big_digests.json)."""
-    _run_shards("shm", 8, "24", {"GKR_TEST_DIGEST": "1"})
+    _run_shards("shm", 8, "24", {"GKR_TEST_DIGEST": "1"})      # ~2.5 min: 2208 rounds x 8 process switches on the one GPU
     _run_shards("shm", 2, "22", {"GKR_TEST_DIGEST": "1"})
 
 

@@ -19,6 +19,16 @@ for step in "$@"; do
     rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
     rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
     shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
+    w8) for v in default spin25; do
+          E=""; [ $v = spin25 ] && E="GKRHIP_WAIT_SPIN_US=25"
+          ( time env $E python - <<'PY'
+import subprocess, sys, os, uuid
+here = os.path.join(os.getcwd(), "tests")
+name = "/gkrhip_t_" + uuid.uuid4().hex[:10]
+ps = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), "shm", "8", str(r), name, "6"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
+print([p.wait() for p in ps])
+PY
+          ) > $OUT/w8_$v.log 2>&1; tail -4 $OUT/w8_$v.log; done ;;
     *) echo "unknown step $step" ;;
   esac
 done
