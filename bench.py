@@ -305,7 +305,7 @@ def main():
         # events on the launching stream over 20 back-to-back launches on 2^bn_gpu-element tables (out of place,
         # table[i] = Montgomery(i), r = 5: BenchmarkFolding's shape)
         iters = 20
-        ms1 = gk.bench_fold(1 << bn_gpu, ntab=1, warmup=3, iters=iters)
+        ms_b2b, ms1 = gk.bench_fold(1 << bn_gpu, ntab=1, warmup=3, iters=iters, isolated=True)
         bytes1 = 96.0 * (1 << (bn_gpu - 1))
         traffic = None
         try:   # PMC pass of the same launches (tools/pmc_bench.sh), committed under profiles/
@@ -319,8 +319,14 @@ def main():
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "launches": iters, "avg_launch_ms": ms1,
                            "algorithmic_bytes_per_launch": bytes1,
-                           "measured": "HIP events on the launching stream around %d back-to-back launches, nothing else "
-                                       "running (gkrhip_bench_fold); 96 B per output element (SURVEY 8d)" % iters}
+                           "measured": "HIP events on the launching stream, one event pair per launch, %d launches one at a time "
+                                       "on an idle GPU (gkrhip_bench_fold) -- the per-kernel duration rocprofv3 reports for the "
+                                       "same launches (profiles/r02_*_fold_launches_by_size.csv); 96 B per output element "
+                                       "(SURVEY 8d)" % iters,
+                           "back_to_back": {"avg_launch_ms": ms_b2b, "achieved": bytes1 / (ms_b2b * 1e-3) / 1e9,
+                                            "frac": bytes1 / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "measured": "the same %d launches queued back to back between one event pair "
+                                                        "(consecutive launches overlap their ramp-up and drain)" % iters}}
         if solo["fold_launches"]:
             sms = solo["fold_ms"] / solo["fold_launches"]
             sb = solo["fold_bytes"] / solo["fold_launches"]

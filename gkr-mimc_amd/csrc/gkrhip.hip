@@ -739,7 +739,7 @@ int gkrhip_mimc_session_verify(gkrhip_session* s, const uint64_t* qprime, const 
     return rc;
 }
 
-int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms) {
+int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms, double* isolated_ms_or_null) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     if (n < 2 || (n & (n - 1)) || ntab < 1 || ntab > GKR_MAX_ARITY + 1) return fail("bench_fold: bad arguments");
@@ -768,6 +768,20 @@ int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = (double)ms / iters;
+    if (isolated_ms_or_null) {
+        // every launch on an idle GPU with its own event pair: the per-kernel duration a profiler reports
+        double tot = 0;
+        for (int i = 0; i < iters; i++) {
+            HIPCHK(hipStreamSynchronize(cx().stream));
+            HIPCHK(hipEventRecord(e0, cx().stream));
+            CHK(launch_fold(sp, dp, ntab, n / 2, r));
+            HIPCHK(hipEventRecord(e1, cx().stream));
+            HIPCHK(hipEventSynchronize(e1));
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            tot += ms;
+        }
+        *isolated_ms_or_null = tot / iters;
+    }
     cx().prof.min_n = saved_min;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -885,6 +899,33 @@ int gkrhip_comm_unique_id(uint8_t out[128]) {
     return 0;
 }
 
+// GKRHIP_COMM_CUS = n: confine the current (RCCL) lane's round kernels to all CUs but n reserved ones and give the
+// collective a stream of its own on the reserved ones (spread over the chip: one per XCD for n = 8)
+static int lane_reserve_comm_cus() {
+    static const int n_res = [] {
+        const char* e = getenv("GKRHIP_COMM_CUS");
+        return e ? std::max(0, std::min(64, atoi(e))) : 0;
+    }();
+    if (n_res == 0 || cx().lc.comm_stream) return 0;
+    const int ncu = cx().n_cu, words = (ncu + 31) / 32;
+    std::vector<uint32_t> res(words, 0u), rest(words, 0u);
+    for (int k = 0; k < n_res; k++) {
+        const int cu = (int)(((long long)k * ncu) / n_res);
+        res[cu / 32] |= 1u << (cu % 32);
+    }
+    for (int cu = 0; cu < ncu; cu++)
+        if (!((res[cu / 32] >> (cu % 32)) & 1u)) rest[cu / 32] |= 1u << (cu % 32);
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    hipStream_t compute = nullptr, comm = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&compute, (uint32_t)words, rest.data()));
+    HIPCHK(hipExtStreamCreateWithCUMask(&comm, (uint32_t)words, res.data()));
+    (void)hipStreamDestroy(cx().stream);
+    cx().stream = compute;
+    cx().lc.comm_stream = comm;
+    HIPCHK(hipEventCreateWithFlags(&cx().lc.comm_ev, hipEventDisableTiming));
+    return 0;
+}
+
 // lane k of the communicator set: lane 0 is the default lane, further lanes are created on demand
 static Ctx* comm_lane(int k) {
     while ((int)gc.lanes.size() <= k) {
@@ -975,6 +1016,7 @@ int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /
         memcpy(&id, ids + (size_t)128 * k, 128);
         NCCLCHK(gc.p_init(&cx().lc.comm, world, id, rank));
         CHK(coll_buffers(4096));
+        CHK(lane_reserve_comm_cus());
     }
     comm_set(world, rank);
     return 0;
@@ -1027,9 +1069,16 @@ int gkrhip_comm_destroy(void) {
             if (l != &g0) ll = std::unique_lock<std::mutex>(l->mu);   // g0.mu is already held
             UseLane u(l);
             (void)hipStreamSynchronize(cx().stream);
+            if (cx().lc.comm_stream) (void)hipStreamSynchronize(cx().lc.comm_stream);
             if (cx().lc.comm) {
                 (void)gc.p_destroy(cx().lc.comm);
                 cx().lc.comm = nullptr;
+            }
+            if (cx().lc.comm_stream) {     // the lane keeps its (CU-masked) compute stream
+                (void)hipStreamDestroy(cx().lc.comm_stream);
+                (void)hipEventDestroy(cx().lc.comm_ev);
+                cx().lc.comm_stream = nullptr;
+                cx().lc.comm_ev = nullptr;
             }
             if (cx().lc.shm) {
                 cx().lc.shm->abort.store(1, std::memory_order_release);   // a peer still waiting here fails instead of hanging

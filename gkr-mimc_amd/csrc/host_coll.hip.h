@@ -120,10 +120,17 @@ int coll_buffers(size_t words) {
         if (_r != ncclSuccess) return fail("%s failed: %s", #x, gc.p_errstr ? gc.p_errstr(_r) : "?"); \
     } while (0)
 
-// in-place sum over ranks of n u64 lanes in device memory, on the library's stream
+// the stream the collective (and what follows it) runs on: the lane's, or its reserved-CU stream
+inline hipStream_t coll_stream() { return cx().lc.comm_stream ? cx().lc.comm_stream : cx().stream; }
+
+// in-place sum over ranks of n u64 lanes in device memory, ordered after everything queued on the lane's stream
 int coll_allreduce(unsigned long long* d, int n) {
     if (cx().lc.comm) {
-        NCCLCHK(gc.p_allreduce(d, d, (size_t)n, ncclUint64, ncclSum, cx().lc.comm, cx().stream));
+        if (cx().lc.comm_stream) {
+            HIPCHK(hipEventRecord(cx().lc.comm_ev, cx().stream));
+            HIPCHK(hipStreamWaitEvent(cx().lc.comm_stream, cx().lc.comm_ev, 0));
+        }
+        NCCLCHK(gc.p_allreduce(d, d, (size_t)n, ncclUint64, ncclSum, cx().lc.comm, coll_stream()));
         return 0;
     }
     if (cx().lc.shm) {
@@ -155,11 +162,11 @@ int coll_publish(int nwords, unsigned int seq) {
         return e ? atoi(e) : 0;
     }();
     if (mode == 1) {
-        HIPCHK(hipMemcpyAsync(cx().h_round, cx().lc.d_buf, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, cx().stream));
-        HIPCHK(hipStreamWriteValue32(cx().stream, cx().d_flag, seq, 0));
+        HIPCHK(hipMemcpyAsync(cx().h_round, cx().lc.d_buf, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, coll_stream()));
+        HIPCHK(hipStreamWriteValue32(coll_stream(), cx().d_flag, seq, 0));
         return 0;
     }
-    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round, nwords, cx().d_flag, seq);
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, coll_stream(), cx().lc.d_buf, cx().d_round, nwords, cx().d_flag, seq);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -203,8 +210,8 @@ int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     memcpy(cx().lc.h_buf + (size_t)v.rank * cnt * 4, mine, (size_t)cnt * 32);
     HIPCHK(hipMemcpyAsync(cx().lc.d_buf, cx().lc.h_buf, words * 8, hipMemcpyHostToDevice, cx().stream));
     CHK(coll_allreduce(cx().lc.d_buf, (int)words));
-    HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, words * 8, hipMemcpyDeviceToHost, cx().stream));
-    HIPCHK(hipStreamSynchronize(cx().stream));
+    HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, words * 8, hipMemcpyDeviceToHost, coll_stream()));
+    HIPCHK(hipStreamSynchronize(coll_stream()));
     memcpy(out.data(), cx().lc.h_buf, words * 8);
     return 0;
 }
@@ -286,8 +293,9 @@ int partial_evals(const GateDesc& g, const DevTable* eq, const DevTable* const* 
     hipLaunchKernelGGL(k_reduce_partials, dim3(nwords), dim3(GKR_BLOCK), 0, cx().stream, cx().d_partials, cx().d_sums, nblocks, nwords);
     HIPCHK(hipGetLastError());
     if (collective) CHK(coll_allreduce(cx().d_sums, nwords));
-    HIPCHK(hipMemcpyAsync(cx().h_sums, cx().d_sums, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, cx().stream));
-    HIPCHK(hipStreamSynchronize(cx().stream));
+    hipStream_t after = collective ? coll_stream() : cx().stream;
+    HIPCHK(hipMemcpyAsync(cx().h_sums, cx().d_sums, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, after));
+    HIPCHK(hipStreamSynchronize(after));
     for (int t = 0; t < nev; t++) evals[t] = limbs9_to_fr(cx().h_sums + (size_t)t * GKR_ACC_WORDS);
     return 0;
 }

@@ -61,6 +61,11 @@ struct LaneColl {
     size_t buf_words = 0;
     unsigned int* h_cflag = nullptr;       // host-mapped completion word of the RCCL path (written by a stream memory operation)
     unsigned int* d_cflag = nullptr;
+    // GKRHIP_COMM_CUS = n > 0 (RCCL lanes): the collective and its publish kernel run on a stream of their own that is
+    // confined to n reserved CUs, the round kernels on a stream confined to the others -- a 1-workgroup collective
+    // kernel then never queues for a workgroup slot behind the compute-bound rounds of the other lanes
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ev = nullptr;
 };
 
 struct Ctx {
@@ -297,6 +302,10 @@ void lane_free() {
     if (cx().lc.h_buf) (void)hipHostFree(cx().lc.h_buf);
     if (cx().lc.h_tmp) (void)hipHostFree(cx().lc.h_tmp);
     if (cx().lc.h_cflag) (void)hipHostFree(cx().lc.h_cflag);
+    if (cx().lc.comm_stream) (void)hipStreamDestroy(cx().lc.comm_stream);
+    if (cx().lc.comm_ev) (void)hipEventDestroy(cx().lc.comm_ev);
+    cx().lc.comm_stream = nullptr;
+    cx().lc.comm_ev = nullptr;
     cx().lc.d_buf = cx().lc.h_buf = cx().lc.h_tmp = nullptr;
     cx().lc.h_cflag = cx().lc.d_cflag = nullptr;
     cx().lc.buf_words = 0;
@@ -596,15 +605,16 @@ int launch_partial_eval_t(const DevTable* eq, const DevTable* const* x, size_t m
 // wait for the sequence number a kernel of this lane publishes with its hand-off (host-mapped flag)
 // `f` defaults to the lane's round flag; deadline_ms > 0 bounds the wait (collective paths: a peer that died or a
 // collective that cannot make progress must surface as an error, never as a hang)
-int wait_flag(unsigned int seq, volatile unsigned int* f = nullptr, double deadline_ms = 0) {
+int wait_flag(unsigned int seq, volatile unsigned int* f = nullptr, double deadline_ms = 0, hipStream_t watch = nullptr) {
     if (!f) f = cx().h_flag;
+    if (!watch) watch = cx().stream;      // the stream whose last operation raises the flag
     unsigned long spins = 0;
     Waiter w;
     double t0 = 0;
     while (*f != seq) {
         w.step();
         if ((++spins & 0xfffff) == 0) {              // every now and then: make sure the GPU is alive
-            hipError_t e = hipStreamQuery(cx().stream);
+            hipError_t e = hipStreamQuery(watch);
             if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
             if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
             if (deadline_ms > 0) {

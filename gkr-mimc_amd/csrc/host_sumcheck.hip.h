@@ -34,7 +34,7 @@ int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int 
     if (t.on_device) {
         CHK(coll_allreduce(cx().lc.d_buf, nsum));     // exact integer sum of limb-split lanes; the tail words are rank-local
         CHK(coll_publish(nsum + ntail, seq));
-        return wait_flag(seq, nullptr, coll_timeout_ms());
+        return wait_flag(seq, nullptr, coll_timeout_ms(), coll_stream());
     }
     CHK(wait_flag(seq));
     if (collective && cx().lc.shm) {

@@ -77,7 +77,7 @@ ABI = {
     "gkrhip_host_limbsplit_reduce": (_I, [_P, _P, _I]),
     "gkrhip_host_mimc_hash": (_I, [_P, _P, _SZ]),
     "gkrhip_host_cipher_round_coeffs": (_I, [_P, _P, _P, _P]),
-    "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D)]),
+    "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_bench_sumcheck": (_I, [_I, _I, _I, _I, _I, C.POINTER(_D), _P]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
@@ -478,10 +478,12 @@ def host_cipher_round_coeffs(M, c, qk):
     return out
 
 
-def bench_fold(n, ntab=1, warmup=3, iters=20):
-    ms = C.c_double(0)
-    _check(load().gkrhip_bench_fold(n, ntab, warmup, iters, C.byref(ms)))
-    return ms.value
+def bench_fold(n, ntab=1, warmup=3, iters=20, isolated=False):
+    """ms per fold of `ntab` tables of n elements: back-to-back launches, or (isolated=True) the pair
+    (back-to-back, one launch at a time on an idle GPU)."""
+    ms, iso = C.c_double(0), C.c_double(0)
+    _check(load().gkrhip_bench_fold(n, ntab, warmup, iters, C.byref(ms), C.byref(iso) if isolated else None))
+    return (ms.value, iso.value) if isolated else ms.value
 
 
 def bench_sumcheck(kind, bn, ninstance=1, warmup=1, iters=3):

@@ -209,8 +209,10 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t *M, const u
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 /* Device-resident fold micro-benchmark (shape of BenchmarkFolding, poly/multilin_test.go:55-78):
  * ntab tables of n elements (table[i] = Montgomery(i)), r = 5, `iters` timed out-of-place folds after
- * `warmup`; *avg_ms = mean kernel time from HIP events on the library's stream. */
-int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double *avg_ms);
+ * `warmup`; *avg_ms = mean time per fold from HIP events on the library's stream around the `iters` back-to-back folds;
+ * *isolated_ms_or_null (optional) = mean over the same number of folds launched one at a time on an idle GPU, each with
+ * its own event pair -- the per-kernel duration a profiler reports. */
+int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double *avg_ms, double *isolated_ms_or_null);
 /* sumcheck.Prove micro-benchmarks on device-resident tables, shaped like the reference's own
  * (sumcheck/prover_test.go:96-125; instances of sumcheck/testing.go:11-57 with L = R = [0, 1, 2, ...]):
  * kind 0 = BenchmarkWithCipherGate (CipherGate, Ark = 145646, one point RandomFrArray(bn)); kind 1 =

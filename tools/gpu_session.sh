@@ -18,6 +18,8 @@ for step in "$@"; do
     bench_hwq8) GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --no-cpu-baseline --no-micro > $OUT/bench_hwq8.json 2> $OUT/bench_hwq8.err ;;
     rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
     rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
+    rccl_cu8) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_cu8.json 2> $OUT/bench_rccl_cu8.err ;;
+    rccl_cu16) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=16 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 1 --no-cpu-baseline --no-micro > $OUT/bench_rccl_cu16.json 2> $OUT/bench_rccl_cu16.err ;;
     shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
     w8) for v in default spin25; do
           E=""; [ $v = spin25 ] && E="GKRHIP_WAIT_SPIN_US=25"
@@ -29,6 +31,7 @@ ps = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"
 print([p.wait() for p in ps])
 PY
           ) > $OUT/w8_$v.log 2>&1; tail -4 $OUT/w8_$v.log; done ;;
+    w8probe) timeout 900 python tools/w8_probe.py > $OUT/w8_probe.log 2>&1; cat $OUT/w8_probe.log ;;
     *) echo "unknown step $step" ;;
   esac
 done
