@@ -139,6 +139,9 @@ def main():
                          "POSIX shared memory (one node only); auto = rccl")
     ap.add_argument("--no-shm-beside", action="store_true",
                     help="N > 1 on one node: do not repeat the timed steps over the shared-memory exchange")
+    ap.add_argument("--device", type=int, default=None,
+                    help="GPU ordinal of this rank (default LOCAL_RANK); several ranks on ONE GPU with --exchange shm is how "
+                         "the multi-rank control flow is exercised on a single-GPU box")
     ap.add_argument("--mem-fraction", type=float, default=0.85,
                     help="share of the free HBM the resident sessions may take (caps --concurrent)")
     args = ap.parse_args()
@@ -157,9 +160,13 @@ def main():
         world = dist.get_world_size()
         rank = dist.get_rank()
     multi = dist is not None and world > 1
+    if multi and args.exchange != "shm":
+        # one hardware queue per lane stream (ROCclr's default is 4 queues for all streams): the collective kernels of
+        # different lanes must be able to run side by side, whatever order the ranks issue them in
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     gk = importlib.import_module("gkr-mimc_amd")
-    gk.init(local_rank)
+    gk.init(local_rank if args.device is None else args.device)
 
     import numpy as np
     gamma = world.bit_length() - 1 if dist is not None else 0
@@ -175,6 +182,8 @@ def main():
     # every proof in flight keeps its own resident assignment (93 tables of 2^bn_gpu elements) plus scratch
     free_b, _total_b = gk.mem_info()
     per_session = (94.25 if args.circuit == "mimc" else 104) * 32 * (1 << bn_gpu)   # tables + two half-size scratch tables + pyramids
+    if args.device is not None and dist is not None:
+        free_b //= world                              # the ranks share one GPU
     nconc = max(1, min(args.concurrent, args.steps, int(args.mem_fraction * free_b // per_session)))
     if multi:
         nconc = min(nconc, 8)                         # one communicator per lane, at most 8

@@ -801,8 +801,22 @@ def test_wire_format_helpers(gk):
 
 
 # ---------------------------------------------------------------- sharded prover (multi-process, one GPU)
+def _release_parent_gpu_context():
+    """The ranks of a sharded test are separate processes time-sharing the GPU with this one.  A parent that still owns
+    hardware queues (it has run dozens of lanes by now) pushes the device into time-slicing its queues across processes
+    -- measured 40x slower rounds for the children (tools/w8_probe.py) -- so the parent gives its context back first;
+    the library re-initialises itself on the next call."""
+    import ctypes
+    importlib.import_module("gkr-mimc_amd").shutdown()
+    try:
+        ctypes.CDLL("libamdhip64.so").hipDeviceReset()
+    except OSError:
+        pass
+
+
 def _run_shards(mode, world, sizes, env=None):
     import os, subprocess, sys, uuid
+    _release_parent_gpu_context()
     here = os.path.dirname(os.path.abspath(__file__))
     name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
     e = dict(os.environ, GKR_ORACLE_THREADS="2")
