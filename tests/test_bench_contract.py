@@ -28,6 +28,15 @@ def test_bench_line_contract():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1
     assert r["traffic"] is None or abs(r["traffic"] / r["algorithmic_bytes_per_launch"] - 1) < 0.05   # no wasted re-reads
+    assert r.get("launches", 0) >= 10                                    # not a single-sample figure
+    if "partial_eval" in d and "mad_issue_frac" in d["partial_eval"]:       # round 2: ceilings from the build's own ISA
+        pe = d["partial_eval"]
+        lp = pe["loop_instructions_per_pair"]
+        assert lp["vector"] == lp["half_rate"] + lp["full_rate"] and lp["v_mad_u64_u32"] > 1000
+        assert 0 < pe["mad_issue_frac"] < pe["frac"] <= 1
+        for k in ("sumcheck_cipher_bn22", "sumcheck_multi_identity_91_bn22", "fold_2p25"):
+            assert k in d["micro"], k
+        assert d["single_proof"]["latency_ms"] > d["ms_per_step"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -1,0 +1,90 @@
+"""GPU tests of the sharded prover (run with -m gpu): several ranks, one process each, time-sharing the ONE GPU of the
+box and exchanging the per-round sums through the library's shared-memory transport (RCCL cannot form a communicator
+of several ranks on one GPU); a 1-rank RCCL communicator with every round forced through ncclAllReduce.
+
+This file sorts before test_gpu_parity.py on purpose and never touches the GPU from the pytest process itself: a
+parent process that owns hardware queues pushes the device into time-slicing its queues across processes, which makes
+the ranks' rounds ~40x slower (tools/w8_probe.py, profiles/r02_w8_probe_parent_context.txt: 2.5 s against minutes for a
+full bN = 24 proof over 8 ranks)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- sharded prover (multi-process, one GPU)
+def _run_shards(mode, world, sizes, env=None):
+    import os, subprocess, sys, uuid
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
+    e = dict(os.environ, GKR_ORACLE_THREADS="2")
+    e.update(env or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), mode, str(world), str(r), name,
+                               sizes], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=1500)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    try:
+        os.unlink("/dev/shm" + name)
+    except OSError:
+        pass
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "SHARD-OK" in out, "rank %d:\n%s" % (r, out[-3000:])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_prover_matches_oracle(world):
+    """shard on the lowest index bits; bN from log2(world) (no local round at all) upwards."""
+    g = world.bit_length() - 1
+    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10} if world < 8 else {3, 4, 8, 11})))
+
+
+def test_sharded_prover_generic_path_and_small_budget():
+    _run_shards("shm", 2, "3,6,9", {"GKRHIP_GENERIC": "1"})
+    _run_shards("shm", 4, "4,9,11", {"GKRHIP_GMAX": "8"})
+
+
+def test_sharded_prover_concurrent_lanes():
+    """Two lanes per rank, each with its own collective channel, two proofs in flight per rank."""
+    _run_shards("shm", 2, "4,9,11", {"GKR_TEST_LANES": "2"})
+    _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
+
+
+def test_sharded_prover_full_size_digests():
+    """BASELINE config 3's size through the sharded driver: 8 ranks time-sharing the GPU (2^21-entry shards, the
+    per-round exchange over shared memory) at bN = 24, and 2 ranks at bN = 22; the transcript must be the one the C
+    oracle produced for the un-sharded proof (tests/golden/gkr_mimc_big_digests.json)."""
+    _run_shards("shm", 8, "24", {"GKR_TEST_DIGEST": "1"})
+    _run_shards("shm", 2, "22", {"GKR_TEST_DIGEST": "1"})
+
+
+def test_sharded_gmimc_circuit():
+    """BASELINE config 5's circuit sharded (linear layers included): small sizes against the C oracle's un-sharded
+    transcript, bN = 14 and 20 against the committed digests."""
+    _run_shards("shm", 2, "1,2,5,9", {"GKR_TEST_CIRCUIT": "gmimc"})
+    _run_shards("shm", 4, "2,3,8,11", {"GKR_TEST_CIRCUIT": "gmimc"})
+    _run_shards("shm", 4, "14,20", {"GKR_TEST_CIRCUIT": "gmimc", "GKR_TEST_DIGEST": "1"})
+    _run_shards("shm", 2, "3,6,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_GENERIC": "1"})
+    # the fused linear rounds through ncclAllReduce (1-rank communicator, every round forced through the collective)
+    _run_shards("rccl", 1, "2,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_FORCE_COLLECTIVE": "1"})
+    # registered 1-, 3- and 4-input gates sharded
+    _run_shards("shm", 4, "2,3,7,10", {"GKR_TEST_CIRCUIT": "variadic"})
+
+
+def test_rccl_plumbing_world1():
+    """RCCL is dlopen()ed, a 1-rank communicator is created and every round's sums go through
+    ncclAllReduce (GKRHIP_FORCE_COLLECTIVE): the call sequence of the multi-GPU path on the one GPU we have."""
+    _run_shards("rccl", 1, "1,2,5,9", {"GKRHIP_FORCE_COLLECTIVE": "1"})
+
+
+
+
+def test_sharded_host_tail_off():
+    """GKRHIP_HOST_TAIL=0: the gathered tail rounds of a sharded sumcheck on the device instead of the host."""
+    _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "0"})

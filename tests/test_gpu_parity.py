@@ -315,7 +315,6 @@ def test_host_tail_rounds(gk):
     _run_case({"GKRHIP_HOST_TAIL": "3"}, "3,9,11", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "5", "GKRHIP_LAT": "0"}, "7,8,11")
     _run_case({"GKRHIP_HOST_TAIL": "2", "GKRHIP_GMAX": "8", "GKRHIP_CLAIM_TRICK": "0"}, "4,10,13")
-    _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "0"})      # sharded: the gathered tail rounds on the device
 
 
 def test_round_kernel_deferred_reduction_variants(gk):
@@ -625,6 +624,75 @@ def test_circuit_of_registered_gates_vs_oracle(gk, bn):
     s.close()
 
 
+def _random_circuit(rng):
+    """A random layered circuit over the gate family: 2-4 input layers, 4-10 gate layers of 1-4 inputs drawn from
+    earlier layers, explicit copy layers for everything that is used more than once (circuit/circuit.go:36-41), the
+    unused layers pruned so that only the last layer has no consumer."""
+    n_in = int(rng.integers(2, 5))
+    raw = [([], None)] * n_in
+    for _ in range(int(rng.integers(4, 11))):
+        k = min(int(rng.integers(1, 5)), len(raw))
+        ins = [int(v) for v in rng.choice(len(raw), size=k, replace=False)]   # distinct: Out is searched by value (gkr/prover.go:78-86)
+        power = 7 if rng.random() < 0.5 else 1
+        raw.append((ins, (int(rng.integers(0, 1 << 62)), power)))
+    # keep what reaches the last layer
+    need = {len(raw) - 1}
+    for l in range(len(raw) - 1, -1, -1):
+        if l in need:
+            need.update(raw[l][0])
+    need.update(range(n_in))
+    # every use of a layer that has several uses goes through a copy layer of its own... the reference's rule is weaker
+    # (only INPUT layers need it, circuit/circuit.go:36-41), so do exactly that: copies for multiply-used inputs
+    uses = {l: 0 for l in range(len(raw))}
+    for l in sorted(need):
+        for p in raw[l][0]:
+            uses[p] += 1
+    L, ren = [], {}
+    for l in range(n_in):
+        L.append(o.Layer([]))
+        ren[l] = l
+    for l in range(n_in):
+        if uses[l] == 0:                      # an input nothing reads: give it a consumer (input layers need a claim)
+            raw.append(([l, len(raw) - 1], (0, 1)))
+            need.add(len(raw) - 1)
+            uses[l] += 1
+        if uses[l] > 1:
+            L.append(o.Layer([l], o.IdentityGate()))
+            ren[l] = len(L) - 1
+    for l in range(n_in, len(raw)):
+        if l not in need:
+            continue
+        ins, (ark, power) = raw[l]
+        L.append(o.Layer([ren[p] for p in ins], o.SumGate(ark, power)))
+        ren[l] = len(L) - 1
+    return o.build_circuit(L), n_in
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_circuits_vs_oracle(gk, seed):
+    """gkr.Prove on random circuits of registered gates (1-4 inputs, power 1 or 7, layers with several consumers, i.e.
+    multi-claim sumchecks of every gate shape): transcript, outputs and verifier verdicts equal the C oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    circ, n_in = _random_circuit(rng)
+    layers = _library_layers(circ)
+    descs = c.circuit_descs(circ)
+    for bn in (1, 3, 7):
+        n = 1 << bn
+        ins = [nasty(n, seed * 10 + k) if k % 2 else c.from_ints([int(v) for v in rng.integers(0, 1 << 62, n)]) for k in range(n_in)]
+        qp = c.random_fr_array(bn)
+        want, wouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+        assert c.gkr_verify_circuit(descs, bn, want, ins, wouts, qp) == 0
+        s = gk.MimcSession(bn, layers=layers)
+        for k in range(n_in):
+            s.load_input(k, ins[k])
+        s.assign()
+        flat = s.prove(qp)
+        assert np.array_equal(flat, want), (seed, bn)
+        assert np.array_equal(s.outputs(), wouts)
+        assert gk.gkr_verify(layers, flat, ins, wouts, qp)
+        s.close()
+
+
 @pytest.mark.parametrize("t", [4, 8])
 def test_gmimc_t4_t8_circuits_vs_oracle(gk, t):
     """GMiMC for t = 4 and 8 (hash/gmimc.go:16-20): the library's circuit (three-input feed-forward gate) against the C
@@ -798,93 +866,6 @@ def test_wire_format_helpers(gk):
         assert np.array_equal(got[i], c.mimc_keyed_permutation(x[i:i + 1], key[i:i + 1])[0])
     for e in load("kat.json")["mimc_perm"]:
         assert fr_to_hex(gk.mimc_permutation_batch(hex_to_fr(e["x"]), hex_to_fr(e["key"]))) == [e["out"]]
-
-
-# ---------------------------------------------------------------- sharded prover (multi-process, one GPU)
-def _release_parent_gpu_context():
-    """The ranks of a sharded test are separate processes time-sharing the GPU with this one.  A parent that still owns
-    hardware queues (it has run dozens of lanes by now) pushes the device into time-slicing its queues across processes
-    -- measured 40x slower rounds for the children (tools/w8_probe.py) -- so the parent gives its context back first;
-    the library re-initialises itself on the next call."""
-    import ctypes
-    importlib.import_module("gkr-mimc_amd").shutdown()
-    try:
-        ctypes.CDLL("libamdhip64.so").hipDeviceReset()
-    except OSError:
-        pass
-
-
-def _run_shards(mode, world, sizes, env=None):
-    import os, subprocess, sys, uuid
-    _release_parent_gpu_context()
-    here = os.path.dirname(os.path.abspath(__file__))
-    name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
-    e = dict(os.environ, GKR_ORACLE_THREADS="2")
-    e.update(env or {})
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), mode, str(world), str(r), name,
-                               sizes], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=1500)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(out)
-    try:
-        os.unlink("/dev/shm" + name)
-    except OSError:
-        pass
-    for r, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and "SHARD-OK" in out, "rank %d:\n%s" % (r, out[-3000:])
-
-
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_prover_matches_oracle(gk, world):
-    """shard on the lowest index bits; bN from log2(world) (no local round at all) upwards."""
-    g = world.bit_length() - 1
-    # (8 processes time-sharing one GPU pay a process switch per rank and round, ~70 ms per round: two small sizes)
-    _run_shards("shm", world, ",".join(str(b) for b in sorted({g, g + 1, g + 2, 7, 10} if world < 8 else {3, 6})))
-
-
-def test_sharded_prover_generic_path_and_small_budget(gk):
-    _run_shards("shm", 2, "3,6,9", {"GKRHIP_GENERIC": "1"})
-    _run_shards("shm", 4, "4,9,11", {"GKRHIP_GMAX": "8"})
-
-
-def test_sharded_prover_concurrent_lanes(gk):
-    """Two lanes per rank, each with its own collective channel, two proofs in flight per rank."""
-    _run_shards("shm", 2, "4,9,11", {"GKR_TEST_LANES": "2"})
-    _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
-
-
-def test_sharded_prover_full_size_digests(gk):
-    """BASELINE config 3's size through the sharded driver: 8 ranks time-sharing the GPU (2^21-entry shards, the
-    per-round exchange over shared memory) at bN = 24, and 2 ranks at bN = 22; the transcript must be the one the C
-    oracle produced for the un-sharded proof (tests/golden/gkr_mimc_big_digests.json)."""
-    _run_shards("shm", 8, "24", {"GKR_TEST_DIGEST": "1"})      # ~2.5 min: 2208 rounds x 8 process switches on the one GPU
-    _run_shards("shm", 2, "22", {"GKR_TEST_DIGEST": "1"})
-
-
-def test_sharded_gmimc_circuit(gk):
-    """BASELINE config 5's circuit sharded (linear layers included): small sizes against the C oracle's un-sharded
-    transcript, bN = 14 and 20 against the committed digests."""
-    _run_shards("shm", 2, "1,2,5,9", {"GKR_TEST_CIRCUIT": "gmimc"})
-    _run_shards("shm", 4, "2,3,8,11", {"GKR_TEST_CIRCUIT": "gmimc"})
-    _run_shards("shm", 4, "14,20", {"GKR_TEST_CIRCUIT": "gmimc", "GKR_TEST_DIGEST": "1"})
-    _run_shards("shm", 2, "3,6,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_GENERIC": "1"})
-    # the fused linear rounds through ncclAllReduce (1-rank communicator, every round forced through the collective)
-    _run_shards("rccl", 1, "2,9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_FORCE_COLLECTIVE": "1"})
-    # registered 1-, 3- and 4-input gates sharded
-    _run_shards("shm", 4, "2,3,7,10", {"GKR_TEST_CIRCUIT": "variadic"})
-
-
-def test_rccl_plumbing_world1(gk):
-    """RCCL is dlopen()ed, a 1-rank communicator is created and every round's sums go through
-    ncclAllReduce (GKRHIP_FORCE_COLLECTIVE): the call sequence of the multi-GPU path on the one GPU we have."""
-    _run_shards("rccl", 1, "1,2,5,9", {"GKRHIP_FORCE_COLLECTIVE": "1"})
 
 
 # ---------------------------------------------------------------- compiled caller (what a cgo shim does)
