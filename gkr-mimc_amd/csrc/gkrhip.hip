@@ -159,6 +159,37 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
 // the middle of a proof keeps its mutex for the whole proof, so the visit waits for proofs in flight; holding the
 // lane list keeps a concurrent session destroy from freeing a lane under the visitor.
 namespace {
+// A host-buffer entry point (Fold, Evaluate, FoldedEqTable, EvalBatch, sumcheck.Prove on host tables, the one-shot
+// verifiers, the wire-format helpers) borrows a lane from the pool for the duration of the call: calls from different
+// host threads (goroutines locked to their OS threads by cgo) run concurrently, each on a stream of its own, instead
+// of queueing on the default lane's mutex.
+struct LaneLease {
+    Ctx* l = nullptr;
+    std::unique_lock<std::mutex> lk;
+    Ctx* prev = nullptr;
+    int acquire() {
+        {
+            std::lock_guard<std::mutex> g(g0.mu);
+            CHK(ensure_ctx());
+            l = lane_create();
+        }
+        if (!l) return fail("cannot create a lane for the call: %s", g_err.c_str());
+        lk = std::unique_lock<std::mutex>(l->mu);
+        prev = g_cur;
+        g_cur = l;
+        return 0;
+    }
+    ~LaneLease() {
+        if (!l) return;
+        g_cur = prev;
+        lk.unlock();
+        lane_destroy(l);
+    }
+};
+#define LEASE_LANE()  \
+    LaneLease lease;  \
+    CHK(lease.acquire())
+
 template <class F>
 int for_each_lane(F&& fn) {
     std::lock_guard<std::mutex> lk0(g0.mu);
@@ -256,8 +287,7 @@ int gkrhip_device_synchronize(void) {
 }
 
 int gkrhip_fold(uint64_t* table, size_t n, const uint64_t r[4]) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (n < 2 || (n & (n - 1))) return fail("Fold: table length %zu is not a power of two >= 2", n);
     ScopedTable t, o;
     CHK(table_alloc(&t, n));
@@ -275,8 +305,7 @@ int gkrhip_fold(uint64_t* table, size_t n, const uint64_t r[4]) {
 }
 
 int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint64_t* coords, int ncoords) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (n < 1 || (n & (n - 1))) return fail("Evaluate: table length %zu is not a power of two", n);
     if (((size_t)1 << ncoords) != n) return fail("Evaluate: table has %zu elements but %d coordinates were given", n, ncoords);
     LocalOnly lo;
@@ -291,8 +320,7 @@ int gkrhip_evaluate(uint64_t out[4], const uint64_t* table, size_t n, const uint
 }
 
 int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mult_or_null) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (bN < 0 || bN > 30) return fail("eq table: bN %d out of range", bN);
     ScopedTable t;
     const size_t n = (size_t)1 << bN;
@@ -307,8 +335,7 @@ int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mu
 
 int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res, const uint64_t* const* xs, int arity,
                            size_t n) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (arity < 1 || arity > GKR_MAX_ARITY) return fail("arity %d not supported (1..%d)", arity, GKR_MAX_ARITY);
     if (n < 1) return fail("EvalBatch: empty tables");
     ScopedTable in[GKR_MAX_ARITY], out;
@@ -331,8 +358,7 @@ int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res,
 int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int bN, const uint64_t* const* X,
                           const uint64_t* qprimes, int nq, const uint64_t* claims, int nclaims, uint64_t* proof,
                           uint64_t* challenges, uint64_t* final_claims) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (bN < 0 || bN > 30) return fail("bN %d out of range", bN);
     if (arity < 1 || arity > GKR_MAX_ARITY) return fail("arity %d not supported (1..%d)", arity, GKR_MAX_ARITY);
     const size_t n = (size_t)1 << bN;
@@ -577,17 +603,17 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
 
 // ---- wire-format helpers (prover/gadget/hints.go) ---------------------------------------------------------
 static int convert_inplace(uint64_t* data, size_t n, const E& factor) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (n == 0) return 0;
-    uint4* d = nullptr;
-    CHK(staging_alloc(&d, 32 * n));
+    ScopedTable st;                       // an AoS image of n elements has the size of a table: from the arena
+    CHK(table_alloc(&st, n));
+    uint4* d = st.base;
     HIPCHK(hipMemcpyAsync(d, data, 32 * n, hipMemcpyHostToDevice, cx().stream));
     hipLaunchKernelGGL(k_convert_aos, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d, n, to_dev(factor));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(data, d, 32 * n, hipMemcpyDeviceToHost, cx().stream));
     HIPCHK(hipStreamSynchronize(cx().stream));
-    HIPCHK(hipFree(d));
+    table_release(&st);
     return 0;
 }
 int gkrhip_to_regular(uint64_t* data, size_t n) {
@@ -597,8 +623,7 @@ int gkrhip_to_regular(uint64_t* data, size_t n) {
 int gkrhip_from_regular(uint64_t* data, size_t n) { return convert_inplace(data, n, hfr::R2); }
 
 int gkrhip_mimc_permutation_batch(uint64_t* out, const uint64_t* x, const uint64_t* key, size_t n) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     if (n == 0) return 0;
     ScopedTable tx, tk, to;
     CHK(table_alloc(&tx, n));
@@ -683,8 +708,7 @@ static int verify_flat(const Circuit& c, int bN, const E* flat, const E* qprime,
 
 int gkrhip_gkr_verify_mimc(int bN, const uint64_t* flat, const uint64_t* in0, const uint64_t* in1, const uint64_t* outputs,
                            const uint64_t* qprime) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     LocalOnly lo;
     if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
     const size_t n = (size_t)1 << bN;
@@ -707,8 +731,7 @@ int gkrhip_gkr_verify_mimc(int bN, const uint64_t* flat, const uint64_t* in0, co
 
 int gkrhip_gkr_verify(const gkrhip_layer* layers, int n_layers, int bN, const uint64_t* flat, const uint64_t* const* inputs,
                       int n_inputs, const uint64_t* outputs, const uint64_t* qprime) {
-    std::lock_guard<std::mutex> lk(g0.mu);
-    CHK(ensure_ctx());
+    LEASE_LANE();
     LocalOnly lo;
     if (bN < 0 || bN > 28) return fail("bN %d out of range", bN);
     Circuit c;

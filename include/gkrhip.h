@@ -11,8 +11,9 @@
  * All functions return 0 on success and a non-zero code otherwise; gkrhip_last_error() describes
  * the last failure of the calling process (the reference panics on the prover side,
  * sumcheck/prover.go:54,114; the Go shim turns non-zero into panic).  Calls block until the result
- * is in host memory.  One context per process, guarded by a mutex (the reference's Prove is called
- * from one goroutine and blocks, sumcheck/prover.go:46-90).
+ * is in host memory.  One context per process; every call works on a lane of its own (stream, hand-off buffers), so
+ * calls from different host threads run concurrently (the reference's Prove is called from one goroutine and blocks,
+ * sumcheck/prover.go:46-90; concurrent callers there share one worker pool).
  *
  * There is NO CPU fallback: every table-sized operation runs in HIP kernels on the selected GPU and
  * gkrhip_init() fails loudly when no gfx950 device is usable.  The host only performs the

@@ -414,6 +414,44 @@ def test_gkr_session_repeatable_and_claims_consistent(gk):
     s.close()
 
 
+def test_concurrent_host_buffer_calls(gk):
+    """Host-buffer entry points borrow a lane each: Fold, FoldedEqTable, sumcheck.Prove and the one-shot gkr.Prove from
+    four host threads at once, every result bit-identical to the oracle's."""
+    import threading
+    bn = 10
+    n = 1 << bn
+    X = [c.random_fr_array(n), nasty(n, 3)]
+    ark = c.from_u64(145646)
+    qs = c.random_fr_array(bn).reshape(1, bn, 4)
+    claims = c.evaluation(c.GATE_CIPHER, ark, qs, c.fr(0), X)
+    r = c.mimc_hash(c.from_u64(9))
+    want = {"fold": c.fold(X[1], r), "eq": c.folded_eq_table(qs[0]), "sc": c.sumcheck_prove(c.GATE_CIPHER, ark, X, qs, claims),
+            "gkr": c.gkr_prove_mimc(bn, X[0], X[1], qs[0])[0]}
+    errs = []
+
+    def work(kind):
+        try:
+            for _ in range(6):
+                if kind == "fold":
+                    assert np.array_equal(gk.fold(X[1], r), want["fold"])
+                elif kind == "eq":
+                    assert np.array_equal(gk.folded_eq_table(qs[0]), want["eq"])
+                elif kind == "sc":
+                    for a, b in zip(gk.sumcheck_prove(X, qs, claims, gk.GATE_CIPHER, ark), want["sc"]):
+                        assert np.array_equal(a, b)
+                else:
+                    assert np.array_equal(gk.gkr_prove_mimc(X[0], X[1], qs[0], want_outputs=False)[0], want["gkr"])
+        except Exception as e:   # noqa: BLE001
+            errs.append((kind, e))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in ("fold", "eq", "sc", "gkr", "sc", "fold")]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+
+
 def test_concurrent_sessions(gk):
     """Independent sessions own a lane (stream + buffers) each and may prove concurrently from different
     host threads; every proof is still bit-identical to the oracle."""
