@@ -333,6 +333,34 @@ int gkrhip_eq_table(uint64_t* out, const uint64_t* q, int bN, const uint64_t* mu
     return 0;
 }
 
+// poly.ChunkOfEqTable (poly/eq.go:61-89): chunk `chunk_id` of the table, written at its place in `table` (which has
+// 2^bN elements).  The prefix weight over the chunk-id bits is scalar host work, the chunk itself one device pass.
+int gkrhip_chunk_of_eq_table(uint64_t* table, size_t chunk_id, size_t chunk_size, const uint64_t* q, int bN,
+                             const uint64_t* mult_or_null) {
+    LEASE_LANE();
+    if (bN < 0 || bN > 30) return fail("eq table: bN %d out of range", bN);
+    const size_t n = (size_t)1 << bN;
+    if (chunk_size < 1 || (chunk_size & (chunk_size - 1)) || chunk_size > n) return fail("ChunkOfEqTable: chunk size %zu", chunk_size);
+    const size_t n_chunks = n / chunk_size;
+    if (chunk_id >= n_chunks) return fail("ChunkOfEqTable: chunk %zu of %zu", chunk_id, n_chunks);
+    int log_chunks = 0;
+    while (((size_t)1 << log_chunks) < n_chunks) log_chunks++;
+    const E* qe = (const E*)q;
+    E r = hfr::ONE;
+    if (mult_or_null) memcpy(r.l, mult_or_null, 32);
+    for (int k = 0; k < log_chunks; k++) {           // eq.go:74-82: bit k of the chunk id <-> qPrime[logNChunks-k-1]
+        const E& rho = qe[log_chunks - k - 1];
+        r = hfr::mul(r, ((chunk_id >> k) & 1) ? rho : hfr::sub(hfr::ONE, rho));
+    }
+    const int m = bN - log_chunks;
+    ScopedTable t;
+    CHK(table_alloc(&t, chunk_size));
+    CHK(build_eq(&t, qe + log_chunks, 1, m, m, &r));
+    CHK(download_table(&t, table + 4 * chunk_id * chunk_size, chunk_size));
+    table_release(&t);
+    return 0;
+}
+
 int gkrhip_gate_eval_batch(int gate, const uint64_t* ark_or_null, uint64_t* res, const uint64_t* const* xs, int arity,
                            size_t n) {
     LEASE_LANE();

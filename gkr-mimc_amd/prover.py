@@ -40,6 +40,7 @@ ABI = {
     "gkrhip_fold": (_I, [_P, _SZ, _P]),
     "gkrhip_evaluate": (_I, [_P, _P, _SZ, _P, _I]),
     "gkrhip_eq_table": (_I, [_P, _P, _I, _P]),
+    "gkrhip_chunk_of_eq_table": (_I, [_P, _SZ, _SZ, _P, _I, _P]),
     "gkrhip_gate_eval_batch": (_I, [_I, _P, _P, _P, _I, _SZ]),
     "gkrhip_sumcheck_prove": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P]),
     "gkrhip_mimc_proof_len": (_SZ, [_I]),
@@ -178,6 +179,14 @@ def folded_eq_table(q, mult=None):
     m = None if mult is None else _fr(mult)
     _check(load().gkrhip_eq_table(_ptr(out), _ptr(q) if bN else None, bN, _ptr(m)))
     return out
+
+
+def chunk_of_eq_table(table, chunk_id, chunk_size, q, mult=None):
+    """poly.ChunkOfEqTable: fills chunk `chunk_id` of `table` (2^len(q) elements) in place."""
+    q = _fr(q).reshape(-1, 4)
+    assert table.dtype == np.uint64 and table.flags.c_contiguous and table.shape == (1 << q.shape[0], 4)
+    m = None if mult is None else _fr(mult)
+    _check(load().gkrhip_chunk_of_eq_table(_ptr(table), chunk_id, chunk_size, _ptr(q) if q.shape[0] else None, q.shape[0], _ptr(m)))
 
 
 def gate_eval_batch(gate, ark, xs):

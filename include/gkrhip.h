@@ -77,6 +77,10 @@ int gkrhip_evaluate(uint64_t out[4], const uint64_t *table, size_t n, const uint
 /* poly.FoldedEqTable(preallocated, qPrime, multiplier...), poly/eq.go:41-59; mult may be NULL. Also the
  * result of any sequence of poly.ChunkOfEqTable calls covering the table (poly/eq.go:62-89). */
 int gkrhip_eq_table(uint64_t *out, const uint64_t *q, int bN, const uint64_t *mult_or_null);
+/* poly.ChunkOfEqTable(preallocatedEq, chunkID, chunkSize, qPrime, multiplier...), poly/eq.go:61-89: fills
+ * table[chunk_id*chunk_size, (chunk_id+1)*chunk_size) of the 2^bN-element table; chunk_size a power of two. */
+int gkrhip_chunk_of_eq_table(uint64_t *table, size_t chunk_id, size_t chunk_size, const uint64_t *q, int bN,
+                             const uint64_t *mult_or_null);
 
 /* ---- circuit.Gate (circuit/gates.go:9-21) ---------------------------------------------------- */
 /* Gate.EvalBatch(res, xs...) / Layer.Evaluate, circuit/circuit.go:48-64. */

@@ -80,6 +80,12 @@ func EqTable(out []fr.Element, qPrime []fr.Element, multiplier *fr.Element) {
 	must(C.gkrhip_eq_table(ptr(out), ptr(qPrime), C.int(len(qPrime)), ptr1(multiplier)))
 }
 
+// ChunkOfEqTable is poly.ChunkOfEqTable (poly/eq.go:61-89): fills chunk chunkID of table (1<<len(qPrime) elements).
+func ChunkOfEqTable(table []fr.Element, chunkID, chunkSize int, qPrime []fr.Element, multiplier *fr.Element) {
+	must(C.gkrhip_chunk_of_eq_table(ptr(table), C.size_t(chunkID), C.size_t(chunkSize), ptr(qPrime), C.int(len(qPrime)),
+		ptr1(multiplier)))
+}
+
 // GateDesc describes a gate of the family the kernels evaluate:
 //
 //	out = (sum of the inputs selected by SumMask + Ark)^Power,  Power = 1 or 7

@@ -31,3 +31,12 @@ func FoldedEqTable(preallocated MultiLin, qPrime []fr.Element, multiplier ...fr.
 	gkrhip.EqTable(preallocated, qPrime, m)
 	return preallocated
 }
+
+// ChunkOfEqTable computes only a chunk of the eqTable for a given chunkSize and chunkID (poly/eq.go:61-89)
+func ChunkOfEqTable(preallocatedEq []fr.Element, chunkID, chunkSize int, qPrime []fr.Element, multiplier ...fr.Element) {
+	var m *fr.Element
+	if len(multiplier) > 0 {
+		m = &multiplier[0]
+	}
+	gkrhip.ChunkOfEqTable(preallocatedEq, chunkID, chunkSize, qPrime, m)
+}

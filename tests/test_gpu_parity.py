@@ -110,6 +110,25 @@ def test_eq_table_evaluate_equals_eval_eq(gk, bn):
     assert np.array_equal(gk.evaluate(eq, h), c.eval_eq(q, h) if bn else c.from_u64(1))
 
 
+@pytest.mark.parametrize("bn,chunk", [(1, 1), (4, 2), (9, 256), (12, 256), (12, 4096), (13, 64)])
+def test_chunk_of_eq_table_vs_oracle(gk, bn, chunk):
+    """poly.ChunkOfEqTable (poly/eq.go:61-89): every chunk lands at its place and the chunks together are the whole
+    table (the reference asserts the same, poly/eq_test.go:28-58), with and without a multiplier."""
+    q = c.random_fr_array(bn)
+    mult = c.mimc_hash(c.from_u64(bn))
+    for m in (None, mult):
+        want = c.folded_eq_table(q, m)
+        assert np.array_equal(c.chunked_eq_table(q, chunk, m), want)
+        table = np.zeros((1 << bn, 4), np.uint64)
+        n_chunks = (1 << bn) // chunk
+        ids = range(n_chunks) if n_chunks <= 8 else [0, 1, n_chunks // 2, n_chunks - 1]
+        for cid in ids:
+            gk.chunk_of_eq_table(table, cid, chunk, q, m)
+            assert np.array_equal(table[cid * chunk:(cid + 1) * chunk], want[cid * chunk:(cid + 1) * chunk]), (bn, chunk, cid)
+        if n_chunks <= 8:
+            assert np.array_equal(table, want)
+
+
 def test_eq_golden(gk):
     for e in load("poly.json")["eq"]:
         m = hex_to_fr(e["mult"]) if e["mult"] else None
