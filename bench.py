@@ -71,6 +71,42 @@ def random_fr_array_np(n):
     return out
 
 
+class ClockSampler:
+    """Engine clock (sclk) of GPU `dev` while a region runs, from `rocm-smi --showclocks --json` in a side thread (a
+    separate process each time: nothing of this process's HIP state is touched).  Best effort: empty if the tool is
+    missing or prints something else."""
+
+    def __init__(self, dev):
+        self.dev, self.mhz, self._stop, self._t = dev, [], threading.Event(), None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--json"], capture_output=True,
+                                     text=True, timeout=5).stdout
+                m = re.search(r'sclk[^()]*\((\d+)Mhz\)', out)
+                if m:
+                    self.mhz.append(int(m.group(1)))
+            except Exception:   # noqa: BLE001
+                return
+            self._stop.wait(0.1)
+
+    def __enter__(self):
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join(timeout=10)
+
+    def median(self):
+        v = sorted(self.mhz)
+        return v[len(v) // 2] if v else None
+
+
 class Job:
     """nconc resident sessions (one lane each) of the same circuit and size, proving concurrently."""
 
@@ -265,7 +301,8 @@ def main():
     latency_ms = 1e3 * (time.perf_counter() - tl)
     solo = gk.profile_get()          # the same launches with no other proof in flight
     gk.profile_reset(1 << bn_gpu)    # HIP-event accounting of the round-0 fold / partial-eval launches
-    dt = timed(job, args.steps)
+    with ClockSampler(local_rank if args.device is None else args.device) as clk:
+        dt = timed(job, args.steps)
     flat = job.last[0]
     prof = gk.profile_get()
     gk.profile_reset(0)
@@ -377,6 +414,12 @@ def main():
                                   "(v_mad_u64_u32) alone at %.1f cycles -- what a carry-free multiplier would cost -- over the "
                                   "measured duration" % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ, HALF_RATE_CYCLES),
             "measured": "HIP events around the round-0 launches of the single-proof pass"}
+        if clk.median():
+            ghz = clk.median() * 1e-3
+            out["partial_eval"]["sclk_mhz_during_timed_steps"] = {"median": clk.median(), "min": min(clk.mhz), "max": max(clk.mhz),
+                                                                   "samples": len(clk.mhz), "source": "rocm-smi --showclocks"}
+            out["partial_eval"]["frac_at_measured_clock"] = ceiling_ms * NOMINAL_GHZ / ghz / avg_ms
+            out["partial_eval"]["mad_issue_frac_at_measured_clock"] = mad_ms * NOMINAL_GHZ / ghz / avg_ms
         if prof["peval_launches"]:
             out["partial_eval"]["in_timed_region"] = {
                 "launches": prof["peval_launches"], "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
