@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: keep 2^bn entries per GPU (total 2^(bn + log2 N))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the sumcheck / fold micro-benchmarks (SURVEY 8d)")
+    ap.add_argument("--no-oneshot", action="store_true", help="skip the PCIe-inclusive one-shot calls from host buffers")
     ap.add_argument("--circuit", choices=["mimc", "gmimc"], default="mimc",
                     help="mimc: examples.MimcCircuit (the headline metric); gmimc: the build-defined GMiMC t=2 circuit "
                          "(BASELINE config 5, quoted at --bn 22)")
@@ -360,19 +361,19 @@ def main():
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass
-        ach = bytes1 / (ms1 * 1e-3) / 1e9
+        ach = bytes1 / (ms_b2b * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_fold<1> on a 2^%d-element table (2^%d outputs)" % (bn_gpu, bn_gpu - 1),
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "launches": iters, "avg_launch_ms": ms1,
+                           "traffic": traffic, "launches": iters, "avg_launch_ms": ms_b2b,
                            "algorithmic_bytes_per_launch": bytes1,
-                           "measured": "HIP events on the launching stream, one event pair per launch, %d launches one at a time "
-                                       "on an idle GPU (gkrhip_bench_fold) -- the per-kernel duration rocprofv3 reports for the "
-                                       "same launches (profiles/r02_*_fold_launches_by_size.csv); 96 B per output element "
-                                       "(SURVEY 8d)" % iters,
-                           "back_to_back": {"avg_launch_ms": ms_b2b, "achieved": bytes1 / (ms_b2b * 1e-3) / 1e9,
-                                            "frac": bytes1 / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "measured": "the same %d launches queued back to back between one event pair "
-                                                        "(consecutive launches overlap their ramp-up and drain)" % iters}}
+                           "measured": "HIP events on the launching stream around %d launches queued back to back, nothing else "
+                                       "running (gkrhip_bench_fold): wall time / %d.  rocprofv3's per-kernel average for the "
+                                       "full-size launches agrees within 2 %% (profiles/r02_v2_solo_fold_launches_by_size.csv: "
+                                       "125.8 us); 96 B per output element (SURVEY 8d)" % (iters, iters),
+                           "one_at_a_time": {"avg_launch_ms": ms1, "achieved": bytes1 / (ms1 * 1e-3) / 1e9,
+                                             "frac": bytes1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "measured": "the same %d launches one at a time on an idle GPU, one event pair each: "
+                                                         "includes the launch latency and the clock ramp after every idle gap" % iters}}
         if solo["fold_launches"]:
             sms = solo["fold_ms"] / solo["fold_launches"]
             sb = solo["fold_bytes"] / solo["fold_launches"]
@@ -457,6 +458,41 @@ def main():
         micro["fold_2p25"] = {"ms": ms, "GB_per_s": 96.0 * (1 << 24) / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 96.0 * (1 << 24) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "mirrors": "BenchmarkFolding, poly/multilin_test.go:55-78 (2^25 elements, table[i] = i, r = 5)"}
         out["micro"] = micro
+    if rank == 0 and not multi and not args.no_oneshot and args.circuit == "mimc":
+        # the production caller's shape (GkrProverHint.Call, prover/gadget/hints.go:197-233): Assign + Prove from HOST
+        # buffers in one call -- upload, limb-plane transposition, canonicality check, assignment, proof, download of
+        # the output table.  PCIe-inclusive; never `value`.
+        job.close()
+        rng = np.random.default_rng(1)
+        n = 1 << bn
+        ins = []
+        for _ in range(2):   # any canonical residues serve as inputs for a timing
+            a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+            a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+            ins.append(a)
+        qp = random_fr_array_np(bn)
+        gk.gkr_prove_mimc(ins[0], ins[1], qp)                      # warm: arena, lane pool
+        t0 = time.perf_counter()
+        gk.gkr_prove_mimc(ins[0], ins[1], qp)
+        one = time.perf_counter() - t0
+        nthr = 4
+
+        def call(_k):
+            gk.gkr_prove_mimc(ins[0], ins[1], qp)
+
+        ths = [threading.Thread(target=call, args=(k,)) for k in range(nthr)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        par = time.perf_counter() - t0
+        out["oneshot_including_pcie"] = {
+            "one_call_s": one, "one_call_hashes_per_s": n / one,
+            "concurrent_calls": nthr, "concurrent_wall_s": par, "concurrent_hashes_per_s": nthr * n / par,
+            "per_call_bytes_over_pcie": 3 * 32 * n,
+            "note": "gkrhip_gkr_prove_mimc on pageable host buffers (2 x %d MiB up, %d MiB down per call); the concurrent figure is "
+                    "%d calls from %d host threads, each on a lane of its own" % (32 * n >> 20, 32 * n >> 20, nthr, nthr)}
     if rank == 0 and not args.no_cpu_baseline and not multi and args.circuit == "mimc":
         out["cpu_baseline"] = cpu_baseline()
     out["build"] = {"source_sha256": (build_info.get("source_sha256") or "")[:16], "hipcc": build_info.get("hipcc", "")}

@@ -8,8 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -- python3 $ROOT/bench.py --concurrent 1 --steps 2 --warmup 1 --no-cpu-baseline --no-micro > $OUT/solo.json 2> $OUT/solo.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lanes5 -- python3 $ROOT/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-micro > $OUT/lanes5.json 2> $OUT/lanes5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -- python3 $ROOT/bench.py --concurrent 1 --steps 2 --warmup 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/solo.json 2> $OUT/solo.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lanes5 -- python3 $ROOT/bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-micro --no-oneshot > $OUT/lanes5.json 2> $OUT/lanes5.err
 python3 - <<PY
 import csv, glob, collections
 for tag in ("solo", "lanes5"):
