@@ -19,7 +19,8 @@ INFO = os.path.join(HERE, "build_info.json")
 SRC = os.path.join(HERE, "csrc", "gkrhip.hip")
 DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
               if f.endswith((".hip", ".h", ".inc"))) + [os.path.join(os.path.dirname(HERE), "include", "gkrhip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xarch_host", "-mbmi2", "-Xarch_host", "-madx"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xarch_host", "-mbmi2", "-Xarch_host", "-madx"] + \
+        os.environ.get("GKRHIP_EXTRA_FLAGS", "").split()      # experiments (e.g. -DGKR_WIDE_MUL2); part of the recorded build
 
 # half-rate vector instructions on gfx950 (4.2-4.4 cycles per wave: profiles/r01_ubench_*.txt); the others issue in 2.4
 HALF = ("v_mad_u64", "v_addc", "v_subb", "v_add_co", "v_sub_co", "v_subrev_co", "v_mul_lo", "v_mul_hi", "v_lshl_add_u64",
