@@ -127,6 +127,13 @@ def main():
         gk.comm_init_shm_lanes(world, rank, nlanes, name)
     else:
         gk.comm_init_lanes(1, 0, np.stack([gk.comm_unique_id() for _ in range(nlanes)]))
+    if os.environ.get("GKR_TEST_DIE") == str(rank):
+        # a rank that leaves without proving: its peers must fail with an error, not hang
+        if os.environ.get("GKR_TEST_DIE_HARD"):
+            os._exit(3)                     # killed: nobody raises the abort word, the deadline has to
+        gk.comm_destroy()                   # orderly exit: raises the abort word of the segment
+        print("DIED rank %d" % rank)
+        return
     circuit = os.environ.get("GKR_TEST_CIRCUIT", "mimc")
     if os.environ.get("GKR_TEST_DIGEST"):
         return digests(gk, world, rank, sizes, circuit)

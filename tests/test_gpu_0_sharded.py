@@ -88,3 +88,39 @@ def test_rccl_plumbing_world1():
 def test_sharded_host_tail_off():
     """GKRHIP_HOST_TAIL=0: the gathered tail rounds of a sharded sumcheck on the device instead of the host."""
     _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "0"})
+
+
+def _run_shards_expect_failure(world, sizes, env, within_s):
+    """Rank GKR_TEST_DIE leaves before proving: every other rank must end with an error inside `within_s` seconds."""
+    import os, subprocess, sys, time, uuid
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
+    e = dict(os.environ, GKR_ORACLE_THREADS="2")
+    e.update(env)
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), "shm", str(world), str(r), name, sizes],
+                              env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=within_s)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung after its peer left")
+        outs.append(out)
+    die = int(env["GKR_TEST_DIE"])
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        if r == die:
+            continue
+        assert p.returncode != 0 and "SHARD-OK" not in out, "rank %d:\n%s" % (r, out[-2000:])
+        assert "peer rank failed or left" in out or "timed out" in out, out[-2000:]
+    return time.time() - t0
+
+
+def test_peer_failure_is_an_error_not_a_hang():
+    """the shared-memory barrier has an abort word (raised by a rank that leaves in an orderly way) and a
+    deadline (for a rank that is killed): the survivors fail with an error either way."""
+    _run_shards_expect_failure(2, "9", {"GKR_TEST_DIE": "1"}, within_s=120)
+    dt = _run_shards_expect_failure(4, "8", {"GKR_TEST_DIE": "2", "GKR_TEST_DIE_HARD": "1", "GKRHIP_COLL_TIMEOUT_S": "4"}, within_s=120)
+    assert dt < 60
