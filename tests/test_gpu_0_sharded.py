@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ---------------------------------------------------------------- sharded prover (multi-process, one GPU)
-def _run_shards(mode, world, sizes, env=None):
+def _run_shards(mode, world, sizes, env=None, collect=None):
     import os, subprocess, sys, uuid
     here = os.path.dirname(os.path.abspath(__file__))
     name = "/gkrhip_test_" + uuid.uuid4().hex[:12]
@@ -36,6 +36,8 @@ def _run_shards(mode, world, sizes, env=None):
         pass
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "SHARD-OK" in out, "rank %d:\n%s" % (r, out[-3000:])
+    if collect is not None:
+        collect.extend(outs)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -62,6 +64,20 @@ def test_sharded_prover_full_size_digests():
     oracle produced for the un-sharded proof (tests/golden/gkr_mimc_big_digests.json)."""
     _run_shards("shm", 8, "24", {"GKR_TEST_DIGEST": "1"})
     _run_shards("shm", 2, "22", {"GKR_TEST_DIGEST": "1"})
+
+
+def test_config4_size_bn26_sharded_equals_unsharded():
+    """BASELINE config 4's problem, bN = 26 (2^26 hashes; the reference itself stops at 2^24, poly/pool.go:13): one proof
+    over 8 shards of 2^23 entries -- the ranks time-sharing the one GPU, 200 GB of resident shards -- and the same proof
+    un-sharded on the one GPU (186 GB of tables).  Every rank's transcript and the un-sharded transcript have the same
+    SHA-256, the native gkr.Verify accepts it on every rank and rejects a corrupted copy.  No oracle reaches this size;
+    the sharded and un-sharded drivers are pinned against the oracle at bN <= 24 by the tests above."""
+    import re
+    one, eight = [], []
+    _run_shards("shm", 1, "26", {"GKR_TEST_HASHONLY": "1"}, collect=one)
+    _run_shards("shm", 8, "26", {"GKR_TEST_HASHONLY": "1"}, collect=eight)
+    shas = {m.group(1) for out in one + eight for m in re.finditer(r"SHA bn=26 ([0-9a-f]{64})", out)}
+    assert len(shas) == 1 and sum(len(re.findall(r"SHA bn=26", out)) for out in one + eight) == 9, shas
 
 
 def test_sharded_gmimc_circuit():
