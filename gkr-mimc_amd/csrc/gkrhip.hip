@@ -629,6 +629,24 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
     return rc;
 }
 
+// Circuit.Assign + gkr.Prove for any circuit of library gates on host tables, in one call (the generic form of
+// gkrhip_gkr_prove_mimc).
+int gkrhip_gkr_prove(const gkrhip_layer* layers, int n_layers, int bN, const uint64_t* const* inputs, int n_inputs,
+                     const uint64_t* qprime, uint64_t* flat, uint64_t* outputs_or_null) {
+    gkrhip_session* s = nullptr;
+    CHK(gkrhip_session_create(&s, layers, n_layers, bN));
+    int rc = 0;
+    if (gkrhip_session_num_inputs(s) != n_inputs) rc = fail("gkr.Prove: the circuit has %d input layers, %d tables were given", gkrhip_session_num_inputs(s), n_inputs);
+    for (int k = 0; k < n_inputs && rc == 0; k++) rc = gkrhip_session_load_input(s, k, inputs[k]);
+    if (rc == 0) rc = gkrhip_mimc_session_assign(s);
+    if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
+    if (rc == 0 && outputs_or_null) rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
+    const std::string err = g_err;
+    gkrhip_mimc_session_destroy(s);
+    if (rc != 0) g_err = err;
+    return rc;
+}
+
 // ---- wire-format helpers (prover/gadget/hints.go) ---------------------------------------------------------
 static int convert_inplace(uint64_t* data, size_t n, const E& factor) {
     LEASE_LANE();

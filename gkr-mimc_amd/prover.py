@@ -62,6 +62,7 @@ ABI = {
     "gkrhip_gate_register": (_I, [_P, C.POINTER(_I)]),
     "gkrhip_gate_lookup": (_I, [_I, _P]),
     "gkrhip_gkr_verify": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "gkrhip_gkr_prove": (_I, [_P, _I, _I, _P, _I, _P, _P, _P]),
     "gkrhip_gkr_verify_mimc": (_I, [_I, _P, _P, _P, _P, _P]),
     "gkrhip_mimc_session_verify": (_I, [_P, _P, _P]),
     "gkrhip_to_regular": (_I, [_P, _SZ]),
@@ -338,6 +339,31 @@ def gmimc_circuit(t):
     layers = _layers_to_list(arr)
     n_in = sum(1 for l in layers if l[0] < 0)
     return layers, [imap[k] for k in range(n_in)]
+
+
+def circuit_proof_len(layers, bN):
+    """GkrProverHint.NbOutputs for a circuit given as a layer list (prover/gadget/hints.go:76-116)."""
+    outs = [0] * len(layers)
+    for gate, ins, _ark in layers:
+        for p in ins:
+            outs[p] += 1
+    sc = sum(bN * (gate_degree(g) + 2) for g, _i, _a in layers if g >= 0)
+    return sc + sum(outs) + bN * sum(outs) + bN
+
+
+def gkr_prove(layers, inputs, q_prime, want_outputs=True):
+    """Circuit.Assign + gkr.Prove for any circuit of library gates on host tables: (flat proof, outputs)."""
+    arr = _layers_from_list(layers)
+    inputs = [_fr(x) for x in inputs]
+    n = inputs[0].shape[0]
+    bN = n.bit_length() - 1
+    q_prime = _fr(q_prime).reshape(-1, 4)
+    flat = np.zeros((circuit_proof_len(layers, bN), 4), np.uint64)
+    outs = np.zeros((n, 4), np.uint64) if want_outputs else None
+    ptrs = (C.c_void_p * len(inputs))(*[x.ctypes.data for x in inputs])
+    _check(load().gkrhip_gkr_prove(C.cast(arr, C.c_void_p), len(layers), bN, ptrs, len(inputs), _ptr(q_prime) if bN else None,
+                                   _ptr(flat), _ptr(outs)))
+    return flat, outs
 
 
 def gkr_verify(layers, flat, inputs, outputs, q_prime):

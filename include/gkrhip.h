@@ -141,6 +141,11 @@ int gkrhip_session_create(gkrhip_session **out, const gkrhip_layer *layers, int 
 int gkrhip_session_load_input(gkrhip_session *s, int input_index, const uint64_t *table);
 size_t gkrhip_session_proof_len(const gkrhip_session *s);
 int gkrhip_session_num_inputs(const gkrhip_session *s);
+/* Circuit.Assign (circuit/assignment.go:12-32) + gkr.Prove (gkr/prover.go:21-47) for any such circuit on host tables in
+ * one call: inputs[k] = table of input layer k (2^bN elements); flat: gkrhip_session_proof_len elements in GkrProofToVec
+ * order; outputs_or_null: the last layer's table. */
+int gkrhip_gkr_prove(const gkrhip_layer *layers, int n_layers, int bN, const uint64_t *const *inputs, int n_inputs,
+                     const uint64_t *qprime, uint64_t *flat, uint64_t *outputs_or_null);
 /* gkr.Verify (gkr/verifier.go:15-59) for any such circuit on host tables: inputs[k] = table of input layer k,
  * outputs = table of the last layer.  0 = accepted, > 0 = rejected, < 0 = error. */
 int gkrhip_gkr_verify(const gkrhip_layer *layers, int n_layers, int bN, const uint64_t *flat, const uint64_t *const *inputs,

@@ -235,6 +235,48 @@ func (s *Session) Close() {
 	}
 }
 
+// GateDegree is circuit.Gate.Degree() of a library gate (the descriptor's power).
+func GateDegree(gate int) int {
+	var d C.gkrhip_gate_desc
+	must(C.gkrhip_gate_lookup(C.int(gate), &d))
+	return int(d.power)
+}
+
+// ProofLen is GkrProverHint.NbOutputs (prover/gadget/hints.go:76-116) for a circuit given as a layer list.
+func ProofLen(layers []Layer, bN int) int {
+	outs := make([]int, len(layers))
+	n := bN // the output layer's qPrime
+	for _, l := range layers {
+		for _, p := range l.In {
+			outs[p]++
+		}
+		if l.Gate >= 0 {
+			n += bN * (GateDegree(l.Gate) + 2)
+		}
+	}
+	for _, o := range outs {
+		n += o + bN*o
+	}
+	return n
+}
+
+// Prove is Circuit.Assign + gkr.Prove for any circuit of library gates on host tables in one call; the flat proof is
+// in GkrProofToVec order.  outputs may be nil.
+func Prove(layers []Layer, bN int, inputs [][]fr.Element, qPrime, outputs []fr.Element) []fr.Element {
+	cl := cLayers(layers)
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	ci := make([]*C.uint64_t, len(inputs))
+	for i := range inputs {
+		ci[i] = ptr(inputs[i])
+		pin.Pin(&inputs[i][0])
+	}
+	flat := make([]fr.Element, ProofLen(layers, bN))
+	must(C.gkrhip_gkr_prove(&cl[0], C.int(len(cl)), C.int(bN), (**C.uint64_t)(unsafe.Pointer(&ci[0])), C.int(len(ci)),
+		ptr(qPrime), ptr(flat), ptr(outputs)))
+	return flat
+}
+
 // Verify is gkr.Verify (gkr/verifier.go:15-59) for any circuit of library gates on host tables: the sumcheck
 // verifiers and the claim bookkeeping run on the host, MultiLin.Evaluate of inputs and outputs on the device.
 func Verify(layers []Layer, bN int, flat []fr.Element, inputs [][]fr.Element, outputs, qPrime []fr.Element) error {

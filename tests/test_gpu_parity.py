@@ -674,6 +674,8 @@ def test_circuit_of_registered_gates_vs_oracle(gk, bn):
     assert s.verify(qp, flat)
     assert gk.gkr_verify(layers, flat, ins, wouts, qp)
     assert c.gkr_verify_circuit(descs, bn, flat, ins, wouts, qp) == 0
+    f2, o2 = gk.gkr_prove(layers, ins, qp)                 # the one-call form on host tables
+    assert np.array_equal(f2, want) and np.array_equal(o2, wouts)
     if bn:
         bad = flat.copy()
         bad[len(bad) // 3, 2] ^= np.uint64(16)
