@@ -22,7 +22,7 @@ for tag in ("solo", "lanes5"):
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
         if "k_fold" in r["Kernel_Name"]:
-            by[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            by[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open("$OUT/solo_fold_launches_by_size.csv", "w") as f:
         f.write('"Kernel","GridThreads","OutputsPerLaunch","Calls","AvgNs","MinNs","MaxNs","AlgorithmicBytes","GBperS_avg"\n')
         for (k, g), v in sorted(by.items(), key=lambda kv: -kv[0][1]):
