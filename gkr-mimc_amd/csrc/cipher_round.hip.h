@@ -88,7 +88,6 @@ struct CipherRoundArgs {
     unsigned long long* partials;   // [GKR_CR_WORDS] accumulator shared by the blocks (atomic adds); zero at launch, reset by the last block
     unsigned int* counter;          // arrival counter, zero at launch, reset by the last block
     unsigned long long* host_out;   // host-mapped: GKR_CR_WORDS sums, then 8 x u64 x 4 tail elements
-    unsigned long long* tail_out;   // where the last round's tail elements go (host_out + GKR_CR_WORDS unless the sums take another way)
     unsigned int* host_flag;        // host-mapped: set to `seq` when host_out is complete
     unsigned int seq;
     unsigned int need_m0;           // 0: M_0 is derived by the host from the running claim (2 products fewer)
@@ -254,7 +253,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
             if (P == 1) {
                 // last round: hand the two remaining entries of each table to the host, which applies
                 // the final fold (two scalar multiplications) to obtain finalClaims (prover.go:79-86)
-                unsigned long long* tail = a.tail_out;
+                unsigned long long* tail = a.host_out + GKR_CR_WORDS;
 #pragma unroll
                 for (int l = 0; l < 4; l++) {
                     tail[0 + l] = (unsigned long long)klo.v[2 * l] | ((unsigned long long)klo.v[2 * l + 1] << 32);

@@ -156,24 +156,11 @@ int coll_allreduce(unsigned long long* d, int n) {
 // then the sequence flag the host polls.  GKRHIP_RCCL_PUBLISH=0: a one-block copy kernel (it has to find a free
 // workgroup slot behind the compute-bound rounds of the other lanes); 1: a copy + a stream memory operation
 // (hipStreamWriteValue32), both executed by the command processor / SDMA without occupying a CU.
-inline int coll_publish_mode() {
+int coll_publish(int nwords, unsigned int seq) {
     static const int mode = [] {
         const char* e = getenv("GKRHIP_RCCL_PUBLISH");
         return e ? atoi(e) : 0;
     }();
-    return mode;
-}
-// out-of-place sum over ranks: n u64 lanes from device memory `src` into `dst` (here: the host-mapped round buffer)
-int coll_allreduce_to(const unsigned long long* src, unsigned long long* dst, int n) {
-    if (cx().lc.comm_stream) {
-        HIPCHK(hipEventRecord(cx().lc.comm_ev, cx().stream));
-        HIPCHK(hipStreamWaitEvent(cx().lc.comm_stream, cx().lc.comm_ev, 0));
-    }
-    NCCLCHK(gc.p_allreduce(src, dst, (size_t)n, ncclUint64, ncclSum, cx().lc.comm, coll_stream()));
-    return 0;
-}
-int coll_publish(int nwords, unsigned int seq) {
-    const int mode = coll_publish_mode();
     if (mode == 1) {
         HIPCHK(hipMemcpyAsync(cx().h_round, cx().lc.d_buf, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, coll_stream()));
         HIPCHK(hipStreamWriteValue32(coll_stream(), cx().d_flag, seq, 0));

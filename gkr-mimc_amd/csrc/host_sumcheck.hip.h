@@ -16,18 +16,13 @@ void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
 // the reduced words reach the host through coll_publish.
 struct RoundTargets {
     unsigned long long* out;
-    unsigned long long* tail;
     unsigned int* flag;
     bool on_device;
-    bool direct;      // GKRHIP_RCCL_PUBLISH=2: ncclAllReduce writes the reduced sums straight into the host-mapped buffer
 };
-inline RoundTargets round_targets(bool collective, int nsum) {
+inline RoundTargets round_targets(bool collective) {
     RoundTargets t;
     t.on_device = collective && cx().lc.comm;
-    t.direct = t.on_device && coll_publish_mode() == 2;
     t.out = t.on_device ? cx().lc.d_buf : cx().d_round;
-    // rank-local tail words never go through the collective: with the direct mode the kernel hands them to the host itself
-    t.tail = (t.direct ? cx().d_round : t.out) + nsum;
     t.flag = t.on_device ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
     return t;
 }
@@ -36,13 +31,6 @@ inline RoundTargets round_targets(bool collective, int nsum) {
 int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int nsum, int ntail, unsigned long long* summed,
                   const unsigned long long** sums) {
     *sums = cx().h_round;
-    if (t.direct) {
-        // one collective kernel and one stream memory operation: the reduced words land in the host-mapped buffer, the
-        // command processor raises the flag behind them
-        CHK(coll_allreduce_to(cx().lc.d_buf, cx().d_round, nsum));
-        HIPCHK(hipStreamWriteValue32(coll_stream(), cx().d_flag, seq, 0));
-        return wait_flag(seq, nullptr, coll_timeout_ms(), coll_stream());
-    }
     if (t.on_device) {
         CHK(coll_allreduce(cx().lc.d_buf, nsum));     // exact integer sum of limb-split lanes; the tail words are rank-local
         CHK(coll_publish(nsum + ntail, seq));
@@ -226,9 +214,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;
         a.tail_tables = k == k_export ? cx().d_tail : nullptr;
-        const RoundTargets tg = round_targets(collective, GKR_CR_WORDS);
+        const RoundTargets tg = round_targets(collective);
         a.host_out = tg.out;
-        a.tail_out = tg.tail;
         a.host_flag = tg.flag;
         a.seq = ++cx().seq;
         const bool derive_m0 = claim && *claim_known;
@@ -526,9 +513,8 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         a.racc = cx().d_racc;
         a.counter = cx().d_counter;
         a.tail_tables = k == k_export ? cx().d_tail : nullptr;
-        const RoundTargets tg = round_targets(collective, GKR_LR_WORDS);
+        const RoundTargets tg = round_targets(collective);
         a.host_out = tg.out;
-        a.tail_out = tg.tail;
         a.host_flag = tg.flag;
         a.seq = ++cx().seq;
         const bool derive_m0 = claim && *claim_known;

@@ -29,7 +29,6 @@ struct LinearRoundArgs {
     unsigned long long* racc;
     unsigned int* counter;
     unsigned long long* host_out;   // GKR_LR_WORDS sums, then arity x (lo, hi) tail elements of 4 u64 in the last round
-    unsigned long long* tail_out;   // the last round's tail elements (host_out + GKR_LR_WORDS unless the sums take another way)
     unsigned int* host_flag;
     unsigned int seq;
     unsigned int need_m0;
@@ -77,7 +76,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
                     }
                 }
                 if (P == 1) {   // last round: the two remaining entries of each table go to the host (final fold there)
-                    unsigned long long* tail = a.tail_out + 8 * t;
+                    unsigned long long* tail = a.host_out + GKR_LR_WORDS + 8 * t;
 #pragma unroll
                     for (int l = 0; l < 4; l++) {
                         tail[l] = (unsigned long long)lo.v[2 * l] | ((unsigned long long)lo.v[2 * l + 1] << 32);

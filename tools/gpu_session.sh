@@ -18,8 +18,6 @@ for step in "$@"; do
     bench_hwq8) GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_hwq8.json 2> $OUT/bench_hwq8.err ;;
     rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
     rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
-    rccl2) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=2 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29516 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_pub2.json 2> $OUT/bench_rccl_pub2.err; tail -3 $OUT/bench_rccl_pub2.err ;;
-    rccl2parity) for circ in mimc gmimc; do GKR_TEST_CIRCUIT=$circ GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=2 timeout 300 python tests/gpu_shard_worker.py rccl 1 0 /x 1,2,5,9,12 2>&1 | tail -2; done ;;
     rccl_cu8) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_cu8.json 2> $OUT/bench_rccl_cu8.err ;;
     rccl_cu16) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=16 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_cu16.json 2> $OUT/bench_rccl_cu16.err ;;
     shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
