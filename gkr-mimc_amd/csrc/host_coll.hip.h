@@ -12,6 +12,7 @@ struct Coll {
     decltype(&ncclGetUniqueId) p_get_id = nullptr;
     decltype(&ncclCommInitRank) p_init = nullptr;
     decltype(&ncclAllReduce) p_allreduce = nullptr;
+    decltype(&ncclAllGather) p_allgather = nullptr;
     decltype(&ncclCommDestroy) p_destroy = nullptr;
     decltype(&ncclGetErrorString) p_errstr = nullptr;
     // per-lane: LaneColl (RCCL communicator, or the host shared-memory transport used by processes of one
@@ -99,9 +100,10 @@ int coll_load() {
     gc.p_get_id = (decltype(gc.p_get_id))dlsym(gc.dl, "ncclGetUniqueId");
     gc.p_init = (decltype(gc.p_init))dlsym(gc.dl, "ncclCommInitRank");
     gc.p_allreduce = (decltype(gc.p_allreduce))dlsym(gc.dl, "ncclAllReduce");
+    gc.p_allgather = (decltype(gc.p_allgather))dlsym(gc.dl, "ncclAllGather");
     gc.p_destroy = (decltype(gc.p_destroy))dlsym(gc.dl, "ncclCommDestroy");
     gc.p_errstr = (decltype(gc.p_errstr))dlsym(gc.dl, "ncclGetErrorString");
-    if (!gc.p_get_id || !gc.p_init || !gc.p_allreduce || !gc.p_destroy || !gc.p_errstr)
+    if (!gc.p_get_id || !gc.p_init || !gc.p_allreduce || !gc.p_allgather || !gc.p_destroy || !gc.p_errstr)
         return fail("RCCL library lacks a required symbol");
     return 0;
 }
@@ -187,7 +189,6 @@ int shm_allreduce_host(unsigned long long* words, int n) {
     return 0;
 }
 // all-gather of `cnt` field elements per rank (host values): rank g's elements land in out[g*cnt ..].
-// Implemented as an all-reduce of a zero-padded buffer (one contributor per slot: the sum is exact).
 int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     const ShardView v = shard_view();
     out.assign((size_t)v.world * cnt, hfr::ZERO);
@@ -205,11 +206,21 @@ int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
         CHK(shm_barrier());
         return 0;
     }
-    CHK(coll_buffers(std::max<size_t>(words, 256)));
-    memset(cx().lc.h_buf, 0, words * 8);
-    memcpy(cx().lc.h_buf + (size_t)v.rank * cnt * 4, mine, (size_t)cnt * 32);
-    HIPCHK(hipMemcpyAsync(cx().lc.d_buf, cx().lc.h_buf, words * 8, hipMemcpyHostToDevice, cx().stream));
-    CHK(coll_allreduce(cx().lc.d_buf, (int)words));
+    if (!cx().lc.comm) {     // the collective code path forced at world = 1 without a communicator
+        for (int i = 0; i < cnt; i++) out[i] = mine[i];
+        return 0;
+    }
+    // RCCL: ncclAllGather of cnt elements per rank (staged through the lane's exchange buffer: send block after the
+    // receive area)
+    const size_t mine_words = (size_t)cnt * 4;
+    CHK(coll_buffers(std::max<size_t>(words + mine_words, 256)));
+    memcpy(cx().lc.h_buf, mine, mine_words * 8);
+    HIPCHK(hipMemcpyAsync(cx().lc.d_buf + words, cx().lc.h_buf, mine_words * 8, hipMemcpyHostToDevice, cx().stream));
+    if (cx().lc.comm_stream) {
+        HIPCHK(hipEventRecord(cx().lc.comm_ev, cx().stream));
+        HIPCHK(hipStreamWaitEvent(cx().lc.comm_stream, cx().lc.comm_ev, 0));
+    }
+    NCCLCHK(gc.p_allgather(cx().lc.d_buf + words, cx().lc.d_buf, mine_words, ncclUint64, cx().lc.comm, coll_stream()));
     HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, words * 8, hipMemcpyDeviceToHost, coll_stream()));
     HIPCHK(hipStreamSynchronize(coll_stream()));
     memcpy(out.data(), cx().lc.h_buf, words * 8);
