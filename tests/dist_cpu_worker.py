@@ -88,6 +88,32 @@ def cipher_rounds(gk, K, S, q, ark, seed, collective, c, proof, chal):
     return c, K[0], S[0]
 
 
+def linear_rounds(gk, gate, X, q, seed, collective, c, proof, chal):
+    """Fused rounds of a single-point LINEAR gate (identity, sums + Ark): the device returns the two sums
+    M_0 = sum W u, M_1 = sum W d of S_k(t) = M_0 + M_1 t (linear_round.hip.h); the ranks add them; the three round
+    coefficients are c ((1-q_k) + (2 q_k - 1) t) (M_0 + M_1 t).  Returns (c, [X_t folded on every challenge])."""
+    X = [list(x) for x in X]
+    for k in range(len(q)):
+        mid = len(X[0]) // 2
+        W = o.folded_eq_table(q[k + 1:], seed)
+        M = [0, 0]
+        for x in range(mid):
+            u = gate.eval(*[t[x] for t in X])
+            d = (gate.eval(*[t[x + mid] for t in X]) - u) % Q            # the gate's linear part of (hi - lo)
+            M[0] = (M[0] + W[x] * u) % Q
+            M[1] = (M[1] + W[x] * d) % Q
+        if collective:
+            M = allreduce_elements(gk, M)
+        a0, a1 = (1 - q[k]) % Q, (2 * q[k] - 1) % Q
+        co = [c * a0 * M[0] % Q, c * (a0 * M[1] + a1 * M[0]) % Q, c * a1 * M[1] % Q]
+        r = from_fr(gk.host_mimc_hash(to_fr(co)))[0]
+        proof.append(co)
+        chal.append(r)
+        c = c * ((1 + 2 * q[k] * r - q[k] - r) % Q) % Q
+        X = [o.fold(t, r) for t in X]
+    return c, [t[0] for t in X]
+
+
 def generic_rounds(gk, gate, eq, X, m, collective, proof, chal):
     for _k in range(m):
         ev = o.partial_evals(eq, X, gate)
@@ -124,6 +150,19 @@ def main():
         K2, S2 = [r[0] for r in rows], [r[1] for r in rows]
         c, kv, sv = cipher_rounds(gk, K2, S2, q[m1:], gate.ark, 1, False, c, proof, chal)
         assert proof == want[0] and chal == want[1] and [c, kv, sv] == want[2], ("cipher", bn, rank)
+        # ---- a linear gate of three inputs, one point (sharded fused linear rounds: the add / sum layers of GMiMC)
+        gate = o.SumGate(o.ARKS[3], 1)
+        n = 1 << bn
+        X = [[(i * i + 7 * t + 1) % Q for i in range(n)] for t in range(3)]
+        q = o.random_fr_array(bn)
+        claims = [o.evaluation(gate, [q], [], *X)]
+        want = o.sumcheck_prove([list(x) for x in X], [q], claims, gate)
+        seed = from_fr(gk.host_shard_seed(to_fr(q[m1:]), rank))[0]
+        proof, chal = [], []
+        c, vals = linear_rounds(gk, gate, [x[rank::world] for x in X], q[:m1], seed, True, 1, proof, chal)
+        rows = allgather_elements(vals, world)
+        c, vals = linear_rounds(gk, gate, [[rows[r][t] for r in range(world)] for t in range(3)], q[m1:], 1, False, c, proof, chal)
+        assert proof == want[0] and chal == want[1] and [c] + vals == want[2], ("linear", bn, rank)
         # ---- identity gate, several claims (MiMC layer 2)
         X, claims, qs, gate = o.initialize_multi_instance(bn, 5)
         want = o.sumcheck_prove(X, qs, claims, gate)
