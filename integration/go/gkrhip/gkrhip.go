@@ -18,6 +18,7 @@ package gkrhip
 #cgo CFLAGS: -I${SRCDIR}/../../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../../gkr-mimc_amd -lgkrhip -Wl,-rpath,${SRCDIR}/../../../gkr-mimc_amd
 #include <stdlib.h>
+#include <string.h>
 #include "gkrhip.h"
 */
 import "C"

@@ -2,8 +2,8 @@
 
 // GPU body of GkrProverHint.Call (prover/gadget/hints.go:197-233): same signature, same input order
 // (qPrime || inputs... || outputs, io_store.go:117-136) and same output order (GkrProofToVec, hints.go:236-271);
-// only the assign+prove step and the bulk big.Int conversions change.  Drop into gkr-mimc/prover/gadget/ with
-// `//go:build !gkrhip` on the pure-Go Call.  Uncompiled here (no Go toolchain in the build image).
+// only the assign+prove step and the bulk big.Int conversions change.  Drop into gkr-mimc/prover/gadget/ and move the
+// pure-Go Call into a file of its own tagged `//go:build !gkrhip` (types, NbOutputs, GkrProofToVec, `debug` stay in hints.go).  Uncompiled here (no Go toolchain in the build image).
 package gadget
 
 import (

@@ -1,7 +1,7 @@
 //go:build gkrhip
 
-// GPU body of sumcheck.Prove (sumcheck/prover.go:46-90).  Drop into gkr-mimc/sumcheck/ with `//go:build !gkrhip`
-// on prover.go's Prove.  Uncompiled here (no Go toolchain in the build image).
+// GPU body of sumcheck.Prove (sumcheck/prover.go:46-90).  Drop into gkr-mimc/sumcheck/ and move prover.go's Prove into
+// a file of its own tagged `//go:build !gkrhip` (build tags are per file; the helpers of prover.go stay).  Uncompiled here (no Go toolchain in the build image).
 package sumcheck
 
 import (
