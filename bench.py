@@ -38,6 +38,11 @@ def cpu_baseline(target_seconds=40.0):
     >= target_seconds/4 (each +1 doubles the work)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import coracle
+    # BASELINE config 1: bN = 10, the size of the reference's own CPU test path (gkr/gkr_test.go)
+    i0 = coracle.random_fr_array(1 << 10)
+    qp = coracle.random_fr_array(10)
+    coracle.gkr_prove_mimc(10, i0, i0.copy(), qp, want_outputs=False)
+    _, _, secs10 = coracle.gkr_prove_mimc(10, i0, i0.copy(), qp, want_outputs=False)
     best = None
     b = 14
     while True:
@@ -53,6 +58,7 @@ def cpu_baseline(target_seconds=40.0):
     muls = 4555.0 * (1 << b)          # field multiplications of gkr.Prove per hash (SURVEY 8a totals)
     return {"value": (1 << b) / secs, "unit": "MiMC hashes GKR-proved/s", "cores": cores,
             "kind": "port", "ns_per_field_mul_per_core": secs * cores / muls * 1e9,
+            "config1_bn10": {"seconds": secs10, "hashes_per_s": (1 << 10) / secs10},
             "sample": "gkr.Prove of 2^%d hashes (RandomFrArray inputs), %.2f s, C restatement of the reference "
                       "algorithm built with -O3 -march=x86-64-v3 -madx (portable unsigned __int128 CIOS product; not the Go "
                       "binary, whose gnark-crypto amd64 assembly is ~1.5-2x faster per multiplication)" % (b, secs)}
