@@ -780,6 +780,24 @@ def test_gmimc_t4_t8_circuits_vs_oracle(gk, t):
         s.close()
 
 
+@pytest.mark.parametrize("t,bn", [(4, 16), (4, 20), (8, 16)])
+def test_gmimc_t4_t8_match_oracle_digest(gk, t, bn):
+    """The GMiMC circuits with the registered three-input feed-forward gate at larger sizes: SHA-256 of the transcript and
+    of the output table against the C oracle's (tests/golden/gkr_gmimc_t48_digests.json; every input layer =
+    RandomFrArray(2^bN), generated on the device)."""
+    want = [e for e in load("gkr_gmimc_t48_digests.json") if e["t"] == t and e["bn"] == bn][0]
+    layers, _imap = gk.gmimc_circuit(t)
+    assert len(layers) == want["n_layers"]
+    s = gk.MimcSession(bn, layers=layers)
+    s.synth_inputs()
+    s.assign()
+    flat = s.prove(c.random_fr_array(bn))
+    assert flat.shape[0] == want["n_elements"]
+    assert hashlib.sha256(flat.astype("<u8").tobytes()).hexdigest() == want["sha256_flat"]
+    assert hashlib.sha256(s.outputs().astype("<u8").tobytes()).hexdigest() == want["sha256_outputs"]
+    s.close()
+
+
 @pytest.mark.parametrize("bn", [14, 20, 22])
 def test_gmimc_baseline_sizes_match_oracle_digest(gk, bn):
     """BASELINE config 5 (bN = 22) and two smaller sizes: SHA-256 of the GPU transcript and of the output table
