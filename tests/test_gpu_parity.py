@@ -216,6 +216,32 @@ def test_sumcheck_linear_gates_single_point_vs_oracle(gk, bn):
         assert np.array_equal(proof, oproof) and np.array_equal(chal, ochal) and np.array_equal(final, ofinal), gate
 
 
+@pytest.mark.parametrize("bn", [0, 1, 2, 5, 9, 14])
+def test_sumcheck_generic_test_like_the_reference(gk, bn):
+    """sumcheck/prover_test.go:42-94 (genericTest over InitializeCipherGateInstance / InitializeMultiInstance(bn, 10)):
+    the claims recombine to Evaluation, the restated sumcheck.Verify accepts the GPU prover's messages with the SAME
+    challenges, and gate(finalClaims[1:]) * finalClaims[0] is the verifier's expected value."""
+    n = 1 << bn
+    tab = c.from_ints(list(range(n)))
+    for kind in ("cipher", "multi"):
+        if kind == "cipher":
+            gate, ogate, ark = gk.GATE_CIPHER, c.GATE_CIPHER, c.from_u64(145646)
+            qs = c.random_fr_array(bn).reshape(1, bn, 4)
+        else:
+            gate, ogate, ark = gk.GATE_IDENTITY, c.GATE_IDENTITY, None
+            qs = np.stack([c.from_ints([(i * j + i) % o.Q for j in range(bn)]).reshape(bn, 4) for i in range(10)])
+        X = [tab, tab.copy()]
+        claims = np.concatenate([c.evaluation(ogate, ark, qs[i:i + 1], c.fr(0), X) for i in range(qs.shape[0])])
+        proof, chal, fin = gk.sumcheck_prove(X, qs, claims, gate, ark)
+        rc, vchal, expected, recomb = c.sumcheck_verify(claims, proof)
+        assert rc == 0 and np.array_equal(vchal, chal)
+        # the verifier's final check (gkr/verifier.go:93-110 does the same with the gate)
+        gate_val = c.gate_eval_batch(ogate, ark, [fin[1:2], fin[2:3]])
+        prod = c.fr()
+        c.lib.oracle_fr_mul(c._p(prod), c._p(np.ascontiguousarray(gate_val)), c._p(np.ascontiguousarray(fin[0:1])))
+        assert np.array_equal(prod, expected), (kind, bn)
+
+
 def test_sumcheck_91_claims(gk):
     # shape of MiMC layer 2 / BenchmarkMultiIdentity (sumcheck/prover_test.go:111-125) at bn = 10
     X, claims, qs = _multi_instance(10, 91)
