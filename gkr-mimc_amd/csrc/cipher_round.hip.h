@@ -289,6 +289,11 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(CipherRoundAr
 // reused by the block reduction afterwards.
 // ------------------------------------------------------------------------------------------------
 #define GKR_WIDE_LDS 3
+#ifdef GKR_NO_SQR
+#define GKR_SQR(x) fr_mont_mul_raw(x, x)
+#else
+#define GKR_SQR(x) fr_mont_sqr_raw(x)
+#endif
 struct WideShared {
     union {
         struct {
@@ -338,7 +343,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
-        const Fr ark = a.ark;
+        const Fr negark = fr_sub(fr_zero(), a.ark);      // q - ark (0 for ark = 0), canonical
         const size_t iters = P >> a.lg_threads;
         for (size_t j = 0; j < iters; j++) {
             const size_t x = j * threads + gtid;
@@ -365,9 +370,9 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
                 slo = ld_fr(a.s_src.lo, a.s_src.hi, x);
                 shi = ld_fr(a.s_src.lo, a.s_src.hi, x + P);
             }
-            // lazy sums: u < 3q, d < 2q.  The product chain is closed below 3q (a*b/2^256 + q < 2.7q for a, b < 3q),
-            // so neither is reduced
-            const Fr u = fr_add_raw(fr_add_raw(klo, slo), ark);
+            // lazy sums u, d < 2q: slo + ark is taken mod q (as slo - (q - ark)) so that the squarings' operands stay
+            // below 2q (fr_mont_sqr_raw doubles them in place); products of operands < 2q stay below 2q
+            const Fr u = fr_add_raw(klo, fr_sub(slo, negark));
             const Fr d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));
             Fr W = ld_fr(a.wj.lo, a.wj.hi, j);            // the same element for every lane of the launch
             Fr W2 = W;
@@ -377,14 +382,14 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             Fr p, r2, A, B, C, D, U4, D4, X0, X1;
             u32 T[FR_WIDE_LIMBS];
             // ordered for short lifetimes: u^2 and its dependants first, then d^2 and its dependants
-            p = fr_mont_mul_raw(u, u);    GKR_SB();
-            U4 = fr_mont_mul_raw(p, p);   GKR_SB();   // u^4
+            p = GKR_SQR(u);       GKR_SB();
+            U4 = GKR_SQR(p);      GKR_SB();   // u^4
             // with late lane weights W is uniform over the launch's lanes: 96-product multiplication (< 3q)
             X0 = WT_LATE ? fr_mul_const2_raw(U4, W2, W) : fr_mont_mul_raw(W, U4);  GKR_SB();
             A = fr_mont_mul_raw(p, u);    GKR_SB();   // u^3
             B = fr_mont_mul_raw(p, d);    GKR_SB();   // u^2 d
-            r2 = fr_mont_mul_raw(d, d);   GKR_SB();
-            D4 = fr_mont_mul_raw(r2, r2); GKR_SB();   // d^4
+            r2 = GKR_SQR(d);      GKR_SB();
+            D4 = GKR_SQR(r2);     GKR_SB();   // d^4
             X1 = WT_LATE ? fr_mul_const2_raw(D4, W2, W) : fr_mont_mul_raw(W, D4);  GKR_SB();
             C = fr_mont_mul_raw(u, r2);   GKR_SB();   // u d^2
             D = fr_mont_mul_raw(r2, d);   GKR_SB();   // d^3

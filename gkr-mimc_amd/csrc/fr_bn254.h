@@ -146,6 +146,15 @@ FR_HD Fr fr_mont_mul_raw(const Fr& a, const Fr& b) {
     return r;
 }
 
+// Montgomery square a*a/2^256 mod q: the cross products a_i*a_j are taken once against the doubled operand (100 limb
+// products instead of 128, fr_sqr_gen.inc).  PRECONDITION a < 2q (2a must fit eight limbs); the result is the very
+// integer fr_mont_mul_raw(a, a) returns (same T, same m_i), in [0, 2q).
+FR_HD Fr fr_mont_sqr_raw(const Fr& a) {
+    Fr r;
+#include "fr_sqr_gen.inc"
+    return r;
+}
+
 // two independent lazy products at once (instruction streams interleaved on the device: fr_mont2_gen.inc)
 FR_HD void fr_mont_mul2_raw(Fr& r0, Fr& r1, const Fr& a0, const Fr& b0, const Fr& a1, const Fr& b1) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -257,13 +266,14 @@ FR_HD Fr fr_reduce_lt4q(const Fr& t) {
 
 // canonical product
 FR_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_reduce_once(fr_mont_mul_raw(a, b)); }
-FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_mul_raw(a, a)); }
+FR_HD Fr fr_sqr(const Fr& a) { return fr_reduce_once(fr_mont_sqr_raw(a)); }
 
 // x^7 as the reference does it: sq, mul, sq, mul (hash/poseidon.go:129-135, circuit/gates/cipher.go:36-40)
+// PRECONDITION x < 2q (the squaring schedule)
 FR_HD Fr fr_pow7(const Fr& x) {
-    Fr t = fr_mont_mul_raw(x, x);   // x^2  (< 2q)
+    Fr t = fr_mont_sqr_raw(x);      // x^2  (< 2q)
     t = fr_mont_mul_raw(t, x);      // x^3
-    t = fr_mont_mul_raw(t, t);      // x^6
+    t = fr_mont_sqr_raw(t);         // x^6
     return fr_mul(t, x);            // x^7, canonical
 }
 

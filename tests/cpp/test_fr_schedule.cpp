@@ -53,6 +53,14 @@ int main() {
             c = fr_reduce_once(fr_mont_mul_raw(aq, bq));
             if (memcmp(&c, &oc, 32)) bad++;
         }
+        // squaring schedule: the same integer as the general product, for canonical and lazy (a + q < 2q) operands
+        {
+            Fr s0 = fr_mont_sqr_raw(a), s1 = fr_mont_mul_raw(a, a);
+            if (memcmp(&s0, &s1, 32)) bad++;
+            Fr aq; u32 cy = 0; for (int j = 0; j < 8; j++) aq.v[j] = fr_addc(a.v[j], Q[j], cy, &cy);
+            s0 = fr_mont_sqr_raw(aq); s1 = fr_mont_mul_raw(aq, aq);
+            if (memcmp(&s0, &s1, 32)) bad++;
+        }
         // x^7
         if (it % 8 == 0) {
             ofr_t t; oracle_fr_mul(&t, &oa, &oa); oracle_fr_mul(&t, &t, &oa); oracle_fr_mul(&t, &t, &t); oracle_fr_mul(&t, &t, &oa);
@@ -123,7 +131,7 @@ int main() {
     // bounds the planner assumed (every limb 0xFFFFFFFF; top limbs at the largest value of a number below 3q / below
     // q), and values just below 3q with 0xFFFFFFFF patterns.  Any wrap-around of an untracked multiply-add counts.
     {
-        const u32 TOP3Q = 0x912ceb58u, TOPQ = 0x30644e72u;      // floor((3q-1)/2^224), floor((q-1)/2^224)
+        const u32 TOP3Q = 0x912ceb58u, TOPQ = 0x30644e72u, TOP2Q = 0x60c89ce5u;   // floor((3q-1)/2^224), floor((q-1)/2^224), floor((2q-1)/2^224)
         auto pat = [&](int mode, u32 top) {
             Fr x;
             for (int j = 0; j < 7; j++) x.v[j] = mode == 0 ? 0xFFFFFFFFu : mode == 1 ? ((j & 1) ? 0xFFFFFFFFu : 0u) : (u32)rnd() | 0xFFFF0000u;
@@ -141,6 +149,9 @@ int main() {
             for (int j = 0; j < FR_WIDE_LIMBS; j++) A[j] = 0xFFFFFFFFu;
             A[16] = 0;
             fr_mac_wide(A, a3, b3);
+            Fr a2 = pat(ma, TOP2Q);                                 // fr_mont_sqr_raw: a < 2q
+            Fr sq = fr_mont_sqr_raw(a2), sm = fr_mont_mul_raw(a2, a2);
+            if (memcmp(&sq, &sm, 32)) bad++;
             Fr ca = pat(mb, TOPQ), cb = pat((mb + 1) % 3, TOPQ);    // fr_mul_const2_raw: a < 3q, ca, cb < q
             (void)fr_mul_const2_raw(a3, ca, cb);
             n++;

@@ -29,6 +29,7 @@ QL = [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0x
 Q_INT = sum(v << (32 * i) for i, v in enumerate(QL))
 TOP_LT3Q = (3 * Q_INT - 1) >> 224        # largest top limb of a value below 3q
 TOP_LTQ = (Q_INT - 1) >> 224             # ... of a canonical value
+TOP_LT2Q = (2 * Q_INT - 1) >> 224        # ... of a lazy product of operands below 2q
 
 
 def opmax(o, bounds):
@@ -62,7 +63,8 @@ def cexpr(o):
     k, i = o
     if k == "one":
         return "1u"
-    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]", "ca": "ca.v[%d]", "cb": "cb.v[%d]"}[k] % i
+    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]", "ca": "ca.v[%d]", "cb": "cb.v[%d]",
+            "d": "d%d", "e": "e%d"}[k] % i
 
 
 def emit_asm(products, ovf_live):
@@ -166,6 +168,58 @@ def gen_mul():
             host += "    r.v[%d] = (u32)acc;\n" % (c - NL)
             # device: copy the finished limb out of the accumulator pair with an explicit move, otherwise
             # hipcc keeps every result limb in the low half of its own 64-bit register tuple (2x VGPRs)
+            dev += '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (c - NL)
+        sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
+        dev += sh
+        host += sh
+        t_max = s_max >> 32
+    fin = "    r.v[%d] = (u32)acc;\n" % (NL - 1)
+    dfin = '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (NL - 1)
+    return dev + dfin, host + fin
+
+
+# ------------------------------------------------------------------------------------------------
+# squaring: the 28 cross products a_i*a_j (i < j) are taken ONCE, against the doubled operand, so the plain half of
+# the product costs 36 limb products instead of 64 (the Montgomery half is unchanged: 100 instead of 128 in all).
+#     a^2 = sum_i a_i^2 2^(64 i) + sum_i a_i 2^(32 i) * 2 (a - a mod 2^(32 (i + 1)))
+# and the limbs of 2 (a - a mod 2^(32 (i + 1))) are those of 2a above position i + 1 (d_j = a_j << 1 | a_(j-1) >> 31)
+# and, at position i + 1, the doubled limb without the bit that came up from a_i (e_(i+1) = a_(i+1) << 1).
+# PRECONDITION a < 2q < 2^255: 2a fits eight limbs.  The result is the same integer a*a/2^256 + (m*q)/2^256 the
+# general schedule produces (same T, same m_i), bit for bit.
+# ------------------------------------------------------------------------------------------------
+def gen_sqr():
+    bounds = {("a", NL - 1): TOP_LT2Q, ("d", NL - 1): (4 * Q_INT - 1) >> 224}
+    for j in range(1, NL):
+        bounds[("e", j)] = M32 - 1
+    pro = ""
+    for j in range(1, NL):
+        pro += "    const u32 e%d = a.v[%d] << 1;\n" % (j, j)
+    for j in range(2, NL):
+        pro += "    const u32 d%d = (a.v[%d] << 1) | (a.v[%d] >> 31);\n" % (j, j, j - 1)
+    dev = host = pro + "    u64 acc = (u64)a.v[0] * a.v[0];\n    u32 ovf;\n"
+    t_max = M32 * M32
+    for c in range(2 * NL - 1):
+        prods = []
+        lo_i, hi_i = max(0, c - (NL - 1)), min(c, NL - 1)
+        if c > 0:
+            for i in range(lo_i, hi_i + 1):
+                j = c - i
+                if i > j:
+                    continue
+                if i == j:
+                    prods.append((("a", i), ("a", i)))
+                elif j == i + 1:
+                    prods.append((("a", i), ("e", j)))
+                else:
+                    prods.append((("a", i), ("d", j)))
+        for i in range(lo_i, hi_i + 1):
+            if c < NL and i == c:
+                continue
+            prods.append((("m", i), ("q", c - i)))
+        last = ("    const u32 m%d = (u32)acc * FR_QINV32;\n" % c, ("m", c), ("q", 0)) if c < NL else None
+        dev, host, s_max = column(dev, host, t_max, prods, bounds, last)
+        if c >= NL:
+            host += "    r.v[%d] = (u32)acc;\n" % (c - NL)
             dev += '    r.v[%d] = FR_LIMB_COPY((u32)acc);\n' % (c - NL)
         sh = "    acc = (acc >> 32) | ((u64)ovf << 32);\n"
         dev += sh
@@ -370,6 +424,14 @@ def gen_mul_const2():
 
 
 def main():
+    outs = os.path.join(os.path.dirname(OUT), "fr_sqr_gen.inc")
+    dev, host = gen_sqr()
+    with open(outs, "w") as f:
+        f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Body of fr_mont_sqr_raw() in fr_bn254.h:\n"
+                "// input `a` < 2q, output `r` = a*a/2^256 mod q in [0, 2q): 36 + 64 limb products (cross products once,\n"
+                "// against the doubled operand).\n")
+        f.write("#if defined(__HIP_DEVICE_COMPILE__)\n" + dev + "#else\n" + host + "#endif\n")
+    print("wrote", outs)
     outc = os.path.join(os.path.dirname(OUT), "fr_mulc2_gen.inc")
     dev, host = gen_mul_const2()
     with open(outc, "w") as f:
