@@ -446,6 +446,19 @@ int gkrhip_gmimc_circuit(int t, gkrhip_layer* layers_out, int capacity, int* inp
     return (int)v.size();
 }
 
+int gkrhip_gmimc_hash_circuit(int t, int nblocks, gkrhip_layer* layers_out, int capacity, int* input_map_out) {
+    std::vector<gkrhip_layer> v;
+    std::vector<int> map;
+    if (gmimc_hash_layers(t, nblocks, &v, &map) != 0) return -1;
+    if (input_map_out)
+        for (size_t k = 0; k < map.size(); k++) input_map_out[k] = map[k];
+    if (layers_out) {
+        if (capacity < (int)v.size()) return fail("gmimc_hash_circuit: capacity %d < %zu layers", capacity, v.size());
+        memcpy(layers_out, v.data(), v.size() * sizeof(gkrhip_layer));
+    }
+    return (int)v.size();
+}
+
 int gkrhip_gate_register(const gkrhip_gate_desc* desc, int* gate_id) { return gate_register(desc, gate_id); }
 int gkrhip_gate_lookup(int gate_id, gkrhip_gate_desc* desc_out) {
     GateDesc g;

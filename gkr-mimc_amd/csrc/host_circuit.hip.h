@@ -85,9 +85,12 @@ struct GmimcBuilder {
     }
     // prune what does not reach the last layer; kept_inputs (optional) receives the original indices of the input
     // layers that remain (an input layer without a consumer would have no claim to check, gkr/verifier.go:120-132)
-    std::vector<gkrhip_layer> finish(std::vector<int>* kept_inputs = nullptr) {
+    // (output: the layer whose table is the circuit's output, default the last one added; it is the last one kept)
+    std::vector<gkrhip_layer> finish(std::vector<int>* kept_inputs = nullptr, int output = -1) {
         std::vector<char> need(L.size(), 0);
-        need.back() = 1;
+        if (output < 0) output = (int)L.size() - 1;
+        need[output] = 1;
+        L.resize(output + 1);
         for (int l = (int)L.size() - 1; l >= 0; l--)
             if (need[l])
                 for (int k = 0; k < L[l].n_in; k++) need[L[l].in[k]] = 1;
@@ -158,6 +161,50 @@ int gmimc_layers(int t, std::vector<gkrhip_layer>* out, std::vector<int>* input_
     }
     B.add(sum3, {st[0], cs0, cb[0]}, hfr::ZERO);
     *out = B.finish(input_map);
+    return 0;
+}
+
+// The whole sponge GMimcT{t}.Hash(msg) for messages of nblocks * t elements (hash/gmimc.go:29-49: state = 0; every
+// block of t elements goes through UpdateInplace; the hash is state[0]).  The whole state is carried from block to
+// block: from the second block on the feed-forward perm[j] + state[j] + block[j] is a "sum3" layer on EVERY branch (a
+// layer with two consumers, round 0 and the feed-forward of the next block, gets two claims like any other).  In the
+// first block the state is zero and the layers are the registered one-input gates "addark1" (x + Ark) and "pow7ark1"
+// ((x + Ark)^7) and a two-input add for the feed-forward.  input_map[k] = index into msg of input layer k.
+int gmimc_hash_layers(int t, int nblocks, std::vector<gkrhip_layer>* out, std::vector<int>* input_map) {
+    if (t != 2 && t != 4 && t != 8) return fail("gmimc hash circuit: t = %d (2, 4 or 8)", t);
+    if (nblocks < 1 || nblocks > 64) return fail("gmimc hash circuit: %d blocks (1..64)", nblocks);
+    int sum3 = -1, add1 = -1, pow1 = -1;
+    auto reg = [&](const char* id, int n_in, unsigned mask, int power, int* g) {
+        gkrhip_gate_desc d;
+        memset(&d, 0, sizeof d);
+        strcpy(d.id, id);
+        d.n_in = n_in;
+        d.sum_mask = mask;
+        d.power = power;
+        return gate_register(&d, g);
+    };
+    CHK(reg("sum3", 3, 7u, 1, &sum3));
+    CHK(reg("addark1", 1, 1u, 1, &add1));
+    CHK(reg("pow7ark1", 1, 1u, 7, &pow1));
+    GmimcBuilder B;
+    for (int i = 0; i < t * nblocks; i++) B.add(-1, {}, hfr::ZERO);
+    std::vector<int> st(t, -1);
+    for (int b = 0; b < nblocks; b++) {
+        std::vector<int> cb(t);
+        for (int j = 0; j < t; j++) cb[j] = B.add(GKRHIP_GATE_IDENTITY, {b * t + j}, hfr::ZERO);
+        const std::vector<int> old = st;
+        std::vector<int> cur = st;
+        for (int i = 0; i < hfr::MIMC_ROUNDS; i++) {
+            std::vector<int> nx(t);
+            for (int j = 1; j < t; j++)
+                nx[j - 1] = cur[j] < 0 ? B.add(add1, {cb[j]}, hfr::ARKS[i]) : B.add(GKRHIP_GATE_ADD, {cur[j], cb[j]}, hfr::ARKS[i]);
+            nx[t - 1] = cur[0] < 0 ? B.add(pow1, {cb[0]}, hfr::ARKS[i]) : B.add(GKRHIP_GATE_CIPHER, {cb[0], cur[0]}, hfr::ARKS[i]);
+            cur = nx;
+        }
+        for (int j = 0; j < t; j++)
+            st[j] = old[j] < 0 ? B.add(GKRHIP_GATE_ADD, {cur[j], cb[j]}, hfr::ZERO) : B.add(sum3, {cur[j], old[j], cb[j]}, hfr::ZERO);
+    }
+    *out = B.finish(input_map, st[0]);
     return 0;
 }
 

@@ -59,6 +59,7 @@ ABI = {
     "gkrhip_session_num_inputs": (_I, [_P]),
     "gkrhip_gmimc_t2_circuit": (_I, [_P, _I]),
     "gkrhip_gmimc_circuit": (_I, [_I, _P, _I, _P]),
+    "gkrhip_gmimc_hash_circuit": (_I, [_I, _I, _P, _I, _P]),
     "gkrhip_gate_register": (_I, [_P, C.POINTER(_I)]),
     "gkrhip_gate_lookup": (_I, [_I, _P]),
     "gkrhip_gkr_verify": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
@@ -336,6 +337,20 @@ def gmimc_circuit(t):
     arr = (LayerDesc * n)()
     imap = (C.c_int * (2 * t))(*([-1] * (2 * t)))
     assert load().gkrhip_gmimc_circuit(t, C.cast(arr, C.c_void_p), n, C.cast(imap, C.c_void_p)) == n
+    layers = _layers_to_list(arr)
+    n_in = sum(1 for l in layers if l[0] < 0)
+    return layers, [imap[k] for k in range(n_in)]
+
+
+def gmimc_hash_circuit(t, nblocks):
+    """The sponge GMimcT{t}.Hash over nblocks * t message elements as a circuit: (layers, input_map); input layer k is
+    msg[input_map[k]]."""
+    n = load().gkrhip_gmimc_hash_circuit(t, nblocks, None, 0, None)
+    if n < 0:
+        _check(n)
+    arr = (LayerDesc * n)()
+    imap = (C.c_int * (t * nblocks))(*([-1] * (t * nblocks)))
+    assert load().gkrhip_gmimc_hash_circuit(t, nblocks, C.cast(arr, C.c_void_p), n, C.cast(imap, C.c_void_p)) == n
     layers = _layers_to_list(arr)
     n_in = sum(1 for l in layers if l[0] < 0)
     return layers, [imap[k] for k in range(n_in)]

@@ -161,6 +161,13 @@ int gkrhip_gmimc_t2_circuit(gkrhip_layer *layers_out, int capacity);
  * the operands that matter and input_map_out (2t ints, may be NULL) names them -- input layer k is state[j] when
  * input_map_out[k] = j < t, block[j - t] otherwise.  Returns the number of layers. */
 int gkrhip_gmimc_circuit(int t, gkrhip_layer *layers_out, int capacity, int *input_map_out);
+/* The whole sponge GMimcT{t}.Hash(msg) for messages of nblocks * t elements (hash/gmimc.go:29-49: state = 0, one
+ * UpdateInplace per block of t elements, the hash is state[0]); nblocks in 1..64.  The state is carried from block to block
+ * (from the second block on the feed-forward is a "sum3" layer on every branch); in the first block, where the state is
+ * zero, the round layers are the registered one-input gates "addark1" (x + Ark) and "pow7ark1" ((x + Ark)^7).
+ * input_map_out (t * nblocks ints, may be NULL): input layer k is msg[input_map_out[k]] (elements the hash does not depend
+ * on -- none for these parameters -- would not be inputs).  Returns the number of layers. */
+int gkrhip_gmimc_hash_circuit(int t, int nblocks, gkrhip_layer *layers_out, int capacity, int *input_map_out);
 
 /* ---- gkr.Verify (gkr/verifier.go:15-132): native verifier; MultiLin.Evaluate of the output and input tables
  * runs on the device, the rest is scalar host work.  Returns 0 = accepted, > 0 = rejected (code in

@@ -183,6 +183,60 @@ func cLayers(layers []Layer) []C.gkrhip_layer {
 	return cl
 }
 
+// goLayers converts the library's layer descriptions back to the Go mirror.
+func goLayers(cl []C.gkrhip_layer) []Layer {
+	out := make([]Layer, len(cl))
+	for i := range cl {
+		out[i].Gate = int(cl[i].gate)
+		out[i].In = make([]int, int(cl[i].n_in))
+		for k := range out[i].In {
+			out[i].In[k] = int(cl[i].in[k])
+		}
+		for k := 0; k < 4; k++ {
+			out[i].Ark[k] = uint64(cl[i].ark[k])
+		}
+	}
+	return out
+}
+
+// GmimcCircuit is the build-defined circuit of one GMiMC compression, out = GMimcT{t}.UpdateInplace(state, block)[0]
+// (hash/gmimc.go:52-65), t = 2, 4 or 8.  Input layer k is state[j] when inputMap[k] = j < t, block[j-t] otherwise.
+func GmimcCircuit(t int) (layers []Layer, inputMap []int) {
+	n := C.gkrhip_gmimc_circuit(C.int(t), nil, 0, nil)
+	if n < 0 {
+		must(n)
+	}
+	cl := make([]C.gkrhip_layer, int(n))
+	im := make([]C.int, 2*t)
+	must(C.gkrhip_gmimc_circuit(C.int(t), &cl[0], n, &im[0]) - n)
+	layers = goLayers(cl)
+	for _, l := range layers {
+		if l.Gate < 0 {
+			inputMap = append(inputMap, int(im[len(inputMap)]))
+		}
+	}
+	return layers, inputMap
+}
+
+// GmimcHashCircuit is the whole sponge GMimcT{t}.Hash(msg) (hash/gmimc.go:29-49) for messages of nblocks*t elements
+// as one circuit.  Input layer k is msg[inputMap[k]].
+func GmimcHashCircuit(t, nblocks int) (layers []Layer, inputMap []int) {
+	n := C.gkrhip_gmimc_hash_circuit(C.int(t), C.int(nblocks), nil, 0, nil)
+	if n < 0 {
+		must(n)
+	}
+	cl := make([]C.gkrhip_layer, int(n))
+	im := make([]C.int, t*nblocks)
+	must(C.gkrhip_gmimc_hash_circuit(C.int(t), C.int(nblocks), &cl[0], n, &im[0]) - n)
+	layers = goLayers(cl)
+	for _, l := range layers {
+		if l.Gate < 0 {
+			inputMap = append(inputMap, int(im[len(inputMap)]))
+		}
+	}
+	return layers, inputMap
+}
+
 // NewSession builds the circuit on the device (circuit.BuildCircuit's rules are enforced by the library).
 func NewSession(layers []Layer, bN int) *Session {
 	cl := cLayers(layers)

@@ -412,6 +412,47 @@ def gmimc_circuit(t):
     return build_circuit([Layer([ren[p] for p in L[l].In], L[l].gate) for l in keep]), input_map
 
 
+def gmimc_hash_circuit(t, nblocks):
+    """Build-defined GKR circuit of the whole sponge GMimcT{t}.Hash(msg) for messages of nblocks * t elements
+    (hash/gmimc.go:29-49: state = 0; for every block of t elements UpdateInplace(state, block); return state[0]).
+    Returns (circuit, input_map): input layer k is msg[input_map[k]].  Every block element sits behind a copy layer
+    (91 rounds and the feed-forward use it); in the first block the state is zero, so a round's layers there are the
+    one-input gates (x + Ark) and (x + Ark)^7 and the feed-forward is perm[j] + block[j]; from the second block on a
+    round is an AddGate layer per linear branch and a CipherGate layer for the S-box branch, and the feed-forward
+    perm[j] + state[j] + block[j] is the three-input SumGate on every branch (the whole state is carried from block to
+    block).  Layers that do not reach the output are pruned."""
+    assert t in (2, 4, 8) and nblocks >= 1
+    L = [Layer([]) for _ in range(t * nblocks)]
+    st = [None] * t
+    for b in range(nblocks):
+        cb = []
+        for j in range(t):
+            L.append(Layer([b * t + j], IdentityGate()))
+            cb.append(len(L) - 1)
+        old, cur = list(st), list(st)
+        for i in range(MIMC_ROUNDS):
+            nx = [None] * t
+            for j in range(1, t):
+                L.append(Layer([cb[j]], SumGate(ARKS[i], 1)) if cur[j] is None else Layer([cur[j], cb[j]], AddGate(ARKS[i])))
+                nx[j - 1] = len(L) - 1
+            L.append(Layer([cb[0]], SumGate(ARKS[i], 7)) if cur[0] is None else Layer([cb[0], cur[0]], CipherGate(ARKS[i])))
+            nx[t - 1] = len(L) - 1
+            cur = nx
+        st = []
+        for j in range(t):
+            L.append(Layer([cur[j], cb[j]], AddGate(0)) if old[j] is None else Layer([cur[j], old[j], cb[j]], SumGate(0, 1)))
+            st.append(len(L) - 1)
+    need = {st[0]}
+    for l in range(len(L) - 1, -1, -1):
+        if l in need:
+            need.update(L[l].In)
+    keep = [l for l in range(len(L)) if l in need]
+    assert keep[-1] == st[0]
+    ren = {l: k for k, l in enumerate(keep)}
+    input_map = [l for l in keep if l < t * nblocks]
+    return build_circuit([Layer([ren[p] for p in L[l].In], L[l].gate) for l in keep]), input_map
+
+
 def assign(c, *inps):
     """circuit/assignment.go:12-32."""
     a = [None] * len(c)

@@ -98,6 +98,41 @@ def test_gmimc_t_circuits_match_oracle(gk):
         assert o.gmimc_hash(msg, e["t"]) == c.to_ints(hex_to_fr(e["out"]))[0]
 
 
+def test_gmimc_hash_circuits_match_oracle(gk):
+    """gkrhip_gmimc_hash_circuit(t, nblocks) -- the whole sponge hash.GMimcHasher.Hash (hash/gmimc.go:29-49) over nblocks
+    blocks -- is layer for layer the circuit pyoracle builds, with the same input map, and that circuit's output is the
+    reference hasher's digest of each instance's message (the hasher itself is pinned on kat.json's gmimc_hash vectors)."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as o
+    for t, nb in ((2, 1), (2, 2), (2, 3), (4, 2), (8, 2)):
+        lib_c, lib_map = gk.gmimc_hash_circuit(t, nb)
+        ref_c, ref_map = o.gmimc_hash_circuit(t, nb)
+        assert lib_map == ref_map and len(lib_c) == len(ref_c)
+        for (gate, ins, ark), lay in zip(lib_c, ref_c):
+            assert ins == lay.In
+            if lay.gate is None:
+                assert gate == -1
+                continue
+            if lay.gate.kind in ("sum", "sum_pow7"):
+                d = gk.gate_lookup(gate)
+                assert (d["n_in"], d["sum_mask"], d["power"]) == (len(lay.In), (1 << len(lay.In)) - 1, lay.gate.power) and gate >= 3
+            else:
+                assert gate == {"identity": gk.GATE_IDENTITY, "cipher": gk.GATE_CIPHER, "add": gk.GATE_ADD}[lay.gate.kind]
+            if lay.gate.kind != "identity":
+                assert ark == o.to_mont_limbs(lay.gate.ark)
+        random.seed(10 * t + nb)
+        msg = [[random.randrange(o.Q) for _ in range(2)] for _ in range(t * nb)]
+        a = o.assign(ref_c, *[msg[k] for k in ref_map])
+        for k in range(2):
+            assert a[-1][k] == o.gmimc_hash([m[k] for m in msg], t)
+    with pytest.raises(gk.prover.GkrHipError):
+        gk.gmimc_hash_circuit(3, 2)
+    with pytest.raises(gk.prover.GkrHipError):
+        gk.gmimc_hash_circuit(2, 0)
+
+
 def test_gate_table(gk):
     """The gate plug point (circuit/gates.go:9-21) as a descriptor table: built-ins, registration, refusals."""
     assert gk.gate_lookup(gk.GATE_IDENTITY) == {"id": "CopyGate", "n_in": 1, "sum_mask": 1, "power": 1}

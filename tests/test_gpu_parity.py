@@ -806,6 +806,34 @@ def test_gmimc_t4_t8_circuits_vs_oracle(gk, t):
         s.close()
 
 
+@pytest.mark.parametrize("t,nb", [(2, 2), (4, 2), (2, 3)])
+def test_gmimc_sponge_circuit_vs_oracle(gk, t, nb):
+    """The whole sponge hash.GMimcHasher.Hash (hash/gmimc.go:29-49) over nb blocks as ONE circuit (state carried from
+    block to block, layers with two consumers, one-input gates in the first block): transcript against the C oracle,
+    outputs against the reference hasher's digest of every instance's message."""
+    layers, imap = gk.gmimc_hash_circuit(t, nb)
+    circ, ref_map = o.gmimc_hash_circuit(t, nb)
+    assert imap == ref_map
+    descs = c.circuit_descs(circ)
+    for bn in (2, 7):
+        n = 1 << bn
+        rng = np.random.default_rng(1000 * t + 10 * nb + bn)
+        vals = [[int(v) for v in rng.integers(0, 1 << 62, n)] for _ in range(t * nb)]
+        ins = [c.from_ints(vals[j]) for j in imap]
+        qp = c.random_fr_array(bn)
+        want, wouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
+        s = gk.MimcSession(bn, layers=layers)
+        for k, tab in enumerate(ins):
+            s.load_input(k, tab)
+        s.assign()
+        flat = s.prove(qp)
+        assert np.array_equal(flat, want) and np.array_equal(s.outputs(), wouts)
+        assert gk.gkr_verify(layers, flat, ins, wouts, qp)
+        if bn == 2:
+            assert c.to_ints(wouts) == [o.gmimc_hash([vals[j][k] for j in range(t * nb)], t) for k in range(n)]
+        s.close()
+
+
 @pytest.mark.parametrize("t,bn", [(4, 16), (4, 20), (8, 16)])
 def test_gmimc_t4_t8_match_oracle_digest(gk, t, bn):
     """The GMiMC circuits with the registered three-input feed-forward gate at larger sizes: SHA-256 of the transcript and

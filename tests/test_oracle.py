@@ -222,6 +222,26 @@ def test_gmimc_circuit_c_oracle_vs_python_oracle(bn):
         assert c.gkr_verify_circuit(descs, bn, bad, cins, outs, c.from_ints(qp)) != 0
 
 
+@pytest.mark.parametrize("t,nb,bn", [(2, 2, 1), (4, 2, 2)])
+def test_gmimc_sponge_circuit_c_oracle_vs_python_oracle(t, nb, bn):
+    """The sponge hash.GMimcHasher.Hash over nb blocks as one circuit (layers with two consumers, one-input gates in the
+    first block): both oracles produce the same transcript, the restated gkr.Verify accepts it, and the outputs are the
+    reference hasher's digests."""
+    n = 1 << bn
+    circ, imap = o.gmimc_hash_circuit(t, nb)
+    msg = [[o.mimc_hash([7 * j + k + 1]) for k in range(n)] for j in range(t * nb)]
+    ins = [msg[j] for j in imap]
+    a = o.assign(circ, *ins)
+    assert a[-1] == [o.gmimc_hash([m[k] for m in msg], t) for k in range(n)]
+    qp = o.random_fr_array(bn)
+    want = o.gkr_proof_to_vec(o.gkr_prove(circ, a, qp))
+    descs = c.circuit_descs(circ)
+    cins = [c.from_ints(x) for x in ins]
+    flat, outs, _ = c.gkr_prove_circuit(descs, bn, cins, c.from_ints(qp))
+    assert c.to_ints(flat) == want and c.to_ints(outs) == a[-1]
+    assert c.gkr_verify_circuit(descs, bn, flat, cins, outs, c.from_ints(qp)) == 0
+
+
 def test_survey_appendix_b():
     """values of an independent restatement of the reference (written by a different
     session, KAT-anchored and verifier-accepted) -- the only second reading of the algorithm this repository
