@@ -32,6 +32,7 @@ print([p.wait() for p in ps])
 PY
           ) > $OUT/w8_$v.log 2>&1; tail -4 $OUT/w8_$v.log; done ;;
     bench2) timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 2 --device 0 --bn 22 --steps 4 --warmup 2 > $OUT/bench_2ranks_1gpu.json 2> $OUT/bench_2ranks_1gpu.err; tail -c 1500 $OUT/bench_2ranks_1gpu.json; tail -5 $OUT/bench_2ranks_1gpu.err ;;
+    bench2_stall) GKRHIP_BENCH_RCCL_LIMIT_S=0.3 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --device 0 --bn 22 --steps 4 --warmup 2 > $OUT/bench_2ranks_stall.json 2> $OUT/bench_2ranks_stall.err; tail -c 900 $OUT/bench_2ranks_stall.json; tail -3 $OUT/bench_2ranks_stall.err ;;
     w8probe) timeout 900 python tools/w8_probe.py > $OUT/w8_probe.log 2>&1; cat $OUT/w8_probe.log ;;
     *) echo "unknown step $step" ;;
   esac
