@@ -458,8 +458,8 @@ def main():
                            "algorithmic_bytes_per_launch": bytes1,
                            "measured": "HIP events on the launching stream around %d launches queued back to back, nothing else "
                                        "running (gkrhip_bench_fold): wall time / %d.  rocprofv3's per-kernel average for the "
-                                       "full-size launches agrees within 3 %% (profiles/r02_v5_solo_fold_launches_by_size.csv: "
-                                       "125.8 us); 96 B per output element (SURVEY 8d)" % (iters, iters),
+                                       "full-size launches agrees within 3 %% (profiles/r02_v6_solo_fold_launches_by_size.csv: "
+                                       "127.6 us over 54 launches); 96 B per output element (SURVEY 8d)" % (iters, iters),
                            "one_at_a_time": {"avg_launch_ms": ms1, "achieved": bytes1 / (ms1 * 1e-3) / 1e9,
                                              "frac": bytes1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "measured": "the same %d launches one at a time on an idle GPU, one event pair each: "
