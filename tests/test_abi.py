@@ -177,10 +177,13 @@ def test_host_scalar_code_vs_oracle(tmp_path):
 
 
 def test_generated_schedule_is_current():
-    inc = os.path.join(ROOT, "gkr-mimc_amd", "csrc", "fr_mont_gen.inc")
-    before = open(inc).read()
+    """Every generated column schedule (product, square, interleaved pair, wide MAC, constant-multiplier product) is what
+    tools/gen_mont_asm.py produces now."""
+    incs = [os.path.join(ROOT, "gkr-mimc_amd", "csrc", f) for f in
+            ("fr_mont_gen.inc", "fr_sqr_gen.inc", "fr_mont2_gen.inc", "fr_mac_wide_gen.inc", "fr_mulc2_gen.inc")]
+    before = [open(f).read() for f in incs]
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_mont_asm.py")], stdout=subprocess.DEVNULL)
-    assert open(inc).read() == before
+    assert [open(f).read() for f in incs] == before
 
 
 def test_product_does_not_reference_oracle():
