@@ -602,8 +602,23 @@ void gkrhip_mimc_session_destroy(gkrhip_session* s) {
     delete s;
 }
 
-int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
-                          uint64_t* outputs_or_null) {
+// regular: in0, in1, qprime, flat and the outputs are REGULAR-form values (the hint interface's big.Int words,
+// prover/gadget/hints.go:202-205,224-231) instead of Montgomery fr.Elements; the bulk conversions ride on the boundary
+// transposition of the tables, the few proof elements are converted on the host.
+static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
+                              uint64_t* outputs_or_null, bool regular) {
+    RegularIO rio(regular);
+    std::vector<E> qp_m;
+    if (regular && bN > 0) {
+        qp_m.resize(bN);
+        for (int i = 0; i < bN; i++) {
+            E v;
+            memcpy(v.l, qprime + 4 * i, 32);
+            if (!hfr::is_canonical(v)) return fail("qPrime holds a value that is not below q");
+            qp_m[i] = hfr::mul(v, hfr::R2);
+        }
+        qprime = (const uint64_t*)qp_m.data();
+    }
     gkrhip_session* s = nullptr;
     CHK(gkrhip_mimc_session_create(&s, bN));
     int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
@@ -622,6 +637,7 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
         dl = std::thread([&]() {
             std::lock_guard<std::mutex> lk(dl_lane->mu);
             UseLane u(dl_lane);
+            RegularIO rio2(regular);
             rc_out = hipSetDevice(g0.device) == hipSuccess ? download_table(session_table(s, (int)s->c.size() - 1), outputs_or_null, s->n)
                                                            : fail("hipSetDevice failed");
             if (rc_out) err_out = g_err;
@@ -638,8 +654,22 @@ int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, cons
     } else if (rc == 0 && outputs_or_null) {
         rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
     }
+    if (rc == 0 && regular) {
+        const E one = {{1, 0, 0, 0}};
+        const size_t len = proof_len(s->c, bN);
+        E* f = (E*)flat;
+        for (size_t i = 0; i < len; i++) f[i] = hfr::mul(f[i], one);
+    }
     gkrhip_mimc_session_destroy(s);
     return rc;
+}
+int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
+                          uint64_t* outputs_or_null) {
+    return prove_mimc_oneshot(bN, in0, in1, qprime, flat, outputs_or_null, false);
+}
+int gkrhip_gkr_prove_mimc_regular(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
+                                  uint64_t* outputs_or_null) {
+    return prove_mimc_oneshot(bN, in0, in1, qprime, flat, outputs_or_null, true);
 }
 
 // Circuit.Assign + gkr.Prove for any circuit of library gates on host tables, in one call (the generic form of

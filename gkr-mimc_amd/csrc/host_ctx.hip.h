@@ -486,18 +486,31 @@ struct ScopedTable : DevTable {
 // call, pay no hipMalloc/hipFree per call.
 // host AoS -> device planes.  Staged through a device AoS buffer and transposed by k_aos_to_planes, which also
 // checks the fr.Element invariant the lazy-reduction bounds of the round kernels rely on (every element < q).
+// RegularIO (thread-local scope): the host images of this thread's uploads / downloads are REGULAR-form elements (the
+// big.Int words of the hint interface) instead of Montgomery fr.Elements; the conversion rides on the transposition.
+thread_local bool g_regular_io = false;
+struct RegularIO {
+    bool prev;
+    explicit RegularIO(bool on = true) : prev(g_regular_io) { g_regular_io = on; }
+    ~RegularIO() { g_regular_io = prev; }
+};
 int upload_table(DevTable* t, const uint64_t* host_aos, size_t n) {
     ScopedTable st;
     CHK(table_alloc(&st, n));
     uint4* stage = st.base;
     HIPCHK(hipMemcpyAsync(stage, host_aos, 32 * n, hipMemcpyHostToDevice, cx().stream));
-    hipLaunchKernelGGL(k_aos_to_planes, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n,
-                       cx().d_bad);
+    if (g_regular_io)
+        hipLaunchKernelGGL(k_aos_to_planes<true>, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n,
+                           cx().d_bad, to_dev(hfr::R2));
+    else
+        hipLaunchKernelGGL(k_aos_to_planes<false>, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, stage, t->planes(), n,
+                           cx().d_bad, to_dev(hfr::ZERO));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(cx().stream));
     if (*(volatile unsigned int*)cx().h_bad) {
         *cx().h_bad = 0;
-        return fail("input table holds an element that is not a canonical fr.Element (limbs >= q)");
+        return fail(g_regular_io ? "input table holds a value that is not below q"
+                                 : "input table holds an element that is not a canonical fr.Element (limbs >= q)");
     }
     table_release(&st);
     return 0;
@@ -506,7 +519,14 @@ int download_table(const DevTable* t, uint64_t* host_aos, size_t n) {
     ScopedTable st;
     CHK(table_alloc(&st, n));
     uint4* stage = st.base;
-    hipLaunchKernelGGL(k_planes_to_aos, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->cplanes(), stage, n);
+    if (g_regular_io) {
+        const E one = {{1, 0, 0, 0}};
+        hipLaunchKernelGGL(k_planes_to_aos<true>, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->cplanes(), stage, n,
+                           to_dev(one));
+    } else {
+        hipLaunchKernelGGL(k_planes_to_aos<false>, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->cplanes(), stage, n,
+                           to_dev(hfr::ZERO));
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_aos, stage, 32 * n, hipMemcpyDeviceToHost, cx().stream));
     HIPCHK(hipStreamSynchronize(cx().stream));

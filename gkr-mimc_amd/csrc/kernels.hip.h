@@ -43,26 +43,44 @@ __device__ __forceinline__ void st_fr(uint4* __restrict__ lo, uint4* __restrict_
 // ------------------------------------------------------------------------------------------------
 // `bad` (host-mapped word) is set when an element is not below q: gnark-crypto keeps fr.Element canonical and the
 // lazy-reduction bounds of the round kernels (u < 3q, d < 2q, fold results < 4q) assume exactly that of table entries
+// SCALE: every element is multiplied by `factor` on the way (Montgomery product): R^2 turns a regular-form boundary image
+// (big.Int words, prover/gadget/hints.go:202-205) into Montgomery form, the plain integer 1 turns Montgomery form into
+// regular form -- the hint's conversions fused into the transposition the boundary needs anyway.
+template <bool SCALE>
 __global__ void __launch_bounds__(GKR_BLOCK) k_aos_to_planes(const uint4* __restrict__ aos, Planes out, size_t n,
-                                                             unsigned int* bad) {
+                                                             unsigned int* bad, Fr factor) {
     const u32 q[8] = {FRQ0, FRQ1, FRQ2, FRQ3, FRQ4, FRQ5, FRQ6, FRQ7};
     bool any_bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 a = aos[2 * i], b = aos[2 * i + 1];
-        out.lo[i] = a;
-        out.hi[i] = b;
+        uint4 a = aos[2 * i], b = aos[2 * i + 1];
         const u32 v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         u32 br = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) (void)fr_subb(v[j], q[j], br, &br);
         any_bad |= br == 0;                           // no borrow: v >= q
+        if (SCALE) {
+            const Fr x = {{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}};
+            const Fr y = fr_mul(x, factor);
+            a = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+            b = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+        }
+        out.lo[i] = a;
+        out.hi[i] = b;
     }
     if (any_bad) atomicOr(bad, 1u);
 }
-__global__ void __launch_bounds__(GKR_BLOCK) k_planes_to_aos(CPlanes in, uint4* __restrict__ aos, size_t n) {
+template <bool SCALE>
+__global__ void __launch_bounds__(GKR_BLOCK) k_planes_to_aos(CPlanes in, uint4* __restrict__ aos, size_t n, Fr factor) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        aos[2 * i] = in.lo[i];
-        aos[2 * i + 1] = in.hi[i];
+        uint4 a = in.lo[i], b = in.hi[i];
+        if (SCALE) {
+            const Fr x = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+            const Fr y = fr_mul(x, factor);
+            a = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+            b = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+        }
+        aos[2 * i] = a;
+        aos[2 * i + 1] = b;
     }
 }
 

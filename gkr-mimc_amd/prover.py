@@ -45,6 +45,7 @@ ABI = {
     "gkrhip_sumcheck_prove": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P]),
     "gkrhip_mimc_proof_len": (_SZ, [_I]),
     "gkrhip_gkr_prove_mimc": (_I, [_I, _P, _P, _P, _P, _P]),
+    "gkrhip_gkr_prove_mimc_regular": (_I, [_I, _P, _P, _P, _P, _P]),
     "gkrhip_mimc_session_create": (_I, [C.POINTER(_P), _I]),
     "gkrhip_mimc_session_load_inputs": (_I, [_P, _P, _P]),
     "gkrhip_mimc_session_synth_inputs": (_I, [_P, _U64, _U64]),
@@ -233,8 +234,9 @@ def mimc_proof_len(bN):
     return load().gkrhip_mimc_proof_len(bN)
 
 
-def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True):
-    """Circuit.Assign(in0, in1) + gkr.Prove(MimcCircuit, a, qPrime); returns (flat proof, outputs)."""
+def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True, regular=False):
+    """Circuit.Assign(in0, in1) + gkr.Prove(MimcCircuit, a, qPrime); returns (flat proof, outputs).  regular=True: every
+    buffer holds regular-form values (the hint interface's big.Int words) instead of Montgomery fr.Elements."""
     in0, in1 = _fr(in0), _fr(in1)
     n = in0.shape[0]
     bN = n.bit_length() - 1
@@ -243,7 +245,8 @@ def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True):
     assert q_prime.shape[0] == bN
     flat = np.zeros((mimc_proof_len(bN), 4), np.uint64)
     outs = np.zeros((n, 4), np.uint64) if want_outputs else None
-    _check(load().gkrhip_gkr_prove_mimc(bN, _ptr(in0), _ptr(in1), _ptr(q_prime) if bN else None, _ptr(flat), _ptr(outs)))
+    fn = load().gkrhip_gkr_prove_mimc_regular if regular else load().gkrhip_gkr_prove_mimc
+    _check(fn(bN, _ptr(in0), _ptr(in1), _ptr(q_prime) if bN else None, _ptr(flat), _ptr(outs)))
     return flat, outs
 
 

@@ -107,6 +107,13 @@ size_t gkrhip_mimc_proof_len(int bN);
  * (hints.go:236-271) kept as Montgomery limbs; outputs_or_null: 2^bN elements = assignment[93]. */
 int gkrhip_gkr_prove_mimc(int bN, const uint64_t *in0, const uint64_t *in1, const uint64_t *qprime,
                           uint64_t *flat, uint64_t *outputs_or_null);
+/* The same with every buffer in REGULAR form (4 little-endian 64-bit words of the value itself, i.e. big.Int.Bits() padded
+ * to four words; every value < q): the body of GkrProverHint.Call (prover/gadget/hints.go:197-233) without 2^(bN+1)
+ * SetBigInt and 1 006*bN+183 ToBigIntRegular conversions on the Go side -- the Montgomery conversion of the input tables
+ * and of the output table rides on the limb-plane transposition the boundary needs anyway, the few proof elements are
+ * converted on the host. */
+int gkrhip_gkr_prove_mimc_regular(int bN, const uint64_t *in0, const uint64_t *in1, const uint64_t *qprime,
+                                  uint64_t *flat, uint64_t *outputs_or_null);
 
 /* Resident session: the assignment stays in HBM, Prove can be repeated (it never mutates the
  * assignment).  This is what the benchmark times (gkr/gkr_test.go:99-105 excludes Assign). */

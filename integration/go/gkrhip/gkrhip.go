@@ -360,6 +360,16 @@ func ProveMimc(bN int, in0, in1, qPrime, outputs []fr.Element) []fr.Element {
 	return flat
 }
 
+// ProveMimcRegular is ProveMimc with every buffer in REGULAR form ([4]uint64 little-endian words of the value itself, what
+// big.Int.Bits() holds): the hint's big.Int conversions become word copies, the Montgomery conversions ride on the library's
+// boundary transposition.  in0, in1, qPrime and the results are NOT valid fr.Elements in the Montgomery sense -- they are
+// carried in []fr.Element only for its memory layout.
+func ProveMimcRegular(bN int, in0, in1, qPrime, outputs []fr.Element) []fr.Element {
+	flat := make([]fr.Element, int(C.gkrhip_mimc_proof_len(C.int(bN))))
+	must(C.gkrhip_gkr_prove_mimc_regular(C.int(bN), ptr(in0), ptr(in1), ptr(qPrime), ptr(flat), ptr(outputs)))
+	return flat
+}
+
 // VerifyMimc is gkr.Verify for examples.MimcCircuit on host tables.
 func VerifyMimc(bN int, flat, in0, in1, outputs, qPrime []fr.Element) error {
 	rc := C.gkrhip_gkr_verify_mimc(C.int(bN), ptr(flat), ptr(in0), ptr(in1), ptr(outputs), ptr(qPrime))

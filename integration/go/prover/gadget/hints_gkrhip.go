@@ -22,9 +22,18 @@ func (h *GkrProverHint) Call(_ ecc.ID, inputsBI []*big.Int, oups []*big.Int) err
 	bN := common.Log2Ceil(h.g.ioStore.Index())
 	paddedIndex := 1 << bN
 
+	// big.Int -> words, no arithmetic: the values stay in REGULAR form and the library converts them to Montgomery form on
+	// the device while it transposes the tables (gkrhip_gkr_prove_mimc_regular); the pure-Go path pays one SetBigInt
+	// (a Montgomery multiplication) per element here, 2^(bN+1) of them
 	drain := make([]fr.Element, len(inputsBI))
 	for i := range drain {
-		drain[i].SetBigInt(inputsBI[i])
+		b := inputsBI[i]
+		if b.Sign() < 0 || b.Cmp(fr.Modulus()) >= 0 {
+			b = new(big.Int).Mod(b, fr.Modulus())
+		}
+		for k, w := range b.Bits() { // little-endian words; big.Word is 64 bits wide on every platform cgo + HIP run on
+			drain[i][k] = uint64(w)
+		}
 	}
 	inputs := make([]poly.MultiLin, h.g.Circuit.InputArity())
 	qPrime, drain := drain[:bN], drain[bN:]
@@ -34,28 +43,36 @@ func (h *GkrProverHint) Call(_ ecc.ID, inputsBI []*big.Int, oups []*big.Int) err
 	outputs, drain := drain[:paddedIndex], drain[paddedIndex:]
 	common.Assert(len(drain) == 0, "The drain was expected to emptied but there remains %v elements", len(drain))
 
-	// Assign + Prove on the device (hints.go:220-222).  The generic path works for any circuit of library gates;
-	// examples.MimcCircuit has a one-call form that also overlaps the download of the outputs with the proof.
+	// Assign + Prove on the device (hints.go:220-222).  examples.MimcCircuit has a one-call form on regular-form buffers;
+	// any other circuit of library gates goes through the generic path on Montgomery elements.
 	t := common.NewTimer("gkr prover hint")
-	var flat []fr.Element
+	var flat []fr.Element // regular form from here on
 	if len(inputs) == 2 && len(h.g.Circuit) == 94 {
-		flat = gkrhip.ProveMimc(bN, inputs[0], inputs[1], qPrime, nil)
+		flat = gkrhip.ProveMimcRegular(bN, inputs[0], inputs[1], qPrime, nil)
+		if debug { // the verifier takes Montgomery elements: convert copies
+			m := func(s []fr.Element) []fr.Element { c := append([]fr.Element{}, s...); gkrhip.FromRegular(c); return c }
+			valid := gkrhip.VerifyMimc(bN, m(flat), m(inputs[0]), m(inputs[1]), m(outputs), m(qPrime))
+			common.Assert(valid == nil, "GKR proof was wrong - Bug in proof generation - %v", valid)
+		}
 	} else {
+		for i := range inputs {
+			gkrhip.FromRegular(inputs[i])
+		}
+		gkrhip.FromRegular(qPrime)
 		flat = gkrNative.FlatFromProof(gkrNative.Prove(h.g.Circuit, h.g.Circuit.Assign(inputs...), qPrime))
+		if debug {
+			gkrhip.FromRegular(outputs)
+			valid := gkrNative.Verify(h.g.Circuit, gkrNative.ProofFromFlat(h.g.Circuit, bN, flat), inputs, outputs, qPrime)
+			common.Assert(valid == nil, "GKR proof was wrong - Bug in proof generation - %v", valid)
+		}
+		gkrhip.ToRegular(flat)
 	}
 	t.Close()
 
-	if debug {
-		valid := gkrNative.Verify(h.g.Circuit, gkrNative.ProofFromFlat(h.g.Circuit, bN, flat), inputs, outputs, qPrime)
-		common.Assert(valid == nil, "GKR proof was wrong - Bug in proof generation - %v", valid)
-	}
-
-	// GkrProofToVec: the flat order IS the library's order; one bulk Montgomery -> regular pass on the device
-	// instead of len(flat) ToBigIntRegular calls
+	// GkrProofToVec: the flat order IS the library's order, and the elements are regular-form words already
 	if len(flat) != len(oups) {
 		panic("expected to have written the entire buffer")
 	}
-	gkrhip.ToRegular(flat)
 	for i := range flat {
 		oups[i].SetBits([]big.Word{big.Word(flat[i][0]), big.Word(flat[i][1]), big.Word(flat[i][2]), big.Word(flat[i][3])})
 	}

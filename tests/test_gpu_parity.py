@@ -952,6 +952,34 @@ def test_native_verifier_agrees_with_oracle(gk, bn):
     assert not gk.gkr_verify_mimc(flat, i0, bad_in, outs, qp)
 
 
+@pytest.mark.parametrize("bn", [0, 1, 5, 11])
+def test_gkr_prove_mimc_on_regular_form_buffers(gk, bn):
+    """gkrhip_gkr_prove_mimc_regular: the hint's body on big.Int words (prover/gadget/hints.go:197-233).  Inputs, qPrime,
+    the flat proof and the output table in REGULAR form equal the Montgomery-form call's, element for element, after
+    conversion; the oracle's transcript pins both."""
+    n = 1 << bn
+    rng = np.random.default_rng(77 + bn)
+
+    def rnd(k):
+        return [int.from_bytes(rng.bytes(32), "little") % o.Q for _ in range(k)]
+
+    def words(vals):
+        return np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in vals], dtype=np.uint64).reshape(-1, 4)
+
+    v0, v1, vq = rnd(n), rnd(n), rnd(bn)
+    flat_r, outs_r = gk.gkr_prove_mimc(words(v0), words(v1), words(vq), regular=True)
+    want, wouts, _ = c.gkr_prove_mimc(bn, c.from_ints(v0), c.from_ints(v1), c.from_ints(vq) if bn else c.from_ints([]))
+    assert np.array_equal(flat_r, words(c.to_ints(want)))
+    assert np.array_equal(outs_r, words(c.to_ints(wouts)))
+    flat_m, outs_m = gk.gkr_prove_mimc(c.from_ints(v0), c.from_ints(v1), c.from_ints(vq) if bn else c.from_ints([]))
+    assert np.array_equal(flat_m, want) and np.array_equal(outs_m, wouts)
+    # a value that is not below q is refused
+    bad = words(v0)
+    bad[0] = words([o.Q])[0]
+    with pytest.raises(gk.prover.GkrHipError):
+        gk.gkr_prove_mimc(bad, words(v1), words(vq), regular=True)
+
+
 def test_non_canonical_input_is_refused(gk):
     """gnark-crypto keeps fr.Element below q and the round kernels' lazy-reduction bounds rely on it: a table with
     an element >= q is refused at the boundary instead of yielding silently different sums."""

@@ -30,3 +30,9 @@ for rep in range(3):
           "download %d MiB)" % (bn, dt, n / dt / 1e6, 32 * n >> 20, 32 * n >> 20), flush=True)
 ok = gk.gkr_verify_mimc(flat, ins[0], ins[1], outs, qp)
 print("gkr.Verify on the last proof:", ok)
+# the same on regular-form buffers (gkrhip_gkr_prove_mimc_regular: the hint's big.Int words, conversions on the device)
+for rep in range(2):
+    t0 = time.perf_counter()
+    flat_r, outs_r = gk.gkr_prove_mimc(ins[0], ins[1], qp, regular=True)
+    dt = time.perf_counter() - t0
+    print("bN=%d  one-shot gkr_prove_mimc_regular (regular-form buffers): %.3f s  -> %.2f M hashes/s" % (bn, dt, n / dt / 1e6), flush=True)
