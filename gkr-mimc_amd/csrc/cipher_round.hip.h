@@ -288,7 +288,9 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(CipherRoundAr
 // MAC), which keeps the kernel inside the 256-VGPR budget of two waves per SIMD.  The LDS region is
 // reused by the block reduction afterwards.
 // ------------------------------------------------------------------------------------------------
+#ifndef GKR_WIDE_LDS
 #define GKR_WIDE_LDS 3
+#endif
 #ifdef GKR_NO_SQR
 #define GKR_SQR(x) fr_mont_mul_raw(x, x)
 #else
@@ -395,13 +397,23 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             D = fr_mont_mul_raw(r2, d);   GKR_SB();   // d^3
             // {W u^4, W d^4} x {u^3, u^2 d, u d^2, d^3}: the seven closing products are wide MACs; the LDS-resident
             // sums are fetched ahead of their MAC
-            wide_lds_load(T, sh, 0); fr_mac_wide(T, X0, B); GKR_SB(); wide_lds_store(sh, 0, T); GKR_SB();  // W u^6 d
-            wide_lds_load(T, sh, 1); fr_mac_wide(T, X0, C); GKR_SB(); wide_lds_store(sh, 1, T); GKR_SB();  // W u^5 d^2
-            wide_lds_load(T, sh, 2); fr_mac_wide(T, X0, D); GKR_SB(); wide_lds_store(sh, 2, T); GKR_SB();  // W u^4 d^3
-            fr_mac_wide(R[0], X1, A); GKR_SB();   // W u^3 d^4
-            fr_mac_wide(R[1], X1, B); GKR_SB();   // W u^2 d^5
-            fr_mac_wide(R[2], X1, C); GKR_SB();   // W u d^6
-            fr_mac_wide(R[3], X1, D); GKR_SB();   // W d^7
+            // sum M_j (j = 1..7) lives in LDS slot j-1 when j-1 < GKR_WIDE_LDS, else in R[j-1-GKR_WIDE_LDS]
+#define GKR_MAC(j, X, Y)                                                                                  \
+    do {                                                                                                  \
+        if ((j) - 1 < GKR_WIDE_LDS) {                                                                     \
+            wide_lds_load(T, sh, (j) - 1); fr_mac_wide(T, X, Y); GKR_SB(); wide_lds_store(sh, (j) - 1, T); GKR_SB(); \
+        } else {                                                                                          \
+            fr_mac_wide(R[(j) - 1 - GKR_WIDE_LDS < 0 ? 0 : (j) - 1 - GKR_WIDE_LDS], X, Y); GKR_SB();      \
+        }                                                                                                 \
+    } while (0)
+            GKR_MAC(1, X0, B);   // W u^6 d
+            GKR_MAC(2, X0, C);   // W u^5 d^2
+            GKR_MAC(3, X0, D);   // W u^4 d^3
+            GKR_MAC(4, X1, A);   // W u^3 d^4
+            GKR_MAC(5, X1, B);   // W u^2 d^5
+            GKR_MAC(6, X1, C);   // W u d^6
+            GKR_MAC(7, X1, D);   // W d^7
+#undef GKR_MAC
 #undef GKR_SB
         }
     }
