@@ -196,6 +196,18 @@ def main():
                     help="share of the free HBM the resident sessions may take (caps --concurrent)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started by hand without a launcher: start the ranks as children (one process per GPU, rendezvous on 127.0.0.1) and
+        # pass their exit code on -- nothing in this process has touched the GPU
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     # stdout carries the ONE JSON line and nothing else: whatever libraries print there (gloo's connection notes, RCCL's
     # version banner) goes to stderr
     sys.stdout.flush()
