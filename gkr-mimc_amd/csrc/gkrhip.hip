@@ -619,10 +619,16 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
         }
         qprime = (const uint64_t*)qp_m.data();
     }
+    const bool trace = getenv("GKRHIP_TRACE_ONESHOT") != nullptr;     // stage times on stderr
+    const double t_0 = now_ms();
     gkrhip_session* s = nullptr;
     CHK(gkrhip_mimc_session_create(&s, bN));
+    const double t_c = now_ms();
     int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
+    const double t_l = now_ms();
     if (rc == 0) rc = gkrhip_mimc_session_assign(s);
+    if (trace && rc == 0) (void)hipStreamSynchronize(s->lane->stream);
+    const double t_a = now_ms();
     // The output table is final once the assignment is: its download (transposition + 2^bN x 32 bytes over PCIe into
     // pageable memory) runs on a lane of its own from a second host thread while this thread proves.
     int rc_out = 0;
@@ -643,7 +649,9 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
             if (rc_out) err_out = g_err;
         });
     }
+    const double t_p0 = now_ms();
     if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
+    const double t_p = now_ms();
     if (dl.joinable()) {
         dl.join();
         lane_destroy(dl_lane);
@@ -660,7 +668,11 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
         E* f = (E*)flat;
         for (size_t i = 0; i < len; i++) f[i] = hfr::mul(f[i], one);
     }
+    const double t_j = now_ms();
     gkrhip_mimc_session_destroy(s);
+    if (trace)
+        fprintf(stderr, "oneshot bN=%d: create %.1f load %.1f assign %.1f spawn-download %.1f prove %.1f join+convert %.1f destroy %.1f ms\n", bN,
+                t_c - t_0, t_l - t_c, t_a - t_l, t_p0 - t_a, t_p - t_p0, t_j - t_p, now_ms() - t_j);
     return rc;
 }
 int gkrhip_gkr_prove_mimc(int bN, const uint64_t* in0, const uint64_t* in1, const uint64_t* qprime, uint64_t* flat,
