@@ -13,7 +13,9 @@
 
 #include "fr_bn254.h"
 
-#define GKR_BLOCK 256
+#ifndef GKR_BLOCK
+#define GKR_BLOCK 256   // threads per workgroup of every grid-shaped kernel (a build parameter for A/B runs: 128 or 256)
+#endif
 #define GKR_MAX_ARITY 4
 #define GKR_MAX_EVALS 9   // cipher gate: degree 8 -> 9 evaluation points (sumcheck/prover.go:95, algo.go:57)
 #define GKR_ACC_WORDS 9   // un-reduced 288-bit lane accumulators
@@ -272,7 +274,7 @@ __device__ __forceinline__ void block_reduce_acc_buf(const Acc9 (&acc)[NS], unsi
                                                      u32 (*tr)[GKR_BLOCK + 1] /* [CH] */,
                                                      unsigned long long (*red)[NS * GKR_ACC_WORDS] /* [GKR_BLOCK/64] */) {
     constexpr int NW = NS * GKR_ACC_WORDS;
-    static_assert(NW % CH == 0 && CH * 4 <= GKR_BLOCK, "chunking");
+    static_assert(NW % CH == 0 && CH * (GKR_BLOCK / 64) <= GKR_BLOCK && NW <= GKR_BLOCK, "chunking");
     const int tid = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < NW / CH; p++) {
@@ -284,7 +286,7 @@ __device__ __forceinline__ void block_reduce_acc_buf(const Acc9 (&acc)[NS], unsi
             tr[c][tid] = acc[wi / GKR_ACC_WORDS].w[wi % GKR_ACC_WORDS];
         }
         __syncthreads();
-        if (tid < CH * 4) {
+        if (tid < CH * (GKR_BLOCK / 64)) {
             const int c = tid % CH, q = tid / CH;
             unsigned long long s = 0;
 #pragma unroll 16
