@@ -380,7 +380,11 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             Fr W2 = W;
             if (WT_LATE) W2 = ld_fr(a.wj2.lo, a.wj2.hi, j);
             else W = fr_mont_mul_raw(W, wt);
+#ifdef GKR_NO_SB
+#define GKR_SB() do { } while (0)
+#else
 #define GKR_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
             Fr p, r2, A, B, C, D, U4, D4, X0, X1;
             u32 T[FR_WIDE_LIMBS];
             // ordered for short lifetimes: u^2 and its dependants first, then d^2 and its dependants
