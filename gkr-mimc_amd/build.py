@@ -1,9 +1,12 @@
 """Build libgkrhip.so for gfx950 with hipcc (in-tree, so the .so travels with the repo snapshot).
 
-The build also records what it was made from: build_info.json holds the SHA-256 of the sources (the loader refuses a
-library whose sources have changed since -- the .so is git-ignored, so a stale one could otherwise travel to the GPU
-box unnoticed) and the instruction counts of the round kernels' main loops taken from the ISA of this very build
-(bench.py prices the VALU-bound kernel against them; nothing is hard-coded there)."""
+The SHA-256 of the sources and flags is compiled INTO the library (-DGKRHIP_SOURCE_SHA, exported by gkrhip_build_id() and
+findable in the file as "GKRHIP_SOURCE_SHA=<hex>"): the loader and needs_build() compare the binary itself with the
+sources on disk, so a stale git-ignored .so next to freshly pulled sources (whose tracked build_info.json already
+describes the new sources) is rebuilt / refused instead of being called through a changed ABI.  build_info.json holds
+what else the build knows about itself: the instruction counts of the round kernels' main loops and the register / LDS /
+scratch figures of every kernel, taken from the ISA of this very build (bench.py prices the VALU-bound kernel against
+them; nothing is hard-coded there)."""
 import collections
 import hashlib
 import json
@@ -25,8 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xar
 # half-rate vector instructions on gfx950 (4.2-4.4 cycles per wave: profiles/r01_ubench_*.txt); the others issue in 2.4
 HALF = ("v_mad_u64", "v_addc", "v_subb", "v_add_co", "v_sub_co", "v_subrev_co", "v_mul_lo", "v_mul_hi", "v_lshl_add_u64",
         "v_lshrrev_b64", "v_lshlrev_b64", "v_alignbit", "v_fma_f64", "v_add_f64", "v_mul_f64")
-LOOP_KERNELS = {"round0": "k_cipher_round_wideILb0ELb1E", "fold_late": "k_cipher_round_wideILb1ELb1E",
-                "fold_early": "k_cipher_round_wideILb1ELb0E"}
+LOOP_KERNELS = {"round0": "k_cipher_round_wideILb0ELb1ELb0E", "fold_late": "k_cipher_round_wideILb1ELb1ELb0E",
+                "fold_early": "k_cipher_round_wideILb1ELb0ELb0E", "round0_pre": "k_cipher_round_wideILb0ELb1ELb1E"}
 
 
 def source_sha():
@@ -53,6 +56,8 @@ def loop_counts(asm_text):
         for n, l in enumerate(body):
             m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < n:
+                if any("s_endpgm" in x for x in body[labels[m.group(1)]:n]):
+                    continue                       # a jump back to an exit block (early return), not a loop
                 if best is None or n - labels[m.group(1)] > best[1] - best[0]:
                     best = (labels[m.group(1)], n)
         if best is None:
@@ -71,16 +76,43 @@ def loop_counts(asm_text):
     return out
 
 
+def kernel_resources(asm_text):
+    """VGPRs, scratch and LDS of every kernel of this build (from the .amdhsa_ directives of the ISA)."""
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm_text, re.S):
+        name, body = m.group(1), m.group(2)
+
+        def val(key):
+            mm = re.search(r"\.amdhsa_%s\s+(\d+)" % key, body)
+            return int(mm.group(1)) if mm else None
+        short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+        short = re.sub(r"\(.*", "", short).replace("void ", "")
+        out[short] = {"vgpr": val("next_free_vgpr"), "accum_offset": val("accum_offset"),
+                      "scratch_bytes": val("private_segment_fixed_size"), "lds_bytes": val("group_segment_fixed_size")}
+    return out
+
+
 def read_info():
+    """build_info.json, or None when it does not describe the library that is on disk."""
     try:
-        return json.load(open(INFO))
+        info = json.load(open(INFO))
     except Exception:
         return None
+    return info if info.get("source_sha256") == binary_sha() else None
+
+
+def binary_sha(path=None):
+    """The source hash compiled into the library file (None: no library, or one built before the hash was embedded)."""
+    try:
+        data = open(path or SO, "rb").read()
+    except OSError:
+        return None
+    m = re.search(rb"GKRHIP_SOURCE_SHA=([0-9a-f]{64})", data)
+    return m.group(1).decode() if m else None
 
 
 def needs_build():
-    info = read_info()
-    return not os.path.exists(SO) or info is None or info.get("source_sha256") != source_sha()
+    return binary_sha() != source_sha()
 
 
 def build(force=False, verbose=False):
@@ -91,16 +123,18 @@ def build(force=False, verbose=False):
     # gkrhip_init refuses a CPU without them
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "libgkrhip.so")
-        cmd = [hipcc] + FLAGS + ["-save-temps", "-o", out, SRC]
+        cmd = [hipcc] + FLAGS + ['-DGKRHIP_SOURCE_SHA="%s"' % source_sha(), "-save-temps", "-o", out, SRC]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=tmp, stdout=None if verbose else subprocess.DEVNULL)
         asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
-        counts = loop_counts(open(os.path.join(tmp, asm[0])).read()) if asm else {}
+        asm_text = open(os.path.join(tmp, asm[0])).read() if asm else ""
+        counts = loop_counts(asm_text)
+        resources = kernel_resources(asm_text)
         shutil.move(out, SO)
     ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.splitlines()
     info = {"source_sha256": source_sha(), "flags": FLAGS, "hipcc": ver[0] if ver else "",
-            "round_kernel_loops": counts,
+            "round_kernel_loops": counts, "kernel_resources": resources,
             "note": "round_kernel_loops: instructions of one index pair's loop body in the ISA of this build "
                     "(half_rate: v_mad_u64_u32, carries, v_mul_lo/hi, 64-bit shifts/adds; full_rate: the other vector instructions)"}
     json.dump(info, open(INFO, "w"), indent=1, sort_keys=True)

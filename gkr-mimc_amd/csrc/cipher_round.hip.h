@@ -93,7 +93,59 @@ struct CipherRoundArgs {
     unsigned int need_m0;           // 0: M_0 is derived by the host from the running claim (2 products fewer)
     unsigned long long* tail_tables;   // host-mapped, or nullptr: this round's tables (2P entries of K, then 2P of S, 4 u64
                                        // each) for the host, which runs the remaining (tiny) rounds itself
+    // pre-launched round (FOLD only): the kernel is queued BEFORE the host has hashed the previous round; r and r_lo
+    // are then not launch arguments but arrive through a host-mapped slot the first lanes poll (see wait_challenge)
+    const unsigned long long* chal;    // host-mapped challenge slot (GKR_CHAL_WORDS words), or nullptr: r, r_lo above are valid
+    unsigned long long* chal_dev;      // device-memory mailbox of the same shape: workgroup 0 forwards the slot to the others
+    unsigned int chal_seq;             // the slot is valid for this launch when the high halves of its words equal chal_seq
+    // PRE (k_cipher_round_wide<false, ., true>): the q-independent products of round 0, computed ahead by k_cipher_pre
+    CPlanes pre[6];                    // u^4, d^4, u^3, u^2 d, u d^2, d^3 at every pair
 };
+
+// ------------------------------------------------------------------------------------------------
+// Challenge hand-over to a pre-launched round kernel.  The host writes 16 words (limbs 0..7: r, 8..15: r * 2^-128), each
+// as (seq << 32) | limb -- an aligned 8-byte word is read atomically over PCIe, so every polling lane sees a
+// consistent (seq, limb) pair whatever order the host's stores arrive in.  seq = 0xFFFFFFFF: the host gave up
+// (error path); a lane also gives up after ~8 s without an answer.  Returns false when the launch must be abandoned
+// (uniformly over the workgroup).  The sixteen limbs come back wave-uniform (SGPRs), like launch arguments.
+// ------------------------------------------------------------------------------------------------
+#define GKR_CHAL_WORDS 16
+#define GKR_CHAL_ABORT 0xFFFFFFFFu
+// Only workgroup 0 polls host memory (sixteen 8-byte reads per poll over PCIe); it forwards the tagged words to a
+// device-memory mailbox the other workgroups poll (L2 atomics).  Hundreds of workgroups polling the host directly
+// saturate the PCIe read path and delay the very hand-off the host is waiting for (measured: +12 ms per proof).
+__device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, unsigned long long* mailbox, unsigned int seq, Fr& r,
+                                               Fr& r_lo) {
+    __shared__ u32 s_ch[GKR_CHAL_WORDS];
+    int bad = 0;
+    if (threadIdx.x < GKR_CHAL_WORDS) {
+        const unsigned long long t0 = wall_clock64();          // 100 MHz
+        const bool first = blockIdx.x == 0;
+        unsigned long long v;
+        for (;;) {
+            v = first ? __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                      : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 s = (u32)(v >> 32);
+            if (s == seq) break;
+            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 800000000ull) {
+                bad = 1;
+                v = (unsigned long long)GKR_CHAL_ABORT << 32;
+                break;
+            }
+            if (first) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(8);
+        }
+        if (first) __hip_atomic_store(mailbox + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ch[threadIdx.x] = (u32)v;
+    }
+    if (__syncthreads_or(bad)) return false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        r.v[j] = __builtin_amdgcn_readfirstlane(s_ch[j]);
+        r_lo.v[j] = __builtin_amdgcn_readfirstlane(s_ch[8 + j]);
+    }
+    return true;
+}
 
 // a += x as an un-reduced 288-bit integer (x < 2^256).  One opaque carry chain: keeps hipcc from
 // widening the nine accumulator words to 64-bit pairs and from sinking all eight accumulations to
@@ -134,6 +186,7 @@ __global__ void __launch_bounds__(128) k_publish_words(const unsigned long long*
 template <bool FOLD, bool HAS_WJ, bool LAT>
 __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     __shared__ unsigned int s_last;
+    if (LAT) __builtin_amdgcn_s_setprio(3);      // a latency-bound round goes first when it shares a SIMD with the look-ahead kernel
     Acc9 acc[GKR_CR_NSUM];
 #pragma unroll
     for (int t = 0; t < GKR_CR_NSUM; t++)
@@ -143,6 +196,8 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     const size_t P = a.P;
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr ch_r = a.r, ch_rlo = a.r_lo;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr ark = a.ark;
@@ -152,7 +207,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
             Fr klo, khi, slo, shi;
             if (FOLD) {
                 // previous round's tables have 4P entries and pair (y, y+2P); this round pairs (x, x+P)
-                const Fr r = a.r;
+                const Fr r = ch_r;
                 const Fr k0 = ld_fr(a.k_src.lo, a.k_src.hi, x), k2 = ld_fr(a.k_src.lo, a.k_src.hi, x + 2 * P);
                 const Fr k1 = ld_fr(a.k_src.lo, a.k_src.hi, x + P), k3 = ld_fr(a.k_src.lo, a.k_src.hi, x + 3 * P);
                 const Fr s0 = ld_fr(a.s_src.lo, a.s_src.hi, x), s2 = ld_fr(a.s_src.lo, a.s_src.hi, x + 2 * P);
@@ -167,7 +222,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
                     shi = fr_add(s1, fr_reduce_once(f3));
                 } else {
                 // poly/multilin.go:32-34; the challenge is a launch-wide constant: 96-product multiplication, < 3q
-                const Fr ra = a.r_lo;
+                const Fr ra = ch_rlo;
                 klo = fr_reduce_lt4q(fr_add_raw(k0, fr_mul_const2_raw(fr_sub(k2, k0), ra, r)));
                 khi = fr_reduce_lt4q(fr_add_raw(k1, fr_mul_const2_raw(fr_sub(k3, k1), ra, r)));
                 slo = fr_reduce_lt4q(fr_add_raw(s0, fr_mul_const2_raw(fr_sub(s2, s0), ra, r)));
@@ -323,8 +378,12 @@ __device__ __forceinline__ void wide_lds_store(WideShared& sh, int slot, const u
 
 // WT_LATE (rounds with many pairs per lane): the per-lane weight Wt is the same for every pair of a lane, so
 // it multiplies the lane's seven reduced sums once after the loop instead of every pair's weight inside it.
-template <bool FOLD, bool WT_LATE>
+// PRE (round 0 only, FOLD = false): u^4, d^4 and the four cubics were computed ahead of time by k_cipher_pre -- they do
+// not depend on the layer's evaluation point -- so the launch on the critical path is two products by the launch-wide
+// weight and the seven wide MACs, reading 192 bytes per pair instead of computing eight products.
+template <bool FOLD, bool WT_LATE, bool PRE = false>
 __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
+    static_assert(!(FOLD && PRE), "the precomputed products exist for round 0 only");
     __shared__ WideShared sh;
     __shared__ unsigned int s_last;
     u32 R[GKR_CR_NSUM - 1 - GKR_WIDE_LDS][FR_WIDE_LIMBS];     // M_4 .. M_7
@@ -343,6 +402,8 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     const size_t P = a.P;
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr ch_r = a.r, ch_rlo = a.r_lo;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr negark = fr_sub(fr_zero(), a.ark);      // q - ark (0 for ark = 0), canonical
@@ -350,14 +411,22 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
         for (size_t j = 0; j < iters; j++) {
             const size_t x = j * threads + gtid;
             Fr klo, khi, slo, shi;
-            if (FOLD) {
-                const Fr r = a.r;
+            Fr p, r2, A, B, C, D, U4, D4, X0, X1;
+            if (PRE) {
+                U4 = ld_fr_nt(a.pre[0].lo, a.pre[0].hi, x);
+                D4 = ld_fr_nt(a.pre[1].lo, a.pre[1].hi, x);
+                A = ld_fr_nt(a.pre[2].lo, a.pre[2].hi, x);
+                B = ld_fr_nt(a.pre[3].lo, a.pre[3].hi, x);
+                C = ld_fr_nt(a.pre[4].lo, a.pre[4].hi, x);
+                D = ld_fr_nt(a.pre[5].lo, a.pre[5].hi, x);
+            } else if (FOLD) {
+                const Fr r = ch_r;
                 const Fr k0 = ld_fr(a.k_src.lo, a.k_src.hi, x), k2 = ld_fr(a.k_src.lo, a.k_src.hi, x + 2 * P);
                 const Fr k1 = ld_fr(a.k_src.lo, a.k_src.hi, x + P), k3 = ld_fr(a.k_src.lo, a.k_src.hi, x + 3 * P);
                 const Fr s0 = ld_fr(a.s_src.lo, a.s_src.hi, x), s2 = ld_fr(a.s_src.lo, a.s_src.hi, x + 2 * P);
                 const Fr s1 = ld_fr(a.s_src.lo, a.s_src.hi, x + P), s3 = ld_fr(a.s_src.lo, a.s_src.hi, x + 3 * P);
                 // poly/multilin.go:32-34; the challenge is a launch-wide constant: 96-product multiplication, < 3q
-                const Fr ra = a.r_lo;
+                const Fr ra = ch_rlo;
                 klo = fr_reduce_lt4q(fr_add_raw(k0, fr_mul_const2_raw(fr_sub(k2, k0), ra, r)));
                 khi = fr_reduce_lt4q(fr_add_raw(k1, fr_mul_const2_raw(fr_sub(k3, k1), ra, r)));
                 slo = fr_reduce_lt4q(fr_add_raw(s0, fr_mul_const2_raw(fr_sub(s2, s0), ra, r)));
@@ -374,8 +443,11 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             }
             // lazy sums u, d < 2q: slo + ark is taken mod q (as slo - (q - ark)) so that the squarings' operands stay
             // below 2q (fr_mont_sqr_raw doubles them in place); products of operands < 2q stay below 2q
-            const Fr u = fr_add_raw(klo, fr_sub(slo, negark));
-            const Fr d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));
+            Fr u, d;
+            if (!PRE) {
+                u = fr_add_raw(klo, fr_sub(slo, negark));
+                d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));
+            }
             Fr W = ld_fr(a.wj.lo, a.wj.hi, j);            // the same element for every lane of the launch
             Fr W2 = W;
             if (WT_LATE) W2 = ld_fr(a.wj2.lo, a.wj2.hi, j);
@@ -385,8 +457,11 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
 #else
 #define GKR_SB() __builtin_amdgcn_sched_barrier(0)
 #endif
-            Fr p, r2, A, B, C, D, U4, D4, X0, X1;
             u32 T[FR_WIDE_LIMBS];
+            if (PRE) {
+                X0 = WT_LATE ? fr_mul_const2_raw(U4, W2, W) : fr_mont_mul_raw(W, U4);  GKR_SB();
+                X1 = WT_LATE ? fr_mul_const2_raw(D4, W2, W) : fr_mont_mul_raw(W, D4);  GKR_SB();
+            } else {
             // ordered for short lifetimes: u^2 and its dependants first, then d^2 and its dependants
             p = GKR_SQR(u);       GKR_SB();
             U4 = GKR_SQR(p);      GKR_SB();   // u^4
@@ -399,6 +474,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
             X1 = WT_LATE ? fr_mul_const2_raw(D4, W2, W) : fr_mont_mul_raw(W, D4);  GKR_SB();
             C = fr_mont_mul_raw(u, r2);   GKR_SB();   // u d^2
             D = fr_mont_mul_raw(r2, d);   GKR_SB();   // d^3
+            }
             // {W u^4, W d^4} x {u^3, u^2 d, u d^2, d^3}: the seven closing products are wide MACs; the LDS-resident
             // sums are fetched ahead of their MAC
             // sum M_j (j = 1..7) lives in LDS slot j-1 when j-1 < GKR_WIDE_LDS, else in R[j-1-GKR_WIDE_LDS]
@@ -458,4 +534,43 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     __syncthreads();                                                // tr aliases the LDS accumulators
     block_reduce_acc_buf<GKR_CR_NSUM, 18, true>(acc, a.partials, sh.tr, sh.red);
     cipher_round_publish(a, &s_last);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cipher_pre: the part of a cipher layer's round 0 that does not depend on the layer's evaluation point.  u = K_lo + S_lo
+// + ark and d = (K_hi - K_lo) + (S_hi - S_lo) are functions of the witness tables alone, and so are u^4, d^4 and the four
+// cubics -- eight of the ten products in front of the closing MACs.  gkr.Prove knows the NEXT layer's tables while the
+// current layer's latency-bound small rounds leave the GPU idle; this kernel fills that idle time (second stream) and the
+// next layer's round 0 on the critical path becomes k_cipher_round_wide<false, ., true>.  Same integers as the fused
+// kernel computes (same schedules, same lazy bounds), so the sums -- and the transcript -- are identical.
+// One pair per lane, many short workgroups: the latency-bound round kernels of the proof find free slots at any time.
+// ------------------------------------------------------------------------------------------------
+struct CipherPreArgs {
+    CPlanes k_src, s_src;   // 2P entries each
+    Planes out[6];          // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each)
+    size_t P;
+    Fr ark;
+};
+// The launch asks for GKR_PRE_LDS bytes of (unused) dynamic LDS so that at most two of its workgroups share a CU: two
+// waves per SIMD are enough for its VALU-bound chains, and the round kernels of the proof (up to 243 VGPRs, 21 KB of LDS)
+// always find room beside it.  Without the cap its small waves refill every slot a finished wave frees and the
+// 243-VGPR round kernel starves until the look-ahead is done (measured: the whole gain lost).
+#define GKR_PRE_LDS (60 * 1024)
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_pre(CipherPreArgs a) {
+    const size_t P = a.P;
+    const Fr negark = fr_sub(fr_zero(), a.ark);
+    for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < P; x += (size_t)gridDim.x * blockDim.x) {
+        const Fr klo = ld_fr(a.k_src.lo, a.k_src.hi, x), khi = ld_fr(a.k_src.lo, a.k_src.hi, x + P);
+        const Fr slo = ld_fr(a.s_src.lo, a.s_src.hi, x), shi = ld_fr(a.s_src.lo, a.s_src.hi, x + P);
+        const Fr u = fr_add_raw(klo, fr_sub(slo, negark));
+        const Fr d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));
+        const Fr p = GKR_SQR(u);
+        st_fr_nt(a.out[0].lo, a.out[0].hi, x, GKR_SQR(p));              // u^4
+        st_fr_nt(a.out[2].lo, a.out[2].hi, x, fr_mont_mul_raw(p, u));   // u^3
+        st_fr_nt(a.out[3].lo, a.out[3].hi, x, fr_mont_mul_raw(p, d));   // u^2 d
+        const Fr r2 = GKR_SQR(d);
+        st_fr_nt(a.out[1].lo, a.out[1].hi, x, GKR_SQR(r2));             // d^4
+        st_fr_nt(a.out[4].lo, a.out[4].hi, x, fr_mont_mul_raw(u, r2));  // u d^2
+        st_fr_nt(a.out[5].lo, a.out[5].hi, x, fr_mont_mul_raw(r2, d));  // d^3
+    }
 }

@@ -30,6 +30,7 @@
 #include "kernels.hip.h"
 #include "cipher_round.hip.h"
 #include "linear_round.hip.h"
+#include "cipher_coop.hip.h"
 
 using hfr::E;
 
@@ -105,6 +106,9 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         qps[l].assign(slots * std::max(bN, 1), hfr::ZERO);
     }
     for (int k = 0; k < bN; k++) qps[L - 1][k] = qprime[k];
+    struct PreScope {            // the look-ahead tables are valid for this call only (the session's inputs may change)
+        ~PreScope() { pre_release(); }
+    } pre_scope;
 
     for (int layer = L - 1; layer >= 0; layer--) {
         const Layer& lay = c[layer];
@@ -112,6 +116,18 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         const int arity = (int)lay.in.size();
         const DevTable* X[GKR_MAX_ARITY];
         for (int k = 0; k < arity; k++) X[k] = session_table(s, lay.in[k]);
+        // Look-ahead: the layer proven next.  If it is a single-point cipher layer, the products of its round 0 that
+        // do not depend on its evaluation point are computed while this layer's small rounds leave the GPU idle.
+        cx().req_K = cx().req_S = nullptr;
+        if (layer >= 1 && c[layer - 1].gate >= 0 && c[layer - 1].out.size() == 1 && c[layer - 1].in.size() == 2) {
+            GateDesc gn;
+            if (gate_get(c[layer - 1].gate, &gn) && gate_is_cipher2(gn)) {
+                cx().req_K = session_table(s, c[layer - 1].in[0]);
+                cx().req_S = session_table(s, c[layer - 1].in[1]);
+                cx().req_ark = c[layer - 1].ark;
+                cx().req_m = bN - shard_view().gamma;
+            }
+        }
         const int nev = gate_degree(lay.gate) + 2;
         sc[layer].assign((size_t)std::max(bN, 1) * nev, hfr::ZERO);
         std::vector<E> next_q(std::max(bN, 1));
@@ -249,10 +265,19 @@ int gkrhip_device_count(void) {
 }
 
 const char* gkrhip_last_error(void) { return g_err.c_str(); }
-const char* gkrhip_version(void) { return "gkrhip 0.1 (gfx950)"; }
+const char* gkrhip_version(void) { return "gkrhip 0.3 (gfx950)"; }
+#ifndef GKRHIP_SOURCE_SHA
+#define GKRHIP_SOURCE_SHA "unrecorded"
+#endif
+// the SHA-256 of the sources and flags this binary was built from (gkr-mimc_amd/build.py finds the marker in the file)
+const char* gkrhip_build_id(void) {
+    static const char id[] = "GKRHIP_SOURCE_SHA=" GKRHIP_SOURCE_SHA;
+    return id + sizeof("GKRHIP_SOURCE_SHA=") - 1;
+}
 
 int gkrhip_set_option(const char* key, long value) {
-    static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail"};
+    static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
+                                 "prelaunch", "prelaunch_lg", "lookahead", "coop"};
     bool known = false;
     for (const char* k : keys) known = known || !strcmp(key, k);
     if (!known) return fail("unknown option %s", key);
@@ -265,6 +290,10 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "wt_late_lj")) l->wt_late_lj = (int)value;
         else if (!strcmp(key, "claim_trick")) l->claim_trick = value != 0;
         else if (!strcmp(key, "host_tail")) l->host_tail = (int)std::max(0L, std::min(6L, value));
+        else if (!strcmp(key, "prelaunch")) l->prelaunch = (int)value;
+        else if (!strcmp(key, "prelaunch_lg")) l->prelaunch_lg = (int)std::max(0L, std::min(30L, value));
+        else if (!strcmp(key, "lookahead")) l->pre_mode = (int)value;
+        else if (!strcmp(key, "coop")) l->coop = (int)value;
         return 0;
     });
 }
@@ -974,6 +1003,9 @@ int gkrhip_bench_sumcheck(int kind, int bn, int ninstance, int warmup, int iters
 }
 
 int gkrhip_profile_reset(size_t min_n) {
+    g_cnt_prelaunched = 0;
+    g_cnt_lookahead = 0;
+    g_cnt_coop = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
         prof_clear(l->prof);
@@ -1264,6 +1296,13 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t* M, const u
     for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, sp[j]), hfr::mul(a1, sp[j - 1]));
     co[8] = hfr::mul(a1, sp[7]);
     memcpy(out, co, sizeof co);
+    return 0;
+}
+
+int gkrhip_profile_latency(uint64_t* prelaunched_rounds, uint64_t* lookahead_round0, uint64_t* coop_rounds) {
+    if (prelaunched_rounds) *prelaunched_rounds = g_cnt_prelaunched.load();
+    if (lookahead_round0) *lookahead_round0 = g_cnt_lookahead.load();
+    if (coop_rounds) *coop_rounds = g_cnt_coop.load();
     return 0;
 }
 

@@ -15,6 +15,10 @@ static inline double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+// process-wide counts of the serial-latency paths (gkrhip_profile_latency): rounds whose kernel was queued ahead of its
+// challenge, round-0 launches on look-ahead products, rounds of the cooperative kernel.  Not per lane: the lanes of
+// one-shot calls go back to the pool (and are cleared) before anybody can ask.
+std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
     uint64_t rounds = 0;
@@ -106,6 +110,30 @@ struct Ctx {
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     int host_tail = 5;                         // GKRHIP_HOST_TAIL: the rounds with at most 2^h pairs run on the host (0: never); measured: -5 % single-proof latency, +1.5 % throughput
+    // ---- serial-latency measures of a proof that is alone on the GPU (round 3) -----------------------------------
+    // pre-launched rounds: round k+1's kernel is queued before the host hashes round k and polls the challenge slot
+    int prelaunch = 1;                         // GKRHIP_PRELAUNCH: 0 never, 1 when the proof is alone on the GPU, 2 always
+    int prelaunch_lg = 16;                     // ... for rounds of at most 2^prelaunch_lg pairs
+    unsigned long long* h_chal = nullptr;      // host-mapped challenge slot (GKR_CHAL_WORDS words)
+    unsigned long long* d_chal = nullptr;
+    unsigned long long* d_chal_dev = nullptr;  // device-memory mailbox: workgroup 0 of a pre-launched kernel forwards the slot to the others
+    // round 0 split: the q-independent products of the NEXT layer's round 0 are computed on `aux` while this layer's
+    // small rounds leave the GPU idle (k_cipher_pre); the next layer's round 0 then only applies the weights
+    int pre_mode = 1;                          // GKRHIP_PRE: 0 never, 1 when the proof is alone on the GPU, 2 always
+    int coop = 1;                              // GKRHIP_COOP: cooperative small-round kernel (eight lanes per pair): 0 never, 1 alone on the GPU, 2 always
+    int coop_lg = 13;                          // ... for rounds of at most 2^coop_lg pairs
+    int coop_wgs = 256;                        // ... on at most this many workgroups
+    hipStream_t aux = nullptr;                 // low-priority stream of the look-ahead kernel
+    hipEvent_t pre_done = nullptr;
+    DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()
+    const uint4* pre_K = nullptr;              // what pre_t was computed from (valid when pre_K != nullptr)
+    const uint4* pre_S = nullptr;
+    E pre_ark;
+    int pre_m = 0;
+    const DevTable* req_K = nullptr;           // look-ahead request of gkr.Prove for the layer it will prove next
+    const DevTable* req_S = nullptr;
+    E req_ark;
+    int req_m = 0;
     hfr::Lagrange* lag = nullptr;
     Profile prof;
     LaneColl lc;
@@ -213,6 +241,7 @@ const int kHostTailMax = 6;       // the host can take over from 2^6 pairs on (G
 const size_t kTailWords = (size_t)GKR_MAX_ARITY * 4 * 2 * (2 << kHostTailMax);   // up to four tables of 2P entries, P <= 2^(kHostTailMax+1), 4 u64 each
 const int kRaccWords = 128;       // shared accumulator / host hand-off buffer: 72 (fused rounds) or up to 81 (nine evaluations) + 16 tail words
 int lane_alloc();
+void table_release_fwd(DevTable* t);
 
 int ctx_init(int dev) {
     if (cx().ready) {
@@ -242,6 +271,12 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
+    if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
+    if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
+    if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));
     cx().lag = new hfr::Lagrange();
     cx().device = dev;
     CHK(lane_alloc());
@@ -277,10 +312,37 @@ int lane_alloc() {
     HIPCHK(hipHostMalloc(&cx().h_bad, 64, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_bad, cx().h_bad, 0));
     *cx().h_bad = 0;
+    HIPCHK(hipHostMalloc(&cx().h_chal, sizeof(unsigned long long) * GKR_CHAL_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_chal, cx().h_chal, 0));
+    memset(cx().h_chal, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS);
+    HIPCHK(hipMalloc(&cx().d_chal_dev, sizeof(unsigned long long) * GKR_CHAL_WORDS));
+    HIPCHK(hipMemset(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS));
+    {
+        int least = 0, greatest = 0;               // the look-ahead kernel must never delay a round kernel
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&cx().aux, hipStreamNonBlocking, least));
+        HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
+    }
     return 0;
+}
+// the look-ahead tables go back to the arena (end of a proof, lane teardown)
+void pre_release() {
+    if (cx().aux) (void)hipStreamSynchronize(cx().aux);
+    for (auto& t : cx().pre_t) table_release_fwd(&t);
+    cx().pre_K = cx().pre_S = nullptr;
+    cx().req_K = cx().req_S = nullptr;
 }
 void lane_free() {
     (void)hipStreamSynchronize(cx().stream);
+    pre_release();
+    if (cx().aux) (void)hipStreamDestroy(cx().aux);
+    if (cx().pre_done) (void)hipEventDestroy(cx().pre_done);
+    cx().aux = nullptr;
+    cx().pre_done = nullptr;
+    if (cx().h_chal) (void)hipHostFree(cx().h_chal);
+    cx().h_chal = cx().d_chal = nullptr;
+    if (cx().d_chal_dev) (void)hipFree(cx().d_chal_dev);
+    cx().d_chal_dev = nullptr;
     (void)hipFree(cx().d_partials);
     (void)hipFree(cx().d_racc);
     (void)hipFree(cx().d_sums);
@@ -333,6 +395,12 @@ void lane_configure(Ctx* l) {
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->host_tail = g0.host_tail;
+    l->prelaunch = g0.prelaunch;
+    l->prelaunch_lg = g0.prelaunch_lg;
+    l->pre_mode = g0.pre_mode;
+    l->coop = g0.coop;
+    l->coop_lg = g0.coop_lg;
+    l->coop_wgs = g0.coop_wgs;
     l->lag = g0.lag;
     l->prof.min_n = g0.prof.min_n;
 }
@@ -447,6 +515,7 @@ void table_release(DevTable* t) {
     t->base = nullptr;
     t->cap = 0;
 }
+void table_release_fwd(DevTable* t) { table_release(t); }
 void table_free(DevTable* t) {
     if (t->base) (void)hipFree(t->base);
     t->base = nullptr;

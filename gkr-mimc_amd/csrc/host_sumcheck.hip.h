@@ -113,6 +113,61 @@ void host_cipher_rounds(const E& ark, int mm, std::vector<E>& K, std::vector<E>&
     }
 }
 
+
+// ---- host side of the challenge hand-over to a pre-launched round kernel (wait_challenge, cipher_round.hip.h) -----
+inline void chal_publish(unsigned int seq, const E& r, const E& r_lo) {
+    volatile unsigned long long* w = cx().h_chal;
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    for (int i = 0; i < 4; i++) {
+        w[2 * i] = tag | (unsigned long long)(uint32_t)r.l[i];
+        w[2 * i + 1] = tag | (unsigned long long)(uint32_t)(r.l[i] >> 32);
+        w[8 + 2 * i] = tag | (unsigned long long)(uint32_t)r_lo.l[i];
+        w[8 + 2 * i + 1] = tag | (unsigned long long)(uint32_t)(r_lo.l[i] >> 32);
+    }
+    __sync_synchronize();
+}
+// A pre-launched kernel that will never get its challenge (error return between the launch and the hash) is told
+// to leave; the lane's stream is drained so that nothing of the failed call is still running when the caller returns.
+struct ChalGuard {
+    bool armed = false;
+    ~ChalGuard() {
+        if (!armed) return;
+        volatile unsigned long long* w = cx().h_chal;
+        for (int i = 0; i < GKR_CHAL_WORDS; i++) w[i] = (unsigned long long)GKR_CHAL_ABORT << 32;
+        __sync_synchronize();
+        (void)hipStreamSynchronize(cx().stream);
+    }
+};
+
+// Queue k_cipher_pre for the layer gkr.Prove announced (cx().req_*) on the lane's look-ahead stream.
+int launch_pre() {
+    const DevTable* K = cx().req_K;
+    const DevTable* S = cx().req_S;
+    cx().req_K = cx().req_S = nullptr;
+    if (!K || !S || cx().req_m < 2) return 0;
+    const size_t P = (size_t)1 << (cx().req_m - 1);
+    for (auto& t : cx().pre_t)
+        if (t.cap != P) {
+            if (t.base) table_release(&t);
+            CHK(table_alloc(&t, P));
+        }
+    CipherPreArgs a;
+    memset(&a, 0, sizeof a);
+    a.k_src = K->cplanes();
+    a.s_src = S->cplanes();
+    for (int i = 0; i < 6; i++) a.out[i] = cx().pre_t[i].planes();
+    a.P = P;
+    a.ark = to_dev(cx().req_ark);
+    hipLaunchKernelGGL(k_cipher_pre, dim3(grid_for(P, 1 << 20)), dim3(GKR_BLOCK), GKR_PRE_LDS, cx().aux, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(cx().pre_done, cx().aux));
+    cx().pre_K = K->base;
+    cx().pre_S = S->base;
+    cx().pre_ark = cx().req_ark;
+    cx().pre_m = cx().req_m;
+    return 0;
+}
+
 // The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
 // q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
 // monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
@@ -183,7 +238,20 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     const int h_tail = (!collective && cx().host_tail > 0 && m >= cx().host_tail + 2) ? std::min(cx().host_tail, kHostTailMax) : 0;
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // round whose tables go to the host
     const int m_dev = h_tail ? k_export + 1 : m;             // rounds on the device
-    for (int k = 0; k < m_dev; k++) {
+    const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    // pre-launched rounds (the next round's kernel is queued before this round is hashed and polls the challenge slot):
+    // not over RCCL, whose all-reduce and publish kernel are queued between the rounds
+    const bool pl_on = !round_targets(collective).on_device && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));
+    const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
+    const bool coop_on = cx().coop >= 2 || (cx().coop == 1 && alone);
+    ChalGuard chal_guard;
+    struct InFlight {
+        RoundTargets tg;
+        unsigned int seq;
+        bool derive_m0;
+    };
+    // queue round k's kernel; `deferred`: r_prev is not known yet, the kernel takes it from the challenge slot
+    auto launch_round = [&](int k, bool deferred, const E& r_in, bool derive_m0, InFlight* out) -> int {
         const size_t P = n >> (k + 1);
         const int gk = threads_log2(k);
         const int lj = m - 1 - k - gk;                 // log2(iterations)
@@ -205,35 +273,58 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         a.P = P;
         a.lg_threads = (unsigned)gk;
-        a.r = to_dev(r_prev);
-        {
-            const E two128 = {{0, 0, 1, 0}};                 // the plain integer 2^128: mul divides by 2^256
-            a.r_lo = to_dev(hfr::mul(r_prev, two128));       // r * 2^-128 (fr_mul_const2_raw's second image)
-        }
         a.ark = to_dev(ark);
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;
         a.tail_tables = k == k_export ? cx().d_tail : nullptr;
-        const RoundTargets tg = round_targets(collective);
-        a.host_out = tg.out;
-        a.host_flag = tg.flag;
-        a.seq = ++cx().seq;
-        const bool derive_m0 = claim && *claim_known;
+        out->tg = round_targets(collective);
+        a.host_out = out->tg.out;
+        a.host_flag = out->tg.flag;
+        a.seq = out->seq = ++cx().seq;
+        out->derive_m0 = derive_m0;
         a.need_m0 = derive_m0 ? 0u : 1u;
+        if (deferred) {
+            a.chal = cx().d_chal;
+            a.chal_dev = cx().d_chal_dev;
+            a.chal_seq = a.seq;
+            chal_guard.armed = true;
+        } else {
+            const E two128 = {{0, 0, 1, 0}};                 // the plain integer 2^128: mul divides by 2^256
+            a.r = to_dev(r_in);
+            a.r_lo = to_dev(hfr::mul(r_in, two128));         // r * 2^-128 (fr_mul_const2_raw's second image)
+        }
         const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
-        const bool timed = 2 * P >= cx().prof.min_n;
+        const bool timed = 2 * P >= cx().prof.min_n && !deferred;
         hipEvent_t e0 = nullptr, e1 = nullptr;
+        // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
+        const bool lat = cx().lat_mode == 2 || (cx().lat_mode == 1 && lj == 0);
+        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat && k != k_export;   // only the plain kernels export
+        const bool late = wide && lj >= cx().wt_late_lj;  // the lane weight multiplies the sums after the loop: 8 products per lane
+        // small rounds of a proof that is alone on the GPU: eight lanes per pair (cipher_coop.hip.h)
+        const bool coop = coop_on && lj == 0 && P <= ((size_t)1 << cx().coop_lg);
+        // round 0 with the q-independent products computed ahead (k_cipher_pre, launched during the previous layer)
+        const bool pre = wide && !fold && cx().pre_K && cx().pre_K == K->base && cx().pre_S == S->base && cx().pre_m == m &&
+                         cx().pre_ark == ark;
+        if (pre) {
+            HIPCHK(hipStreamWaitEvent(cx().stream, cx().pre_done, 0));
+            for (int i = 0; i < 6; i++) a.pre[i] = cx().pre_t[i].cplanes();
+            cx().pre_K = cx().pre_S = nullptr;             // consumed
+        }
         if (timed) {
             e0 = prof_event();
             e1 = prof_event();
             HIPCHK(hipEventRecord(e0, cx().stream));
         }
-        const double t_l0 = now_ms();
-        // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
-        const bool lat = cx().lat_mode == 2 || (cx().lat_mode == 1 && lj == 0);
-        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat && k != k_export;   // only the plain kernels export
-        const bool late = wide && lj >= cx().wt_late_lj;  // the lane weight multiplies the sums after the loop: 8 products per lane
-        if (wide) {
+        if (coop) {
+            const int cgrid = (int)std::min<size_t>((P + GKR_COOP_PAIRS - 1) / GKR_COOP_PAIRS, (size_t)cx().coop_wgs);
+            if (fold) hipLaunchKernelGGL((k_cipher_round_coop<true>), dim3(cgrid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else hipLaunchKernelGGL((k_cipher_round_coop<false>), dim3(cgrid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            g_cnt_coop.fetch_add(1, std::memory_order_relaxed);
+        } else if (pre) {
+            if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else hipLaunchKernelGGL((k_cipher_round_wide<false, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            g_cnt_lookahead.fetch_add(1, std::memory_order_relaxed);
+        } else if (wide) {
             if (fold) {
                 if (late) hipLaunchKernelGGL((k_cipher_round_wide<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
                 else hipLaunchKernelGGL((k_cipher_round_wide<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
@@ -255,12 +346,37 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             cx().prof.peval_launches++;
             cx().prof.peval_modmuls += ((derive_m0 ? 17.0 : 18.0) + (lj > 0 && !late ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
+        return 0;
+    };
+    InFlight cur, nxt;
+    {
+        const double t_l0 = now_ms();
+        CHK(launch_round(0, false, hfr::ZERO, claim && *claim_known, &cur));
+        cx().prof.host_launch_ms += now_ms() - t_l0;
+    }
+    bool pre_requested = cx().req_K != nullptr && pre_on;
+    for (int k = 0; k < m_dev; k++) {
+        const size_t P = n >> (k + 1);
+        const double t_l0 = now_ms();
+        // round k+1 queued now, behind round k's kernel: its dispatch overlaps the hash below
+        const bool have_next = k + 1 < m_dev;
+        const bool prelaunched = have_next && pl_on && (P >> 1) <= ((size_t)1 << cx().prelaunch_lg);
+        if (prelaunched) {
+            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
+            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+        }
+        // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
+        if (pre_requested && k >= 1 && (P <= ((size_t)1 << 16) || k == m_dev - 1)) {
+            CHK(launch_pre());
+            pre_requested = false;
+        }
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
         unsigned long long summed[GKR_CR_WORDS];
         const unsigned long long* sums = nullptr;
-        CHK(round_collect(collective, tg, a.seq, GKR_CR_WORDS, 16, summed, &sums));
+        CHK(round_collect(collective, cur.tg, cur.seq, GKR_CR_WORDS, 16, summed, &sums));
         const double t_w = now_ms();
+        const bool derive_m0 = cur.derive_m0;
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
         // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
@@ -281,6 +397,17 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_h0 = now_ms();
         const E r = hfr::mimc_hash(co, 9);
         const double t_h1 = now_ms();
+        double t_l2 = t_h1;
+        if (prelaunched) {
+            const E two128 = {{0, 0, 1, 0}};
+            chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
+            chal_guard.armed = false;
+            cur = nxt;
+        } else if (have_next) {
+            CHK(launch_round(k + 1, false, r, claim != nullptr, &nxt));
+            cur = nxt;
+            t_l2 = now_ms();
+        }
         chal[k] = r;
         c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
         r_prev = r;
@@ -304,12 +431,13 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             tail[2] = tail[3] = Sh[0];
             r_prev = chal[m - 1];
         }
-        cx().prof.host_launch_ms += t_l1 - t_l0;
+        cx().prof.host_launch_ms += (t_l1 - t_l0) + (t_l2 - t_h1);
         cx().prof.host_wait_ms += t_w - t_l1;
         cx().prof.host_other_ms += t_h0 - t_w;
         cx().prof.host_hash_ms += t_h1 - t_h0;
         cx().prof.rounds++;
     }
+    if (pre_requested) CHK(launch_pre());      // no round was small enough: still ahead of the next layer's pyramids
     r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
     cx().racc_dirty = false;
@@ -486,7 +614,16 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     const int h_tail = (!collective && cx().host_tail > 0 && m >= cx().host_tail + 2) ? std::min(cx().host_tail, kHostTailMax) : 0;
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // see cipher_rounds
     const int m_dev = h_tail ? k_export + 1 : m;
-    for (int k = 0; k < m_dev; k++) {
+    const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    const bool pl_on = !round_targets(collective).on_device && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));   // see cipher_rounds
+    const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
+    ChalGuard chal_guard;
+    struct InFlight {
+        RoundTargets tg;
+        unsigned int seq;
+        bool derive_m0;
+    };
+    auto launch_round = [&](int k, bool deferred, const E& r_in, bool derive_m0, InFlight* out) -> int {
         const size_t P = n >> (k + 1);
         const int gk = std::min(g_lin, m - 1 - k);
         const int lj = m - 1 - k - gk;
@@ -505,19 +642,28 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         }
         a.P = P;
         a.lg_threads = (unsigned)gk;
-        a.r = to_dev(r_prev);
-        a.r_lo = to_dev(hfr::mul(r_prev, two128));
+        if (deferred) {
+            chal_guard.armed = true;
+        } else {
+            a.r = to_dev(r_in);
+            a.r_lo = to_dev(hfr::mul(r_in, two128));
+        }
         a.ark = to_dev(ark);
         a.arity = arity;
         a.sum_mask = g.mask;
         a.racc = cx().d_racc;
         a.counter = cx().d_counter;
         a.tail_tables = k == k_export ? cx().d_tail : nullptr;
-        const RoundTargets tg = round_targets(collective);
-        a.host_out = tg.out;
-        a.host_flag = tg.flag;
-        a.seq = ++cx().seq;
-        const bool derive_m0 = claim && *claim_known;
+        out->tg = round_targets(collective);
+        a.host_out = out->tg.out;
+        a.host_flag = out->tg.flag;
+        a.seq = out->seq = ++cx().seq;
+        if (deferred) {
+            a.chal = cx().d_chal;
+            a.chal_dev = cx().d_chal_dev;
+            a.chal_seq = a.seq;
+        }
+        out->derive_m0 = derive_m0;
         a.need_m0 = derive_m0 ? 0u : 1u;
         const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
         if (fold) {
@@ -528,9 +674,27 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             else hipLaunchKernelGGL((k_linear_round<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
         }
         HIPCHK(hipGetLastError());
+        return 0;
+    };
+    InFlight cur, nxt;
+    CHK(launch_round(0, false, hfr::ZERO, claim && *claim_known, &cur));
+    bool pre_requested = cx().req_K != nullptr && pre_on;
+    for (int k = 0; k < m_dev; k++) {
+        const size_t P = n >> (k + 1);
+        const bool have_next = k + 1 < m_dev;
+        const bool prelaunched = have_next && pl_on && (P >> 1) <= ((size_t)1 << cx().prelaunch_lg);
+        if (prelaunched) {
+            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
+            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+        }
+        if (pre_requested && k >= 1 && (P <= ((size_t)1 << 16) || k == m_dev - 1)) {   // the next (cipher) layer's look-ahead
+            CHK(launch_pre());
+            pre_requested = false;
+        }
         unsigned long long summed[GKR_LR_WORDS];
         const unsigned long long* sums = nullptr;
-        CHK(round_collect(collective, tg, a.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
+        CHK(round_collect(collective, cur.tg, cur.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
+        const bool derive_m0 = cur.derive_m0;
         // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
         const E cm1 = hfr::mul(c, limbs9_to_fr(sums + GKR_ACC_WORDS));
         const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, limbs9_to_fr(sums));
@@ -541,6 +705,14 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         co[1] = hfr::add(hfr::mul(a0, cm1), hfr::mul(a1, cm0));
         co[2] = hfr::mul(a1, cm1);
         const E r = hfr::mimc_hash(co, 3);
+        if (prelaunched) {
+            chal_publish(nxt.seq, r, hfr::mul(r, two128));
+            chal_guard.armed = false;
+            cur = nxt;
+        } else if (have_next) {
+            CHK(launch_round(k + 1, false, r, claim != nullptr, &nxt));
+            cur = nxt;
+        }
         chal[k] = r;
         c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
         r_prev = r;
@@ -560,6 +732,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             r_prev = chal[m - 1];
         }
     }
+    if (pre_requested) CHK(launch_pre());
     r_last = r_prev;
     HIPCHK(hipStreamSynchronize(cx().stream));
     cx().racc_dirty = false;

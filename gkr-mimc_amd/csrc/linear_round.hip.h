@@ -33,6 +33,9 @@ struct LinearRoundArgs {
     unsigned int seq;
     unsigned int need_m0;
     unsigned long long* tail_tables;   // host-mapped, or nullptr: this round's tables (2P entries per table, 4 u64 each)
+    const unsigned long long* chal;    // pre-launched round: r, r_lo arrive through this host-mapped slot (cipher_round.hip.h)
+    unsigned long long* chal_dev;
+    unsigned int chal_seq;
 };
 
 template <bool FOLD, bool HAS_WJ>
@@ -44,6 +47,8 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
     const size_t P = a.P;
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr ch_r = a.r, ch_rlo = a.r_lo;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const size_t iters = P >> a.lg_threads;
@@ -55,8 +60,8 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
                 if (FOLD) {
                     const Fr x0 = ld_fr(a.src[t].lo, a.src[t].hi, x), x2 = ld_fr(a.src[t].lo, a.src[t].hi, x + 2 * P);
                     const Fr x1 = ld_fr(a.src[t].lo, a.src[t].hi, x + P), x3 = ld_fr(a.src[t].lo, a.src[t].hi, x + 3 * P);
-                    lo = fr_reduce_lt4q(fr_add_raw(x0, fr_mul_const2_raw(fr_sub(x2, x0), a.r_lo, a.r)));   // poly/multilin.go:32-34
-                    hi = fr_reduce_lt4q(fr_add_raw(x1, fr_mul_const2_raw(fr_sub(x3, x1), a.r_lo, a.r)));
+                    lo = fr_reduce_lt4q(fr_add_raw(x0, fr_mul_const2_raw(fr_sub(x2, x0), ch_rlo, ch_r)));   // poly/multilin.go:32-34
+                    hi = fr_reduce_lt4q(fr_add_raw(x1, fr_mul_const2_raw(fr_sub(x3, x1), ch_rlo, ch_r)));
                     st_fr(a.dst[t].lo, a.dst[t].hi, x, lo);
                     st_fr(a.dst[t].lo, a.dst[t].hi, x + P, hi);
                 } else {

@@ -34,6 +34,7 @@ ABI = {
     "gkrhip_device_count": (_I, []),
     "gkrhip_last_error": (C.c_char_p, []),
     "gkrhip_version": (C.c_char_p, []),
+    "gkrhip_build_id": (C.c_char_p, []),
     "gkrhip_device_synchronize": (_I, []),
     "gkrhip_mem_info": (_I, [C.POINTER(_SZ), C.POINTER(_SZ)]),
     "gkrhip_set_option": (_I, [C.c_char_p, C.c_long]),
@@ -86,6 +87,7 @@ ABI = {
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
+    "gkrhip_profile_latency": (_I, [C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
 }
 
 
@@ -106,11 +108,14 @@ def load():
         raise GkrHipError("libgkrhip.so not built: run `python __graft_entry__.py` (or gkr-mimc_amd/build.py); "
                           "there is no CPU fallback")
     from . import build as _build
-    info = _build.read_info()
-    if info is None or info.get("source_sha256") != _build.source_sha():
-        raise GkrHipError("libgkrhip.so was not built from the sources in this tree (build_info.json missing or stale): "
-                          "run `python __graft_entry__.py`; there is no CPU fallback")
+    # the hash compiled into the binary itself (not a tracked side file) against the sources on disk
+    if _build.binary_sha(_SO) != _build.source_sha():
+        raise GkrHipError("libgkrhip.so was not built from the sources in this tree (the source hash compiled into it "
+                          "differs): run `python __graft_entry__.py`; there is no CPU fallback")
     lib = C.CDLL(_SO)
+    lib.gkrhip_build_id.restype = C.c_char_p
+    if lib.gkrhip_build_id().decode() != _build.source_sha():
+        raise GkrHipError("libgkrhip.so reports a different build id than its file holds")
     for name, (res, args) in ABI.items():
         f = getattr(lib, name)
         f.restype = res
@@ -557,7 +562,9 @@ def profile_get():
     _check(load().gkrhip_profile_get(C.byref(fl), C.byref(fm), C.byref(fb), C.byref(pl), C.byref(pm), C.byref(pmm)))
     r, hh, hw, hl, ho = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
     _check(load().gkrhip_profile_host(C.byref(r), C.byref(hh), C.byref(hw), C.byref(hl), C.byref(ho)))
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _check(load().gkrhip_profile_latency(C.byref(a), C.byref(b), C.byref(c)))
     return {"fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
             "peval_launches": pl.value, "peval_ms": pm.value, "peval_modmuls": pmm.value,
             "rounds": r.value, "host_hash_ms": hh.value, "host_wait_ms": hw.value, "host_launch_ms": hl.value,
-            "host_other_ms": ho.value}
+            "host_other_ms": ho.value, "prelaunched_rounds": a.value, "lookahead_round0": b.value, "coop_rounds": c.value}

@@ -60,10 +60,14 @@ void gkrhip_shutdown(void);
 int gkrhip_device_count(void);
 const char *gkrhip_last_error(void);
 const char *gkrhip_version(void);
+/* SHA-256 (hex) of the sources and compiler flags this binary was built from; the loaders compare it with the sources
+ * they sit next to (gkr-mimc_amd/build.py) so that a stale binary is never called through a changed ABI */
+const char *gkrhip_build_id(void);
 int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
 int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
- * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail" -- applied to every existing lane,
+ * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
+ * "coop" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
  * gkrhip_init) */
 int gkrhip_set_option(const char *key, long value);
@@ -253,6 +257,10 @@ int gkrhip_profile_get(uint64_t *fold_launches, double *fold_ms, double *fold_by
 /* Host-side wall-clock split of the fused cipher rounds since the last reset: Fiat-Shamir hashing,
  * waiting for the round kernel, launching, other scalar work (all in ms), and the number of rounds. */
 int gkrhip_profile_host(uint64_t *rounds, double *hash_ms, double *wait_ms, double *launch_ms, double *other_ms);
+/* How often the serial-latency paths ran since the last reset: rounds whose kernel was queued ahead of its challenge
+ * (it polls a host-mapped slot), round-0 launches that used products computed during the previous layer, rounds run by
+ * the cooperative eight-lanes-per-pair kernel.  The parity tests use it to prove that a switch selected the path. */
+int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_round0, uint64_t *coop_rounds);
 
 #ifdef __cplusplus
 }

@@ -13,11 +13,22 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import coracle as c  # noqa: E402
 
 
+def check_expected_paths(gk):
+    """GKRHIP_CASE_EXPECT=prelaunched_rounds,lookahead_round0,...: the named serial-latency paths must have run (a switch
+    that silently selects nothing would make the comparison above vacuous); GKRHIP_CASE_EXPECT_NOT: must not have run."""
+    prof = gk.profile_get()
+    for name in filter(None, os.environ.get("GKRHIP_CASE_EXPECT", "").split(",")):
+        assert prof[name] > 0, (name, prof)
+    for name in filter(None, os.environ.get("GKRHIP_CASE_EXPECT_NOT", "").split(",")):
+        assert prof[name] == 0, (name, prof)
+
+
 def main():
     sizes = [int(x) for x in sys.argv[1].split(",")]
     circuit = sys.argv[2] if len(sys.argv) > 2 else "mimc"
     gk = importlib.import_module("gkr-mimc_amd")
     gk.init(0)
+    gk.profile_reset(0)
     if circuit == "gmimc":      # the build-defined GMiMC (t = 2) circuit: cipher, add and identity layers
         import pyoracle as o
         layers = gk.gmimc_t2_circuit()
@@ -34,6 +45,7 @@ def main():
             oflat, _oouts, _ = c.gkr_prove_circuit(descs, bn, ins, qp)
             assert np.array_equal(flat, oflat), ("gmimc", bn)
             s.close()
+        check_expected_paths(gk)
         print("CASE-OK", sizes)
         return
     for bn in sizes:
@@ -51,6 +63,7 @@ def main():
         flat, outs = gk.gkr_prove_mimc(i0, X[1], qp)
         oflat, oouts, _ = c.gkr_prove_mimc(bn, i0, X[1], qp)
         assert np.array_equal(flat, oflat) and np.array_equal(outs, oouts), ("gkr", bn)
+    check_expected_paths(gk)
     print("CASE-OK", sizes)
 
 

@@ -374,6 +374,48 @@ def test_round_kernel_deferred_reduction_variants(gk):
     _run_case({"GKRHIP_GMAX": "8", "GKRHIP_SOLO_BOOST": "0"}, "10,11,12")
 
 
+def test_prelaunched_rounds(gk):
+    """Round k+1's kernel queued before round k is hashed (it polls the host-mapped challenge slot): the same transcript
+    with the pre-launch forced on for every round size, off, and combined with the other round variants; the counter
+    proves the path ran."""
+    on = {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRELAUNCH_LG": "30", "GKRHIP_CASE_EXPECT": "prelaunched_rounds"}
+    _run_case(on, "1,2,3,5,9,12,14")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "2,6,10")
+    _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_HOST_TAIL="3"), "9,11,13")
+    _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_LAT="0", GKRHIP_CLAIM_TRICK="0"), "8,12")
+    _run_case(dict(on, GKRHIP_GMAX="8"), "3,9,11", circuit="gmimc")           # the linear rounds too
+    _run_case({"GKRHIP_PRELAUNCH": "0", "GKRHIP_CASE_EXPECT_NOT": "prelaunched_rounds"}, "2,9,12")
+    _run_case({"GKRHIP_PRELAUNCH": "1", "GKRHIP_PRELAUNCH_LG": "4", "GKRHIP_HOST_TAIL": "0", "GKRHIP_CASE_EXPECT": "prelaunched_rounds"}, "7,10")
+
+
+def test_cooperative_small_rounds(gk):
+    """k_cipher_round_coop (eight lanes per pair, products dealt level by level through LDS) for the small rounds: same
+    transcript with the kernel forced on for every size it takes, with the last round and the host-tail export inside
+    it, several iterations per workgroup, all eight sums on the device, pre-launched or not, and switched off."""
+    on = {"GKRHIP_COOP": "2", "GKRHIP_CASE_EXPECT": "coop_rounds"}
+    _run_case(on, "1,2,3,5,6,9,12,14")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "1,2,4,7,10,13")               # the P = 1 round and its tail words
+    _run_case(dict(on, GKRHIP_HOST_TAIL="3", GKRHIP_COOP_WGS="2"), "6,9,11")  # export + several iterations per workgroup
+    _run_case(dict(on, GKRHIP_CLAIM_TRICK="0", GKRHIP_PRELAUNCH="0"), "3,8,12")
+    _run_case(dict(on, GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_HOST_TAIL="1"), "5,10,14")
+    _run_case(dict(on, GKRHIP_COOP_LG="6", GKRHIP_GMAX="8"), "9,12")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="2"), "4,9", circuit="gmimc")
+    _run_case({"GKRHIP_COOP": "0", "GKRHIP_CASE_EXPECT_NOT": "coop_rounds"}, "3,9,12")
+
+
+def test_lookahead_round0(gk):
+    """The q-independent products of a cipher layer's round 0 computed during the previous layer (k_cipher_pre on the
+    look-ahead stream) and consumed by k_cipher_round_wide<false, ., true>: same transcript, early and late lane
+    weights, MiMC and GMiMC circuits, and with the look-ahead switched off."""
+    on = {"GKRHIP_PRE": "2", "GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT": "lookahead_round0"}
+    _run_case(on, "11,12,14,15")
+    _run_case(dict(on, GKRHIP_WT_LATE_LJ="99"), "11,13")
+    _run_case(dict(on, GKRHIP_WT_LATE_LJ="1", GKRHIP_SOLO_BOOST="0", GKRHIP_PRELAUNCH="0"), "10,12")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "11,12", circuit="gmimc")
+    _run_case({"GKRHIP_PRE": "0", "GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT_NOT": "lookahead_round0"}, "11,13")
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT": "lookahead_round0,prelaunched_rounds"}, "12")   # the defaults, alone on the GPU
+
+
 def test_round_kernel_deferred_reduction_carry_corners(gk):
     """Tables made of the carry-corner values (limbs of 0xFFFFFFFF, q-1, 0, 1) through gkr.Prove with a small
     thread budget, so that every lane accumulates many wide products of extreme operands."""
