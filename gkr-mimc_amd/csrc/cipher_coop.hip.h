@@ -53,8 +53,23 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_coop(CipherRoundA
     __builtin_amdgcn_s_setprio(3);
     const int role = threadIdx.x / GKR_COOP_PAIRS, pl = threadIdx.x % GKR_COOP_PAIRS;
     const size_t P = a.P;
+    // The table entries and the weight do not depend on the challenge: a pre-launched kernel requests those of its first
+    // iteration BEFORE it waits for r, so the loads' latency overlaps the host's hash
+    const size_t x0 = (size_t)blockIdx.x * GKR_COOP_PAIRS + pl;
+    Fr pf_lo = fr_zero(), pf_hi = fr_zero(), pf_W = fr_zero();
+    {
+        const CPlanes src = role < 2 ? a.k_src : a.s_src;
+        const size_t off = (role & 1) ? P : 0;                 // roles 1, 3: the high half of the pair
+        if (x0 < P) {
+            if (role < 4) {
+                pf_lo = ld_fr(src.lo, src.hi, x0 + off);
+                if (FOLD) pf_hi = ld_fr(src.lo, src.hi, x0 + off + 2 * P);
+            }
+            pf_W = ld_fr(a.wt.lo, a.wt.hi, x0);
+        }
+    }
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
     Acc9 acc;
 #pragma unroll
     for (int j = 0; j < GKR_ACC_WORDS; j++) acc.w[j] = 0;
@@ -62,19 +77,21 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_coop(CipherRoundA
     for (size_t base = (size_t)blockIdx.x * GKR_COOP_PAIRS; base < P; base += (size_t)gridDim.x * GKR_COOP_PAIRS) {
         const size_t x = base + pl;
         const bool live = x < P;
+        const bool first_it = base == (size_t)blockIdx.x * GKR_COOP_PAIRS;
         // ---- level F: the four table entries of the pair, one role each (poly/multilin.go:32-34)
         if (role < 4) {
             Fr v = fr_zero();
             if (live) {
                 const CPlanes src = role < 2 ? a.k_src : a.s_src;
-                const size_t off = (role & 1) ? P : 0;                 // roles 1, 3: the high half of the pair
+                const size_t off = (role & 1) ? P : 0;
                 if (FOLD) {
-                    const Fr lo = ld_fr(src.lo, src.hi, x + off), hi = ld_fr(src.lo, src.hi, x + off + 2 * P);
+                    const Fr lo = first_it ? pf_lo : ld_fr(src.lo, src.hi, x + off);
+                    const Fr hi = first_it ? pf_hi : ld_fr(src.lo, src.hi, x + off + 2 * P);
                     v = fr_reduce_lt4q(fr_add_raw(lo, fr_mul_const2_raw(fr_sub(hi, lo), ch_rlo, ch_r)));
                     const Planes dst = role < 2 ? a.k_dst : a.s_dst;
                     st_fr(dst.lo, dst.hi, x + off, v);
                 } else {
-                    v = ld_fr(src.lo, src.hi, x + off);
+                    v = first_it ? pf_lo : ld_fr(src.lo, src.hi, x + off);
                 }
                 if (a.tail_tables) coop_export(a.tail_tables + 4 * ((size_t)role * P + x), v);      // K: [0, 2P), S: [2P, 4P)
                 if (P == 1) coop_export(a.host_out + GKR_CR_WORDS + 4 * role, v);
@@ -88,7 +105,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_coop(CipherRoundA
             const Fr klo = coop_ld(sh, 0, pl), khi = coop_ld(sh, 1, pl), slo = coop_ld(sh, 2, pl), shi = coop_ld(sh, 3, pl);
             u = fr_add_raw(fr_add_raw(klo, slo), a.ark);                     // < 3q
             d = fr_add_raw(fr_sub(khi, klo), fr_sub(shi, slo));              // < 2q
-            W = live ? ld_fr(a.wt.lo, a.wt.hi, x) : fr_zero();
+            W = first_it ? pf_W : (live ? ld_fr(a.wt.lo, a.wt.hi, x) : fr_zero());
         }
         // ---- level A: u^2, d^2, ud, Wu, Wd
         if (role < 5) {

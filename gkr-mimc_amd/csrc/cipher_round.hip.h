@@ -111,31 +111,45 @@ struct CipherRoundArgs {
 // ------------------------------------------------------------------------------------------------
 #define GKR_CHAL_WORDS 16
 #define GKR_CHAL_ABORT 0xFFFFFFFFu
-// Only workgroup 0 polls host memory (sixteen 8-byte reads per poll over PCIe); it forwards the tagged words to a
-// device-memory mailbox the other workgroups poll (L2 atomics).  Hundreds of workgroups polling the host directly
-// saturate the PCIe read path and delay the very hand-off the host is waiting for (measured: +12 ms per proof).
+// Workgroup 0 polls host memory (sixteen 8-byte reads per poll over PCIe) and forwards the tagged words to a
+// device-memory mailbox; the other workgroups poll the mailbox (L2 atomics) and look at the host slot themselves only
+// every 64th time (~20 us).  Hundreds of workgroups polling the host directly saturate the PCIe read path and delay the
+// very hand-off the host is waiting for (measured: +12 ms per proof) -- but the mailbox must stay a SHORTCUT, never a
+// dependency: workgroup 0 need not be resident (several pre-launched kernels, e.g. of several processes sharing the GPU,
+// can each hold part of the machine while their workgroups 0 wait for a slot: measured, a deadlock until the time-out).
+// Whoever reads the words from the host forwards them; the writes are idempotent.
 __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, unsigned long long* mailbox, unsigned int seq, Fr& r,
-                                               Fr& r_lo) {
+                                               Fr& r_lo, unsigned long long* diag = nullptr) {
     __shared__ u32 s_ch[GKR_CHAL_WORDS];
     int bad = 0;
     if (threadIdx.x < GKR_CHAL_WORDS) {
         const unsigned long long t0 = wall_clock64();          // 100 MHz
         const bool first = blockIdx.x == 0;
         unsigned long long v;
-        for (;;) {
-            v = first ? __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                      : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool from_host = first;
+        for (unsigned it = 0;; it++) {
+            // uniform over the sixteen lanes: they count the same iterations until the first of them leaves
+            from_host = first || (it & 63u) == 63u;
+            v = from_host ? __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                          : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 s = (u32)(v >> 32);
             if (s == seq) break;
             if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 800000000ull) {
                 bad = 1;
+                if (diag && threadIdx.x == 0) {          // why the launch was abandoned (the host's error message quotes it)
+                    diag[0] = ((unsigned long long)blockIdx.x << 32) | (s == GKR_CHAL_ABORT ? 1u : 2u);
+                    diag[1] = wall_clock64() - t0;
+                    diag[2] = v;
+                    diag[3] = seq;
+                }
                 v = (unsigned long long)GKR_CHAL_ABORT << 32;
+                from_host = false;
                 break;
             }
             if (first) __builtin_amdgcn_s_sleep(2);
             else __builtin_amdgcn_s_sleep(8);
         }
-        if (first) __hip_atomic_store(mailbox + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (from_host) __hip_atomic_store(mailbox + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_ch[threadIdx.x] = (u32)v;
     }
     if (__syncthreads_or(bad)) return false;
@@ -197,7 +211,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr ark = a.ark;
@@ -403,7 +417,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr negark = fr_sub(fr_zero(), a.ark);      // q - ark (0 for ark = 0), canonical

@@ -166,6 +166,13 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         cur += slots * bN;
     }
     if (cur != proof_len(c, bN)) return fail("internal: flat proof length mismatch");
+    if (getenv("GKRHIP_TRACE_ROUNDS")) {       // where one proof's host time went (cumulative since the last profile reset)
+        const Profile& p = cx().prof;
+        fprintf(stderr, "rounds trace: hash %.2f wait %.2f launch %.2f other %.2f setup %.2f host-tail arithmetic %.2f ms\n", p.host_hash_ms,
+                p.host_wait_ms, p.host_launch_ms, p.host_other_ms, p.setup_ms, p.tail_ms);
+        for (int lg = 39; lg >= 0; lg--)
+            if (p.cnt_lg[lg]) fprintf(stderr, "  2^%-2d pairs: %5llu rounds, wait %.1f us each\n", lg, (unsigned long long)p.cnt_lg[lg], 1e3 * p.wait_lg[lg] / p.cnt_lg[lg]);
+    }
     return 0;
 }
 
@@ -289,7 +296,7 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "wide_mode")) l->wide_mode = (int)value;
         else if (!strcmp(key, "wt_late_lj")) l->wt_late_lj = (int)value;
         else if (!strcmp(key, "claim_trick")) l->claim_trick = value != 0;
-        else if (!strcmp(key, "host_tail")) l->host_tail = (int)std::max(0L, std::min(6L, value));
+        else if (!strcmp(key, "host_tail")) l->host_tail = l->host_tail_solo = (int)std::max(0L, std::min(6L, value));
         else if (!strcmp(key, "prelaunch")) l->prelaunch = (int)value;
         else if (!strcmp(key, "prelaunch_lg")) l->prelaunch_lg = (int)std::max(0L, std::min(30L, value));
         else if (!strcmp(key, "lookahead")) l->pre_mode = (int)value;

@@ -311,17 +311,23 @@ int partial_evals(const GateDesc& g, const DevTable* eq, const DevTable* const* 
     return 0;
 }
 
+// Coordinates (and seeds) of a layer -> cx().d_q.  Staged through one of two pinned buffers and copied on the lane's
+// stream WITHOUT waiting: the kernels that read d_q are queued behind the copy, and the host waits for one of them
+// (a round's flag, a stream synchronisation) before it stages the next coordinates -- two buffers make that a certainty.
 int stage_coords(const E* coords, size_t n) {
     if (n > cx().d_q_cap) {
+        HIPCHK(hipStreamSynchronize(cx().stream));
         if (cx().d_q) HIPCHK(hipFree(cx().d_q));
+        for (auto& h : cx().h_q)
+            if (h) HIPCHK(hipHostFree(h));
         cx().d_q_cap = std::max<size_t>(n, 256);
         HIPCHK(hipMalloc(&cx().d_q, sizeof(Fr) * cx().d_q_cap));
+        for (auto& h : cx().h_q) HIPCHK(hipHostMalloc(&h, sizeof(Fr) * cx().d_q_cap, hipHostMallocDefault));
     }
     if (n == 0) return 0;
-    std::vector<Fr> stage(n);
+    Fr* stage = cx().h_q[cx().h_q_next ^= 1];
     for (size_t i = 0; i < n; i++) stage[i] = to_dev(coords[i]);
-    HIPCHK(hipMemcpyAsync(cx().d_q, stage.data(), sizeof(Fr) * n, hipMemcpyHostToDevice, cx().stream));
-    HIPCHK(hipStreamSynchronize(cx().stream));  // `stage` is pageable host memory
+    HIPCHK(hipMemcpyAsync(cx().d_q, stage, sizeof(Fr) * n, hipMemcpyHostToDevice, cx().stream));
     return 0;
 }
 

@@ -22,6 +22,9 @@ std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
     uint64_t rounds = 0;
+    double wait_lg[40] = {0};                  // GKRHIP_TRACE_ROUNDS: host wait per cipher round, by log2(pairs)
+    uint64_t cnt_lg[40] = {0};
+    double setup_ms = 0, tail_ms = 0;          // per-layer set-up (coordinates, pyramids, tables); host-tail rounds
     size_t min_n = (size_t)1 << 62;
     uint64_t fold_launches = 0, peval_launches = 0;
     double fold_bytes = 0, peval_modmuls = 0;
@@ -44,6 +47,8 @@ inline void prof_clear(Profile& p) {              // events go back to the lane'
     p.fold_bytes = p.peval_modmuls = 0;
     p.host_hash_ms = p.host_wait_ms = p.host_launch_ms = p.host_other_ms = 0;
     p.rounds = 0;
+    for (int i = 0; i < 40; i++) p.wait_lg[i] = 0, p.cnt_lg[i] = 0;
+    p.setup_ms = p.tail_ms = 0;
 }
 
 // per-lane state of the collective (one communicator / shared-memory segment per lane: the lanes of a rank
@@ -85,6 +90,8 @@ struct Ctx {
     uint4* h_small = nullptr;                  // pinned
     Fr* d_q = nullptr;                         // qPrime coordinates + seeds staging
     size_t d_q_cap = 0;
+    Fr* h_q[2] = {nullptr, nullptr};           // pinned staging of d_q (alternating)
+    int h_q_next = 0;
     unsigned long long* h_tail = nullptr;      // host-mapped: the tables of the round after which the host takes over (GKRHIP_HOST_TAIL)
     unsigned long long* d_tail = nullptr;
     unsigned int* h_bad = nullptr;             // host-mapped: set by k_aos_to_planes when an uploaded element is >= q
@@ -107,9 +114,12 @@ struct Ctx {
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
     int g_lin = 0;                             // GKRHIP_GLIN: log2(max threads) of the linear-gate round kernel when above g_max (measured: no gain)
     int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
+    int solo_med = 1;                          // GKRHIP_SOLO_MED: see threads_log2 in cipher_rounds
+    int lat_spread = 1;                        // GKRHIP_LAT_SPREAD: one workgroup per CU for small latency-bound launches
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     int host_tail = 5;                         // GKRHIP_HOST_TAIL: the rounds with at most 2^h pairs run on the host (0: never); measured: -5 % single-proof latency, +1.5 % throughput
+    int host_tail_solo = 4;                    // GKRHIP_HOST_TAIL_SOLO: the same for a proof that is alone on the GPU, whose small rounds are fast (cooperative kernel, pre-launched): bN = 20 107.6 ms against 110-112 with 5 and 111.5 with 3; GKRHIP_HOST_TAIL sets both
     // ---- serial-latency measures of a proof that is alone on the GPU (round 3) -----------------------------------
     // pre-launched rounds: round k+1's kernel is queued before the host hashes round k and polls the challenge slot
     int prelaunch = 1;                         // GKRHIP_PRELAUNCH: 0 never, 1 when the proof is alone on the GPU, 2 always
@@ -121,8 +131,8 @@ struct Ctx {
     // small rounds leave the GPU idle (k_cipher_pre); the next layer's round 0 then only applies the weights
     int pre_mode = 1;                          // GKRHIP_PRE: 0 never, 1 when the proof is alone on the GPU, 2 always
     int coop = 1;                              // GKRHIP_COOP: cooperative small-round kernel (eight lanes per pair): 0 never, 1 alone on the GPU, 2 always
-    int coop_lg = 13;                          // ... for rounds of at most 2^coop_lg pairs
-    int coop_wgs = 256;                        // ... on at most this many workgroups
+    int coop_lg = 14;                          // ... for rounds of at most 2^coop_lg pairs
+    int coop_wgs = 512;                        // ... on at most this many workgroups
     hipStream_t aux = nullptr;                 // low-priority stream of the look-ahead kernel
     hipEvent_t pre_done = nullptr;
     DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()
@@ -270,7 +280,10 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
-    if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));   // an explicit setting holds for both
+    if (const char* e = getenv("GKRHIP_HOST_TAIL_SOLO")) cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("GKRHIP_SOLO_MED")) cx().solo_med = atoi(e);
+    if (const char* e = getenv("GKRHIP_LAT_SPREAD")) cx().lat_spread = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
@@ -317,12 +330,6 @@ int lane_alloc() {
     memset(cx().h_chal, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS);
     HIPCHK(hipMalloc(&cx().d_chal_dev, sizeof(unsigned long long) * GKR_CHAL_WORDS));
     HIPCHK(hipMemset(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS));
-    {
-        int least = 0, greatest = 0;               // the look-ahead kernel must never delay a round kernel
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&cx().aux, hipStreamNonBlocking, least));
-        HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
-    }
     return 0;
 }
 // the look-ahead tables go back to the arena (end of a proof, lane teardown)
@@ -354,6 +361,10 @@ void lane_free() {
     (void)hipFree(cx().d_counter);
     if (cx().d_q) (void)hipFree(cx().d_q);
     cx().d_q = nullptr;
+    for (auto& h : cx().h_q) {
+        if (h) (void)hipHostFree(h);
+        h = nullptr;
+    }
     cx().d_q_cap = 0;
     if (cx().h_tail) (void)hipHostFree(cx().h_tail);
     cx().h_tail = cx().d_tail = nullptr;
@@ -395,6 +406,9 @@ void lane_configure(Ctx* l) {
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->host_tail = g0.host_tail;
+    l->host_tail_solo = g0.host_tail_solo;
+    l->solo_med = g0.solo_med;
+    l->lat_spread = g0.lat_spread;
     l->prelaunch = g0.prelaunch;
     l->prelaunch_lg = g0.prelaunch_lg;
     l->pre_mode = g0.pre_mode;
@@ -705,7 +719,11 @@ int wait_flag(unsigned int seq, volatile unsigned int* f = nullptr, double deadl
         if ((++spins & 0xfffff) == 0) {              // every now and then: make sure the GPU is alive
             hipError_t e = hipStreamQuery(watch);
             if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
-            if (e == hipSuccess && *f != seq) return fail("round kernel finished without publishing its result");
+            if (e == hipSuccess && *f != seq) {
+                const unsigned long long* dg = cx().h_round + 104;      // wait_challenge's note, if it abandoned the launch
+                return fail("round kernel finished without publishing its result (flag %u, expected %u; challenge wait: code %llx after %llu ticks, "
+                            "word %llx, seq %llu)", *f, seq, dg[0], dg[1], dg[2], dg[3]);
+            }
             if (deadline_ms > 0) {
                 if (t0 == 0) t0 = now_ms();
                 else if (now_ms() - t0 > deadline_ms) return fail("timed out after %.0f s waiting for the per-round exchange", deadline_ms * 1e-3);

@@ -3,8 +3,12 @@
 #pragma once
 // ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
 template <bool FOLD, bool HAS_WJ>
-void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat) {
-    if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat, bool alone) {
+    // a latency-bound launch of at most one workgroup per CU asks for enough (unused) dynamic LDS that two of its
+    // workgroups cannot share a CU: the dispatcher otherwise packs some CUs with two lone-wave workgroups and leaves others idle
+    // (only for a proof that is alone on the GPU: beside other proofs' kernels the extra LDS would keep the launch waiting)
+    const size_t spread = (cx().lat_spread && alone && grid <= cx().n_cu) ? (size_t)64 * 1024 : 0;
+    if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), spread, cx().stream, a);
     else hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
 }
 
@@ -146,6 +150,12 @@ int launch_pre() {
     cx().req_K = cx().req_S = nullptr;
     if (!K || !S || cx().req_m < 2) return 0;
     const size_t P = (size_t)1 << (cx().req_m - 1);
+    if (!cx().aux) {      // created on first use: a lane that never looks ahead holds one hardware queue, not two
+        int least = 0, greatest = 0;               // lowest priority: the look-ahead kernel must never delay a round kernel
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&cx().aux, hipStreamNonBlocking, least));
+        HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
+    }
     for (auto& t : cx().pre_t)
         if (t.cap != P) {
             if (t.base) table_release(&t);
@@ -177,6 +187,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
                   E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
                   bool* claim_known) {
     const size_t n = (size_t)1 << m;
+    const double t_setup0 = now_ms();
     // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the
     // other lanes' kernels fill the second wave slot.  A proof that is alone on the GPU gets twice the threads for
     // the rounds that still have two pairs per lane (two workgroups per CU instead of a lone wave per SIMD).
@@ -185,7 +196,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     const int g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
     auto threads_log2 = [&](int k) {                   // k = round
         const int rem = m - 1 - k;                     // log2(pairs of the round)
-        return rem >= g_big + 1 ? g_big : std::min(cx().g_max, rem);
+        // solo_med: a proof alone on the GPU also runs the round with 2^g_big pairs one pair per lane (two waves per SIMD)
+        return rem >= g_big + (cx().solo_med ? 0 : 1) ? g_big : std::min(cx().g_max, rem);
     };
     const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
     CHK(stage_coords(q, (size_t)m));
@@ -235,13 +247,13 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     E r_prev = hfr::ZERO;
     // GKRHIP_HOST_TAIL = h > 0: the device runs the rounds down to 2^(h+1) pairs, exports that round's tables and the
     // host finishes (un-sharded rounds only: the sharded local rounds exchange device-produced words)
-    const int h_tail = (!collective && cx().host_tail > 0 && m >= cx().host_tail + 2) ? std::min(cx().host_tail, kHostTailMax) : 0;
+    const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    const int h_want = alone ? cx().host_tail_solo : cx().host_tail;
+    const int h_tail = (!collective && h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // round whose tables go to the host
     const int m_dev = h_tail ? k_export + 1 : m;             // rounds on the device
-    const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
-    // pre-launched rounds (the next round's kernel is queued before this round is hashed and polls the challenge slot):
-    // not over RCCL, whose all-reduce and publish kernel are queued between the rounds
-    const bool pl_on = !round_targets(collective).on_device && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));
+    // pre-launched rounds: the next round's kernel is queued before this round is hashed and polls the challenge slot
+    const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);
     const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
     const bool coop_on = cx().coop >= 2 || (cx().coop == 1 && alone);
     ChalGuard chal_guard;
@@ -333,11 +345,11 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
                 else hipLaunchKernelGGL((k_cipher_round_wide<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             }
         } else if (fold) {
-            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat);
-            else launch_cipher_round<true, false>(a, grid, lat);
+            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat, alone);
+            else launch_cipher_round<true, false>(a, grid, lat, alone);
         } else {
-            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat);
-            else launch_cipher_round<false, false>(a, grid, lat);
+            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat, alone);
+            else launch_cipher_round<false, false>(a, grid, lat, alone);
         }
         HIPCHK(hipGetLastError());
         if (timed) {
@@ -351,6 +363,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     InFlight cur, nxt;
     {
         const double t_l0 = now_ms();
+        cx().prof.setup_ms += t_l0 - t_setup0;
         CHK(launch_round(0, false, hfr::ZERO, claim && *claim_known, &cur));
         cx().prof.host_launch_ms += now_ms() - t_l0;
     }
@@ -361,7 +374,11 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         // round k+1 queued now, behind round k's kernel: its dispatch overlaps the hash below
         const bool have_next = k + 1 < m_dev;
         const bool prelaunched = have_next && pl_on && (P >> 1) <= ((size_t)1 << cx().prelaunch_lg);
-        if (prelaunched) {
+        // Un-sharded: queued BEFORE waiting for round k (the launch call itself is hidden behind round k's kernel).
+        // Sharded: AFTER the exchange of round k -- the kernel then only ever spins for the duration of this rank's own
+        // hash, never for a peer that is seconds behind (ranks reach the first exchange of a proof at different times),
+        // and over RCCL it stays behind the all-reduce and the publish kernel in stream order.
+        if (prelaunched && !collective) {
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
         }
@@ -376,6 +393,10 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const unsigned long long* sums = nullptr;
         CHK(round_collect(collective, cur.tg, cur.seq, GKR_CR_WORDS, 16, summed, &sums));
         const double t_w = now_ms();
+        if (prelaunched && collective) {
+            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
+            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+        }
         const bool derive_m0 = cur.derive_m0;
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
@@ -425,7 +446,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
                 Sh[x] = fold2(tt[2 * P + x], tt[3 * P + x], r);
             }
             const int mm = m - 1 - k;                  // variables left
+            const double t_t0 = now_ms(), h_before = cx().prof.host_hash_ms;
             host_cipher_rounds(ark, mm, Kh, Sh, q + k + 1, seed, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim, claim_known);
+            cx().prof.tail_ms += (now_ms() - t_t0) - (cx().prof.host_hash_ms - h_before);
             // hand back in the shape the device path uses: the caller folds (lo, hi) with r_last
             tail[0] = tail[1] = Kh[0];
             tail[2] = tail[3] = Sh[0];
@@ -433,14 +456,22 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         cx().prof.host_launch_ms += (t_l1 - t_l0) + (t_l2 - t_h1);
         cx().prof.host_wait_ms += t_w - t_l1;
+        {
+            int lg = 0;
+            while (((size_t)1 << lg) < P) lg++;
+            cx().prof.wait_lg[lg] += t_w - t_l1;
+            cx().prof.cnt_lg[lg]++;
+        }
         cx().prof.host_other_ms += t_h0 - t_w;
         cx().prof.host_hash_ms += t_h1 - t_h0;
         cx().prof.rounds++;
     }
     if (pre_requested) CHK(launch_pre());      // no round was small enough: still ahead of the next layer's pyramids
     r_last = r_prev;
+    const double t_end0 = now_ms();
     HIPCHK(hipStreamSynchronize(cx().stream));
     cx().racc_dirty = false;
+    cx().prof.setup_ms += now_ms() - t_end0;
     table_release(&pyrT);
     for (int v = 0; v < 2; v++) {
         if (pyrU[v].base) table_release(&pyrU[v]);
@@ -615,7 +646,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // see cipher_rounds
     const int m_dev = h_tail ? k_export + 1 : m;
     const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
-    const bool pl_on = !round_targets(collective).on_device && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));   // see cipher_rounds
+    const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);   // see cipher_rounds
     const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
     ChalGuard chal_guard;
     struct InFlight {
@@ -683,7 +714,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         const size_t P = n >> (k + 1);
         const bool have_next = k + 1 < m_dev;
         const bool prelaunched = have_next && pl_on && (P >> 1) <= ((size_t)1 << cx().prelaunch_lg);
-        if (prelaunched) {
+        if (prelaunched && !collective) {      // see cipher_rounds
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
         }
@@ -694,6 +725,10 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         unsigned long long summed[GKR_LR_WORDS];
         const unsigned long long* sums = nullptr;
         CHK(round_collect(collective, cur.tg, cur.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
+        if (prelaunched && collective) {
+            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
+            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+        }
         const bool derive_m0 = cur.derive_m0;
         // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
         const E cm1 = hfr::mul(c, limbs9_to_fr(sums + GKR_ACC_WORDS));

@@ -34,8 +34,10 @@ def _run_shards(mode, world, sizes, env=None, collect=None):
         os.unlink("/dev/shm" + name)
     except OSError:
         pass
-    for r, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and "SHARD-OK" in out, "rank %d:\n%s" % (r, out[-3000:])
+    bad = [r for r, (p, out) in enumerate(zip(procs, outs)) if p.returncode != 0 or "SHARD-OK" not in out]
+    # the rank that failed first is the interesting one: its peers only report that somebody left
+    bad.sort(key=lambda r: "a peer rank failed or left" in outs[r])
+    assert not bad, "ranks %s failed; rank %d:\n%s" % (bad, bad[0], outs[bad[0]][-3000:])
     if collect is not None:
         collect.extend(outs)
 

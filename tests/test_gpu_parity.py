@@ -354,7 +354,7 @@ def test_host_tail_rounds(gk):
     """GKRHIP_HOST_TAIL = h: the device exports the tables of the round with 2^(h+1) pairs and the host runs the last
     h+1 rounds of every single-point cipher sumcheck itself -- the same transcript for every h, also with the
     throughput kernel as the exporting round and when the sumcheck is too short to have a device round at all."""
-    for h in ("0", "1", "3", "6"):     # 0: every round on the device (the default is 5)
+    for h in ("0", "1", "3", "5", "6"):     # 0: every round on the device (the default is 4)
         _run_case({"GKRHIP_HOST_TAIL": h}, "1,2,3,5,8,9,12")
     _run_case({"GKRHIP_HOST_TAIL": "0"}, "2,9", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "3"}, "3,9,11", circuit="gmimc")
