@@ -1009,6 +1009,53 @@ int gkrhip_bench_sumcheck(int kind, int bn, int ninstance, int warmup, int iters
     return 0;
 }
 
+// BenchmarkPartialEvalWithCipher's shape (sumcheck/prover_test.go:127-147): InitializeCipherGateInstance(bn) -- L = R =
+// [0, 1, 2, ...], CipherGate(Ark = 145646), q = RandomFrArray(bn) --, the Eq table built once (makeEqTable), then `iters`
+// times dispatchPartialEvals of the un-folded instance: the nine evaluations t = 0..8 of round 0 over 2^(bn-1) pairs by the
+// reference-shaped evaluator (k_partial_eval<7, 2, 9> on the materialised Eq table), each call handing its sums to the
+// host as consumeAccumulate would receive them.  *us_per_call = wall clock per dispatch; evals0 (may be NULL) receives the
+// first evaluation of the last call (a value to cross-check: it is the instance's claim minus evals[1]).
+int gkrhip_bench_partial_eval(int bn, int warmup, int iters, double* us_per_call, uint64_t evals0[4]) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    if (bn < 1 || bn > 28 || iters < 1) return fail("bench_partial_eval: bad arguments");
+    LocalOnly lo;
+    const size_t n = (size_t)1 << bn;
+    ScopedTable L, R, eq;
+    CHK(table_alloc(&L, n));
+    CHK(table_alloc(&R, n));
+    CHK(table_alloc(&eq, n));
+    for (DevTable* t : {(DevTable*)&L, (DevTable*)&R}) {
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t->planes(), n);
+        HIPCHK(hipGetLastError());
+    }
+    std::vector<E> q(bn);
+    for (int j = 0; j < bn; j++) q[j] = hfr::from_u64(((unsigned long long)j * j) ^ 0xf45c9df123fULL);   // common.RandomFrArray
+    const E one = hfr::ONE;
+    CHK(build_eq(&eq, q.data(), 1, bn, bn, &one));
+    GateDesc g;
+    CHK(gate_resolve(GKRHIP_GATE_CIPHER, 2, &g));
+    const E ark = hfr::from_u64(145646);
+    const DevTable* X[2] = {&L, &R};
+    E evals[GKR_MAX_EVALS];
+    if (cx().racc_dirty) {
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+    }
+    cx().racc_dirty = true;
+    const size_t saved_min = cx().prof.min_n;
+    cx().prof.min_n = (size_t)1 << 62;
+    for (int i = 0; i < warmup; i++) CHK(partial_evals(g, &eq, X, n / 2, ark, evals, 9, false));
+    const double t0 = now_ms();
+    for (int i = 0; i < iters; i++) CHK(partial_evals(g, &eq, X, n / 2, ark, evals, 9, false));
+    *us_per_call = (now_ms() - t0) * 1e3 / iters;
+    cx().prof.min_n = saved_min;
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    cx().racc_dirty = false;
+    if (evals0) memcpy(evals0, evals[0].l, 32);
+    return 0;
+}
+
 int gkrhip_profile_reset(size_t min_n) {
     g_cnt_prelaunched = 0;
     g_cnt_lookahead = 0;
@@ -1185,6 +1232,60 @@ int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /
     return 0;
 }
 
+// RCCL through the ticker (host_coll.hip.h): ONE communicator for the process, `nlanes` lanes that exchange through it
+int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t id_bytes[128]) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    CHK(comm_common(world, rank, nlanes));
+    if (nlanes > kTickMaxLanes) return fail("comm_init_tick: at most %d lanes", kTickMaxLanes);
+    if (g_ticker) return fail("a ticker is already running");
+    CHK(coll_load());
+    Ticker* t = new Ticker();
+    t->nlanes = nlanes;
+    t->world = world;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, 128);
+    {
+        ncclResult_t r = gc.p_init(&t->comm, world, id, rank);
+        if (r != ncclSuccess) {
+            delete t;
+            return fail("ncclCommInitRank failed: %s", gc.p_errstr ? gc.p_errstr(r) : "?");
+        }
+    }
+    const size_t total = kTickHeader + (size_t)nlanes * kTickStride;
+    hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(&t->h_send, sizeof(unsigned long long) * total, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostMalloc(&t->h_recv, sizeof(unsigned long long) * total, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostMalloc(&t->h_done, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_send, t->h_send, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_recv, t->h_recv, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_done, t->h_done, 0);
+    if (e != hipSuccess) {
+        (void)gc.p_destroy(t->comm);
+        delete t;
+        return fail("comm_init_tick: %s", hipGetErrorString(e));
+    }
+    memset(t->h_send, 0, sizeof(unsigned long long) * total);
+    memset(t->h_recv, 0, sizeof(unsigned long long) * total);
+    *t->h_done = 0;
+    for (int k = 0; k < nlanes; k++) {
+        Ctx* l = comm_lane(k);
+        if (!l) return fail("cannot create lane %d: %s", k, g_err.c_str());
+        l->lc.tick_lane = k;
+    }
+    comm_set(world, rank);
+    t->running.store(true);
+    g_ticker = t;
+    t->th = std::thread(ticker_main, t, g0.device);
+    return 0;
+}
+// ticks issued / ticks in which no lane of any rank had words (measurement)
+int gkrhip_comm_tick_stats(uint64_t* ticks, uint64_t* idle_ticks) {
+    if (ticks) *ticks = g_ticker ? g_ticker->ticks.load() : 0;
+    if (idle_ticks) *idle_ticks = g_ticker ? g_ticker->idle_ticks.load() : 0;
+    return 0;
+}
+
 int gkrhip_comm_init(int world, int rank, const uint8_t id_bytes[128]) {
     if (world == 1 && !id_bytes) {   // explicit single-GPU mode without a communicator
         std::lock_guard<std::mutex> lk(g0.mu);
@@ -1226,6 +1327,20 @@ int gkrhip_comm_init_shm(int world, int rank, const char* name) { return gkrhip_
 
 int gkrhip_comm_destroy(void) {
     std::lock_guard<std::mutex> lk(g0.mu);
+    if (g_ticker) {
+        // the tickers of all ranks leave together: after the tick in which every rank has voted to stop
+        Ticker* t = g_ticker;
+        t->stop_vote.store(true, std::memory_order_release);
+        if (t->th.joinable()) t->th.join();
+        (void)hipStreamSynchronize(t->stream);
+        if (t->comm) (void)gc.p_destroy(t->comm);
+        (void)hipStreamDestroy(t->stream);
+        (void)hipHostFree(t->h_send);
+        (void)hipHostFree(t->h_recv);
+        (void)hipHostFree(t->h_done);
+        g_ticker = nullptr;
+        delete t;
+    }
     for (Ctx* l : gc.lanes) {
         {
             std::unique_lock<std::mutex> ll;
@@ -1243,6 +1358,7 @@ int gkrhip_comm_destroy(void) {
                 cx().lc.comm_stream = nullptr;
                 cx().lc.comm_ev = nullptr;
             }
+            cx().lc.tick_lane = -1;
             if (cx().lc.shm) {
                 cx().lc.shm->abort.store(1, std::memory_order_release);   // a peer still waiting here fails instead of hanging
                 munmap((void*)cx().lc.shm, cx().lc.shm_bytes);

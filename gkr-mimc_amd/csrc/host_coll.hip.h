@@ -173,6 +173,169 @@ int coll_publish(int nwords, unsigned int seq) {
     return 0;
 }
 
+// ---- the ticker: every lane's exchange through ONE communicator, ONE stream, ONE issuing thread ----------------------
+// Several proofs in flight per rank (lanes) each need a tiny all-reduce per sumcheck round, at times that differ from
+// lane to lane and from rank to rank.  One communicator per lane (round 1-2) makes each lane's collectives ordered, but
+// the collectives of DIFFERENT lanes are then issued in rank-dependent order from different host threads, and that is
+// only deadlock-free while every lane's stream sits on a hardware queue of its own (two collective kernels waiting for
+// their peers on one queue can block each other across ranks) -- an assumption about the runtime, not a property of the
+// code.  The ticker removes the assumption: a single thread per rank issues back-to-back "ticks" on a single
+// communicator and stream; a tick is ONE ncclAllReduce (ncclUint64, ncclSum) over the concatenation of every lane's slot,
+//     slot k = [ count | payload (kTickPayload words) ],
+// where a lane that has words to exchange contributes (1, words) and every other lane contributes zeros.  After the
+// tick every rank reads the same sums: count == world means lane k's exchange is complete on all ranks (the payload is
+// the sum); 0 < count < world means some ranks were not there yet -- the ranks that were simply contribute again in the
+// next tick.  Every rank takes the same decision from the same numbers, the order of collectives on the one communicator
+// is trivially identical everywhere, and lanes progress independently.  An all-gather is the all-reduce of a vector each
+// rank fills at its own offset.  A word of the header carries the votes to stop (gkrhip_comm_destroy): the tickers leave
+// together after the tick in which every rank voted.
+// The send/receive buffers are host-mapped (the all-reduce kernel reads and writes them over the fabric; 13 KB per
+// tick), so a lane's sums go kernel -> host (as un-sharded) -> tick -> host with no extra device copy; only the ticker
+// thread touches them, lanes hand their words over through per-lane staging areas.
+const int kTickPayload = 192;                 // words: 72/18/81 round sums, or world x (arity + 1) x 4 gathered words
+const int kTickStride = kTickPayload + 8;     // count + padding + payload
+const int kTickHeader = 8;                    // word 0: votes to stop
+const int kTickMaxLanes = 8;
+struct TickSlot {
+    std::atomic<int> state{0};                // 0 free, 1 posted by the lane, 2 result ready
+    int nwords = 0;
+    unsigned long long words[kTickPayload];
+};
+struct Ticker {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int nlanes = 0, world = 1;
+    unsigned long long *h_send = nullptr, *d_send = nullptr, *h_recv = nullptr, *d_recv = nullptr;
+    unsigned int *h_done = nullptr, *d_done = nullptr;
+    TickSlot slot[kTickMaxLanes];
+    bool in_flight[kTickMaxLanes] = {false};
+    std::thread th;
+    std::atomic<bool> stop_vote{false}, failed{false}, running{false};
+    std::atomic<unsigned long long> ticks{0}, idle_ticks{0};
+    std::string error;
+    std::mutex err_mu;
+};
+Ticker* g_ticker = nullptr;
+
+void ticker_fail(Ticker* t, const std::string& why) {
+    std::lock_guard<std::mutex> lk(t->err_mu);
+    if (!t->failed.load()) t->error = why;
+    t->failed.store(true, std::memory_order_release);
+}
+
+void ticker_main(Ticker* t, int device) {
+    if (hipSetDevice(device) != hipSuccess) {
+        ticker_fail(t, "ticker: hipSetDevice failed");
+        return;
+    }
+    const size_t total = kTickHeader + (size_t)t->nlanes * kTickStride;
+    unsigned int tick_id = 0;
+    int idle_run = 0;
+    while (!t->failed.load(std::memory_order_acquire)) {
+        // a tick goes out at once when a lane of this rank has words (or this rank wants to stop); an idle rank still
+        // joins -- its peers may have words -- after a short wait that grows while nothing happens anywhere
+        bool any = t->stop_vote.load(std::memory_order_acquire);
+        const double t_wait0 = now_ms();
+        const double max_wait_ms = idle_run < 64 ? 0.05 : (idle_run < 1024 ? 0.25 : 1.0);
+        for (;;) {
+            for (int k = 0; k < t->nlanes; k++) any = any || t->slot[k].state.load(std::memory_order_acquire) == 1;
+            if (any || now_ms() - t_wait0 > max_wait_ms) break;
+            __builtin_ia32_pause();
+        }
+        // assemble: nobody else touches h_send / h_recv, and no collective is in flight here
+        t->h_send[0] = t->stop_vote.load(std::memory_order_acquire) ? 1ull : 0ull;
+        for (int k = 0; k < t->nlanes; k++) {
+            unsigned long long* s = t->h_send + kTickHeader + (size_t)k * kTickStride;
+            if (t->slot[k].state.load(std::memory_order_acquire) == 1) {
+                if (!t->in_flight[k]) {
+                    s[0] = 1;
+                    memcpy(s + 8, t->slot[k].words, sizeof(unsigned long long) * t->slot[k].nwords);
+                    t->in_flight[k] = true;
+                }
+            } else if (s[0] != 0) {
+                memset(s, 0, sizeof(unsigned long long) * kTickStride);
+            }
+        }
+        __sync_synchronize();
+        ++tick_id;
+        ncclResult_t r = gc.p_allreduce(t->d_send, t->d_recv, total, ncclUint64, ncclSum, t->comm, t->stream);
+        if (r != ncclSuccess) {
+            ticker_fail(t, std::string("ticker: ncclAllReduce failed: ") + (gc.p_errstr ? gc.p_errstr(r) : "?"));
+            break;
+        }
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, t->stream, (const unsigned long long*)t->d_recv, t->d_recv, 0, t->d_done, tick_id);
+        {   // completion: the flag kernel is ordered behind the all-reduce on the ticker's stream
+            const double t0 = now_ms();
+            unsigned long spins = 0;
+            while (*(volatile unsigned int*)t->h_done != tick_id) {
+                __builtin_ia32_pause();
+                if ((++spins & 0x3fff) == 0) {
+                    hipError_t e = hipStreamQuery(t->stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) {
+                        ticker_fail(t, std::string("ticker: stream error: ") + hipGetErrorString(e));
+                        break;
+                    }
+                    if (now_ms() - t0 > coll_timeout_ms()) {
+                        ticker_fail(t, "ticker: a tick did not complete within the collective time-out (a peer rank is gone?)");
+                        break;
+                    }
+                }
+            }
+            if (t->failed.load()) break;
+            __sync_synchronize();
+        }
+        t->ticks.fetch_add(1, std::memory_order_relaxed);
+        bool progressed = false;
+        for (int k = 0; k < t->nlanes; k++) {
+            const unsigned long long* rv = t->h_recv + kTickHeader + (size_t)k * kTickStride;
+            if (rv[0] == (unsigned long long)t->world && t->in_flight[k]) {
+                memcpy(t->slot[k].words, rv + 8, sizeof(unsigned long long) * t->slot[k].nwords);
+                unsigned long long* s = t->h_send + kTickHeader + (size_t)k * kTickStride;
+                memset(s, 0, sizeof(unsigned long long) * kTickStride);
+                t->in_flight[k] = false;
+                t->slot[k].state.store(2, std::memory_order_release);
+                progressed = true;
+            } else if (rv[0] > (unsigned long long)t->world) {
+                ticker_fail(t, "ticker: a lane's count exceeds the world size (ranks disagree about the lanes)");
+            }
+            progressed = progressed || rv[0] != 0;
+        }
+        idle_run = progressed ? 0 : idle_run + 1;
+        if (!progressed) t->idle_ticks.fetch_add(1, std::memory_order_relaxed);
+        if (t->h_recv[0] == (unsigned long long)t->world) break;      // every rank voted to stop
+    }
+    t->running.store(false, std::memory_order_release);
+}
+
+// in-place sum over the ranks of n host words of the current lane, through the ticker
+int tick_allreduce(unsigned long long* words, int n) {
+    Ticker* t = g_ticker;
+    const int k = cx().lc.tick_lane;
+    if (!t || k < 0 || k >= t->nlanes) return fail("tick exchange: the lane has no ticker slot");
+    if (n > kTickPayload) return fail("tick exchange of %d words exceeds the slot (%d)", n, kTickPayload);
+    TickSlot& s = t->slot[k];
+    memcpy(s.words, words, sizeof(unsigned long long) * n);
+    s.nwords = n;
+    s.state.store(1, std::memory_order_release);
+    Waiter w;
+    const double t0 = now_ms();
+    unsigned long spins = 0;
+    while (s.state.load(std::memory_order_acquire) != 2) {
+        w.step();
+        if ((++spins & 0xfff) == 0) {
+            if (t->failed.load(std::memory_order_acquire)) {
+                std::lock_guard<std::mutex> lk(t->err_mu);
+                return fail("sharded prover: %s", t->error.c_str());
+            }
+            if (!t->running.load(std::memory_order_acquire)) return fail("sharded prover: the ticker has stopped (communicator destroyed)");
+            if (now_ms() - t0 > coll_timeout_ms()) return fail("sharded prover: timed out after %.0f s waiting for the other ranks (tick exchange)", coll_timeout_ms() * 1e-3);
+        }
+    }
+    memcpy(words, s.words, sizeof(unsigned long long) * n);
+    s.state.store(0, std::memory_order_release);
+    return 0;
+}
+
 // The same sum over ranks for words that are already on the host (the round kernel's host-mapped hand-off):
 // slot write, barrier, sum, barrier.  No device round trip at all.
 int shm_allreduce_host(unsigned long long* words, int n) {
@@ -197,6 +360,16 @@ int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
         return 0;
     }
     const size_t words = (size_t)v.world * cnt * 4;
+    if (cx().lc.tick_lane >= 0) {
+        // through the ticker: the all-reduce of a vector every rank fills at its own offset
+        if (words > (size_t)kTickPayload) return fail("tick all-gather of %d elements per rank exceeds the slot", cnt);
+        unsigned long long buf[kTickPayload];
+        memset(buf, 0, sizeof(unsigned long long) * words);
+        memcpy(buf + (size_t)v.rank * cnt * 4, mine, (size_t)cnt * 32);
+        CHK(tick_allreduce(buf, (int)words));
+        memcpy(out.data(), buf, words * 8);
+        return 0;
+    }
     if (cx().lc.shm && !cx().lc.comm) {
         // host transport: every rank writes its elements into its slot and reads the others' -- no device round trip
         if ((size_t)cnt * 4 > kShmSlotWords) return fail("shm all-gather of %d elements exceeds the slot", cnt);
@@ -267,7 +440,8 @@ int gather0(const DevTable* const* t, int ntab, E* out) {
 int partial_evals(const GateDesc& g, const DevTable* eq, const DevTable* const* x, size_t mid, const E& ark, E* evals,
                   int nev, bool collective) {
     int nblocks = 0;
-    const bool direct = !collective;      // un-sharded: the kernel hands the sums to the host itself
+    const bool tick = collective && cx().lc.tick_lane >= 0;
+    const bool direct = !collective || tick;      // un-sharded (or exchanged on the host through the ticker): the kernel hands the sums to the host itself
     const bool timed = 2 * mid >= cx().prof.min_n;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
@@ -298,7 +472,14 @@ int partial_evals(const GateDesc& g, const DevTable* eq, const DevTable* const* 
     const int nwords = nev * GKR_ACC_WORDS;
     if (direct) {
         CHK(wait_flag(cx().seq));
-        for (int t = 0; t < nev; t++) evals[t] = limbs9_to_fr(cx().h_round + (size_t)t * GKR_ACC_WORDS);
+        const unsigned long long* sums = cx().h_round;
+        unsigned long long summed[GKR_MAX_EVALS * GKR_ACC_WORDS];
+        if (tick) {
+            memcpy(summed, cx().h_round, sizeof(unsigned long long) * nwords);
+            CHK(tick_allreduce(summed, nwords));
+            sums = summed;
+        }
+        for (int t = 0; t < nev; t++) evals[t] = limbs9_to_fr(sums + (size_t)t * GKR_ACC_WORDS);
         return 0;
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(nwords), dim3(GKR_BLOCK), 0, cx().stream, cx().d_partials, cx().d_sums, nblocks, nwords);

@@ -75,6 +75,7 @@ struct LaneColl {
     // kernel then never queues for a workgroup slot behind the compute-bound rounds of the other lanes
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ev = nullptr;
+    int tick_lane = -1;                    // >= 0: this lane exchanges through the process's ticker (host_coll.hip.h), slot tick_lane
 };
 
 struct Ctx {
@@ -449,7 +450,7 @@ void lane_destroy(Ctx* l, bool pool = true) {
         g_lanes.erase(std::remove(g_lanes.begin(), g_lanes.end(), l), g_lanes.end());
     }
     UseLane u(l);
-    if (pool && !l->lc.comm && !l->lc.shm) {
+    if (pool && !l->lc.comm && !l->lc.shm && l->lc.tick_lane < 0) {
         (void)hipStreamSynchronize(l->stream);
         prof_clear(l->prof);
         std::lock_guard<std::mutex> lk(g_lane_pool_mu);

@@ -41,7 +41,11 @@ int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int 
         return wait_flag(seq, nullptr, coll_timeout_ms(), coll_stream());
     }
     CHK(wait_flag(seq));
-    if (collective && cx().lc.shm) {
+    if (collective && cx().lc.tick_lane >= 0) {          // RCCL through the ticker: one communicator for all lanes
+        memcpy(summed, cx().h_round, sizeof(unsigned long long) * nsum);
+        CHK(tick_allreduce(summed, nsum));
+        *sums = summed;
+    } else if (collective && cx().lc.shm) {
         memcpy(summed, cx().h_round, sizeof(unsigned long long) * nsum);
         CHK(shm_allreduce_host(summed, nsum));
         *sums = summed;

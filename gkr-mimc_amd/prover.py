@@ -76,6 +76,8 @@ ABI = {
     "gkrhip_comm_init_shm": (_I, [_I, _I, C.c_char_p]),
     "gkrhip_comm_init_lanes": (_I, [_I, _I, _I, _P]),
     "gkrhip_comm_init_shm_lanes": (_I, [_I, _I, _I, C.c_char_p]),
+    "gkrhip_comm_init_tick": (_I, [_I, _I, _I, _P]),
+    "gkrhip_comm_tick_stats": (_I, [C.POINTER(_U64), C.POINTER(_U64)]),
     "gkrhip_comm_destroy": (_I, []),
     "gkrhip_comm_info": (_I, [C.POINTER(_I), C.POINTER(_I)]),
     "gkrhip_host_shard_seed": (_I, [_P, _P, _I, _I]),
@@ -84,6 +86,7 @@ ABI = {
     "gkrhip_host_cipher_round_coeffs": (_I, [_P, _P, _P, _P]),
     "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_bench_sumcheck": (_I, [_I, _I, _I, _I, _I, C.POINTER(_D), _P]),
+    "gkrhip_bench_partial_eval": (_I, [_I, _I, _I, C.POINTER(_D), _P]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -505,6 +508,18 @@ def comm_init_shm_lanes(world, rank, nlanes, name):
     _check(load().gkrhip_comm_init_shm_lanes(world, rank, nlanes, name.encode()))
 
 
+def comm_init_tick(world, rank, nlanes, unique_id):
+    """nlanes lanes over ONE RCCL communicator (the ticker): deterministic order of collectives on every rank."""
+    uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+    _check(load().gkrhip_comm_init_tick(world, rank, nlanes, _ptr(uid)))
+
+
+def comm_tick_stats():
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _check(load().gkrhip_comm_tick_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def comm_destroy():
     _check(load().gkrhip_comm_destroy())
 
@@ -550,6 +565,14 @@ def bench_sumcheck(kind, bn, ninstance=1, warmup=1, iters=3):
     fin = np.zeros((1, 4), np.uint64)
     _check(load().gkrhip_bench_sumcheck(kind, bn, ninstance, warmup, iters, C.byref(ms), _ptr(fin)))
     return ms.value, fin
+
+
+def bench_partial_eval(bn, warmup=10, iters=200):
+    """BenchmarkPartialEvalWithCipher's shape: (microseconds per dispatchPartialEvals, evals[0] as a (1, 4) array)."""
+    us = C.c_double(0)
+    e0 = np.zeros((1, 4), dtype=np.uint64)
+    _check(load().gkrhip_bench_partial_eval(bn, warmup, iters, C.byref(us), _ptr(e0)))
+    return us.value, e0
 
 
 def profile_reset(min_n):

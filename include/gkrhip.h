@@ -223,6 +223,13 @@ int gkrhip_comm_init_shm(int world, int rank, const char *name);
  * big rounds. */
 int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t *unique_ids /* nlanes x 128 */);
 int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char *name);
+/* Several lanes over ONE RCCL communicator ("ticker"): a single thread per rank issues back-to-back all-reduces over
+ * the concatenation of every lane's slot on one communicator and stream, so the order of collectives is the same on
+ * every rank by construction whatever order the lanes' proofs reach their rounds in (no assumption about hardware
+ * queues; DESIGN.md section 6 has the argument).  A lane's exchange completes in the first tick in which every rank
+ * contributed to its slot.  This is the multi-lane RCCL transport of bench.py. */
+int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t unique_id[128]);
+int gkrhip_comm_tick_stats(uint64_t *ticks, uint64_t *idle_ticks);
 int gkrhip_comm_destroy(void);
 int gkrhip_comm_info(int *world, int *rank);
 
@@ -248,6 +255,11 @@ int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double *avg_ms,
  * built outside the timer; *avg_ms = wall-clock per Prove (Fiat-Shamir hashing included); final_claim0 (may be NULL)
  * receives finalClaims[0] of the last run. */
 int gkrhip_bench_sumcheck(int kind, int bn, int ninstance, int warmup, int iters, double *avg_ms, uint64_t final_claim0[4]);
+/* BenchmarkPartialEvalWithCipher's shape (sumcheck/prover_test.go:127-147): the instance of
+ * InitializeCipherGateInstance(bn) with its Eq table built once, then `iters` x dispatchPartialEvals of round 0 (nine
+ * evaluations over 2^(bn-1) pairs, reference-shaped evaluator), sums handed to the host every call.  *us_per_call = wall
+ * clock per dispatch; evals0 (may be NULL) = evals[0] of the last call. */
+int gkrhip_bench_partial_eval(int bn, int warmup, int iters, double *us_per_call, uint64_t evals0[4]);
 /* Per-kernel accounting of the calling process since the last reset: HIP-event time of every fold
  * launch whose input table has >= min_n elements. */
 int gkrhip_profile_reset(size_t min_n);

@@ -42,8 +42,13 @@ def usable_cpus():
 
 
 def _load():
-    if not os.path.exists(_SO):
+    # make is a no-op when the library is current; a stale one (sources changed, .so git-ignored) is rebuilt.  On a box
+    # without make/gcc the prebuilt library that travelled with the tree is used as it is.
+    try:
         build()
+    except Exception:
+        if not os.path.exists(_SO):
+            raise
     # libgomp reads these when it is first loaded: sleep instead of spinning at barriers
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     os.environ.setdefault("OMP_PROC_BIND", "false")
@@ -52,6 +57,8 @@ def _load():
     sig = {
         "oracle_fr_from_u64": (None, [P, C.c_uint64]),
         "oracle_fr_mul": (None, [P, P, P]),
+        "oracle_fr_mul_generic": (None, [P, P, P]),
+        "oracle_bench_fr_mul": (None, [C.c_long, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "oracle_fr_add": (None, [P, P, P]),
         "oracle_fr_sub": (None, [P, P, P]),
         "oracle_fr_inverse": (None, [P, P]),
@@ -91,6 +98,13 @@ def _load():
 
 lib = _load()
 lib.oracle_set_num_threads(int(os.environ.get("GKR_ORACLE_THREADS", min(usable_cpus(), 64))))
+
+
+def bench_fr_mul(n=2_000_000, generic=False):
+    """(ns per dependent multiplication, ns per independent multiplication) on one core."""
+    a, b = C.c_double(0), C.c_double(0)
+    lib.oracle_bench_fr_mul(n, 1 if generic else 0, C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def fr(n=1):

@@ -43,6 +43,8 @@ typedef struct {
 
 /* fr helpers */
 void oracle_fr_from_u64(ofr_t *out, uint64_t v);                 /* fr.Element.SetUint64 */
+void oracle_fr_mul_generic(ofr_t *o, const ofr_t *a, const ofr_t *b);
+void oracle_bench_fr_mul(long n, int generic, double *ns_dependent, double *ns_independent);
 void oracle_fr_mul(ofr_t *out, const ofr_t *a, const ofr_t *b);
 void oracle_fr_add(ofr_t *out, const ofr_t *a, const ofr_t *b);
 void oracle_fr_sub(ofr_t *out, const ofr_t *a, const ofr_t *b);

@@ -146,6 +146,8 @@ def main():
     nlanes = int(os.environ.get("GKR_TEST_LANES", "1"))
     if mode == "shm":
         gk.comm_init_shm_lanes(world, rank, nlanes, name)
+    elif mode == "tick":       # all lanes over one RCCL communicator (1-rank communicator: every exchange is a real ncclAllReduce)
+        gk.comm_init_tick(1, 0, nlanes, gk.comm_unique_id())
     else:
         gk.comm_init_lanes(1, 0, np.stack([gk.comm_unique_id() for _ in range(nlanes)]))
     if os.environ.get("GKR_TEST_DIE") == str(rank):

@@ -60,6 +60,18 @@ def test_sharded_prover_concurrent_lanes():
     _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
 
 
+def test_rccl_ticker_world1_forced():
+    """The multi-lane RCCL transport (one communicator, one issuing thread, batched ticks) with every round forced through
+    it at world = 1: one lane and eight lanes in flight, MiMC and GMiMC (cipher, linear and multi-claim layers, the
+    per-layer gather), against the oracle."""
+    env = {"GKRHIP_FORCE_COLLECTIVE": "1"}
+    _run_shards("tick", 1, "2,3,9,12", env)
+    _run_shards("tick", 1, "4,9,11", dict(env, GKR_TEST_LANES="8"))
+    _run_shards("tick", 1, "3,9", dict(env, GKR_TEST_CIRCUIT="gmimc"))
+    _run_shards("tick", 1, "5,10", dict(env, GKRHIP_GENERIC="1", GKR_TEST_LANES="2"))
+    _run_shards("tick", 1, "20", dict(env, GKR_TEST_DIGEST="1"))
+
+
 def test_sharded_prover_full_size_digests():
     """BASELINE config 3's size through the sharded driver: 8 ranks time-sharing the GPU (2^21-entry shards, the
     per-round exchange over shared memory) at bN = 24, and 2 ranks at bN = 22; the transcript must be the one the C
