@@ -6,13 +6,17 @@ beside it.
 
     python bench.py --gpus N --steps K --warmup W [--bn B] [--weak] [--exchange rccl|shm]
 
-N = 1: one process, GPU 0, bN = 24 (BASELINE config 3, the size the metric is quoted on).
+N = 1: one process, GPU 0, bN = 24 (BASELINE config 3, the size the metric is quoted on); the line also carries BASELINE
+configs 2 (bN = 20) and 5 (GMiMC, bN = 22) under "configs" and the reference-shaped micro-benchmarks under "micro".
 N > 1: launched by torch.distributed.run, one rank per GPU; ONE proof of 2^26 hashes (BASELINE config 4 at
 N = 8: a 2^23-entry shard per GPU) sharded on the low index bits, the per-round sum of the round-polynomial
-words all-reduced with RCCL (north_star's transport); on one node the same K steps run FIRST over the host
-shared-memory exchange and are reported beside the RCCL figure -- and should the RCCL pass fail or stall (it has never run
-on more than one GPU), the line is still printed, from the shared-memory pass, saying so.  --weak keeps 2^bn entries per
-GPU instead (total 2^(bn + log2 N)).
+words all-reduced with RCCL (north_star's transport).  The rank processes the launcher starts never touch the GPU: each
+runs the K steps as a sequence of PASSES, every pass in a fresh child process (own rendezvous port), so that a pass that
+fails or stalls is killed and the next one still runs: (1) host shared-memory exchange (one node), (2) RCCL with ONE
+lane (one communicator: no ordering question), (3) RCCL with several lanes through the ticker (one communicator, one
+issuing thread), (4) RCCL with one communicator per lane.  `value` is the best RCCL pass; every pass is in the line
+("passes").  If no RCCL pass succeeds the line is still printed, from the shared-memory pass, marked "degraded":
+"rccl_failed" with n_gpus_rccl = 0, and bench.py exits with code 3.  --weak keeps 2^bn entries per GPU instead.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -38,6 +42,9 @@ def cpu_baseline(target_seconds=40.0):
     """Time the CPU oracle (C restatement, OpenMP over the host cores) on a bounded sample of the same
     workload: gkr.Prove of 2^b MiMC hashes with RandomFrArray inputs; b grows until a run takes
     >= target_seconds/4 (each +1 doubles the work)."""
+    # the OpenMP workers spin between the ~10^4 short parallel regions of a proof instead of sleeping (read when the
+    # runtime is first loaded; the tests keep the passive policy because they oversubscribe the cores)
+    os.environ["OMP_WAIT_POLICY"] = "ACTIVE"
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import coracle
     # BASELINE config 1: bN = 10, the size of the reference's own CPU test path (gkr/gkr_test.go)
@@ -58,12 +65,20 @@ def cpu_baseline(target_seconds=40.0):
     b, secs = best
     cores = coracle.lib.oracle_num_threads()
     muls = 4555.0 * (1 << b)          # field multiplications of gkr.Prove per hash (SURVEY 8a totals)
+    dep, ind = coracle.bench_fr_mul(4_000_000)
+    dep_g, ind_g = coracle.bench_fr_mul(4_000_000, generic=True)
     return {"value": (1 << b) / secs, "unit": "MiMC hashes GKR-proved/s", "cores": cores,
             "kind": "port", "ns_per_field_mul_per_core": secs * cores / muls * 1e9,
+            "fr_mul_isolated_ns": {"nocarry_unrolled": {"dependent": dep, "independent": ind},
+                                   "generic_looped_round2": {"dependent": dep_g, "independent": ind_g},
+                                   "note": "oracle_bench_fr_mul on one core of this host: the port's fr.Element.Mul alone (a chain of "
+                                           "dependent products / eight independent chains); gnark-crypto's amd64 assembly is ~20-30 ns"},
             "config1_bn10": {"seconds": secs10, "hashes_per_s": (1 << 10) / secs10},
-            "sample": "gkr.Prove of 2^%d hashes (RandomFrArray inputs), %.2f s, C restatement of the reference "
-                      "algorithm built with -O3 -march=x86-64-v3 -madx (portable unsigned __int128 CIOS product; not the Go "
-                      "binary, whose gnark-crypto amd64 assembly is ~1.5-2x faster per multiplication)" % (b, secs)}
+            "sample": "gkr.Prove of 2^%d hashes (RandomFrArray inputs), %.2f s, C restatement of the reference algorithm (its "
+                      "sub-chunk structure, 45 Mul + 51 Add per index pair and round, the serial Fiat-Shamir chain) built with "
+                      "ROCm clang -O3 -march=x86-64-v3 -madx + libomp, spinning workers; ns_per_field_mul_per_core is the whole "
+                      "prover's time per multiplication (additions, memory passes and the serial hashing included), not the "
+                      "multiplication alone; not the Go binary" % (b, secs)}
 
 
 def random_fr_array_np(n):
@@ -165,7 +180,7 @@ class Job:
         self.sessions = []
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -177,24 +192,117 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the sumcheck / fold micro-benchmarks (SURVEY 8d)")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the PCIe-inclusive one-shot calls from host buffers")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2 (bN = 20) and 5 (GMiMC bN = 22)")
     ap.add_argument("--circuit", choices=["mimc", "gmimc"], default="mimc",
                     help="mimc: examples.MimcCircuit (the headline metric); gmimc: the build-defined GMiMC t=2 circuit "
                          "(BASELINE config 5, quoted at --bn 22)")
     ap.add_argument("--concurrent", type=int, default=5,
-                    help="independent proofs in flight (each on its own resident session/lane/stream and, when "
-                         "sharded, its own communicator); 1 = strictly one proof at a time")
+                    help="independent proofs in flight (each on its own resident session/lane/stream); 1 = strictly one "
+                         "proof at a time")
     ap.add_argument("--exchange", choices=["rccl", "shm", "auto"], default="rccl",
-                    help="transport of the per-round 576-byte sum of the sharded prover: rccl = ncclAllReduce over xGMI on "
-                         "the lane's stream (the headline transport); shm = the ranks add the words on the host through "
-                         "POSIX shared memory (one node only); auto = rccl")
-    ap.add_argument("--no-shm-beside", action="store_true",
-                    help="N > 1 on one node: do not repeat the timed steps over the shared-memory exchange")
+                    help="N > 1: rccl = the RCCL passes after the shared-memory pass (the headline is the best RCCL pass); "
+                         "shm = only the host shared-memory exchange (one node)")
+    ap.add_argument("--passes", default=None,
+                    help="N > 1: comma-separated passes to run instead of the default sequence "
+                         "(shm, rccl_one_lane, rccl_tick, rccl_lanes)")
+    ap.add_argument("--pass", dest="pass_name", default=None, help=argparse.SUPPRESS)    # one pass of an N > 1 run (child process)
     ap.add_argument("--device", type=int, default=None,
-                    help="GPU ordinal of this rank (default LOCAL_RANK); several ranks on ONE GPU with --exchange shm is how "
-                         "the multi-rank control flow is exercised on a single-GPU box")
+                    help="GPU ordinal of this rank (default LOCAL_RANK); several ranks on ONE GPU is how the multi-rank "
+                         "control flow is exercised on a single-GPU box (only the shared-memory pass can succeed there)")
     ap.add_argument("--mem-fraction", type=float, default=0.85,
                     help="share of the free HBM the resident sessions may take (caps --concurrent)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+DEFAULT_PASSES = ["shm", "rccl_one_lane", "rccl_tick", "rccl_lanes"]
+PASS_TRANSPORT = {
+    "shm": "host shared memory (one node): the ranks add the 576-byte round sums on the host",
+    "rccl_one_lane": "RCCL ncclAllReduce (ncclUint64, ncclSum) over xGMI on the lane's stream, ONE lane (one communicator)",
+    "rccl_tick": "RCCL ncclAllReduce over xGMI, all lanes through the ticker (one communicator, one issuing thread, batched ticks)",
+    "rccl_lanes": "RCCL ncclAllReduce over xGMI, one communicator and stream per lane (GPU_MAX_HW_QUEUES = 8)",
+}
+
+
+def orchestrate(args):
+    """The rank process torch.distributed.run started, for N > 1: runs the passes as child processes (this process never
+    touches the GPU), rank 0 assembles the line.  Exit code 0: an RCCL pass produced the headline; 3: none did."""
+    import subprocess
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    one_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
+    if args.passes:
+        passes = [p for p in args.passes.split(",") if p]
+    elif args.exchange == "shm":
+        passes = ["shm"]
+    else:
+        passes = [p for p in DEFAULT_PASSES if p != "shm" or one_node]
+    limit_s = float(os.environ.get("GKRHIP_BENCH_PASS_LIMIT_S", "0")) or (240.0 + 3.0 * (args.steps + args.warmup))
+    results = {}
+    argv = [a for a in sys.argv[1:]]
+    for i, name in enumerate(passes):
+        env = dict(os.environ, MASTER_PORT=str(base_port + 1 + i), GKRHIP_COLL_TIMEOUT_S=os.environ.get("GKRHIP_COLL_TIMEOUT_S", "60"))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the children rendezvous on a store of their own (rank 0's child hosts it)
+        if name == "rccl_lanes":
+            # one hardware queue per lane stream (ROCclr's default is 4 queues for all streams): the collective kernels of
+            # different lanes must be able to run side by side, whatever order the ranks issue them in
+            env.setdefault("GPU_MAX_HW_QUEUES", "8")
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--pass", name]
+        t0 = time.time()
+        try:
+            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit_s)
+            out, rc = cp.stdout.decode(errors="replace"), cp.returncode
+        except subprocess.TimeoutExpired as e:
+            out, rc = (e.stdout or b"").decode(errors="replace"), None       # the child (and its spinning kernels) was killed
+        res = None
+        for line in out.strip().splitlines()[::-1]:
+            try:
+                res = json.loads(line)
+                break
+            except Exception:
+                continue
+        if rc == 0 and (res is not None or rank != 0):
+            results[name] = res or {}
+        else:
+            why = ("did not finish within %.0f s (killed)" % limit_s) if rc is None else \
+                  ((res or {}).get("error") or "exit code %s" % rc)
+            results[name] = {"error": why, "seconds": time.time() - t0}
+            print("bench.py: pass %s failed on rank %d: %s" % (name, rank, why), file=sys.stderr)
+    ok_rccl = [n for n in passes if n.startswith("rccl") and "error" not in results[n]]
+    code = 0 if (ok_rccl or args.exchange == "shm" or not any(n.startswith("rccl") for n in passes)) else 3
+    if rank == 0:
+        summary = {}
+        for n in passes:
+            r = results[n]
+            summary[n] = ({"error": r["error"]} if "error" in r else
+                          {k: r[k] for k in ("value", "ms_per_step", "concurrent_proofs", "single_proof_latency_ms", "transport",
+                                              "proof_verified_by_native_gkr_verify", "tick_stats") if k in r})
+        head_name = max(ok_rccl, key=lambda n: results[n]["value"]) if ok_rccl else \
+            ("shm" if "shm" in results and "error" not in results["shm"] else None)
+        if head_name is None:
+            line = {"metric": "MiMC hashes GKR-proved/sec", "value": None, "unit": "hashes/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+                    "vs_baseline": None, "dtype": "u32x8 (BN254-Fr Montgomery, 256-bit integer)", "data": "synthetic",
+                    "config": {"workload": "no pass succeeded"}, "degraded": "all_passes_failed", "n_gpus_rccl": 0,
+                    "passes": summary, "roofline": None, "cpu_baseline": None}
+            code = 3
+        else:
+            line = dict(results[head_name]["line"])
+            line["passes"] = summary
+            line["headline_pass"] = head_name
+            line["value_transport"] = "rccl" if head_name.startswith("rccl") else "shm"
+            line["n_gpus_rccl"] = world if head_name.startswith("rccl") else 0
+            if not head_name.startswith("rccl") and any(n.startswith("rccl") for n in passes):
+                line["degraded"] = "rccl_failed"        # the headline is NOT an RCCL measurement; bench.py exits with code 3
+            if "shm" in summary and head_name != "shm" and "error" not in results["shm"]:
+                line["config"]["shm_exchange_beside"] = summary["shm"]
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+    return code
+
+
+def main():
+    args = parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started by hand without a launcher: start the ranks as children (one process per GPU, rendezvous on 127.0.0.1) and
@@ -207,6 +315,9 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.pass_name:
+        raise SystemExit(orchestrate(args))
 
     # stdout carries the ONE JSON line and nothing else: whatever libraries print there (gloo's connection notes, RCCL's
     # version banner) goes to stderr
@@ -221,23 +332,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if args.gpus > 1 or world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
+    if args.pass_name or world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
         # torch.distributed carries only the bootstrap (128-byte communicator ids), the barriers and the max-over-ranks
         # of the timing -- over gloo, so that the only RCCL in the process is the one libgkrhip dlopen()s and torch
         # never initialises the GPU
+        import datetime
         import torch
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo")
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
         world = dist.get_world_size()
         rank = dist.get_rank()
     multi = dist is not None and world > 1
-    if multi and args.exchange != "shm":
-        # one hardware queue per lane stream (ROCclr's default is 4 queues for all streams): the collective kernels of
-        # different lanes must be able to run side by side, whatever order the ranks issue them in
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    pass_name = args.pass_name or ("shm" if args.exchange == "shm" else "rccl_one_lane") if multi else None
 
     gk = importlib.import_module("gkr-mimc_amd")
-    gk.init(local_rank if args.device is None else args.device)
+    try:
+        gk.init(local_rank if args.device is None else args.device)
+    except Exception as e:      # noqa: BLE001
+        if args.pass_name and rank == 0:
+            emit({"error": "gkrhip_init: %s" % e})
+        raise
 
     import numpy as np
     gamma = world.bit_length() - 1 if dist is not None else 0
@@ -252,58 +366,53 @@ def main():
     bn_gpu = bn - gamma
     # every proof in flight keeps its own resident assignment (93 tables of 2^bn_gpu elements) plus scratch
     free_b, _total_b = gk.mem_info()
-    per_session = (94.25 if args.circuit == "mimc" else 104) * 32 * (1 << bn_gpu)   # tables + two half-size scratch tables + pyramids
-    if args.device is not None and dist is not None:
-        free_b //= world                              # the ranks share one GPU
-    nconc = max(1, min(args.concurrent, args.steps, int(args.mem_fraction * free_b // per_session)))
+
+    def lanes_that_fit(circuit, bn_local, want, steps):
+        per_session = (94.25 if circuit == "mimc" else 104) * 32 * (1 << bn_local)   # tables + two half-size scratch tables + pyramids
+        fb = free_b // world if (args.device is not None and dist is not None) else free_b     # the ranks share one GPU
+        n = max(1, min(want, steps, int(args.mem_fraction * fb // per_session)))
+        if n > 1 and steps % n and steps % (n - 1) == 0:
+            n -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
+        return n
+
+    nconc = lanes_that_fit(args.circuit, bn_gpu, args.concurrent, args.steps)
     if multi:
-        nconc = min(nconc, 8)                         # one communicator per lane, at most 8
-    if nconc > 1 and args.steps % nconc and args.steps % (nconc - 1) == 0:
-        nconc -= 1                                    # K steps deal evenly to one lane fewer: no straggler lane
+        nconc = 1 if pass_name == "rccl_one_lane" else min(nconc, 8)     # at most 8 lanes per rank
     if dist is not None:
         t = torch.tensor([nconc], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)     # same number of lanes on every rank
         nconc = int(t.item())
     layers = gk.gmimc_t2_circuit() if args.circuit == "gmimc" else None
-    one_node = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world
 
-    def install(transport_kind):
-        """Install the library's communicators, one per lane (the per-round all-reduce of the limb-split sums lives
-        inside the C++ round loop).  Returns a description of the transport actually installed."""
+    def install(kind):
+        """Install the library's transport for this pass (the per-round exchange lives inside the C++ round loop)."""
         tag = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
         dist.broadcast_object_list(tag, src=0)        # a name no earlier run can have left behind
-        shm_name = "/gkrhip_bench_%s" % tag[0]
-        if transport_kind == "shm":
-            gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
-            return "host shared memory (one node)"
+        if kind == "shm":
+            gk.comm_init_shm_lanes(world, rank, nconc, "/gkrhip_bench_%s" % tag[0])
+            return
+        nids = nconc if kind == "rccl_lanes" else 1
         err = ""
         try:
-            box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nconc)) if rank == 0 else None]
+            box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nids)) if rank == 0 else None]
         except Exception as e:      # noqa: BLE001 -- reported below, never silent
             box, err = [None], str(e)
         dist.broadcast_object_list(box, src=0)
         ok = 0
         if box[0] is not None:
             try:
-                gk.comm_init_lanes(world, rank, np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nconc, 128))
+                ids = np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nids, 128)
+                if kind == "rccl_tick":
+                    gk.comm_init_tick(world, rank, nconc, ids[0])
+                else:
+                    gk.comm_init_lanes(world, rank, ids)
                 ok = 1
             except Exception as e:  # noqa: BLE001
                 err = str(e)
         t = torch.tensor([ok], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 1:
-            return "RCCL ncclAllReduce (ncclUint64, ncclSum) over xGMI, one communicator per lane"
-        if not one_node:
-            raise SystemExit("bench.py: RCCL communicator init failed (%s) and the ranks span several nodes" % err)
-        # RCCL communicators could not be created on some rank: the same call sites run over the library's
-        # host shared-memory transport (single node only) and the JSON line says so
-        gk.comm_destroy()
-        dist.barrier()
-        gk.comm_init_shm_lanes(world, rank, nconc, shm_name)
-        msg = "host shared memory (RCCL communicator init failed: %s)" % (err or "on another rank")
-        if rank == 0:
-            print("bench.py: " + msg, file=sys.stderr)
-        return msg
+        if int(t.item()) != 1:
+            raise RuntimeError("RCCL communicator init failed (%s)" % (err or "on another rank"))
 
     def sync_all():
         gk.synchronize()
@@ -322,24 +431,31 @@ def main():
             dt = float(t.item())
         return dt
 
-    def run_phase(kind):
-        """Sessions, warm-up, one proof alone (latency), the K timed steps, the native verifier -- over one transport
-        (None: a single GPU).  Returns what the JSON line is assembled from; the job stays open."""
-        ph = {"transport": install(kind) if dist is not None else None}
-        job = Job(gk, bn, nconc, layers)
-        ph["job"] = job
-        job.run_steps(max(args.warmup, 1 if nconc > 1 and args.warmup else 0))
+    def run_phase(job, bn_local, warmup, steps, dev):
+        """Warm-up, one proof alone (latency), the K timed steps, the native verifier.  The job stays open."""
+        ph = {}
+        job.run_steps(max(warmup, 1 if job.nconc > 1 and warmup else 0))
         # single-proof latency (one proof alone on the GPU), reported beside the throughput figure
-        gk.profile_reset(1 << bn_gpu)
+        gk.profile_reset(1 << bn_local)
         sync_all()
         tl = time.perf_counter()
         job.last[0] = job.sessions[0].prove(job.qprime)
         sync_all()
         ph["latency_ms"] = 1e3 * (time.perf_counter() - tl)
         ph["solo"] = gk.profile_get()          # the same launches with no other proof in flight
-        gk.profile_reset(1 << bn_gpu)          # HIP-event accounting of the round-0 fold / partial-eval launches
-        with ClockSampler(local_rank if args.device is None else args.device) as clk:
-            ph["dt"] = timed(job, args.steps)
+        # once more alone with the look-ahead off: round 0 as the ONE fused launch the proofs in flight run (all ten
+        # products and the seven multiply-accumulates) -- the VALU-bound kernel the issue ceilings are quoted for
+        ph["solo_fused"] = None
+        if ph["solo"]["lookahead_round0"] and not multi:
+            gk.set_option("lookahead", 0)
+            gk.profile_reset(1 << bn_local)
+            job.sessions[0].prove(job.qprime)
+            sync_all()
+            ph["solo_fused"] = gk.profile_get()
+            gk.set_option("lookahead", 1)
+        gk.profile_reset(1 << bn_local)        # HIP-event accounting of the round-0 fold / partial-eval launches
+        with ClockSampler(dev) as clk:
+            ph["dt"] = timed(job, steps)
         ph["clk"] = clk
         ph["flat"] = job.last[0]
         ph["prof"] = gk.profile_get()
@@ -348,68 +464,22 @@ def main():
         ph["verified"] = bool(job.sessions[0].verify(job.qprime, ph["flat"]))
         return ph
 
-    # N > 1 on one node with the RCCL headline: the SAME K steps run first over the host shared-memory exchange (the
-    # transport every multi-rank test of this repository exercises), then over RCCL.  Should the RCCL pass fail or stall
-    # (no multi-GPU box was available to the build), the line still appears: measured over the host exchange, saying so.
-    shm_first = multi and one_node and args.exchange != "shm" and not args.no_shm_beside
-    beside = None
-    rccl_error = None
-    if shm_first:
-        beside = run_phase("shm")
-        beside["job"].close()
-        gk.comm_destroy()
-        dist.barrier()
-    watchdog = None
-    emitted = threading.Event()
-    if beside is not None:
-        limit_s = float(os.environ.get("GKRHIP_BENCH_RCCL_LIMIT_S", "0")) or (120.0 + 20.0 * beside["dt"] * (1 + args.warmup / max(args.steps, 1)))
-
-        def give_up():
-            if emitted.is_set():
-                return
-            if rank == 0:
-                emit(fallback_line("the RCCL pass did not finish within %.0f s" % limit_s))
-            os._exit(0)           # collective kernels may still be spinning on the device: no orderly teardown
-
-        watchdog = threading.Timer(limit_s, give_up)
-        watchdog.daemon = True
-
-    def fallback_line(why):
-        """The JSON line from the shared-memory pass alone (the RCCL pass failed or stalled)."""
-        o = {"metric": ("MiMC hashes GKR-proved/sec at bN=%d" if args.circuit == "mimc" else
-                        "GMiMC(t=2) compressions GKR-proved/sec at bN=%d") % bn, "value": float(1 << bn) * args.steps / beside["dt"],
-             "unit": "hashes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-             "ms_per_step": 1e3 * beside["dt"] / args.steps, "higher_is_better": True,
-             "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-             "dtype": "u32x8 (BN254-Fr Montgomery, 256-bit integer)", "data": "synthetic",
-             "config": {"workload": "gkr.Prove(MimcCircuit): ONE proof of 2^%d hashes (bN_total = %d), hypercube sharded on its "
-                                    "low index bits over %d GPU(s) (2^%d-entry shard per GPU), inputs RandomFrArray, assignment "
-                                    "resident in HBM; per-round exchange: %s" % (bn, bn, world, bn_gpu, beside["transport"]),
-                        "bN": bn, "bN_total": bn, "bN_per_gpu": bn_gpu, "concurrent_proofs": nconc,
-                        "single_proof_latency_ms": beside["latency_ms"],
-                        "proof_verified_by_native_gkr_verify": beside["verified"],
-                        "per_round_exchange": beside["transport"] + " (RCCL pass: " + why + ")"},
-             "single_proof_latency_ms": beside["latency_ms"], "roofline": None, "cpu_baseline": None}
-        return o
-
+    dev = local_rank if args.device is None else args.device
     try:
-        if watchdog is not None:
-            watchdog.start()
-        head = run_phase(None if dist is None else ("shm" if args.exchange == "shm" else "rccl"))
-    except Exception as e:      # noqa: BLE001 -- reported in the line
-        if beside is None:
-            raise
-        rccl_error = str(e)
-        emitted.set()
-        if rank == 0:
-            emit(fallback_line(rccl_error))
-        os._exit(0)
-    finally:
-        if watchdog is not None:
-            watchdog.cancel()
-    emitted.set()
-    transport, job, dt, latency_ms = head["transport"], head["job"], head["dt"], head["latency_ms"]
+        if multi:
+            install(pass_name)
+        job = Job(gk, bn, nconc, layers)
+        head = run_phase(job, bn_gpu, args.warmup, args.steps, dev)
+    except Exception as e:      # noqa: BLE001 -- a pass reports its failure to the orchestrator and exits non-zero
+        if args.pass_name:
+            if rank == 0:
+                emit({"error": str(e)})
+            print("bench.py: pass %s failed on rank %d: %s" % (pass_name, rank, e), file=sys.stderr)
+            os._exit(4)           # collective kernels may still be spinning on the device: no orderly teardown
+        raise
+    dt, latency_ms = head["dt"], head["latency_ms"]
     solo, prof, clk, flat, verified = head["solo"], head["prof"], head["clk"], head["flat"], head["verified"]
+    transport = PASS_TRANSPORT[pass_name] if multi else None
 
     hashes = float(1 << bn) * args.steps
     n_gpus = world if dist is not None else 1
@@ -438,14 +508,19 @@ def main():
         "single_proof_latency_ms": latency_ms,
     }
     if dist is not None:
-        out["config"]["per_round_exchange"] = transport + ": all-reduce of 72 limb-split u64 lanes per sumcheck round"
+        out["config"]["per_round_exchange"] = (transport or "") + ": all-reduce of 72 limb-split u64 lanes per sumcheck round"
         out["config"]["bootstrap"] = "torch.distributed gloo (ids, barriers, max-over-ranks of the timing); the only RCCL in the process is the one libgkrhip dlopen()s"
     if solo.get("rounds"):
         out["single_proof"] = {"latency_ms": latency_ms, "hashes_per_s": float(1 << bn) / (latency_ms * 1e-3),
                                "rounds": solo["rounds"], "host_hash_ms": solo["host_hash_ms"], "host_wait_ms": solo["host_wait_ms"],
                                "host_launch_ms": solo["host_launch_ms"], "host_other_ms": solo["host_other_ms"],
+                               "prelaunched_rounds": solo["prelaunched_rounds"], "lookahead_round0": solo["lookahead_round0"],
+                               "coop_rounds": solo["coop_rounds"],
                                "note": "one gkr.Prove alone on the GPU (BenchmarkGkr's shape): the serial chain of rounds -- "
-                                       "Fiat-Shamir hash on the host, then the next round kernel -- is not overlapped with anything; "
+                                       "Fiat-Shamir hash on the host, then the next round kernel.  Round 3: the next round's kernel "
+                                       "is queued before the hash and polls a host-mapped challenge slot (prelaunched_rounds), the "
+                                       "q-independent products of the next layer's round 0 are computed during this layer's small "
+                                       "rounds (lookahead_round0), small rounds run eight lanes per pair (coop_rounds); "
                                        "host_wait_ms is the time the host waited for round kernels (their GPU time plus hand-off latency)"}
 
     build_info = importlib.import_module("gkr-mimc_amd.build").read_info() or {}
@@ -457,12 +532,14 @@ def main():
         ms_b2b, ms1 = gk.bench_fold(1 << bn_gpu, ntab=1, warmup=3, iters=iters, isolated=True)
         bytes1 = 96.0 * (1 << (bn_gpu - 1))
         traffic = None
-        try:   # PMC pass of the same launches (tools/pmc_bench.sh), committed under profiles/
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fold_traffic.json")))
-            if pm.get("bn") == bn_gpu:
-                traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        for name in ("r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # PMC pass of the same launches (tools/pmc_bench.sh)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if pm.get("bn") == bn_gpu:
+                    traffic = pm["traffic_bytes_per_launch"]
+                    break
+            except Exception:
+                pass
         ach = bytes1 / (ms_b2b * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_fold<1> on a 2^%d-element table (2^%d outputs)" % (bn_gpu, bn_gpu - 1),
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -470,8 +547,8 @@ def main():
                            "algorithmic_bytes_per_launch": bytes1,
                            "measured": "HIP events on the launching stream around %d launches queued back to back, nothing else "
                                        "running (gkrhip_bench_fold): wall time / %d.  rocprofv3's per-kernel average for the "
-                                       "full-size launches agrees within 3 %% (profiles/r02_v6_solo_fold_launches_by_size.csv: "
-                                       "127.6 us over 54 launches); 96 B per output element (SURVEY 8d)" % (iters, iters),
+                                       "full-size launches agrees within 3 %% (profiles/: fold launches by size); 96 B per output "
+                                       "element (SURVEY 8d)" % (iters, iters),
                            "one_at_a_time": {"avg_launch_ms": ms1, "achieved": bytes1 / (ms1 * 1e-3) / 1e9,
                                              "frac": bytes1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "measured": "the same %d launches one at a time on an idle GPU, one event pair each: "
@@ -493,57 +570,114 @@ def main():
                 "measured": "same launches inside the K timed steps with %d proofs in flight: the launch duration includes "
                             "waiting for CU slots held by the other lanes' VALU-bound kernels" % nconc}
     loops = build_info.get("round_kernel_loops", {})
-    if solo["peval_launches"] and args.circuit == "mimc" and "round0" in loops:
-        # the dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit): priced
-        # against instruction-issue ceilings taken from the ISA of THIS build (gkr-mimc_amd/build_info.json)
-        lp = loops["round0"]
+
+    def price_round0(which, launches, total_ms, modmuls, label, with_clock):
+        """The dominant kernel by time is VALU-bound (exact 256-bit modular arithmetic: no MFMA, no HBM limit): priced
+        against instruction-issue ceilings taken from the ISA of THIS build (gkr-mimc_amd/build_info.json)."""
+        lp = loops[which]
         pairs = float(1 << (bn_gpu - 1))
-        avg_ms = solo["peval_ms"] / solo["peval_launches"]
+        avg_ms = total_ms / launches
         waves_per_simd = pairs / (N_SIMD * 64)
         issue_cycles = HALF_RATE_CYCLES * lp["half_rate"] + FULL_RATE_CYCLES * lp["full_rate"]
         ceiling_ms = waves_per_simd * issue_cycles / (NOMINAL_GHZ * 1e9) * 1e3
         mad_ms = waves_per_simd * HALF_RATE_CYCLES * lp["v_mad_u64_u32"] / (NOMINAL_GHZ * 1e9) * 1e3
+        o = {"kernel": label, "bound": "integer VALU issue (no MFMA: modular arithmetic)", "launches": launches,
+             "avg_launch_ms": avg_ms, "loop_instructions_per_pair": lp, "issue_cycles_per_pair": issue_cycles,
+             "ceiling_ms": ceiling_ms, "frac": ceiling_ms / avg_ms, "mad_only_ms": mad_ms, "mad_issue_frac": mad_ms / avg_ms,
+             "field_products_per_s": modmuls / (total_ms * 1e-3)}
+        if with_clock and clk.median():
+            ghz = clk.median() * 1e-3
+            o["sclk_mhz_during_timed_steps"] = {"median": clk.median(), "min": min(clk.mhz), "max": max(clk.mhz),
+                                                "samples": len(clk.mhz), "source": "rocm-smi --showclocks"}
+            o["frac_at_measured_clock"] = ceiling_ms * NOMINAL_GHZ / ghz / avg_ms
+            o["mad_issue_frac_at_measured_clock"] = mad_ms * NOMINAL_GHZ / ghz / avg_ms
+        return o
+
+    if args.circuit == "mimc" and "round0" in loops and prof["peval_launches"]:
+        # the round-0 launches of the TIMED steps (several proofs in flight run the fused kernel: all ten products and the
+        # seven multiply-accumulates in one launch); with other lanes' kernels on the GPU a launch takes longer than alone
         # the algorithmic count, independent of the schedule: the round's 10 field products (schoolbook 64 limb products +
         # 64 of the Montgomery half each) and 7 plain multiply-accumulates (64) -- squarings, constant-multiplier images
         # and carry planning lower the instructions issued, not this number
         SCHOOLBOOK_LIMB_PRODUCTS = 10 * 128 + 7 * 64
+        fused = head.get("solo_fused") or (solo if not solo["lookahead_round0"] else None)
+        alone_fused = bool(fused and fused["peval_launches"])
+        src = fused if alone_fused else prof
+        pe = price_round0("round0", src["peval_launches"], src["peval_ms"], src["peval_modmuls"],
+                          "k_cipher_round_wide<false,true> (round 0 of a cipher layer: 2^%d index pairs; per pair 10 field "
+                          "products, 2 of them by a launch-wide constant, and 7 multiply-accumulates with deferred reduction)" % (bn_gpu - 1),
+                          with_clock=True)
+        waves_per_simd = float(1 << (bn_gpu - 1)) / (N_SIMD * 64)
         school_ms = waves_per_simd * HALF_RATE_CYCLES * SCHOOLBOOK_LIMB_PRODUCTS / (NOMINAL_GHZ * 1e9) * 1e3
-        out["partial_eval"] = {
-            "kernel": "k_cipher_round_wide<false,true> (round 0 of a cipher layer: 2^%d index pairs; per pair 10 field "
-                      "products, 2 of them by a launch-wide constant, and 7 multiply-accumulates with deferred reduction)" % (bn_gpu - 1),
-            "bound": "integer VALU issue (no MFMA: modular arithmetic)",
-            "launches": solo["peval_launches"], "avg_launch_ms": avg_ms,
-            "loop_instructions_per_pair": lp, "issue_cycles_per_pair": issue_cycles,
-            "ceiling_ms": ceiling_ms, "frac": ceiling_ms / avg_ms,
-            "mad_only_ms": mad_ms, "mad_issue_frac": mad_ms / avg_ms,
-            "schoolbook_limb_products_per_pair": SCHOOLBOOK_LIMB_PRODUCTS, "schoolbook_frac": school_ms / avg_ms,
-            "field_products_per_s": solo["peval_modmuls"] / (solo["peval_ms"] * 1e-3),
-            "ceiling_assumption": "frac: every vector instruction of this build's loop body at its measured issue cost (%.1f / %.1f "
-                                  "cycles per wave), the port never idle, nominal %.1f GHz; mad_issue_frac: the limb products "
-                                  "(v_mad_u64_u32) alone at %.1f cycles -- what a carry-free multiplier would cost -- over the "
-                                  "measured duration; schoolbook_frac: the same for the schoolbook limb products of the round's field "
-                                  "operations (10 x 128 + 7 x 64 per pair), a count no schedule changes"
-                                  % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ, HALF_RATE_CYCLES),
-            "measured": "HIP events around the round-0 launches of the single-proof pass"}
-        if clk.median():
-            ghz = clk.median() * 1e-3
-            out["partial_eval"]["sclk_mhz_during_timed_steps"] = {"median": clk.median(), "min": min(clk.mhz), "max": max(clk.mhz),
-                                                                   "samples": len(clk.mhz), "source": "rocm-smi --showclocks"}
-            out["partial_eval"]["frac_at_measured_clock"] = ceiling_ms * NOMINAL_GHZ / ghz / avg_ms
-            out["partial_eval"]["mad_issue_frac_at_measured_clock"] = mad_ms * NOMINAL_GHZ / ghz / avg_ms
-        if prof["peval_launches"]:
-            out["partial_eval"]["in_timed_region"] = {
-                "launches": prof["peval_launches"], "avg_launch_ms": prof["peval_ms"] / prof["peval_launches"],
-                "note": "launch durations with %d proofs in flight overlap the other lanes' kernels" % nconc}
+        pe["schoolbook_limb_products_per_pair"] = SCHOOLBOOK_LIMB_PRODUCTS
+        pe["schoolbook_frac"] = school_ms / pe["avg_launch_ms"]
+        pe["ceiling_assumption"] = ("frac: every vector instruction of this build's loop body at its measured issue cost (%.1f / %.1f "
+                                    "cycles per wave), the port never idle, nominal %.1f GHz; mad_issue_frac: the limb products "
+                                    "(v_mad_u64_u32) alone at %.1f cycles -- what a carry-free multiplier would cost -- over the "
+                                    "measured duration; schoolbook_frac: the same for the schoolbook limb products of the round's field "
+                                    "operations (10 x 128 + 7 x 64 per pair), a count no schedule changes"
+                                    % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ, HALF_RATE_CYCLES))
+        pe["measured"] = ("HIP events around the round-0 launches of one proof alone on the GPU with the look-ahead switched off "
+                          "(the fused kernel the proofs in flight run)" if alone_fused else
+                          "HIP events around the round-0 launches of the K timed steps, %d proofs in flight: a launch overlaps the "
+                          "other lanes' kernels, so its duration is longer than alone on the GPU (0.83 ms alone: profiles/)" % nconc)
+        out["partial_eval"] = pe
+        if solo["lookahead_round0"] and solo["peval_launches"] and "round0_pre" in loops:
+            # a proof ALONE on the GPU runs round 0 in two parts: k_cipher_pre (8 of the 10 products, during the previous
+            # layer's small rounds, off the critical path) and this launch (2 products by the launch-wide weight + 7 MACs)
+            out["partial_eval"]["single_proof_round0"] = price_round0(
+                "round0_pre", solo["peval_launches"], solo["peval_ms"], solo["peval_modmuls"],
+                "k_cipher_round_wide<false,true,true> (round 0 on look-ahead products: 192 B read per pair, 2 products by the "
+                "launch-wide weight and 7 multiply-accumulates)", with_clock=False)
     if prof.get("rounds"):
         out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
                                          ("host_hash_ms", "host_wait_ms", "host_launch_ms", "host_other_ms")}
         out["host_split_ms_per_step"]["rounds"] = prof["rounds"] / args.steps
 
-    if beside is not None:   # the same K steps over the host shared-memory exchange (measured first), beside the RCCL headline
-        out["config"]["shm_exchange_beside"] = {"value": hashes / beside["dt"], "ms_per_step": 1e3 * beside["dt"] / args.steps,
-                                                "transport": beside["transport"], "single_proof_latency_ms": beside["latency_ms"]}
+    if args.pass_name:
+        # one pass of an N > 1 run: hand the line to the orchestrator
+        job.close()
+        res = {"value": out["value"], "ms_per_step": out["ms_per_step"], "concurrent_proofs": nconc,
+               "single_proof_latency_ms": latency_ms, "transport": transport,
+               "proof_verified_by_native_gkr_verify": verified, "line": out}
+        if pass_name == "rccl_tick":
+            tk, idle = gk.comm_tick_stats()
+            res["tick_stats"] = {"ticks": tk, "idle_ticks": idle}
+        out["roofline"] = out.get("roofline")
+        out["cpu_baseline"] = None
+        if rank == 0:
+            emit(res)
+        gk.comm_destroy()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
+    if rank == 0 and not multi and not args.no_configs and args.circuit == "mimc":
+        # BASELINE configs 2 (bN = 20 on one GPU) and 5 (the GMiMC circuit at bN = 22) in the driver-run line: throughput with
+        # several proofs in flight and one proof alone (BenchmarkGkr's shape), each verified by the native gkr.Verify
+        job.close()
+        configs = {}
+        for key, circ, cbn, csteps in (("bn20", "mimc", 20, 20), ("gmimc_bn22", "gmimc", 22, 10)):
+            cl = lanes_that_fit(circ, cbn, args.concurrent, csteps)
+            cj = Job(gk, cbn, cl, gk.gmimc_t2_circuit() if circ == "gmimc" else None)
+            cj.run_steps(max(2, cl))
+            lat = []
+            for _ in range(3):
+                sync_all()
+                t0 = time.perf_counter()
+                cj.last[0] = cj.sessions[0].prove(cj.qprime)
+                lat.append(1e3 * (time.perf_counter() - t0))
+            cdt = timed(cj, csteps)
+            ok = bool(cj.sessions[0].verify(cj.qprime, cj.last[0]))
+            cj.close()
+            configs[key] = {"hashes_per_s": float(1 << cbn) * csteps / cdt, "ms_per_step": 1e3 * cdt / csteps, "steps": csteps,
+                            "concurrent_proofs": cl, "single_proof_ms": sorted(lat)[1],
+                            "single_proof_hashes_per_s": float(1 << cbn) / (sorted(lat)[1] * 1e-3),
+                            "proof_verified_by_native_gkr_verify": ok,
+                            "workload": ("gkr.Prove(MimcCircuit) at bN = 20 (BASELINE config 2)" if circ == "mimc" else
+                                         "gkr.Prove(GMiMC t = 2 circuit: cipher, add and copy layers) at bN = 22 (BASELINE config 5); "
+                                         "a hash here is one GMiMC compression")}
+        out["configs"] = configs
     if rank == 0 and not multi and not args.no_micro and args.circuit == "mimc":
         # SURVEY 8d micro-benchmarks, shaped like the reference's own (device-resident tables)
         job.close()
@@ -557,6 +691,13 @@ def main():
         ms = gk.bench_fold(1 << 25, ntab=1, warmup=2, iters=10)
         micro["fold_2p25"] = {"ms": ms, "GB_per_s": 96.0 * (1 << 24) / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 96.0 * (1 << 24) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "mirrors": "BenchmarkFolding, poly/multilin_test.go:55-78 (2^25 elements, table[i] = i, r = 5)"}
+        us, _ = gk.bench_partial_eval(15, warmup=20, iters=2000)
+        micro["partial_eval_bn15"] = {"us_per_dispatch": us, "index_pairs_per_s": float(1 << 14) / (us * 1e-6),
+                                      "field_products_per_s": 45.0 * (1 << 14) / (us * 1e-6),
+                                      "mirrors": "BenchmarkPartialEvalWithCipher, sumcheck/prover_test.go:127-147 (bn = 15: the Eq table built "
+                                                 "once, then dispatchPartialEvals of round 0 -- nine evaluations over 2^14 pairs -- in a loop; "
+                                                 "the reference times 30000 dispatches per iteration, this is the time of ONE dispatch, sums "
+                                                 "handed to the host every time)"}
         out["micro"] = micro
     if rank == 0 and not multi and not args.no_oneshot and args.circuit == "mimc":
         # the production caller's shape (GkrProverHint.Call, prover/gadget/hints.go:197-233): Assign + Prove from HOST

@@ -497,6 +497,7 @@ int table_alloc(DevTable* t, size_t cap) {
     hipError_t e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
     if (e != hipSuccess) {
         // drop the cache and retry once
+        (void)hipGetLastError();       // the failed attempt must not surface later as a stale "out of memory"
         for (auto& f : g_pool.free_list) (void)hipFree(f.second);
         g_pool.free_list.clear();
         e = hipMalloc(&p, sizeof(uint4) * 2 * cap);

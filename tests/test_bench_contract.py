@@ -41,6 +41,29 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    if "configs" in d:      # round 3: BASELINE configs 2 and 5 and the partial-evaluation micro-benchmark in the driver-run line
+        for key, bn in (("bn20", 20), ("gmimc_bn22", 22)):
+            e = d["configs"][key]
+            assert e["proof_verified_by_native_gkr_verify"] is True
+            assert abs(e["hashes_per_s"] - (1 << bn) * 1e3 / e["ms_per_step"]) / e["hashes_per_s"] < 1e-6
+            assert e["single_proof_ms"] > e["ms_per_step"] > 0
+        assert d["micro"]["partial_eval_bn15"]["us_per_dispatch"] > 0
+        assert c["ns_per_field_mul_per_core"] <= 25, "the CPU baseline must be in the class of gnark-crypto's assembly"
+        assert c["fr_mul_isolated_ns"]["nocarry_unrolled"]["independent"] > 0
+        sp = d["single_proof"]
+        assert sp["prelaunched_rounds"] > 0 and sp["lookahead_round0"] > 0 and sp["coop_rounds"] > 0
+
+
+def test_multi_rank_line_is_marked_when_no_rccl_pass_succeeded():
+    """Two ranks on ONE GPU (profiles/r03_*_2ranks_on_one_gpu_*.json): RCCL cannot form a communicator there, so the line comes
+    from the shared-memory pass -- and must say so in top-level fields a driver cannot miss."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_bench_2ranks_on_one_gpu_bn22.json")))
+    if not files:
+        return
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["degraded"] == "rccl_failed" and d["n_gpus_rccl"] == 0 and d["value_transport"] == "shm"
+    assert d["headline_pass"] == "shm" and set(d["passes"]) == {"shm", "rccl_one_lane", "rccl_tick", "rccl_lanes"}
+    assert all("error" in d["passes"][p] for p in ("rccl_one_lane", "rccl_tick", "rccl_lanes")) and d["passes"]["shm"]["value"] > 0
 
 
 def test_bench_defaults_finish_quickly():
