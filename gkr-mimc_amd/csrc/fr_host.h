@@ -4,6 +4,8 @@
 // the reduction of the limb-split device sums, claim routing and the tiny tail rounds.
 // Product code: never includes or links anything under oracle/.
 #pragma once
+#include <stdio.h>
+#include <string>
 #include <stdint.h>
 #include <string.h>
 
@@ -221,6 +223,30 @@ static inline E mimc_hash(const E* in, size_t n) {
         state = add(add(state, ns), in[k]);
     }
     return state;
+}
+
+// fr.Element.String(): the decimal of the regular form
+static inline std::string to_decimal(const E& a) {
+    const E one = {{1, 0, 0, 0}};
+    E v = mul(a, one);                       // out of Montgomery form
+    std::string out;
+    for (;;) {
+        // v /= 10^18, remainder rem
+        const u64 D = 1000000000000000000ull;
+        u128 rem = 0;
+        bool zero = true;
+        for (int i = 3; i >= 0; i--) {
+            const u128 cur = (rem << 64) | v.l[i];
+            v.l[i] = (u64)(cur / D);
+            rem = cur % D;
+            zero = zero && v.l[i] == 0;
+        }
+        char buf[32];
+        snprintf(buf, sizeof buf, zero ? "%llu" : "%018llu", (unsigned long long)rem);
+        out = std::string(buf) + out;
+        if (zero) break;
+    }
+    return out;
 }
 
 // poly/lagrange.go:31-39

@@ -272,6 +272,19 @@ int gkrhip_device_count(void) {
 }
 
 const char* gkrhip_last_error(void) { return g_err.c_str(); }
+// Thread-independent form: the message of the failure that returned `code` (every failing call returns a code of its own),
+// copied into buf (NUL-terminated, truncated to cap); falls back to the calling thread's last message for a code the ring
+// no longer holds.  Returns the full length of the message.
+size_t gkrhip_last_error_r(int code, char* buf, size_t cap) {
+    std::string m;
+    if (!error_lookup(code, &m)) m = g_err;
+    if (buf && cap) {
+        const size_t n = std::min(m.size(), cap - 1);
+        memcpy(buf, m.data(), n);
+        buf[n] = 0;
+    }
+    return m.size();
+}
 const char* gkrhip_version(void) { return "gkrhip 0.3 (gfx950)"; }
 #ifndef GKRHIP_SOURCE_SHA
 #define GKRHIP_SOURCE_SHA "unrecorded"
@@ -442,6 +455,35 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t* ark_or_null, int arity, int 
     return rc;
 }
 
+// sumcheck.Verify (sumcheck/verifier.go:28-65): scalar work only (Fiat-Shamir hashing, evaluations of the round
+// polynomials), so it runs on the host and needs no GPU.  Returns 0 = accepted, 1 + i = round i's check
+// P_i(0) + P_i(1) == expected failed (gkrhip_last_error has the reference's message).
+int gkrhip_sumcheck_verify(const uint64_t* claims, int nclaims, const uint64_t* proof, int bN, int ncoeffs, uint64_t* challenges,
+                           uint64_t final_claim[4], uint64_t recomb_chal[4]) {
+    if (nclaims < 1) return fail("sumcheck.Verify: no claim (the reference indexes claims[0] of an empty slice and panics)");
+    if (bN < 0 || ncoeffs < 1 || ncoeffs > 64) return fail("sumcheck.Verify: bad proof shape (%d rounds of %d coefficients)", bN, ncoeffs);
+    const E* cl = (const E*)claims;
+    const E* pr = (const E*)proof;
+    // recombineMultiClaims (:58-65): with >= 1 claims the challenge is always drawn, also for a single claim
+    const E recomb = hfr::mimc_hash(cl, (size_t)nclaims);
+    E expected = hfr::eval_univariate(cl, nclaims, recomb);
+    for (int i = 0; i < bN; i++) {
+        const E* p = pr + (size_t)i * ncoeffs;
+        const E actual = hfr::add(hfr::eval_univariate(p, ncoeffs, hfr::ZERO), hfr::eval_univariate(p, ncoeffs, hfr::ONE));
+        if (actual != expected) {
+            (void)fail("at round %d verifier eval at 0 + 1 = %s || expected = %s", i, hfr::to_decimal(actual).c_str(),
+                       hfr::to_decimal(expected).c_str());
+            return 1 + i;
+        }
+        const E r = hfr::mimc_hash(p, (size_t)ncoeffs);
+        if (challenges) memcpy(challenges + 4 * (size_t)i, r.l, 32);
+        expected = hfr::eval_univariate(p, ncoeffs, r);
+    }
+    if (final_claim) memcpy(final_claim, expected.l, 32);
+    if (recomb_chal) memcpy(recomb_chal, recomb.l, 32);
+    return 0;
+}
+
 size_t gkrhip_mimc_proof_len(int bN) { return (size_t)822 * bN + 183 + (size_t)184 * bN; }
 
 static int session_create_for(gkrhip_session** out, const Circuit& circ, int bN);
@@ -472,7 +514,7 @@ int gkrhip_gmimc_t2_circuit(gkrhip_layer* layers_out, int capacity) {
 int gkrhip_gmimc_circuit(int t, gkrhip_layer* layers_out, int capacity, int* input_map_out) {
     std::vector<gkrhip_layer> v;
     std::vector<int> map;
-    if (gmimc_layers(t, &v, &map) != 0) return -1;
+    if (const int rc = gmimc_layers(t, &v, &map)) return rc;
     if (input_map_out)
         for (size_t k = 0; k < map.size(); k++) input_map_out[k] = map[k];
     if (layers_out) {
@@ -485,7 +527,7 @@ int gkrhip_gmimc_circuit(int t, gkrhip_layer* layers_out, int capacity, int* inp
 int gkrhip_gmimc_hash_circuit(int t, int nblocks, gkrhip_layer* layers_out, int capacity, int* input_map_out) {
     std::vector<gkrhip_layer> v;
     std::vector<int> map;
-    if (gmimc_hash_layers(t, nblocks, &v, &map) != 0) return -1;
+    if (const int rc = gmimc_hash_layers(t, nblocks, &v, &map)) return rc;
     if (input_map_out)
         for (size_t k = 0; k < map.size(); k++) input_map_out[k] = map[k];
     if (layers_out) {

@@ -225,15 +225,41 @@ struct Pool {
     std::vector<std::pair<size_t, uint4*>> free_list;  // (cap, base) cache of table buffers
 } g_pool;
 thread_local std::string g_err;
+// Every failure gets a code of its own (<= -16) and its message is kept under that code in a process-wide ring, so that a
+// caller whose thread has changed between the failing call and the question (a goroutine that migrated to another OS
+// thread between the cgo call and must()) still gets ITS message: gkrhip_last_error_r(code, ...).  gkrhip_last_error()
+// keeps answering from the calling thread's last failure.
+struct ErrRing {
+    static const int N = 256;
+    std::mutex mu;
+    int code[N] = {0};
+    std::string msg[N];
+    unsigned long long next = 0;
+} g_errs;
 
 int fail(const char* fmt, ...) {
-    char buf[512];
+    char buf[768];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_err = buf;
-    return -1;
+    std::lock_guard<std::mutex> lk(g_errs.mu);
+    const unsigned long long n = g_errs.next++;
+    const int code = -(int)(16 + (n % 0x3ffffff0ull));
+    g_errs.code[n % ErrRing::N] = code;
+    g_errs.msg[n % ErrRing::N] = buf;
+    return code;
+}
+// the message recorded under `code` (false: it has left the ring, or the code is not a failure code of this library)
+bool error_lookup(int code, std::string* out) {
+    std::lock_guard<std::mutex> lk(g_errs.mu);
+    for (int i = 0; i < ErrRing::N; i++)
+        if (g_errs.code[i] == code && code != 0) {
+            *out = g_errs.msg[i];
+            return true;
+        }
+    return false;
 }
 
 #define HIPCHK(x)                                                                                 \

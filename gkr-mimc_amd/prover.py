@@ -33,6 +33,8 @@ ABI = {
     "gkrhip_shutdown": (None, []),
     "gkrhip_device_count": (_I, []),
     "gkrhip_last_error": (C.c_char_p, []),
+    "gkrhip_last_error_r": (_SZ, [_I, C.c_char_p, _SZ]),
+    "gkrhip_sumcheck_verify": (_I, [_P, _I, _P, _I, _I, _P, _P, _P]),
     "gkrhip_version": (C.c_char_p, []),
     "gkrhip_build_id": (C.c_char_p, []),
     "gkrhip_device_synchronize": (_I, []),
@@ -127,9 +129,16 @@ def load():
     return lib
 
 
+def error_message(rc):
+    """The message of the failure that returned `rc` (thread-independent: gkrhip_last_error_r)."""
+    buf = C.create_string_buffer(1024)
+    load().gkrhip_last_error_r(int(rc), buf, len(buf))
+    return buf.value.decode(errors="replace")
+
+
 def _check(rc):
     if rc != 0:
-        raise GkrHipError(load().gkrhip_last_error().decode() or "gkrhip error %d" % rc)
+        raise GkrHipError(error_message(rc) or "gkrhip error %d" % rc)
 
 
 def init(device=0):
@@ -236,6 +245,24 @@ def sumcheck_prove(X, q_primes, claims, gate, ark=None):
                                         _ptr(claims) if claims.shape[0] else None, claims.shape[0],
                                         _ptr(proof), _ptr(chal), _ptr(final)))
     return proof[: bN * nc].reshape(bN, nc, 4), chal[:bN], final
+
+
+def sumcheck_verify(claims, proof):
+    """sumcheck.Verify(claims, proof) -> (challenges[bN], finalClaim, recombChal); raises GkrHipError with the reference's
+    message when a round's check fails (the reference returns err).  Host-only: needs no GPU."""
+    claims = _fr(claims).reshape(-1, 4)
+    proof = _fr(proof)
+    assert proof.ndim == 3
+    bN, nc = proof.shape[0], proof.shape[1]
+    chal = np.zeros((max(bN, 1), 4), np.uint64)
+    fin, rec = np.zeros((1, 4), np.uint64), np.zeros((1, 4), np.uint64)
+    flat = np.ascontiguousarray(proof.reshape(-1, 4)) if bN else np.zeros((1, 4), np.uint64)
+    rc = load().gkrhip_sumcheck_verify(_ptr(claims) if claims.shape[0] else None, claims.shape[0], _ptr(flat), bN, max(nc, 1),
+                                       _ptr(chal), _ptr(fin), _ptr(rec))
+    if rc > 0:
+        raise GkrHipError(load().gkrhip_last_error().decode())
+    _check(rc)
+    return chal[:bN], fin, rec
 
 
 def mimc_proof_len(bN):

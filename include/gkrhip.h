@@ -8,9 +8,10 @@
  * passes with no conversion on the Go side.  Host input buffers are read-only to the library unless
  * stated; outputs are written into caller-allocated buffers.
  *
- * All functions return 0 on success and a non-zero code otherwise; gkrhip_last_error() describes
- * the last failure of the calling process (the reference panics on the prover side,
- * sumcheck/prover.go:54,114; the Go shim turns non-zero into panic).  Calls block until the result
+ * All functions return 0 on success and a non-zero code otherwise.  Every failure returns a code of its own (<= -16);
+ * gkrhip_last_error_r(code, buf, cap) returns the message of THAT failure from any thread (a goroutine may have moved
+ * to another OS thread between the cgo call and the question), gkrhip_last_error() the last failure of the calling
+ * THREAD (the reference panics on the prover side, sumcheck/prover.go:54,114; the Go shim turns non-zero into panic).  Calls block until the result
  * is in host memory.  One context per process; every call works on a lane of its own (stream, hand-off buffers), so
  * calls from different host threads run concurrently (the reference's Prove is called from one goroutine and blocks,
  * sumcheck/prover.go:46-90; concurrent callers there share one worker pool).
@@ -58,7 +59,8 @@ int gkrhip_gate_lookup(int gate_id, gkrhip_gate_desc *desc_out);   /* 0 if gate_
 int gkrhip_init(int device_ordinal);      /* idempotent; selects the GPU, creates the stream/arena */
 void gkrhip_shutdown(void);
 int gkrhip_device_count(void);
-const char *gkrhip_last_error(void);
+const char *gkrhip_last_error(void);                               /* last failure of the calling thread */
+size_t gkrhip_last_error_r(int code, char *buf, size_t cap);        /* the failure that returned `code`, from any thread; returns its length */
 const char *gkrhip_version(void);
 /* SHA-256 (hex) of the sources and compiler flags this binary was built from; the loaders compare it with the sources
  * they sit next to (gkr-mimc_amd/build.py) so that a stale binary is never called through a changed ABI */
@@ -105,6 +107,13 @@ int gkrhip_sumcheck_prove(int gate, const uint64_t *ark_or_null, int arity, int 
 /* ---- gkr.Prove for examples.MimcCircuit (gkr/prover.go:21-47, examples/mimc.go:10-37) --------- */
 /* Number of field elements of the flat proof, = GkrProverHint.NbOutputs (prover/gadget/hints.go:76-116):
  * 822*bN + 183 + 184*bN. */
+/* sumcheck.Verify(claims, proof) (sumcheck/verifier.go:28-56): proof = bN rounds of `ncoeffs` coefficients (low -> high).
+ * Scalar host work (the Fiat-Shamir chain), no GPU needed.  Returns 0 = accepted -- challenges[bN], *final_claim (the
+ * alleged evaluation the caller still has to check against the gate, as the reference leaves it) and *recomb_chal (the
+ * recombination challenge of the claims) are filled; 1 + i = the check of round i failed (err != nil in the reference:
+ * gkrhip_last_error carries its message "at round i verifier eval at 0 + 1 = ... || expected = ..."); < 0 = bad arguments. */
+int gkrhip_sumcheck_verify(const uint64_t *claims, int nclaims, const uint64_t *proof, int bN, int ncoeffs,
+                           uint64_t *challenges, uint64_t final_claim[4], uint64_t recomb_chal[4]);
 size_t gkrhip_mimc_proof_len(int bN);
 /* Circuit.Assign(in0,in1) (circuit/assignment.go:12-32) + gkr.Prove, as GkrProverHint.Call does
  * (prover/gadget/hints.go:220-222).  flat: gkrhip_mimc_proof_len(bN) elements in GkrProofToVec order

@@ -1,4 +1,4 @@
-//go:build gkrhip
+//go:build gkrhip && (amd64 || arm64)
 
 // GPU bodies of gkr.Prove (gkr/prover.go:21-47) and gkr.Verify (gkr/verifier.go:15-59).  Drop into gkr-mimc/gkr/
 // with `//go:build !gkrhip` on the pure-Go Prove / Verify.  Uncompiled here (no Go toolchain in the build image);

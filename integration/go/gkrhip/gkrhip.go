@@ -1,4 +1,4 @@
-//go:build gkrhip
+//go:build gkrhip && (amd64 || arm64)
 
 // Package gkrhip is the one cgo package of the MI355X back end: Go-typed wrappers over include/gkrhip.h
 // (libgkrhip.so).  Every []fr.Element is passed as unsafe.Pointer(&s[0]): gnark-crypto's fr.Element is
@@ -41,10 +41,19 @@ const (
 // MaxGateInputs is the largest len(Layer.In) the library's gate descriptors express.
 const MaxGateInputs = int(C.GKRHIP_MAX_GATE_INPUTS)
 
+// must turns a non-zero return code into a panic carrying the message of THAT failure.  The message is asked for by
+// code (gkrhip_last_error_r), not from thread-local state: between the failing cgo call and this one the goroutine may
+// have been moved to another OS thread, whose own "last error" would be empty or somebody else's.
 func must(rc C.int) {
 	if rc != 0 {
-		panic("gkrhip: " + C.GoString(C.gkrhip_last_error()))
+		panic("gkrhip: " + errorText(rc))
 	}
+}
+
+func errorText(rc C.int) string {
+	var buf [1024]C.char
+	C.gkrhip_last_error_r(rc, &buf[0], C.size_t(len(buf)))
+	return C.GoString(&buf[0])
 }
 
 // ptr is the address of the first limb of a slice of field elements (nil for an empty slice).
@@ -150,6 +159,26 @@ func SumcheckProve(gate int, degree int, ark *fr.Element, X [][]fr.Element, qPri
 	must(C.gkrhip_sumcheck_prove(C.int(gate), ptr1(ark), C.int(len(X)), C.int(bN), (**C.uint64_t)(unsafe.Pointer(&cx[0])),
 		ptr(flatQ), C.int(len(qPrimes)), ptr(claims), C.int(len(claims)), ptr(proof), ptr(challenges), ptr(finalClaims)))
 	return proof[:bN*nCoeff], challenges[:bN], finalClaims
+}
+
+// SumcheckVerify is sumcheck.Verify's body (sumcheck/verifier.go:28-56): proof is round-major, nCoeff coefficients per
+// round.  A failed round check comes back as the reference's error ("at round i verifier eval at 0 + 1 = ... ||
+// expected = ..."); bad arguments panic like every other misuse.
+func SumcheckVerify(claims, proof []fr.Element, bN, nCoeff int) (challenges []fr.Element, finalClaim, recombChal fr.Element, err error) {
+	challenges = make([]fr.Element, bN+1)
+	if nCoeff < 1 {
+		nCoeff = 1
+	}
+	// the round check's message is the calling thread's last error: keep the goroutine on its thread for the two calls
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	rc := C.gkrhip_sumcheck_verify(ptr(claims), C.int(len(claims)), ptr(proof), C.int(bN), C.int(nCoeff), ptr(challenges),
+		ptr1(&finalClaim), ptr1(&recombChal))
+	if rc > 0 {
+		return nil, fr.Element{}, fr.Element{}, errors.New(C.GoString(C.gkrhip_last_error()))
+	}
+	must(rc)
+	return challenges[:bN], finalClaim, recombChal, nil
 }
 
 // Layer mirrors circuit.Layer for the library: Gate < 0 marks an input layer.

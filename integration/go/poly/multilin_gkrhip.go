@@ -1,4 +1,4 @@
-//go:build gkrhip
+//go:build gkrhip && (amd64 || arm64)
 
 // GPU bodies of the poly functions on the GKR hot path.  Drop this file into gkr-mimc/poly/ and put
 // `//go:build !gkrhip` on the pure-Go definitions it replaces (poly/multilin.go:19-23,59-66, poly/eq.go:41-59);

@@ -1,4 +1,4 @@
-//go:build gkrhip
+//go:build gkrhip && (amd64 || arm64)
 
 // GPU body of GkrProverHint.Call (prover/gadget/hints.go:197-233): same signature, same input order
 // (qPrime || inputs... || outputs, io_store.go:117-136) and same output order (GkrProofToVec, hints.go:236-271);
@@ -9,13 +9,40 @@ package gadget
 import (
 	"math/big"
 
+	"github.com/consensys/gkr-mimc/circuit"
 	"github.com/consensys/gkr-mimc/common"
+	"github.com/consensys/gkr-mimc/examples"
 	"github.com/consensys/gkr-mimc/gkrhip"
 	gkrNative "github.com/consensys/gkr-mimc/gkr"
 	"github.com/consensys/gkr-mimc/poly"
 	"github.com/consensys/gnark-crypto/ecc"
 	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
 )
+
+// isMimcCircuit reports whether c is examples.MimcCircuit() (examples/mimc.go:10-37) layer for layer: the same wiring and
+// the same gates (Gate.ID() of a CipherGate carries its Ark, circuit/gates/cipher.go:22).  Only then may the one-call
+// MiMC entry point stand in for Assign + Prove; a different circuit that merely has 94 layers and two inputs takes the
+// generic path.
+func isMimcCircuit(c circuit.Circuit) bool {
+	ref := examples.MimcCircuit()
+	if len(c) != len(ref) {
+		return false
+	}
+	for l := range c {
+		if (c[l].Gate == nil) != (ref[l].Gate == nil) || len(c[l].In) != len(ref[l].In) {
+			return false
+		}
+		if c[l].Gate != nil && c[l].Gate.ID() != ref[l].Gate.ID() {
+			return false
+		}
+		for k := range c[l].In {
+			if c[l].In[k] != ref[l].In[k] {
+				return false
+			}
+		}
+	}
+	return true
+}
 
 // Call computes the GKR proof on the GPU and writes it into oups in GkrProofToVec order
 func (h *GkrProverHint) Call(_ ecc.ID, inputsBI []*big.Int, oups []*big.Int) error {
@@ -31,7 +58,7 @@ func (h *GkrProverHint) Call(_ ecc.ID, inputsBI []*big.Int, oups []*big.Int) err
 		if b.Sign() < 0 || b.Cmp(fr.Modulus()) >= 0 {
 			b = new(big.Int).Mod(b, fr.Modulus())
 		}
-		for k, w := range b.Bits() { // little-endian words; big.Word is 64 bits wide on every platform cgo + HIP run on
+		for k, w := range b.Bits() { // little-endian words; big.Word is 64 bits wide on amd64 / arm64 (the build constraint above)
 			drain[i][k] = uint64(w)
 		}
 	}
@@ -47,7 +74,7 @@ func (h *GkrProverHint) Call(_ ecc.ID, inputsBI []*big.Int, oups []*big.Int) err
 	// any other circuit of library gates goes through the generic path on Montgomery elements.
 	t := common.NewTimer("gkr prover hint")
 	var flat []fr.Element // regular form from here on
-	if len(inputs) == 2 && len(h.g.Circuit) == 94 {
+	if isMimcCircuit(h.g.Circuit) {
 		flat = gkrhip.ProveMimcRegular(bN, inputs[0], inputs[1], qPrime, nil)
 		if debug { // the verifier takes Montgomery elements: convert copies
 			m := func(s []fr.Element) []fr.Element { c := append([]fr.Element{}, s...); gkrhip.FromRegular(c); return c }

@@ -1,4 +1,4 @@
-//go:build gkrhip
+//go:build gkrhip && (amd64 || arm64)
 
 // GPU body of sumcheck.Prove (sumcheck/prover.go:46-90).  Drop into gkr-mimc/sumcheck/ and move prover.go's Prove into
 // a file of its own tagged `//go:build !gkrhip` (build tags are per file; the helpers of prover.go stay).  Uncompiled here (no Go toolchain in the build image).
@@ -65,4 +65,24 @@ func Prove(X []poly.MultiLin, qPrimes [][]fr.Element, claims []fr.Element, gate 
 		poly.DumpLarge(x)
 	}
 	return proof, challenges, finalClaims
+}
+
+// Verify is sumcheck.Verify (sumcheck/verifier.go:28-56) through the library, so that the package is replaced
+// symmetrically (move the pure-Go Verify into a file tagged `//go:build !gkrhip`; recombineMultiClaims stays).  It is
+// scalar work -- the Fiat-Shamir chain -- and runs on the host inside libgkrhip; same outputs, same error text.
+func Verify(claims []fr.Element, proof Proof) (challenges []fr.Element, finalClaim, recombChal fr.Element, err error) {
+	bn := len(proof)
+	nCoeff := 0
+	if bn > 0 {
+		nCoeff = len(proof[0])
+	}
+	flat := make([]fr.Element, 0, bn*nCoeff)
+	for _, p := range proof {
+		flat = append(flat, p...)
+	}
+	challenges, finalClaim, recombChal, err = gkrhip.SumcheckVerify(claims, flat, bn, nCoeff)
+	if err != nil {
+		return nil, fr.Element{}, fr.Element{}, err
+	}
+	return challenges, finalClaim, recombChal, nil
 }

@@ -39,6 +39,49 @@ def test_no_gpu_fails_loudly(gk):
         gk.fold(np.zeros((4, 4), np.uint64), np.zeros((1, 4), np.uint64))
 
 
+def test_sumcheck_verify_entry_point_vs_oracle(gk):
+    """gkrhip_sumcheck_verify (sumcheck/verifier.go:28-56, host-only) against the oracle's restated verifier on oracle-made
+    proofs: cipher gate with one claim, identity gate with several claims, every output, and corrupted proofs (the round
+    of the rejection and the reference's error text)."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as c
+    for bn, gate, ninst in ((0, c.GATE_CIPHER, 1), (1, c.GATE_CIPHER, 1), (6, c.GATE_CIPHER, 1), (5, c.GATE_IDENTITY, 3), (7, c.GATE_IDENTITY, 10)):
+        n = 1 << bn
+        X = [c.random_fr_array(n), c.from_ints([(7 * i * i + 3) % 1000003 for i in range(n)])]
+        ark = c.from_u64(145646)
+        qs = np.stack([c.from_ints([(i * j + i + 1) for j in range(bn)]) if bn else c.fr(0) for i in range(ninst)]).reshape(ninst, bn, 4)
+        claims = np.concatenate([c.evaluation(gate, ark, qs[i:i + 1], c.fr(0), X) for i in range(ninst)])
+        proof, chal, _fin = c.sumcheck_prove(gate, ark, X, qs, claims)
+        rc, ochal, ofinal, orecomb = c.sumcheck_verify(claims, proof)
+        assert rc == 0
+        gchal, gfinal, grecomb = gk.sumcheck_verify(claims, proof)
+        assert np.array_equal(gchal, ochal) and np.array_equal(gchal, chal)
+        assert np.array_equal(gfinal, ofinal) and np.array_equal(grecomb, orecomb)
+        for rnd in range(bn):
+            bad = proof.copy()
+            bad[rnd, rnd % proof.shape[1], 1] ^= np.uint64(4)
+            assert c.sumcheck_verify(claims, bad)[0] != 0
+            with pytest.raises(gk.prover.GkrHipError, match=r"at round %d verifier eval at 0 \+ 1 = \d+ \|\| expected = \d+" % rnd):
+                gk.sumcheck_verify(claims, bad)
+    with pytest.raises(gk.prover.GkrHipError, match="no claim"):
+        gk.sumcheck_verify(np.zeros((0, 4), np.uint64), np.zeros((1, 3, 4), np.uint64))
+
+
+def test_error_codes_are_readable_from_another_thread(gk, tmp_path):
+    """tests/cpp/test_abi_errors.cpp: every failure has a code of its own and gkrhip_last_error_r(code) answers from any
+    thread (a goroutine may have migrated between the failing cgo call and must())."""
+    exe = str(tmp_path / "test_abi_errors")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_abi_errors.cpp"), "-ldl", "-pthread"])
+    out = subprocess.run([exe, gk.prover.library_path()], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ABI-ERRORS-OK" in out.stdout, out.stdout + out.stderr
+    import numpy as np
+    with pytest.raises(gk.prover.GkrHipError) as e1:
+        gk.sumcheck_verify(np.zeros((0, 4), np.uint64), np.zeros((1, 3, 4), np.uint64))
+    assert "no claim" in str(e1.value)
+
+
 def test_gmimc_circuit_description_matches_oracle(gk):
     """The library's build-defined GMiMC (t = 2) circuit (BASELINE config 5) is layer for layer the circuit the
     Python oracle proves, and that circuit computes hash.GMimcHasher's compression (checked in pyoracle)."""

@@ -336,3 +336,20 @@ def test_variadic_gates_c_vs_python(bn):
     cf, cout, _ = c.gkr_prove_circuit(descs, bn, [c.from_ints(x) for x in ins], c.from_ints(qp) if bn else c.fr(0))
     assert c.to_ints(cf) == o.gkr_proof_to_vec(pr) and c.to_ints(cout) == a[-1]
     assert c.gkr_verify_circuit(descs, bn, cf, [c.from_ints(x) for x in ins], cout, c.from_ints(qp) if bn else c.fr(0)) == 0
+
+
+def test_fr_mul_variants_agree():
+    """The unrolled no-carry CIOS (fr.Element.Mul as gnark-crypto's assembly does it) and the looped five-word CIOS of
+    rounds 1-2 give the same canonical products, corner values included."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    qm1 = c.from_ints([21888242871839275222246405745257275088548364400416034343698204186575808495616])
+    vals = [c.fr(1)[0:1], c.from_u64(1), qm1, c.from_ints([(1 << 253) + 12345]), c.random_fr_array(6)[5:6]]
+    vals += [c.from_ints([int.from_bytes(rng.bytes(32), "little") % 21888242871839275222246405745257275088548364400416034343698204186575808495617])
+             for _ in range(40)]
+    for a in vals:
+        for b in vals:
+            o1, o2 = c.fr(1), c.fr(1)
+            c.lib.oracle_fr_mul(o1.ctypes.data, a.ctypes.data, b.ctypes.data)
+            c.lib.oracle_fr_mul_generic(o2.ctypes.data, a.ctypes.data, b.ctypes.data)
+            assert np.array_equal(o1, o2)
