@@ -728,7 +728,12 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
         });
     }
     const double t_p0 = now_ms();
-    if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
+    if (rc == 0) {
+        // the regular-form scope is for the BOUNDARY images only (inputs above, outputs and the flat proof below): inside
+        // the proof every host value is a Montgomery element -- a sharded proof uploads gathered elements (small_table)
+        RegularIO inside(false);
+        rc = gkrhip_mimc_session_prove(s, qprime, flat);
+    }
     const double t_p = now_ms();
     if (dl.joinable()) {
         dl.join();
@@ -1207,6 +1212,11 @@ static int shm_attach(int world, int rank, const char* name) {   // on the curre
             usleep(1000);
         }
     }
+    ino_t ino = 0;
+    {
+        struct stat st;
+        if (fstat(fd, &st) == 0) ino = st.st_ino;
+    }
     void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) return fail("mmap of %s failed", name);
@@ -1219,6 +1229,7 @@ static int shm_attach(int world, int rank, const char* name) {   // on the curre
     if (rank == 0) {
         h->magic.store(kShmMagic ^ (unsigned long long)ts.tv_sec, std::memory_order_release);
     } else {
+        unsigned polls = 0;
         for (;;) {
             const unsigned long long m = h->magic.load(std::memory_order_acquire);
             clock_gettime(CLOCK_REALTIME, &ts);
@@ -1229,6 +1240,22 @@ static int shm_attach(int world, int rank, const char* name) {   // on the curre
                 return fail("shm segment %s is stale or was never initialised by rank 0", name);
             }
             usleep(1000);
+            // This mapping may be the LEFTOVER of an earlier run that this rank opened before rank 0 unlinked it and
+            // created the fresh segment: look at the name again every now and then and move to the new file
+            if ((++polls & 127) == 0) {
+                const int fd2 = shm_open(name, O_RDWR, 0600);
+                struct stat st;
+                if (fd2 >= 0 && fstat(fd2, &st) == 0 && st.st_ino != ino && (size_t)st.st_size >= bytes) {
+                    void* p2 = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, 0);
+                    if (p2 != MAP_FAILED) {
+                        munmap(p, bytes);
+                        p = p2;
+                        h = (ShmHdr*)p;
+                        ino = st.st_ino;
+                    }
+                }
+                if (fd2 >= 0) close(fd2);
+            }
         }
     }
     cx().lc.shm = h;

@@ -271,13 +271,13 @@ def mimc_proof_len(bN):
 
 def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True, regular=False):
     """Circuit.Assign(in0, in1) + gkr.Prove(MimcCircuit, a, qPrime); returns (flat proof, outputs).  regular=True: every
-    buffer holds regular-form values (the hint interface's big.Int words) instead of Montgomery fr.Elements."""
+    buffer holds regular-form values (the hint interface's big.Int words) instead of Montgomery fr.Elements.  With a
+    communicator installed in0/in1/outputs are this rank's shard and bN (= len(q_prime)) is the global size."""
     in0, in1 = _fr(in0), _fr(in1)
     n = in0.shape[0]
-    bN = n.bit_length() - 1
-    assert n == 1 << bN and in1.shape[0] == n
     q_prime = _fr(q_prime).reshape(-1, 4)
-    assert q_prime.shape[0] == bN
+    bN = q_prime.shape[0] if q_prime.shape[0] else n.bit_length() - 1
+    assert n & (n - 1) == 0 and n <= 1 << bN and in1.shape[0] == n
     flat = np.zeros((mimc_proof_len(bN), 4), np.uint64)
     outs = np.zeros((n, 4), np.uint64) if want_outputs else None
     fn = load().gkrhip_gkr_prove_mimc_regular if regular else load().gkrhip_gkr_prove_mimc

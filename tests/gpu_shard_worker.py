@@ -91,6 +91,24 @@ def hash_only(gk, world, rank, sizes):
     print("SHARD-OK rank %d/%d hash-only %s" % (rank, world, sizes))
 
 
+def regular_oneshot(gk, world, rank, sizes):
+    """The hint-shaped one-shot call on REGULAR-form buffers with a communicator installed (the session of the call
+    shards): this rank's shard of the inputs in, the un-sharded oracle transcript (converted to regular form) out."""
+    for bn in sizes:
+        n = 1 << bn
+        i0 = c.random_fr_array(n)
+        i1 = c.from_ints([(5 * i * i + 11 * i + 3) for i in range(n)])
+        qp = c.random_fr_array(bn)
+        oflat, oouts, _ = c.gkr_prove_mimc(bn, i0, i1, qp)
+        def reg(a):       # Montgomery elements -> the words of their regular form
+            return np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in c.to_ints(a)], dtype=np.uint64).reshape(-1, 4)
+        flat, outs = gk.gkr_prove_mimc(reg(i0[rank::world].copy()), reg(i1[rank::world].copy()), reg(qp), regular=True)
+        assert np.array_equal(flat, reg(oflat)), ("regular transcript", bn, rank)
+        assert np.array_equal(outs, reg(oouts[rank::world].copy())), ("regular outputs", bn, rank)
+    gk.comm_destroy()
+    print("SHARD-OK rank %d/%d regular %s" % (rank, world, sizes))
+
+
 def gmimc_small(gk, world, rank, sizes):
     """The GMiMC (t = 2) circuit sharded: cipher, add and identity layers against the C oracle's un-sharded transcript."""
     import pyoracle as o
@@ -158,6 +176,8 @@ def main():
         print("DIED rank %d" % rank)
         return
     circuit = os.environ.get("GKR_TEST_CIRCUIT", "mimc")
+    if os.environ.get("GKR_TEST_REGULAR"):
+        return regular_oneshot(gk, world, rank, sizes)
     if os.environ.get("GKR_TEST_HASHONLY"):
         return hash_only(gk, world, rank, sizes)
     if os.environ.get("GKR_TEST_DIGEST"):

@@ -60,6 +60,14 @@ def test_sharded_prover_concurrent_lanes():
     _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
 
 
+def test_sharded_oneshot_on_regular_form_buffers():
+    """gkrhip_gkr_prove_mimc_regular with a communicator installed: the regular-form scope covers the boundary images
+    only, the gathered Montgomery elements of the sharded phase 2 (multi-claim key-copy layer, host tail off) are uploaded
+    as they are."""
+    _run_shards("shm", 2, "1,2,5,9", {"GKR_TEST_REGULAR": "1"})
+    _run_shards("shm", 4, "2,6,10", {"GKR_TEST_REGULAR": "1", "GKRHIP_HOST_TAIL": "0"})
+
+
 def test_rccl_ticker_world1_forced():
     """The multi-lane RCCL transport (one communicator, one issuing thread, batched ticks) with every round forced through
     it at world = 1: one lane and eight lanes in flight, MiMC and GMiMC (cipher, linear and multi-claim layers, the
