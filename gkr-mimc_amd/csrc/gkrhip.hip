@@ -31,6 +31,7 @@
 #include "cipher_round.hip.h"
 #include "linear_round.hip.h"
 #include "cipher_coop.hip.h"
+#include "ntt.hip.h"
 
 using hfr::E;
 
@@ -43,6 +44,7 @@ namespace {
 #include "host_coll.hip.h"
 #include "host_sumcheck.hip.h"
 #include "host_circuit.hip.h"
+#include "host_ntt.hip.h"
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -250,6 +252,7 @@ void gkrhip_shutdown(void) {
     (void)hipSetDevice(cx().device);
     lane_free();
     lane_pool_drain();
+    ntt_domains_free();
     {
         std::lock_guard<std::mutex> pl(g_pool.mu);
         for (auto& f : g_pool.free_list) (void)hipFree(f.second);
@@ -944,6 +947,100 @@ int gkrhip_mimc_session_verify(gkrhip_session* s, const uint64_t* qprime, const 
     const int rc = verify_flat(s->c, s->bN, (const E*)flat, (const E*)qprime, eval);
     if (rc > 0) fail("gkr.Verify rejected the proof (code %d)", rc);
     return rc;
+}
+
+// computeH (prover/gadget/prove.go:308-359): a, b, c hold n Montgomery elements each (the solved R1CS vectors), zero-padded
+// here to the domain (cardinality = a power of two >= n; 0 = the next power of two, as fft.NewDomain chooses it); h receives
+// `cardinality` REGULAR-form values in the order the reference returns them (coefficients of H, bit-reversed positions).
+int gkrhip_compute_h(uint64_t* h, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t n, size_t cardinality) {
+    LEASE_LANE();
+    if (n < 1) return fail("computeH: empty vectors");
+    size_t card = cardinality;
+    if (card == 0) {
+        card = 1;
+        while (card < n) card <<= 1;
+    }
+    if ((card & (card - 1)) || card < n) return fail("computeH: domain cardinality %zu is not a power of two >= %zu", card, n);
+    int logn = 0;
+    while (((size_t)1 << logn) < card) logn++;
+    if (logn == 0) {      // a domain of one point: generator 1, coset shift u = -1 (order 2): h = (a*b - c) * (-2)^-1, regular form
+        E ea, eb, ec;
+        memcpy(ea.l, a, 32);
+        memcpy(eb.l, b, 32);
+        memcpy(ec.l, c, 32);
+        if (!hfr::is_canonical(ea) || !hfr::is_canonical(eb) || !hfr::is_canonical(ec)) return fail("computeH: input is not a canonical fr.Element");
+        const E r = to_plain(hfr::mul(hfr::sub(hfr::mul(ea, eb), ec), hfr::pow_q_minus_2(hfr::sub(hfr::ZERO, hfr::from_u64(2)))));
+        memcpy(h, r.l, 32);
+        return 0;
+    }
+    ScopedTable t[3];
+    DevTable* tp[3];
+    const uint64_t* src[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) {
+        CHK(table_alloc(&t[i], card));
+        CHK(upload_table(&t[i], src[i], n));
+        if (card > n) {
+            hipLaunchKernelGGL(k_ntt_zero, dim3(grid_for(card - n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t[i].planes(), n, card);
+            HIPCHK(hipGetLastError());
+        }
+        tp[i] = &t[i];
+    }
+    CHK(compute_h_dev(tp, logn, nullptr));
+    CHK(download_table(&t[0], h, card));
+    for (int i = 0; i < 3; i++) table_release(&t[i]);
+    return 0;
+}
+
+// computeH on device-resident synthetic vectors (a[i] = Montgomery(i + 1), b[i] = Montgomery(2 i + 3), c = a * b pointwise
+// truncated to n = 2^logn - 1 entries... the values do not matter for the timing): `iters` runs after `warmup`;
+// *avg_ms = HIP-event time of one computeH on the device (transforms and pointwise step; no PCIe), *passes = passes over HBM
+// per computeH, *bytes = HBM bytes those passes move (32 B read + 32 B written per element and array named by a pass).
+int gkrhip_bench_compute_h(int logn, int warmup, int iters, double* avg_ms, int* passes, double* bytes) {
+    std::lock_guard<std::mutex> lk(g0.mu);
+    CHK(ensure_ctx());
+    if (logn < 1 || logn > 27 || iters < 1) return fail("bench_compute_h: bad arguments");
+    const size_t n = (size_t)1 << logn;
+    ScopedTable t[3];
+    DevTable* tp[3];
+    for (int i = 0; i < 3; i++) {
+        CHK(table_alloc(&t[i], n));
+        tp[i] = &t[i];
+    }
+    auto fill = [&]() {
+        for (int i = 0; i < 3; i++)
+            hipLaunchKernelGGL(k_random_fr_array, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t[i].planes(), n,
+                               (unsigned long long)(i + 1), (unsigned long long)(7 * i + 1));
+        return hipGetLastError();
+    };
+    int np = 0;
+    for (int i = 0; i < warmup; i++) {
+        HIPCHK(fill());
+        CHK(compute_h_dev(tp, logn, &np));
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    double tot = 0;
+    for (int i = 0; i < iters; i++) {
+        HIPCHK(fill());
+        HIPCHK(hipEventRecord(e0, cx().stream));
+        CHK(compute_h_dev(tp, logn, &np));
+        HIPCHK(hipEventRecord(e1, cx().stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = tot / iters;
+    const int per = (logn + 2) / 3;                 // passes of one transform
+    if (passes) *passes = np;
+    // inverse transforms: 3 arrays read+written per pass; coset transforms: 3 arrays read+written, the last pass reads 3 and writes 1;
+    // final inverse transform: 1 array
+    if (bytes) *bytes = 32.0 * (double)n * (per * 6.0 + (per - 1) * 6.0 + 4.0 + per * 2.0);
+    for (int i = 0; i < 3; i++) table_release(&t[i]);
+    return 0;
 }
 
 int gkrhip_bench_fold(size_t n, int ntab, int warmup, int iters, double* avg_ms, double* isolated_ms_or_null) {

@@ -89,6 +89,8 @@ ABI = {
     "gkrhip_bench_fold": (_I, [_SZ, _I, _I, _I, C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_bench_sumcheck": (_I, [_I, _I, _I, _I, _I, C.POINTER(_D), _P]),
     "gkrhip_bench_partial_eval": (_I, [_I, _I, _I, C.POINTER(_D), _P]),
+    "gkrhip_compute_h": (_I, [_P, _P, _P, _P, _SZ, _SZ]),
+    "gkrhip_bench_compute_h": (_I, [_I, _I, _I, C.POINTER(_D), C.POINTER(_I), C.POINTER(_D)]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -592,6 +594,25 @@ def bench_sumcheck(kind, bn, ninstance=1, warmup=1, iters=3):
     fin = np.zeros((1, 4), np.uint64)
     _check(load().gkrhip_bench_sumcheck(kind, bn, ninstance, warmup, iters, C.byref(ms), _ptr(fin)))
     return ms.value, fin
+
+
+def compute_h(a, b, c, cardinality=0):
+    """computeH(a, b, c, domain) of prover/gadget/prove.go:308-359: Montgomery (n, 4) arrays in, the domain's `cardinality`
+    REGULAR-form values out (the reference's order: coefficients of H at bit-reversed positions)."""
+    a, b, c = _fr(a), _fr(b), _fr(c)
+    n = a.shape[0]
+    assert b.shape[0] == n and c.shape[0] == n and n >= 1
+    card = cardinality or (1 << (n - 1).bit_length())
+    h = np.zeros((card, 4), np.uint64)
+    _check(load().gkrhip_compute_h(_ptr(h), _ptr(a), _ptr(b), _ptr(c), n, cardinality))
+    return h
+
+
+def bench_compute_h(logn, warmup=1, iters=3):
+    """(ms per computeH on device-resident vectors, passes over HBM, HBM bytes moved by those passes)."""
+    ms, np_, by = C.c_double(0), C.c_int(0), C.c_double(0)
+    _check(load().gkrhip_bench_compute_h(logn, warmup, iters, C.byref(ms), C.byref(np_), C.byref(by)))
+    return ms.value, np_.value, by.value
 
 
 def bench_partial_eval(bn, warmup=10, iters=200):

@@ -250,6 +250,20 @@ int gkrhip_host_limbsplit_reduce(uint64_t out[4], const uint64_t *lanes, int nla
 int gkrhip_host_mimc_hash(uint64_t out[4], const uint64_t *in, size_t n);
 int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t *M, const uint64_t c[4], const uint64_t qk[4]);
 
+/* ---- computeH: the H part of Groth16's Krs (prover/gadget/prove.go:308-359) --------------------------------------
+ * The next prover cost once GKR is fast: three inverse FFTs, three coset FFTs, the pointwise
+ * (a*b - c) * (-2)^-1, one inverse coset FFT over BN254 Fr, FromMont.  a, b, c: n Montgomery elements each (zero-padded to
+ * the domain by the library); cardinality: a power of two >= n, or 0 for the next power of two (fft.NewDomain's choice);
+ * h: `cardinality` REGULAR-form values in the reference's order (the coefficients of H at bit-reversed positions: this
+ * version of computeH does not bit-reverse after the last FFTInverse(DIF)).  The transforms are gnark-crypto's
+ * fft.Domain (un-vendored dependency, v0.6.1-0.20220110145513-493bb1c180d9): the result is pinned on that package's
+ * published algorithm and on the identity H * (X^n - 1) = A*B - C, not on bytes of the Go binary ("parity unpinned").
+ * The MSMs of the same function (prove.go:76,189,202,221,277) need curve arithmetic and are out of scope. */
+int gkrhip_compute_h(uint64_t *h, const uint64_t *a, const uint64_t *b, const uint64_t *c, size_t n, size_t cardinality);
+/* computeH on device-resident vectors: *avg_ms = HIP-event time per computeH (no PCIe), *passes = passes over HBM,
+ * *bytes = HBM bytes those passes move (32 B read + 32 B written per element of every array a pass names). */
+int gkrhip_bench_compute_h(int logn, int warmup, int iters, double *avg_ms, int *passes, double *bytes);
+
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 /* Device-resident fold micro-benchmark (shape of BenchmarkFolding, poly/multilin_test.go:55-78):
  * ntab tables of n elements (table[i] = Montgomery(i)), r = 5, `iters` timed out-of-place folds after

@@ -353,3 +353,46 @@ def test_fr_mul_variants_agree():
             c.lib.oracle_fr_mul(o1.ctypes.data, a.ctypes.data, b.ctypes.data)
             c.lib.oracle_fr_mul_generic(o2.ctypes.data, a.ctypes.data, b.ctypes.data)
             assert np.array_equal(o1, o2)
+
+
+def test_compute_h_restatement_against_schoolbook_division():
+    """oracle/pyoracle_fft.py (computeH as prover/gadget/prove.go:308-359 runs it on gnark-crypto's fft.Domain -- an
+    un-vendored dependency, so "parity unpinned") against mathematics: for satisfied constraints (c = a*b on the domain)
+    the result is the quotient (A*B - C) / (X^n - 1) by schoolbook polynomial arithmetic, at the bit-reversed positions;
+    for arbitrary c it agrees with (A*B - C) * (-2)^-1 on the odd coset; the committed fixtures are what it produces."""
+    import json
+    import random
+    import pyoracle_fft as F
+    random.seed(5)
+    for n in (1, 2, 4, 8, 16, 32):
+        dom = F.Domain(n, 1)
+        assert pow(dom.generator, n, F.Q) == 1 and (n == 1 or pow(dom.generator, n // 2, F.Q) == F.Q - 1)
+        assert pow(dom.finer_generator, n, F.Q) == F.Q - 1                 # Z = X^n - 1 is -2 on the coset
+        a = [random.randrange(F.Q) for _ in range(n)]
+        b = [random.randrange(F.Q) for _ in range(n)]
+        c = [x * y % F.Q for x, y in zip(a, b)]
+        H = F.h_by_division(a, b, c, dom)
+        assert F.compute_h(a, b, c) == [H[F.bit_reverse(p, dom.log)] for p in range(n)]
+    n = 16
+    dom = F.Domain(n, 1)
+    a, b, c = ([random.randrange(F.Q) for _ in range(n)] for _ in range(3))
+    h = F.compute_h(a, b, c)
+    Hc = [h[F.bit_reverse(k, dom.log)] for k in range(n)]
+    A, B, C = (F.interpolate_naive(v, dom) for v in (a, b, c))
+    ev = lambda P, x: sum(co * pow(x, k, F.Q) for k, co in enumerate(P)) % F.Q      # noqa: E731
+    for j in range(n):
+        x = dom.finer_generator * pow(dom.generator, j, F.Q) % F.Q
+        assert ev(Hc, x) * (F.Q - 2) % F.Q == (ev(A, x) * ev(B, x) - ev(C, x)) % F.Q
+    # FFT / FFTInverse round trips in both decimations and on the coset
+    v = [random.randrange(F.Q) for _ in range(n)]
+    w = list(v)
+    F.fft(dom, w, "DIF", 0)
+    assert [w[F.bit_reverse(i, dom.log)] for i in range(n)] == [ev(v, pow(dom.generator, i, F.Q)) for i in range(n)]
+    F.fft_inverse(dom, w, "DIT", 0)
+    assert w == v
+    F.fft(dom, w, "DIF", 1)
+    F.fft_inverse(dom, w, "DIT", 1)
+    assert w == v
+    for e in load("compute_h.json"):
+        got = F.compute_h([int(x, 16) for x in e["a"]], [int(x, 16) for x in e["b"]], [int(x, 16) for x in e["c"]], e["cardinality"] or None)
+        assert [hex(x) for x in got] == e["h"]
