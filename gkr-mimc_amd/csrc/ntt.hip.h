@@ -4,7 +4,7 @@
 //     a, b, c  <- FFT(., DIT, 1)                 three FFTs on the coset u * <g> (u of order 2n, u^2 = g), natural order out
 //     a        <- (a * b - c) * (-2)^-1          pointwise (Z = X^n - 1 is -2 on the coset)
 //     a        <- FFTInverse(a, DIF, 1)          inverse coset FFT, bit-reversed order out;  then FromMont
-// (gnark-crypto's fft.Domain, an un-vendored dependency: the algorithm is restated in oracle/pyoracle_fft.py, "parity
+// (gnark-crypto's fft.Domain, an un-vendored dependency: the algorithm is restated by the test oracle, "parity
 // unpinned").  Radix-2 butterflies, in place, up to three stages per pass held in registers (eight elements per lane): a
 // 2^24-point transform is eight passes over HBM instead of twenty-four.  The element-wise factors ride on passes that
 // exist anyway: the 1/n of the first inverse transforms and the coset shift u^rev(p) are ONE factor applied when the first
