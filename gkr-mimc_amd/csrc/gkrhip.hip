@@ -1013,9 +1013,10 @@ int gkrhip_bench_compute_h(int logn, int warmup, int iters, double* avg_ms, int*
         return hipGetLastError();
     };
     int np = 0;
+    double by = 0;
     for (int i = 0; i < warmup; i++) {
         HIPCHK(fill());
-        CHK(compute_h_dev(tp, logn, &np));
+        CHK(compute_h_dev(tp, logn, &np, &by));
     }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
@@ -1024,7 +1025,7 @@ int gkrhip_bench_compute_h(int logn, int warmup, int iters, double* avg_ms, int*
     for (int i = 0; i < iters; i++) {
         HIPCHK(fill());
         HIPCHK(hipEventRecord(e0, cx().stream));
-        CHK(compute_h_dev(tp, logn, &np));
+        CHK(compute_h_dev(tp, logn, &np, &by));
         HIPCHK(hipEventRecord(e1, cx().stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0;
@@ -1034,11 +1035,8 @@ int gkrhip_bench_compute_h(int logn, int warmup, int iters, double* avg_ms, int*
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_ms = tot / iters;
-    const int per = (logn + 2) / 3;                 // passes of one transform
     if (passes) *passes = np;
-    // inverse transforms: 3 arrays read+written per pass; coset transforms: 3 arrays read+written, the last pass reads 3 and writes 1;
-    // final inverse transform: 1 array
-    if (bytes) *bytes = 32.0 * (double)n * (per * 6.0 + (per - 1) * 6.0 + 4.0 + per * 2.0);
+    if (bytes) *bytes = by;
     for (int i = 0; i < 3; i++) table_release(&t[i]);
     return 0;
 }

@@ -98,62 +98,121 @@ int ntt_launch(const NttPassArgs& a, int R, int narr) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+// S stages in passes of at most three, as even as possible (13 -> 3 3 3 2 2)
+inline std::vector<int> ntt_split(int S) {
+    std::vector<int> v;
+    if (S <= 0) return v;
+    const int np = (S + 2) / 3;
+    for (int i = 0; i < np; i++) v.push_back(S / np + (i < S % np ? 1 : 0));
+    return v;
+}
 
 // computeH on three device tables of n = 2^logn elements (already zero-padded).  On return t[0] holds the reference's
-// result -- the coefficients of H in bit-reversed order, REGULAR form --, t[1] and t[2] are scratch.  passes_out (optional)
-// receives the number of passes over HBM (each reads and writes the arrays it names once).
-int compute_h_dev(DevTable* const* t, int logn, int* passes_out) {
+// result -- the coefficients of H in bit-reversed order, REGULAR form --, t[1] and t[2] are scratch.  passes_out / bytes_out
+// (optional): passes over HBM and the bytes they move (32 B read + 32 B written per element of every array a pass names).
+int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_out = nullptr) {
     NttDomain* dom = nullptr;
     CHK(ntt_domain(logn, &dom));
-    const int kR = 3;                                 // stages per pass (eight elements per lane)
+    // transforms of more than 2^ltile points: the ltile stages that stay inside 2^ltile consecutive elements run in the
+    // LDS-tiled kernel (one pass), the others in register passes of up to three stages
+    const int L = logn > GKR_NTT_LTILE ? GKR_NTT_LTILE : 0;
+    NttDomain* tile_dom = nullptr;
+    if (L) CHK(ntt_domain(L, &tile_dom));
     int passes = 0;
+    double bytes = 0;
+    const double arr_bytes = 32.0 * (double)((size_t)1 << logn);
+    E root_plain;
+    memcpy(root_plain.l, kRoot2_28, 32);
+    const E zeta = host_pow(hfr::mul(root_plain, hfr::R2), 1ull << (kMaxOrderRoot - 3));     // primitive 8th root of unity
+    const E zeta_inv = hfr::pow_q_minus_2(zeta);
     NttPassArgs a;
-    auto base_args = [&](int narr) {
+    auto base_args = [&](int narr, bool inverse) {
         memset(&a, 0, sizeof a);
         for (int i = 0; i < narr; i++) a.d[i] = t[i]->planes();
         a.tw = dom->tw.cplanes();
+        if (L) a.tw_tile = tile_dom->tw.cplanes();
         a.logn = logn;
+        a.ltile = L;
+        a.inverse = inverse ? 1 : 0;
+        E z = hfr::ONE;
+        for (int k = 0; k < 4; k++) {
+            a.z[k] = to_dev(z);
+            z = hfr::mul(z, inverse ? zeta_inv : zeta);
+        }
+    };
+    auto tile = [&](bool dit, int narr) -> int {
+        const dim3 grid((unsigned)((size_t)1 << (logn - L)), narr), block(GKR_BLOCK);
+        if (dit) hipLaunchKernelGGL(k_ntt_tile<true>, grid, block, 0, cx().stream, a);
+        else hipLaunchKernelGGL(k_ntt_tile<false>, grid, block, 0, cx().stream, a);
+        HIPCHK(hipGetLastError());
+        passes++;
+        bytes += 2 * narr * arr_bytes;
+        return 0;
+    };
+    const std::vector<int> split = ntt_split(logn - L);      // the register passes of one transform
+    // FFTInverse(., DIF, coset): register passes over the large distances, then the tile; `post` rides on the last store
+    auto dif_inverse = [&](int narr, int post, const E& k0, const E& k1) -> int {
+        int s0 = 0;
+        for (size_t i = 0; i < split.size(); i++) {
+            base_args(narr, true);
+            a.s0 = s0;
+            if (!L && i + 1 == split.size()) {
+                a.post = post;
+                a.k0 = to_dev(k0);
+                a.k1 = to_dev(k1);
+            }
+            CHK((ntt_launch<false, false>(a, split[i], narr)));
+            passes++;
+            bytes += 2 * narr * arr_bytes;
+            s0 += split[i];
+        }
+        if (L) {
+            base_args(narr, true);
+            a.post = post;
+            a.k0 = to_dev(k0);
+            a.k1 = to_dev(k1);
+            CHK(tile(false, narr));
+        }
+        return 0;
     };
     // 1. FFTInverse(a | b | c, DIF, 0) without its 1/n (folded into the next load)                      (:326-328)
-    for (int s0 = 0; s0 < logn; s0 += kR) {
-        base_args(3);
-        a.s0 = s0;
-        a.inverse = 1;
-        CHK((ntt_launch<false, false>(a, std::min(kR, logn - s0), 3)));
-        passes++;
-    }
+    CHK(dif_inverse(3, 0, hfr::ZERO, hfr::ZERO));
     // 2. FFT(., DIT, 1): first load multiplies position p by u^rev(p) / n, last pass does the pointwise step        (:330-347)
     const E minus_two_inv = hfr::pow_q_minus_2(hfr::sub(hfr::ZERO, hfr::from_u64(2)));
-    for (int s0 = 0; s0 < logn; s0 += kR) {
-        const bool first = s0 == 0, last = s0 + kR >= logn;
-        base_args(3);
-        a.s0 = s0;
-        if (first) {
-            a.pre = 2;
-            a.k0 = to_dev(dom->card_inv);
-            a.k1 = to_dev(hfr::mul(dom->card_inv, dom->finer));
+    const E pre_k0 = dom->card_inv, pre_k1 = hfr::mul(dom->card_inv, dom->finer);
+    if (L) {
+        base_args(3, false);
+        a.pre = 2;
+        a.k0 = to_dev(pre_k0);
+        a.k1 = to_dev(pre_k1);
+        CHK(tile(true, 3));
+    }
+    {
+        int s0 = L;
+        for (size_t i = 0; i < split.size(); i++) {
+            const bool first = !L && i == 0, last = i + 1 == split.size();
+            base_args(3, false);
+            a.s0 = s0;
+            if (first) {
+                a.pre = 2;
+                a.k0 = to_dev(pre_k0);
+                a.k1 = to_dev(pre_k1);
+            }
+            if (last) {
+                a.k2 = to_dev(minus_two_inv);
+                CHK((ntt_launch<true, true>(a, split[i], 3)));
+                bytes += 4 * arr_bytes;              // reads three arrays, writes one
+            } else {
+                CHK((ntt_launch<true, false>(a, split[i], 3)));
+                bytes += 6 * arr_bytes;
+            }
+            passes++;
+            s0 += split[i];
         }
-        if (last) {
-            a.k2 = to_dev(minus_two_inv);
-            CHK((ntt_launch<true, true>(a, std::min(kR, logn - s0), 3)));
-        } else {
-            CHK((ntt_launch<true, false>(a, std::min(kR, logn - s0), 3)));
-        }
-        passes++;
     }
     // 3. FFTInverse(a, DIF, 1): last store multiplies position p by u^-rev(p) / n and leaves Montgomery form       (:350-356)
-    for (int s0 = 0; s0 < logn; s0 += kR) {
-        base_args(1);
-        a.s0 = s0;
-        a.inverse = 1;
-        if (s0 + kR >= logn) {
-            a.post = 3;
-            a.k0 = to_dev(to_plain(dom->card_inv));
-            a.k1 = to_dev(to_plain(hfr::mul(dom->card_inv, dom->finer_inv)));
-        }
-        CHK((ntt_launch<false, false>(a, std::min(kR, logn - s0), 1)));
-        passes++;
-    }
+    CHK(dif_inverse(1, 3, to_plain(dom->card_inv), to_plain(hfr::mul(dom->card_inv, dom->finer_inv))));
     if (passes_out) *passes_out = passes;
+    if (bytes_out) *bytes_out = bytes;
     return 0;
 }

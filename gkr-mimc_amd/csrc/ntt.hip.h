@@ -6,11 +6,17 @@
 //     a        <- FFTInverse(a, DIF, 1)          inverse coset FFT, bit-reversed order out;  then FromMont
 // (gnark-crypto's fft.Domain, an un-vendored dependency: the algorithm is restated by the test oracle, "parity
 // unpinned").  Radix-2 butterflies, in place, up to three stages per pass held in registers (eight elements per lane): a
-// 2^24-point transform is eight passes over HBM instead of twenty-four.  The element-wise factors ride on passes that
+// 2^24-point transform is six passes over HBM instead of twenty-four (five register passes over the large strides, one
+// LDS-tiled pass over the eleven stages whose butterflies stay inside 2048 consecutive elements).  The element-wise factors ride on passes that
 // exist anyway: the 1/n of the first inverse transforms and the coset shift u^rev(p) are ONE factor applied when the first
 // DIT pass loads; the pointwise step is done by the LAST DIT pass, which transforms the same index group of a, b and c and
 // stores only (a*b - c) * (-2)^-1; the final 1/n, the inverse coset shift and FromMont are one factor (kept in regular
 // form, so the Montgomery product leaves the Montgomery domain) applied when the last DIF pass stores.
+// Measured (gkrhip_bench_compute_h, MI355X): 2^24 points 22.5 ms = 18 passes moving 44 GB at 1.95 TB/s (0.24 of the HBM
+// peak): the transforms are bound by integer VALU issue like the sumcheck rounds, not by HBM -- ~16 field products per
+// element and transform (12 butterflies + the products that derive a group's twiddles from three loaded ones) is ~2 x 10^9
+// products per computeH at the ~10^11 products/s the field arithmetic sustains.  With one twiddle load per butterfly and
+// every stage in register passes (the first version) the same computeH took 32 ms.
 // No MFMA: exact modular arithmetic.  One twiddle table omega^i, i < n/2, serves every stage and both directions
 // (omega^-i = -omega^(n/2 - i)).
 #pragma once
@@ -19,12 +25,15 @@
 struct NttPassArgs {
     Planes d[3];          // the arrays of this launch (blockIdx.y selects; TRIPLE: all three in one lane), in place
     CPlanes tw;           // omega^i, i < n/2 (Montgomery form)
+    CPlanes tw_tile;      // tile kernel: the twiddles of the 2^ltile-point domain, (omega^(n / 2^ltile))^i, i < 2^(ltile-1)
     int logn, s0;         // transform size, first stage of this pass
+    int ltile;            // tile kernel: log2 of the tile (the last ltile DIF stages / first ltile DIT stages)
     int inverse;          // twiddles omega^-i
     int pre, post;        // 0 none | pre 2: x *= tw[e >> 1] * (e odd ? k1 : k0), e = rev(p)   (coset shift and 1/n)
                           //        | post 1: x *= k0 | post 3: x *= inv_tw[e >> 1] * (e odd ? k1 : k0) with k0, k1 in REGULAR form
     Fr k0, k1;
     Fr k2;                // TRIPLE: (-2)^-1
+    Fr z[4];              // z[k] = zeta^k, zeta = omega^(+-n/8) the primitive 8th root of unity of this direction (z[0] = 1)
 };
 
 __device__ __forceinline__ Fr ntt_twiddle(const CPlanes& tw, int logn, bool inverse, size_t e) {      // e < n/2
@@ -34,44 +43,70 @@ __device__ __forceinline__ Fr ntt_twiddle(const CPlanes& tw, int logn, bool inve
 }
 __device__ __forceinline__ size_t ntt_rev(size_t p, int logn) { return logn ? (size_t)(__brevll((unsigned long long)p) >> (64 - logn)) : 0; }
 
-// the 2^R elements of group g of one array through R stages; x[] in, x[] out (canonical elements throughout)
-template <int R, bool DIT>
-__device__ __forceinline__ void ntt_group(const NttPassArgs& a, const Planes& d, size_t base, int lg_q, Fr (&x)[1 << R]) {
-    constexpr int E = 1 << R;
-    const size_t q = (size_t)1 << lg_q;
-#pragma unroll
-    for (int t = 0; t < E; t++) {
-        const size_t p = base + (size_t)t * q;
-        x[t] = ld_fr(d.lo, d.hi, p);
-        if (a.pre == 2) {
-            const size_t e = ntt_rev(p, a.logn);
-            const Fr f = fr_mul(ld_fr(a.tw.lo, a.tw.hi, e >> 1), (e & 1) ? a.k1 : a.k0);
-            x[t] = fr_mul(x[t], f);
-        }
+// element-wise factors of the first load / last store (p = global position)
+__device__ __forceinline__ Fr ntt_pre(const NttPassArgs& a, size_t p, const Fr& x) {
+    if (a.pre != 2) return x;
+    const size_t e = ntt_rev(p, a.logn);
+    return fr_mul(x, fr_mul(ld_fr(a.tw.lo, a.tw.hi, e >> 1), (e & 1) ? a.k1 : a.k0));
+}
+__device__ __forceinline__ Fr ntt_post(const NttPassArgs& a, size_t p, const Fr& x) {
+    if (a.post == 1) return fr_mul(x, a.k0);
+    if (a.post == 3) {
+        const size_t e = ntt_rev(p, a.logn);
+        const Fr f = fr_mul(ntt_twiddle(a.tw, a.logn, true, e >> 1), (e & 1) ? a.k1 : a.k0);   // regular form: Montgomery x regular
+        return fr_mul(x, f);                                                                   // ... and the result leaves Montgomery form
     }
+    return x;
+}
+
+// R radix-2 stages on the 2^R elements x[t] of one group (element t sits at position base + t * 2^lg_q of a transform of
+// 2^lgn points whose twiddles are `tw`; low = base mod 2^lg_q).  The twiddle of the pair (t, t + dist) of stage r is
+//     DIF:  omega^((low + (t mod 2^(R-1-r)) * q) * n / (2 d_r))  =  W_r * zeta_(R-r)^(t mod 2^(R-1-r)),   W_r = omega^(low << (s0 + r)) = W_0^(2^r)
+//     DIT:  omega^((low + (t mod 2^r) * q) * n / (2 d_r))        =  V_r * zeta_(r+1)^(t mod 2^r),          V_r = omega^(low << (lgn - 1 - lg_q - r))
+// with zeta_m a primitive 2^m-th root of unity -- launch-wide constants (a.z) -- so a group loads R twiddles instead of
+// one per butterfly (three instead of twelve for eight elements) at the price of four products by constants.
+template <int R, bool DIT>
+__device__ __forceinline__ void ntt_stages(const NttPassArgs& a, const CPlanes& tw, int lgn, size_t low, int lg_q, Fr (&x)[1 << R]) {
+    constexpr int E = 1 << R;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int dist = DIT ? (1 << r) : (1 << (R - 1 - r));                 // in units of q
-        const int lg_d = lg_q + (DIT ? r : R - 1 - r);                         // log2 of the butterfly distance
-        const int sh = a.logn - 1 - lg_d;                                      // n / (2 d)
+        const int m = DIT ? r + 1 : R - r;                                     // zeta_m: 2^m-th roots at this stage
+        const size_t e = DIT ? (low << (lgn - 1 - lg_q - r)) : (low << (lgn - lg_q - R + r));
+        const Fr w0 = ntt_twiddle(tw, lgn, a.inverse != 0, e);
+        Fr w[E / 2];                                                           // w[k] = w0 * zeta_m^k, k < 2^(m-1)
+        w[0] = w0;
+#pragma unroll
+        for (int k = 1; k < (1 << (m - 1)); k++) w[k] = fr_mul(w0, a.z[k << (3 - m)]);
 #pragma unroll
         for (int t = 0; t < E; t++) {
             if (t & dist) continue;
-            const size_t p = base + (size_t)t * q;
-            const size_t e = (p & (((size_t)1 << lg_d) - 1)) << sh;
-            const Fr w = ntt_twiddle(a.tw, a.logn, a.inverse != 0, e);
+            const Fr& wk = w[t & (dist - 1)];
             if (DIT) {
-                const Fr y = fr_mul(x[t + dist], w);
+                const Fr y = fr_mul(x[t + dist], wk);
                 const Fr s = fr_add(x[t], y);
                 x[t + dist] = fr_sub(x[t], y);
                 x[t] = s;
             } else {
                 const Fr s = fr_add(x[t], x[t + dist]);
-                x[t + dist] = fr_mul(fr_sub(x[t], x[t + dist]), w);
+                x[t + dist] = fr_mul(fr_sub(x[t], x[t + dist]), wk);
                 x[t] = s;
             }
         }
     }
+}
+
+// the 2^R elements of group g of one array through R stages; x[] out (canonical elements throughout)
+template <int R, bool DIT>
+__device__ __forceinline__ void ntt_group(const NttPassArgs& a, const Planes& d, size_t base, size_t low, int lg_q, Fr (&x)[1 << R]) {
+    constexpr int E = 1 << R;
+    const size_t q = (size_t)1 << lg_q;
+#pragma unroll
+    for (int t = 0; t < E; t++) {
+        const size_t p = base + (size_t)t * q;
+        x[t] = ntt_pre(a, p, ld_fr(d.lo, d.hi, p));
+    }
+    ntt_stages<R, DIT>(a, a.tw, a.logn, low, lg_q, x);
 }
 
 template <int R, bool DIT, bool TRIPLE>
@@ -88,29 +123,81 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_pass(NttPassArgs a) {
     Fr x[E];
     if (TRIPLE) {
         Fr y[E];
-        ntt_group<R, DIT>(a, a.d[0], base, lg_q, x);
-        ntt_group<R, DIT>(a, a.d[1], base, lg_q, y);
+        ntt_group<R, DIT>(a, a.d[0], base, low, lg_q, x);
+        ntt_group<R, DIT>(a, a.d[1], base, low, lg_q, y);
 #pragma unroll
         for (int t = 0; t < E; t++) x[t] = fr_mul(x[t], y[t]);
-        ntt_group<R, DIT>(a, a.d[2], base, lg_q, y);
+        ntt_group<R, DIT>(a, a.d[2], base, low, lg_q, y);
 #pragma unroll
         for (int t = 0; t < E; t++) x[t] = fr_mul(fr_sub(x[t], y[t]), a.k2);      // (a*b - c) * (-2)^-1   (prove.go:341-347)
     } else {
-        ntt_group<R, DIT>(a, a.d[blockIdx.y], base, lg_q, x);
+        ntt_group<R, DIT>(a, a.d[blockIdx.y], base, low, lg_q, x);
     }
     const Planes out = a.d[TRIPLE ? 0 : blockIdx.y];
 #pragma unroll
     for (int t = 0; t < E; t++) {
         const size_t p = base + (size_t)t * q;
-        Fr v = x[t];
-        if (a.post == 1) {
-            v = fr_mul(v, a.k0);
-        } else if (a.post == 3) {
-            const size_t e = ntt_rev(p, a.logn);
-            const Fr f = fr_mul(ntt_twiddle(a.tw, a.logn, true, e >> 1), (e & 1) ? a.k1 : a.k0);   // regular form: Montgomery x regular
-            v = fr_mul(v, f);                                                       // ... and the result leaves Montgomery form
-        }
+        const Fr v = ntt_post(a, p, x[t]);
         st_fr(out.lo, out.hi, p, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile kernel: the ltile stages whose butterflies stay inside an aligned block of 2^ltile consecutive elements -- the
+// LAST stages of a DIF transform, the FIRST of a DIT transform -- in ONE pass over HBM: the block is loaded into LDS with
+// fully coalesced accesses (the register passes would touch these stages with strides below a cache line), transformed
+// there as a complete 2^ltile-point transform (its twiddles are the small domain's: omega^(n / 2^ltile) generates it) in
+// sub-passes of up to three stages, and stored back.  LDS index i lives at i + (i >> 3): a lane that walks its group with
+// stride 2^lg_q then meets its neighbours' elements in different banks for every lg_q.
+// ------------------------------------------------------------------------------------------------
+#define GKR_NTT_LTILE 11
+#define GKR_NTT_TILE (1 << GKR_NTT_LTILE)
+struct NttTileShared {
+    uint4 lo[GKR_NTT_TILE + GKR_NTT_TILE / 8], hi[GKR_NTT_TILE + GKR_NTT_TILE / 8];
+};
+__device__ __forceinline__ int ntt_sw(int i) { return i + (i >> 3); }
+__device__ __forceinline__ Fr ntt_lds_ld(const NttTileShared& sh, int i) {
+    const uint4 a = sh.lo[ntt_sw(i)], b = sh.hi[ntt_sw(i)];
+    Fr r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+__device__ __forceinline__ void ntt_lds_st(NttTileShared& sh, int i, const Fr& x) {
+    sh.lo[ntt_sw(i)] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    sh.hi[ntt_sw(i)] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+template <int R, bool DIT>
+__device__ __forceinline__ void ntt_tile_subpass(const NttPassArgs& a, NttTileShared& sh, int L, int ls0) {
+    constexpr int E = 1 << R;
+    const int lg_q = DIT ? ls0 : L - ls0 - R;
+    for (int g = threadIdx.x; g < (1 << (L - R)); g += blockDim.x) {
+        const int low = g & ((1 << lg_q) - 1), high = g >> lg_q;
+        const int base = (high << (lg_q + R)) | low;
+        Fr x[E];
+#pragma unroll
+        for (int t = 0; t < E; t++) x[t] = ntt_lds_ld(sh, base + (t << lg_q));
+        ntt_stages<R, DIT>(a, a.tw_tile, L, (size_t)low, lg_q, x);
+#pragma unroll
+        for (int t = 0; t < E; t++) ntt_lds_st(sh, base + (t << lg_q), x[t]);
+    }
+}
+template <bool DIT>
+__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_tile(NttPassArgs a) {
+    __shared__ NttTileShared sh;
+    const int L = a.ltile;
+    const size_t tile0 = (size_t)blockIdx.x << L;
+    const Planes d = a.d[blockIdx.y];
+    for (int i = threadIdx.x; i < (1 << L); i += blockDim.x) ntt_lds_st(sh, i, ntt_pre(a, tile0 + i, ld_fr(d.lo, d.hi, tile0 + i)));
+    __syncthreads();
+    for (int ls0 = 0; ls0 < L; ls0 += 3) {
+        const int R = min(3, L - ls0);
+        if (R == 3) ntt_tile_subpass<3, DIT>(a, sh, L, ls0);
+        else if (R == 2) ntt_tile_subpass<2, DIT>(a, sh, L, ls0);
+        else ntt_tile_subpass<1, DIT>(a, sh, L, ls0);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < (1 << L); i += blockDim.x) {
+        const Fr v = ntt_post(a, tile0 + i, ntt_lds_ld(sh, i));
+        st_fr(d.lo, d.hi, tile0 + i, v);
     }
 }
 
