@@ -2,7 +2,7 @@
 # A/B of two builds on ONE box: default flags, then GKRHIP_EXTRA_FLAGS="$2" (rebuilt on the box), each benched twice.
 # Usage: bash tools/ab_flags.sh <tag> "<extra flags>"
 TAG=$1; FL=$2; OUT=gpurun_out/$TAG; mkdir -p $OUT
-B="--no-cpu-baseline --no-micro --no-oneshot ${AB_BENCH_ARGS:-}"
+B="--no-cpu-baseline --no-micro --no-oneshot --no-configs ${AB_BENCH_ARGS:-}"
 run() { timeout 600 python bench.py $B > $OUT/$1.json 2> $OUT/$1.err; python3 - $OUT/$1.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

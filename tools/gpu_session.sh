@@ -7,20 +7,20 @@ mkdir -p $OUT
 for step in "$@"; do
   case $step in
     tests) timeout 1800 python -m pytest tests -m gpu -x -q --durations=25 > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log ;;
-    tail4) GKRHIP_HOST_TAIL=4 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_tail4.json 2> $OUT/bench_tail4.err ;;
-    tail6) GKRHIP_HOST_TAIL=6 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_tail6.json 2> $OUT/bench_tail6.err ;;
-    solo_tail0) timeout 600 python bench.py --concurrent 1 --steps 4 --warmup 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_solo_tail0.json 2> $OUT/bench_solo_tail0.err ;;
-    solo_tail5) GKRHIP_HOST_TAIL=5 timeout 600 python bench.py --concurrent 1 --steps 4 --warmup 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_solo_tail5.json 2> $OUT/bench_solo_tail5.err ;;
+    tail4) GKRHIP_HOST_TAIL=4 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_tail4.json 2> $OUT/bench_tail4.err ;;
+    tail6) GKRHIP_HOST_TAIL=6 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_tail6.json 2> $OUT/bench_tail6.err ;;
+    solo_tail0) timeout 600 python bench.py --concurrent 1 --steps 4 --warmup 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_solo_tail0.json 2> $OUT/bench_solo_tail0.err ;;
+    solo_tail5) GKRHIP_HOST_TAIL=5 timeout 600 python bench.py --concurrent 1 --steps 4 --warmup 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_solo_tail5.json 2> $OUT/bench_solo_tail5.err ;;
     ubench) timeout 600 ./tools/ubench > $OUT/ubench.txt 2>&1; grep -E "wg/CU=(2|8)" $OUT/ubench.txt | grep -E "mont_raw|fr_mac|f52|fma64|add64f|lshladd64|mad64 " ;;
     gmimc) timeout 600 python bench.py --circuit gmimc --bn 22 --no-cpu-baseline > $OUT/bench_gmimc22.json 2> $OUT/bench_gmimc22.err ;;
     oneshot) timeout 600 python tools/pcie_inclusive.py 24 > $OUT/oneshot24.txt 2>&1; tail -3 $OUT/oneshot24.txt ;;
     bench) timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json ;;
-    bench_hwq8) GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_hwq8.json 2> $OUT/bench_hwq8.err ;;
-    rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
-    rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
-    rccl_cu8) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_cu8.json 2> $OUT/bench_rccl_cu8.err ;;
-    rccl_cu16) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=16 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_rccl_cu16.json 2> $OUT/bench_rccl_cu16.err ;;
-    shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro --no-oneshot > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
+    bench_hwq8) GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_hwq8.json 2> $OUT/bench_hwq8.err ;;
+    rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
+    rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
+    rccl_cu8) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_cu8.json 2> $OUT/bench_rccl_cu8.err ;;
+    rccl_cu16) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=16 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_cu16.json 2> $OUT/bench_rccl_cu16.err ;;
+    shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
     w8) for v in default spin25; do
           E=""; [ $v = spin25 ] && E="GKRHIP_WAIT_SPIN_US=25"
           ( time env $E python - <<'PY'

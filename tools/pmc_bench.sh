@@ -9,11 +9,11 @@ OUT=$ROOT/gpurun_out/pmc_bench
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $ROOT/bench.py --bn $BN --steps 2 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $ROOT/bench.py --bn $BN --steps 2 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/$C.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json
-res = {"bn": $BN, "command": "bench.py --bn $BN --steps 2 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot"}
+res = {"bn": $BN, "command": "bench.py --bn $BN --steps 2 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob("$OUT/%s/*/*counter_collection.csv" % c)
     vals = []
@@ -35,7 +35,7 @@ PY
 
 # VALU-side counters of the round kernels (one more pass, SQ block only)
 cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/SQ -- python3 $ROOT/bench.py --bn $BN --steps 1 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot > $OUT/SQ.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/SQ -- python3 $ROOT/bench.py --bn $BN --steps 1 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/SQ.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 fs = glob.glob("$OUT/SQ/*/*counter_collection.csv")
@@ -53,6 +53,6 @@ for key in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0))[:8]:
     rows.append({"kernel": key[0], "grid_threads": key[1], "dispatches": cnt[key], **{c: a[c] for c in sorted(a)},
                  "valu_active_fraction_of_wave_cycles": a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"] if a.get("SQ_WAVE_CYCLES") else None,
                  "valu_insts_per_wave": a["SQ_INSTS_VALU"] / a["SQ_WAVES"] if a.get("SQ_WAVES") else None})
-json.dump({"bn": $BN, "command": "bench.py --bn $BN --steps 1 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot", "kernels": rows}, open("$OUT/sq_summary.json", "w"), indent=1)
+json.dump({"bn": $BN, "command": "bench.py --bn $BN --steps 1 --warmup 0 --concurrent 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs", "kernels": rows}, open("$OUT/sq_summary.json", "w"), indent=1)
 print(json.dumps(rows[:3]))
 PY

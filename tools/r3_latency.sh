@@ -2,7 +2,7 @@
 # Round 3: A/B of the serial-latency switches on ONE box (a proof alone on the GPU).  Usage: bash tools/r3_latency.sh <tag> [bn...]
 TAG=${1:-lat}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-B="--concurrent 1 --steps 4 --warmup 2 --no-cpu-baseline --no-micro --no-oneshot"
+B="--concurrent 1 --steps 4 --warmup 2 --no-cpu-baseline --no-micro --no-oneshot --no-configs"
 for bn in ${@:-24 20}; do
   for v in "0 0 0" "1 0 0" "0 1 0" "1 1 0" "1 1 1"; do
     set -- $v
