@@ -135,6 +135,142 @@ class ClockSampler:
         return v[len(v) // 2] if v else None
 
 
+class Rendezvous:
+    """The bootstrap of a multi-rank pass without torch: the 128-byte communicator ids, the barriers and the max-over-ranks
+    of the timing travel over plain TCP sockets (rank 0 listens on MASTER_ADDR:MASTER_PORT, the other ranks connect; every
+    operation is a gather to rank 0 followed by a broadcast).  A GPU process that never imports torch loads ONE ROCm: the
+    system's libamdhip64 and librccl that libgkrhip.so was built and tested against -- torch bundles its own copies of both
+    (RCCL 2.26.6 / HIP 7.0 against the image's 7.2), and importing it first would make dlopen("librccl.so.1") resolve to
+    those.  GKRHIP_BENCH_BOOTSTRAP=gloo selects torch.distributed (gloo) instead; same operations."""
+
+    def __init__(self, rank, world, addr, port, timeout=600.0):
+        import pickle
+        import socket
+        import struct
+        self.rank, self.world, self._pickle, self._struct = rank, world, pickle, struct
+        self.peers = {}
+        deadline = time.time() + timeout
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            while len(self.peers) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(timeout)
+                r = struct.unpack("<i", self._recvn(c, 4))[0]
+                self.peers[r] = c
+            srv.close()
+        else:
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(timeout)
+            c.sendall(struct.pack("<i", rank))
+            self.peers[0] = c
+
+    @staticmethod
+    def _recvn(c, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("a rank left the rendezvous")
+            buf += chunk
+        return buf
+
+    def _send(self, c, obj):
+        data = self._pickle.dumps(obj)
+        c.sendall(self._struct.pack("<q", len(data)) + data)
+
+    def _recv(self, c):
+        n = self._struct.unpack("<q", self._recvn(c, 8))[0]
+        return self._pickle.loads(self._recvn(c, n))
+
+    def allreduce(self, value, op):
+        """op over the values of all ranks (min / max), the same result on every rank."""
+        if self.rank == 0:
+            vals = [value] + [self._recv(self.peers[r]) for r in sorted(self.peers)]
+            res = op(vals)
+            for r in sorted(self.peers):
+                self._send(self.peers[r], res)
+            return res
+        self._send(self.peers[0], value)
+        return self._recv(self.peers[0])
+
+    def broadcast(self, obj):
+        """rank 0's object on every rank."""
+        if self.rank == 0:
+            for r in sorted(self.peers):
+                self._send(self.peers[r], obj)
+            return obj
+        return self._recv(self.peers[0])
+
+    def barrier(self):
+        self.allreduce(0, max)
+
+    def close(self):
+        for c in self.peers.values():
+            try:
+                c.close()
+            except OSError:
+                pass
+
+
+class LocalRendezvous:
+    """One rank: nothing to exchange (the launcher's own store sits on MASTER_PORT)."""
+    rank, world = 0, 1
+
+    def allreduce(self, value, op):
+        return value
+
+    def broadcast(self, obj):
+        return obj
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class GlooRendezvous:
+    """The same operations over torch.distributed (gloo); torch never initialises the GPU."""
+
+    def __init__(self):
+        import datetime
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allreduce(self, value, op):
+        t = self.torch.tensor([value], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN if op is min else self.dist.ReduceOp.MAX)
+        v = float(t.item())
+        return int(v) if isinstance(value, int) else v
+
+    def broadcast(self, obj):
+        box = [obj if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
 class Job:
     """nconc resident sessions (one lane each) of the same circuit and size, proving concurrently."""
 
@@ -333,17 +469,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if args.pass_name or world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run
-        # torch.distributed carries only the bootstrap (128-byte communicator ids), the barriers and the max-over-ranks
-        # of the timing -- over gloo, so that the only RCCL in the process is the one libgkrhip dlopen()s and torch
-        # never initialises the GPU
-        import datetime
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
-        world = dist.get_world_size()
-        rank = dist.get_rank()
+        # The bootstrap carries only the 128-byte communicator ids, the barriers and the max-over-ranks of the timing.
+        if world == 1:
+            dist = LocalRendezvous()
+        elif os.environ.get("GKRHIP_BENCH_BOOTSTRAP", "tcp") == "gloo":
+            dist = GlooRendezvous()
+        else:
+            dist = Rendezvous(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")))
+        world, rank = dist.world, dist.rank
+    if args.pass_name and dist is None:
+        dist = LocalRendezvous()          # a transport at world = 1 (GKRHIP_FORCE_COLLECTIVE=1 sends every round through it)
     multi = dist is not None and world > 1
-    pass_name = args.pass_name or ("shm" if args.exchange == "shm" else "rccl_one_lane") if multi else None
+    pass_name = args.pass_name or (("shm" if args.exchange == "shm" else "rccl_one_lane") if multi else None)
 
     gk = importlib.import_module("gkr-mimc_amd")
     try:
@@ -376,32 +513,31 @@ def main():
         return n
 
     nconc = lanes_that_fit(args.circuit, bn_gpu, args.concurrent, args.steps)
-    if multi:
+    if pass_name:
         nconc = 1 if pass_name == "rccl_one_lane" else min(nconc, 8)     # at most 8 lanes per rank
     if dist is not None:
-        t = torch.tensor([nconc], dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)     # same number of lanes on every rank
-        nconc = int(t.item())
+        nconc = int(dist.allreduce(int(nconc), min))     # same number of lanes on every rank
     layers = gk.gmimc_t2_circuit() if args.circuit == "gmimc" else None
 
     def install(kind):
         """Install the library's transport for this pass (the per-round exchange lives inside the C++ round loop)."""
-        tag = [("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
-        dist.broadcast_object_list(tag, src=0)        # a name no earlier run can have left behind
+        tag = dist.broadcast(("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None)   # a name no earlier run can have left behind
         if kind == "shm":
-            gk.comm_init_shm_lanes(world, rank, nconc, "/gkrhip_bench_%s" % tag[0])
+            gk.comm_init_shm_lanes(world, rank, nconc, "/gkrhip_bench_%s" % tag)
             return
         nids = nconc if kind == "rccl_lanes" else 1
         err = ""
-        try:
-            box = [b"".join(gk.comm_unique_id().tobytes() for _ in range(nids)) if rank == 0 else None]
-        except Exception as e:      # noqa: BLE001 -- reported below, never silent
-            box, err = [None], str(e)
-        dist.broadcast_object_list(box, src=0)
-        ok = 0
-        if box[0] is not None:
+        blob = None
+        if rank == 0:
             try:
-                ids = np.frombuffer(box[0], dtype=np.uint8).copy().reshape(nids, 128)
+                blob = b"".join(gk.comm_unique_id().tobytes() for _ in range(nids))
+            except Exception as e:      # noqa: BLE001 -- reported below, never silent
+                err = str(e)
+        blob = dist.broadcast(blob)
+        ok = 0
+        if blob is not None:
+            try:
+                ids = np.frombuffer(blob, dtype=np.uint8).copy().reshape(nids, 128)
                 if kind == "rccl_tick":
                     gk.comm_init_tick(world, rank, nconc, ids[0])
                 else:
@@ -409,9 +545,7 @@ def main():
                 ok = 1
             except Exception as e:  # noqa: BLE001
                 err = str(e)
-        t = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) != 1:
+        if int(dist.allreduce(int(ok), min)) != 1:
             raise RuntimeError("RCCL communicator init failed (%s)" % (err or "on another rank"))
 
     def sync_all():
@@ -426,9 +560,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = float(dist.allreduce(float(dt), max))       # the slowest rank's time
         return dt
 
     def run_phase(job, bn_local, warmup, steps, dev):
@@ -466,7 +598,7 @@ def main():
 
     dev = local_rank if args.device is None else args.device
     try:
-        if multi:
+        if pass_name:
             install(pass_name)
         job = Job(gk, bn, nconc, layers)
         head = run_phase(job, bn_gpu, args.warmup, args.steps, dev)
@@ -479,7 +611,7 @@ def main():
         raise
     dt, latency_ms = head["dt"], head["latency_ms"]
     solo, prof, clk, flat, verified = head["solo"], head["prof"], head["clk"], head["flat"], head["verified"]
-    transport = PASS_TRANSPORT[pass_name] if multi else None
+    transport = PASS_TRANSPORT[pass_name] if pass_name else None
 
     hashes = float(1 << bn) * args.steps
     n_gpus = world if dist is not None else 1
@@ -509,7 +641,8 @@ def main():
     }
     if dist is not None:
         out["config"]["per_round_exchange"] = (transport or "") + ": all-reduce of 72 limb-split u64 lanes per sumcheck round"
-        out["config"]["bootstrap"] = "torch.distributed gloo (ids, barriers, max-over-ranks of the timing); the only RCCL in the process is the one libgkrhip dlopen()s"
+        out["config"]["bootstrap"] = ("torch.distributed gloo" if isinstance(dist, GlooRendezvous) else "plain TCP rendezvous on MASTER_ADDR:MASTER_PORT (no torch in the GPU processes: one ROCm runtime, the system's)") + \
+                                     " for the communicator ids, the barriers and the max-over-ranks of the timing"
     if solo.get("rounds"):
         out["single_proof"] = {"latency_ms": latency_ms, "hashes_per_s": float(1 << bn) / (latency_ms * 1e-3),
                                "rounds": solo["rounds"], "host_hash_ms": solo["host_hash_ms"], "host_wait_ms": solo["host_wait_ms"],
@@ -649,7 +782,7 @@ def main():
             emit(res)
         gk.comm_destroy()
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
         return
 
     if rank == 0 and not multi and not args.no_configs and args.circuit == "mimc":
@@ -742,7 +875,7 @@ def main():
     job.close()
     if dist is not None:
         gk.comm_destroy()
-        dist.destroy_process_group()
+        dist.close()
 
 
 if __name__ == "__main__":
