@@ -1093,3 +1093,15 @@ def test_soak_lanes_deterministic(gk):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "20"], capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0 and "mismatches: []" in out.stdout, out.stdout + out.stderr
+
+
+def test_soak_lanes_with_the_solo_paths_forced_on(gk):
+    """The same soak with the round-3 serial-latency paths forced on for EVERY lane (pre-launched rounds polling their
+    challenge, look-ahead kernels on second streams, the cooperative kernel): many spinning kernels, look-ahead launches and
+    mailboxes at once must neither deadlock (the in-kernel wait would time out) nor change a byte of any proof."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRE="2", GKRHIP_COOP="2", GKRHIP_PRELAUNCH_LG="30")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "15"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0 and "mismatches: []" in out.stdout, out.stdout + out.stderr

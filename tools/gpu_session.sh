@@ -1,5 +1,6 @@
 #!/bin/bash
-# One GPU-box session of the round: parity tests, default bench line, RCCL-path variants at world = 1.
+# One GPU-box session of the round: parity tests, default bench line, the transports at world = 1 (every round forced
+# through the exchange: bench.py --pass <shm|rccl_one_lane|rccl_tick|rccl_lanes>), two ranks on the one GPU.
 # Usage (from the repo root, through gpurun):  bash tools/gpu_session.sh <tag> [steps...]
 TAG=${1:-s}; shift
 OUT=gpurun_out/$TAG
@@ -16,11 +17,10 @@ for step in "$@"; do
     oneshot) timeout 600 python tools/pcie_inclusive.py 24 > $OUT/oneshot24.txt 2>&1; tail -3 $OUT/oneshot24.txt ;;
     bench) timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json ;;
     bench_hwq8) GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_hwq8.json 2> $OUT/bench_hwq8.err ;;
-    rccl0) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_pub0.json 2> $OUT/bench_rccl_pub0.err ;;
-    rccl1) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_RCCL_PUBLISH=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_pub1.json 2> $OUT/bench_rccl_pub1.err ;;
-    rccl_cu8) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=8 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_cu8.json 2> $OUT/bench_rccl_cu8.err ;;
-    rccl_cu16) GKRHIP_FORCE_COLLECTIVE=1 GKRHIP_COMM_CUS=16 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 1 --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_cu16.json 2> $OUT/bench_rccl_cu16.err ;;
-    shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --exchange shm --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
+    rccl0) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python bench.py --pass rccl_one_lane --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_one_lane.json 2> $OUT/bench_rccl_one_lane.err ;;
+    rccl1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python bench.py --pass rccl_tick --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_tick.json 2> $OUT/bench_rccl_tick.err ;;
+    rccl_lanes) GKRHIP_FORCE_COLLECTIVE=1 GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --pass rccl_lanes --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_lanes.json 2> $OUT/bench_rccl_lanes.err ;;
+    shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python bench.py --pass shm --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
     w8) for v in default spin25; do
           E=""; [ $v = spin25 ] && E="GKRHIP_WAIT_SPIN_US=25"
           ( time env $E python - <<'PY'
@@ -32,7 +32,6 @@ print([p.wait() for p in ps])
 PY
           ) > $OUT/w8_$v.log 2>&1; tail -4 $OUT/w8_$v.log; done ;;
     bench2) timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 2 --device 0 --bn 22 --steps 4 --warmup 2 > $OUT/bench_2ranks_1gpu.json 2> $OUT/bench_2ranks_1gpu.err; tail -c 1500 $OUT/bench_2ranks_1gpu.json; tail -5 $OUT/bench_2ranks_1gpu.err ;;
-    bench2_stall) GKRHIP_BENCH_RCCL_LIMIT_S=0.3 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --device 0 --bn 22 --steps 4 --warmup 2 > $OUT/bench_2ranks_stall.json 2> $OUT/bench_2ranks_stall.err; tail -c 900 $OUT/bench_2ranks_stall.json; tail -3 $OUT/bench_2ranks_stall.err ;;
     w8probe) timeout 900 python tools/w8_probe.py > $OUT/w8_probe.log 2>&1; cat $OUT/w8_probe.log ;;
     *) echo "unknown step $step" ;;
   esac
