@@ -63,8 +63,10 @@ __device__ __forceinline__ Fr ntt_post(const NttPassArgs& a, size_t p, const Fr&
 // 2^lgn points whose twiddles are `tw`; low = base mod 2^lg_q).  The twiddle of the pair (t, t + dist) of stage r is
 //     DIF:  omega^((low + (t mod 2^(R-1-r)) * q) * n / (2 d_r))  =  W_r * zeta_(R-r)^(t mod 2^(R-1-r)),   W_r = omega^(low << (s0 + r)) = W_0^(2^r)
 //     DIT:  omega^((low + (t mod 2^r) * q) * n / (2 d_r))        =  V_r * zeta_(r+1)^(t mod 2^r),          V_r = omega^(low << (lgn - 1 - lg_q - r))
-// with zeta_m a primitive 2^m-th root of unity -- launch-wide constants (a.z) -- so a group loads R twiddles instead of
-// one per butterfly (three instead of twelve for eight elements) at the price of four products by constants.
+// with zeta_m a primitive 2^m-th root of unity -- launch-wide constants (a.z) -- so a group loads R twiddles (three for eight
+// elements) and derives the other four by products with constants.  -DGKR_NTT_LOAD_TW reads all seven distinct entries
+// omega^(e_r + k * n / 2^m) instead: measured 23.9 against 22.5 ms at 2^24 points (1.18 against 1.26 ms at 2^20): neither
+// the products nor the loads alone bound the passes.
 template <int R, bool DIT>
 __device__ __forceinline__ void ntt_stages(const NttPassArgs& a, const CPlanes& tw, int lgn, size_t low, int lg_q, Fr (&x)[1 << R]) {
     constexpr int E = 1 << R;
@@ -73,11 +75,16 @@ __device__ __forceinline__ void ntt_stages(const NttPassArgs& a, const CPlanes& 
         const int dist = DIT ? (1 << r) : (1 << (R - 1 - r));                 // in units of q
         const int m = DIT ? r + 1 : R - r;                                     // zeta_m: 2^m-th roots at this stage
         const size_t e = DIT ? (low << (lgn - 1 - lg_q - r)) : (low << (lgn - lg_q - R + r));
-        const Fr w0 = ntt_twiddle(tw, lgn, a.inverse != 0, e);
-        Fr w[E / 2];                                                           // w[k] = w0 * zeta_m^k, k < 2^(m-1)
-        w[0] = w0;
+        Fr w[E / 2];                                                           // w[k] = omega^e * zeta_m^k = omega^(e + k * n / 2^m), k < 2^(m-1)
+        w[0] = ntt_twiddle(tw, lgn, a.inverse != 0, e);
 #pragma unroll
-        for (int k = 1; k < (1 << (m - 1)); k++) w[k] = fr_mul(w0, a.z[k << (3 - m)]);
+        for (int k = 1; k < (1 << (m - 1)); k++) {
+#ifndef GKR_NTT_LOAD_TW
+            w[k] = fr_mul(w[0], a.z[k << (3 - m)]);          // one load per stage, the rest by products with constants
+#else
+            w[k] = ntt_twiddle(tw, lgn, a.inverse != 0, e + ((size_t)k << (lgn - m)));      // seven loads per group of eight
+#endif
+        }
 #pragma unroll
         for (int t = 0; t < E; t++) {
             if (t & dist) continue;
