@@ -361,13 +361,19 @@ int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     }
     const size_t words = (size_t)v.world * cnt * 4;
     if (cx().lc.tick_lane >= 0) {
-        // through the ticker: the all-reduce of a vector every rank fills at its own offset
-        if (words > (size_t)kTickPayload) return fail("tick all-gather of %d elements per rank exceeds the slot", cnt);
-        unsigned long long buf[kTickPayload];
-        memset(buf, 0, sizeof(unsigned long long) * words);
-        memcpy(buf + (size_t)v.rank * cnt * 4, mine, (size_t)cnt * 32);
-        CHK(tick_allreduce(buf, (int)words));
-        memcpy(out.data(), buf, words * 8);
+        // through the ticker: the all-reduce of a vector every rank fills at its own offset, in chunks of as many elements per
+        // rank as fit a slot
+        const int per = kTickPayload / (4 * v.world);
+        if (per < 1) return fail("tick all-gather: %d ranks do not fit a slot", v.world);
+        for (int c0 = 0; c0 < cnt; c0 += per) {
+            const int cn = std::min(per, cnt - c0);
+            unsigned long long buf[kTickPayload];
+            const size_t w = (size_t)v.world * cn * 4;
+            memset(buf, 0, sizeof(unsigned long long) * w);
+            memcpy(buf + (size_t)v.rank * cn * 4, mine + c0, (size_t)cn * 32);
+            CHK(tick_allreduce(buf, (int)w));
+            for (int r = 0; r < v.world; r++) memcpy(&out[(size_t)r * cnt + c0], buf + (size_t)r * cn * 4, (size_t)cn * 32);
+        }
         return 0;
     }
     if (cx().lc.shm && !cx().lc.comm) {

@@ -121,6 +121,7 @@ struct Ctx {
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     int host_tail = 5;                         // GKRHIP_HOST_TAIL: the rounds with at most 2^h pairs run on the host (0: never); measured: -5 % single-proof latency, +1.5 % throughput
     int host_tail_solo = 4;                    // GKRHIP_HOST_TAIL_SOLO: the same for a proof that is alone on the GPU, whose small rounds are fast (cooperative kernel, pre-launched): bN = 20 107.6 ms against 110-112 with 5 and 111.5 with 3; GKRHIP_HOST_TAIL sets both
+    int host_tail_sharded = 4;                 // GKRHIP_HOST_TAIL_SHARDED: sharded local rounds: the ranks gather the tables of the round with 2^(h+1) pairs and finish on the host (0: every local round exchanged)
     // ---- serial-latency measures of a proof that is alone on the GPU (round 3) -----------------------------------
     // pre-launched rounds: round k+1's kernel is queued before the host hashes round k and polls the challenge slot
     int prelaunch = 1;                         // GKRHIP_PRELAUNCH: 0 never, 1 when the proof is alone on the GPU, 2 always
@@ -309,6 +310,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));   // an explicit setting holds for both
     if (const char* e = getenv("GKRHIP_HOST_TAIL_SOLO")) cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("GKRHIP_HOST_TAIL_SHARDED")) cx().host_tail_sharded = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("GKRHIP_SOLO_MED")) cx().solo_med = atoi(e);
     if (const char* e = getenv("GKRHIP_LAT_SPREAD")) cx().lat_spread = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
@@ -434,6 +436,7 @@ void lane_configure(Ctx* l) {
     l->force_collective = g0.force_collective;
     l->host_tail = g0.host_tail;
     l->host_tail_solo = g0.host_tail_solo;
+    l->host_tail_sharded = g0.host_tail_sharded;
     l->solo_med = g0.solo_med;
     l->lat_spread = g0.lat_spread;
     l->prelaunch = g0.prelaunch;

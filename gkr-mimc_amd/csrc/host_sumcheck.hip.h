@@ -189,7 +189,7 @@ int launch_pre() {
 // (K_lo, K_hi, S_lo, S_hi) and r_last the last challenge (the caller applies the final fold).
 int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, const E* q, const E& seed, bool collective,
                   E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
-                  bool* claim_known) {
+                  bool* claim_known, int gamma_tail = 0, bool* did_gamma = nullptr) {
     const size_t n = (size_t)1 << m;
     const double t_setup0 = now_ms();
     // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the
@@ -252,8 +252,15 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // GKRHIP_HOST_TAIL = h > 0: the device runs the rounds down to 2^(h+1) pairs, exports that round's tables and the
     // host finishes (un-sharded rounds only: the sharded local rounds exchange device-produced words)
     const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
-    const int h_want = alone ? cx().host_tail_solo : cx().host_tail;
-    const int h_tail = (!collective && h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
+    // Sharded (round 3): the host tail exists too.  The ranks gather the tables the export round leaves (2^h entries per
+    // table and rank after the fold) and every rank finishes ALL remaining rounds -- the h local ones and the log2(world)
+    // rounds over the shard bits (q[m .. m + gamma_tail)) -- on the gathered tables of 2^h * world entries: one gather
+    // instead of h + 1 exchanged device rounds and the per-layer gather of phase 2.
+    const bool sh_tail = collective && gamma_tail > 0 && did_gamma && cx().host_tail_sharded > 0 && m >= cx().host_tail_sharded + 2 &&
+                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0);
+    const int h_want = collective ? (sh_tail ? cx().host_tail_sharded : 0) : (alone ? cx().host_tail_solo : cx().host_tail);
+    const int h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
+    if (did_gamma) *did_gamma = false;
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // round whose tables go to the host
     const int m_dev = h_tail ? k_export + 1 : m;             // rounds on the device
     // pre-launched rounds: the next round's kernel is queued before this round is hashed and polls the challenge slot
@@ -451,12 +458,36 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             }
             const int mm = m - 1 - k;                  // variables left
             const double t_t0 = now_ms(), h_before = cx().prof.host_hash_ms;
+            if (sh_tail) {
+                // gather every rank's P + P folded entries; global index = local index * world + rank (the shard bits are
+                // the LOWEST index bits, bound last), eq weights over all remaining coordinates with seed 1
+                const ShardView sv = shard_view();
+                std::vector<E> mine(2 * P), all;
+                for (size_t x = 0; x < P; x++) {
+                    mine[x] = Kh[x];
+                    mine[P + x] = Sh[x];
+                }
+                CHK(coll_allgather(mine.data(), (int)(2 * P), all));
+                std::vector<E> Kg(P * sv.world), Sg(P * sv.world);
+                for (int g = 0; g < sv.world; g++)
+                    for (size_t x = 0; x < P; x++) {
+                        Kg[x * sv.world + g] = all[(size_t)g * 2 * P + x];
+                        Sg[x * sv.world + g] = all[(size_t)g * 2 * P + P + x];
+                    }
+                host_cipher_rounds(ark, mm + gamma_tail, Kg, Sg, q + k + 1, hfr::ONE, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim,
+                                   claim_known);
+                tail[0] = tail[1] = Kg[0];
+                tail[2] = tail[3] = Sg[0];
+                r_prev = chal[m + gamma_tail - 1];
+                *did_gamma = true;
+            } else {
             host_cipher_rounds(ark, mm, Kh, Sh, q + k + 1, seed, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim, claim_known);
-            cx().prof.tail_ms += (now_ms() - t_t0) - (cx().prof.host_hash_ms - h_before);
             // hand back in the shape the device path uses: the caller folds (lo, hi) with r_last
             tail[0] = tail[1] = Kh[0];
             tail[2] = tail[3] = Sh[0];
             r_prev = chal[m - 1];
+            }
+            cx().prof.tail_ms += (now_ms() - t_t0) - (cx().prof.host_hash_ms - h_before);
         }
         cx().prof.host_launch_ms += (t_l1 - t_l0) + (t_l2 - t_h1);
         cx().prof.host_wait_ms += t_w - t_l1;
@@ -502,6 +533,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     const int gamma = shard.gamma, m1 = bN - gamma;
     if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
     E c = hfr::ONE, tail[4], r_last, kv, sv;
+    bool did_gamma = false;      // the sharded host tail has run the rounds over the shard bits as well
     // running claim: known from the start when the caller vouches for it, otherwise from round 1 on
     E claim = trusted_claim ? *trusted_claim : hfr::ZERO;
     bool claim_known = trusted_claim != nullptr;
@@ -509,7 +541,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     if (m1 >= 1) {
         const E seed = gamma ? shard_seed(q + m1, gamma, shard.rank) : hfr::ONE;
         CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last,
-                          claim_p, &claim_known));
+                          claim_p, &claim_known, gamma, &did_gamma));
         kv = fold2(tail[0], tail[1], r_last);
         sv = fold2(tail[2], tail[3], r_last);
     } else {
@@ -519,7 +551,7 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
         kv = v[0];
         sv = v[1];
     }
-    if (gamma > 0) {
+    if (gamma > 0 && !did_gamma) {
         const E mine[2] = {kv, sv};
         std::vector<E> all;
         CHK(coll_allgather(mine, 2, all));
@@ -608,7 +640,8 @@ void host_linear_rounds(const GateDesc& g, const E& ark, int mm, std::vector<std
 // of 3 coefficients, tail[2t], tail[2t+1] = the two remaining entries of table t and r_last the last challenge (the
 // caller applies the final fold).
 int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const* X, const E* q, const E& seed, bool collective,
-                  E& c, E* proof, E* chal, E* tail, E& r_last, E* claim /* running claim, or nullptr */, bool* claim_known) {
+                  E& c, E* proof, E* chal, E* tail, E& r_last, E* claim /* running claim, or nullptr */, bool* claim_known,
+                  int gamma_tail = 0, bool* did_gamma = nullptr) {
     const size_t n = (size_t)1 << m;
     const int arity = g.n_in;
     // HBM-bound rounds with a few dozen registers per lane: many more lanes than the compute-bound cipher rounds
@@ -646,7 +679,12 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     if (collective) CHK(coll_buffers(256));
     const E two128 = {{0, 0, 1, 0}};
     E r_prev = hfr::ZERO;
-    const int h_tail = (!collective && cx().host_tail > 0 && m >= cx().host_tail + 2) ? std::min(cx().host_tail, kHostTailMax) : 0;
+    // sharded host tail: see cipher_rounds
+    const bool sh_tail = collective && gamma_tail > 0 && did_gamma && cx().host_tail_sharded > 0 && m >= cx().host_tail_sharded + 2 &&
+                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0);
+    const int h_want = collective ? (sh_tail ? cx().host_tail_sharded : 0) : cx().host_tail;
+    const int h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
+    if (did_gamma) *did_gamma = false;
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // see cipher_rounds
     const int m_dev = h_tail ? k_export + 1 : m;
     const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
@@ -766,9 +804,26 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             std::vector<std::vector<E>> Th(arity, std::vector<E>(P));
             for (int t = 0; t < arity; t++)
                 for (size_t x = 0; x < P; x++) Th[t][x] = fold2(tt[(size_t)t * 2 * P + x], tt[(size_t)t * 2 * P + x + P], r);
+            if (sh_tail) {
+                const ShardView sv = shard_view();
+                std::vector<E> mine((size_t)arity * P), all;
+                for (int t = 0; t < arity; t++)
+                    for (size_t x = 0; x < P; x++) mine[(size_t)t * P + x] = Th[t][x];
+                CHK(coll_allgather(mine.data(), (int)((size_t)arity * P), all));
+                std::vector<std::vector<E>> Tg(arity, std::vector<E>(P * sv.world));
+                for (int gr = 0; gr < sv.world; gr++)
+                    for (int t = 0; t < arity; t++)
+                        for (size_t x = 0; x < P; x++) Tg[t][x * sv.world + gr] = all[(size_t)gr * arity * P + (size_t)t * P + x];
+                host_linear_rounds(g, ark, m - 1 - k + gamma_tail, Tg, q + k + 1, hfr::ONE, c, proof + (size_t)3 * (k + 1), chal + k + 1, claim,
+                                   claim_known);
+                for (int t = 0; t < arity; t++) tail[2 * t] = tail[2 * t + 1] = Tg[t][0];
+                r_prev = chal[m + gamma_tail - 1];
+                *did_gamma = true;
+            } else {
             host_linear_rounds(g, ark, m - 1 - k, Th, q + k + 1, seed, c, proof + (size_t)3 * (k + 1), chal + k + 1, claim, claim_known);
             for (int t = 0; t < arity; t++) tail[2 * t] = tail[2 * t + 1] = Th[t][0];
             r_prev = chal[m - 1];
+            }
         }
     }
     if (pre_requested) CHK(launch_pre());
@@ -790,18 +845,19 @@ int sumcheck_linear_fast(const GateDesc& g, const E& ark, int bN, const DevTable
     const int gamma = shard.gamma, m1 = bN - gamma, arity = g.n_in;
     if (m1 < 0) return fail("bN %d is smaller than log2(world) %d", bN, gamma);
     E c = hfr::ONE, tail[2 * GKR_MAX_ARITY], r_last, v[GKR_MAX_ARITY];
+    bool did_gamma = false;
     E claim = trusted_claim ? *trusted_claim : hfr::ZERO;
     bool claim_known = trusted_claim != nullptr;
     E* claim_p = track_claim ? &claim : nullptr;
     if (m1 >= 1) {
         const E seed = gamma ? shard_seed(q + m1, gamma, shard.rank) : hfr::ONE;
         CHK(linear_rounds(g, ark, m1, X, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last, claim_p,
-                          &claim_known));
+                          &claim_known, gamma, &did_gamma));
         for (int t = 0; t < arity; t++) v[t] = fold2(tail[2 * t], tail[2 * t + 1], r_last);
     } else {
         CHK(gather0(X, arity, v));
     }
-    if (gamma > 0) {
+    if (gamma > 0 && !did_gamma) {
         std::vector<E> all;
         CHK(coll_allgather(v, arity, all));
         if (cx().host_tail > 0) {

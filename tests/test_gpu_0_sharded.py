@@ -123,6 +123,23 @@ def test_rccl_plumbing_world1():
 
 
 
+def test_sharded_host_tail_gather():
+    """GKRHIP_HOST_TAIL_SHARDED = h: the ranks gather the tables of the round with 2^(h+1) pairs and every rank finishes the
+    remaining local rounds AND the rounds over the shard bits on the host -- same transcript for h = 0 (every local round
+    exchanged), 1, 4 (default), 6, over the shared-memory exchange and through the ticker / a per-lane communicator at world 1."""
+    for h in ("0", "1", "6"):
+        _run_shards("shm", 4, "8,9,12", {"GKRHIP_HOST_TAIL_SHARDED": h})
+    _run_shards("shm", 2, "7,11", {"GKRHIP_HOST_TAIL_SHARDED": "3", "GKRHIP_GMAX": "8"})
+    _run_shards("shm", 8, "10,12", {"GKRHIP_HOST_TAIL_SHARDED": "2"})
+    _run_shards("tick", 1, "9,12", {"GKRHIP_FORCE_COLLECTIVE": "1", "GKRHIP_HOST_TAIL_SHARDED": "5"})     # chunked gather through the ticker
+    _run_shards("rccl", 1, "9,11", {"GKRHIP_FORCE_COLLECTIVE": "1", "GKRHIP_HOST_TAIL_SHARDED": "3"})
+    # the fused linear rounds (add / copy layers of the GMiMC circuit, registered 1-, 3- and 4-input gates) gather as well
+    _run_shards("shm", 4, "8,10", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_HOST_TAIL_SHARDED": "2"})
+    _run_shards("shm", 2, "9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_HOST_TAIL_SHARDED": "6"})
+    _run_shards("shm", 4, "9,10", {"GKR_TEST_CIRCUIT": "variadic", "GKRHIP_HOST_TAIL_SHARDED": "3"})
+    _run_shards("tick", 1, "9", {"GKRHIP_FORCE_COLLECTIVE": "1", "GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_HOST_TAIL_SHARDED": "4"})
+
+
 def test_sharded_host_tail_off():
     """GKRHIP_HOST_TAIL=0: the gathered tail rounds of a sharded sumcheck on the device instead of the host."""
     _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "0"})
