@@ -356,6 +356,8 @@ PASS_TRANSPORT = {
     "rccl_one_lane": "RCCL ncclAllReduce (ncclUint64, ncclSum) over xGMI on the lane's stream, ONE lane (one communicator)",
     "rccl_tick": "RCCL ncclAllReduce over xGMI, all lanes through the ticker (one communicator, one issuing thread, batched ticks)",
     "rccl_lanes": "RCCL ncclAllReduce over xGMI, one communicator and stream per lane (GPU_MAX_HW_QUEUES = 8)",
+    "rccl_tick_dev": "RCCL ncclAllReduce over xGMI, all lanes through the ticker, the all-reduce on device staging buffers "
+                     "(run only when the ticker pass on host-mapped buffers failed)",
 }
 
 
@@ -376,8 +378,13 @@ def orchestrate(args):
     limit_s = float(os.environ.get("GKRHIP_BENCH_PASS_LIMIT_S", "0")) or (240.0 + 3.0 * (args.steps + args.warmup))
     results = {}
     argv = [a for a in sys.argv[1:]]
-    for i, name in enumerate(passes):
+    i = -1
+    while i + 1 < len(passes):
+        i += 1
+        name = passes[i]
         env = dict(os.environ, MASTER_PORT=str(base_port + 1 + i), GKRHIP_COLL_TIMEOUT_S=os.environ.get("GKRHIP_COLL_TIMEOUT_S", "60"))
+        if name == "rccl_tick_dev":
+            env["GKRHIP_TICK_DEVICE_BUF"] = "1"
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the children rendezvous on a store of their own (rank 0's child hosts it)
         if name == "rccl_lanes":
             # one hardware queue per lane stream (ROCclr's default is 4 queues for all streams): the collective kernels of
@@ -404,6 +411,8 @@ def orchestrate(args):
                   ((res or {}).get("error") or "exit code %s" % rc)
             results[name] = {"error": why, "seconds": time.time() - t0}
             print("bench.py: pass %s failed on rank %d: %s" % (name, rank, why), file=sys.stderr)
+            if name == "rccl_tick" and "rccl_tick_dev" not in passes:
+                passes.append("rccl_tick_dev")       # the same ticker with the all-reduce on device staging buffers (every rank fails alike)
     ok_rccl = [n for n in passes if n.startswith("rccl") and "error" not in results[n]]
     code = 0 if (ok_rccl or args.exchange == "shm" or not any(n.startswith("rccl") for n in passes)) else 3
     if rank == 0:
@@ -538,7 +547,7 @@ def main():
         if blob is not None:
             try:
                 ids = np.frombuffer(blob, dtype=np.uint8).copy().reshape(nids, 128)
-                if kind == "rccl_tick":
+                if kind in ("rccl_tick", "rccl_tick_dev"):
                     gk.comm_init_tick(world, rank, nconc, ids[0])
                 else:
                     gk.comm_init_lanes(world, rank, ids)
@@ -778,7 +787,7 @@ def main():
         res = {"value": out["value"], "ms_per_step": out["ms_per_step"], "concurrent_proofs": nconc,
                "single_proof_latency_ms": latency_ms, "transport": transport,
                "proof_verified_by_native_gkr_verify": verified, "line": out}
-        if pass_name == "rccl_tick":
+        if pass_name in ("rccl_tick", "rccl_tick_dev"):
             tk, idle = gk.comm_tick_stats()
             res["tick_stats"] = {"ticks": tk, "idle_ticks": idle}
         out["roofline"] = out.get("roofline")

@@ -1396,27 +1396,86 @@ int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /
     return 0;
 }
 
-// RCCL through the ticker (host_coll.hip.h): ONE communicator for the process, `nlanes` lanes that exchange through it
-int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t id_bytes[128]) {
+// The ticker (host_coll.hip.h): ONE exchange channel for the process, `nlanes` lanes that exchange through it.
+// id_bytes != nullptr: an RCCL communicator (mode 0: all-reduce on the host-mapped buffers; mode 1: on device staging
+// buffers); shm_name != nullptr: a host all-reduce through a POSIX shared-memory segment (several ranks on one GPU: tests).
+static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* id_bytes, int mode, const char* shm_name) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
     CHK(comm_common(world, rank, nlanes));
     if (nlanes > kTickMaxLanes) return fail("comm_init_tick: at most %d lanes", kTickMaxLanes);
     if (g_ticker) return fail("a ticker is already running");
-    CHK(coll_load());
     Ticker* t = new Ticker();
     t->nlanes = nlanes;
     t->world = world;
-    ncclUniqueId id;
-    memcpy(&id, id_bytes, 128);
-    {
+    t->rank = rank;
+    t->dev_buf = mode == 1;
+    const size_t total = kTickHeader + (size_t)nlanes * kTickStride;
+    if (id_bytes) {
+        CHK(coll_load());
+        ncclUniqueId id;
+        memcpy(&id, id_bytes, 128);
         ncclResult_t r = gc.p_init(&t->comm, world, id, rank);
         if (r != ncclSuccess) {
             delete t;
             return fail("ncclCommInitRank failed: %s", gc.p_errstr ? gc.p_errstr(r) : "?");
         }
+    } else {
+        // the lanes' shm_attach machinery on a throw-away lane context: creates / maps / validates the segment
+        Ctx tmp;
+        UseLane u(&tmp);
+        const size_t saved = 0;
+        (void)saved;
+        const size_t bytes = 4096 + sizeof(unsigned long long) * total * world;
+        int fd = -1;
+        const double t_start = now_ms();
+        if (rank == 0) {
+            (void)shm_unlink(shm_name);
+            fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+                delete t;
+                return fail("shm_open/ftruncate(%s) failed", shm_name);
+            }
+        } else {
+            for (;;) {
+                fd = shm_open(shm_name, O_RDWR, 0600);
+                struct stat st;
+                if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+                if (fd >= 0) close(fd);
+                if (now_ms() - t_start > coll_timeout_ms()) {
+                    delete t;
+                    return fail("shm segment %s did not appear", shm_name);
+                }
+                usleep(1000);
+            }
+        }
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) {
+            delete t;
+            return fail("mmap of %s failed", shm_name);
+        }
+        t->shm = (ShmHdr*)p;
+        t->shm_slots = (unsigned long long*)((char*)p + 4096);
+        t->shm_bytes = bytes;
+        t->shm_name = shm_name;
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        if (rank == 0) {
+            t->shm->magic.store(kShmMagic ^ (unsigned long long)ts.tv_sec, std::memory_order_release);
+        } else {
+            for (;;) {     // a name of this run only (the callers use fresh names): wait for rank 0's stamp
+                const unsigned long long m = t->shm->magic.load(std::memory_order_acquire);
+                if (m != 0) break;
+                if (now_ms() - t_start > coll_timeout_ms()) {
+                    munmap(p, bytes);
+                    delete t;
+                    return fail("shm segment %s was never initialised by rank 0", shm_name);
+                }
+                usleep(1000);
+            }
+        }
     }
-    const size_t total = kTickHeader + (size_t)nlanes * kTickStride;
     hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(&t->h_send, sizeof(unsigned long long) * total, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostMalloc(&t->h_recv, sizeof(unsigned long long) * total, hipHostMallocMapped | hipHostMallocCoherent);
@@ -1424,8 +1483,10 @@ int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t id_byte
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_send, t->h_send, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_recv, t->h_recv, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_done, t->h_done, 0);
+    if (e == hipSuccess && t->dev_buf) e = hipMalloc(&t->d_stage_send, sizeof(unsigned long long) * total);
+    if (e == hipSuccess && t->dev_buf) e = hipMalloc(&t->d_stage_recv, sizeof(unsigned long long) * total);
     if (e != hipSuccess) {
-        (void)gc.p_destroy(t->comm);
+        if (t->comm) (void)gc.p_destroy(t->comm);
         delete t;
         return fail("comm_init_tick: %s", hipGetErrorString(e));
     }
@@ -1442,6 +1503,18 @@ int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t id_byte
     g_ticker = t;
     t->th = std::thread(ticker_main, t, g0.device);
     return 0;
+}
+int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t id_bytes[128]) {
+    if (!id_bytes) return fail("comm_init_tick: no unique id");
+    static const int mode = [] {
+        const char* e = getenv("GKRHIP_TICK_DEVICE_BUF");
+        return e ? atoi(e) : 0;
+    }();
+    return comm_init_tick_impl(world, rank, nlanes, id_bytes, mode, nullptr);
+}
+int gkrhip_comm_init_tick_shm(int world, int rank, int nlanes, const char* name) {
+    if (!name) return fail("comm_init_tick_shm: no segment name");
+    return comm_init_tick_impl(world, rank, nlanes, nullptr, 0, name);
 }
 // ticks issued / ticks in which no lane of any rank had words (measurement)
 int gkrhip_comm_tick_stats(uint64_t* ticks, uint64_t* idle_ticks) {
@@ -1498,6 +1571,13 @@ int gkrhip_comm_destroy(void) {
         if (t->th.joinable()) t->th.join();
         (void)hipStreamSynchronize(t->stream);
         if (t->comm) (void)gc.p_destroy(t->comm);
+        if (t->shm) {
+            t->shm->abort.store(1, std::memory_order_release);
+            munmap((void*)t->shm, t->shm_bytes);
+            if (t->rank == 0) (void)shm_unlink(t->shm_name.c_str());     // every ticker has left (they stop together)
+        }
+        if (t->d_stage_send) (void)hipFree(t->d_stage_send);
+        if (t->d_stage_recv) (void)hipFree(t->d_stage_recv);
         (void)hipStreamDestroy(t->stream);
         (void)hipHostFree(t->h_send);
         (void)hipHostFree(t->h_recv);

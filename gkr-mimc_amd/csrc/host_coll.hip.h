@@ -207,6 +207,16 @@ struct Ticker {
     int nlanes = 0, world = 1;
     unsigned long long *h_send = nullptr, *d_send = nullptr, *h_recv = nullptr, *d_recv = nullptr;
     unsigned int *h_done = nullptr, *d_done = nullptr;
+    // transport of a tick: ncclAllReduce on the host-mapped buffers (default) | ncclAllReduce on device staging buffers with
+    // copies around it (dev_buf: insurance should a RCCL build refuse host-mapped user buffers) | a host all-reduce through
+    // a POSIX shared-memory segment (shm: the SAME ticker logic with several ranks on one GPU, which RCCL cannot do -- tests)
+    bool dev_buf = false;
+    unsigned long long *d_stage_send = nullptr, *d_stage_recv = nullptr;
+    ShmHdr* shm = nullptr;
+    unsigned long long* shm_slots = nullptr;
+    size_t shm_bytes = 0;
+    std::string shm_name;
+    int rank = 0;
     TickSlot slot[kTickMaxLanes];
     bool in_flight[kTickMaxLanes] = {false};
     std::thread th;
@@ -221,6 +231,32 @@ void ticker_fail(Ticker* t, const std::string& why) {
     std::lock_guard<std::mutex> lk(t->err_mu);
     if (!t->failed.load()) t->error = why;
     t->failed.store(true, std::memory_order_release);
+}
+
+// barrier of the ticker's own shared-memory segment (the lanes' shm_barrier works on the current lane's segment)
+bool ticker_shm_barrier(Ticker* t) {
+    ShmHdr* h = t->shm;
+    const unsigned gen = h->gen.load(std::memory_order_acquire);
+    if (h->abort.load(std::memory_order_acquire)) return false;
+    if (h->arrive.fetch_add(1, std::memory_order_acq_rel) == (unsigned)t->world - 1) {
+        h->arrive.store(0, std::memory_order_relaxed);
+        h->gen.fetch_add(1, std::memory_order_release);
+        return true;
+    }
+    const double t0 = now_ms();
+    unsigned long spins = 0;
+    while (h->gen.load(std::memory_order_acquire) == gen) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfff) != 0) continue;
+        if (h->abort.load(std::memory_order_acquire)) return h->gen.load(std::memory_order_acquire) != gen;
+        if (now_ms() - t0 > coll_timeout_ms()) {
+            h->abort.store(1, std::memory_order_release);
+            return false;
+        }
+        struct timespec ts = {0, 2000};
+        nanosleep(&ts, nullptr);       // several ranks' tickers share the cores of one box in the tests
+    }
+    return true;
 }
 
 void ticker_main(Ticker* t, int device) {
@@ -258,13 +294,38 @@ void ticker_main(Ticker* t, int device) {
         }
         __sync_synchronize();
         ++tick_id;
-        ncclResult_t r = gc.p_allreduce(t->d_send, t->d_recv, total, ncclUint64, ncclSum, t->comm, t->stream);
+        if (t->shm) {
+            // host all-reduce: slot write, barrier, sum, barrier
+            memcpy(t->shm_slots + (size_t)t->rank * total, t->h_send, sizeof(unsigned long long) * total);
+            if (!ticker_shm_barrier(t)) {
+                ticker_fail(t, "ticker: a peer rank failed or left (shared-memory tick)");
+                break;
+            }
+            for (size_t i = 0; i < total; i++) {
+                unsigned long long sum = 0;
+                for (int r = 0; r < t->world; r++) sum += t->shm_slots[(size_t)r * total + i];
+                t->h_recv[i] = sum;
+            }
+            if (!ticker_shm_barrier(t)) {
+                ticker_fail(t, "ticker: a peer rank failed or left (shared-memory tick)");
+                break;
+            }
+        } else {
+        unsigned long long* sb = t->dev_buf ? t->d_stage_send : t->d_send;
+        unsigned long long* rb = t->dev_buf ? t->d_stage_recv : t->d_recv;
+        if (t->dev_buf && hipMemcpyAsync(sb, t->h_send, sizeof(unsigned long long) * total, hipMemcpyHostToDevice, t->stream) != hipSuccess) {
+            ticker_fail(t, "ticker: staging copy failed");
+            break;
+        }
+        ncclResult_t r = gc.p_allreduce(sb, rb, total, ncclUint64, ncclSum, t->comm, t->stream);
         if (r != ncclSuccess) {
             ticker_fail(t, std::string("ticker: ncclAllReduce failed: ") + (gc.p_errstr ? gc.p_errstr(r) : "?"));
             break;
         }
-        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, t->stream, (const unsigned long long*)t->d_recv, t->d_recv, 0, t->d_done, tick_id);
-        {   // completion: the flag kernel is ordered behind the all-reduce on the ticker's stream
+        // the reduced words reach the host buffer (a copy kernel in staging mode), then the flag: ordered behind the all-reduce
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, t->stream, (const unsigned long long*)rb, t->d_recv,
+                           t->dev_buf ? (int)total : 0, t->d_done, tick_id);
+        {
             const double t0 = now_ms();
             unsigned long spins = 0;
             while (*(volatile unsigned int*)t->h_done != tick_id) {
@@ -283,6 +344,7 @@ void ticker_main(Ticker* t, int device) {
             }
             if (t->failed.load()) break;
             __sync_synchronize();
+        }
         }
         t->ticks.fetch_add(1, std::memory_order_relaxed);
         bool progressed = false;

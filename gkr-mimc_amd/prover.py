@@ -79,6 +79,7 @@ ABI = {
     "gkrhip_comm_init_lanes": (_I, [_I, _I, _I, _P]),
     "gkrhip_comm_init_shm_lanes": (_I, [_I, _I, _I, C.c_char_p]),
     "gkrhip_comm_init_tick": (_I, [_I, _I, _I, _P]),
+    "gkrhip_comm_init_tick_shm": (_I, [_I, _I, _I, C.c_char_p]),
     "gkrhip_comm_tick_stats": (_I, [C.POINTER(_U64), C.POINTER(_U64)]),
     "gkrhip_comm_destroy": (_I, []),
     "gkrhip_comm_info": (_I, [C.POINTER(_I), C.POINTER(_I)]),
@@ -541,6 +542,11 @@ def comm_init_tick(world, rank, nlanes, unique_id):
     """nlanes lanes over ONE RCCL communicator (the ticker): deterministic order of collectives on every rank."""
     uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
     _check(load().gkrhip_comm_init_tick(world, rank, nlanes, _ptr(uid)))
+
+
+def comm_init_tick_shm(world, rank, nlanes, name):
+    """The ticker with its tick all-reduce over host shared memory (several ranks on one GPU: tests)."""
+    _check(load().gkrhip_comm_init_tick_shm(world, rank, nlanes, name.encode()))
 
 
 def comm_tick_stats():

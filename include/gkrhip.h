@@ -238,6 +238,12 @@ int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char *name
  * queues; DESIGN.md section 6 has the argument).  A lane's exchange completes in the first tick in which every rank
  * contributed to its slot.  This is the multi-lane RCCL transport of bench.py. */
 int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t unique_id[128]);
+/* The same ticker with the tick's all-reduce done on the host through a POSIX shared-memory segment `name` (ranks of one
+ * node): every line of the ticker's logic -- slots, counts, re-contribution, votes to stop -- with several ranks sharing
+ * ONE GPU, which RCCL cannot do; this is how the multi-rank behaviour of the ticker is tested on a single-GPU box.
+ * (GKRHIP_TICK_DEVICE_BUF=1 makes gkrhip_comm_init_tick run ncclAllReduce on device staging buffers with copies around it
+ * instead of on the host-mapped buffers.) */
+int gkrhip_comm_init_tick_shm(int world, int rank, int nlanes, const char *name);
 int gkrhip_comm_tick_stats(uint64_t *ticks, uint64_t *idle_ticks);
 int gkrhip_comm_destroy(void);
 int gkrhip_comm_info(int *world, int *rank);

@@ -164,6 +164,8 @@ def main():
     nlanes = int(os.environ.get("GKR_TEST_LANES", "1"))
     if mode == "shm":
         gk.comm_init_shm_lanes(world, rank, nlanes, name)
+    elif mode == "tickshm":    # the ticker's logic with several ranks on the one GPU: its tick is a host all-reduce through shared memory
+        gk.comm_init_tick_shm(world, rank, nlanes, name + "_tick")
     elif mode == "tick":       # all lanes over one RCCL communicator (1-rank communicator: every exchange is a real ncclAllReduce)
         gk.comm_init_tick(1, 0, nlanes, gk.comm_unique_id())
     else:

@@ -80,6 +80,21 @@ def test_rccl_ticker_world1_forced():
     _run_shards("tick", 1, "20", dict(env, GKR_TEST_DIGEST="1"))
 
 
+def test_ticker_multi_rank_over_shared_memory():
+    """The ticker with 2, 4 and 8 ranks on the one GPU (its tick all-reduce done on the host through shared memory; everything
+    else -- slots, counts, contributing again until every rank is there, lanes of different ranks out of phase, the chunked
+    gather, the votes to stop -- is the code an 8-GPU run executes): one and several lanes per rank, MiMC and GMiMC, against the
+    oracle, and the bN = 22 digest over 2 ranks."""
+    _run_shards("tickshm", 2, "1,2,5,9,11")
+    _run_shards("tickshm", 4, "2,3,8,11")
+    _run_shards("tickshm", 8, "3,4,9")
+    _run_shards("tickshm", 2, "4,9,11", {"GKR_TEST_LANES": "3"})
+    _run_shards("tickshm", 4, "9,10", {"GKR_TEST_LANES": "2", "GKRHIP_HOST_TAIL_SHARDED": "0"})
+    _run_shards("tickshm", 2, "3,9", {"GKR_TEST_CIRCUIT": "gmimc"})
+    _run_shards("tickshm", 2, "22", {"GKR_TEST_DIGEST": "1"})
+    _run_shards("tick", 1, "9,12", {"GKRHIP_FORCE_COLLECTIVE": "1", "GKRHIP_TICK_DEVICE_BUF": "1", "GKR_TEST_LANES": "4"})
+
+
 def test_sharded_prover_full_size_digests():
     """BASELINE config 3's size through the sharded driver: 8 ranks time-sharing the GPU (2^21-entry shards, the
     per-round exchange over shared memory) at bN = 24, and 2 ranks at bN = 22; the transcript must be the one the C
