@@ -12,9 +12,9 @@ N > 1: launched by torch.distributed.run, one rank per GPU; ONE proof of 2^26 ha
 N = 8: a 2^23-entry shard per GPU) sharded on the low index bits, the per-round sum of the round-polynomial
 words all-reduced with RCCL (north_star's transport).  The rank processes the launcher starts never touch the GPU: each
 runs the K steps as a sequence of PASSES, every pass in a fresh child process (own rendezvous port), so that a pass that
-fails or stalls is killed and the next one still runs: (1) host shared-memory exchange (one node), (2) RCCL with ONE
-lane (one communicator: no ordering question), (3) RCCL with several lanes through the ticker (one communicator, one
-issuing thread), (4) RCCL with one communicator per lane.  `value` is the best RCCL pass; every pass is in the line
+fails or stalls is killed and the next one still runs: (1) host shared-memory exchange (one node), (1b) the same through the
+ticker (its logic with the tick all-reduce on the host), (2) RCCL with ONE lane (one communicator: no ordering question),
+(3) RCCL with several lanes through the ticker (one communicator, one issuing thread), (4) RCCL with one communicator per lane.  `value` is the best RCCL pass; every pass is in the line
 ("passes").  If no RCCL pass succeeds the line is still printed, from the shared-memory pass, marked "degraded":
 "rccl_failed" with n_gpus_rccl = 0, and bench.py exits with code 3.  --weak keeps 2^bn entries per GPU instead.
 Prints ONE JSON line on rank 0.
@@ -350,9 +350,10 @@ def parse_args():
     return ap.parse_args()
 
 
-DEFAULT_PASSES = ["shm", "rccl_one_lane", "rccl_tick", "rccl_lanes"]
+DEFAULT_PASSES = ["shm", "shm_tick", "rccl_one_lane", "rccl_tick", "rccl_lanes"]
 PASS_TRANSPORT = {
     "shm": "host shared memory (one node): the ranks add the 576-byte round sums on the host",
+    "shm_tick": "host shared memory (one node), all lanes through the ticker: the ticker's logic with its tick all-reduce done on the host",
     "rccl_one_lane": "RCCL ncclAllReduce (ncclUint64, ncclSum) over xGMI on the lane's stream, ONE lane (one communicator)",
     "rccl_tick": "RCCL ncclAllReduce over xGMI, all lanes through the ticker (one communicator, one issuing thread, batched ticks)",
     "rccl_lanes": "RCCL ncclAllReduce over xGMI, one communicator and stream per lane (GPU_MAX_HW_QUEUES = 8)",
@@ -374,7 +375,7 @@ def orchestrate(args):
     elif args.exchange == "shm":
         passes = ["shm"]
     else:
-        passes = [p for p in DEFAULT_PASSES if p != "shm" or one_node]
+        passes = [p for p in DEFAULT_PASSES if not p.startswith("shm") or one_node]
     limit_s = float(os.environ.get("GKRHIP_BENCH_PASS_LIMIT_S", "0")) or (240.0 + 3.0 * (args.steps + args.warmup))
     results = {}
     argv = [a for a in sys.argv[1:]]
@@ -533,6 +534,9 @@ def main():
         tag = dist.broadcast(("%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None)   # a name no earlier run can have left behind
         if kind == "shm":
             gk.comm_init_shm_lanes(world, rank, nconc, "/gkrhip_bench_%s" % tag)
+            return
+        if kind == "shm_tick":
+            gk.comm_init_tick_shm(world, rank, nconc, "/gkrhip_bench_tick_%s" % tag)
             return
         nids = nconc if kind == "rccl_lanes" else 1
         err = ""
@@ -787,7 +791,7 @@ def main():
         res = {"value": out["value"], "ms_per_step": out["ms_per_step"], "concurrent_proofs": nconc,
                "single_proof_latency_ms": latency_ms, "transport": transport,
                "proof_verified_by_native_gkr_verify": verified, "line": out}
-        if pass_name in ("rccl_tick", "rccl_tick_dev"):
+        if pass_name in ("rccl_tick", "rccl_tick_dev", "shm_tick"):
             tk, idle = gk.comm_tick_stats()
             res["tick_stats"] = {"ticks": tk, "idle_ticks": idle}
         out["roofline"] = out.get("roofline")

@@ -62,7 +62,7 @@ def test_multi_rank_line_is_marked_when_no_rccl_pass_succeeded():
         return
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["degraded"] == "rccl_failed" and d["n_gpus_rccl"] == 0 and d["value_transport"] == "shm"
-    assert d["headline_pass"] == "shm" and set(d["passes"]) - {"rccl_tick_dev"} == {"shm", "rccl_one_lane", "rccl_tick", "rccl_lanes"}
+    assert d["headline_pass"] == "shm" and set(d["passes"]) - {"rccl_tick_dev", "shm_tick"} == {"shm", "rccl_one_lane", "rccl_tick", "rccl_lanes"}
     assert all("error" in d["passes"][p] for p in ("rccl_one_lane", "rccl_tick", "rccl_lanes")) and d["passes"]["shm"]["value"] > 0
 
 
@@ -72,3 +72,36 @@ def test_bench_defaults_finish_quickly():
     import sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_bench_rendezvous_over_tcp():
+    """bench.py's torch-free bootstrap of a multi-rank pass (ids, barriers, min / max over the ranks) with three processes on
+    127.0.0.1: broadcast of rank 0's object, min and max all-reduces, barriers, in the order a pass uses them."""
+    import socket
+    import subprocess
+    import sys
+    import textwrap
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import bench
+        rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        r = bench.Rendezvous(rank, world, "127.0.0.1", port, timeout=60)
+        assert r.allreduce(5 - rank, min) == 5 - (world - 1)
+        blob = r.broadcast(b"x" * 384 if rank == 0 else None)
+        assert blob == b"x" * 384
+        assert r.allreduce(1 if rank != 1 else 0, min) == 0
+        r.barrier()
+        assert abs(r.allreduce(0.25 * (rank + 1), max) - 0.25 * world) < 1e-12
+        r.barrier()
+        r.close()
+        print("RDV-OK", rank)
+    """ % ROOT)
+    ps = [subprocess.Popen([sys.executable, "-c", code, str(k), "3", str(port)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+          for k in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in ps]
+    for k, (p, o) in enumerate(zip(ps, outs)):
+        assert p.returncode == 0 and "RDV-OK %d" % k in o, o
