@@ -144,8 +144,21 @@ struct ChalGuard {
         for (int i = 0; i < GKR_CHAL_WORDS; i++) w[i] = (unsigned long long)GKR_CHAL_ABORT << 32;
         __sync_synchronize();
         (void)hipStreamSynchronize(cx().stream);
+        // the abort tags must not outlive the launch they were meant for: the next pre-launched kernel of this lane polls
+        // the slot (and the device mailbox the tags were forwarded to) before any new challenge is published
+        for (int i = 0; i < GKR_CHAL_WORDS; i++) w[i] = 0;
+        __sync_synchronize();
+        (void)hipMemsetAsync(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS, cx().stream);
+        (void)hipStreamSynchronize(cx().stream);
     }
 };
+
+// test hook, see cipher_rounds
+const int g_test_fail_round = [] {
+    const char* e = getenv("GKRHIP_TEST_FAIL_AFTER_PRELAUNCH");
+    return e ? atoi(e) : -1;
+}();
+std::atomic<bool> g_test_fail_armed{true};
 
 // Queue k_cipher_pre for the layer gkr.Prove announced (cx().req_*) on the lane's look-ahead stream.
 int launch_pre() {
@@ -398,6 +411,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             CHK(launch_pre());
             pre_requested = false;
         }
+        // test hook (GKRHIP_TEST_FAIL_AFTER_PRELAUNCH=k, once per process): an error return while a pre-launched kernel is
+        // waiting for its challenge -- the guard must tell it to leave, drain the stream and clear the abort tags
+        if (prelaunched && k == g_test_fail_round && g_test_fail_armed.exchange(false)) return fail("injected failure after a pre-launch (test hook)");
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
         unsigned long long summed[GKR_CR_WORDS];

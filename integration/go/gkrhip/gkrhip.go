@@ -181,6 +181,20 @@ func SumcheckVerify(claims, proof []fr.Element, bN, nCoeff int) (challenges []fr
 	return challenges[:bN], finalClaim, recombChal, nil
 }
 
+// ComputeH is computeH's body (prover/gadget/prove.go:308-359): the three inverse FFTs, the three coset FFTs, the pointwise
+// (a*b - c) * (-2)^-1 and the inverse coset FFT over fft.NewDomain(cardinality, 1, .) on the device.  a, b, c are the solved
+// R1CS vectors (Montgomery elements, len <= cardinality; the library pads with zeros as computeH does); the result has
+// `cardinality` elements holding REGULAR-form values at bit-reversed positions, exactly what the reference returns after its
+// FromMont loop (prove.go:352-356).
+func ComputeH(a, b, c []fr.Element, cardinality uint64) []fr.Element {
+	if len(b) != len(a) || len(c) != len(a) {
+		panic("gkrhip: computeH: a, b, c differ in length")
+	}
+	h := make([]fr.Element, cardinality)
+	must(C.gkrhip_compute_h(ptr(h), ptr(a), ptr(b), ptr(c), C.size_t(len(a)), C.size_t(cardinality)))
+	return h
+}
+
 // Layer mirrors circuit.Layer for the library: Gate < 0 marks an input layer.
 type Layer struct {
 	Gate int

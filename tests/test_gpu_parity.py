@@ -403,6 +403,39 @@ def test_cooperative_small_rounds(gk):
     _run_case({"GKRHIP_COOP": "0", "GKRHIP_CASE_EXPECT_NOT": "coop_rounds"}, "3,9,12")
 
 
+def test_error_while_a_prelaunched_kernel_waits(gk):
+    """An error return between the pre-launch of a round and the publication of its challenge (injected by a test hook):
+    the call fails with that error, the waiting kernel is told to leave, and the NEXT proofs on the same lane -- whose
+    pre-launched kernels poll the same slot and mailbox -- are bit-exact again (the abort tags were cleared)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, sys
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import coracle as c
+        gk = importlib.import_module("gkr-mimc_amd")
+        gk.init(0)
+        bn = 12
+        s = gk.MimcSession(bn); s.synth_inputs(); s.assign()
+        qp = c.random_fr_array(bn)
+        try:
+            s.prove(qp)
+            raise SystemExit("the injected failure did not surface")
+        except gk.GkrHipError as e:
+            assert "injected failure" in str(e), e
+        i0 = c.random_fr_array(1 << bn)
+        want = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)[0]
+        for _ in range(3):
+            assert np.array_equal(s.prove(qp), want)
+        assert gk.profile_get()["prelaunched_rounds"] > 0
+        print("ABORT-PATH-OK")
+    """ % (root, os.path.join(root, "oracle")))
+    env = dict(os.environ, GKRHIP_TEST_FAIL_AFTER_PRELAUNCH="3", GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ABORT-PATH-OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_lookahead_round0(gk):
     """The q-independent products of a cipher layer's round 0 computed during the previous layer (k_cipher_pre on the
     look-ahead stream) and consumed by k_cipher_round_wide<false, ., true>: same transcript, early and late lane
