@@ -1421,11 +1421,7 @@ static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* i
             return fail("ncclCommInitRank failed: %s", gc.p_errstr ? gc.p_errstr(r) : "?");
         }
     } else {
-        // the lanes' shm_attach machinery on a throw-away lane context: creates / maps / validates the segment
-        Ctx tmp;
-        UseLane u(&tmp);
-        const size_t saved = 0;
-        (void)saved;
+        // rank 0 creates the segment (header + one tick buffer per rank), the others map it once it has its size
         const size_t bytes = 4096 + sizeof(unsigned long long) * total * world;
         int fd = -1;
         const double t_start = now_ms();

@@ -536,22 +536,6 @@ int table_alloc(DevTable* t, size_t cap) {
     t->cap = cap;
     return 0;
 }
-// large transient buffers (boundary staging): same policy as the arena -- on failure give the cached tables
-// back to the driver and retry once
-int staging_alloc(uint4** p, size_t bytes) {
-    hipError_t e = hipMalloc((void**)p, bytes);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        {
-            std::lock_guard<std::mutex> lk(g_pool.mu);
-            for (auto& f : g_pool.free_list) (void)hipFree(f.second);
-            g_pool.free_list.clear();
-        }
-        e = hipMalloc((void**)p, bytes);
-        if (e != hipSuccess) return fail("hipMalloc of a %zu-byte staging buffer failed: %s", bytes, hipGetErrorString(e));
-    }
-    return 0;
-}
 void table_release(DevTable* t) {
     if (t->base) {
         std::lock_guard<std::mutex> lk(g_pool.mu);

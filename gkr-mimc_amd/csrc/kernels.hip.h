@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_reduce_partials(const unsigned lo
         red[threadIdx.x] = s;
         __syncthreads();
         for (int off = GKR_BLOCK / 2; off >= 1; off >>= 1) {
-            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
             __syncthreads();
         }
         if (threadIdx.x == 0) out[k] = red[0];
