@@ -61,10 +61,33 @@ __device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, siz
 __global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
     eq_suffix_pyramid_body(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
-// up to three pyramids of a layer in one launch (blockIdx.y selects; unused slots have max_level < 0)
+// up to four pyramids of a layer in one launch (blockIdx.y selects; unused slots have max_level < 0)
 struct PyramidArgs3 {
-    PyramidArgs p[3];
+    PyramidArgs p[4];
 };
+// The upper levels of a wide pyramid without the long chains: level s > lo_level of the pyramid over q[.. nc) is
+//     level_s[idx] = level_lo[idx mod 2^lo_level] * H_(s - lo_level)[idx >> lo_level],
+// H being the (small) pyramid over the next coordinates q[.. nc - lo_level).  k_eq_suffix_pyramids builds the levels up to
+// lo_level and H with short chains on few threads; this kernel fills levels lo_level + 1 .. hi_level with ONE product per
+// entry.  (Every lane of the one-kernel form walks the whole chain of hi_level products whether it stores or not: 2^17
+// lanes x 17 products = 29 us on the critical path of every layer at bN = 24, against ~13 us for the two launches.)
+struct PyramidExpandArgs {
+    Planes out;          // the wide pyramid (levels <= lo_level already there)
+    CPlanes h;           // H pyramid (levels 1 .. hi_level - lo_level)
+    int lo_level, hi_level;
+};
+__global__ void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)1 << a.hi_level)) return;
+    const size_t lo_mask = ((size_t)1 << a.lo_level) - 1;
+    const Fr base = ld_fr(a.out.lo, a.out.hi, lo_mask + (idx & lo_mask));           // level lo_level sits at offset 2^lo_level - 1
+    for (int s = a.lo_level + 1; s <= a.hi_level; s++) {
+        if (idx >= ((size_t)1 << s)) continue;
+        const int t = s - a.lo_level;
+        const Fr hv = ld_fr(a.h.lo, a.h.hi, (((size_t)1 << t) - 1) + (idx >> a.lo_level));
+        st_fr(a.out.lo, a.out.hi, (((size_t)1 << s) - 1) + idx, fr_mul(base, hv));
+    }
+}
 __global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a) {
     const PyramidArgs& p = a.p[blockIdx.y];
     if (p.max_level < 0) return;

@@ -115,6 +115,7 @@ struct Ctx {
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
     int g_lin = 0;                             // GKRHIP_GLIN: log2(max threads) of the linear-gate round kernel when above g_max (measured: no gain)
     int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
+    int pyr_split = 12;                        // GKRHIP_PYR_SPLIT: the per-lane eq pyramid above 2^n entries in two launches (0: one launch)
     int solo_med = 1;                          // GKRHIP_SOLO_MED: see threads_log2 in cipher_rounds
     int lat_spread = 1;                        // GKRHIP_LAT_SPREAD: one workgroup per CU for small latency-bound launches
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
@@ -311,6 +312,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));   // an explicit setting holds for both
     if (const char* e = getenv("GKRHIP_HOST_TAIL_SOLO")) cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("GKRHIP_HOST_TAIL_SHARDED")) cx().host_tail_sharded = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("GKRHIP_PYR_SPLIT")) cx().pyr_split = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_SOLO_MED")) cx().solo_med = atoi(e);
     if (const char* e = getenv("GKRHIP_LAT_SPREAD")) cx().lat_spread = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
@@ -437,6 +439,7 @@ void lane_configure(Ctx* l) {
     l->host_tail = g0.host_tail;
     l->host_tail_solo = g0.host_tail_solo;
     l->host_tail_sharded = g0.host_tail_sharded;
+    l->pyr_split = g0.pyr_split;
     l->solo_med = g0.solo_med;
     l->lat_spread = g0.lat_spread;
     l->prelaunch = g0.prelaunch;

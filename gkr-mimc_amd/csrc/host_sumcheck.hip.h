@@ -226,14 +226,27 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // the per-lane pyramid (over all of q) and the per-iteration pyramids (one per thread split) in ONE launch
     PyramidArgs3 pa3;
     memset(&pa3, 0, sizeof pa3);
-    for (int v = 0; v < 3; v++) pa3.p[v].max_level = -1;
+    for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
+    // the per-lane pyramid in two steps when it is wide (GKRHIP_PYR_SPLIT, default 12): levels up to 2^12 entries and the small
+    // pyramid H over the next coordinates here, the upper levels by k_eq_pyramid_expand with one product per entry
+    const int gLow = (cx().pyr_split > 0 && gT > cx().pyr_split + 1) ? cx().pyr_split : gT;
+    ScopedTable pyrH;
     pa3.p[0].out = pyrT.planes();
     pa3.p[0].out2 = Planes{nullptr, nullptr};
     pa3.p[0].q = cx().d_q;
     pa3.p[0].nc = m;
-    pa3.p[0].max_level = gT;
+    pa3.p[0].max_level = gLow;
     pa3.p[0].seed = to_dev(seed);
-    int widest = gT;
+    if (gLow < gT) {
+        CHK(table_alloc(&pyrH, (size_t)2 << (gT - gLow)));
+        pa3.p[3].out = pyrH.planes();
+        pa3.p[3].out2 = Planes{nullptr, nullptr};
+        pa3.p[3].q = cx().d_q;
+        pa3.p[3].nc = m - gLow;
+        pa3.p[3].max_level = gT - gLow;
+        pa3.p[3].seed = to_dev(hfr::ONE);
+    }
+    int widest = std::max(gLow, gT - gLow);            // the launch covers the widest of its pyramids
     for (int v = 0; v < (g_big != gsplit[0] ? 2 : 1); v++) {
         const int mU = m - 1 - gsplit[v];              // log2(iterations of round 0 at this split)
         CHK(table_alloc(&pyrU[v], (size_t)2 << std::max(mU, 0)));
@@ -249,8 +262,17 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             widest = std::max(widest, mU);
         }
     }
-    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 3), dim3(GKR_BLOCK), 0, cx().stream, pa3);
+    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 4), dim3(GKR_BLOCK), 0, cx().stream, pa3);
     HIPCHK(hipGetLastError());
+    if (gLow < gT) {
+        PyramidExpandArgs xa;
+        xa.out = pyrT.planes();
+        xa.h = pyrH.cplanes();
+        xa.lo_level = gLow;
+        xa.hi_level = gT;
+        hipLaunchKernelGGL(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
+        HIPCHK(hipGetLastError());
+    }
     // the shared accumulator and the arrival counter are zero between launches (the last workgroup of every launch
     // resets them); only a call that failed half-way can leave them dirty
     if (cx().racc_dirty) {
@@ -524,6 +546,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     cx().racc_dirty = false;
     cx().prof.setup_ms += now_ms() - t_end0;
     table_release(&pyrT);
+    if (pyrH.base) table_release(&pyrH);
     for (int v = 0; v < 2; v++) {
         if (pyrU[v].base) table_release(&pyrU[v]);
         if (pyrU2[v].base) table_release(&pyrU2[v]);
@@ -671,7 +694,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
     PyramidArgs3 pa3;
     memset(&pa3, 0, sizeof pa3);
-    for (int v = 0; v < 3; v++) pa3.p[v].max_level = -1;
+    for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
     pa3.p[0].out = pyrT.planes();
     pa3.p[0].q = cx().d_q;
     pa3.p[0].nc = m;

@@ -342,6 +342,17 @@ def test_round_kernel_small_thread_budget(gk):
     _run_case({"GKRHIP_GMAX": "10"}, "11,12,14")
 
 
+def test_eq_pyramid_in_two_launches(gk):
+    """The per-lane eq pyramid built in two launches (levels up to 2^n entries with short chains, the upper levels with one
+    product per entry from a small second pyramid) and in one: same weights, same transcript, for splits below, at and above
+    the pyramid's height, with shard-like thread budgets."""
+    _run_case({"GKRHIP_PYR_SPLIT": "3", "GKRHIP_GMAX": "8"}, "9,11,13")
+    _run_case({"GKRHIP_PYR_SPLIT": "1"}, "5,10,14")
+    _run_case({"GKRHIP_PYR_SPLIT": "0"}, "9,14")
+    _run_case({"GKRHIP_PYR_SPLIT": "12"}, "14,15,16")
+    _run_case({"GKRHIP_PYR_SPLIT": "5", "GKRHIP_GMAX": "10"}, "12", circuit="gmimc")
+
+
 def test_round_kernel_variants(gk):
     """The throughput kernel everywhere (GKRHIP_LAT=0) and the interleaved-pair kernel everywhere
     (GKRHIP_LAT=2, with and without the per-iteration eq factor) give the same transcript."""
