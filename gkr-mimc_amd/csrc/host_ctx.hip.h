@@ -136,6 +136,7 @@ struct Ctx {
     int coop = 1;                              // GKRHIP_COOP: cooperative small-round kernel (eight lanes per pair): 0 never, 1 alone on the GPU, 2 always
     int coop_lg = 14;                          // ... for rounds of at most 2^coop_lg pairs
     int coop_wgs = 512;                        // ... on at most this many workgroups
+    int pre_start_lg = 16;                     // GKRHIP_PRE_START_LG: the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
     hipStream_t aux = nullptr;                 // low-priority stream of the look-ahead kernel
     hipEvent_t pre_done = nullptr;
     DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()
@@ -318,6 +319,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_PRE_START_LG")) cx().pre_start_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));
@@ -445,6 +447,7 @@ void lane_configure(Ctx* l) {
     l->prelaunch = g0.prelaunch;
     l->prelaunch_lg = g0.prelaunch_lg;
     l->pre_mode = g0.pre_mode;
+    l->pre_start_lg = g0.pre_start_lg;
     l->coop = g0.coop;
     l->coop_lg = g0.coop_lg;
     l->coop_wgs = g0.coop_wgs;

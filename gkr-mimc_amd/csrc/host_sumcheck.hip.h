@@ -185,7 +185,11 @@ int launch_pre() {
     for (int i = 0; i < 6; i++) a.out[i] = cx().pre_t[i].planes();
     a.P = P;
     a.ark = to_dev(cx().req_ark);
-    hipLaunchKernelGGL(k_cipher_pre, dim3(grid_for(P, 1 << 20)), dim3(GKR_BLOCK), GKR_PRE_LDS, cx().aux, a);
+    static const size_t pre_lds = [] {            // GKRHIP_PRE_LDS_KB: the occupancy cap of the look-ahead kernel (60: two workgroups per CU)
+        const char* e = getenv("GKRHIP_PRE_LDS_KB");
+        return e ? (size_t)std::max(0, std::min(150, atoi(e))) * 1024 : (size_t)GKR_PRE_LDS;
+    }();
+    hipLaunchKernelGGL(k_cipher_pre, dim3(grid_for(P, 1 << 20)), dim3(GKR_BLOCK), pre_lds, cx().aux, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(cx().pre_done, cx().aux));
     cx().pre_K = K->base;
@@ -429,7 +433,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
         }
         // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
-        if (pre_requested && k >= 1 && (P <= ((size_t)1 << 16) || k == m_dev - 1)) {
+        if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {
             CHK(launch_pre());
             pre_requested = false;
         }
@@ -799,7 +803,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
         }
-        if (pre_requested && k >= 1 && (P <= ((size_t)1 << 16) || k == m_dev - 1)) {   // the next (cipher) layer's look-ahead
+        if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {   // the next (cipher) layer's look-ahead
             CHK(launch_pre());
             pre_requested = false;
         }
