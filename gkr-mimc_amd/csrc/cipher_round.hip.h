@@ -135,8 +135,9 @@ struct CipherRoundArgs {
 #define GKR_CHAL_WORDS 16
 #define GKR_CHAL_ABORT 0xFFFFFFFFu
 // Workgroup 0 polls host memory (sixteen 8-byte reads per poll over PCIe) and forwards the tagged words to a
-// device-memory mailbox; the other workgroups poll the mailbox (L2 atomics) and look at the host slot themselves only
-// every 64th time (~20 us).  Hundreds of workgroups polling the host directly saturate the PCIe read path and delay the
+// device-memory mailbox; the other workgroups poll the mailbox (L2 atomics, every ~0.5 us) and look at the host slot themselves
+// only every 1024th time (~0.5 ms: with 512 workgroups waiting, every 64th time was 26 GB/s of PCIe reads and doubled the
+// latency of the rounds of 2^17 / 2^18 pairs).  Hundreds of workgroups polling the host directly saturate the PCIe read path and delay the
 // very hand-off the host is waiting for (measured: +12 ms per proof) -- but the mailbox must stay a SHORTCUT, never a
 // dependency: workgroup 0 need not be resident (several pre-launched kernels, e.g. of several processes sharing the GPU,
 // can each hold part of the machine while their workgroups 0 wait for a slot: measured, a deadlock until the time-out).
@@ -152,7 +153,7 @@ __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, u
         bool from_host = first;
         for (unsigned it = 0;; it++) {
             // uniform over the sixteen lanes: they count the same iterations until the first of them leaves
-            from_host = first || (it & 63u) == 63u;
+            from_host = first || (it & 1023u) == 1023u;
             v = from_host ? __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                           : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 s = (u32)(v >> 32);
@@ -170,7 +171,7 @@ __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, u
                 break;
             }
             if (first) __builtin_amdgcn_s_sleep(2);
-            else __builtin_amdgcn_s_sleep(8);
+            else __builtin_amdgcn_s_sleep(16);
         }
         if (from_host) __hip_atomic_store(mailbox + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_ch[threadIdx.x] = (u32)v;

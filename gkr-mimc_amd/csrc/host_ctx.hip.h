@@ -126,7 +126,7 @@ struct Ctx {
     // ---- serial-latency measures of a proof that is alone on the GPU (round 3) -----------------------------------
     // pre-launched rounds: round k+1's kernel is queued before the host hashes round k and polls the challenge slot
     int prelaunch = 1;                         // GKRHIP_PRELAUNCH: 0 never, 1 when the proof is alone on the GPU, 2 always
-    int prelaunch_lg = 16;                     // ... for rounds of at most 2^prelaunch_lg pairs
+    int prelaunch_lg = 30;                     // ... for rounds of at most 2^prelaunch_lg pairs (every round since the waiting workgroups poll the host only rarely; 16 before: same-box 279.8 -> 277.9 ms at bN = 24)
     unsigned long long* h_chal = nullptr;      // host-mapped challenge slot (GKR_CHAL_WORDS words)
     unsigned long long* d_chal = nullptr;
     unsigned long long* d_chal_dev = nullptr;  // device-memory mailbox: workgroup 0 of a pre-launched kernel forwards the slot to the others
