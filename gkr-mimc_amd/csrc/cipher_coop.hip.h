@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_coop(CipherRoundA
         unsigned long long s = 0;
 #pragma unroll 8
         for (int i = 0; i < GKR_COOP_PAIRS; i++) s += sh.red[rr][w][(i + threadIdx.x) % GKR_COOP_PAIRS];
-        if (s) (void)__hip_atomic_fetch_add(a.partials + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s) (void)__hip_atomic_fetch_add(a.partials + (blockIdx.x % GKR_RACC_SLOTS) * GKR_RACC_STRIDE + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     publish_sums(a.partials, a.counter, a.host_out, a.host_flag, a.seq, GKR_CR_WORDS, &s_last);
 }

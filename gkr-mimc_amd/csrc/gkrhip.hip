@@ -1181,7 +1181,7 @@ int gkrhip_bench_partial_eval(int bn, int warmup, int iters, double* us_per_call
     const DevTable* X[2] = {&L, &R};
     E evals[GKR_MAX_EVALS];
     if (cx().racc_dirty) {
-        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     }
     cx().racc_dirty = true;

@@ -340,8 +340,9 @@ int lane_alloc() {
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&cx().d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
     HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));
-    HIPCHK(hipMalloc(&cx().d_racc, sizeof(unsigned long long) * kRaccWords));
-    HIPCHK(hipMemset(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords));
+    static_assert(kRaccWords == GKR_RACC_STRIDE, "one accumulator copy per stride");
+    HIPCHK(hipMalloc(&cx().d_racc, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS));
+    HIPCHK(hipMemset(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS));
     HIPCHK(hipHostMalloc(&cx().h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
     HIPCHK(hipMalloc(&cx().d_small, sizeof(uint4) * 2 * 8));
     HIPCHK(hipHostMalloc(&cx().h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));

@@ -280,7 +280,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // the shared accumulator and the arrival counter are zero between launches (the last workgroup of every launch
     // resets them); only a call that failed half-way can leave them dirty
     if (cx().racc_dirty) {
-        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     }
     cx().racc_dirty = true;                            // until this call has run to its end
@@ -715,7 +715,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
                        cx().stream, pa3);
     HIPCHK(hipGetLastError());
     if (cx().racc_dirty) {   // see cipher_rounds
-        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     }
     cx().racc_dirty = true;
@@ -936,7 +936,7 @@ int generic_rounds(const GateDesc& g, const E& ark, int m, DevTable* eq, const D
     const size_t n = (size_t)1 << m;
     const int nev = g.power + 2, arity = g.n_in;
     if (cx().racc_dirty) {   // see cipher_rounds
-        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords, cx().stream));
+        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
     }
     cx().racc_dirty = true;

@@ -19,6 +19,11 @@
 #define GKR_MAX_ARITY 4
 #define GKR_MAX_EVALS 9   // cipher gate: degree 8 -> 9 evaluation points (sumcheck/prover.go:95, algo.go:57)
 #define GKR_ACC_WORDS 9   // un-reduced 288-bit lane accumulators
+// The launch-wide accumulator of the round kernels exists GKR_RACC_SLOTS times (stride GKR_RACC_STRIDE words): workgroup b
+// adds into copy b mod 8 and the last workgroup sums the copies.  Hundreds of workgroups finishing together otherwise
+// queue their 72 atomic adds on the same 72 addresses (512 adds per address for a round of 2^17 pairs).
+#define GKR_RACC_SLOTS 8
+#define GKR_RACC_STRIDE 128
 
 
 struct Planes {
@@ -300,7 +305,7 @@ __device__ __forceinline__ void block_reduce_acc_buf(const Acc9 (&acc)[NS], unsi
 #pragma unroll
         for (int q = 0; q < GKR_BLOCK / 64; q++) s += red[q][tid];
         if (ATOMIC) {
-            if (s) (void)__hip_atomic_fetch_add(out + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s) (void)__hip_atomic_fetch_add(out + (blockIdx.x % GKR_RACC_SLOTS) * GKR_RACC_STRIDE + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             out[tid] = s;
         }
@@ -335,8 +340,13 @@ __device__ __forceinline__ void publish_sums(unsigned long long* racc, unsigned 
     __syncthreads();
     if (*s_last) {
         if ((int)threadIdx.x < nwords) {
-            host_out[threadIdx.x] = __hip_atomic_load(racc + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            racc[threadIdx.x] = 0;
+            unsigned long long sum = 0;
+#pragma unroll
+            for (int sl = 0; sl < GKR_RACC_SLOTS; sl++) {
+                sum += __hip_atomic_load(racc + sl * GKR_RACC_STRIDE + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                racc[sl * GKR_RACC_STRIDE + threadIdx.x] = 0;
+            }
+            host_out[threadIdx.x] = sum;
         }
         __threadfence_system();
         __syncthreads();
