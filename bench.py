@@ -601,7 +601,7 @@ def main():
             job.sessions[0].prove(job.qprime)
             sync_all()
             ph["solo_fused"] = gk.profile_get()
-            gk.set_option("lookahead", 1)
+            gk.set_option("lookahead", int(os.environ.get("GKRHIP_PRE", "1")))      # back to what the library was started with
         gk.profile_reset(1 << bn_local)        # HIP-event accounting of the round-0 fold / partial-eval launches
         with ClockSampler(dev) as clk:
             ph["dt"] = timed(job, steps)
