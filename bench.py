@@ -14,7 +14,8 @@ words all-reduced with RCCL (north_star's transport).  The rank processes the la
 runs the K steps as a sequence of PASSES, every pass in a fresh child process (own rendezvous port), so that a pass that
 fails or stalls is killed and the next one still runs: (1) host shared-memory exchange (one node), (1b) the same through the
 ticker (its logic with the tick all-reduce on the host), (2) RCCL with ONE lane (one communicator: no ordering question),
-(3) RCCL with several lanes through the ticker (one communicator, one issuing thread), (4) RCCL with one communicator per lane.  `value` is the best RCCL pass; every pass is in the line
+(3) RCCL with several lanes through the ticker (one communicator, one issuing thread); when (3) fails also (3b) the ticker on
+device staging buffers and (4) RCCL with one communicator per lane; GKRHIP_BENCH_ALL_PASSES=1 runs all of them.  `value` is the best RCCL pass; every pass is in the line
 ("passes").  If no RCCL pass succeeds the line is still printed, from the shared-memory pass, marked "degraded":
 "rccl_failed" with n_gpus_rccl = 0, and bench.py exits with code 3.  --weak keeps 2^bn entries per GPU instead.
 Prints ONE JSON line on rank 0.
@@ -350,7 +351,11 @@ def parse_args():
     return ap.parse_args()
 
 
-DEFAULT_PASSES = ["shm", "shm_tick", "rccl_one_lane", "rccl_tick", "rccl_lanes"]
+# shm: the transport every multi-rank test exercises; rccl_one_lane: RCCL without any ordering question; rccl_tick: the
+# multi-lane RCCL transport.  Added on demand: rccl_tick_dev and rccl_lanes when rccl_tick fails; everything (also shm_tick)
+# with GKRHIP_BENCH_ALL_PASSES=1.  Three passes keep an N-GPU run within a couple of minutes.
+DEFAULT_PASSES = ["shm", "rccl_one_lane", "rccl_tick"]
+ALL_PASSES = ["shm", "shm_tick", "rccl_one_lane", "rccl_tick", "rccl_lanes"]
 PASS_TRANSPORT = {
     "shm": "host shared memory (one node): the ranks add the 576-byte round sums on the host",
     "shm_tick": "host shared memory (one node), all lanes through the ticker: the ticker's logic with its tick all-reduce done on the host",
@@ -375,7 +380,8 @@ def orchestrate(args):
     elif args.exchange == "shm":
         passes = ["shm"]
     else:
-        passes = [p for p in DEFAULT_PASSES if not p.startswith("shm") or one_node]
+        base = ALL_PASSES if os.environ.get("GKRHIP_BENCH_ALL_PASSES") else DEFAULT_PASSES
+        passes = [p for p in base if not p.startswith("shm") or one_node]
     limit_s = float(os.environ.get("GKRHIP_BENCH_PASS_LIMIT_S", "0")) or (240.0 + 3.0 * (args.steps + args.warmup))
     results = {}
     argv = [a for a in sys.argv[1:]]
@@ -412,8 +418,10 @@ def orchestrate(args):
                   ((res or {}).get("error") or "exit code %s" % rc)
             results[name] = {"error": why, "seconds": time.time() - t0}
             print("bench.py: pass %s failed on rank %d: %s" % (name, rank, why), file=sys.stderr)
-            if name == "rccl_tick" and "rccl_tick_dev" not in passes:
-                passes.append("rccl_tick_dev")       # the same ticker with the all-reduce on device staging buffers (every rank fails alike)
+            if name == "rccl_tick":     # every rank fails alike: the same follow-up passes everywhere
+                for extra in ("rccl_tick_dev", "rccl_lanes"):      # the ticker on device staging buffers; one communicator per lane
+                    if extra not in passes:
+                        passes.append(extra)
     ok_rccl = [n for n in passes if n.startswith("rccl") and "error" not in results[n]]
     code = 0 if (ok_rccl or args.exchange == "shm" or not any(n.startswith("rccl") for n in passes)) else 3
     if rank == 0:

@@ -62,8 +62,8 @@ def test_multi_rank_line_is_marked_when_no_rccl_pass_succeeded():
         return
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["degraded"] == "rccl_failed" and d["n_gpus_rccl"] == 0 and d["value_transport"] == "shm"
-    assert d["headline_pass"] == "shm" and set(d["passes"]) - {"rccl_tick_dev", "shm_tick"} == {"shm", "rccl_one_lane", "rccl_tick", "rccl_lanes"}
-    assert all("error" in d["passes"][p] for p in ("rccl_one_lane", "rccl_tick", "rccl_lanes")) and d["passes"]["shm"]["value"] > 0
+    assert d["headline_pass"] == "shm" and {"shm", "rccl_one_lane", "rccl_tick"} <= set(d["passes"]) <= {"shm", "shm_tick", "rccl_one_lane", "rccl_tick", "rccl_tick_dev", "rccl_lanes"}
+    assert all("error" in v for p, v in d["passes"].items() if p.startswith("rccl")) and d["passes"]["shm"]["value"] > 0
 
 
 def test_bench_defaults_finish_quickly():
