@@ -382,7 +382,7 @@ def orchestrate(args):
     else:
         base = ALL_PASSES if os.environ.get("GKRHIP_BENCH_ALL_PASSES") else DEFAULT_PASSES
         passes = [p for p in base if not p.startswith("shm") or one_node]
-    limit_s = float(os.environ.get("GKRHIP_BENCH_PASS_LIMIT_S", "0")) or (240.0 + 3.0 * (args.steps + args.warmup))
+    limit_s = float(os.environ.get("GKRHIP_BENCH_PASS_LIMIT_S", "0")) or (120.0 + 3.0 * (args.steps + args.warmup))
     results = {}
     argv = [a for a in sys.argv[1:]]
     i = -1
