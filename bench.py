@@ -674,12 +674,14 @@ def main():
                                "rounds": solo["rounds"], "host_hash_ms": solo["host_hash_ms"], "host_wait_ms": solo["host_wait_ms"],
                                "host_launch_ms": solo["host_launch_ms"], "host_other_ms": solo["host_other_ms"],
                                "prelaunched_rounds": solo["prelaunched_rounds"], "lookahead_round0": solo["lookahead_round0"],
-                               "coop_rounds": solo["coop_rounds"],
+                               "coop_rounds": solo["coop_rounds"], "spec_rounds": solo.get("spec_rounds", 0),
                                "note": "one gkr.Prove alone on the GPU (BenchmarkGkr's shape): the serial chain of rounds -- "
                                        "Fiat-Shamir hash on the host, then the next round kernel.  Round 3: the next round's kernel "
                                        "is queued before the hash and polls a host-mapped challenge slot (prelaunched_rounds), the "
                                        "q-independent products of the next layer's round 0 are computed during this layer's small "
-                                       "rounds (lookahead_round0), small rounds run eight lanes per pair (coop_rounds); "
+                                       "rounds (lookahead_round0), small rounds run eight lanes per pair (coop_rounds) or, smaller still, speculatively "
+                                       "for the eight candidate values of the previous challenge while the host still hashes, and are "
+                                       "interpolated at the true challenge (spec_rounds); "
                                        "host_wait_ms is the time the host waited for round kernels (their GPU time plus hand-off latency)"}
 
     build_info = importlib.import_module("gkr-mimc_amd.build").read_info() or {}

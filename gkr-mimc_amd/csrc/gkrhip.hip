@@ -31,6 +31,7 @@
 #include "cipher_round.hip.h"
 #include "linear_round.hip.h"
 #include "cipher_coop.hip.h"
+#include "cipher_spec.hip.h"
 #include "ntt.hip.h"
 
 using hfr::E;
@@ -300,7 +301,7 @@ const char* gkrhip_build_id(void) {
 
 int gkrhip_set_option(const char* key, long value) {
     static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
-                                 "prelaunch", "prelaunch_lg", "lookahead", "coop"};
+                                 "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg"};
     bool known = false;
     for (const char* k : keys) known = known || !strcmp(key, k);
     if (!known) return fail("unknown option %s", key);
@@ -317,6 +318,8 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "prelaunch_lg")) l->prelaunch_lg = (int)std::max(0L, std::min(30L, value));
         else if (!strcmp(key, "lookahead")) l->pre_mode = (int)value;
         else if (!strcmp(key, "coop")) l->coop = (int)value;
+        else if (!strcmp(key, "spec")) l->spec = (int)value;
+        else if (!strcmp(key, "spec_lg")) l->spec_lg = (int)std::max(5L, std::min(16L, value));
         return 0;
     });
 }
@@ -1202,6 +1205,7 @@ int gkrhip_profile_reset(size_t min_n) {
     g_cnt_prelaunched = 0;
     g_cnt_lookahead = 0;
     g_cnt_coop = 0;
+    g_cnt_spec = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
         prof_clear(l->prof);
@@ -1666,6 +1670,17 @@ int gkrhip_profile_latency(uint64_t* prelaunched_rounds, uint64_t* lookahead_rou
     if (prelaunched_rounds) *prelaunched_rounds = g_cnt_prelaunched.load();
     if (lookahead_round0) *lookahead_round0 = g_cnt_lookahead.load();
     if (coop_rounds) *coop_rounds = g_cnt_coop.load();
+    return 0;
+}
+
+int gkrhip_profile_counter(const char* name, uint64_t* value) {
+    if (!name || !value) return fail("gkrhip_profile_counter: null argument");
+    const std::string n(name);
+    if (n == "prelaunched_rounds") *value = g_cnt_prelaunched.load();
+    else if (n == "lookahead_round0") *value = g_cnt_lookahead.load();
+    else if (n == "coop_rounds") *value = g_cnt_coop.load();
+    else if (n == "spec_rounds") *value = g_cnt_spec.load();
+    else return fail("gkrhip_profile_counter: unknown counter '%s'", name);
     return 0;
 }
 

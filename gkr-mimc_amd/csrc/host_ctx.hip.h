@@ -18,7 +18,7 @@ static inline double now_ms() {
 // process-wide counts of the serial-latency paths (gkrhip_profile_latency): rounds whose kernel was queued ahead of its
 // challenge, round-0 launches on look-ahead products, rounds of the cooperative kernel.  Not per lane: the lanes of
 // one-shot calls go back to the pool (and are cleared) before anybody can ask.
-std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0};
+std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0}, g_cnt_spec{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
     uint64_t rounds = 0;
@@ -127,7 +127,7 @@ struct Ctx {
     // pre-launched rounds: round k+1's kernel is queued before the host hashes round k and polls the challenge slot
     int prelaunch = 1;                         // GKRHIP_PRELAUNCH: 0 never, 1 when the proof is alone on the GPU, 2 always
     int prelaunch_lg = 30;                     // ... for rounds of at most 2^prelaunch_lg pairs (every round since the waiting workgroups poll the host only rarely; 16 before: same-box 279.8 -> 277.9 ms at bN = 24)
-    unsigned long long* h_chal = nullptr;      // host-mapped challenge slot (GKR_CHAL_WORDS words)
+    unsigned long long* h_chal = nullptr;      // host-mapped challenge slots (kChalSlots x GKR_CHAL_WORDS words): slot 0 the pre-launched round kernels', 1 and 2 the speculative rounds' (alternating)
     unsigned long long* d_chal = nullptr;
     unsigned long long* d_chal_dev = nullptr;  // device-memory mailbox: workgroup 0 of a pre-launched kernel forwards the slot to the others
     // round 0 split: the q-independent products of the NEXT layer's round 0 are computed on `aux` while this layer's
@@ -136,6 +136,16 @@ struct Ctx {
     int coop = 1;                              // GKRHIP_COOP: cooperative small-round kernel (eight lanes per pair): 0 never, 1 alone on the GPU, 2 always
     int coop_lg = 14;                          // ... for rounds of at most 2^coop_lg pairs
     int coop_wgs = 512;                        // ... on at most this many workgroups
+    // speculative small rounds (cipher_spec.hip.h): round k runs for the eight candidate values 0..7 of r_{k-1} while the host
+    // still hashes round k-1; the host interpolates at the true challenge
+    int spec = 1;                              // GKRHIP_SPEC: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
+    int spec_max_m = 22;                       // GKRHIP_SPEC_MAX_M: spec == 1 takes layers of at most 2^n entries
+    int spec_lg = 13;                          // GKRHIP_SPEC_LG: ... for rounds of at most 2^spec_lg pairs (eight lanes per pair: 2^16 lanes = one wave per SIMD)
+    unsigned long long* h_spec = nullptr;      // host-mapped: two result buffers of GKR_SPEC_BUF_WORDS words (rounds alternate)
+    unsigned long long* d_spec = nullptr;
+    unsigned long long* d_spec_racc = nullptr; // GKR_SPEC_CAND accumulator sets, zero between launches
+    E spec_pts[8];                             // Montgomery forms of the candidate points 0..7
+    E spec_invden[8];                          // 1 / prod_{j != i} (i - j): Lagrange denominators on the points 0..7
     int pre_start_lg = 16;                     // GKRHIP_PRE_START_LG: the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
     hipStream_t aux = nullptr;                 // low-priority stream of the look-ahead kernel
     hipEvent_t pre_done = nullptr;
@@ -279,6 +289,7 @@ bool error_lookup(int code, std::string* out) {
 const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
 const int kHostTailMax = 6;       // the host can take over from 2^6 pairs on (GKRHIP_HOST_TAIL <= 6)
 const size_t kTailWords = (size_t)GKR_MAX_ARITY * 4 * 2 * (2 << kHostTailMax);   // up to four tables of 2P entries, P <= 2^(kHostTailMax+1), 4 u64 each
+const int kChalSlots = 3;
 const int kRaccWords = 128;       // shared accumulator / host hand-off buffer: 72 (fused rounds) or up to 81 (nine evaluations) + 16 tail words
 int lane_alloc();
 void table_release_fwd(DevTable* t);
@@ -320,6 +331,9 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_PRE_START_LG")) cx().pre_start_lg = std::max(0, std::min(30, atoi(e)));
+    if (const char* e = getenv("GKRHIP_SPEC")) cx().spec = atoi(e);
+    if (const char* e = getenv("GKRHIP_SPEC_MAX_M")) cx().spec_max_m = std::max(0, std::min(40, atoi(e)));
+    if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));
@@ -359,11 +373,11 @@ int lane_alloc() {
     HIPCHK(hipHostMalloc(&cx().h_bad, 64, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_bad, cx().h_bad, 0));
     *cx().h_bad = 0;
-    HIPCHK(hipHostMalloc(&cx().h_chal, sizeof(unsigned long long) * GKR_CHAL_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostMalloc(&cx().h_chal, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_chal, cx().h_chal, 0));
-    memset(cx().h_chal, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS);
-    HIPCHK(hipMalloc(&cx().d_chal_dev, sizeof(unsigned long long) * GKR_CHAL_WORDS));
-    HIPCHK(hipMemset(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS));
+    memset(cx().h_chal, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots);
+    HIPCHK(hipMalloc(&cx().d_chal_dev, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots));
+    HIPCHK(hipMemset(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots));
     return 0;
 }
 // the look-ahead tables go back to the arena (end of a proof, lane teardown)
@@ -402,6 +416,10 @@ void lane_free() {
     cx().d_q_cap = 0;
     if (cx().h_tail) (void)hipHostFree(cx().h_tail);
     cx().h_tail = cx().d_tail = nullptr;
+    if (cx().h_spec) (void)hipHostFree(cx().h_spec);
+    cx().h_spec = cx().d_spec = nullptr;
+    if (cx().d_spec_racc) (void)hipFree(cx().d_spec_racc);
+    cx().d_spec_racc = nullptr;
     if (cx().h_bad) (void)hipHostFree(cx().h_bad);
     cx().h_bad = cx().d_bad = nullptr;
     // the exchange buffers of a communicator lane
@@ -449,6 +467,9 @@ void lane_configure(Ctx* l) {
     l->prelaunch_lg = g0.prelaunch_lg;
     l->pre_mode = g0.pre_mode;
     l->pre_start_lg = g0.pre_start_lg;
+    l->spec = g0.spec;
+    l->spec_lg = g0.spec_lg;
+    l->spec_max_m = g0.spec_max_m;
     l->coop = g0.coop;
     l->coop_lg = g0.coop_lg;
     l->coop_wgs = g0.coop_wgs;

@@ -123,8 +123,8 @@ void host_cipher_rounds(const E& ark, int mm, std::vector<E>& K, std::vector<E>&
 
 
 // ---- host side of the challenge hand-over to a pre-launched round kernel (wait_challenge, cipher_round.hip.h) -----
-inline void chal_publish(unsigned int seq, const E& r, const E& r_lo) {
-    volatile unsigned long long* w = cx().h_chal;
+inline void chal_publish(unsigned int seq, const E& r, const E& r_lo, int slot = 0) {
+    volatile unsigned long long* w = cx().h_chal + (size_t)slot * GKR_CHAL_WORDS;
     const unsigned long long tag = (unsigned long long)seq << 32;
     for (int i = 0; i < 4; i++) {
         w[2 * i] = tag | (unsigned long long)(uint32_t)r.l[i];
@@ -141,14 +141,14 @@ struct ChalGuard {
     ~ChalGuard() {
         if (!armed) return;
         volatile unsigned long long* w = cx().h_chal;
-        for (int i = 0; i < GKR_CHAL_WORDS; i++) w[i] = (unsigned long long)GKR_CHAL_ABORT << 32;
+        for (int i = 0; i < GKR_CHAL_WORDS * kChalSlots; i++) w[i] = (unsigned long long)GKR_CHAL_ABORT << 32;
         __sync_synchronize();
         (void)hipStreamSynchronize(cx().stream);
         // the abort tags must not outlive the launch they were meant for: the next pre-launched kernel of this lane polls
         // the slot (and the device mailbox the tags were forwarded to) before any new challenge is published
-        for (int i = 0; i < GKR_CHAL_WORDS; i++) w[i] = 0;
+        for (int i = 0; i < GKR_CHAL_WORDS * kChalSlots; i++) w[i] = 0;
         __sync_synchronize();
-        (void)hipMemsetAsync(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS, cx().stream);
+        (void)hipMemsetAsync(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots, cx().stream);
         (void)hipStreamSynchronize(cx().stream);
     }
 };
@@ -197,6 +197,42 @@ int launch_pre() {
     cx().pre_ark = cx().req_ark;
     cx().pre_m = cx().req_m;
     return 0;
+}
+
+// ---- speculative small rounds (cipher_spec.hip.h) ------------------------------------------------------------------
+// buffers of the lane, allocated the first time a proof takes the path
+int spec_ensure() {
+    if (cx().h_spec) return 0;
+    HIPCHK(hipHostMalloc(&cx().h_spec, sizeof(unsigned long long) * 2 * GKR_SPEC_BUF_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_spec, cx().h_spec, 0));
+    memset(cx().h_spec, 0, sizeof(unsigned long long) * 2 * GKR_SPEC_BUF_WORDS);
+    HIPCHK(hipMalloc(&cx().d_spec_racc, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS));
+    HIPCHK(hipMemset(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS));
+    for (int i = 0; i < GKR_SPEC_CAND; i++) cx().spec_pts[i] = hfr::from_u64((hfr::u64)i);
+    for (int i = 0; i < GKR_SPEC_CAND; i++) {      // 1 / prod_{j != i} (i - j)
+        E den = hfr::ONE;
+        for (int j = 0; j < GKR_SPEC_CAND; j++)
+            if (j != i) den = hfr::mul(den, hfr::sub(cx().spec_pts[i], cx().spec_pts[j]));
+        cx().spec_invden[i] = hfr::pow_q_minus_2(den);
+    }
+    return 0;
+}
+// M_j(r), j = j0..7, from the candidates' sums (cand[i * 8 + j] = M_j(i), i = 0..7, canonical elements: the kernel's last
+// workgroup reduces them): M_j has degree 7 in r, so the Lagrange basis on the points 0..7 reproduces it exactly
+void spec_interpolate(const E* cand, const E& r, int j0, E* M) {
+    E d[GKR_SPEC_CAND], pre[GKR_SPEC_CAND], suf[GKR_SPEC_CAND], L[GKR_SPEC_CAND];
+    for (int i = 0; i < GKR_SPEC_CAND; i++) d[i] = hfr::sub(r, cx().spec_pts[i]);
+    pre[0] = hfr::ONE;
+    for (int i = 1; i < GKR_SPEC_CAND; i++) pre[i] = hfr::mul(pre[i - 1], d[i - 1]);
+    suf[GKR_SPEC_CAND - 1] = hfr::ONE;
+    for (int i = GKR_SPEC_CAND - 2; i >= 0; i--) suf[i] = hfr::mul(suf[i + 1], d[i + 1]);
+    for (int i = 0; i < GKR_SPEC_CAND; i++) L[i] = hfr::mul(hfr::mul(pre[i], suf[i]), cx().spec_invden[i]);
+    for (int j = j0; j < GKR_CR_NSUM; j++) {
+        E acc = hfr::ZERO;
+        for (int i = 0; i < GKR_SPEC_CAND; i++)
+            acc = hfr::add(acc, hfr::mul(L[i], cand[i * GKR_CR_NSUM + j]));
+        M[j] = acc;
+    }
 }
 
 // The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
@@ -282,6 +318,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     if (cx().racc_dirty) {
         HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+        if (cx().d_spec_racc) HIPCHK(hipMemsetAsync(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS, cx().stream));
     }
     cx().racc_dirty = true;                            // until this call has run to its end
     if (collective) CHK(coll_buffers(256));
@@ -306,6 +343,27 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);
     const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
     const bool coop_on = cx().coop >= 2 || (cx().coop == 1 && alone);
+    // speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the eight candidate values of r_{k-1} while the
+    // host hashes round k-1.  Needs the pre-launched rounds (the launches it rides behind) and the host tail (its export).
+    int k_s = -1;
+    // (spec == 1: only while the look-ahead kernel of the next layer is small -- from 2^23 entries on it needs the whole
+    // idle time of the small rounds, and eight candidates' worth of lanes beside it cost more than the waits they remove:
+    // bN = 24 measured 279.5 -> 281..285 ms, bN = 22 155 -> 150, bN = 20 109 -> 104)
+    if ((cx().spec >= 2 || (cx().spec == 1 && alone && m <= cx().spec_max_m)) && !collective && pl_on && h_tail > 0) {
+        for (int k = 2; k <= k_export && k_s < 0; k++) {
+            const int rem = m - 1 - k;               // log2(pairs of round k)
+            if (rem <= cx().spec_lg && threads_log2(k) == rem) k_s = k;     // one pair per lane
+        }
+    }
+    auto is_spec = [&](int k) { return k_s >= 0 && k >= k_s && k <= k_export; };
+    ScopedTable ks2, ss2;                            // the speculative launches alternate between (ks, ss) and these
+    if (k_s >= 0) {
+        CHK(spec_ensure());
+        if (k_s < k_export) {
+            CHK(table_alloc(&ks2, (size_t)4 << (m - 1 - (k_s + 1))));      // round k_s + 1 stores the tables of round k_s: 4 P entries
+            CHK(table_alloc(&ss2, (size_t)4 << (m - 1 - (k_s + 1))));
+        }
+    }
     ChalGuard chal_guard;
     struct InFlight {
         RoundTargets tg;
@@ -410,6 +468,50 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         return 0;
     };
+    // queue the speculative launch of round k (k_s <= k <= k_export).  k == k_s reads the tables R_{k-1} leaves in (ks, ss)
+    // and needs no challenge; later rounds read the tables of round k-2, fold them with r_{k-2} (polled from slot
+    // 1 + (k & 1)) and store the tables of round k-1 in the other pair of buffers
+    unsigned int spec_seq[2] = {0, 0};               // by parity of the round
+    auto launch_spec = [&](int k) -> int {
+        const size_t P = n >> (k + 1);
+        const int gk = m - 1 - k;
+        const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
+        CipherSpecArgs a;
+        memset(&a, 0, sizeof a);
+        const ScopedTable& srcK = (pref || odd) ? ks : ks2;
+        const ScopedTable& srcS = (pref || odd) ? ss : ss2;
+        a.k_src = srcK.cplanes();
+        a.s_src = srcS.cplanes();
+        if (!pref && !last) {
+            a.k_dst = (odd ? ks2 : ks).planes();
+            a.s_dst = (odd ? ss2 : ss).planes();
+        }
+        const size_t offT = ((size_t)1 << gk) - 1;
+        a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
+        a.P = P;
+        a.ark = to_dev(ark);
+        for (int i = 0; i < GKR_SPEC_CAND; i++) a.rho[i] = to_dev(cx().spec_pts[i]);
+        a.partials = cx().d_spec_racc;
+        a.counter = cx().d_counter;
+        a.host_out = cx().d_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
+        a.seq = spec_seq[k & 1] = ++cx().seq;
+        a.need_m0 = claim ? 0u : 1u;
+        a.prefolded = pref ? 1u : 0u;
+        a.tail_tables = last ? cx().d_tail : nullptr;
+        if (!pref) {
+            const int slot = 1 + (k & 1);
+            a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
+            a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
+            a.chal_seq = a.seq;
+            chal_guard.armed = true;
+        }
+        const int gx = (int)std::max<size_t>(P / GKR_BLOCK, 1);
+        const bool row8 = !pref || last;             // the fold-and-store row (a plain copy to the host when the tables are folded already)
+        hipLaunchKernelGGL(k_cipher_round_spec, dim3(gx, row8 ? GKR_SPEC_CAND + 1 : GKR_SPEC_CAND), dim3(GKR_BLOCK), 0, cx().stream, a);
+        HIPCHK(hipGetLastError());
+        g_cnt_spec.fetch_add(1, std::memory_order_relaxed);
+        return 0;
+    };
     InFlight cur, nxt;
     {
         const double t_l0 = now_ms();
@@ -423,7 +525,10 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_l0 = now_ms();
         // round k+1 queued now, behind round k's kernel: its dispatch overlaps the hash below
         const bool have_next = k + 1 < m_dev;
-        const bool prelaunched = have_next && pl_on && (P >> 1) <= ((size_t)1 << cx().prelaunch_lg);
+        const bool next_spec = is_spec(k + 1), next2_spec = is_spec(k + 2);
+        const unsigned int seq_spec_k = spec_seq[k & 1];          // round k's own speculative launch (round k+2's reuses the entry below)
+        // (the round before the first speculative one is always pre-launched: the speculative launch rides behind it)
+        const bool prelaunched = have_next && !next_spec && pl_on && ((P >> 1) <= ((size_t)1 << cx().prelaunch_lg) || next2_spec);
         // Un-sharded: queued BEFORE waiting for round k (the launch call itself is hidden behind round k's kernel).
         // Sharded: AFTER the exchange of round k -- the kernel then only ever spins for the duration of this rank's own
         // hash, never for a peer that is seconds behind (ranks reach the first exchange of a proof at different times),
@@ -431,6 +536,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         if (prelaunched && !collective) {
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+            if (next2_spec) CHK(launch_spec(k + 2));             // the first speculative round: behind R_{k+1}, whose tables it reads
+        } else if (next_spec && next2_spec) {
+            CHK(launch_spec(k + 2));                             // polls r_k
         }
         // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
         if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {
@@ -439,24 +547,30 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         // test hook (GKRHIP_TEST_FAIL_AFTER_PRELAUNCH=k, once per process): an error return while a pre-launched kernel is
         // waiting for its challenge -- the guard must tell it to leave, drain the stream and clear the abort tags
-        if (prelaunched && k == g_test_fail_round && g_test_fail_armed.exchange(false)) return fail("injected failure after a pre-launch (test hook)");
+        if ((prelaunched || (next_spec && next2_spec)) && k == g_test_fail_round && g_test_fail_armed.exchange(false))
+            return fail("injected failure after a pre-launch (test hook)");
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
         unsigned long long summed[GKR_CR_WORDS];
         const unsigned long long* sums = nullptr;
-        CHK(round_collect(collective, cur.tg, cur.seq, GKR_CR_WORDS, 16, summed, &sums));
+        const bool this_spec = is_spec(k);
+        const unsigned long long* cand = cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
+        if (this_spec) CHK(wait_flag(seq_spec_k, (volatile unsigned int*)(cand + GKR_SPEC_FLAG_WORD)));
+        else CHK(round_collect(collective, cur.tg, cur.seq, GKR_CR_WORDS, 16, summed, &sums));
         const double t_w = now_ms();
         if (prelaunched && collective) {
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
         }
-        const bool derive_m0 = cur.derive_m0;
+        const bool derive_m0 = this_spec ? claim != nullptr : cur.derive_m0;
         // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
         // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
         // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
-        E csp[8];
-        for (int j = derive_m0 ? 1 : 0; j < 8; j++)
-            csp[j] = hfr::mul(c, hfr::mul(limbs9_to_fr(sums + (size_t)j * GKR_ACC_WORDS), hfr::from_u64(binom7[j])));
+        E csp[8], Mj[8];
+        if (this_spec) spec_interpolate((const E*)cand, chal[k - 1], derive_m0 ? 1 : 0, Mj);      // the candidates at the true r_{k-1}
+        else
+            for (int j = derive_m0 ? 1 : 0; j < 8; j++) Mj[j] = limbs9_to_fr(sums + (size_t)j * GKR_ACC_WORDS);
+        for (int j = derive_m0 ? 1 : 0; j < 8; j++) csp[j] = hfr::mul(c, hfr::mul(Mj[j], hfr::from_u64(binom7[j])));
         if (derive_m0) {
             E rest = csp[1];
             for (int j = 2; j < 8; j++) rest = hfr::add(rest, csp[j]);
@@ -472,7 +586,12 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const E r = hfr::mimc_hash(co, 9);
         const double t_h1 = now_ms();
         double t_l2 = t_h1;
-        if (prelaunched) {
+        if (next_spec) {
+            if (next2_spec) {                                // round k+2's speculative launch folds with r_k
+                chal_publish(spec_seq[k & 1], r, r, 1 + (k & 1));
+                chal_guard.armed = false;
+            }
+        } else if (prelaunched) {
             const E two128 = {{0, 0, 1, 0}};
             chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
             chal_guard.armed = false;
@@ -494,6 +613,14 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             // the exported tables (2P entries each) folded with this round's challenge are the host's starting point
             const E* tt = (const E*)cx().h_tail;
             std::vector<E> Kh(P), Sh(P);
+            if (this_spec) {
+                // the speculative launch exported the tables of round k-1 (4P entries each): two folds on the host
+                const E& r1 = chal[k - 1];
+                for (size_t x = 0; x < P; x++) {
+                    Kh[x] = fold2(fold2(tt[x], tt[x + 2 * P], r1), fold2(tt[x + P], tt[x + 3 * P], r1), r);
+                    Sh[x] = fold2(fold2(tt[4 * P + x], tt[4 * P + x + 2 * P], r1), fold2(tt[4 * P + x + P], tt[4 * P + x + 3 * P], r1), r);
+                }
+            } else
             for (size_t x = 0; x < P; x++) {
                 Kh[x] = fold2(tt[x], tt[x + P], r);
                 Sh[x] = fold2(tt[2 * P + x], tt[3 * P + x], r);
@@ -557,6 +684,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     }
     table_release(&ks);
     table_release(&ss);
+    if (ks2.base) table_release(&ks2);
+    if (ss2.base) table_release(&ss2);
     return 0;
 }
 

@@ -96,6 +96,7 @@ ABI = {
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_latency": (_I, [C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
+    "gkrhip_profile_counter": (_I, [C.c_char_p, C.POINTER(_U64)]),
 }
 
 
@@ -641,7 +642,9 @@ def profile_get():
     _check(load().gkrhip_profile_host(C.byref(r), C.byref(hh), C.byref(hw), C.byref(hl), C.byref(ho)))
     a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     _check(load().gkrhip_profile_latency(C.byref(a), C.byref(b), C.byref(c)))
-    return {"fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
+    sp = C.c_uint64(0)
+    _check(load().gkrhip_profile_counter(b"spec_rounds", C.byref(sp)))
+    return {"spec_rounds": sp.value, "fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
             "peval_launches": pl.value, "peval_ms": pm.value, "peval_modmuls": pmm.value,
             "rounds": r.value, "host_hash_ms": hh.value, "host_wait_ms": hw.value, "host_launch_ms": hl.value,
             "host_other_ms": ho.value, "prelaunched_rounds": a.value, "lookahead_round0": b.value, "coop_rounds": c.value}

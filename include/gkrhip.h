@@ -69,7 +69,7 @@ int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
 int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
  * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
- * "coop" -- applied to every existing lane,
+ * "coop", "spec", "spec_lg" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
  * gkrhip_init) */
 int gkrhip_set_option(const char *key, long value);
@@ -302,6 +302,10 @@ int gkrhip_profile_host(uint64_t *rounds, double *hash_ms, double *wait_ms, doub
  * (it polls a host-mapped slot), round-0 launches that used products computed during the previous layer, rounds run by
  * the cooperative eight-lanes-per-pair kernel.  The parity tests use it to prove that a switch selected the path. */
 int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_round0, uint64_t *coop_rounds);
+/* The same counters by name ("prelaunched_rounds", "lookahead_round0", "coop_rounds", and "spec_rounds": rounds whose
+ * sums were computed speculatively for the eight candidate values 0..7 of the previous challenge while the host was still
+ * hashing, and interpolated at the true challenge).  Unknown name: error. */
+int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus
 }

@@ -403,7 +403,7 @@ def test_cooperative_small_rounds(gk):
     """k_cipher_round_coop (eight lanes per pair, products dealt level by level through LDS) for the small rounds: same
     transcript with the kernel forced on for every size it takes, with the last round and the host-tail export inside
     it, several iterations per workgroup, all eight sums on the device, pre-launched or not, and switched off."""
-    on = {"GKRHIP_COOP": "2", "GKRHIP_CASE_EXPECT": "coop_rounds"}
+    on = {"GKRHIP_COOP": "2", "GKRHIP_SPEC": "0", "GKRHIP_CASE_EXPECT": "coop_rounds"}   # (the speculative rounds would take the small ones)
     _run_case(on, "1,2,3,5,6,9,12,14")
     _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "1,2,4,7,10,13")               # the P = 1 round and its tail words
     _run_case(dict(on, GKRHIP_HOST_TAIL="3", GKRHIP_COOP_WGS="2"), "6,9,11")  # export + several iterations per workgroup
@@ -412,6 +412,28 @@ def test_cooperative_small_rounds(gk):
     _run_case(dict(on, GKRHIP_COOP_LG="6", GKRHIP_GMAX="8"), "9,12")
     _run_case(dict(on, GKRHIP_HOST_TAIL="2"), "4,9", circuit="gmimc")
     _run_case({"GKRHIP_COOP": "0", "GKRHIP_CASE_EXPECT_NOT": "coop_rounds"}, "3,9,12")
+
+
+def test_speculative_small_rounds(gk):
+    """k_cipher_round_spec: the small rounds run for the eight candidate values 0..7 of the previous challenge while the host
+    is still hashing, and the host interpolates the candidates at the true challenge (degree 7 in r: exact).  Same transcript
+    with the path forced on -- every start round the sizes allow (first speculative round = the export round; several
+    speculative rounds with the tables alternating between two buffers; start at round 2 straight off the first fold), all
+    eight sums on the device, every host-tail depth, beside the cooperative kernel and the look-ahead -- and switched off."""
+    on = {"GKRHIP_SPEC": "2", "GKRHIP_CASE_EXPECT": "spec_rounds"}
+    _run_case(on, "7,8,9,10,12,14,16")
+    _run_case(dict(on, GKRHIP_SPEC_LG="5"), "8,9,11,13")                  # one or two speculative rounds just before the host takes over
+    _run_case(dict(on, GKRHIP_SPEC_LG="16", GKRHIP_GMAX="16"), "9,13,15")  # from round 2 on
+    _run_case(dict(on, GKRHIP_HOST_TAIL="1"), "5,6,9,12")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="6"), "9,10,13")
+    _run_case(dict(on, GKRHIP_CLAIM_TRICK="0"), "8,11")                   # M_0 from the candidates as well
+    _run_case(dict(on, GKRHIP_COOP="0", GKRHIP_PRE="0"), "9,12")
+    _run_case(dict(on, GKRHIP_PRE="2", GKRHIP_GMAX="8", GKRHIP_CASE_EXPECT="spec_rounds,lookahead_round0"), "11,13")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="3"), "7,10", circuit="gmimc")
+    _run_case({"GKRHIP_CASE_EXPECT": "spec_rounds,prelaunched_rounds,coop_rounds"}, "12,15")   # the defaults, alone on the GPU
+    _run_case({"GKRHIP_SPEC": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")
+    _run_case({"GKRHIP_SPEC": "2", "GKRHIP_PRELAUNCH": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")    # needs the pre-launched rounds
+    _run_case({"GKRHIP_SPEC": "2", "GKRHIP_HOST_TAIL": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")    # ... and the host tail
 
 
 def test_error_while_a_prelaunched_kernel_waits(gk):
@@ -442,9 +464,11 @@ def test_error_while_a_prelaunched_kernel_waits(gk):
         assert gk.profile_get()["prelaunched_rounds"] > 0
         print("ABORT-PATH-OK")
     """ % (root, os.path.join(root, "oracle")))
-    env = dict(os.environ, GKRHIP_TEST_FAIL_AFTER_PRELAUNCH="3", GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ABORT-PATH-OK" in out.stdout, out.stdout + out.stderr
+    # the kernel left waiting is a pre-launched round kernel (GKRHIP_SPEC=0) or a speculative launch two rounds ahead
+    for spec in ("0", "2"):
+        env = dict(os.environ, GKRHIP_TEST_FAIL_AFTER_PRELAUNCH="3", GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "ABORT-PATH-OK" in out.stdout, (spec, out.stdout + out.stderr)
 
 
 def test_lookahead_round0(gk):
