@@ -139,7 +139,7 @@ struct Ctx {
     // speculative small rounds (cipher_spec.hip.h): round k runs for the eight candidate values 0..7 of r_{k-1} while the host
     // still hashes round k-1; the host interpolates at the true challenge
     int spec = 1;                              // GKRHIP_SPEC: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
-    int spec_max_m = 22;                       // GKRHIP_SPEC_MAX_M: spec == 1 takes layers of at most 2^n entries
+    int spec_max_m = 23;                       // GKRHIP_SPEC_MAX_M: spec == 1 takes layers of at most 2^n entries
     int spec_lg = 13;                          // GKRHIP_SPEC_LG: ... for rounds of at most 2^spec_lg pairs (eight lanes per pair: 2^16 lanes = one wave per SIMD)
     unsigned long long* h_spec = nullptr;      // host-mapped: two result buffers of GKR_SPEC_BUF_WORDS words (rounds alternate)
     unsigned long long* d_spec = nullptr;

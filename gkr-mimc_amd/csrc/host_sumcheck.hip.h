@@ -346,9 +346,10 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the eight candidate values of r_{k-1} while the
     // host hashes round k-1.  Needs the pre-launched rounds (the launches it rides behind) and the host tail (its export).
     int k_s = -1;
-    // (spec == 1: only while the look-ahead kernel of the next layer is small -- from 2^23 entries on it needs the whole
-    // idle time of the small rounds, and eight candidates' worth of lanes beside it cost more than the waits they remove:
-    // bN = 24 measured 279.5 -> 281..285 ms, bN = 22 155 -> 150, bN = 20 109 -> 104)
+    // (spec == 1: only while the look-ahead kernel of the next layer is small -- at 2^24 entries it needs the whole idle
+    // time of the small rounds, and eight candidates' worth of lanes beside it cost what the waits they remove were worth,
+    // whenever the look-ahead starts: bN = 24 measured 279.5 -> 281..285 ms, bN = 23 200.4 -> 198.3, bN = 22 155 -> 150,
+    // bN = 20 109 -> 104)
     if ((cx().spec >= 2 || (cx().spec == 1 && alone && m <= cx().spec_max_m)) && !collective && pl_on && h_tail > 0) {
         for (int k = 2; k <= k_export && k_s < 0; k++) {
             const int rem = m - 1 - k;               // log2(pairs of round k)
