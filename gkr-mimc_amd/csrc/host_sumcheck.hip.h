@@ -472,7 +472,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // queue the speculative launch of round k (k_s <= k <= k_export).  k == k_s reads the tables R_{k-1} leaves in (ks, ss)
     // and needs no challenge; later rounds read the tables of round k-2, fold them with r_{k-2} (polled from slot
     // 1 + (k & 1)) and store the tables of round k-1 in the other pair of buffers
-    unsigned int spec_seq[2] = {0, 0};               // by parity of the round
+    std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);      // by round
+    bool spec_queued = false;                        // the layer's speculative launches are in the stream
     auto launch_spec = [&](int k) -> int {
         const size_t P = n >> (k + 1);
         const int gk = m - 1 - k;
@@ -495,7 +496,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.partials = cx().d_spec_racc;
         a.counter = cx().d_counter;
         a.host_out = cx().d_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
-        a.seq = spec_seq[k & 1] = ++cx().seq;
+        a.seq = spec_seq[k] = ++cx().seq;
         a.need_m0 = claim ? 0u : 1u;
         a.prefolded = pref ? 1u : 0u;
         a.tail_tables = last ? cx().d_tail : nullptr;
@@ -527,7 +528,6 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         // round k+1 queued now, behind round k's kernel: its dispatch overlaps the hash below
         const bool have_next = k + 1 < m_dev;
         const bool next_spec = is_spec(k + 1), next2_spec = is_spec(k + 2);
-        const unsigned int seq_spec_k = spec_seq[k & 1];          // round k's own speculative launch (round k+2's reuses the entry below)
         // (the round before the first speculative one is always pre-launched: the speculative launch rides behind it)
         const bool prelaunched = have_next && !next_spec && pl_on && ((P >> 1) <= ((size_t)1 << cx().prelaunch_lg) || next2_spec);
         // Un-sharded: queued BEFORE waiting for round k (the launch call itself is hidden behind round k's kernel).
@@ -537,9 +537,15 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         if (prelaunched && !collective) {
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
-            if (next2_spec) CHK(launch_spec(k + 2));             // the first speculative round: behind R_{k+1}, whose tables it reads
-        } else if (next_spec && next2_spec) {
-            CHK(launch_spec(k + 2));                             // polls r_k
+            if (next2_spec) {
+                // ALL speculative launches of the layer, now: behind R_{k+1}, whose tables the first one reads, each polling
+                // its own challenge in stream order -- and while the host is about to wait for a round of 2^(spec_lg+2) pairs
+                // anyway (launched one by one inside the speculative regime, their ~3 us each sat in the serial chain)
+                for (int kk = k + 2; kk <= (cx().spec_batch ? k_export : k + 2); kk++) CHK(launch_spec(kk));
+                spec_queued = true;
+            }
+        } else if (!cx().spec_batch && next_spec && next2_spec) {
+            CHK(launch_spec(k + 2));                             // GKRHIP_SPEC_BATCH=0: one by one, two rounds ahead
         }
         // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
         if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {
@@ -548,7 +554,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         // test hook (GKRHIP_TEST_FAIL_AFTER_PRELAUNCH=k, once per process): an error return while a pre-launched kernel is
         // waiting for its challenge -- the guard must tell it to leave, drain the stream and clear the abort tags
-        if ((prelaunched || (next_spec && next2_spec)) && k == g_test_fail_round && g_test_fail_armed.exchange(false))
+        if ((prelaunched || (next_spec && next2_spec)) && k == g_test_fail_round && g_test_fail_armed.exchange(false))   // (a speculative launch waits for r_k)
             return fail("injected failure after a pre-launch (test hook)");
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
@@ -556,7 +562,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const unsigned long long* sums = nullptr;
         const bool this_spec = is_spec(k);
         const unsigned long long* cand = cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
-        if (this_spec) CHK(wait_flag(seq_spec_k, (volatile unsigned int*)(cand + GKR_SPEC_FLAG_WORD)));
+        if (this_spec) CHK(wait_flag(spec_seq[k], (volatile unsigned int*)(cand + GKR_SPEC_FLAG_WORD)));
         else CHK(round_collect(collective, cur.tg, cur.seq, GKR_CR_WORDS, 16, summed, &sums));
         const double t_w = now_ms();
         if (prelaunched && collective) {
@@ -589,13 +595,13 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         double t_l2 = t_h1;
         if (next_spec) {
             if (next2_spec) {                                // round k+2's speculative launch folds with r_k
-                chal_publish(spec_seq[k & 1], r, r, 1 + (k & 1));
-                chal_guard.armed = false;
+                chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
+                chal_guard.armed = k + 2 < k_export;         // later speculative launches are still waiting for theirs
             }
         } else if (prelaunched) {
             const E two128 = {{0, 0, 1, 0}};
             chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
-            chal_guard.armed = false;
+            chal_guard.armed = spec_queued && k_s < k_export;    // (the speculative launches behind it wait for their own)
             cur = nxt;
         } else if (have_next) {
             CHK(launch_round(k + 1, false, r, claim != nullptr, &nxt));
