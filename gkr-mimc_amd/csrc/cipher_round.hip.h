@@ -129,7 +129,7 @@ struct CipherRoundArgs {
 // Challenge hand-over to a pre-launched round kernel.  The host writes 16 words (limbs 0..7: r, 8..15: r * 2^-128), each
 // as (seq << 32) | limb -- an aligned 8-byte word is read atomically over PCIe, so every polling lane sees a
 // consistent (seq, limb) pair whatever order the host's stores arrive in.  seq = 0xFFFFFFFF: the host gave up
-// (error path); a lane also gives up after ~8 s without an answer.  Returns false when the launch must be abandoned
+// (error path); a lane also gives up after ~20 s without an answer.  Returns false when the launch must be abandoned
 // (uniformly over the workgroup).  The sixteen limbs come back wave-uniform (SGPRs), like launch arguments.
 // ------------------------------------------------------------------------------------------------
 #define GKR_CHAL_WORDS 16
@@ -141,14 +141,18 @@ struct CipherRoundArgs {
 // very hand-off the host is waiting for (measured: +12 ms per proof) -- but the mailbox must stay a SHORTCUT, never a
 // dependency: workgroup 0 need not be resident (several pre-launched kernels, e.g. of several processes sharing the GPU,
 // can each hold part of the machine while their workgroups 0 wait for a slot: measured, a deadlock until the time-out).
-// Whoever reads the words from the host forwards them; the writes are idempotent.
+// Whoever reads the words from the host forwards them; the writes are idempotent.  ONE workgroup per launch, also of a 2-D grid:
+// the speculative launches (nine rows of workgroups) first had one host-polling workgroup per row, and a soak with the path forced on
+// for fourteen lanes -- 126 workgroups reading host memory back to back -- lost proofs to kernels that did not see, within 20 s, a
+// challenge the host had published before they started (the PCIe read path again); with one polling workgroup per launch the
+// same soak is clean.
 __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, unsigned long long* mailbox, unsigned int seq, Fr& r,
                                                Fr& r_lo, unsigned long long* diag = nullptr) {
     __shared__ u32 s_ch[GKR_CHAL_WORDS];
     int bad = 0;
     if (threadIdx.x < GKR_CHAL_WORDS) {
         const unsigned long long t0 = wall_clock64();          // 100 MHz
-        const bool first = blockIdx.x == 0;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;      // (ONE workgroup of the launch, also of a 2-D grid)
         unsigned long long v;
         bool from_host = first;
         for (unsigned it = 0;; it++) {
@@ -158,7 +162,7 @@ __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, u
                           : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 s = (u32)(v >> 32);
             if (s == seq) break;
-            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 800000000ull) {
+            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 2000000000ull) {
                 bad = 1;
                 if (diag && threadIdx.x == 0) {          // why the launch was abandoned (the host's error message quotes it)
                     diag[0] = ((unsigned long long)blockIdx.x << 32) | (s == GKR_CHAL_ABORT ? 1u : 2u);

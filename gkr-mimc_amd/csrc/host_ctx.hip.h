@@ -140,11 +140,16 @@ struct Ctx {
     // still hashes round k-1; the host interpolates at the true challenge
     int spec = 1;                              // GKRHIP_SPEC: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
     int spec_max_m = 23;                       // GKRHIP_SPEC_MAX_M: spec == 1 takes layers of at most 2^n entries
-    int spec_batch = 1;                        // GKRHIP_SPEC_BATCH: queue all speculative launches of a layer at once (0: one per round, two rounds ahead)
+    int spec_batch = 0;                        // GKRHIP_SPEC_BATCH: queue all speculative launches of a layer at once (0: one per round, two rounds ahead).  Same latency for one proof; with fourteen lanes the burst of launches blocked in the runtime for 20 s while a pre-launched kernel waited: off
     int spec_lg = 13;                          // GKRHIP_SPEC_LG: ... for rounds of at most 2^spec_lg pairs (eight lanes per pair: 2^16 lanes = one wave per SIMD)
     unsigned long long* h_spec = nullptr;      // host-mapped: two result buffers of GKR_SPEC_BUF_WORDS words (rounds alternate)
     unsigned long long* d_spec = nullptr;
     unsigned long long* d_spec_racc = nullptr; // GKR_SPEC_CAND accumulator sets, zero between launches
+    // what the host last did with the challenge slots (quoted by the error message when a waiting kernel gave up)
+    unsigned int dbg_pub_seq[3] = {0, 0, 0};
+    double dbg_pub_ms[3] = {0, 0, 0};
+    unsigned int dbg_defer_seq = 0;
+    double dbg_defer_ms = 0;
     E spec_pts[8];                             // Montgomery forms of the candidate points 0..7
     E spec_invden[8];                          // 1 / prod_{j != i} (i - j): Lagrange denominators on the points 0..7
     int pre_start_lg = 16;                     // GKRHIP_PRE_START_LG: the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
@@ -767,8 +772,17 @@ int wait_flag(unsigned int seq, volatile unsigned int* f = nullptr, double deadl
             if (e != hipSuccess && e != hipErrorNotReady) return fail("round kernel failed: %s", hipGetErrorString(e));
             if (e == hipSuccess && *f != seq) {
                 const unsigned long long* dg = cx().h_round + 104;      // wait_challenge's note, if it abandoned the launch
+                const unsigned long long* ds = cx().h_spec ? cx().h_spec : dg;      // the speculative launches' notes (two buffers)
+                const double now = now_ms();
                 return fail("round kernel finished without publishing its result (flag %u, expected %u; challenge wait: code %llx after %llu ticks, "
-                            "word %llx, seq %llu)", *f, seq, dg[0], dg[1], dg[2], dg[3]);
+                            "word %llx, seq %llu; speculative: %llx %llu %llx %llu | %llx %llu %llx %llu; host: last deferred launch seq %u %.1f ms ago, "
+                            "published seq %u / %u / %u to slots 0 / 1 / 2 %.1f / %.1f / %.1f ms ago, slot tags now %llx %llx %llx)",
+                            *f, seq, dg[0], dg[1], dg[2], dg[3], cx().h_spec ? ds[580] : 0ull, cx().h_spec ? ds[581] : 0ull,
+                            cx().h_spec ? ds[582] : 0ull, cx().h_spec ? ds[583] : 0ull, cx().h_spec ? ds[640 + 580] : 0ull,
+                            cx().h_spec ? ds[640 + 581] : 0ull, cx().h_spec ? ds[640 + 582] : 0ull, cx().h_spec ? ds[640 + 583] : 0ull,
+                            cx().dbg_defer_seq, now - cx().dbg_defer_ms, cx().dbg_pub_seq[0], cx().dbg_pub_seq[1], cx().dbg_pub_seq[2],
+                            now - cx().dbg_pub_ms[0], now - cx().dbg_pub_ms[1], now - cx().dbg_pub_ms[2], cx().h_chal[0] >> 32,
+                            cx().h_chal[16] >> 32, cx().h_chal[32] >> 32);
             }
             if (deadline_ms > 0) {
                 if (t0 == 0) t0 = now_ms();

@@ -133,6 +133,8 @@ inline void chal_publish(unsigned int seq, const E& r, const E& r_lo, int slot =
         w[8 + 2 * i + 1] = tag | (unsigned long long)(uint32_t)(r_lo.l[i] >> 32);
     }
     __sync_synchronize();
+    cx().dbg_pub_seq[slot] = seq;
+    cx().dbg_pub_ms[slot] = now_ms();
 }
 // A pre-launched kernel that will never get its challenge (error return between the launch and the hash) is told
 // to leave; the lane's stream is drained so that nothing of the failed call is still running when the caller returns.
@@ -160,14 +162,15 @@ const int g_test_fail_round = [] {
 }();
 std::atomic<bool> g_test_fail_armed{true};
 
-// Queue k_cipher_pre for the layer gkr.Prove announced (cx().req_*) on the lane's look-ahead stream.
-int launch_pre() {
-    const DevTable* K = cx().req_K;
-    const DevTable* S = cx().req_S;
-    cx().req_K = cx().req_S = nullptr;
-    if (!K || !S || cx().req_m < 2) return 0;
+// The slow parts of the look-ahead -- the second stream (created on first use: a lane that never looks ahead holds one
+// hardware queue, not two) and the six scratch tables (a miss in the arena is a hipMalloc behind the arena's lock) -- are done
+// at the START of the round loop, where no kernel of the lane is waiting for the host: a pre-launched or speculative kernel
+// gives up after 20 s without its challenge, and nothing that can block for an unbounded time (another lane holding the arena's
+// lock across its own hipMalloc) belongs between a pre-launch and the publication of its challenge.
+int pre_prepare() {
+    if (!cx().req_K || !cx().req_S || cx().req_m < 2) return 0;
     const size_t P = (size_t)1 << (cx().req_m - 1);
-    if (!cx().aux) {      // created on first use: a lane that never looks ahead holds one hardware queue, not two
+    if (!cx().aux) {
         int least = 0, greatest = 0;               // lowest priority: the look-ahead kernel must never delay a round kernel
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&cx().aux, hipStreamNonBlocking, least));
@@ -178,6 +181,16 @@ int launch_pre() {
             if (t.base) table_release(&t);
             CHK(table_alloc(&t, P));
         }
+    return 0;
+}
+// Queue k_cipher_pre for the layer gkr.Prove announced (cx().req_*) on the lane's look-ahead stream.
+int launch_pre() {
+    CHK(pre_prepare());                            // (a no-op after the call at the start of the round loop)
+    const DevTable* K = cx().req_K;
+    const DevTable* S = cx().req_S;
+    cx().req_K = cx().req_S = nullptr;
+    if (!K || !S || cx().req_m < 2) return 0;
+    const size_t P = (size_t)1 << (cx().req_m - 1);
     CipherPreArgs a;
     memset(&a, 0, sizeof a);
     a.k_src = K->cplanes();
@@ -342,6 +355,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // pre-launched rounds: the next round's kernel is queued before this round is hashed and polls the challenge slot
     const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);
     const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
+    if (pre_on) CHK(pre_prepare());                  // nothing of this lane is waiting for the host yet
     const bool coop_on = cx().coop >= 2 || (cx().coop == 1 && alone);
     // speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the eight candidate values of r_{k-1} while the
     // host hashes round k-1.  Needs the pre-launched rounds (the launches it rides behind) and the host tail (its export).
@@ -409,6 +423,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             a.chal_dev = cx().d_chal_dev;
             a.chal_seq = a.seq;
             chal_guard.armed = true;
+            cx().dbg_defer_seq = a.seq;
+            cx().dbg_defer_ms = now_ms();
         } else {
             const E two128 = {{0, 0, 1, 0}};                 // the plain integer 2^128: mul divides by 2^256
             a.r = to_dev(r_in);
@@ -506,6 +522,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
             a.chal_seq = a.seq;
             chal_guard.armed = true;
+            cx().dbg_defer_seq = a.seq;
+            cx().dbg_defer_ms = now_ms();
         }
         const int gx = (int)std::max<size_t>(P / GKR_BLOCK, 1);
         const bool row8 = !pref || last;             // the fold-and-store row (a plain copy to the host when the tables are folded already)
@@ -869,6 +887,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
     const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);   // see cipher_rounds
     const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
+    if (pre_on) CHK(pre_prepare());                  // see cipher_rounds
     ChalGuard chal_guard;
     struct InFlight {
         RoundTargets tg;
