@@ -140,6 +140,7 @@ struct Ctx {
     // still hashes round k-1; the host interpolates at the true challenge
     int spec = 1;                              // GKRHIP_SPEC: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
     int spec_max_m = 23;                       // GKRHIP_SPEC_MAX_M: spec == 1 takes layers of at most 2^n entries
+    int spec_poll = 1;                         // GKRHIP_SPEC_POLL: 1: a speculative launch is queued two rounds ahead and polls for its challenge; 0: it is launched with the challenge as an argument once the host has it
     int spec_batch = 0;                        // GKRHIP_SPEC_BATCH: queue all speculative launches of a layer at once (0: one per round, two rounds ahead).  Same latency for one proof; with fourteen lanes the burst of launches blocked in the runtime for 20 s while a pre-launched kernel waited: off
     int spec_lg = 13;                          // GKRHIP_SPEC_LG: ... for rounds of at most 2^spec_lg pairs (eight lanes per pair: 2^16 lanes = one wave per SIMD)
     unsigned long long* h_spec = nullptr;      // host-mapped: two result buffers of GKR_SPEC_BUF_WORDS words (rounds alternate)
@@ -340,6 +341,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_SPEC")) cx().spec = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC_MAX_M")) cx().spec_max_m = std::max(0, std::min(40, atoi(e)));
     if (const char* e = getenv("GKRHIP_SPEC_BATCH")) cx().spec_batch = atoi(e);
+    if (const char* e = getenv("GKRHIP_SPEC_POLL")) cx().spec_poll = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
@@ -477,6 +479,7 @@ void lane_configure(Ctx* l) {
     l->spec = g0.spec;
     l->spec_lg = g0.spec_lg;
     l->spec_batch = g0.spec_batch;
+    l->spec_poll = g0.spec_poll;
     l->spec_max_m = g0.spec_max_m;
     l->coop = g0.coop;
     l->coop_lg = g0.coop_lg;

@@ -490,7 +490,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // 1 + (k & 1)) and store the tables of round k-1 in the other pair of buffers
     std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);      // by round
     bool spec_queued = false;                        // the layer's speculative launches are in the stream
-    auto launch_spec = [&](int k) -> int {
+    auto launch_spec = [&](int k, const E* r_arg = nullptr) -> int {
         const size_t P = n >> (k + 1);
         const int gk = m - 1 - k;
         const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
@@ -516,7 +516,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.need_m0 = claim ? 0u : 1u;
         a.prefolded = pref ? 1u : 0u;
         a.tail_tables = last ? cx().d_tail : nullptr;
-        if (!pref) {
+        if (!pref && r_arg) {
+            a.r = to_dev(*r_arg);                    // GKRHIP_SPEC_POLL=0: launched once r_{k-2} is known, no polling
+        } else if (!pref) {
             const int slot = 1 + (k & 1);
             a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
             a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
@@ -562,7 +564,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
                 for (int kk = k + 2; kk <= (cx().spec_batch ? k_export : k + 2); kk++) CHK(launch_spec(kk));
                 spec_queued = true;
             }
-        } else if (!cx().spec_batch && next_spec && next2_spec) {
+        } else if (!cx().spec_batch && cx().spec_poll && next_spec && next2_spec) {
             CHK(launch_spec(k + 2));                             // GKRHIP_SPEC_BATCH=0: one by one, two rounds ahead
         }
         // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
@@ -612,7 +614,9 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_h1 = now_ms();
         double t_l2 = t_h1;
         if (next_spec) {
-            if (next2_spec) {                                // round k+2's speculative launch folds with r_k
+            if (next2_spec && !cx().spec_poll && !cx().spec_batch) {
+                CHK(launch_spec(k + 2, &r));                 // round k+2's speculative launch, with r_k as a launch argument
+            } else if (next2_spec) {                         // round k+2's speculative launch folds with r_k
                 chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
                 chal_guard.armed = k + 2 < k_export;         // later speculative launches are still waiting for theirs
             }

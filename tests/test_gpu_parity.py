@@ -428,6 +428,8 @@ def test_speculative_small_rounds(gk):
     _run_case(dict(on, GKRHIP_HOST_TAIL="6"), "9,10,13")
     _run_case(dict(on, GKRHIP_CLAIM_TRICK="0"), "8,11")                   # M_0 from the candidates as well
     _run_case(dict(on, GKRHIP_COOP="0", GKRHIP_PRE="0"), "9,12")
+    _run_case(dict(on, GKRHIP_SPEC_POLL="0"), "8,10,13")                  # launched with the challenge as an argument instead of polling for it
+    _run_case(dict(on, GKRHIP_SPEC_BATCH="1"), "9,13")                    # all of a layer's speculative launches queued at once
     _run_case(dict(on, GKRHIP_PRE="2", GKRHIP_GMAX="8", GKRHIP_CASE_EXPECT="spec_rounds,lookahead_round0"), "11,13")
     _run_case(dict(on, GKRHIP_HOST_TAIL="3"), "7,10", circuit="gmimc")
     _run_case({"GKRHIP_CASE_EXPECT": "spec_rounds,prelaunched_rounds,coop_rounds"}, "12,15")   # the defaults, alone on the GPU
