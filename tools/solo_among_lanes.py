@@ -16,7 +16,7 @@ def warm(s):
 ths = [threading.Thread(target=warm, args=(s,)) for s in ss]
 [t.start() for t in ths]; [t.join() for t in ths]
 gk.synchronize()
-for which in (0, lanes - 1):
+for which in (range(lanes) if os.environ.get('SOLO_ALL') else (0, lanes - 1)):
     lat = []
     for _ in range(reps):
         gk.profile_reset(0)
