@@ -887,19 +887,21 @@ def main():
         def call(_k):
             gk.gkr_prove_mimc(ins[0], ins[1], qp)
 
-        ths = [threading.Thread(target=call, args=(k,)) for k in range(nthr)]
-        t0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        par = time.perf_counter() - t0
+        par = None
+        for _round in range(2):      # the first round is untimed: the device arena holds whatever the earlier parts of this run left in it
+            ths = [threading.Thread(target=call, args=(k,)) for k in range(nthr)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            par = time.perf_counter() - t0
         out["oneshot_including_pcie"] = {
             "one_call_s": one, "one_call_hashes_per_s": n / one,
             "concurrent_calls": nthr, "concurrent_wall_s": par, "concurrent_hashes_per_s": nthr * n / par,
             "per_call_bytes_over_pcie": 3 * 32 * n,
             "note": "gkrhip_gkr_prove_mimc on pageable host buffers (2 x %d MiB up, %d MiB down per call); the concurrent figure is "
-                    "%d calls from %d host threads, each on a lane of its own" % (32 * n >> 20, 32 * n >> 20, nthr, nthr)}
+                    "%d calls from %d host threads, each on a lane of its own (second round: the first fills the device arena)" % (32 * n >> 20, 32 * n >> 20, nthr, nthr)}
     if rank == 0 and not args.no_cpu_baseline and not multi and args.circuit == "mimc":
         out["cpu_baseline"] = cpu_baseline()
     out["build"] = {"source_sha256": (build_info.get("source_sha256") or "")[:16], "hipcc": build_info.get("hipcc", "")}
