@@ -820,8 +820,8 @@ def main():
         configs = {}
         # small proofs are bound by the serial chain of rounds, not by the GPU: more of them in flight (a 2^20-hash assignment
         # is 3 GB) -- measured: bN = 20 31.9 / 38.3 / 42.4 / 44.3 M hashes/s with 5 / 8 / 12 / 16 lanes (later, one box: 44.8 / 47.0 / 47.5 / 47.9 with
-        # 16 / 24 / 32 / 48), GMiMC bN = 22 78.7 / 85.5 with 5 / 8
-        for key, circ, cbn, csteps, clanes in (("bn20", "mimc", 20, 48, 24), ("gmimc_bn22", "gmimc", 22, 16, 8)):
+        # 16 / 24 / 32 / 48), GMiMC bN = 22 78.7 / 85.5 with 5 / 8 (later: 85.8 / 89.3 / 89.2 with 8 / 12 / 16)
+        for key, circ, cbn, csteps, clanes in (("bn20", "mimc", 20, 48, 24), ("gmimc_bn22", "gmimc", 22, 24, 12)):
             cl = lanes_that_fit(circ, cbn, max(args.concurrent, clanes) if args.concurrent > 1 else 1, csteps)
             cj = Job(gk, cbn, cl, gk.gmimc_t2_circuit() if circ == "gmimc" else None)
             cj.run_steps(max(2, cl))
