@@ -47,11 +47,15 @@ def test_bench_line_contract():
             assert e["proof_verified_by_native_gkr_verify"] is True
             assert abs(e["hashes_per_s"] - (1 << bn) * 1e3 / e["ms_per_step"]) / e["hashes_per_s"] < 1e-6
             assert e["single_proof_ms"] > e["ms_per_step"] > 0
+            hq = e.get("with_16_hardware_queues")      # end of round 3: the same config in a child process with GKRHIP_HW_QUEUES=16
+            if hq and "error" not in hq:
+                assert hq["hw_queues"] == 16 and hq["proof_verified_by_native_gkr_verify"] is True and hq["hashes_per_s"] > 0
         assert d["micro"]["partial_eval_bn15"]["us_per_dispatch"] > 0
         assert c["ns_per_field_mul_per_core"] <= 25, "the CPU baseline must be in the class of gnark-crypto's assembly"
         assert c["fr_mul_isolated_ns"]["nocarry_unrolled"]["independent"] > 0
         sp = d["single_proof"]
         assert sp["prelaunched_rounds"] > 0 and sp["lookahead_round0"] > 0 and sp["coop_rounds"] > 0
+        assert "spec_rounds" not in sp or sp["spec_rounds"] == 0       # bN = 24: the speculative rounds stay off by their size limit
 
 
 def test_multi_rank_line_is_marked_when_no_rccl_pass_succeeded():
