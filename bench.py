@@ -361,7 +361,7 @@ PASS_TRANSPORT = {
     "shm_tick": "host shared memory (one node), all lanes through the ticker: the ticker's logic with its tick all-reduce done on the host",
     "rccl_one_lane": "RCCL ncclAllReduce (ncclUint64, ncclSum) over xGMI on the lane's stream, ONE lane (one communicator)",
     "rccl_tick": "RCCL ncclAllReduce over xGMI, all lanes through the ticker (one communicator, one issuing thread, batched ticks)",
-    "rccl_lanes": "RCCL ncclAllReduce over xGMI, one communicator and stream per lane (GPU_MAX_HW_QUEUES = 8)",
+    "rccl_lanes": "RCCL ncclAllReduce over xGMI, one communicator and stream per lane (one hardware queue each: GPU_MAX_HW_QUEUES = 16)",
     "rccl_tick_dev": "RCCL ncclAllReduce over xGMI, all lanes through the ticker, the all-reduce on device staging buffers "
                      "(run only when the ticker pass on host-mapped buffers failed)",
 }
@@ -393,10 +393,12 @@ def orchestrate(args):
         if name == "rccl_tick_dev":
             env["GKRHIP_TICK_DEVICE_BUF"] = "1"
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # the children rendezvous on a store of their own (rank 0's child hosts it)
-        if name == "rccl_lanes":
-            # one hardware queue per lane stream (ROCclr's default is 4 queues for all streams): the collective kernels of
-            # different lanes must be able to run side by side, whatever order the ranks issue them in
-            env.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # 16 hardware queues per process instead of the runtime's 4: with up to 8 lanes per rank, kernels of different lanes that
+        # share a hardware queue run one after the other (world = 1 with every round forced through the exchange, 8 lanes at
+        # bN = 23 -- a rank's share of the 2^26 proof: shm 75.1 -> 79.4 M hashes/s, rccl_tick 70.0 -> 74.8); and the rccl_lanes
+        # pass NEEDS one queue per lane stream: the collective kernels of different lanes must be able to run side by side,
+        # whatever order the ranks issue them in
+        env.setdefault("GPU_MAX_HW_QUEUES", "16")
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--pass", name]
         t0 = time.time()
         try:
