@@ -309,9 +309,10 @@ int ctx_init(int dev) {
     // Streams share the runtime's hardware queues (4 by default), and kernels of different streams in one hardware queue run
     // one after the other -- with many small proofs in flight that, not the GPU, is the limit: bN = 20 with 24 lanes 46.4 M
     // hashes/s on 4 queues, 47.3 on 8, 54.0 on 16, 52.4 on 24; the GMiMC circuit at bN = 22 with 8 lanes 85.1 / 88.2 / 91.4;
-    // bN = 24 with 5 lanes: no difference.  But it is not free: in two bench.py runs 16 queues cost the proof that is alone
-    // on the GPU 10 ms (289.6 / 292.1 against 279-283 ms at bN = 24, five sessions alive), so the runtime's default stays and
-    // GKRHIP_HW_QUEUES=n is a knob for hosts that prove many small instances at once.  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the knob only takes effect if the library
+    // bN = 24 with 5 lanes: no difference.  For the proof that is alone on the GPU (bN = 24, five sessions alive) the picture
+    // is mixed: 289.6 / 292.1 ms in two bench.py runs with 16 queues against 279-283 with the runtime's 4, and 276.2 / 277.2
+    // against 277.7 / 277.8 in two same-box pairs -- so the runtime's default stays and GKRHIP_HW_QUEUES=n is a knob for
+    // hosts that prove many small instances at once (bench.py uses it for exactly those measurements).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the knob only takes effect if the library
     // makes the process's first HIP call; an explicit setting of the variable is left alone.
     if (!getenv("GPU_MAX_HW_QUEUES")) {
         const char* hq = getenv("GKRHIP_HW_QUEUES");
