@@ -438,6 +438,23 @@ def test_speculative_small_rounds(gk):
     _run_case({"GKRHIP_SPEC": "2", "GKRHIP_HOST_TAIL": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")    # ... and the host tail
 
 
+def test_speculative_rounds_random_settings(gk):
+    """The speculative path under seeded random combinations of everything that moves its boundaries: the size, where the host
+    takes over, the largest round the path takes, the thread limit of a round (which decides where one-pair-per-lane rounds
+    begin), polling or argument launches, with and without the cooperative kernel and the look-ahead beside it."""
+    import random
+    rng = random.Random(20261003)
+    for _ in range(10):
+        env = {"GKRHIP_SPEC": "2", "GKRHIP_CASE_EXPECT": "spec_rounds",
+               "GKRHIP_HOST_TAIL": str(rng.randint(1, 6)), "GKRHIP_SPEC_LG": str(rng.randint(5, 16)),
+               "GKRHIP_GMAX": str(rng.choice([8, 10, 12, 16])), "GKRHIP_SPEC_POLL": str(rng.randint(0, 1)),
+               "GKRHIP_COOP": str(rng.choice([0, 2])), "GKRHIP_PRE": str(rng.choice([0, 2])),
+               "GKRHIP_CLAIM_TRICK": str(rng.choice([0, 1, 1]))}
+        env["GKRHIP_SPEC_LG"] = str(max(int(env["GKRHIP_SPEC_LG"]), int(env["GKRHIP_HOST_TAIL"]) + 1))   # the export round itself qualifies
+        sizes = sorted(rng.sample(range(int(env["GKRHIP_HOST_TAIL"]) + 4, 15), 2))
+        _run_case(env, ",".join(map(str, sizes)))
+
+
 def test_error_while_a_prelaunched_kernel_waits(gk):
     """An error return between the pre-launch of a round and the publication of its challenge (injected by a test hook):
     the call fails with that error, the waiting kernel is told to leave, and the NEXT proofs on the same lane -- whose
