@@ -396,3 +396,44 @@ def test_compute_h_restatement_against_schoolbook_division():
     for e in load("compute_h.json"):
         got = F.compute_h([int(x, 16) for x in e["a"]], [int(x, 16) for x in e["b"]], [int(x, 16) for x in e["c"]], e["cardinality"] or None)
         assert [hex(x) for x in got] == e["h"]
+
+
+def test_round_sums_are_degree_7_in_the_previous_challenge():
+    """The fact the speculative rounds rest on (cipher_spec.hip.h): with the tables of round k being the tables of round
+    k-1 folded with r (poly/multilin.go:27-34), the monomial sums M_j(r) = sum_x W(x) u_x(r)^(7-j) d_x(r)^j of the cipher
+    gate's round are polynomials of degree 7 in r -- so their values at r = 0..7 determine them, and Lagrange interpolation
+    on those eight points reproduces the sums at any challenge exactly.  Plain Python integers, no library code."""
+    import random
+    q = o.Q
+    rng = random.Random(7)
+    P = 4                                                     # pairs of round k; the previous round's tables have 4P entries
+    K = [rng.randrange(q) for _ in range(4 * P)]
+    S = [rng.randrange(q) for _ in range(4 * P)]
+    W = [rng.randrange(q) for _ in range(P)]
+    ark = rng.randrange(q)
+
+    def sums(r):
+        fold = lambda t: [(t[i] + r * (t[i + 2 * P] - t[i])) % q for i in range(2 * P)]     # binds the top index bit
+        k, s = fold(K), fold(S)
+        out = []
+        for j in range(8):
+            acc = 0
+            for x in range(P):
+                u = (k[x] + s[x] + ark) % q
+                d = ((k[x + P] - k[x]) + (s[x + P] - s[x])) % q
+                acc += W[x] * pow(u, 7 - j, q) * pow(d, j, q)
+            out.append(acc % q)
+        return out
+
+    cand = [sums(i) for i in range(8)]
+    for r in (8, 12345, rng.randrange(q), q - 1, 3):          # (3: one of the points themselves)
+        L = []
+        for i in range(8):
+            num = den = 1
+            for jj in range(8):
+                if jj != i:
+                    num = num * (r - jj) % q
+                    den = den * (i - jj) % q
+            L.append(num * pow(den, q - 2, q) % q)
+        got = [sum(L[i] * cand[i][j] for i in range(8)) % q for j in range(8)]
+        assert got == sums(r), r
