@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Soak of the paths a proof takes when it is ALONE on the GPU (pre-launched rounds, look-ahead, cooperative and speculative
+kernels -- the defaults): proofs of several sizes one at a time, every proof of a size byte-identical to the first one (which
+the native verifier accepted).   python tools/stress_solo.py [seconds]"""
+import hashlib, importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import random_fr_array_np  # noqa: E402
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    gk = importlib.import_module("gkr-mimc_amd")
+    gk.init(0)
+    sizes = [7, 9, 10, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22]
+    sess, want, qps = {}, {}, {}
+    for bn in sizes:
+        s = gk.MimcSession(bn); s.synth_inputs(); s.assign()
+        sess[bn] = s
+        qps[bn] = random_fr_array_np(bn)
+        flat = s.prove(qps[bn])
+        assert s.verify(qps[bn], flat), bn
+        want[bn] = hashlib.sha256(flat.tobytes()).hexdigest()
+    gk.profile_reset(0)
+    stop, n, bad = time.time() + budget, 0, []
+    while time.time() < stop and not bad:
+        for bn in sizes:
+            if hashlib.sha256(sess[bn].prove(qps[bn]).tobytes()).hexdigest() != want[bn]:
+                bad.append((bn, n))
+            n += 1
+    p = gk.profile_get()
+    print("solo soak: %d proofs of sizes %s one at a time, mismatches: %s; speculative rounds %d, cooperative %d, pre-launched %d, look-ahead %d"
+          % (n, sizes, bad, p["spec_rounds"], p["coop_rounds"], p["prelaunched_rounds"], p["lookahead_round0"]))
+    sys.exit(1 if bad else 0)
+
+main()
