@@ -1182,6 +1182,19 @@ def test_soak_lanes_deterministic(gk):
     assert out.returncode == 0 and "mismatches: []" in out.stdout, out.stdout + out.stderr
 
 
+def test_soak_one_proof_at_a_time(gk):
+    """The paths a proof takes when it is alone on the GPU, as they are by default: proofs of fourteen sizes one at a time for a
+    few seconds, every one byte-identical to the first of its size (which the native verifier accepted), and the speculative,
+    cooperative, pre-launched and look-ahead paths all taken."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_solo.py"), "8"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: []" in out.stdout, out.stdout + out.stderr
+    counts = dict(zip(("spec", "coop", "pre", "look"), [int(w.strip(",")) for w in out.stdout.split("speculative rounds")[1].replace(
+        "cooperative", "").replace("pre-launched", "").replace("look-ahead", "").split()[:4]]))
+    assert all(v > 0 for v in counts.values()), counts
+
+
 def test_soak_lanes_with_the_solo_paths_forced_on(gk):
     """The same soak with the round-3 serial-latency paths forced on for EVERY lane (pre-launched rounds polling their
     challenge, look-ahead kernels on second streams, the cooperative kernel): many spinning kernels, look-ahead launches and
