@@ -22,6 +22,7 @@
 // folds K and S separately and stores them (the next launch's input, and the host tail's export).
 #pragma once
 #include "cipher_round.hip.h"
+#include "linear_round.hip.h"
 
 #define GKR_SPEC_CAND 8                                         // candidates rho = 0 .. 7: degree 7 in r
 #define GKR_SPEC_SET_WORDS (GKR_RACC_SLOTS * GKR_RACC_STRIDE)   // accumulator words per candidate (striped like the round kernels')
@@ -64,7 +65,8 @@ __device__ __forceinline__ Fr spec_fold(const Fr& lo, const Fr& hi, const Fr& r)
 // lo (256 bits) + top * 2^256 and stores lo mod q + top * R mod q as a canonical element (4 u64) -- two products on a
 // GPU that is waiting anyway, instead of 56 reductions on the host inside the serial chain.
 __device__ __forceinline__ void spec_publish(unsigned long long* racc, unsigned int* counter, unsigned long long* host_out,
-                                             unsigned int* host_flag, unsigned int seq, unsigned int nblocks, unsigned int* s_last) {
+                                             unsigned int* host_flag, unsigned int seq, unsigned int nblocks, unsigned int* s_last,
+                                             int ncand = GKR_SPEC_CAND, int nsum = GKR_CR_NSUM) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -80,8 +82,8 @@ __device__ __forceinline__ void spec_publish(unsigned long long* racc, unsigned 
     }
     __syncthreads();
     if (*s_last) {
-        if (threadIdx.x < GKR_SPEC_CAND * GKR_CR_NSUM) {
-            const int cand = threadIdx.x / GKR_CR_NSUM, j = threadIdx.x % GKR_CR_NSUM;
+        if ((int)threadIdx.x < ncand * nsum) {
+            const int cand = threadIdx.x / nsum, j = threadIdx.x % nsum;
             unsigned long long* base = racc + (size_t)cand * GKR_SPEC_SET_WORDS + (size_t)j * GKR_ACC_WORDS;
             unsigned long long w[GKR_ACC_WORDS];
 #pragma unroll
@@ -215,4 +217,79 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_spec(CipherSpecAr
     // arrival count: its stores must be complete before the host, or the next launch, is told
     block_reduce_acc<GKR_CR_NSUM, 18, true>(acc, a.partials + (size_t)(row < GKR_SPEC_CAND ? row : 0) * GKR_SPEC_SET_WORDS);
     spec_publish(a.partials, a.counter, a.host_out, (unsigned int*)(a.host_out + GKR_SPEC_FLAG_WORD), a.seq, gridDim.x * gridDim.y, &s_last);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same for the single-point round of a LINEAR gate (linear_round.hip.h): its two sums are LINEAR in the previous
+// challenge, M_j(r) = (1 - r) M_j(0) + r M_j(1), and the candidates 0 and 1 need no arithmetic of their own: folding the
+// tables of round k-1 with 0 or 1 selects their lower or upper half.  Grid rows 0, 1: the candidates; row 2: fold with
+// r_{k-2} and store (and export) the tables of round k-1.
+// ------------------------------------------------------------------------------------------------------------------
+#define GKR_LSPEC_CAND 2
+struct LinearSpecArgs {
+    CPlanes src[GKR_MAX_ARITY];   // prefolded == 0: the tables of round k-2 (8P entries); else of round k-1 (4P entries)
+    Planes dst[GKR_MAX_ARITY];    // the tables of round k-1 (4P entries; lo == nullptr: not stored)
+    CPlanes wt;
+    size_t P;
+    Fr r;
+    Fr ark;
+    int arity;
+    unsigned sum_mask;
+    unsigned long long* partials;   // GKR_LSPEC_CAND sets of GKR_SPEC_SET_WORDS words
+    unsigned int* counter;
+    unsigned long long* host_out;   // host-mapped: GKR_SPEC_BUF_WORDS words (4 canonical elements: M_0(0), M_1(0), M_0(1), M_1(1))
+    unsigned int seq;
+    unsigned int need_m0;
+    unsigned int prefolded;
+    unsigned long long* tail_tables;   // host-mapped or nullptr: the tables of round k-1, table t at 4 * t * 4P (4P entries of 4 u64)
+    const unsigned long long* chal;
+    unsigned long long* chal_dev;
+    unsigned int chal_seq;
+};
+
+__global__ void __launch_bounds__(GKR_BLOCK) k_linear_round_spec(LinearSpecArgs a) {
+    __shared__ unsigned int s_last;
+    __builtin_amdgcn_s_setprio(3);
+    const size_t P = a.P;
+    const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = x < P;
+    const unsigned row = blockIdx.y;
+    Fr r = a.r, r_unused = a.r;
+    if (!a.prefolded && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, r, r_unused, a.host_out + GKR_SPEC_DIAG_WORD)) return;
+    Acc9 acc[GKR_LR_NSUM];
+#pragma unroll
+    for (int t = 0; t < GKR_LR_NSUM; t++)
+#pragma unroll
+        for (int j = 0; j < GKR_ACC_WORDS; j++) acc[t].w[j] = 0;
+    // entry y of round k-1's table (4P entries): read, or folded from the entries (y, y + 4P) of round k-2's
+    auto entry = [&](int t, size_t y) {
+        const Fr lo = ld_fr(a.src[t].lo, a.src[t].hi, y);
+        return a.prefolded ? lo : spec_fold(lo, ld_fr(a.src[t].lo, a.src[t].hi, y + 4 * P), r);
+    };
+    if (row == GKR_LSPEC_CAND) {
+        if (live && (a.dst[0].lo || a.tail_tables)) {
+            for (int t = 0; t < a.arity; t++)
+                for (int i = 0; i < 4; i++) {
+                    const Fr f = entry(t, x + (size_t)i * P);
+                    if (a.dst[0].lo) st_fr(a.dst[t].lo, a.dst[t].hi, x + (size_t)i * P, f);
+                    if (a.tail_tables) spec_export(a.tail_tables + 4 * ((size_t)t * 4 * P + x + (size_t)i * P), f);
+                }
+        }
+    } else if (live) {
+        // candidate rho = row: round k's tables are the lower (0) or upper (1) half of round k-1's; this pair is (x, x + P) of it
+        const size_t base = x + 2 * P * row;
+        Fr u = a.ark, d = fr_zero();
+        for (int t = 0; t < a.arity; t++)
+            if ((a.sum_mask >> t) & 1u) {
+                const Fr lo = entry(t, base), hi = entry(t, base + P);
+                u = fr_add(u, lo);
+                d = fr_add(d, fr_sub(hi, lo));
+            }
+        const Fr W = ld_fr(a.wt.lo, a.wt.hi, x);
+        if (a.need_m0) acc_add_raw(acc[0], fr_mont_mul_raw(W, u));
+        acc_add_raw(acc[1], fr_mont_mul_raw(W, d));
+    }
+    block_reduce_acc<GKR_LR_NSUM, 18, true>(acc, a.partials + (size_t)(row < GKR_LSPEC_CAND ? row : 0) * GKR_SPEC_SET_WORDS);
+    spec_publish(a.partials, a.counter, a.host_out, (unsigned int*)(a.host_out + GKR_SPEC_FLAG_WORD), a.seq, gridDim.x * gridDim.y, &s_last,
+                 GKR_LSPEC_CAND, GKR_LR_NSUM);
 }

@@ -875,6 +875,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     if (cx().racc_dirty) {   // see cipher_rounds
         HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
+        if (cx().d_spec_racc) HIPCHK(hipMemsetAsync(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS, cx().stream));
     }
     cx().racc_dirty = true;
     if (collective) CHK(coll_buffers(256));
@@ -892,6 +893,23 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);   // see cipher_rounds
     const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
     if (pre_on) CHK(pre_prepare());                  // see cipher_rounds
+    // speculative rounds (cipher_spec.hip.h, k_linear_round_spec): the two sums of a linear gate's round are linear in the
+    // previous challenge, so the candidates 0 and 1 -- the lower and the upper half of the previous round's tables -- suffice
+    int k_s = -1;
+    if ((cx().spec >= 2 || (cx().spec == 1 && alone && m <= cx().spec_max_m)) && !collective && pl_on && h_tail > 0 &&
+        (size_t)arity * 4 * 4 * ((size_t)2 << h_tail) <= kTailWords) {        // the export: 4P entries per table, P = 2^(h+1)
+        for (int k = 2; k <= k_export && k_s < 0; k++) {
+            const int rem = m - 1 - k;
+            if (rem <= cx().spec_lg && std::min(g_lin, rem) == rem) k_s = k;
+        }
+    }
+    auto is_spec = [&](int k) { return k_s >= 0 && k >= k_s && k <= k_export; };
+    ScopedTable scratch2[GKR_MAX_ARITY];
+    if (k_s >= 0) {
+        CHK(spec_ensure());
+        if (k_s < k_export)
+            for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch2[t], (size_t)4 << (m - 1 - (k_s + 1))));
+    }
     ChalGuard chal_guard;
     struct InFlight {
         RoundTargets tg;
@@ -951,16 +969,64 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         HIPCHK(hipGetLastError());
         return 0;
     };
+    // the speculative launch of round k (see cipher_rounds): k == k_s reads the tables R_{k-1} leaves in `scratch`; later rounds
+    // read the tables of round k-2, fold them with r_{k-2} (slot 1 + (k & 1), or the launch argument) and store round k-1's
+    std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);
+    auto launch_spec = [&](int k, const E* r_arg) -> int {
+        const size_t P = n >> (k + 1);
+        const int gk = m - 1 - k;
+        const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
+        LinearSpecArgs a;
+        memset(&a, 0, sizeof a);
+        for (int t = 0; t < arity; t++) {
+            a.src[t] = ((pref || odd) ? scratch[t] : scratch2[t]).cplanes();
+            if (!pref && !last) a.dst[t] = (odd ? scratch2[t] : scratch[t]).planes();
+        }
+        const size_t offT = ((size_t)1 << gk) - 1;
+        a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
+        a.P = P;
+        a.ark = to_dev(ark);
+        a.arity = arity;
+        a.sum_mask = g.mask;
+        a.partials = cx().d_spec_racc;
+        a.counter = cx().d_counter;
+        a.host_out = cx().d_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
+        a.seq = spec_seq[k] = ++cx().seq;
+        a.need_m0 = claim ? 0u : 1u;
+        a.prefolded = pref ? 1u : 0u;
+        a.tail_tables = last ? cx().d_tail : nullptr;
+        if (!pref && r_arg) {
+            a.r = to_dev(*r_arg);
+        } else if (!pref) {
+            const int slot = 1 + (k & 1);
+            a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
+            a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
+            a.chal_seq = a.seq;
+            chal_guard.armed = true;
+            cx().dbg_defer_seq = a.seq;
+            cx().dbg_defer_ms = now_ms();
+        }
+        const int gx = (int)std::max<size_t>(P / GKR_BLOCK, 1);
+        hipLaunchKernelGGL(k_linear_round_spec, dim3(gx, (!pref || last) ? GKR_LSPEC_CAND + 1 : GKR_LSPEC_CAND), dim3(GKR_BLOCK), 0,
+                           cx().stream, a);
+        HIPCHK(hipGetLastError());
+        g_cnt_spec.fetch_add(1, std::memory_order_relaxed);
+        return 0;
+    };
     InFlight cur, nxt;
     CHK(launch_round(0, false, hfr::ZERO, claim && *claim_known, &cur));
     bool pre_requested = cx().req_K != nullptr && pre_on;
     for (int k = 0; k < m_dev; k++) {
         const size_t P = n >> (k + 1);
         const bool have_next = k + 1 < m_dev;
-        const bool prelaunched = have_next && pl_on && (P >> 1) <= ((size_t)1 << cx().prelaunch_lg);
+        const bool next_spec = is_spec(k + 1), next2_spec = is_spec(k + 2), this_spec = is_spec(k);
+        const bool prelaunched = have_next && !next_spec && pl_on && ((P >> 1) <= ((size_t)1 << cx().prelaunch_lg) || next2_spec);
         if (prelaunched && !collective) {      // see cipher_rounds
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+            if (next2_spec) CHK(launch_spec(k + 2, nullptr));      // the first speculative round: behind R_{k+1}, no challenge of its own
+        } else if (cx().spec_poll && next_spec && next2_spec) {
+            CHK(launch_spec(k + 2, nullptr));                      // polls r_k
         }
         if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {   // the next (cipher) layer's look-ahead
             CHK(launch_pre());
@@ -968,15 +1034,26 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         }
         unsigned long long summed[GKR_LR_WORDS];
         const unsigned long long* sums = nullptr;
-        CHK(round_collect(collective, cur.tg, cur.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
+        const E* cand = (const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS);      // M_0(0), M_1(0), M_0(1), M_1(1)
+        if (this_spec) CHK(wait_flag(spec_seq[k], (volatile unsigned int*)((const unsigned long long*)cand + GKR_SPEC_FLAG_WORD)));
+        else CHK(round_collect(collective, cur.tg, cur.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
         if (prelaunched && collective) {
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
         }
-        const bool derive_m0 = cur.derive_m0;
+        const bool derive_m0 = this_spec ? claim != nullptr : cur.derive_m0;
         // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
-        const E cm1 = hfr::mul(c, limbs9_to_fr(sums + GKR_ACC_WORDS));
-        const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, limbs9_to_fr(sums));
+        E M0 = hfr::ZERO, M1;
+        if (this_spec) {                         // linear in the previous challenge: M(r) = M(0) + r (M(1) - M(0))
+            const E& r1 = chal[k - 1];
+            M1 = hfr::add(cand[1], hfr::mul(r1, hfr::sub(cand[3], cand[1])));
+            if (!derive_m0) M0 = hfr::add(cand[0], hfr::mul(r1, hfr::sub(cand[2], cand[0])));
+        } else {
+            M1 = limbs9_to_fr(sums + GKR_ACC_WORDS);
+            if (!derive_m0) M0 = limbs9_to_fr(sums);
+        }
+        const E cm1 = hfr::mul(c, M1);
+        const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, M0);
         const E a0 = hfr::sub(hfr::ONE, q[k]);
         const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
         E* co = proof + (size_t)k * 3;
@@ -984,7 +1061,14 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         co[1] = hfr::add(hfr::mul(a0, cm1), hfr::mul(a1, cm0));
         co[2] = hfr::mul(a1, cm1);
         const E r = hfr::mimc_hash(co, 3);
-        if (prelaunched) {
+        if (next_spec) {
+            if (next2_spec && !cx().spec_poll) {
+                CHK(launch_spec(k + 2, &r));                 // with r_k as a launch argument
+            } else if (next2_spec) {
+                chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
+                chal_guard.armed = false;
+            }
+        } else if (prelaunched) {
             chal_publish(nxt.seq, r, hfr::mul(r, two128));
             chal_guard.armed = false;
             cur = nxt;
@@ -1004,6 +1088,14 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         if (k == k_export) {
             const E* tt = (const E*)cx().h_tail;
             std::vector<std::vector<E>> Th(arity, std::vector<E>(P));
+            if (this_spec) {                     // the speculative launch exported the tables of round k-1 (4P entries each)
+                const E& r1 = chal[k - 1];
+                for (int t = 0; t < arity; t++) {
+                    const E* tb = tt + (size_t)t * 4 * P;
+                    for (size_t x = 0; x < P; x++)
+                        Th[t][x] = fold2(fold2(tb[x], tb[x + 2 * P], r1), fold2(tb[x + P], tb[x + 3 * P], r1), r);
+                }
+            } else
             for (int t = 0; t < arity; t++)
                 for (size_t x = 0; x < P; x++) Th[t][x] = fold2(tt[(size_t)t * 2 * P + x], tt[(size_t)t * 2 * P + x + P], r);
             if (sh_tail) {
@@ -1035,6 +1127,8 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     table_release(&pyrT);
     table_release(&pyrU);
     for (int t = 0; t < arity; t++) table_release(&scratch[t]);
+    for (int t = 0; t < arity; t++)
+        if (scratch2[t].base) table_release(&scratch2[t]);
     return 0;
 }
 

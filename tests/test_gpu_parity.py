@@ -431,7 +431,13 @@ def test_speculative_small_rounds(gk):
     _run_case(dict(on, GKRHIP_SPEC_POLL="0"), "8,10,13")                  # launched with the challenge as an argument instead of polling for it
     _run_case(dict(on, GKRHIP_SPEC_BATCH="1"), "9,13")                    # all of a layer's speculative launches queued at once
     _run_case(dict(on, GKRHIP_PRE="2", GKRHIP_GMAX="8", GKRHIP_CASE_EXPECT="spec_rounds,lookahead_round0"), "11,13")
+    # the GMiMC circuit: cipher layers and LINEAR layers (add, copy: k_linear_round_spec, two candidates -- their sums are linear in r)
     _run_case(dict(on, GKRHIP_HOST_TAIL="3"), "7,10", circuit="gmimc")
+    _run_case(on, "9,12,13", circuit="gmimc")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="1", GKRHIP_SPEC_LG="6"), "5,6,8", circuit="gmimc")
+    _run_case(dict(on, GKRHIP_SPEC_POLL="0", GKRHIP_HOST_TAIL="2"), "7,11", circuit="gmimc")
+    _run_case(dict(on, GKRHIP_CLAIM_TRICK="0", GKRHIP_HOST_TAIL="4"), "8,10", circuit="gmimc")
+    _run_case(dict(on, GKRHIP_SPEC="0", GKRHIP_CASE_EXPECT="", GKRHIP_CASE_EXPECT_NOT="spec_rounds"), "9", circuit="gmimc")
     _run_case({"GKRHIP_CASE_EXPECT": "spec_rounds,prelaunched_rounds,coop_rounds"}, "12,15")   # the defaults, alone on the GPU
     _run_case({"GKRHIP_SPEC": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")
     _run_case({"GKRHIP_SPEC": "2", "GKRHIP_PRELAUNCH": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")    # needs the pre-launched rounds
