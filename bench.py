@@ -613,14 +613,14 @@ def main():
         job.run_steps(max(warmup, 1 if job.nconc > 1 and warmup else 0))
         # single-proof latency (one proof alone on the GPU), reported beside the throughput figure
         lat = []
-        for _ in range(3):                     # three proofs, one at a time: the median is reported, the last one's split kept
-            gk.profile_reset(1 << bn_local)
+        for _ in range(3 if multi else 5):     # proofs one at a time: the median is reported, the last one's split kept (five at N = 1:
+            gk.profile_reset(1 << bn_local)    # the first proof alone after the lanes' warm-up is slower, and boxes have shown stray slow samples)
             sync_all()
             tl = time.perf_counter()
             job.last[0] = job.sessions[0].prove(job.qprime)
             sync_all()
             lat.append(1e3 * (time.perf_counter() - tl))
-        ph["latency_ms"] = sorted(lat)[1]
+        ph["latency_ms"] = sorted(lat)[len(lat) // 2]
         ph["latency_samples_ms"] = lat
         ph["solo"] = gk.profile_get()          # the same launches with no other proof in flight
         # once more alone with the look-ahead off: round 0 as the ONE fused launch the proofs in flight run (all ten
