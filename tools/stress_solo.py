@@ -20,6 +20,19 @@ def main():
         flat = s.prove(qps[bn])
         assert s.verify(qps[bn], flat), bn
         want[bn] = hashlib.sha256(flat.tobytes()).hexdigest()
+    # the GMiMC circuit as well (keys 100 + bn): cipher layers and linear layers (their speculative rounds have two candidates)
+    layers = gk.gmimc_t2_circuit()
+    for bn in (8, 11, 14, 17):
+        s = gk.MimcSession(bn, layers=layers)
+        for i in range(4):
+            s.load_input(i, random_fr_array_np(1 << bn) if i % 2 == 0 else random_fr_array_np(1 << bn)[::-1].copy())
+        s.assign()
+        key = 100 + bn
+        sess[key], qps[key] = s, random_fr_array_np(bn)
+        flat = s.prove(qps[key])
+        assert s.verify(qps[key], flat), key
+        want[key] = hashlib.sha256(flat.tobytes()).hexdigest()
+    sizes = sizes + [100 + bn for bn in (8, 11, 14, 17)]
     gk.profile_reset(0)
     stop, n, bad = time.time() + budget, 0, []
     while time.time() < stop and not bad:
