@@ -129,7 +129,8 @@ struct CipherRoundArgs {
 // Challenge hand-over to a pre-launched round kernel.  The host writes 16 words (limbs 0..7: r, 8..15: r * 2^-128), each
 // as (seq << 32) | limb -- an aligned 8-byte word is read atomically over PCIe, so every polling lane sees a
 // consistent (seq, limb) pair whatever order the host's stores arrive in.  seq = 0xFFFFFFFF: the host gave up
-// (error path); a lane also gives up after ~20 s without an answer.  Returns false when the launch must be abandoned
+// (error path); a lane also gives up after ~1 s without an answer (the host then runs the layer's rounds once more without
+// queueing anything ahead of its challenge: rounds_with_retry in host_sumcheck.hip.h).  Returns false when the launch must be abandoned
 // (uniformly over the workgroup).  The sixteen limbs come back wave-uniform (SGPRs), like launch arguments.
 // ------------------------------------------------------------------------------------------------
 #define GKR_CHAL_WORDS 16
@@ -162,7 +163,7 @@ __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, u
                           : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 s = (u32)(v >> 32);
             if (s == seq) break;
-            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 2000000000ull) {
+            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 100000000ull) {
                 bad = 1;
                 if (diag && threadIdx.x == 0) {          // why the launch was abandoned (the host's error message quotes it)
                     diag[0] = ((unsigned long long)blockIdx.x << 32) | (s == GKR_CHAL_ABORT ? 1u : 2u);

@@ -1206,6 +1206,7 @@ int gkrhip_profile_reset(size_t min_n) {
     g_cnt_lookahead = 0;
     g_cnt_coop = 0;
     g_cnt_spec = 0;
+    g_cnt_retries = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
         prof_clear(l->prof);
@@ -1680,6 +1681,7 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "lookahead_round0") *value = g_cnt_lookahead.load();
     else if (n == "coop_rounds") *value = g_cnt_coop.load();
     else if (n == "spec_rounds") *value = g_cnt_spec.load();
+    else if (n == "chal_retries") *value = g_cnt_retries.load();
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);
     return 0;
 }

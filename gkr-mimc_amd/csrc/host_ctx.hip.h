@@ -18,7 +18,7 @@ static inline double now_ms() {
 // process-wide counts of the serial-latency paths (gkrhip_profile_latency): rounds whose kernel was queued ahead of its
 // challenge, round-0 launches on look-ahead products, rounds of the cooperative kernel.  Not per lane: the lanes of
 // one-shot calls go back to the pool (and are cleared) before anybody can ask.
-std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0}, g_cnt_spec{0};
+std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0}, g_cnt_spec{0}, g_cnt_retries{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
     uint64_t rounds = 0;
@@ -639,6 +639,11 @@ struct ScopedTable : DevTable {
 // RegularIO (thread-local scope): the host images of this thread's uploads / downloads are REGULAR-form elements (the
 // big.Int words of the hint interface) instead of Montgomery fr.Elements; the conversion rides on the transposition.
 thread_local bool g_regular_io = false;
+// A pre-launched or speculative kernel that does not see its challenge within a second gives up; the round loop then fails with
+// g_chal_timeout set, and its caller runs the layer's rounds once more in safe mode (nothing queued ahead of its challenge):
+// the layer's inputs are untouched by the rounds, so the retry produces the same transcript.
+thread_local bool g_chal_timeout = false;
+thread_local bool g_safe_mode = false;
 struct RegularIO {
     bool prev;
     explicit RegularIO(bool on = true) : prev(g_regular_io) { g_regular_io = on; }
@@ -789,13 +794,18 @@ int wait_flag(unsigned int seq, volatile unsigned int* f = nullptr, double deadl
             if (e == hipSuccess && *f != seq) {
                 const unsigned long long* dg = cx().h_round + 104;      // wait_challenge's note, if it abandoned the launch
                 const unsigned long long* ds = cx().h_spec ? cx().h_spec : dg;      // the speculative launches' notes (two buffers)
+                // (code 2 in the low half of a note: a workgroup's wait for its challenge ran out -- recoverable, see g_chal_timeout)
+                g_chal_timeout = (dg[0] & 0xffffffffull) == 2 || (cx().h_spec && ((ds[580] & 0xffffffffull) == 2 || (ds[640 + 580] & 0xffffffffull) == 2));
+                const unsigned long long note[12] = {dg[0], dg[1], dg[2], dg[3], cx().h_spec ? ds[580] : 0ull, cx().h_spec ? ds[581] : 0ull,
+                                                     cx().h_spec ? ds[582] : 0ull, cx().h_spec ? ds[583] : 0ull, cx().h_spec ? ds[640 + 580] : 0ull,
+                                                     cx().h_spec ? ds[640 + 581] : 0ull, cx().h_spec ? ds[640 + 582] : 0ull, cx().h_spec ? ds[640 + 583] : 0ull};
+                cx().h_round[104] = 0;                                           // the notes are quoted once
+                if (cx().h_spec) cx().h_spec[580] = cx().h_spec[640 + 580] = 0;
                 const double now = now_ms();
                 return fail("round kernel finished without publishing its result (flag %u, expected %u; challenge wait: code %llx after %llu ticks, "
                             "word %llx, seq %llu; speculative: %llx %llu %llx %llu | %llx %llu %llx %llu; host: last deferred launch seq %u %.1f ms ago, "
                             "published seq %u / %u / %u to slots 0 / 1 / 2 %.1f / %.1f / %.1f ms ago, slot tags now %llx %llx %llx)",
-                            *f, seq, dg[0], dg[1], dg[2], dg[3], cx().h_spec ? ds[580] : 0ull, cx().h_spec ? ds[581] : 0ull,
-                            cx().h_spec ? ds[582] : 0ull, cx().h_spec ? ds[583] : 0ull, cx().h_spec ? ds[640 + 580] : 0ull,
-                            cx().h_spec ? ds[640 + 581] : 0ull, cx().h_spec ? ds[640 + 582] : 0ull, cx().h_spec ? ds[640 + 583] : 0ull,
+                            *f, seq, note[0], note[1], note[2], note[3], note[4], note[5], note[6], note[7], note[8], note[9], note[10], note[11],
                             cx().dbg_defer_seq, now - cx().dbg_defer_ms, cx().dbg_pub_seq[0], cx().dbg_pub_seq[1], cx().dbg_pub_seq[2],
                             now - cx().dbg_pub_ms[0], now - cx().dbg_pub_ms[1], now - cx().dbg_pub_ms[2], cx().h_chal[0] >> 32,
                             cx().h_chal[16] >> 32, cx().h_chal[32] >> 32);

@@ -161,6 +161,13 @@ const int g_test_fail_round = [] {
     return e ? atoi(e) : -1;
 }();
 std::atomic<bool> g_test_fail_armed{true};
+// test hook (GKRHIP_TEST_DROP_CHALLENGE=k, once per process): the challenge of round k is NOT published -- the kernel waiting
+// for it runs out of time, the round loop fails with g_chal_timeout and rounds_with_retry runs the layer again in safe mode
+const int g_test_drop_round = [] {
+    const char* e = getenv("GKRHIP_TEST_DROP_CHALLENGE");
+    return e ? atoi(e) : -1;
+}();
+std::atomic<bool> g_test_drop_armed{true};
 
 // The slow parts of the look-ahead -- the second stream (created on first use: a lane that never looks ahead holds one
 // hardware queue, not two) and the six scratch tables (a miss in the arena is a hipMalloc behind the arena's lock) -- are done
@@ -210,6 +217,30 @@ int launch_pre() {
     cx().pre_ark = cx().req_ark;
     cx().pre_m = cx().req_m;
     return 0;
+}
+
+// A round loop that failed because a waiting kernel's time ran out (g_chal_timeout: the kernel left without touching anything,
+// ChalGuard drained the stream) is run ONCE more in safe mode -- no kernel queued ahead of its challenge, no look-ahead.  The
+// loops read the layer's tables and write scratch tables only, so with the running values restored the retry produces the
+// same transcript; seen so far only with every latency path forced on for a dozen lanes at once (a kernel polling host memory
+// did not see, within its time, a challenge the host had written before it started), where it used to cost the proof.
+template <class F>
+int rounds_with_retry(E& c, E& claim, bool& claim_known, F&& run) {
+    const E c0 = c, claim0 = claim;
+    const bool known0 = claim_known;
+    g_chal_timeout = false;
+    int rc = run();
+    if (rc != 0 && g_chal_timeout && !g_safe_mode && !shard_view().gamma) {      // (sharded: the ranks would have to agree on the retry)
+        g_chal_timeout = false;
+        c = c0;
+        claim = claim0;
+        claim_known = known0;
+        g_safe_mode = true;
+        g_cnt_retries.fetch_add(1, std::memory_order_relaxed);
+        rc = run();
+        g_safe_mode = false;
+    }
+    return rc;
 }
 
 // ---- speculative small rounds (cipher_spec.hip.h) ------------------------------------------------------------------
@@ -353,8 +384,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // round whose tables go to the host
     const int m_dev = h_tail ? k_export + 1 : m;             // rounds on the device
     // pre-launched rounds: the next round's kernel is queued before this round is hashed and polls the challenge slot
-    const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);
-    const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
+    const bool pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));
+    const bool pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone));
     if (pre_on) CHK(pre_prepare());                  // nothing of this lane is waiting for the host yet
     const bool coop_on = cx().coop >= 2 || (cx().coop == 1 && alone);
     // speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the eight candidate values of r_{k-1} while the
@@ -617,12 +648,13 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             if (next2_spec && !cx().spec_poll && !cx().spec_batch) {
                 CHK(launch_spec(k + 2, &r));                 // round k+2's speculative launch, with r_k as a launch argument
             } else if (next2_spec) {                         // round k+2's speculative launch folds with r_k
-                chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
+                if (!(k == g_test_drop_round && g_test_drop_armed.exchange(false))) chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
                 chal_guard.armed = k + 2 < k_export;         // later speculative launches are still waiting for theirs
             }
         } else if (prelaunched) {
             const E two128 = {{0, 0, 1, 0}};
-            chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
+            if (!(k == g_test_drop_round && g_test_drop_armed.exchange(false)))
+                chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
             chal_guard.armed = spec_queued && k_s < k_export;    // (the speculative launches behind it wait for their own)
             cur = nxt;
         } else if (have_next) {
@@ -741,8 +773,11 @@ int sumcheck_cipher_fast(const E& ark, int bN, const DevTable* K, const DevTable
     E* claim_p = track_claim ? &claim : nullptr;
     if (m1 >= 1) {
         const E seed = gamma ? shard_seed(q + m1, gamma, shard.rank) : hfr::ONE;
-        CHK(cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last,
-                          claim_p, &claim_known, gamma, &did_gamma));
+        // (see rounds_with_retry: a layer whose pre-launched kernel missed its challenge is run once more, nothing queued ahead)
+        CHK(rounds_with_retry(c, claim, claim_known, [&]() {
+            return cipher_rounds(ark, m1, K, S, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last,
+                                 claim_p, &claim_known, gamma, &did_gamma);
+        }));
         kv = fold2(tail[0], tail[1], r_last);
         sv = fold2(tail[2], tail[3], r_last);
     } else {
@@ -890,8 +925,8 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     const int k_export = h_tail ? m - 2 - h_tail : -1;      // see cipher_rounds
     const int m_dev = h_tail ? k_export + 1 : m;
     const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
-    const bool pl_on = cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone);   // see cipher_rounds
-    const bool pre_on = cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone);
+    const bool pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));   // see cipher_rounds
+    const bool pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone));
     if (pre_on) CHK(pre_prepare());                  // see cipher_rounds
     // speculative rounds (cipher_spec.hip.h, k_linear_round_spec): the two sums of a linear gate's round are linear in the
     // previous challenge, so the candidates 0 and 1 -- the lower and the upper half of the previous round's tables -- suffice
@@ -1147,8 +1182,10 @@ int sumcheck_linear_fast(const GateDesc& g, const E& ark, int bN, const DevTable
     E* claim_p = track_claim ? &claim : nullptr;
     if (m1 >= 1) {
         const E seed = gamma ? shard_seed(q + m1, gamma, shard.rank) : hfr::ONE;
-        CHK(linear_rounds(g, ark, m1, X, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last, claim_p,
-                          &claim_known, gamma, &did_gamma));
+        CHK(rounds_with_retry(c, claim, claim_known, [&]() {
+            return linear_rounds(g, ark, m1, X, q, seed, gamma > 0 || cx().force_collective, c, proof, challenges, tail, r_last, claim_p,
+                                 &claim_known, gamma, &did_gamma);
+        }));
         for (int t = 0; t < arity; t++) v[t] = fold2(tail[2 * t], tail[2 * t + 1], r_last);
     } else {
         CHK(gather0(X, arity, v));

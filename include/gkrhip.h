@@ -304,7 +304,9 @@ int gkrhip_profile_host(uint64_t *rounds, double *hash_ms, double *wait_ms, doub
 int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_round0, uint64_t *coop_rounds);
 /* The same counters by name ("prelaunched_rounds", "lookahead_round0", "coop_rounds", and "spec_rounds": rounds whose
  * sums were computed speculatively for the eight candidate values 0..7 of the previous challenge while the host was still
- * hashing, and interpolated at the true challenge).  Unknown name: error. */
+ * hashing, and interpolated at the true challenge), and "chal_retries": layers whose rounds were run a second time, nothing
+ * queued ahead of its challenge, because a waiting kernel's time (1 s) ran out -- the result is the same, the proof is merely
+ * late.  Unknown name: error. */
 int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus

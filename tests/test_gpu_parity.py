@@ -496,6 +496,37 @@ def test_error_while_a_prelaunched_kernel_waits(gk):
         assert out.returncode == 0 and "ABORT-PATH-OK" in out.stdout, (spec, out.stdout + out.stderr)
 
 
+def test_layer_retried_after_a_missed_challenge(gk):
+    """A kernel that waits for its challenge gives up after a second (seen for real only with every latency path forced on for
+    a dozen lanes at once: a polling kernel did not see a challenge the host had written).  The round loop then fails
+    recoverably and the layer's rounds run once more with nothing queued ahead -- same transcript, the proof is merely late.
+    Provoked with a test hook that withholds ONE challenge: from a pre-launched round kernel and from a speculative launch."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, sys
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import coracle as c
+        gk = importlib.import_module("gkr-mimc_amd")
+        gk.init(0)
+        bn = 12
+        s = gk.MimcSession(bn); s.synth_inputs(); s.assign()
+        qp = c.random_fr_array(bn)
+        i0 = c.random_fr_array(1 << bn)
+        want = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)[0]
+        gk.profile_reset(0)
+        for _ in range(3):
+            assert np.array_equal(s.prove(qp), want)
+        assert gk.profile_get()["chal_retries"] == 1, gk.profile_get()
+        print("RETRY-OK")
+    """ % (root, os.path.join(root, "oracle")))
+    for spec in ("0", "2"):
+        env = dict(os.environ, GKRHIP_TEST_DROP_CHALLENGE="3", GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "RETRY-OK" in out.stdout, (spec, out.stdout + out.stderr)
+
+
 def test_lookahead_round0(gk):
     """The q-independent products of a cipher layer's round 0 computed during the previous layer (k_cipher_pre on the
     look-ahead stream) and consumed by k_cipher_round_wide<false, ., true>: same transcript, early and late lane

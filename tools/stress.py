@@ -46,7 +46,7 @@ def main():
         t.start()
     for t in ths:
         t.join()
-    print("proofs per lane:", counts, "total", sum(counts), "mismatches:", bad)
+    print("proofs per lane:", counts, "total", sum(counts), "mismatches:", bad, "layers retried after a missed challenge:", gk.profile_get()["chal_retries"])
     sys.exit(1 if bad else 0)
 
 
