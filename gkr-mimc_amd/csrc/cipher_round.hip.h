@@ -143,10 +143,10 @@ struct CipherRoundArgs {
 // dependency: workgroup 0 need not be resident (several pre-launched kernels, e.g. of several processes sharing the GPU,
 // can each hold part of the machine while their workgroups 0 wait for a slot: measured, a deadlock until the time-out).
 // Whoever reads the words from the host forwards them; the writes are idempotent.  ONE workgroup per launch, also of a 2-D grid:
-// the speculative launches (nine rows of workgroups) first had one host-polling workgroup per row, and a soak with the path forced on
-// for fourteen lanes -- 126 workgroups reading host memory back to back -- lost proofs to kernels that did not see, within 20 s, a
-// challenge the host had published before they started (the PCIe read path again); with one polling workgroup per launch the
-// same soak is clean.
+// the speculative launches (nine rows of workgroups) first had one host-polling workgroup per row, and soaks with every path forced
+// on for a dozen lanes lost proofs to kernels that did not see, within their time, a challenge the host had published before they
+// started; with one polling workgroup per launch that is rare but still happens under that load (never with one proof at a
+// time), and it now costs a second, not the proof: the host runs the layer again (rounds_with_retry).
 __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, unsigned long long* mailbox, unsigned int seq, Fr& r,
                                                Fr& r_lo, unsigned long long* diag = nullptr) {
     __shared__ u32 s_ch[GKR_CHAL_WORDS];
