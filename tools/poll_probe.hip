@@ -17,14 +17,13 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 
 __global__ void k_wait(const unsigned long long* slot, unsigned long long* ack, unsigned long long want, int pollers, unsigned long long* gave_up) {
     __shared__ int ok;
-    if (threadIdx.x == 0) {
-        ok = 1;
-        if ((int)blockIdx.x < pollers) {
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
-                if (wall_clock64() - t0 > 300000000ull) { ok = 0; break; }      // 3 s
-                __builtin_amdgcn_s_sleep(2);
-            }
+    if (threadIdx.x == 0) ok = 1;
+    __syncthreads();
+    if (threadIdx.x < 16 && (int)blockIdx.x < pollers) {          // sixteen lanes, sixteen tagged words: one 128-byte read per poll
+        const unsigned long long t0 = wall_clock64();
+        while ((__hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32) != want) {
+            if (wall_clock64() - t0 > 300000000ull) { ok = 0; break; }      // 3 s
+            __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
@@ -50,7 +49,8 @@ int main(int argc, char** argv) {
     for (int l = 0; l < lanes; l++) {
         CK(hipHostMalloc(&slot[l], 128, hipHostMallocMapped | hipHostMallocCoherent));
         CK(hipHostMalloc(&ack[l], 128, hipHostMallocMapped | hipHostMallocCoherent));
-        slot[l][0] = 0; ack[l][0] = 0;
+        for (int w = 0; w < 16; w++) slot[l][w] = 0;
+        ack[l][0] = 0;
         CK(hipHostGetDevicePointer((void**)&dslot[l], slot[l], 0));
         CK(hipHostGetDevicePointer((void**)&dack[l], ack[l], 0));
         CK(hipStreamCreateWithFlags(&st[l], hipStreamNonBlocking));
@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
                 const double th0 = now_us();
                 while (now_us() - th0 < 35.0) {}                      // the hash
                 const double t0 = now_us();
-                *(volatile unsigned long long*)slot[l] = i;
+                for (int w = 0; w < 16; w++) ((volatile unsigned long long*)slot[l])[w] = (i << 32) | (unsigned)(w * 2654435761u + i);
                 __sync_synchronize();
                 while (*(volatile unsigned long long*)ack[l] != i) {
                     if (now_us() - t0 > 5e6) { printf("lane %d round %llu: no ack after 5 s (ack %llu)\n", l, i, ack[l][0]); exit(2); }
