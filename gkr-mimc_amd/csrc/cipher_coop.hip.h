@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_coop(CipherRoundA
         }
     }
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104, a.chal_limit_s)) return;
     Acc9 acc;
 #pragma unroll
     for (int j = 0; j < GKR_ACC_WORDS; j++) acc.w[j] = 0;

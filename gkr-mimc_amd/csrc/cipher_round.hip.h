@@ -121,6 +121,7 @@ struct CipherRoundArgs {
     const unsigned long long* chal;    // host-mapped challenge slot (GKR_CHAL_WORDS words), or nullptr: r, r_lo above are valid
     unsigned long long* chal_dev;      // device-memory mailbox of the same shape: workgroup 0 forwards the slot to the others
     unsigned int chal_seq;             // the slot is valid for this launch when the high halves of its words equal chal_seq
+    unsigned int chal_limit_s;         // give up after this many seconds without the challenge (0: one second)
     // PRE (k_cipher_round_wide<false, ., true>): the q-independent products of round 0, computed ahead by k_cipher_pre
     CPlanes pre[6];                    // u^4, d^4, u^3, u^2 d, u d^2, d^3 at every pair
 };
@@ -130,7 +131,8 @@ struct CipherRoundArgs {
 // as (seq << 32) | limb -- an aligned 8-byte word is read atomically over PCIe, so every polling lane sees a
 // consistent (seq, limb) pair whatever order the host's stores arrive in.  seq = 0xFFFFFFFF: the host gave up
 // (error path); a lane also gives up after ~1 s without an answer (the host then runs the layer's rounds once more without
-// queueing anything ahead of its challenge: rounds_with_retry in host_sumcheck.hip.h).  Returns false when the launch must be abandoned
+// queueing anything ahead of its challenge: rounds_with_retry in host_sumcheck.hip.h) -- after limit_s seconds where the launch says
+// so (the sharded rounds, which have no retry: 20 s).  Returns false when the launch must be abandoned
 // (uniformly over the workgroup).  The sixteen limbs come back wave-uniform (SGPRs), like launch arguments.
 // ------------------------------------------------------------------------------------------------
 #define GKR_CHAL_WORDS 16
@@ -148,7 +150,7 @@ struct CipherRoundArgs {
 // started; with one polling workgroup per launch that is rare but still happens under that load (never with one proof at a
 // time), and it now costs a second, not the proof: the host runs the layer again (rounds_with_retry).
 __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, unsigned long long* mailbox, unsigned int seq, Fr& r,
-                                               Fr& r_lo, unsigned long long* diag = nullptr) {
+                                               Fr& r_lo, unsigned long long* diag = nullptr, unsigned int limit_s = 0) {
     __shared__ u32 s_ch[GKR_CHAL_WORDS];
     int bad = 0;
     if (threadIdx.x < GKR_CHAL_WORDS) {
@@ -163,7 +165,7 @@ __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, u
                           : __hip_atomic_load(mailbox + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 s = (u32)(v >> 32);
             if (s == seq) break;
-            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > 100000000ull) {
+            if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > (unsigned long long)(limit_s ? limit_s : 1u) * 100000000ull) {
                 bad = 1;
                 if (diag && threadIdx.x == 0) {          // why the launch was abandoned (the host's error message quotes it)
                     diag[0] = ((unsigned long long)blockIdx.x << 32) | (s == GKR_CHAL_ABORT ? 1u : 2u);
@@ -240,7 +242,7 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104, a.chal_limit_s)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr ark = a.ark;
@@ -446,7 +448,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104, a.chal_limit_s)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const Fr negark = fr_sub(fr_zero(), a.ark);      // q - ark (0 for ark = 0), canonical

@@ -453,6 +453,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             a.chal = cx().d_chal;
             a.chal_dev = cx().d_chal_dev;
             a.chal_seq = a.seq;
+            a.chal_limit_s = collective ? 20u : 0u;          // no retry across ranks: a generous limit there
             chal_guard.armed = true;
             cx().dbg_defer_seq = a.seq;
             cx().dbg_defer_ms = now_ms();
@@ -990,6 +991,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             a.chal = cx().d_chal;
             a.chal_dev = cx().d_chal_dev;
             a.chal_seq = a.seq;
+            a.chal_limit_s = collective ? 20u : 0u;
         }
         out->derive_m0 = derive_m0;
         a.need_m0 = derive_m0 ? 0u : 1u;

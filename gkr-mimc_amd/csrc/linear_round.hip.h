@@ -36,6 +36,7 @@ struct LinearRoundArgs {
     const unsigned long long* chal;    // pre-launched round: r, r_lo arrive through this host-mapped slot (cipher_round.hip.h)
     unsigned long long* chal_dev;
     unsigned int chal_seq;
+    unsigned int chal_limit_s;     // see CipherRoundArgs
 };
 
 template <bool FOLD, bool HAS_WJ>
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
     const size_t threads = (size_t)1 << a.lg_threads;
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr ch_r = a.r, ch_rlo = a.r_lo;
-    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104)) return;
+    if (FOLD && a.chal && !wait_challenge(a.chal, a.chal_dev, a.chal_seq, ch_r, ch_rlo, a.host_out + 104, a.chal_limit_s)) return;
     if (gtid < threads) {
         const Fr wt = ld_fr(a.wt.lo, a.wt.hi, gtid);
         const size_t iters = P >> a.lg_threads;
