@@ -502,27 +502,6 @@ def main():
     multi = dist is not None and world > 1
     pass_name = args.pass_name or (("shm" if args.exchange == "shm" else "rccl_one_lane") if multi else None)
 
-    # The configs of many small proofs (BASELINE 2 and 5) once more with 16 hardware queues instead of the runtime's 4
-    # (GKRHIP_HW_QUEUES -> GPU_MAX_HW_QUEUES, read when the runtime initialises: hence child processes, run before this
-    # process touches the GPU): with 24 / 12 lanes, kernels of different streams in one hardware queue run one after the other.
-    hwq = {}
-    if not multi and rank == 0 and not args.pass_name and not args.no_configs and args.circuit == "mimc" and args.bn is None and \
-            args.concurrent > 1 and not os.environ.get("GKRHIP_BENCH_CHILD") and not os.environ.get("GPU_MAX_HW_QUEUES") and \
-            not os.environ.get("GKRHIP_HW_QUEUES"):
-        import subprocess
-        for key, extra in (("bn20", ["--bn", "20", "--concurrent", "24", "--steps", "48", "--warmup", "24"]),
-                           ("gmimc_bn22", ["--circuit", "gmimc", "--bn", "22", "--concurrent", "12", "--steps", "24", "--warmup", "12"])):
-            try:
-                cp = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra +
-                                    ["--no-cpu-baseline", "--no-micro", "--no-oneshot", "--no-configs"],
-                                    env=dict(os.environ, GKRHIP_HW_QUEUES="16", GKRHIP_BENCH_CHILD="1"), capture_output=True, text=True, timeout=180)
-                line = json.loads(cp.stdout.strip().splitlines()[-1])
-                hwq[key] = {"hw_queues": 16, "hashes_per_s": line["value"], "ms_per_step": line["ms_per_step"],
-                            "concurrent_proofs": line["config"]["concurrent_proofs"],
-                            "proof_verified_by_native_gkr_verify": line["config"]["proof_verified_by_native_gkr_verify"]}
-            except Exception as e:      # noqa: BLE001 -- an extra: its failure must not cost the line
-                hwq[key] = {"hw_queues": 16, "error": str(e)[:200]}
-
     gk = importlib.import_module("gkr-mimc_amd")
     try:
         gk.init(local_rank if args.device is None else args.device)
@@ -863,7 +842,7 @@ def main():
                             "concurrent_proofs": cl, "single_proof_ms": sorted(lat)[1], "single_proof_samples_ms": lat,
                             "single_proof_hashes_per_s": float(1 << cbn) / (sorted(lat)[1] * 1e-3),
                             "proof_verified_by_native_gkr_verify": ok,
-                            "with_16_hardware_queues": hwq.get(key),
+                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                             "workload": ("gkr.Prove(MimcCircuit) at bN = 20 (BASELINE config 2)" if circ == "mimc" else
                                          "gkr.Prove(GMiMC t = 2 circuit: cipher, add and copy layers) at bN = 22 (BASELINE config 5); "
                                          "a hash here is one GMiMC compression")}

@@ -33,6 +33,8 @@
 #include "cipher_coop.hip.h"
 #include "cipher_spec.hip.h"
 #include "ntt.hip.h"
+#include "fp_host.h"
+#include "g1.hip.h"
 
 using hfr::E;
 
@@ -46,6 +48,7 @@ namespace {
 #include "host_sumcheck.hip.h"
 #include "host_circuit.hip.h"
 #include "host_ntt.hip.h"
+#include "host_msm.hip.h"
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1041,6 +1044,144 @@ int gkrhip_bench_compute_h(int logn, int warmup, int iters, double* avg_ms, int*
     if (passes) *passes = np;
     if (bytes) *bytes = by;
     for (int i = 0; i < 3; i++) table_release(&t[i]);
+    return 0;
+}
+
+// ---- G1 multi-scalar multiplication (gnark-crypto's MultiExp at prover/gadget/prove.go:76,91,189,202,221) ----------
+int gkrhip_g1_bases_create(gkrhip_g1_bases** out, const uint64_t* points, size_t n) {
+    if (!out || (n && !points)) return fail("g1_bases_create: null argument");
+    LEASE_LANE();
+    CHK(msm_check_points(points, n));
+    gkrhip_g1_bases* b = nullptr;
+    CHK(g1_bases_alloc(&b, n));
+    if (n) {
+        hipError_t e = hipMemcpyAsync(b->d_points, points, n * 64, hipMemcpyHostToDevice, cx().stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(cx().stream);
+        if (e != hipSuccess) {
+            g1_bases_free(b);
+            return fail("upload of %zu G1 points failed: %s", n, hipGetErrorString(e));
+        }
+    }
+    *out = b;
+    return 0;
+}
+int gkrhip_g1_bases_generate(gkrhip_g1_bases** out, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
+    if (!out || !base || (n && !scalars)) return fail("g1_bases_generate: null argument");
+    LEASE_LANE();
+    gkrhip_g1_bases* b = nullptr;
+    CHK(g1_bases_alloc(&b, n));
+    const int rc = g1_batch_mul_dev(b->d_points, base, scalars, n, flags);
+    if (rc) {
+        g1_bases_free(b);
+        return rc;
+    }
+    *out = b;
+    return 0;
+}
+size_t gkrhip_g1_bases_len(const gkrhip_g1_bases* b) { return b ? b->n : 0; }
+int gkrhip_g1_bases_read(const gkrhip_g1_bases* b, uint64_t* out, size_t first, size_t count) {
+    if (!b || !out) return fail("g1_bases_read: null argument");
+    if (first > b->n || count > b->n - first) return fail("g1_bases_read: [%zu, %zu) outside %zu points", first, first + count, b->n);
+    LEASE_LANE();
+    if (count) {
+        HIPCHK(hipMemcpyAsync(out, b->d_points + 4 * first, count * 64, hipMemcpyDeviceToHost, cx().stream));
+        HIPCHK(hipStreamSynchronize(cx().stream));
+    }
+    return 0;
+}
+void gkrhip_g1_bases_destroy(gkrhip_g1_bases* b) { g1_bases_free(b); }
+int gkrhip_msm_g1_set_window(gkrhip_g1_bases* b, int c) {
+    if (!b) return fail("msm_g1_set_window: null handle");
+    if (c != 0 && (c < 2 || c > 16)) return fail("msm: window size %d outside 2..16 (0 = automatic)", c);
+    std::lock_guard<std::mutex> lk(b->mu);
+    b->c_forced = c;
+    return 0;
+}
+int gkrhip_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* b, const uint64_t* scalars, size_t n, int flags) {
+    if (!out_affine || !b || (n && !scalars)) return fail("msm_g1: null argument");
+    LEASE_LANE();
+    return msm_run(b, scalars, n, flags, out_affine);
+}
+int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t* points, const uint64_t* scalars, size_t n, int flags) {
+    gkrhip_g1_bases* b = nullptr;
+    CHK(gkrhip_g1_bases_create(&b, points, n));
+    const int rc = gkrhip_msm_g1(out_affine, b, scalars, n, flags);
+    gkrhip_g1_bases_destroy(b);
+    return rc;
+}
+int gkrhip_g1_batch_scalar_mul(uint64_t* out, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
+    if (!base || (n && (!out || !scalars))) return fail("g1_batch_scalar_mul: null argument");
+    gkrhip_g1_bases* b = nullptr;
+    CHK(gkrhip_g1_bases_generate(&b, base, scalars, n, flags));
+    const int rc = gkrhip_g1_bases_read(b, out, 0, n);
+    gkrhip_g1_bases_destroy(b);
+    return rc;
+}
+int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
+                        double* host_tail_ms, uint64_t result_or_null[8]) {
+    if (logn < 0 || logn > 26 || iters < 1 || !avg_ms) return fail("bench_msm_g1: bad arguments");
+    LEASE_LANE();
+    const size_t n = (size_t)1 << logn;
+    gkrhip_g1_bases* b = nullptr;
+    CHK(g1_bases_alloc(&b, n));
+    struct Guard {
+        gkrhip_g1_bases* b;
+        uint4* s = nullptr;
+        MsmTimes tm;
+        ~Guard() {
+            for (hipEvent_t e : tm.ev)
+                if (e) (void)hipEventDestroy(e);
+            if (s) (void)hipFree(s);
+            g1_bases_free(b);
+        }
+    } g{b};
+    b->c_forced = c_or_0;
+    CHK(msm_work_prepare(&b->w, n, c_or_0));
+    HIPCHK(hipMalloc((void**)&g.s, n * 32));
+    // bases [k_i] G, G = (1, 2), k_i pseudo-random; scalars pseudo-random below q
+    hipLaunchKernelGGL(k_msm_synth_scalars, dim3(grid_for(n, 4096)), dim3(GKR_BLOCK), 0, cx().stream, g.s, n, 0x1234567u);
+    {
+        MsmArgs a;
+        memset(&a, 0, sizeof a);
+        a.scalars = g.s;
+        a.n = n;
+        G1Aff gen;
+        const Fp one = fp_one();
+        gen.x = one;
+        gen.y = fp_add(one, one);
+        hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream, a, gen, b->d_points);
+    }
+    hipLaunchKernelGGL(k_msm_synth_scalars, dim3(grid_for(n, 4096)), dim3(GKR_BLOCK), 0, cx().stream, g.s, n, 0x7654321u);
+    HIPCHK(hipGetLastError());
+    for (hipEvent_t& e : g.tm.ev) HIPCHK(hipEventCreate(&e));
+    for (int i = 0; i < warmup; i++) CHK(msm_dev(b, g.s, n, 0, nullptr));
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    double tot = 0, ph[5] = {0, 0, 0, 0, 0}, tail = 0;
+    g.tm.on = true;
+    hfp::Aff r{hfp::ZERO, hfp::ZERO};
+    for (int i = 0; i < iters; i++) {
+        CHK(msm_dev(b, g.s, n, 0, &g.tm));
+        HIPCHK(hipEventSynchronize(g.tm.ev[5]));
+        const double t0 = now_ms();
+        r = msm_host_tail(&b->w);
+        tail += now_ms() - t0;
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, g.tm.ev[0], g.tm.ev[5]));
+        tot += ms;
+        for (int k = 0; k < 5; k++) {
+            HIPCHK(hipEventElapsedTime(&ms, g.tm.ev[k], g.tm.ev[k + 1]));
+            ph[k] += ms;
+        }
+    }
+    *avg_ms = tot / iters;
+    if (phase_ms)
+        for (int k = 0; k < 5; k++) phase_ms[k] = ph[k] / iters;
+    if (c_used) *c_used = b->w.c;
+    if (host_tail_ms) *host_tail_ms = tail / iters;
+    if (result_or_null) {
+        memcpy(result_or_null, r.x.l, 32);
+        memcpy(result_or_null + 4, r.y.l, 32);
+    }
     return 0;
 }
 

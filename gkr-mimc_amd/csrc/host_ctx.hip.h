@@ -307,16 +307,18 @@ int ctx_init(int dev) {
         return 0;
     }
     // Streams share the runtime's hardware queues (4 by default), and kernels of different streams in one hardware queue run
-    // one after the other -- with many small proofs in flight that, not the GPU, is the limit: bN = 20 with 24 lanes 46.4 M
-    // hashes/s on 4 queues, 47.3 on 8, 54.0 on 16, 52.4 on 24; the GMiMC circuit at bN = 22 with 8 lanes 85.1 / 88.2 / 91.4;
-    // bN = 24 with 5 lanes: no difference.  For the proof that is alone on the GPU (bN = 24, five sessions alive) the picture
-    // is mixed: 289.6 / 292.1 ms in two bench.py runs with 16 queues against 279-283 with the runtime's 4, and 276.2 / 277.2
-    // against 277.7 / 277.8 in two same-box pairs -- so the runtime's default stays and GKRHIP_HW_QUEUES=n is a knob for
-    // hosts that prove many small instances at once (bench.py uses it for exactly those measurements).  The runtime reads GPU_MAX_HW_QUEUES when it initialises, so the knob only takes effect if the library
-    // makes the process's first HIP call; an explicit setting of the variable is left alone.
+    // one after the other -- with many small proofs in flight that, not the GPU, is the limit.  Same-box interleaved A/B of
+    // round 4, five runs each, runtime default against 16 queues (profiles/r04_hwq_ab_summary.json):
+    //     bN = 20, 24 lanes      46.6 -> 53.8 M hashes/s (+15 %)     the proof alone 102.7 -> 102.1 ms
+    //     GMiMC bN = 22, 12 lanes 87.4 -> 94.2 M/s       (+7.7 %)    the proof alone 119.9 -> 124.2 ms (+3.6 %)
+    //     bN = 24, 5 lanes       82.2 -> 81.4 M hashes/s (-0.9 %, inside the spread of either set)   alone 278.4 -> 279.2 ms
+    // (earlier sweeps: 8 queues give a third of the gain, 24 less than 16).  So the library asks for 16 unless told otherwise:
+    // GKRHIP_HW_QUEUES=n sets another count, GKRHIP_HW_QUEUES=0 leaves the runtime's default, and an explicit
+    // GPU_MAX_HW_QUEUES is left alone.  The runtime reads the variable when it initialises, so this only takes effect if
+    // the library makes the process's first HIP call.
     if (!getenv("GPU_MAX_HW_QUEUES")) {
         const char* hq = getenv("GKRHIP_HW_QUEUES");
-        const int nq = hq ? atoi(hq) : 0;
+        const int nq = hq ? atoi(hq) : 16;
         if (nq > 0) setenv("GPU_MAX_HW_QUEUES", std::to_string(std::min(nq, 64)).c_str(), 0);
     }
     int n = 0;

@@ -264,11 +264,50 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t *M, const u
  * version of computeH does not bit-reverse after the last FFTInverse(DIF)).  The transforms are gnark-crypto's
  * fft.Domain (un-vendored dependency, v0.6.1-0.20220110145513-493bb1c180d9): the result is pinned on that package's
  * published algorithm and on the identity H * (X^n - 1) = A*B - C, not on bytes of the Go binary ("parity unpinned").
- * The MSMs of the same function (prove.go:76,189,202,221,277) need curve arithmetic and are out of scope. */
+ * The G1 MSMs of the same function are gkrhip_msm_g1 below. */
 int gkrhip_compute_h(uint64_t *h, const uint64_t *a, const uint64_t *b, const uint64_t *c, size_t n, size_t cardinality);
 /* computeH on device-resident vectors: *avg_ms = HIP-event time per computeH (no PCIe), *passes = passes over HBM,
  * *bytes = HBM bytes those passes move (32 B read + 32 B written per element of every array a pass names). */
 int gkrhip_bench_compute_h(int logn, int warmup, int iters, double *avg_ms, int *passes, double *bytes);
+
+
+/* ---- G1 multi-scalar multiplication: gnark-crypto's (*G1Jac).MultiExp / (*G1Affine).MultiExp -----------------------
+ * as the reference's Groth16 prover calls them: prover/gadget/prove.go:76,91 (krsNotGkr, KrsPrivNotGkr over
+ * pk.privKNotGkr), :189 (bs1 over pk.G1.B), :202 (ar over pk.G1.A), :221 (krs2 over pk.G1.Z with the h of computeH).
+ * Memory images are gnark-crypto's: a point is a bn254.G1Affine = {X, Y fp.Element} = 8 uint64 (Montgomery form, canonical;
+ * the point at infinity is (0, 0)); a scalar is an fr.Element = 4 uint64.  The reference passes scalars in REGULAR form
+ * (it calls FromMont first: prove.go:66,116-120,355-357) -- that is the default here; GKRHIP_MSM_SCALARS_MONT says they are
+ * still in Montgomery form (MultiExpConfig.ScalarsMont).  The result is written as a G1Affine; a G1Jac caller takes
+ * (X, Y, 1) -- any Jacobian representative of the same point is equivalent for every use the reference makes of it
+ * (AddMixed, AddAssign, ScalarMultiplication, FromJacobian: prove.go:194-196,207-210,236-262).
+ * The bases of these calls are proving-key vectors, fixed across proofs: gkrhip_g1_bases_create uploads them once and
+ * they stay in HBM (like a session's assignment); gkrhip_msm_g1 then moves only the scalars.  gkrhip_msm_g1_once is
+ * the one-call form with the exact shape of MultiExp(points, scalars, config).
+ * gnark-crypto is an un-vendored dependency (v0.6.1-0.20220110145513-493bb1c180d9): the result is a group element whose
+ * affine coordinates are unique, pinned by the test oracle's big-integer arithmetic, not by bytes of the Go binary
+ * ("parity unpinned").  n <= 2^26.  G2 (prove.go:277) is not built. */
+#define GKRHIP_MSM_SCALARS_MONT 1
+typedef struct gkrhip_g1_bases gkrhip_g1_bases;
+int gkrhip_g1_bases_create(gkrhip_g1_bases **out, const uint64_t *points /* n x 8 */, size_t n);
+/* bases[i] = [scalars[i]] base, computed on the device and left there (a fixed-base batch as in Groth16's setup) */
+int gkrhip_g1_bases_generate(gkrhip_g1_bases **out, const uint64_t base[8], const uint64_t *scalars /* n x 4 */, size_t n, int flags);
+size_t gkrhip_g1_bases_len(const gkrhip_g1_bases *b);
+int gkrhip_g1_bases_read(const gkrhip_g1_bases *b, uint64_t *out /* count x 8 */, size_t first, size_t count);
+void gkrhip_g1_bases_destroy(gkrhip_g1_bases *b);
+/* out = sum_{i < n} [scalars[i]] bases[i], n <= gkrhip_g1_bases_len(b) */
+int gkrhip_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases *b, const uint64_t *scalars /* n x 4 */, size_t n, int flags);
+int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t *points, const uint64_t *scalars, size_t n, int flags);
+/* window size of the bucket method for this handle: 0 = chosen from n (default), 2..16 forced (every choice gives the same
+ * point; the parity tests sweep it) */
+int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
+/* bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out[i] = [scalars[i]] base as G1Affine */
+int gkrhip_g1_batch_scalar_mul(uint64_t *out /* n x 8 */, const uint64_t base[8], const uint64_t *scalars, size_t n, int flags);
+/* MSM of 2^logn synthetic device-resident bases ([k_i] G, k_i pseudo-random) and scalars (pseudo-random below q):
+ * *avg_ms = HIP-event time per MSM up to the window sums' arrival on the host (no scalar upload); phase_ms[5] = digit sort,
+ * bucket accumulation, big buckets, window reduction, copy of the window sums; *c_used = the window size; result_or_null = the
+ * affine sum of the last run (the caller checks it against gkrhip_msm_g1 on the same data read back). */
+int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double *avg_ms, double phase_ms[5], int *c_used,
+                        double *host_tail_ms, uint64_t result_or_null[8]);
 
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 /* Device-resident fold micro-benchmark (shape of BenchmarkFolding, poly/multilin_test.go:55-78):

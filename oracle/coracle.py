@@ -86,6 +86,11 @@ def _load():
         "oracle_circuit_proof_len": (C.c_size_t, [P, C.c_int, C.c_int]),
         "oracle_gkr_prove_circuit": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
         "oracle_gkr_verify_circuit": (C.c_int, [P, C.c_int, C.c_int, P, P, C.c_int, P, P]),
+        "oracle_g1_on_curve": (C.c_int, [P]),
+        "oracle_g1_scalar_mul": (None, [P, P, P]),
+        "oracle_g1_batch_scalar_mul": (None, [P, P, P, C.c_size_t]),
+        "oracle_g1_add": (None, [P, P, P]),
+        "oracle_g1_msm": (None, [P, P, P, C.c_size_t]),
         "oracle_num_threads": (C.c_int, []),
         "oracle_set_num_threads": (None, [C.c_int]),
     }
@@ -338,3 +343,41 @@ def gkr_verify_circuit(descs, bN, flat, inputs, outputs, qprime):
     return lib.oracle_gkr_verify_circuit(C.cast(descs, C.c_void_p), len(descs), bN, _p(np.ascontiguousarray(flat)),
                                          _ptr_array(ins), len(ins), _p(np.ascontiguousarray(outputs)),
                                          _p(qprime) if bN else None)
+
+
+# ---- BN254 G1 (g1_oracle.c; parity unpinned: see the header there) -------------------------------------------------
+G1_GEN = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f,
+                   0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)   # (1, 2), Montgomery
+
+
+def g1_on_curve(pt):
+    pt = np.ascontiguousarray(pt, dtype=np.uint64)
+    return bool(lib.oracle_g1_on_curve(_p(pt)))
+
+
+def g1_scalar_mul(base, scalar):
+    out = np.zeros(8, dtype=np.uint64)
+    lib.oracle_g1_scalar_mul(_p(out), _p(np.ascontiguousarray(base, dtype=np.uint64)), _p(np.ascontiguousarray(scalar, dtype=np.uint64)))
+    return out
+
+
+def g1_batch_scalar_mul(base, scalars):
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.zeros((scalars.shape[0], 8), dtype=np.uint64)
+    lib.oracle_g1_batch_scalar_mul(_p(out), _p(np.ascontiguousarray(base, dtype=np.uint64)), _p(scalars), scalars.shape[0])
+    return out
+
+
+def g1_add(a, b):
+    out = np.zeros(8, dtype=np.uint64)
+    lib.oracle_g1_add(_p(out), _p(np.ascontiguousarray(a, dtype=np.uint64)), _p(np.ascontiguousarray(b, dtype=np.uint64)))
+    return out
+
+
+def g1_msm(points, scalars):
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    assert points.shape[0] == scalars.shape[0]
+    out = np.zeros(8, dtype=np.uint64)
+    lib.oracle_g1_msm(_p(out), _p(points), _p(scalars), points.shape[0])
+    return out

@@ -111,6 +111,15 @@ int oracle_gkr_verify_circuit(const oracle_layer_desc *layers, int n_layers, int
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);
 
+/* ---- BN254 G1 (g1_oracle.c): gnark-crypto's MultiExp / BatchScalarMultiplicationG1 as called at
+ * prover/gadget/prove.go:76,91,177,189,202,221 -- PARITY UNPINNED (un-vendored dependency), pinned on the big-integer
+ * arithmetic of pyoracle_ec.py.  Points: G1Affine images (8 u64, Montgomery, infinity = zeros); scalars: 4 u64, regular form. */
+int oracle_g1_on_curve(const uint64_t pt[8]);
+void oracle_g1_scalar_mul(uint64_t out[8], const uint64_t base[8], const uint64_t scalar[4]);
+void oracle_g1_batch_scalar_mul(uint64_t *out, const uint64_t base[8], const uint64_t *scalars, size_t n);
+void oracle_g1_add(uint64_t out[8], const uint64_t a[8], const uint64_t b[8]);
+void oracle_g1_msm(uint64_t out[8], const uint64_t *points, const uint64_t *scalars, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

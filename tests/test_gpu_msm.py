@@ -1,0 +1,214 @@
+"""GPU parity tests of the G1 multi-scalar multiplication (gnark-crypto's MultiExp as the reference calls it at
+prover/gadget/prove.go:76,91,189,202,221; BatchScalarMultiplicationG1 at :177) through the C ABI:
+bit-exact (affine images) against the C oracle's per-term double-and-add (oracle/g1_oracle.c, itself pinned on big-integer
+arithmetic by tests/test_oracle_ec.py -- "parity unpinned" against Go bytes: un-vendored dependency), and at sizes the
+oracle does not reach in seconds through the linearity of the map scalars -> MSM."""
+import importlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import coracle as c  # noqa: E402
+import pyoracle_ec as ec  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+Q = ec.R_ORDER
+
+
+@pytest.fixture(scope="module")
+def gk():
+    g = importlib.import_module("gkr-mimc_amd")
+    g.init(0)
+    return g
+
+
+def rand_scalars(rng, n):
+    """(n, 4) regular-form scalars below q, with the corner values the window recoding cares about."""
+    vals = [rng.randrange(Q) for _ in range(n)]
+    corners = [0, 1, Q - 1, Q - 2, 2 ** 253, 2 ** 254 - 1 if 2 ** 254 - 1 < Q else Q - 3, 0x8000, 0x7fff, 0x8001, 0xffff, 0x10000,
+               (1 << 128) - 1, 1 << 128, int("8000" * 15, 16), int("7fff" * 15, 16), int("ffff" * 15, 16) % Q]
+    for i, v in enumerate(corners):
+        if i < n:
+            vals[(7 * i + 3) % n] = v % Q
+    return ec.scalars_to_image(vals) if n else np.zeros((0, 4), dtype=np.uint64)
+
+
+def rand_points(seed, n):
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    return c.g1_batch_scalar_mul(c.G1_GEN, k) if n else np.zeros((0, 8), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 17, 64, 100, 1000, 4096, 1 << 14])
+def test_msm_vs_oracle(gk, n):
+    rng = random.Random(100 + n)
+    pts = rand_points(n + 1, n)
+    if n >= 17:
+        pts[3] = 0                      # point at infinity, gnark-crypto's (0, 0)
+        pts[5] = pts[4]                 # repeated point
+        pts[9] = pts[4]
+        pts[11, 4:] = ec.point_to_image(ec.neg(ec.point_from_image(pts[10])))[4:]   # a point and its negative
+        pts[11, :4] = pts[10, :4]
+    sc = rand_scalars(rng, n)
+    if n >= 17:
+        sc[5] = sc[4]                   # same point, same scalar: the bucket meets P + P (doubling branch)
+        sc[11] = sc[10]                 # P and -P in one bucket: the sum passes through infinity
+    want = c.g1_msm(pts, sc)
+    assert gk.multi_exp_g1(pts, sc).tolist() == want.tolist()
+    if n:
+        b = gk.G1Bases(points=pts)
+        assert len(b) == n
+        assert b.multi_exp(sc).tolist() == want.tolist()
+        assert b.multi_exp(sc).tolist() == want.tolist()               # the work buffers are reused
+        # a prefix of the bases (prove.go's MSMs run over filtered sub-vectors)
+        m = n // 2
+        assert b.multi_exp(sc[:m]).tolist() == c.g1_msm(pts[:m], sc[:m]).tolist()
+        b.close()
+
+
+@pytest.mark.parametrize("cw", list(range(2, 17)))
+def test_msm_every_window_size(gk, cw):
+    """Every window size gives the same point (the recoding's carries, the top window, the chunked reduction)."""
+    rng = random.Random(cw)
+    n = 300
+    pts = rand_points(77, n)
+    sc = rand_scalars(rng, n)
+    b = gk.G1Bases(points=pts)
+    b.set_window(cw)
+    assert b.multi_exp(sc).tolist() == c.g1_msm(pts, sc).tolist()
+    b.close()
+
+
+def test_msm_skewed_scalars(gk):
+    """The 0/1 wires of a real witness: most points of window 0 land in one bucket (the workgroup-per-bucket path), and a
+    bucket holding one point many times exercises the doubling branch of the mixed addition."""
+    n = 6000
+    pts = rand_points(5, n)
+    ones = ec.scalars_to_image([1] * n)
+    assert gk.multi_exp_g1(pts, ones).tolist() == c.g1_msm(pts, ones).tolist()
+    rng = random.Random(9)
+    sc = ec.scalars_to_image([rng.choice([0, 1, 1, 1, 2, Q - 1]) for _ in range(n)])
+    assert gk.multi_exp_g1(pts, sc).tolist() == c.g1_msm(pts, sc).tolist()
+    same = np.repeat(pts[:1], n, axis=0)           # n copies of one point, equal scalars: [n * s] P
+    s = rng.randrange(Q)
+    want = c.g1_scalar_mul(pts[0], ec.scalar_to_limbs(n * s % Q))
+    assert gk.multi_exp_g1(same, ec.scalars_to_image([s] * n)).tolist() == want.tolist()
+    # everything cancels: the result is the point at infinity, encoded (0, 0)
+    pm = np.concatenate([pts[:100], pts[:100]])
+    scm = ec.scalars_to_image([5] * 100 + [Q - 5] * 100)
+    assert gk.multi_exp_g1(pm, scm).tolist() == [0] * 8
+
+
+def test_msm_montgomery_scalars(gk):
+    """MultiExpConfig.ScalarsMont: the same scalars handed over as fr.Elements (Montgomery form)."""
+    rng = random.Random(21)
+    n = 500
+    pts = rand_points(8, n)
+    vals = [rng.randrange(Q) for _ in range(n)]
+    want = c.g1_msm(pts, ec.scalars_to_image(vals))
+    assert gk.multi_exp_g1(pts, c.from_ints(vals), scalars_mont=True).tolist() == want.tolist()
+
+
+def test_batch_scalar_multiplication(gk):
+    """bn254.BatchScalarMultiplicationG1 (prove.go:177) and the device-generated bases."""
+    rng = random.Random(31)
+    base = rand_points(9, 1)[0]
+    sc = rand_scalars(rng, 200)
+    want = c.g1_batch_scalar_mul(base, sc)
+    assert np.array_equal(gk.batch_scalar_multiplication_g1(base, sc), want)
+    b = gk.G1Bases(base=base, scalars=sc)
+    assert np.array_equal(b.read(), want)
+    assert np.array_equal(b.read(3, 5), want[3:8])
+    k = rand_scalars(rng, 200)
+    assert b.multi_exp(k).tolist() == c.g1_msm(want, k).tolist()
+    b.close()
+    inf = np.zeros(8, dtype=np.uint64)
+    assert not gk.batch_scalar_multiplication_g1(inf, sc[:4]).any()
+
+
+def test_msm_errors(gk):
+    pts = rand_points(3, 4)
+    bad = pts.copy()
+    bad[2, 3] = np.uint64(0xFFFFFFFFFFFFFFFF)          # X >= p: not a canonical fp.Element
+    with pytest.raises(gk.GkrHipError, match="canonical"):
+        gk.multi_exp_g1(bad, rand_scalars(random.Random(1), 4))
+    b = gk.G1Bases(points=pts)
+    with pytest.raises(gk.GkrHipError, match="scalars for"):
+        b.multi_exp(rand_scalars(random.Random(1), 5))
+    with pytest.raises(gk.GkrHipError, match="window"):
+        b.set_window(17)
+    b.close()
+
+
+def test_msm_linearity_2p20(gk):
+    """n = 2^20 (the oracle would need minutes): MSM(s) + MSM(t) == MSM(s + t mod q) on device-generated bases, a prefix sum
+    against the oracle, and the all-ones MSM against the plain sum of a slice."""
+    n = 1 << 20
+    rng = np.random.default_rng(2024)
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    b = gk.G1Bases(base=c.G1_GEN, scalars=k)
+    head = b.read(0, 64)
+    assert np.array_equal(head, c.g1_batch_scalar_mul(c.G1_GEN, k[:64]))
+    s = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    t = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 60) - 1)
+    t[:, 3] &= np.uint64((1 << 60) - 1)
+    # s + t as 256-bit integers (both below 2^252: no reduction needed, the sum stays below q)
+    st = np.zeros_like(s)
+    carry = np.zeros(n, dtype=np.uint64)
+    for j in range(4):
+        a = s[:, j] + t[:, j]
+        c1 = (a < s[:, j]).astype(np.uint64)
+        a2 = a + carry
+        c2 = (a2 < a).astype(np.uint64)
+        st[:, j] = a2
+        carry = c1 + c2
+    assert not carry.any()
+    ms, mt, mst = b.multi_exp(s), b.multi_exp(t), b.multi_exp(st)
+    assert c.g1_on_curve(ms) and c.g1_on_curve(mt)
+    assert c.g1_add(ms, mt).tolist() == mst.tolist()
+    m = 1 << 12
+    assert b.multi_exp(s[:m]).tolist() == c.g1_msm(b.read(0, m), s[:m]).tolist()
+    # against [sum k_i s_i] G on the whole vector: the bases are known multiples of G
+    tot = 0
+    ki = [sum(int(row[j]) << (64 * j) for j in range(4)) for row in k[:m]]
+    si = [sum(int(row[j]) << (64 * j) for j in range(4)) for row in s[:m]]
+    tot = sum(x * y for x, y in zip(ki, si)) % Q
+    assert b.multi_exp(s[:m]).tolist() == c.g1_scalar_mul(c.G1_GEN, ec.scalar_to_limbs(tot)).tolist()
+    b.close()
+
+
+def _synth_scalars(n, seed):
+    """Python mirror of k_msm_synth_scalars: limbs of (mix(i, seed))^7 as Montgomery products (x^7 R^-6 mod q)."""
+    M = (1 << 32) - 1
+    rinv = pow(1 << 256, -1, Q)
+    out = []
+    for i in range(n):
+        limbs = [(i ^ 0x9df123f) & M, ((i >> 32) + 0xf45c) & M, seed, 0x2545f491, (i * 0x9e3779b9) & M, 3, seed ^ 0x5bd1e995, 0]
+        x = sum(v << (32 * j) for j, v in enumerate(limbs))
+        out.append(pow(x, 7, Q) * pow(rinv, 6, Q) % Q)
+    return out
+
+
+def test_bench_msm_result(gk):
+    """The micro-benchmark computes a real MSM: its result on the synthetic device-resident data equals the oracle's on the
+    same data rebuilt in Python."""
+    logn = 9
+    n = 1 << logn
+    r = gk.bench_msm_g1(logn, warmup=1, iters=2)
+    ks = _synth_scalars(n, 0x1234567)
+    ss = _synth_scalars(n, 0x7654321)
+    tot = sum(a * b for a, b in zip(ks, ss)) % Q
+    assert r["result"].tolist() == c.g1_scalar_mul(c.G1_GEN, ec.scalar_to_limbs(tot)).tolist()
+    assert r["ms"] > 0 and r["c"] >= 2 and abs(sum(r["phases_ms"].values()) - r["ms"]) < 0.2 * r["ms"] + 0.05
+    r12 = gk.bench_msm_g1(logn, c=12, warmup=0, iters=1)
+    assert r12["c"] == 12 and r12["result"].tolist() == r["result"].tolist()

@@ -25,11 +25,28 @@ import os
 
 NL = 8
 M32 = (1 << 32) - 1
-QL = [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72]
-Q_INT = sum(v << (32 * i) for i, v in enumerate(QL))
-TOP_LT3Q = (3 * Q_INT - 1) >> 224        # largest top limb of a value below 3q
-TOP_LTQ = (Q_INT - 1) >> 224             # ... of a canonical value
-TOP_LT2Q = (2 * Q_INT - 1) >> 224        # ... of a lazy product of operands below 2q
+# The modulus is a parameter: BN254's scalar field Fr (the sumcheck / NTT kernels) and its base field Fp (the curve
+# arithmetic of the multi-scalar multiplications, g1.hip.h).  set_field() switches the limbs every bound is computed from and
+# the prefix of the constants the generated text names (FRQ0.. / FR_QINV32 or FPQ0.. / FP_QINV32).
+FIELDS = {
+    "FR": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "FP": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+}
+PFX = "FR"
+
+
+def set_field(pfx):
+    global PFX, QL, Q_INT, TOP_LT3Q, TOP_LTQ, TOP_LT2Q
+    PFX = pfx
+    Q_INT = FIELDS[pfx]
+    QL = [(Q_INT >> (32 * i)) & M32 for i in range(NL)]
+    TOP_LT3Q = (3 * Q_INT - 1) >> 224        # largest top limb of a value below 3q
+    TOP_LTQ = (Q_INT - 1) >> 224             # ... of a canonical value
+    TOP_LT2Q = (2 * Q_INT - 1) >> 224        # ... of a lazy product of operands below 2q
+
+
+set_field("FR")
+assert QL == [0xf0000001, 0x43e1f593, 0x79b97091, 0x2833e848, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72]
 
 
 def opmax(o, bounds):
@@ -63,7 +80,7 @@ def cexpr(o):
     k, i = o
     if k == "one":
         return "1u"
-    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": "FRQ%d", "A": "A[%d]", "ca": "ca.v[%d]", "cb": "cb.v[%d]",
+    return {"a": "a.v[%d]", "b": "b.v[%d]", "m": "m%d", "q": PFX + "Q%d", "A": "A[%d]", "ca": "ca.v[%d]", "cb": "cb.v[%d]",
             "d": "d%d", "e": "e%d"}[k] % i
 
 
@@ -148,8 +165,8 @@ def column(dev, host, t_max, prods, bounds, last=None):
     return dev, host, s_max
 
 
-def gen_mul():
-    bounds = {}
+def gen_mul(bounds=None):
+    bounds = dict(bounds or {})
     dev = host = "    u64 acc = (u64)a.v[0] * b.v[0];\n    u32 ovf;\n"
     t_max = M32 * M32
     for c in range(2 * NL - 1):
@@ -162,7 +179,7 @@ def gen_mul():
             if c < NL and i == c:
                 continue  # m_c * q_0 is added once m_c is known
             prods.append((("m", i), ("q", c - i)))
-        last = ("    const u32 m%d = (u32)acc * FR_QINV32;\n" % c, ("m", c), ("q", 0)) if c < NL else None
+        last = ("    const u32 m%d = (u32)acc * %s_QINV32;\n" % (c, PFX), ("m", c), ("q", 0)) if c < NL else None
         dev, host, s_max = column(dev, host, t_max, prods, bounds, last)
         if c >= NL:
             host += "    r.v[%d] = (u32)acc;\n" % (c - NL)
@@ -216,7 +233,7 @@ def gen_sqr():
             if c < NL and i == c:
                 continue
             prods.append((("m", i), ("q", c - i)))
-        last = ("    const u32 m%d = (u32)acc * FR_QINV32;\n" % c, ("m", c), ("q", 0)) if c < NL else None
+        last = ("    const u32 m%d = (u32)acc * %s_QINV32;\n" % (c, PFX), ("m", c), ("q", 0)) if c < NL else None
         dev, host, s_max = column(dev, host, t_max, prods, bounds, last)
         if c >= NL:
             host += "    r.v[%d] = (u32)acc;\n" % (c - NL)
@@ -239,7 +256,7 @@ def gen_sqr():
 def cexpr2(o, ch):
     k, i = o
     if k == "q":
-        return "FRQ%d" % i
+        return PFX + "Q%d" % i
     return {"a": "a%d.v[%d]", "b": "b%d.v[%d]", "m": "m%d_%d"}[k] % (ch, i)
 
 
@@ -329,7 +346,7 @@ def gen_mul2():
         if c < NL:
             pm = M32 * QL[0]
             track = s_max + pm >= (1 << 64)
-            dev += "    const u32 m0_%d = (u32)acc0 * FR_QINV32, m1_%d = (u32)acc1 * FR_QINV32;\n" % (c, c)
+            dev += "    const u32 m0_%d = (u32)acc0 * %s_QINV32, m1_%d = (u32)acc1 * %s_QINV32;\n" % (c, PFX, c, PFX)
             t, live = emit_asm2([(("m", c), ("q", 0), track)], live)
             dev += t
             s_max += pm
@@ -409,7 +426,7 @@ def gen_mul_const2():
             j = c - i
             if 0 <= j < NL and not (c < H and i == c):
                 prods.append((("m", i), ("q", j)))
-        last = ("    const u32 m%d = (u32)acc * FR_QINV32;\n" % c, ("m", c), ("q", 0)) if c < H else None
+        last = ("    const u32 m%d = (u32)acc * %s_QINV32;\n" % (c, PFX), ("m", c), ("q", 0)) if c < H else None
         dev, host, s_max = column(dev, host, t_max, prods, bounds, last)
         if c >= H:
             host += "    r.v[%d] = (u32)acc;\n" % (c - H)
@@ -460,6 +477,24 @@ def main():
                 "// Needs: u32/u64 typedefs, FRQ0..FRQ7, FR_QINV32, FR_MADC (portable branch).\n")
         f.write("#if defined(__HIP_DEVICE_COMPILE__)\n" + dev + "#else\n" + host + "#endif\n")
     print("wrote", OUT)
+    # the base field Fp of the curve arithmetic (fp_bn254.h): every Fp value a kernel holds is below 2p, which the carry
+    # planning of the product uses (top limbs below 2^31)
+    set_field("FP")
+    outp = os.path.join(os.path.dirname(OUT), "fp_mont_gen.inc")
+    dev, host = gen_mul({("a", NL - 1): TOP_LT2Q, ("b", NL - 1): TOP_LT2Q})
+    with open(outp, "w") as f:
+        f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Body of fp_mul() in fp_bn254.h:\n"
+                "// inputs `a`, `b` < 2p (BN254 base field), output `r` = a*b/2^256 mod p in [0, 2p).\n")
+        f.write("#if defined(__HIP_DEVICE_COMPILE__)\n" + dev + "#else\n" + host + "#endif\n")
+    print("wrote", outp)
+    outp = os.path.join(os.path.dirname(OUT), "fp_sqr_gen.inc")
+    dev, host = gen_sqr()
+    with open(outp, "w") as f:
+        f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.  Body of fp_sqr() in fp_bn254.h:\n"
+                "// input `a` < 2p, output `r` = a*a/2^256 mod p in [0, 2p), the integer fp_mul(a, a) returns.\n")
+        f.write("#if defined(__HIP_DEVICE_COMPILE__)\n" + dev + "#else\n" + host + "#endif\n")
+    print("wrote", outp)
+    set_field("FR")
 
 
 if __name__ == "__main__":
