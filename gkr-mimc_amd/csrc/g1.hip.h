@@ -8,9 +8,10 @@
 //
 // Pippenger's bucket method laid out for a GPU instead of gnark-crypto's one-goroutine-per-window loop:
 //   1. every scalar (regular form, < q < 2^254) is cut into W = ceil(255 / c) SIGNED digits of c bits
-//      (d in [-2^(c-1)+1, 2^(c-1)]: half the buckets, the sign negates the point's y);
-//   2. the (window, |digit|) pairs are counting-sorted: a histogram (k_msm_count), one exclusive scan (k_msm_scan), a
-//      scatter of point indices (k_msm_scatter) -- atomics on 32-bit counters only, never on points;
+//      (d in [-2^(c-1), 2^(c-1)]: half the buckets, the sign negates the point's y);
+//   2. the (window, |digit|) pairs are counting-sorted with every atomic in LDS: a workgroup owns one window of one chunk
+//      of the scalars and keeps that window's whole histogram (128 KiB at c = 16) in gfx950's 160 KiB LDS
+//      (k_msm_hist, k_msm_totals, k_msm_scan, k_msm_chunk_off, k_msm_scatter) -- never an atomic on a point;
 //   3. ONE LANE PER BUCKET adds its run of points with mixed additions into an extended-Jacobian (XYZZ) accumulator
 //      (k_msm_accumulate: 8 M + 2 S per point, the bulk of the work: W * n additions); the few buckets far above the mean
 //      (skewed scalars: the 0/1 wires of a real witness put most points of window 0 into bucket 1) are summed by a whole
@@ -115,6 +116,20 @@ __device__ __forceinline__ void g1x_madd(G1X& p, const G1Aff& a) {
     p.zz = fp_mul(p.zz, pp);
     p.zzz = fp_mul(p.zzz, ppp);
 }
+// The common case alone, for the hot loop of the bucket accumulation: p += a when neither is infinity and a != +-p;
+// returns false and leaves p untouched otherwise (the caller then takes g1x_madd).  Keeping the doubling out of the loop
+// body keeps its 6 products out of the loop's instruction stream (and of the instruction cache's working set).
+__device__ __forceinline__ bool g1x_madd_fast(G1X& p, const G1Aff& a) {
+    const Fp pp_ = fp_sub(fp_mul(a.x, p.zz), p.x), r = fp_sub(fp_mul(a.y, p.zzz), p.y);
+    if (fp_is_zero(pp_) || g1x_is_inf(p) || g1_aff_is_inf(a)) return false;
+    const Fp pp = fp_sqr(pp_), ppp = fp_mul(pp_, pp), q = fp_mul(p.x, pp);
+    const Fp x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(q));
+    p.y = fp_sub(fp_mul(r, fp_sub(q, x3)), fp_mul(p.y, ppp));
+    p.x = x3;
+    p.zz = fp_mul(p.zz, pp);
+    p.zzz = fp_mul(p.zzz, ppp);
+    return true;
+}
 // p += q (add-2008-s: 12 M + 2 S), every special case handled
 __device__ __forceinline__ void g1x_add(G1X& p, const G1X& q) {
     if (g1x_is_inf(q)) return;
@@ -171,9 +186,15 @@ struct MsmArgs {
     int scalars_mont;         // 1: the scalars are in Montgomery form (MultiExpConfig.ScalarsMont), converted on the fly
     unsigned int* count;      // W * nb bucket sizes
     unsigned int* offset;     // exclusive scan of count
-    unsigned int* cursor;     // scatter cursors (a copy of offset)
+    unsigned int* chist;      // [W][nchunk][nb] chunk histograms, then chunk offsets
+    unsigned int* order;      // [W][nb] bucket ids of a window by decreasing size
+    unsigned int* tile_sum;   // scan tiles of MSM_SCAN_TILE buckets
+    unsigned int ntiles;
+    unsigned int nchunk;      // chunks of the scalar vector (one sorting workgroup per window and chunk)
+    size_t chunk_len;
+    u32 bias[8];              // H: half a window added to every window but the top one
     unsigned int* entries;    // point index | sign << 31, sorted by (window, bucket)
-    unsigned int* big;        // [0] = number of big buckets, [1 + k] = their ids
+    unsigned int* big;        // [0] = number of big buckets, [1 + k] = their ids, [big_cap + 1] = a scalar was not below 2^254
     unsigned int big_threshold, big_cap;
     G1XPlanes buckets;        // W * nb
     G1XPlanes parts;          // W * nchunk chunk sums
@@ -192,73 +213,193 @@ __device__ __forceinline__ void msm_load_scalar(const MsmArgs& a, size_t i, u32 
 #pragma unroll
     for (int j = 0; j < 8; j++) s[j] = x.v[j];
 }
-// F(window, bucket index = |d| - 1, negative) for every non-zero digit of the scalar.  C is a template parameter so that
-// every limb index below is a compile-time constant (the scalar stays in registers).
-template <int C, typename F>
-__device__ __forceinline__ void msm_digits(const u32 (&s)[8], F&& f) {
-    constexpr int W = (255 + C - 1) / C;
-    constexpr u32 HALF = 1u << (C - 1);
-    u32 carry = 0;
+// Signed digits without a carry chain: with H = sum_{j < W-1} 2^(c j + c - 1) (half a window added to every window but the
+// top one) the plain c-bit windows d'_j of s + H give d_j = d'_j - 2^(c-1) in [-2^(c-1), 2^(c-1) - 1] for j < W - 1 and
+// d_(W-1) = d'_(W-1) <= 2^(c-1) (s < 2^254 and c W >= 255), and sum_j d_j 2^(c j) = s.  Every window's digit is then a
+// function of s alone, which lets a workgroup own ONE window.  Returns the bucket index |d| - 1 (and the sign), or
+// 0xffffffff for a zero digit; MSM_DIGIT_BAD when the top digit leaves the bucket range (a scalar >= 2^254: not an fr.Element).
+#define MSM_DIGIT_NONE 0xffffffffu
+#define MSM_DIGIT_BAD 0xfffffffeu
+__device__ __forceinline__ bool msm_bias_scalar(const MsmArgs& a, u32 (&s)[8]) {      // false: s + H left 256 bits
+    u32 cy = 0;
 #pragma unroll
-    for (int j = 0; j < W; j++) {
-        const int bit = j * C, limb = bit >> 5, sh = bit & 31;          // C * (W - 1) < 255: limb <= 7
-        u32 d = s[limb] >> sh;
-        if (sh + C > 32 && limb < 7) d |= s[limb < 7 ? limb + 1 : 7] << (32 - sh);
-        d = (d & ((1u << C) - 1u)) + carry;
-        const bool neg = d > HALF;
-        carry = neg ? 1u : 0u;
-        const u32 mag = neg ? (1u << C) - d : d;
-        if (mag) f(j, mag - 1u, neg);
+    for (int l = 0; l < 8; l++) s[l] = fr_addc(s[l], a.bias[l], cy, &cy);
+    return cy == 0;
+}
+__device__ __forceinline__ u32 msm_digit(const MsmArgs& a, const u32 (&sb)[8], int j, bool* neg) {
+    const int bit = j * a.c, limb = bit >> 5, sh = bit & 31;      // uniform across the workgroup: selects, not indexed registers
+    u32 lo = 0, hi = 0;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        lo = (l == limb) ? sb[l] : lo;
+        hi = (l == limb + 1) ? sb[l] : hi;
     }
+    const u32 dp = (u32)((((u64)hi << 32) | lo) >> sh) & ((1u << a.c) - 1u);
+    const u32 half = a.nb;
+    if (j == a.W - 1) {
+        *neg = false;
+        return dp == 0 ? MSM_DIGIT_NONE : (dp > half ? MSM_DIGIT_BAD : dp - 1u);
+    }
+    *neg = dp < half;
+    const u32 mag = *neg ? half - dp : dp - half;
+    return mag ? mag - 1u : MSM_DIGIT_NONE;
 }
 
-template <int C>
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_count(MsmArgs a) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+// Counting sort of the (window, bucket) pairs with every atomic in LDS.  Workgroup (j, k) owns window j of the k-th chunk
+// of the scalars and keeps the window's whole histogram -- 2^(c-1) words, 128 KiB at c = 16: gfx950's 160 KiB of LDS per CU
+// is what makes one pass per window possible -- so the 16 n increments of an MSM never leave the CU.
+//   k_msm_hist:      chunk histograms            chist[j][k][b]
+//   k_msm_totals / k_msm_scan / k_msm_offsets:   bucket sizes, their exclusive scan, the chunks' write positions
+//   k_msm_scatter:   the chunk again, cursors in LDS initialised from chist: entries[cursor[b]++] = index | sign
+#define MSM_SORT_THREADS 1024
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(MsmArgs a) {
+    extern __shared__ unsigned int hist[];
+    const int j = blockIdx.x;
+    const unsigned int k = blockIdx.y;
+    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
+    bool bad = false;
+    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
         u32 s[8];
         msm_load_scalar(a, i, s);
-        msm_digits<C>(s, [&](int j, u32 b, bool) { atomicAdd(&a.count[(size_t)j * a.nb + b], 1u); });
+        const bool fits = msm_bias_scalar(a, s);
+        bool neg;
+        const u32 b = msm_digit(a, s, j, &neg);
+        if (b == MSM_DIGIT_BAD || !fits) bad = true;
+        else if (b != MSM_DIGIT_NONE) atomicAdd(&hist[b], 1u);
     }
+    if (bad) a.big[a.big_cap + 1] = 1u;      // error word behind the big-bucket list
+    __syncthreads();
+    unsigned int* out = a.chist + ((size_t)j * a.nchunk + k) * a.nb;
+    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) out[b] = hist[b];
 }
-template <int C>
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_scatter(MsmArgs a) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
-        u32 s[8];
-        msm_load_scalar(a, i, s);
-        msm_digits<C>(s, [&](int j, u32 b, bool neg) {
-            const u32 pos = atomicAdd(&a.cursor[(size_t)j * a.nb + b], 1u);
-            a.entries[pos] = (u32)i | (neg ? 0x80000000u : 0u);
-        });
-    }
-}
-// exclusive scan of the W * nb counts by ONE workgroup (a few hundred thousand words: microseconds), cursors initialised,
-// the buckets above the threshold listed for k_msm_accumulate_big
+// Exclusive scan of the W * nb bucket sizes in tiles of MSM_SCAN_TILE buckets, every access coalesced:
+//   k_msm_totals:   count[t] = sum_k chist[.][k][.], tile sums                       (one workgroup per tile)
+//   k_msm_scan:     exclusive scan of the tile sums                                   (one workgroup)
+//   k_msm_offsets:  offset[t] = tile base + scan inside the tile; chunk offsets chist[j][k][b] <- offset + sum_{k' < k};
+//                   the buckets above the threshold listed for k_msm_accumulate_big   (one workgroup per tile)
 #define MSM_SCAN_THREADS 1024
-__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_scan(MsmArgs a) {
-    __shared__ unsigned int part[MSM_SCAN_THREADS];
-    const size_t total = (size_t)a.W * a.nb;
-    const size_t per = (total + MSM_SCAN_THREADS - 1) / MSM_SCAN_THREADS;
-    const size_t lo = min(total, per * threadIdx.x), hi = min(total, lo + per);
-    unsigned int s = 0;
-    for (size_t t = lo; t < hi; t++) s += a.count[t];
-    part[threadIdx.x] = s;
+#define MSM_SCAN_TILE 2048
+__device__ __forceinline__ unsigned int msm_block_scan(unsigned int* sh, unsigned int v) {      // inclusive scan over the workgroup
+    sh[threadIdx.x] = v;
     __syncthreads();
     for (int d = 1; d < MSM_SCAN_THREADS; d <<= 1) {
-        const unsigned int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        const unsigned int x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
         __syncthreads();
-        part[threadIdx.x] += v;
+        sh[threadIdx.x] += x;
         __syncthreads();
     }
-    unsigned int run = part[threadIdx.x] - s;
-    for (size_t t = lo; t < hi; t++) {
-        const unsigned int cnt = a.count[t];
+    return sh[threadIdx.x];
+}
+__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_totals(MsmArgs a) {
+    __shared__ unsigned int sh[MSM_SCAN_THREADS];
+    const size_t total = (size_t)a.W * a.nb;
+    unsigned int mine = 0;
+#pragma unroll
+    for (int h = 0; h < MSM_SCAN_TILE / MSM_SCAN_THREADS; h++) {
+        const size_t t = (size_t)blockIdx.x * MSM_SCAN_TILE + h * MSM_SCAN_THREADS + threadIdx.x;
+        if (t < total) {
+            const size_t j = t / a.nb, b = t % a.nb;
+            unsigned int s = 0;
+            for (unsigned int k = 0; k < a.nchunk; k++) s += a.chist[(j * a.nchunk + k) * a.nb + b];
+            a.count[t] = s;
+            mine += s;
+        }
+    }
+    const unsigned int incl = msm_block_scan(sh, mine);
+    if (threadIdx.x == MSM_SCAN_THREADS - 1) a.tile_sum[blockIdx.x] = incl;
+}
+__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_scan(MsmArgs a) {      // ntiles <= MSM_SCAN_THREADS * 8 (host checks)
+    __shared__ unsigned int sh[MSM_SCAN_THREADS];
+    const unsigned int per = (a.ntiles + MSM_SCAN_THREADS - 1) / MSM_SCAN_THREADS;
+    const unsigned int lo = min(a.ntiles, per * threadIdx.x), hi = min(a.ntiles, lo + per);
+    unsigned int s = 0;
+    for (unsigned int t = lo; t < hi; t++) s += a.tile_sum[t];
+    unsigned int run = msm_block_scan(sh, s) - s;
+    for (unsigned int t = lo; t < hi; t++) {
+        const unsigned int c = a.tile_sum[t];
+        a.tile_sum[t] = run;
+        run += c;
+    }
+}
+__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
+    __shared__ unsigned int sh[MSM_SCAN_THREADS];
+    const size_t total = (size_t)a.W * a.nb;
+    const size_t t0 = (size_t)blockIdx.x * MSM_SCAN_TILE + (size_t)threadIdx.x * (MSM_SCAN_TILE / MSM_SCAN_THREADS);   // consecutive buckets per lane
+    unsigned int c[MSM_SCAN_TILE / MSM_SCAN_THREADS], mine = 0;
+#pragma unroll
+    for (int h = 0; h < MSM_SCAN_TILE / MSM_SCAN_THREADS; h++) {
+        c[h] = t0 + h < total ? a.count[t0 + h] : 0u;
+        mine += c[h];
+    }
+    unsigned int run = a.tile_sum[blockIdx.x] + msm_block_scan(sh, mine) - mine;
+#pragma unroll
+    for (int h = 0; h < MSM_SCAN_TILE / MSM_SCAN_THREADS; h++) {
+        const size_t t = t0 + h;
+        if (t >= total) break;
         a.offset[t] = run;
-        a.cursor[t] = run;
-        if (cnt > a.big_threshold) {
+        if (c[h] > a.big_threshold) {
             const unsigned int k = atomicAdd(&a.big[0], 1u);
             if (k < a.big_cap) a.big[1 + k] = (unsigned int)t;
         }
-        run += cnt;
+        const size_t j = t / a.nb, b = t % a.nb;
+        unsigned int r2 = run;
+        for (unsigned int k = 0; k < a.nchunk; k++) {
+            unsigned int* p = &a.chist[(j * a.nchunk + k) * a.nb + b];
+            const unsigned int x = *p;
+            *p = r2;
+            r2 += x;
+        }
+        run += c[h];
+    }
+}
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(MsmArgs a) {
+    extern __shared__ unsigned int cursor[];
+    const int j = blockIdx.x;
+    const unsigned int k = blockIdx.y;
+    const unsigned int* in = a.chist + ((size_t)j * a.nchunk + k) * a.nb;
+    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) cursor[b] = in[b];
+    __syncthreads();
+    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
+    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
+        u32 s[8];
+        msm_load_scalar(a, i, s);
+        (void)msm_bias_scalar(a, s);
+        bool neg;
+        const u32 b = msm_digit(a, s, j, &neg);
+        if (b < MSM_DIGIT_BAD) a.entries[atomicAdd(&cursor[b], 1u)] = (u32)i | (neg ? 0x80000000u : 0u);
+    }
+}
+// Lanes of a wave run for as long as their longest bucket: the buckets of a window are handed to the lanes in order of
+// size (largest first), so that the 64 buckets of a wave hold nearly the same number of points (a counting sort of the
+// window's 2^(c-1) bucket ids by their counts, one workgroup per window, everything in LDS).  Big buckets sort as empty:
+// they belong to k_msm_accumulate_big.
+#define MSM_ORDER_BINS 1024
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
+    __shared__ unsigned int bin[MSM_ORDER_BINS + 1];
+    const unsigned int j = blockIdx.x;
+    const unsigned int* cnt = a.count + (size_t)j * a.nb;
+    for (unsigned int i = threadIdx.x; i <= MSM_ORDER_BINS; i += MSM_SORT_THREADS) bin[i] = 0;
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) {
+        const unsigned int c = cnt[b];
+        atomicAdd(&bin[c > a.big_threshold ? 0u : min(c, (unsigned int)MSM_ORDER_BINS)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {            // start of every size class, largest class first (a thousand additions)
+        unsigned int run = 0;
+        for (int i = MSM_ORDER_BINS; i >= 0; i--) {
+            const unsigned int c = bin[i];
+            bin[i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) {
+        const unsigned int c = cnt[b];
+        const unsigned int pos = atomicAdd(&bin[c > a.big_threshold ? 0u : min(c, (unsigned int)MSM_ORDER_BINS)], 1u);
+        a.order[(size_t)j * a.nb + pos] = b;
     }
 }
 
@@ -270,14 +411,46 @@ __device__ __forceinline__ G1Aff msm_entry_point(const MsmArgs& a, unsigned int 
     if (e & 0x80000000u) p.y = fp_neg(p.y);
     return p;
 }
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_accumulate(MsmArgs a) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)a.W * a.nb) return;
+#ifndef MSM_ACC_MINBLOCKS
+#define MSM_ACC_MINBLOCKS 3      // workgroups per CU the register allocation must allow (4: 128 registers, spills, measured 8-12 % slower)
+#endif
+__global__ void __launch_bounds__(GKR_BLOCK, MSM_ACC_MINBLOCKS) k_msm_accumulate(MsmArgs a) {
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= (size_t)a.W * a.nb) return;
+    const size_t t = lane - lane % a.nb + a.order[lane];          // the lane's bucket: the (lane mod nb)-th largest of its window
     const unsigned int cnt = a.count[t], start = a.offset[t];
     G1X acc;
     g1x_set_inf(acc);
-    if (cnt <= a.big_threshold)
-        for (unsigned int k = 0; k < cnt; k++) g1x_madd(acc, msm_entry_point(a, a.entries[start + k]));
+    if (cnt && cnt <= a.big_threshold) {
+        // Software pipeline of a lane's chain index -> point -> 10 products: the index is loaded two points ahead and the
+        // point one ahead, so neither HBM round trip sits between two additions.  The inner loop is the common case only;
+        // the first point of a bucket and the rare doubling / cancellation leave it for the complete addition.
+        const unsigned int* ent = a.entries + start;
+        G1Aff cur = msm_entry_point(a, ent[0]);
+        unsigned int k = 1;
+        unsigned int e_nxt = cnt > 1 ? ent[1] : 0u;
+        for (;;) {
+            bool done = false;
+            for (;;) {
+                if (k >= cnt) {
+                    done = true;
+                    break;
+                }
+                const G1Aff nxt = msm_entry_point(a, e_nxt);
+                const unsigned int e_nn = k + 1 < cnt ? ent[k + 1] : 0u;
+                if (!g1x_madd_fast(acc, cur)) break;       // e_nxt still names point k: the slow path re-loads it
+                cur = nxt;
+                e_nxt = e_nn;
+                k++;
+            }
+            if (done) break;
+            g1x_madd(acc, cur);
+            cur = msm_entry_point(a, e_nxt);
+            k++;
+            e_nxt = k < cnt ? ent[k] : 0u;
+        }
+        g1x_madd(acc, cur);
+    }
     g1x_st(a.buckets, t, acc);        // a big bucket is overwritten by k_msm_accumulate_big (launched after this kernel)
 }
 // LDS tree over the workgroup's XYZZ partial sums; the result is in sh[0]

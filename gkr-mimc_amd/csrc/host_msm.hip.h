@@ -27,7 +27,10 @@ struct MsmWork {
     unsigned int nb = 0;
     int chunk = 0;
     unsigned int big_cap = 0;
-    unsigned int* counts = nullptr;      // count | offset | cursor, W * nb words each
+    unsigned int* counts = nullptr;      // count | offset | order (W * nb words each) | chunk histograms (W * nchunk * nb)
+    unsigned int nchunk = 0, ntiles = 0;
+    size_t chunk_len = 0;
+    uint32_t bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int* entries = nullptr;
     unsigned int* big = nullptr;
     uint4* scalars = nullptr;            // n_cap x 32 B staging of host scalars
@@ -65,19 +68,32 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced) {
     w->n_cap = n;
     // chunk of the window reduction: enough lanes to cover the GPU once (W * nb / chunk >= ~16 K) without making the
     // chunk offset's double-and-add (~2 c group operations) the bulk of a lane's work
-    int chunk = 32;
+    // (measured at c = 16: chunks of 32 / 16 / 8 / 4 buckets 0.73 / 0.54 / 0.52 / 0.71 ms for the whole reduction)
+    int chunk = 8;
     while (chunk > 4 && (size_t)w->W * (w->nb / chunk) < 16384) chunk >>= 1;
     if ((unsigned)chunk > w->nb) chunk = (int)w->nb;
     w->chunk = chunk;
     w->nparts = (size_t)w->W * (w->nb / chunk);
     const size_t nbk = (size_t)w->W * w->nb;
-    w->big_cap = (unsigned int)std::min<size_t>((size_t)w->W * n / 256 + 16, (size_t)1 << 24);
-    HIPCHK(hipMalloc((void**)&w->counts, 3 * nbk * sizeof(unsigned int)));
+    w->big_cap = (unsigned int)std::min<size_t>((size_t)w->W * n / 128 + 16, (size_t)1 << 25);
+    // sorting workgroups: one per window and chunk of the scalars; a chunk is long enough to amortise the workgroup's
+    // histogram traffic (2^(c-1) words in and out) and short enough that W * nchunk workgroups cover the CUs several times
+    // (one workgroup per CU at c = 16: measured 2.72 / 1.96 / 1.96 ms of sorting at 2^22 points with 8 / 16..32 / 64 chunks,
+    // 10.6 / 8.9 / 6.9 ms at 2^24 with 8 / 16 / 64)
+    w->nchunk = (unsigned int)std::min<size_t>(128, std::max<size_t>(1, n / 131072));
+    w->chunk_len = (n + w->nchunk - 1) / w->nchunk;
+    memset(w->bias, 0, sizeof w->bias);
+    for (int j = 0; j + 1 < w->W; j++) {
+        const int bit = j * c + c - 1;
+        w->bias[bit >> 5] |= 1u << (bit & 31);
+    }
+    w->ntiles = (unsigned int)((nbk + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE);
+    HIPCHK(hipMalloc((void**)&w->counts, ((3 + (size_t)w->nchunk) * nbk + w->ntiles) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->entries, std::max<size_t>(1, (size_t)w->W * n) * sizeof(unsigned int)));
-    HIPCHK(hipMalloc((void**)&w->big, ((size_t)w->big_cap + 1) * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&w->big, ((size_t)w->big_cap + 2) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
     HIPCHK(hipMalloc((void**)&w->xyzz, 8 * (nbk + w->nparts + (size_t)w->W) * sizeof(uint4)));
-    HIPCHK(hipHostMalloc((void**)&w->h_wins, 8 * (size_t)w->W * sizeof(uint4)));
+    HIPCHK(hipHostMalloc((void**)&w->h_wins, (8 * (size_t)w->W + 1) * sizeof(uint4)));      // + the error word
     return 0;
 }
 
@@ -91,14 +107,6 @@ struct MsmTimes {      // HIP-event split of one MSM (bench only)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool on = false;
 };
-
-template <int C>
-void msm_launch_sort(const MsmArgs& a, hipStream_t st, int grid, MsmTimes* tm) {
-    hipLaunchKernelGGL(k_msm_count<C>, dim3(grid), dim3(GKR_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(MSM_SCAN_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_msm_scatter<C>, dim3(grid), dim3(GKR_BLOCK), 0, st, a);
-    (void)tm;
-}
 
 // The device part: the W window sums of sum_{i<n} [s_i] P_i land in w->h_wins (the caller synchronises the stream).
 // d_scalars: n x 32 B on the device.
@@ -117,26 +125,41 @@ int msm_dev(gkrhip_g1_bases* b, const uint4* d_scalars, size_t n, int flags, Msm
     a.scalars_mont = (flags & GKRHIP_MSM_SCALARS_MONT) ? 1 : 0;
     a.count = w->counts;
     a.offset = w->counts + nbk;
-    a.cursor = w->counts + 2 * nbk;
+    a.order = w->counts + 2 * nbk;
+    a.chist = w->counts + 3 * nbk;
+    a.tile_sum = a.chist + (size_t)w->nchunk * nbk;
+    a.ntiles = w->ntiles;
+    a.nchunk = w->nchunk;
+    a.chunk_len = w->chunk_len;
+    memcpy(a.bias, w->bias, sizeof a.bias);
     a.entries = w->entries;
     a.big = w->big;
     // a bucket far above the mean (n / nb points per bucket and window for uniform digits) gets a workgroup of its own
-    a.big_threshold = (unsigned int)std::max<size_t>(512, 8 * (n / w->nb));
+    a.big_threshold = (unsigned int)std::max<size_t>(128, 4 * (n / w->nb));
     a.big_cap = w->big_cap;
     a.buckets = G1XPlanes{w->xyzz, nbk};
     a.parts = G1XPlanes{w->xyzz + 8 * nbk, w->nparts};
     a.wins = G1XPlanes{w->xyzz + 8 * (nbk + w->nparts), (size_t)w->W};
     a.chunk = w->chunk;
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
-    HIPCHK(hipMemsetAsync(a.count, 0, nbk * sizeof(unsigned int), st));
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
-    const int grid = grid_for(std::max<size_t>(n, 1), 4096);
-    switch (w->c) {
-#define MSM_CASE(C) case C: msm_launch_sort<C>(a, st, grid, tm); break;
-        MSM_CASE(2) MSM_CASE(3) MSM_CASE(4) MSM_CASE(5) MSM_CASE(6) MSM_CASE(7) MSM_CASE(8) MSM_CASE(9) MSM_CASE(10)
-        MSM_CASE(11) MSM_CASE(12) MSM_CASE(13) MSM_CASE(14) MSM_CASE(15) MSM_CASE(16)
-#undef MSM_CASE
-        default: return fail("msm: window size %d", w->c);
+    HIPCHK(hipMemsetAsync(a.big + a.big_cap + 1, 0, sizeof(unsigned int), st));
+    {
+        static std::once_flag once;       // histograms above 64 KiB of dynamic LDS need the attribute (gfx950: 160 KiB per CU)
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+            (void)hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+        });
+        // windows fastest: the W workgroups that read one chunk of the scalars run side by side (window by window instead:
+        // -3 % at 2^22 points, +3 % at 2^20)
+        const dim3 sgrid(w->W, w->nchunk), sblock(MSM_SORT_THREADS);
+        const size_t lds = (size_t)w->nb * sizeof(unsigned int);
+        hipLaunchKernelGGL(k_msm_hist, sgrid, sblock, lds, st, a);
+        hipLaunchKernelGGL(k_msm_totals, dim3(w->ntiles), dim3(MSM_SCAN_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(MSM_SCAN_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_msm_offsets, dim3(w->ntiles), dim3(MSM_SCAN_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_msm_scatter, sgrid, sblock, lds, st, a);
+        hipLaunchKernelGGL(k_msm_order, dim3(w->W), sblock, 0, st, a);
     }
     HIPCHK(hipGetLastError());
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[1], st));
@@ -149,6 +172,7 @@ int msm_dev(gkrhip_g1_bases* b, const uint4* d_scalars, size_t n, int flags, Msm
     HIPCHK(hipGetLastError());
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[4], st));
     HIPCHK(hipMemcpyAsync(w->h_wins, a.wins.base, 8 * (size_t)w->W * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(w->h_wins + 8 * (size_t)w->W, a.big + a.big_cap + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[5], st));
     return 0;
 }
@@ -183,6 +207,7 @@ int msm_run(gkrhip_g1_bases* b, const uint64_t* scalars, size_t n, int flags, ui
     if (n) HIPCHK(hipMemcpyAsync(b->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
     CHK(msm_dev(b, b->w.scalars, n, flags, nullptr));
     HIPCHK(hipStreamSynchronize(cx().stream));
+    if (b->w.h_wins[8 * (size_t)b->w.W].x) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
     const hfp::Aff r = msm_host_tail(&b->w);
     memcpy(out_affine, r.x.l, 32);
     memcpy(out_affine + 4, r.y.l, 32);

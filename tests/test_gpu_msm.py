@@ -145,6 +145,11 @@ def test_msm_errors(gk):
         b.multi_exp(rand_scalars(random.Random(1), 5))
     with pytest.raises(gk.GkrHipError, match="window"):
         b.set_window(17)
+    big = rand_scalars(random.Random(2), 4)
+    big[1, 3] = np.uint64(0xFFFFFFFFFFFFFFFF)           # far above 2^254: not a reduced fr.Element
+    with pytest.raises(gk.GkrHipError, match="2\\^254"):
+        b.multi_exp(big)
+    assert b.multi_exp(big[:1]).tolist() == c.g1_msm(pts[:1], big[:1]).tolist()      # the handle is still usable
     b.close()
 
 

@@ -1,0 +1,18 @@
+"""MSM micro-benchmark on device-resident synthetic data (gkrhip_bench_msm_g1): python tools/msm_bench.py [logn...] [c=N]"""
+import importlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gk = importlib.import_module("gkr-mimc_amd")
+gk.init(0)
+args = [a for a in sys.argv[1:] if not a.startswith("c=")]
+cs = [int(a[2:]) for a in sys.argv[1:] if a.startswith("c=")] or [0]
+for logn in [int(a) for a in args] or [16, 18, 20, 22]:
+    for cw in cs:
+        r = gk.bench_msm_g1(logn, c=cw, warmup=1, iters=3)
+        r.pop("result")
+        r["logn"] = logn
+        r["points_per_s"] = (1 << logn) / (r["ms"] * 1e-3)
+        print(json.dumps(r))
