@@ -36,6 +36,14 @@ NOMINAL_GHZ = 2.4         # MI355X engine clock (MI355X_MICROARCH.md)
 HALF_RATE_CYCLES = 4.3    # v_mad_u64_u32 / carries / v_mul_lo_u32 per wave and SIMD (profiles/r01_ubench_instruction_rates.txt)
 FULL_RATE_CYCLES = 2.4
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
+
+
+def COMPUTE_H_PRODUCTS(logn):
+    """Field products of one computeH on 2^logn points: seven transforms of logn * n / 2 butterflies (one product each), the
+    per-element factors (coset shift and 1/n on the three forward loads: 2 products; the last store's factor: 2), the
+    pointwise step (2).  The products that derive a group's twiddles from the loaded ones are overhead, not counted."""
+    n = float(1 << logn)
+    return 7 * logn * n / 2 + 3 * 2 * n + 2 * n + 2 * n
 BN_TOTAL_MULTI = 26       # BASELINE config 4
 
 
@@ -144,30 +152,45 @@ class Rendezvous:
     (RCCL 2.26.6 / HIP 7.0 against the image's 7.2), and importing it first would make dlopen("librccl.so.1") resolve to
     those.  GKRHIP_BENCH_BOOTSTRAP=gloo selects torch.distributed (gloo) instead; same operations."""
 
+    MAX_FRAME = 1 << 20       # the largest message is eight 128-byte communicator ids
+
     def __init__(self, rank, world, addr, port, timeout=600.0):
-        import pickle
+        import hashlib
         import socket
         import struct
-        self.rank, self.world, self._pickle, self._struct = rank, world, pickle, struct
+        self.rank, self.world, self._struct = rank, world, struct
         self.peers = {}
         deadline = time.time() + timeout
+        # Frames are JSON (ints, floats, strings, None, bytes as hex): nothing a peer sends is ever executed.  A connection is
+        # accepted only with the run's token (the launcher's run id and port, the same in every rank's environment) and a
+        # rank in 1..world-1 that has not connected yet.  Ranks of one node meet on the loopback interface.
+        token = hashlib.sha256(("%s|%d|%d" % (os.environ.get("TORCHELASTIC_RUN_ID", ""), port, world)).encode()).digest()[:16]
+        one_node = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+            srv.bind(("127.0.0.1" if one_node or addr == "localhost" else addr, port))
             srv.listen(world)
             srv.settimeout(timeout)
             while len(self.peers) < world - 1:
                 c, _ = srv.accept()
+                try:
+                    c.settimeout(10.0)
+                    hello = self._recvn(c, 20)
+                    r = struct.unpack("<i", hello[:4])[0]
+                    if hello[4:] != token or not 0 < r < world or r in self.peers:
+                        raise ConnectionError("bad hello")
+                except (OSError, ConnectionError):
+                    c.close()            # not one of this run's ranks: ignored, the accept loop goes on
+                    continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 c.settimeout(timeout)
-                r = struct.unpack("<i", self._recvn(c, 4))[0]
                 self.peers[r] = c
             srv.close()
         else:
             while True:
                 try:
-                    c = socket.create_connection((addr, port), timeout=5.0)
+                    c = socket.create_connection(("127.0.0.1" if one_node else addr, port), timeout=5.0)
                     break
                 except OSError:
                     if time.time() > deadline:
@@ -175,7 +198,7 @@ class Rendezvous:
                     time.sleep(0.05)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             c.settimeout(timeout)
-            c.sendall(struct.pack("<i", rank))
+            c.sendall(struct.pack("<i", rank) + token)
             self.peers[0] = c
 
     @staticmethod
@@ -189,12 +212,17 @@ class Rendezvous:
         return buf
 
     def _send(self, c, obj):
-        data = self._pickle.dumps(obj)
+        data = json.dumps({"hex": obj.hex()} if isinstance(obj, (bytes, bytearray)) else {"v": obj}).encode()
+        if len(data) > self.MAX_FRAME:
+            raise ValueError("rendezvous frame of %d bytes" % len(data))
         c.sendall(self._struct.pack("<q", len(data)) + data)
 
     def _recv(self, c):
         n = self._struct.unpack("<q", self._recvn(c, 8))[0]
-        return self._pickle.loads(self._recvn(c, n))
+        if not 0 < n <= self.MAX_FRAME:
+            raise ConnectionError("rendezvous frame length %d" % n)
+        d = json.loads(self._recvn(c, n).decode())
+        return bytes.fromhex(d["hex"]) if "hex" in d else d["v"]
 
     def allreduce(self, value, op):
         """op over the values of all ranks (min / max), the same result on every rank."""
@@ -694,19 +722,22 @@ def main():
         iters = 20
         ms_b2b, ms1 = gk.bench_fold(1 << bn_gpu, ntab=1, warmup=3, iters=iters, isolated=True)
         bytes1 = 96.0 * (1 << (bn_gpu - 1))
-        traffic = None
-        for name in ("r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # PMC pass of the same launches (tools/pmc_bench.sh)
+        # HBM bytes per launch from the PMC counters need rocprofv3 around the process (separate --pmc passes): they are NOT
+        # of this run -- the number is read from the committed builder-side pass and labelled as such
+        traffic, traffic_source = None, None
+        for name in ("r04_pmc_fold_traffic.json", "r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # tools/pmc_bench.sh
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pm.get("bn") == bn_gpu:
                     traffic = pm["traffic_bytes_per_launch"]
+                    traffic_source = "profiles/%s (builder-side rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launches; not measured in this run)" % name
                     break
             except Exception:
                 pass
         ach = bytes1 / (ms_b2b * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_fold<1> on a 2^%d-element table (2^%d outputs)" % (bn_gpu, bn_gpu - 1),
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "launches": iters, "avg_launch_ms": ms_b2b,
+                           "traffic": traffic, "traffic_source": traffic_source, "launches": iters, "avg_launch_ms": ms_b2b,
                            "algorithmic_bytes_per_launch": bytes1,
                            "measured": "HIP events on the launching stream around %d launches queued back to back, nothing else "
                                        "running (gkrhip_bench_fold): wall time / %d.  rocprofv3's per-kernel average for the "
@@ -867,6 +898,35 @@ def main():
                                                  "once, then dispatchPartialEvals of round 0 -- nine evaluations over 2^14 pairs -- in a loop; "
                                                  "the reference times 30000 dispatches per iteration, this is the time of ONE dispatch, sums "
                                                  "handed to the host every time)"}
+        # The Groth16 pieces of SURVEY 8 f4 on device-resident synthetic data: the G1 multi-scalar multiplication
+        # (gnark-crypto's MultiExp at prover/gadget/prove.go:76,91,189,202,221) and computeH (prove.go:308-359)
+        lp = loops.get("msm_accumulate")
+        for lg in (20, 22):
+            r = gk.bench_msm_g1(lg, warmup=1, iters=3)
+            nwin = -(-255 // r["c"])
+            madds = float(nwin) * (1 << lg)          # one mixed addition per scalar and window (zero digits are 2^-c of them)
+            e = {"ms": r["ms"], "points_per_s": float(1 << lg) / (r["ms"] * 1e-3), "window_bits": r["c"], "windows": nwin,
+                 "phases_ms": r["phases_ms"], "host_tail_ms": r["host_tail_ms"],
+                 "measured": "HIP events on the library's stream from the first sorting kernel to the arrival of the window sums on "
+                             "the host; bases and scalars resident in HBM; host_tail_ms (Horner over the window sums + one inversion, "
+                             "CPU) is beside it, not inside",
+                 "mirrors": "(*G1Jac).MultiExp(points, scalars, cfg), 2^%d random points [k_i]G and random scalars below q" % lg}
+            if lp:
+                issue_cycles = HALF_RATE_CYCLES * lp["half_rate"] + FULL_RATE_CYCLES * lp["full_rate"]
+                ceil_ms = madds / (N_SIMD * 64) * issue_cycles / (NOMINAL_GHZ * 1e9) * 1e3
+                e["accumulate"] = {"kernel": "k_msm_accumulate", "bound": "integer VALU issue (no MFMA: modular arithmetic)",
+                                   "mixed_additions": madds, "loop_instructions_per_addition": lp, "issue_cycles_per_addition": issue_cycles,
+                                   "ceiling_ms": ceil_ms, "ms": r["phases_ms"]["accumulate"], "frac": ceil_ms / r["phases_ms"]["accumulate"],
+                                   "field_products_per_s": 10.0 * madds / (r["phases_ms"]["accumulate"] * 1e-3),
+                                   "ceiling_assumption": "every vector instruction of the innermost loop of this build (one mixed addition, "
+                                                         "8 M + 2 S) at its measured issue cost (%.1f / %.1f cycles per wave), every lane busy, "
+                                                         "nominal %.1f GHz" % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ)}
+            micro["msm_g1_2p%d" % lg] = e
+        ms, npass, by = gk.bench_compute_h(24, warmup=1, iters=3)
+        micro["compute_h_2p24"] = {"ms": ms, "passes": npass, "GB_per_s": by / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "field_products": COMPUTE_H_PRODUCTS(24), "field_products_per_s": COMPUTE_H_PRODUCTS(24) / (ms * 1e-3),
+                                   "mirrors": "computeH (prover/gadget/prove.go:308-359) on three device-resident vectors of 2^24 elements: "
+                                              "three inverse FFTs, three coset FFTs, the pointwise step, one inverse coset FFT, FromMont"}
         out["micro"] = micro
     if rank == 0 and not multi and not args.no_oneshot and args.circuit == "mimc":
         # the production caller's shape (GkrProverHint.Call, prover/gadget/hints.go:197-233): Assign + Prove from HOST

@@ -25,7 +25,8 @@ inline E to_plain(const E& m) {       // the regular-form integer of a Montgomer
 struct NttDomain {
     int logn = -1;
     E gen, finer, finer_inv, card_inv;      // Domain.Generator (order n), FinerGenerator (order 2n), its inverse, 1/n
-    DevTable tw;                            // omega^i, i < n/2
+    DevTable tw;                            // omega^i, i <= n/2
+    DevTable coset_fwd, coset_inv;          // u^rev(p) / n (Montgomery form) and u^-rev(p) / n (REGULAR form), p < n
 };
 std::mutex g_ntt_mu;
 std::vector<NttDomain*> g_ntt_domains;      // one per size, kept for the life of the process (n/2 elements each)
@@ -63,11 +64,20 @@ int ntt_domain(int logn, NttDomain** out) {
     CHK(upload_table(&tlo, (const uint64_t*)lo.data(), nlo));
     CHK(upload_table(&thi, (const uint64_t*)hi.data(), nhi));
     void* p = nullptr;
-    HIPCHK(hipMalloc(&p, sizeof(uint4) * 2 * n_half));
+    const size_t n = (size_t)1 << logn;
+    HIPCHK(hipMalloc(&p, sizeof(uint4) * 2 * (n_half + 1 + 2 * n)));
     d->tw.base = (uint4*)p;
-    d->tw.cap = n_half;
-    hipLaunchKernelGGL(k_ntt_twiddles, dim3(grid_for(n_half, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->tw.planes(), tlo.cplanes(),
+    d->tw.cap = n_half + 1;
+    d->coset_fwd.base = d->tw.base + 2 * (n_half + 1);
+    d->coset_fwd.cap = n;
+    d->coset_inv.base = d->coset_fwd.base + 2 * n;
+    d->coset_inv.cap = n;
+    hipLaunchKernelGGL(k_ntt_twiddles, dim3(grid_for(n_half + 1, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->tw.planes(), tlo.cplanes(),
                        thi.cplanes(), l0, n_half);
+    hipLaunchKernelGGL(k_ntt_coset_table, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->coset_fwd.planes(),
+                       d->tw.cplanes(), logn, 0, to_dev(d->card_inv), to_dev(hfr::mul(d->card_inv, d->finer)));
+    hipLaunchKernelGGL(k_ntt_coset_table, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->coset_inv.planes(),
+                       d->tw.cplanes(), logn, 1, to_dev(to_plain(d->card_inv)), to_dev(to_plain(hfr::mul(d->card_inv, d->finer_inv))));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(cx().stream));
     table_release(&tlo);
@@ -85,25 +95,23 @@ void ntt_domains_free() {
     g_ntt_domains.clear();
 }
 
-template <bool DIT, bool TRIPLE>
-int ntt_launch(const NttPassArgs& a, int R, int narr) {
-    const size_t groups = (size_t)1 << (a.logn - R);
-    const dim3 grid((unsigned)((groups + GKR_BLOCK - 1) / GKR_BLOCK), TRIPLE ? 1 : narr), block(GKR_BLOCK);
-    switch (R) {
-        case 1: hipLaunchKernelGGL((k_ntt_pass<1, DIT, TRIPLE>), grid, block, 0, cx().stream, a); break;
-        case 2: hipLaunchKernelGGL((k_ntt_pass<2, DIT, TRIPLE>), grid, block, 0, cx().stream, a); break;
-        case 3: hipLaunchKernelGGL((k_ntt_pass<3, DIT, TRIPLE>), grid, block, 0, cx().stream, a); break;
-        default: return fail("ntt: %d stages per pass", R);
+// The passes of one transform of 2^logn points: the contiguous tile takes min(logn, 11) stages (the last of a DIF transform,
+// the first of a DIT transform), the other stages go in strided tiles of at most seven stages each, as even as possible
+// (24 -> 7 + 6 | 11).  Returned in DIF order (first stage first): {stages, lcols} per pass, the contiguous pass last.
+struct NttPassPlan {
+    int stages, lcols;
+};
+inline std::vector<NttPassPlan> ntt_plan(int logn) {
+    std::vector<NttPassPlan> v;
+    const int lc = std::min(logn, GKR_NTT_LTILE), rest = logn - lc;
+    if (rest > 0) {
+        const int np = (rest + 6) / 7;
+        for (int i = 0; i < np; i++) {
+            const int st = rest / np + (i < rest % np ? 1 : 0);
+            v.push_back({st, GKR_NTT_LTILE - st});
+        }
     }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-// S stages in passes of at most three, as even as possible (13 -> 3 3 3 2 2)
-inline std::vector<int> ntt_split(int S) {
-    std::vector<int> v;
-    if (S <= 0) return v;
-    const int np = (S + 2) / 3;
-    for (int i = 0; i < np; i++) v.push_back(S / np + (i < S % np ? 1 : 0));
+    v.push_back({lc, 0});
     return v;
 }
 
@@ -113,105 +121,78 @@ inline std::vector<int> ntt_split(int S) {
 int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_out = nullptr) {
     NttDomain* dom = nullptr;
     CHK(ntt_domain(logn, &dom));
-    // transforms of more than 2^ltile points: the ltile stages that stay inside 2^ltile consecutive elements run in the
-    // LDS-tiled kernel (one pass), the others in register passes of up to three stages
-    const int L = logn > GKR_NTT_LTILE ? GKR_NTT_LTILE : 0;
-    NttDomain* tile_dom = nullptr;
-    if (L) CHK(ntt_domain(L, &tile_dom));
     int passes = 0;
     double bytes = 0;
     const double arr_bytes = 32.0 * (double)((size_t)1 << logn);
     E root_plain;
     memcpy(root_plain.l, kRoot2_28, 32);
-    const E zeta = host_pow(hfr::mul(root_plain, hfr::R2), 1ull << (kMaxOrderRoot - 3));     // primitive 8th root of unity
+    const E zeta = logn >= 2 ? host_pow(hfr::mul(root_plain, hfr::R2), 1ull << (kMaxOrderRoot - 2)) : hfr::ONE;     // primitive 4th root of unity
     const E zeta_inv = hfr::pow_q_minus_2(zeta);
+    const E two128 = {{0, 0, 1, 0}};                                        // the plain integer 2^128: a Montgomery product with it divides by 2^128
+    const std::vector<NttPassPlan> plan = ntt_plan(logn);
     NttPassArgs a;
     auto base_args = [&](int narr, bool inverse) {
         memset(&a, 0, sizeof a);
-        for (int i = 0; i < narr; i++) a.d[i] = t[i]->planes();
+        for (int i = 0; i < 3; i++) a.d[i] = t[i]->planes();
+        (void)narr;
         a.tw = dom->tw.cplanes();
-        if (L) a.tw_tile = tile_dom->tw.cplanes();
         a.logn = logn;
-        a.ltile = L;
-        a.inverse = inverse ? 1 : 0;
-        E z = hfr::ONE;
-        for (int k = 0; k < 4; k++) {
-            a.z[k] = to_dev(z);
-            z = hfr::mul(z, inverse ? zeta_inv : zeta);
-        }
+        const E z = inverse ? zeta_inv : zeta;
+        a.zb = to_dev(z);
+        a.za = to_dev(hfr::mul(z, two128));
     };
-    auto tile = [&](bool dit, int narr) -> int {
-        const dim3 grid((unsigned)((size_t)1 << (logn - L)), narr), block(GKR_BLOCK);
-        if (dit) hipLaunchKernelGGL(k_ntt_tile<true>, grid, block, 0, cx().stream, a);
-        else hipLaunchKernelGGL(k_ntt_tile<false>, grid, block, 0, cx().stream, a);
+    // one pass: local stages `stages` starting at transform stage s0, tile columns 2^lcols
+    auto launch = [&](bool dit, int narr, int s0, const NttPassPlan& pp, int arrays_read) -> int {
+        a.s0 = s0;
+        a.lrows = pp.stages;
+        a.lcols = pp.lcols;
+        a.lgQ = pp.lcols == 0 ? 0 : (dit ? s0 : logn - s0 - pp.stages);
+        const dim3 grid((unsigned)((size_t)1 << (logn - pp.stages - pp.lcols)), narr), block(GKR_NTT_WG);
+        // computeH needs exactly these two: FFT(., DIT, .) forward and FFTInverse(., DIF, .)
+        if (dit) hipLaunchKernelGGL((k_ntt_tile<true, false>), grid, block, 0, cx().stream, a);
+        else hipLaunchKernelGGL((k_ntt_tile<false, true>), grid, block, 0, cx().stream, a);
         HIPCHK(hipGetLastError());
         passes++;
-        bytes += 2 * narr * arr_bytes;
+        bytes += (arrays_read + narr) * arr_bytes;
         return 0;
     };
-    const std::vector<int> split = ntt_split(logn - L);      // the register passes of one transform
-    // FFTInverse(., DIF, coset): register passes over the large distances, then the tile; `post` rides on the last store
-    auto dif_inverse = [&](int narr, int post, const E& k0, const E& k1) -> int {
+    // FFTInverse(., DIF, coset): strided tiles over the large distances, then the contiguous tile
+    auto dif_inverse = [&](int narr, bool pointwise, int post, const E& k2) -> int {
         int s0 = 0;
-        for (size_t i = 0; i < split.size(); i++) {
+        for (size_t i = 0; i < plan.size(); i++) {
             base_args(narr, true);
-            a.s0 = s0;
-            if (!L && i + 1 == split.size()) {
-                a.post = post;
-                a.k0 = to_dev(k0);
-                a.k1 = to_dev(k1);
+            if (pointwise && i == 0) {
+                a.pre = 3;
+                a.k2 = to_dev(k2);
             }
-            CHK((ntt_launch<false, false>(a, split[i], narr)));
-            passes++;
-            bytes += 2 * narr * arr_bytes;
-            s0 += split[i];
-        }
-        if (L) {
-            base_args(narr, true);
-            a.post = post;
-            a.k0 = to_dev(k0);
-            a.k1 = to_dev(k1);
-            CHK(tile(false, narr));
+            if (i + 1 == plan.size() && post) {
+                a.post = post;
+                a.coset = dom->coset_inv.cplanes();
+            }
+            CHK(launch(false, narr, s0, plan[i], pointwise && i == 0 ? 3 : narr));
+            s0 += plan[i].stages;
         }
         return 0;
     };
     // 1. FFTInverse(a | b | c, DIF, 0) without its 1/n (folded into the next load)                      (:326-328)
-    CHK(dif_inverse(3, 0, hfr::ZERO, hfr::ZERO));
-    // 2. FFT(., DIT, 1): first load multiplies position p by u^rev(p) / n, last pass does the pointwise step        (:330-347)
-    const E minus_two_inv = hfr::pow_q_minus_2(hfr::sub(hfr::ZERO, hfr::from_u64(2)));
-    const E pre_k0 = dom->card_inv, pre_k1 = hfr::mul(dom->card_inv, dom->finer);
-    if (L) {
-        base_args(3, false);
-        a.pre = 2;
-        a.k0 = to_dev(pre_k0);
-        a.k1 = to_dev(pre_k1);
-        CHK(tile(true, 3));
-    }
+    CHK(dif_inverse(3, false, 0, hfr::ZERO));
+    // 2. FFT(., DIT, 1): the first load multiplies position p by u^rev(p) / n                            (:330-332)
     {
-        int s0 = L;
-        for (size_t i = 0; i < split.size(); i++) {
-            const bool first = !L && i == 0, last = i + 1 == split.size();
+        int s0 = 0;
+        for (size_t i = plan.size(); i-- > 0;) {          // DIT: the contiguous tile first, then the strided ones, small distances first
             base_args(3, false);
-            a.s0 = s0;
-            if (first) {
+            if (i + 1 == plan.size()) {
                 a.pre = 2;
-                a.k0 = to_dev(pre_k0);
-                a.k1 = to_dev(pre_k1);
+                a.coset = dom->coset_fwd.cplanes();
             }
-            if (last) {
-                a.k2 = to_dev(minus_two_inv);
-                CHK((ntt_launch<true, true>(a, split[i], 3)));
-                bytes += 4 * arr_bytes;              // reads three arrays, writes one
-            } else {
-                CHK((ntt_launch<true, false>(a, split[i], 3)));
-                bytes += 6 * arr_bytes;
-            }
-            passes++;
-            s0 += split[i];
+            CHK(launch(true, 3, s0, plan[i], 3));
+            s0 += plan[i].stages;
         }
     }
-    // 3. FFTInverse(a, DIF, 1): last store multiplies position p by u^-rev(p) / n and leaves Montgomery form       (:350-356)
-    CHK(dif_inverse(1, 3, to_plain(dom->card_inv), to_plain(hfr::mul(dom->card_inv, dom->finer_inv))));
+    // 3. (a * b - c) * (-2)^-1 when the last transform loads (:334-347); FFTInverse(a, DIF, 1): the last store multiplies
+    //    position p by u^-rev(p) / n and leaves Montgomery form                                            (:350-356)
+    const E minus_two_inv = hfr::pow_q_minus_2(hfr::sub(hfr::ZERO, hfr::from_u64(2)));
+    CHK(dif_inverse(1, true, 3, minus_two_inv));
     if (passes_out) *passes_out = passes;
     if (bytes_out) *bytes_out = bytes;
     return 0;

@@ -1,167 +1,148 @@
 // ntt.hip.h -- number-theoretic transforms over BN254 Fr on limb planes, for computeH: the H part of Groth16's Krs as the
-// reference's prover gadget computes it (prover/gadget/prove.go:308-359; SURVEY section 8 row f4, second half):
+// reference's prover gadget computes it (prover/gadget/prove.go:308-359):
 //     a, b, c  <- FFTInverse(., DIF, 0)          three inverse FFTs, output in bit-reversed order
 //     a, b, c  <- FFT(., DIT, 1)                 three FFTs on the coset u * <g> (u of order 2n, u^2 = g), natural order out
 //     a        <- (a * b - c) * (-2)^-1          pointwise (Z = X^n - 1 is -2 on the coset)
 //     a        <- FFTInverse(a, DIF, 1)          inverse coset FFT, bit-reversed order out;  then FromMont
 // (gnark-crypto's fft.Domain, an un-vendored dependency: the algorithm is restated by the test oracle, "parity
-// unpinned").  Radix-2 butterflies, in place, up to three stages per pass held in registers (eight elements per lane): a
-// 2^24-point transform is six passes over HBM instead of twenty-four (five register passes over the large strides, one
-// LDS-tiled pass over the eleven stages whose butterflies stay inside 2048 consecutive elements).  The element-wise factors ride on passes that
-// exist anyway: the 1/n of the first inverse transforms and the coset shift u^rev(p) are ONE factor applied when the first
-// DIT pass loads; the pointwise step is done by the LAST DIT pass, which transforms the same index group of a, b and c and
-// stores only (a*b - c) * (-2)^-1; the final 1/n, the inverse coset shift and FromMont are one factor (kept in regular
-// form, so the Montgomery product leaves the Montgomery domain) applied when the last DIF pass stores.
-// Measured (gkrhip_bench_compute_h, MI355X): 2^24 points 22.5 ms = 18 passes moving 44 GB at 1.95 TB/s (0.24 of the HBM
-// peak): the transforms are bound by integer VALU issue like the sumcheck rounds, not by HBM -- ~16 field products per
-// element and transform (12 butterflies + the products that derive a group's twiddles from three loaded ones) is ~2 x 10^9
-// products per computeH at the ~10^11 products/s the field arithmetic sustains.  With one twiddle load per butterfly and
-// every stage in register passes (the first version) the same computeH took 32 ms.
+// unpinned").  Radix-2 butterflies, in place.
+//
+// EVERY pass over HBM is an LDS pass (round 4; round 3 held the large strides in registers, three stages per pass, and ran
+// at half the field-product rate of the sumcheck kernels: two waves per SIMD, loads, arithmetic and stores of a wave one
+// after the other).  A workgroup of 512 lanes owns a TILE of 2048 elements = 2^lrows rows at stride 2^lgQ x 2^lcols
+// consecutive elements, loads it into LDS (64 KiB + padding: two workgroups per CU, four waves per SIMD), runs lrows
+// butterfly stages on the row index in sub-passes of two stages (four elements per lane in registers: ~110 VGPRs), and
+// stores it back.  The contiguous tile (lcols = 0, lgQ = 0) takes the eleven stages whose butterflies stay inside 2048
+// consecutive elements -- the LAST stages of a DIF transform, the FIRST of a DIT transform; the larger distances go in
+// tiles of up to 128 rows x 16 consecutive elements (256-byte segments per plane and row).  A 2^24-point transform is
+// THREE passes over HBM (7 + 6 + 11 stages) instead of six.
+// The element-wise factors ride on passes that exist anyway: the 1/n of the first inverse transforms and the coset shift
+// u^rev(p) are ONE factor applied when the first DIT pass loads; the pointwise step (a*b - c) * (-2)^-1 is done by the first
+// pass of the last transform when it loads (three arrays in, one out); the final 1/n, the inverse coset shift and
+// FromMont are one factor (kept in regular form, so the Montgomery product leaves the Montgomery domain) applied when the
+// last pass stores.
 // No MFMA: exact modular arithmetic.  One twiddle table omega^i, i < n/2, serves every stage and both directions
-// (omega^-i = -omega^(n/2 - i)).
+// (omega^-i = -omega^(n/2 - i)); a group of four elements loads two twiddles and derives the third by a product with a
+// launch-wide constant (the 96-limb-product form fr_mul_const2_raw).
 #pragma once
 #include "kernels.hip.h"
 
 struct NttPassArgs {
-    Planes d[3];          // the arrays of this launch (blockIdx.y selects; TRIPLE: all three in one lane), in place
+    Planes d[3];          // the arrays of this launch (blockIdx.y selects; pre == 3 reads all three and writes d[0]), in place
     CPlanes tw;           // omega^i, i < n/2 (Montgomery form)
-    CPlanes tw_tile;      // tile kernel: the twiddles of the 2^ltile-point domain, (omega^(n / 2^ltile))^i, i < 2^(ltile-1)
     int logn, s0;         // transform size, first stage of this pass
-    int ltile;            // tile kernel: log2 of the tile (the last ltile DIF stages / first ltile DIT stages)
-    int inverse;          // twiddles omega^-i
-    int pre, post;        // 0 none | pre 2: x *= tw[e >> 1] * (e odd ? k1 : k0), e = rev(p)   (coset shift and 1/n)
-                          //        | post 1: x *= k0 | post 3: x *= inv_tw[e >> 1] * (e odd ? k1 : k0) with k0, k1 in REGULAR form
-    Fr k0, k1;
-    Fr k2;                // TRIPLE: (-2)^-1
-    Fr z[4];              // z[k] = zeta^k, zeta = omega^(+-n/8) the primitive 8th root of unity of this direction (z[0] = 1)
+    int lrows, lcols, lgQ;   // tile: 2^lrows rows at stride 2^lgQ, 2^lcols consecutive elements per row
+    CPlanes coset;        // pre 2 / post 3: the per-position factor table of the domain (k_ntt_coset_table)
+    int pre, post;        // 0 none | pre 2: x *= coset[p] = u^rev(p) / n                       (coset shift and the 1/n of step 1)
+                          //        | pre 3: x = (d[0][p] * d[1][p] - d[2][p]) * k2            (pointwise step, prove.go:341-347)
+                          //        | post 3: x *= coset[p] = u^-rev(p) / n in REGULAR form    (the product leaves Montgomery form)
+    Fr k2;                // pre 3: (-2)^-1
+    Fr zb, za;            // zeta = omega^(+-n/4), the primitive 4th root of unity of this direction: zb = zeta, za = zeta * 2^-128
 };
 
+// The twiddle table holds omega^i for i <= n/2 (the last entry is -1).  A forward stage loads w = omega^e; an inverse stage
+// loads w' = omega^(n/2 - e) = -omega^-e and the butterflies swap the operands of their subtraction instead of negating it.
 __device__ __forceinline__ Fr ntt_twiddle(const CPlanes& tw, int logn, bool inverse, size_t e) {      // e < n/2
-    if (!inverse) return ld_fr(tw.lo, tw.hi, e);
-    if (e == 0) return fr_one();
-    return fr_sub(fr_zero(), ld_fr(tw.lo, tw.hi, ((size_t)1 << (logn - 1)) - e));   // omega^-e = -omega^(n/2 - e)
+    return ld_fr(tw.lo, tw.hi, inverse ? ((size_t)1 << (logn - 1)) - e : e);
 }
 __device__ __forceinline__ size_t ntt_rev(size_t p, int logn) { return logn ? (size_t)(__brevll((unsigned long long)p) >> (64 - logn)) : 0; }
 
-// element-wise factors of the first load / last store (p = global position)
-__device__ __forceinline__ Fr ntt_pre(const NttPassArgs& a, size_t p, const Fr& x) {
-    if (a.pre != 2) return x;
-    const size_t e = ntt_rev(p, a.logn);
-    return fr_mul(x, fr_mul(ld_fr(a.tw.lo, a.tw.hi, e >> 1), (e & 1) ? a.k1 : a.k0));
+// Lazy range of the butterflies: every value in LDS and in registers is in [0, 2q); what comes from HBM is canonical and what
+// goes back is made canonical (fr_reduce_once).  Twiddles are canonical, so (x - y + 2q) * w < 4q * q stays an exact lazy
+// Montgomery product below 2q.
+#define FR_2Q_LIMBS {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u}
+__device__ __forceinline__ Fr ntt_add2q(const Fr& a, const Fr& b) {          // a + b mod 2q
+    const u32 q2[8] = FR_2Q_LIMBS;
+    const Fr s = fr_add_raw(a, b);
+    u32 d[8], br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = fr_subb(s.v[j], q2[j], br, &br);
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = br ? s.v[j] : d[j];
+    return r;
 }
-__device__ __forceinline__ Fr ntt_post(const NttPassArgs& a, size_t p, const Fr& x) {
-    if (a.post == 1) return fr_mul(x, a.k0);
-    if (a.post == 3) {
-        const size_t e = ntt_rev(p, a.logn);
-        const Fr f = fr_mul(ntt_twiddle(a.tw, a.logn, true, e >> 1), (e & 1) ? a.k1 : a.k0);   // regular form: Montgomery x regular
-        return fr_mul(x, f);                                                                   // ... and the result leaves Montgomery form
-    }
-    return x;
+__device__ __forceinline__ Fr ntt_sub2q(const Fr& a, const Fr& b) {          // a - b mod 2q
+    const u32 q2[8] = FR_2Q_LIMBS;
+    u32 s[8], br = 0, c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = fr_subb(a.v[j], b.v[j], br, &br);
+    const u32 mask = 0u - br;
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = fr_addc(s[j], q2[j] & mask, c, &c);
+    return r;
+}
+__device__ __forceinline__ Fr ntt_sub_plus2q(const Fr& a, const Fr& b) {     // a - b + 2q in (0, 4q): no comparison
+    const u32 q2[8] = FR_2Q_LIMBS;
+    u32 s[8], br = 0, c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = fr_subb(a.v[j], b.v[j], br, &br);
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = fr_addc(s[j], q2[j], c, &c);
+    return r;
 }
 
-// R radix-2 stages on the 2^R elements x[t] of one group (element t sits at position base + t * 2^lg_q of a transform of
-// 2^lgn points whose twiddles are `tw`; low = base mod 2^lg_q).  The twiddle of the pair (t, t + dist) of stage r is
-//     DIF:  omega^((low + (t mod 2^(R-1-r)) * q) * n / (2 d_r))  =  W_r * zeta_(R-r)^(t mod 2^(R-1-r)),   W_r = omega^(low << (s0 + r)) = W_0^(2^r)
-//     DIT:  omega^((low + (t mod 2^r) * q) * n / (2 d_r))        =  V_r * zeta_(r+1)^(t mod 2^r),          V_r = omega^(low << (lgn - 1 - lg_q - r))
-// with zeta_m a primitive 2^m-th root of unity -- launch-wide constants (a.z) -- so a group loads R twiddles (three for eight
-// elements) and derives the other four by products with constants.  -DGKR_NTT_LOAD_TW reads all seven distinct entries
-// omega^(e_r + k * n / 2^m) instead: measured 23.9 against 22.5 ms at 2^24 points (1.18 against 1.26 ms at 2^20): neither
-// the products nor the loads alone bound the passes.
-template <int R, bool DIT>
-__device__ __forceinline__ void ntt_stages(const NttPassArgs& a, const CPlanes& tw, int lgn, size_t low, int lg_q, Fr (&x)[1 << R]) {
+// element-wise factors of the first load / last store (p = global position); loads return values below 2q
+__device__ __forceinline__ Fr ntt_load(const NttPassArgs& a, const Planes& d, size_t p) {
+    if (a.pre == 3) {
+        const Fr x = ld_fr(a.d[0].lo, a.d[0].hi, p), y = ld_fr(a.d[1].lo, a.d[1].hi, p), z = ld_fr(a.d[2].lo, a.d[2].hi, p);
+        return fr_mont_mul_raw(ntt_sub_plus2q(fr_mont_mul_raw(x, y), z), a.k2);      // (< 2q - z + 2q) * k2, k2 canonical
+    }
+    const Fr x = ld_fr(d.lo, d.hi, p);
+    if (a.pre != 2) return x;
+    return fr_mont_mul_raw(x, ld_fr(a.coset.lo, a.coset.hi, p));
+}
+__device__ __forceinline__ Fr ntt_store_value(const NttPassArgs& a, size_t p, const Fr& x) {      // x < 2q -> canonical
+    if (a.post == 3) return fr_reduce_once(fr_mont_mul_raw(x, ld_fr(a.coset.lo, a.coset.hi, p)));   // Montgomery x regular: leaves Montgomery form
+    return fr_reduce_once(x);
+}
+
+// R <= 2 radix-2 stages on the 2^R elements x[t] of one group (element t sits at position base + t * 2^lg_q of a transform of
+// 2^lgn points; low = base mod 2^lg_q).  The twiddle of the pair (t, t + dist) of stage r is
+//     DIF:  omega^((low + (t mod 2^(R-1-r)) * q) * n / (2 d_r))  =  W_r * zeta^(t mod 2^(R-1-r)),   W_r = omega^(low << (lgn - lg_q - R + r))
+//     DIT:  omega^((low + (t mod 2^r) * q) * n / (2 d_r))        =  V_r * zeta^(t mod 2^r),          V_r = omega^(low << (lgn - 1 - lg_q - r))
+// with zeta the primitive 4th root of unity of the direction -- a launch-wide constant -- so a group of four loads two
+// twiddles and derives the third by one product with a constant.
+template <int R, bool DIT, bool INV>
+__device__ __forceinline__ void ntt_stages(const NttPassArgs& a, int lgn, size_t low, int lg_q, Fr (&x)[1 << R]) {
+    static_assert(R == 1 || R == 2, "sub-passes of one or two stages");
     constexpr int E = 1 << R;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int dist = DIT ? (1 << r) : (1 << (R - 1 - r));                 // in units of q
-        const int m = DIT ? r + 1 : R - r;                                     // zeta_m: 2^m-th roots at this stage
+        const bool two = DIT ? (r == 1) : (R == 2 && r == 0);                  // the stage with two distinct twiddles
         const size_t e = DIT ? (low << (lgn - 1 - lg_q - r)) : (low << (lgn - lg_q - R + r));
-        Fr w[E / 2];                                                           // w[k] = omega^e * zeta_m^k = omega^(e + k * n / 2^m), k < 2^(m-1)
-        w[0] = ntt_twiddle(tw, lgn, a.inverse != 0, e);
-#pragma unroll
-        for (int k = 1; k < (1 << (m - 1)); k++) {
-#ifndef GKR_NTT_LOAD_TW
-            w[k] = fr_mul(w[0], a.z[k << (3 - m)]);          // one load per stage, the rest by products with constants
-#else
-            w[k] = ntt_twiddle(tw, lgn, a.inverse != 0, e + ((size_t)k << (lgn - m)));      // seven loads per group of eight
-#endif
-        }
+        Fr w[2];
+        w[0] = ntt_twiddle(a.tw, lgn, INV, e);
+        if (two) w[1] = fr_reduce_lt4q(fr_mul_const2_raw(w[0], a.za, a.zb));
 #pragma unroll
         for (int t = 0; t < E; t++) {
             if (t & dist) continue;
-            const Fr& wk = w[t & (dist - 1)];
+            const Fr& wk = w[two ? (t & (dist - 1)) : 0];
             if (DIT) {
-                const Fr y = fr_mul(x[t + dist], wk);
-                const Fr s = fr_add(x[t], y);
-                x[t + dist] = fr_sub(x[t], y);
-                x[t] = s;
+                const Fr y = fr_mont_mul_raw(x[t + dist], wk);           // inverse: -(x_hi * omega^-e)
+                const Fr s = ntt_add2q(x[t], y), d = ntt_sub2q(x[t], y);
+                x[t] = INV ? d : s;
+                x[t + dist] = INV ? s : d;
             } else {
-                const Fr s = fr_add(x[t], x[t + dist]);
-                x[t + dist] = fr_mul(fr_sub(x[t], x[t + dist]), wk);
+                const Fr s = ntt_add2q(x[t], x[t + dist]);
+                const Fr d = INV ? ntt_sub_plus2q(x[t + dist], x[t]) : ntt_sub_plus2q(x[t], x[t + dist]);
+                x[t + dist] = fr_mont_mul_raw(d, wk);
                 x[t] = s;
             }
         }
     }
 }
 
-// the 2^R elements of group g of one array through R stages; x[] out (canonical elements throughout)
-template <int R, bool DIT>
-__device__ __forceinline__ void ntt_group(const NttPassArgs& a, const Planes& d, size_t base, size_t low, int lg_q, Fr (&x)[1 << R]) {
-    constexpr int E = 1 << R;
-    const size_t q = (size_t)1 << lg_q;
-#pragma unroll
-    for (int t = 0; t < E; t++) {
-        const size_t p = base + (size_t)t * q;
-        x[t] = ntt_pre(a, p, ld_fr(d.lo, d.hi, p));
-    }
-    ntt_stages<R, DIT>(a, a.tw, a.logn, low, lg_q, x);
-}
-
-template <int R, bool DIT, bool TRIPLE>
-__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_pass(NttPassArgs a) {
-    constexpr int E = 1 << R;
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ((size_t)1 << (a.logn - R))) return;
-    // DIF: the pass covers distances n >> (s0+1) .. n >> (s0+R), element stride q = n >> (s0+R);  DIT: distances 1 << s0 ..,
-    // element stride q = 1 << s0.  Group g -> base index: R zero bits inserted at bit log2(q).
-    const int lg_q = DIT ? a.s0 : a.logn - a.s0 - R;
-    const size_t low = g & (((size_t)1 << lg_q) - 1), high = g >> lg_q;
-    const size_t base = (high << (lg_q + R)) | low;
-    const size_t q = (size_t)1 << lg_q;
-    Fr x[E];
-    if (TRIPLE) {
-        Fr y[E];
-        ntt_group<R, DIT>(a, a.d[0], base, low, lg_q, x);
-        ntt_group<R, DIT>(a, a.d[1], base, low, lg_q, y);
-#pragma unroll
-        for (int t = 0; t < E; t++) x[t] = fr_mul(x[t], y[t]);
-        ntt_group<R, DIT>(a, a.d[2], base, low, lg_q, y);
-#pragma unroll
-        for (int t = 0; t < E; t++) x[t] = fr_mul(fr_sub(x[t], y[t]), a.k2);      // (a*b - c) * (-2)^-1   (prove.go:341-347)
-    } else {
-        ntt_group<R, DIT>(a, a.d[blockIdx.y], base, low, lg_q, x);
-    }
-    const Planes out = a.d[TRIPLE ? 0 : blockIdx.y];
-#pragma unroll
-    for (int t = 0; t < E; t++) {
-        const size_t p = base + (size_t)t * q;
-        const Fr v = ntt_post(a, p, x[t]);
-        st_fr(out.lo, out.hi, p, v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tile kernel: the ltile stages whose butterflies stay inside an aligned block of 2^ltile consecutive elements -- the
-// LAST stages of a DIF transform, the FIRST of a DIT transform -- in ONE pass over HBM: the block is loaded into LDS with
-// fully coalesced accesses (the register passes would touch these stages with strides below a cache line), transformed
-// there as a complete 2^ltile-point transform (its twiddles are the small domain's: omega^(n / 2^ltile) generates it) in
-// sub-passes of up to three stages, and stored back.  LDS index i lives at i + (i >> 3): a lane that walks its group with
-// stride 2^lg_q then meets its neighbours' elements in different banks for every lg_q.
-// ------------------------------------------------------------------------------------------------
 #define GKR_NTT_LTILE 11
 #define GKR_NTT_TILE (1 << GKR_NTT_LTILE)
+#define GKR_NTT_WG 512
 struct NttTileShared {
     uint4 lo[GKR_NTT_TILE + GKR_NTT_TILE / 8], hi[GKR_NTT_TILE + GKR_NTT_TILE / 8];
 };
+// LDS index i lives at i + (i >> 3): lanes that walk row groups with a power-of-two stride meet different banks
 __device__ __forceinline__ int ntt_sw(int i) { return i + (i >> 3); }
 __device__ __forceinline__ Fr ntt_lds_ld(const NttTileShared& sh, int i) {
     const uint4 a = sh.lo[ntt_sw(i)], b = sh.hi[ntt_sw(i)];
@@ -172,46 +153,69 @@ __device__ __forceinline__ void ntt_lds_st(NttTileShared& sh, int i, const Fr& x
     sh.lo[ntt_sw(i)] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
     sh.hi[ntt_sw(i)] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
-template <int R, bool DIT>
-__device__ __forceinline__ void ntt_tile_subpass(const NttPassArgs& a, NttTileShared& sh, int L, int ls0) {
+// R stages on the row index of the tile, starting at the pass's local stage ls0; tile_low = the tile's column offset
+// (global position bits below lgQ that all its elements share, plus the column)
+template <int R, bool DIT, bool INV>
+__device__ __forceinline__ void ntt_tile_subpass(const NttPassArgs& a, NttTileShared& sh, int ls0, size_t tile_low) {
     constexpr int E = 1 << R;
-    const int lg_q = DIT ? ls0 : L - ls0 - R;
-    for (int g = threadIdx.x; g < (1 << (L - R)); g += blockDim.x) {
-        const int low = g & ((1 << lg_q) - 1), high = g >> lg_q;
-        const int base = (high << (lg_q + R)) | low;
+    const int lgqr = DIT ? ls0 : a.lrows - ls0 - R;            // log2 of the element stride of a group, in rows
+    const int cmask = (1 << a.lcols) - 1;
+    const int ngroups = 1 << (a.lrows + a.lcols - R);
+    for (int idx = threadIdx.x; idx < ngroups; idx += GKR_NTT_WG) {
+        const int c = idx & cmask, g = idx >> a.lcols;
+        const int low_r = g & ((1 << lgqr) - 1), high_r = g >> lgqr;
+        const int r_base = (high_r << (lgqr + R)) | low_r;
         Fr x[E];
 #pragma unroll
-        for (int t = 0; t < E; t++) x[t] = ntt_lds_ld(sh, base + (t << lg_q));
-        ntt_stages<R, DIT>(a, a.tw_tile, L, (size_t)low, lg_q, x);
+        for (int t = 0; t < E; t++) x[t] = ntt_lds_ld(sh, ((r_base + (t << lgqr)) << a.lcols) | c);
+        ntt_stages<R, DIT, INV>(a, a.logn, ((size_t)low_r << a.lgQ) | tile_low | (size_t)c, a.lgQ + lgqr, x);
 #pragma unroll
-        for (int t = 0; t < E; t++) ntt_lds_st(sh, base + (t << lg_q), x[t]);
+        for (int t = 0; t < E; t++) ntt_lds_st(sh, ((r_base + (t << lgqr)) << a.lcols) | c, x[t]);
     }
 }
-template <bool DIT>
-__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_tile(NttPassArgs a) {
+// one pass: stages s0 .. s0 + lrows - 1 of the transform on every tile.  blockIdx.x = tile, blockIdx.y = array.
+template <bool DIT, bool INV>
+__global__ void __launch_bounds__(GKR_NTT_WG, 2) k_ntt_tile(NttPassArgs a) {
     __shared__ NttTileShared sh;
-    const int L = a.ltile;
-    const size_t tile0 = (size_t)blockIdx.x << L;
+    const int lt = a.lrows + a.lcols;                                     // log2 of the tile (11 unless the transform is smaller)
+    const size_t per_hi = (size_t)1 << (a.lgQ - a.lcols);                 // tiles that share the position bits above the rows
+    const size_t hi = blockIdx.x / per_hi, cblk = blockIdx.x % per_hi;
+    const size_t p0 = (hi << (a.lgQ + a.lrows)) | (cblk << a.lcols);
+    const int cmask = (1 << a.lcols) - 1;
     const Planes d = a.d[blockIdx.y];
-    for (int i = threadIdx.x; i < (1 << L); i += blockDim.x) ntt_lds_st(sh, i, ntt_pre(a, tile0 + i, ld_fr(d.lo, d.hi, tile0 + i)));
+    for (int i = threadIdx.x; i < (1 << lt); i += GKR_NTT_WG) {
+        const size_t p = p0 | ((size_t)(i >> a.lcols) << a.lgQ) | (size_t)(i & cmask);
+        ntt_lds_st(sh, i, ntt_load(a, d, p));
+    }
     __syncthreads();
-    for (int ls0 = 0; ls0 < L; ls0 += 3) {
-        const int R = min(3, L - ls0);
-        if (R == 3) ntt_tile_subpass<3, DIT>(a, sh, L, ls0);
-        else if (R == 2) ntt_tile_subpass<2, DIT>(a, sh, L, ls0);
-        else ntt_tile_subpass<1, DIT>(a, sh, L, ls0);
+    for (int ls0 = 0; ls0 < a.lrows; ls0 += 2) {
+        if (a.lrows - ls0 >= 2) ntt_tile_subpass<2, DIT, INV>(a, sh, ls0, cblk << a.lcols);
+        else ntt_tile_subpass<1, DIT, INV>(a, sh, ls0, cblk << a.lcols);
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < (1 << L); i += blockDim.x) {
-        const Fr v = ntt_post(a, tile0 + i, ntt_lds_ld(sh, i));
-        st_fr(d.lo, d.hi, tile0 + i, v);
+    for (int i = threadIdx.x; i < (1 << lt); i += GKR_NTT_WG) {
+        const size_t p = p0 | ((size_t)(i >> a.lcols) << a.lgQ) | (size_t)(i & cmask);
+        st_fr(d.lo, d.hi, p, ntt_store_value(a, p, ntt_lds_ld(sh, i)));
     }
 }
 
-// twiddle table: tw[i] = hi[i >> l0] * lo[i & (2^l0 - 1)], the two small tables computed on the host
+// twiddle table: tw[i] = hi[i >> l0] * lo[i & (2^l0 - 1)] for i < n/2, the two small tables computed on the host; tw[n/2] = -1
 __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes lo, CPlanes hi, int l0, size_t n_half) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_half; i += (size_t)gridDim.x * blockDim.x)
-        st_fr(tw.lo, tw.hi, i, fr_mul(ld_fr(hi.lo, hi.hi, i >> l0), ld_fr(lo.lo, lo.hi, i & (((size_t)1 << l0) - 1))));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_half; i += (size_t)gridDim.x * blockDim.x)
+        st_fr(tw.lo, tw.hi, i, i == n_half ? fr_sub(fr_zero(), fr_one())
+                                           : fr_mul(ld_fr(hi.lo, hi.hi, i >> l0), ld_fr(lo.lo, lo.hi, i & (((size_t)1 << l0) - 1))));
+}
+// The per-position factors of the coset transforms, as gnark-crypto's fft.Domain precomputes its CosetTable / CosetTableInv
+// (here indexed by the position in the bit-reversed vector the factor is applied to, with the 1/n folded in):
+//     fwd[p] = u^rev(p) * k0        inv[p] = u^-rev(p) * k0'         (u^e = omega^(e >> 1) * (e odd ? u : 1); k1 = k0 * u, k1' = k0' / u)
+__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_coset_table(Planes out, CPlanes tw, int logn, int inverse, Fr k0, Fr k1) {
+    const size_t n = (size_t)1 << logn;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = ntt_rev(p, logn);
+        Fr w = ld_fr(tw.lo, tw.hi, inverse ? (n >> 1) - (e >> 1) : (e >> 1));      // inverse: -omega^-(e >> 1)
+        if (inverse) w = fr_sub(fr_zero(), w);
+        st_fr(out.lo, out.hi, p, fr_mul(w, (e & 1) ? k1 : k0));
+    }
 }
 // zero padding of an array from n to the domain size
 __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_zero(Planes d, size_t from, size_t to) {
