@@ -25,7 +25,7 @@ inline E to_plain(const E& m) {       // the regular-form integer of a Montgomer
 struct NttDomain {
     int logn = -1;
     E gen, finer, finer_inv, card_inv;      // Domain.Generator (order n), FinerGenerator (order 2n), its inverse, 1/n
-    DevTable tw;                            // omega^i, i <= n/2
+    DevTable tw;                            // per-stage twiddle tables T_s[j] = omega^(j << s), n + logn entries (ntt.hip.h)
     DevTable coset_fwd, coset_inv;          // u^rev(p) / n (Montgomery form) and u^-rev(p) / n (REGULAR form), p < n
 };
 std::mutex g_ntt_mu;
@@ -65,15 +65,16 @@ int ntt_domain(int logn, NttDomain** out) {
     CHK(upload_table(&thi, (const uint64_t*)hi.data(), nhi));
     void* p = nullptr;
     const size_t n = (size_t)1 << logn;
-    HIPCHK(hipMalloc(&p, sizeof(uint4) * 2 * (n_half + 1 + 2 * n)));
+    const size_t ntw = n + logn;
+    HIPCHK(hipMalloc(&p, sizeof(uint4) * 2 * (ntw + 2 * n)));
     d->tw.base = (uint4*)p;
-    d->tw.cap = n_half + 1;
-    d->coset_fwd.base = d->tw.base + 2 * (n_half + 1);
+    d->tw.cap = ntw;
+    d->coset_fwd.base = d->tw.base + 2 * ntw;
     d->coset_fwd.cap = n;
     d->coset_inv.base = d->coset_fwd.base + 2 * n;
     d->coset_inv.cap = n;
-    hipLaunchKernelGGL(k_ntt_twiddles, dim3(grid_for(n_half + 1, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->tw.planes(), tlo.cplanes(),
-                       thi.cplanes(), l0, n_half);
+    hipLaunchKernelGGL(k_ntt_twiddles, dim3(grid_for(ntw, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->tw.planes(), tlo.cplanes(),
+                       thi.cplanes(), l0, logn);
     hipLaunchKernelGGL(k_ntt_coset_table, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->coset_fwd.planes(),
                        d->tw.cplanes(), logn, 0, to_dev(d->card_inv), to_dev(hfr::mul(d->card_inv, d->finer)));
     hipLaunchKernelGGL(k_ntt_coset_table, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->coset_inv.planes(),
@@ -124,11 +125,6 @@ int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_o
     int passes = 0;
     double bytes = 0;
     const double arr_bytes = 32.0 * (double)((size_t)1 << logn);
-    E root_plain;
-    memcpy(root_plain.l, kRoot2_28, 32);
-    const E zeta = logn >= 2 ? host_pow(hfr::mul(root_plain, hfr::R2), 1ull << (kMaxOrderRoot - 2)) : hfr::ONE;     // primitive 4th root of unity
-    const E zeta_inv = hfr::pow_q_minus_2(zeta);
-    const E two128 = {{0, 0, 1, 0}};                                        // the plain integer 2^128: a Montgomery product with it divides by 2^128
     const std::vector<NttPassPlan> plan = ntt_plan(logn);
     NttPassArgs a;
     auto base_args = [&](int narr, bool inverse) {
@@ -137,9 +133,7 @@ int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_o
         (void)narr;
         a.tw = dom->tw.cplanes();
         a.logn = logn;
-        const E z = inverse ? zeta_inv : zeta;
-        a.zb = to_dev(z);
-        a.za = to_dev(hfr::mul(z, two128));
+        (void)inverse;
     };
     // one pass: local stages `stages` starting at transform stage s0, tile columns 2^lcols
     auto launch = [&](bool dit, int narr, int s0, const NttPassPlan& pp, int arrays_read) -> int {

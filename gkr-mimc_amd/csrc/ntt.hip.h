@@ -37,13 +37,16 @@ struct NttPassArgs {
                           //        | pre 3: x = (d[0][p] * d[1][p] - d[2][p]) * k2            (pointwise step, prove.go:341-347)
                           //        | post 3: x *= coset[p] = u^-rev(p) / n in REGULAR form    (the product leaves Montgomery form)
     Fr k2;                // pre 3: (-2)^-1
-    Fr zb, za;            // zeta = omega^(+-n/4), the primitive 4th root of unity of this direction: zb = zeta, za = zeta * 2^-128
 };
 
-// The twiddle table holds omega^i for i <= n/2 (the last entry is -1).  A forward stage loads w = omega^e; an inverse stage
-// loads w' = omega^(n/2 - e) = -omega^-e and the butterflies swap the operands of their subtraction instead of negating it.
-__device__ __forceinline__ Fr ntt_twiddle(const CPlanes& tw, int logn, bool inverse, size_t e) {      // e < n/2
-    return ld_fr(tw.lo, tw.hi, inverse ? ((size_t)1 << (logn - 1)) - e : e);
+// Twiddles are kept PER STAGE SHIFT s: T_s[j] = omega^(j * 2^s), j <= n / 2^(s+1) (the last entry is -1), T_s starting at
+// entry n - n / 2^s + s of one allocation of n + logn + 1 entries.  A stage whose twiddle exponents are multiples of 2^s then
+// reads CONSECUTIVE entries for consecutive positions, whatever s is (one table omega^i, i < n/2, read at stride 2^s costs a
+// cache line per lane from s = 2 on).  A forward stage loads w = omega^e; an inverse stage loads w' = omega^(n/2 - e) =
+// -omega^-e and the butterflies swap the operands of their subtraction instead of negating.
+__device__ __forceinline__ Fr ntt_twiddle(const CPlanes& tw, int logn, bool inverse, int shift, size_t j) {      // omega^(+-(j << shift)), j < n / 2^(shift+1)
+    const size_t n = (size_t)1 << logn, off = n - (n >> shift) + shift, cnt = n >> (shift + 1);
+    return ld_fr(tw.lo, tw.hi, off + (inverse ? cnt - j : j));
 }
 __device__ __forceinline__ size_t ntt_rev(size_t p, int logn) { return logn ? (size_t)(__brevll((unsigned long long)p) >> (64 - logn)) : 0; }
 
@@ -103,8 +106,9 @@ __device__ __forceinline__ Fr ntt_store_value(const NttPassArgs& a, size_t p, co
 // 2^lgn points; low = base mod 2^lg_q).  The twiddle of the pair (t, t + dist) of stage r is
 //     DIF:  omega^((low + (t mod 2^(R-1-r)) * q) * n / (2 d_r))  =  W_r * zeta^(t mod 2^(R-1-r)),   W_r = omega^(low << (lgn - lg_q - R + r))
 //     DIT:  omega^((low + (t mod 2^r) * q) * n / (2 d_r))        =  V_r * zeta^(t mod 2^r),          V_r = omega^(low << (lgn - 1 - lg_q - r))
-// with zeta the primitive 4th root of unity of the direction -- a launch-wide constant -- so a group of four loads two
-// twiddles and derives the third by one product with a constant.
+// with zeta the primitive 4th root of unity of the direction: omega^(e + n/4) sits a quarter of the stage's table further, so a
+// group of four loads its three twiddles, all coalesced (deriving the third by a product with the constant zeta instead:
+// 16.3 against 13.8 ms per computeH at 2^24).
 template <int R, bool DIT, bool INV>
 __device__ __forceinline__ void ntt_stages(const NttPassArgs& a, int lgn, size_t low, int lg_q, Fr (&x)[1 << R]) {
     static_assert(R == 1 || R == 2, "sub-passes of one or two stages");
@@ -113,10 +117,10 @@ __device__ __forceinline__ void ntt_stages(const NttPassArgs& a, int lgn, size_t
     for (int r = 0; r < R; r++) {
         const int dist = DIT ? (1 << r) : (1 << (R - 1 - r));                 // in units of q
         const bool two = DIT ? (r == 1) : (R == 2 && r == 0);                  // the stage with two distinct twiddles
-        const size_t e = DIT ? (low << (lgn - 1 - lg_q - r)) : (low << (lgn - lg_q - R + r));
+        const int shift = DIT ? lgn - 1 - lg_q - r : lgn - lg_q - R + r;       // the twiddle exponents of this stage are (low + ...) << shift
         Fr w[2];
-        w[0] = ntt_twiddle(a.tw, lgn, INV, e);
-        if (two) w[1] = fr_reduce_lt4q(fr_mul_const2_raw(w[0], a.za, a.zb));
+        w[0] = ntt_twiddle(a.tw, lgn, INV, shift, low);
+        if (two) w[1] = ntt_twiddle(a.tw, lgn, INV, shift, low + ((size_t)1 << (lgn - shift - 2)));      // times the 4th root of unity: a quarter of T_s further
 #pragma unroll
         for (int t = 0; t < E; t++) {
             if (t & dist) continue;
@@ -199,11 +203,17 @@ __global__ void __launch_bounds__(GKR_NTT_WG, 2) k_ntt_tile(NttPassArgs a) {
     }
 }
 
-// twiddle table: tw[i] = hi[i >> l0] * lo[i & (2^l0 - 1)] for i < n/2, the two small tables computed on the host; tw[n/2] = -1
-__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes lo, CPlanes hi, int l0, size_t n_half) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_half; i += (size_t)gridDim.x * blockDim.x)
-        st_fr(tw.lo, tw.hi, i, i == n_half ? fr_sub(fr_zero(), fr_one())
-                                           : fr_mul(ld_fr(hi.lo, hi.hi, i >> l0), ld_fr(lo.lo, lo.hi, i & (((size_t)1 << l0) - 1))));
+// twiddle tables: omega^i = hi[i >> l0] * lo[i & (2^l0 - 1)] for i < n/2 (the two small tables computed on the host), -1 for
+// i = n/2; entry (s, j) of the per-stage layout is omega^(j << s)
+__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes lo, CPlanes hi, int l0, int logn) {
+    const size_t n = (size_t)1 << logn, total = n + logn;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        int s = 0;
+        while (s + 1 <= logn - 1 && g >= n - (n >> (s + 1)) + (s + 1)) s++;       // the table this entry belongs to
+        const size_t j = g - (n - (n >> s) + s), i = j << s;
+        st_fr(tw.lo, tw.hi, g, i == (n >> 1) ? fr_sub(fr_zero(), fr_one())
+                                             : fr_mul(ld_fr(hi.lo, hi.hi, i >> l0), ld_fr(lo.lo, lo.hi, i & (((size_t)1 << l0) - 1))));
+    }
 }
 // The per-position factors of the coset transforms, as gnark-crypto's fft.Domain precomputes its CosetTable / CosetTableInv
 // (here indexed by the position in the bit-reversed vector the factor is applied to, with the 1/n folded in):
@@ -212,7 +222,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_coset_table(Planes out, CPlan
     const size_t n = (size_t)1 << logn;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
         const size_t e = ntt_rev(p, logn);
-        Fr w = ld_fr(tw.lo, tw.hi, inverse ? (n >> 1) - (e >> 1) : (e >> 1));      // inverse: -omega^-(e >> 1)
+        Fr w = ld_fr(tw.lo, tw.hi, inverse ? (n >> 1) - (e >> 1) : (e >> 1));      // T_0; inverse: -omega^-(e >> 1)
         if (inverse) w = fr_sub(fr_zero(), w);
         st_fr(out.lo, out.hi, p, fr_mul(w, (e & 1) ? k1 : k0));
     }
