@@ -305,6 +305,15 @@ const char* gkrhip_build_id(void) {
 int gkrhip_set_option(const char* key, long value) {
     static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
                                  "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg"};
+    // fault injection of the tests (host_sumcheck.hip.h): process-wide, fires once, -1 disarms
+    if (!strcmp(key, "test_fail_after_prelaunch")) {
+        g_test_fail_round.store((int)value);
+        return 0;
+    }
+    if (!strcmp(key, "test_drop_challenge")) {
+        g_test_drop_round.store((int)value);
+        return 0;
+    }
     bool known = false;
     for (const char* k : keys) known = known || !strcmp(key, k);
     if (!known) return fail("unknown option %s", key);

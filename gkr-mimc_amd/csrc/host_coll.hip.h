@@ -414,6 +414,9 @@ int shm_allreduce_host(unsigned long long* words, int n) {
     return 0;
 }
 // all-gather of `cnt` field elements per rank (host values): rank g's elements land in out[g*cnt ..].
+// the per-round exchange of this lane runs on the host (shared memory or the ticker): round_collect can carry a vote
+inline bool host_exchange() { return cx().lc.tick_lane >= 0 || cx().lc.shm != nullptr; }
+
 int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     const ShardView v = shard_view();
     out.assign((size_t)v.world * cnt, hfr::ZERO);

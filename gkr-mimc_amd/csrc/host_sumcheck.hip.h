@@ -30,7 +30,7 @@ inline RoundTargets round_targets(bool collective) {
     t.flag = t.on_device ? (unsigned int*)(cx().lc.d_buf + 192) : cx().d_flag;
     return t;
 }
-// Wait for round `seq`; on return *sums points at nsum words summed over the ranks (scratch: `summed`, nsum words) and
+// Wait for round `seq`; on return *sums points at nsum words summed over the ranks (scratch: `summed`, nsum + 1 words) and
 // cx().h_round + nsum holds this rank's ntail tail words.
 int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int nsum, int ntail, unsigned long long* summed,
                   const unsigned long long** sums) {
@@ -40,17 +40,26 @@ int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int 
         CHK(coll_publish(nsum + ntail, seq));
         return wait_flag(seq, nullptr, coll_timeout_ms(), coll_stream());
     }
-    CHK(wait_flag(seq));
-    if (collective && cx().lc.tick_lane >= 0) {          // RCCL through the ticker: one communicator for all lanes
-        memcpy(summed, cx().h_round, sizeof(unsigned long long) * nsum);
-        CHK(tick_allreduce(summed, nsum));
+    const int rc = wait_flag(seq);
+    if (collective && host_exchange()) {
+        // The ranks exchange one word more than the sums: a vote.  A rank whose round kernel gave up waiting for its challenge
+        // (recoverable: g_chal_timeout) still takes part in the exchange, with zero sums and vote 1; any vote makes EVERY rank
+        // leave the layer's rounds at this very exchange with g_chal_timeout set, and rounds_with_retry runs them again in safe
+        // mode on all ranks together (the exchanges of the retry line up: every rank restarts the layer).
+        if (rc != 0 && !g_chal_timeout) return rc;
+        if (rc != 0) memset(summed, 0, sizeof(unsigned long long) * nsum);
+        else memcpy(summed, cx().h_round, sizeof(unsigned long long) * nsum);
+        summed[nsum] = rc != 0 ? 1ull : 0ull;
+        if (cx().lc.tick_lane >= 0) CHK(tick_allreduce(summed, nsum + 1));      // RCCL through the ticker: one communicator for all lanes
+        else CHK(shm_allreduce_host(summed, nsum + 1));
+        if (summed[nsum]) {
+            g_chal_timeout = true;
+            return rc != 0 ? rc : fail("the round kernel of %llu peer rank(s) gave up waiting for its challenge: the layer's rounds are run again", summed[nsum]);
+        }
         *sums = summed;
-    } else if (collective && cx().lc.shm) {
-        memcpy(summed, cx().h_round, sizeof(unsigned long long) * nsum);
-        CHK(shm_allreduce_host(summed, nsum));
-        *sums = summed;
+        return 0;
     }
-    return 0;
+    return rc;
 }
 
 inline E fold2(const E& lo, const E& hi, const E& r) { return hfr::add(lo, hfr::mul(hfr::sub(hi, lo), r)); }
@@ -155,19 +164,16 @@ struct ChalGuard {
     }
 };
 
-// test hook, see cipher_rounds
-const int g_test_fail_round = [] {
-    const char* e = getenv("GKRHIP_TEST_FAIL_AFTER_PRELAUNCH");
-    return e ? atoi(e) : -1;
-}();
-std::atomic<bool> g_test_fail_armed{true};
-// test hook (GKRHIP_TEST_DROP_CHALLENGE=k, once per process): the challenge of round k is NOT published -- the kernel waiting
-// for it runs out of time, the round loop fails with g_chal_timeout and rounds_with_retry runs the layer again in safe mode
-const int g_test_drop_round = [] {
-    const char* e = getenv("GKRHIP_TEST_DROP_CHALLENGE");
-    return e ? atoi(e) : -1;
-}();
-std::atomic<bool> g_test_drop_armed{true};
+// Fault injection for the tests, armed only through gkrhip_set_option("test_fail_after_prelaunch" / "test_drop_challenge", k)
+// -- never from the environment: a stray variable must not be able to cost a proof.  Each fires once.
+//   test_fail_after_prelaunch = k: an error return in round k while a pre-launched kernel is waiting for its challenge;
+//   test_drop_challenge = k: the challenge of round k is NOT published -- the kernel waiting for it runs out of time, the round
+//   loop fails with g_chal_timeout and rounds_with_retry runs the layer again in safe mode.
+std::atomic<int> g_test_fail_round{-1}, g_test_drop_round{-1};
+inline bool test_fire(std::atomic<int>& hook, int k) {
+    int want = k;
+    return hook.load(std::memory_order_relaxed) == k && hook.compare_exchange_strong(want, -1);
+}
 
 // The slow parts of the look-ahead -- the second stream (created on first use: a lane that never looks ahead holds one
 // hardware queue, not two) and the six scratch tables (a miss in the arena is a hipMalloc behind the arena's lock) -- are done
@@ -219,18 +225,22 @@ int launch_pre() {
     return 0;
 }
 
-// A round loop that failed because a waiting kernel's time ran out (g_chal_timeout: the kernel left without touching anything,
-// ChalGuard drained the stream) is run ONCE more in safe mode -- no kernel queued ahead of its challenge, no look-ahead.  The
-// loops read the layer's tables and write scratch tables only, so with the running values restored the retry produces the
-// same transcript; seen so far only with every latency path forced on for a dozen lanes at once (a kernel polling host memory
-// did not see, within its time, a challenge the host had written before it started), where it used to cost the proof.
+// A round loop that failed because a waiting kernel's time ran out (g_chal_timeout; ChalGuard drained the stream) is run ONCE
+// more in safe mode -- no kernel queued ahead of its challenge, no look-ahead.  The invariant the retry rests on: the round
+// loops READ the layer's tables and WRITE only scratch tables, the lane's accumulators and its hand-off buffers.  Workgroups
+// have clocks of their own, so some of an abandoned launch may have folded, stored into scratch and added into d_racc /
+// d_counter while others left: the scratch tables are rewritten from the layer's tables by the retry's own launches, and the
+// accumulators are re-zeroed at the start of the retried loop (racc_dirty is still set from the failed run).  With the running
+// values (c, claim) restored the retry therefore produces the same transcript.  Sharded over a host-side exchange (shared
+// memory, ticker) the ranks agree on the retry through the vote word of round_collect; the device-side RCCL exchange of a
+// single lane has no vote: its kernels wait 20 s and a miss fails the proof on every rank.
 template <class F>
 int rounds_with_retry(E& c, E& claim, bool& claim_known, F&& run) {
     const E c0 = c, claim0 = claim;
     const bool known0 = claim_known;
     g_chal_timeout = false;
     int rc = run();
-    if (rc != 0 && g_chal_timeout && !g_safe_mode && !shard_view().gamma) {      // (sharded: the ranks would have to agree on the retry)
+    if (rc != 0 && g_chal_timeout && !g_safe_mode && (!shard_view().gamma || host_exchange())) {      // (sharded: the ranks agree on the retry through the vote word of round_collect)
         g_chal_timeout = false;
         c = c0;
         claim = claim0;
@@ -453,7 +463,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             a.chal = cx().d_chal;
             a.chal_dev = cx().d_chal_dev;
             a.chal_seq = a.seq;
-            a.chal_limit_s = collective ? 20u : 0u;          // no retry across ranks: a generous limit there
+            a.chal_limit_s = collective && !host_exchange() ? 20u : 0u;          // no retry across ranks on the device-side exchange: a generous limit there
             chal_guard.armed = true;
             cx().dbg_defer_seq = a.seq;
             cx().dbg_defer_ms = now_ms();
@@ -606,11 +616,11 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         // test hook (GKRHIP_TEST_FAIL_AFTER_PRELAUNCH=k, once per process): an error return while a pre-launched kernel is
         // waiting for its challenge -- the guard must tell it to leave, drain the stream and clear the abort tags
-        if ((prelaunched || (next_spec && next2_spec)) && k == g_test_fail_round && g_test_fail_armed.exchange(false))   // (a speculative launch waits for r_k)
+        if ((prelaunched || (next_spec && next2_spec)) && test_fire(g_test_fail_round, k))   // (a speculative launch waits for r_k)
             return fail("injected failure after a pre-launch (test hook)");
         const double t_l1 = now_ms();
         const unsigned long long* words = cx().h_round;
-        unsigned long long summed[GKR_CR_WORDS];
+        unsigned long long summed[GKR_CR_WORDS + 1];
         const unsigned long long* sums = nullptr;
         const bool this_spec = is_spec(k);
         const unsigned long long* cand = cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
@@ -649,12 +659,12 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             if (next2_spec && !cx().spec_poll && !cx().spec_batch) {
                 CHK(launch_spec(k + 2, &r));                 // round k+2's speculative launch, with r_k as a launch argument
             } else if (next2_spec) {                         // round k+2's speculative launch folds with r_k
-                if (!(k == g_test_drop_round && g_test_drop_armed.exchange(false))) chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
+                if (!test_fire(g_test_drop_round, k)) chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
                 chal_guard.armed = k + 2 < k_export;         // later speculative launches are still waiting for theirs
             }
         } else if (prelaunched) {
             const E two128 = {{0, 0, 1, 0}};
-            if (!(k == g_test_drop_round && g_test_drop_armed.exchange(false)))
+            if (!test_fire(g_test_drop_round, k))
                 chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
             chal_guard.armed = spec_queued && k_s < k_export;    // (the speculative launches behind it wait for their own)
             cur = nxt;
@@ -991,7 +1001,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             a.chal = cx().d_chal;
             a.chal_dev = cx().d_chal_dev;
             a.chal_seq = a.seq;
-            a.chal_limit_s = collective ? 20u : 0u;
+            a.chal_limit_s = collective && !host_exchange() ? 20u : 0u;
         }
         out->derive_m0 = derive_m0;
         a.need_m0 = derive_m0 ? 0u : 1u;
@@ -1069,7 +1079,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
             CHK(launch_pre());
             pre_requested = false;
         }
-        unsigned long long summed[GKR_LR_WORDS];
+        unsigned long long summed[GKR_LR_WORDS + 1];
         const unsigned long long* sums = nullptr;
         const E* cand = (const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS);      // M_0(0), M_1(0), M_0(1), M_1(1)
         if (this_spec) CHK(wait_flag(spec_seq[k], (volatile unsigned int*)((const unsigned long long*)cand + GKR_SPEC_FLAG_WORD)));

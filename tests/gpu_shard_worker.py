@@ -178,6 +178,12 @@ def main():
         print("DIED rank %d" % rank)
         return
     circuit = os.environ.get("GKR_TEST_CIRCUIT", "mimc")
+    if os.environ.get("GKR_TEST_DROP_RANK") == str(rank):
+        # this rank withholds ONE challenge from its pre-launched round kernel: the kernel gives up after a second, the rank
+        # votes for a retry in the round's exchange and every rank runs the layer's rounds again (same transcript)
+        gk.set_option("test_drop_challenge", int(os.environ.get("GKR_TEST_DROP_ROUND", "3")))
+    if os.environ.get("GKR_TEST_EXPECT_RETRIES"):
+        gk.profile_reset(0)
     if os.environ.get("GKR_TEST_REGULAR"):
         return regular_oneshot(gk, world, rank, sizes)
     if os.environ.get("GKR_TEST_HASHONLY"):
@@ -210,6 +216,9 @@ def main():
         assert np.array_equal(s.evaluate_layer(93, pt), c.evaluate(oouts, pt)), ("evaluate", bn, rank)
         assert np.array_equal(flat, s.prove(qp)), ("repeat", bn, rank)
         s.close()
+    if os.environ.get("GKR_TEST_EXPECT_RETRIES"):
+        got = gk.profile_get()["chal_retries"]
+        assert got == int(os.environ["GKR_TEST_EXPECT_RETRIES"]), ("chal_retries", rank, got)
     gk.comm_destroy()
     print("SHARD-OK rank %d/%d %s" % (rank, world, sizes))
 

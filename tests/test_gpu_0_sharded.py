@@ -60,6 +60,17 @@ def test_sharded_prover_concurrent_lanes():
     _run_shards("rccl", 1, "3,9", {"GKR_TEST_LANES": "3", "GKRHIP_FORCE_COLLECTIVE": "1"})
 
 
+def test_sharded_retry_after_a_missed_challenge():
+    """One of four ranks withholds a challenge from its pre-launched round kernel (test hook, armed through
+    gkrhip_set_option): the kernel gives up after a second, the rank votes in the round's exchange, EVERY rank leaves the
+    layer's rounds at that exchange and runs them again in safe mode -- same transcript as the oracle, one retry per rank.
+    Over both host-side exchanges: shared memory and the ticker."""
+    env = {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRELAUNCH_LG": "30", "GKR_TEST_DROP_RANK": "2", "GKR_TEST_DROP_ROUND": "3",
+           "GKR_TEST_EXPECT_RETRIES": "1"}
+    _run_shards("shm", 4, "12", env)
+    _run_shards("tickshm", 2, "11", dict(env, GKR_TEST_DROP_RANK="1"))
+
+
 def test_sharded_oneshot_on_regular_form_buffers():
     """gkrhip_gkr_prove_mimc_regular with a communicator installed: the regular-form scope covers the boundary images
     only, the gathered Montgomery elements of the sharded phase 2 (multi-claim key-copy layer, host tail off) are uploaded

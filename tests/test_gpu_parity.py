@@ -477,6 +477,7 @@ def test_error_while_a_prelaunched_kernel_waits(gk):
         bn = 12
         s = gk.MimcSession(bn); s.synth_inputs(); s.assign()
         qp = c.random_fr_array(bn)
+        gk.set_option("test_fail_after_prelaunch", 3)      # fault injection is armed through the option, never the environment
         try:
             s.prove(qp)
             raise SystemExit("the injected failure did not surface")
@@ -491,7 +492,7 @@ def test_error_while_a_prelaunched_kernel_waits(gk):
     """ % (root, os.path.join(root, "oracle")))
     # the kernel left waiting is a pre-launched round kernel (GKRHIP_SPEC=0) or a speculative launch two rounds ahead
     for spec in ("0", "2"):
-        env = dict(os.environ, GKRHIP_TEST_FAIL_AFTER_PRELAUNCH="3", GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "ABORT-PATH-OK" in out.stdout, (spec, out.stdout + out.stderr)
 
@@ -516,13 +517,14 @@ def test_layer_retried_after_a_missed_challenge(gk):
         i0 = c.random_fr_array(1 << bn)
         want = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)[0]
         gk.profile_reset(0)
+        gk.set_option("test_drop_challenge", 3)
         for _ in range(3):
             assert np.array_equal(s.prove(qp), want)
         assert gk.profile_get()["chal_retries"] == 1, gk.profile_get()
         print("RETRY-OK")
     """ % (root, os.path.join(root, "oracle")))
     for spec in ("0", "2"):
-        env = dict(os.environ, GKRHIP_TEST_DROP_CHALLENGE="3", GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "RETRY-OK" in out.stdout, (spec, out.stdout + out.stderr)
 
