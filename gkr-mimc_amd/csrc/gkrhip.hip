@@ -1554,6 +1554,29 @@ int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /
 // The ticker (host_coll.hip.h): ONE exchange channel for the process, `nlanes` lanes that exchange through it.
 // id_bytes != nullptr: an RCCL communicator (mode 0: all-reduce on the host-mapped buffers; mode 1: on device staging
 // buffers); shm_name != nullptr: a host all-reduce through a POSIX shared-memory segment (several ranks on one GPU: tests).
+// everything a (possibly half-built) ticker owns; the lanes that were pointed at it are released too
+static void ticker_release(Ticker* t) {
+    if (!t) return;
+    for (Ctx* l : gc.lanes) {
+        if (!l) continue;
+        l->lc.tick_lane = -1;
+        if (l != &g0) lane_destroy(l, /*pool=*/false);
+    }
+    gc.lanes.clear();
+    gc.next_lane = 0;
+    if (t->comm) (void)gc.p_destroy(t->comm);
+    if (t->shm) {
+        t->shm->abort.store(1, std::memory_order_release);      // a peer already waiting in the segment fails instead of hanging
+        munmap((void*)t->shm, t->shm_bytes);
+    }
+    if (t->h_send) (void)hipHostFree(t->h_send);
+    if (t->h_recv) (void)hipHostFree(t->h_recv);
+    if (t->h_done) (void)hipHostFree(t->h_done);
+    if (t->d_stage_send) (void)hipFree(t->d_stage_send);
+    if (t->d_stage_recv) (void)hipFree(t->d_stage_recv);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
 static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* id_bytes, int mode, const char* shm_name) {
     std::lock_guard<std::mutex> lk(g0.mu);
     CHK(ensure_ctx());
@@ -1565,15 +1588,22 @@ static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* i
     t->world = world;
     t->rank = rank;
     t->dev_buf = mode == 1;
+    // ONE way out of every failure below: whatever exists by then (communicator, mapping, buffers, stream, the lanes'
+    // slot numbers) is released, so that the peers see this rank leave instead of waiting for its first tick
+    auto bail = [&](int rc) {
+        ticker_release(t);
+        return rc;
+    };
     const size_t total = kTickHeader + (size_t)nlanes * kTickStride;
     if (id_bytes) {
-        CHK(coll_load());
+        const int lrc = coll_load();
+        if (lrc) return bail(lrc);
         ncclUniqueId id;
         memcpy(&id, id_bytes, 128);
         ncclResult_t r = gc.p_init(&t->comm, world, id, rank);
         if (r != ncclSuccess) {
-            delete t;
-            return fail("ncclCommInitRank failed: %s", gc.p_errstr ? gc.p_errstr(r) : "?");
+            t->comm = nullptr;
+            return bail(fail("ncclCommInitRank failed: %s", gc.p_errstr ? gc.p_errstr(r) : "?"));
         }
     } else {
         // rank 0 creates the segment (header + one tick buffer per rank), the others map it once it has its size
@@ -1584,8 +1614,8 @@ static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* i
             (void)shm_unlink(shm_name);
             fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
             if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
-                delete t;
-                return fail("shm_open/ftruncate(%s) failed", shm_name);
+                if (fd >= 0) close(fd);
+                return bail(fail("shm_open/ftruncate(%s) failed", shm_name));
             }
         } else {
             for (;;) {
@@ -1593,19 +1623,18 @@ static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* i
                 struct stat st;
                 if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
                 if (fd >= 0) close(fd);
-                if (now_ms() - t_start > coll_timeout_ms()) {
-                    delete t;
-                    return fail("shm segment %s did not appear", shm_name);
-                }
+                if (now_ms() - t_start > coll_timeout_ms()) return bail(fail("shm segment %s did not appear", shm_name));
                 usleep(1000);
             }
         }
+        ino_t ino = 0;
+        {
+            struct stat st;
+            if (fstat(fd, &st) == 0) ino = st.st_ino;
+        }
         void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
-        if (p == MAP_FAILED) {
-            delete t;
-            return fail("mmap of %s failed", shm_name);
-        }
+        if (p == MAP_FAILED) return bail(fail("mmap of %s failed", shm_name));
         t->shm = (ShmHdr*)p;
         t->shm_slots = (unsigned long long*)((char*)p + 4096);
         t->shm_bytes = bytes;
@@ -1615,15 +1644,31 @@ static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* i
         if (rank == 0) {
             t->shm->magic.store(kShmMagic ^ (unsigned long long)ts.tv_sec, std::memory_order_release);
         } else {
-            for (;;) {     // a name of this run only (the callers use fresh names): wait for rank 0's stamp
+            // as shm_attach: only a segment rank 0 stamped within the time-out window is accepted, and the name is looked at
+            // again every now and then -- this mapping may be the leftover of a crashed run that was opened before rank 0
+            // unlinked it and created the fresh one
+            unsigned polls = 0;
+            for (;;) {
                 const unsigned long long m = t->shm->magic.load(std::memory_order_acquire);
-                if (m != 0) break;
-                if (now_ms() - t_start > coll_timeout_ms()) {
-                    munmap(p, bytes);
-                    delete t;
-                    return fail("shm segment %s was never initialised by rank 0", shm_name);
-                }
+                clock_gettime(CLOCK_REALTIME, &ts);
+                const long long age = (long long)ts.tv_sec - (long long)(m ^ kShmMagic);
+                if (m != 0 && age >= -5 && age * 1e3 <= coll_timeout_ms() + 5e3) break;
+                if (now_ms() - t_start > coll_timeout_ms()) return bail(fail("shm segment %s is stale or was never initialised by rank 0", shm_name));
                 usleep(1000);
+                if ((++polls & 127) == 0) {
+                    const int fd2 = shm_open(shm_name, O_RDWR, 0600);
+                    struct stat st;
+                    if (fd2 >= 0 && fstat(fd2, &st) == 0 && st.st_ino != ino && (size_t)st.st_size >= bytes) {
+                        void* p2 = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, 0);
+                        if (p2 != MAP_FAILED) {
+                            munmap((void*)t->shm, bytes);
+                            t->shm = (ShmHdr*)p2;
+                            t->shm_slots = (unsigned long long*)((char*)p2 + 4096);
+                            ino = st.st_ino;
+                        }
+                    }
+                    if (fd2 >= 0) close(fd2);
+                }
             }
         }
     }
@@ -1636,17 +1681,13 @@ static int comm_init_tick_impl(int world, int rank, int nlanes, const uint8_t* i
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&t->d_done, t->h_done, 0);
     if (e == hipSuccess && t->dev_buf) e = hipMalloc(&t->d_stage_send, sizeof(unsigned long long) * total);
     if (e == hipSuccess && t->dev_buf) e = hipMalloc(&t->d_stage_recv, sizeof(unsigned long long) * total);
-    if (e != hipSuccess) {
-        if (t->comm) (void)gc.p_destroy(t->comm);
-        delete t;
-        return fail("comm_init_tick: %s", hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return bail(fail("comm_init_tick: %s", hipGetErrorString(e)));
     memset(t->h_send, 0, sizeof(unsigned long long) * total);
     memset(t->h_recv, 0, sizeof(unsigned long long) * total);
     *t->h_done = 0;
     for (int k = 0; k < nlanes; k++) {
         Ctx* l = comm_lane(k);
-        if (!l) return fail("cannot create lane %d: %s", k, g_err.c_str());
+        if (!l) return bail(fail("cannot create lane %d: %s", k, g_err.c_str()));
         l->lc.tick_lane = k;
     }
     comm_set(world, rank);

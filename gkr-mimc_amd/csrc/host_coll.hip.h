@@ -376,6 +376,11 @@ int tick_allreduce(unsigned long long* words, int n) {
     if (!t || k < 0 || k >= t->nlanes) return fail("tick exchange: the lane has no ticker slot");
     if (n > kTickPayload) return fail("tick exchange of %d words exceeds the slot (%d)", n, kTickPayload);
     TickSlot& s = t->slot[k];
+    if (t->failed.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(t->err_mu);
+        return fail("sharded prover: %s", t->error.c_str());
+    }
+    if (s.state.load(std::memory_order_acquire) != 0) return fail("tick exchange: the lane's slot is still in use by an abandoned exchange");
     memcpy(s.words, words, sizeof(unsigned long long) * n);
     s.nwords = n;
     s.state.store(1, std::memory_order_release);
@@ -390,7 +395,14 @@ int tick_allreduce(unsigned long long* words, int n) {
                 return fail("sharded prover: %s", t->error.c_str());
             }
             if (!t->running.load(std::memory_order_acquire)) return fail("sharded prover: the ticker has stopped (communicator destroyed)");
-            if (now_ms() - t0 > coll_timeout_ms()) return fail("sharded prover: timed out after %.0f s waiting for the other ranks (tick exchange)", coll_timeout_ms() * 1e-3);
+            if (now_ms() - t0 > coll_timeout_ms()) {
+                // The slot stays posted and the ticker would go on contributing these words: a peer that arrives later (or
+                // starts its next proof on this lane) would complete ITS exchange against the payload of this abandoned one.
+                // A lane's time-out therefore stops the ticker: every lane of this rank fails, and the peers' ticks run
+                // into their own time-out -- all ranks error out together instead of one of them proving on stale sums.
+                ticker_fail(t, "a lane timed out waiting for the other ranks (tick exchange): the ticker is stopped");
+                return fail("sharded prover: timed out after %.0f s waiting for the other ranks (tick exchange)", coll_timeout_ms() * 1e-3);
+            }
         }
     }
     memcpy(words, s.words, sizeof(unsigned long long) * n);
@@ -416,6 +428,15 @@ int shm_allreduce_host(unsigned long long* words, int n) {
 // all-gather of `cnt` field elements per rank (host values): rank g's elements land in out[g*cnt ..].
 // the per-round exchange of this lane runs on the host (shared memory or the ticker): round_collect can carry a vote
 inline bool host_exchange() { return cx().lc.tick_lane >= 0 || cx().lc.shm != nullptr; }
+// Sharded host tail (one gather of the exported tables instead of h + 1 exchanged rounds): through the ticker a gather of cnt
+// elements per rank is ceil(cnt / (kTickPayload / (4 world))) ticks -- 11 for the 64 elements of a cipher layer at h = 4 on 8
+// ranks, against the 5 ticks of the rounds it replaces -- so on that transport the tail is taken only where the gather is
+// the shorter one (2 ranks: 3 ticks against 5).  The other transports gather in one exchange.
+inline bool sharded_tail_pays(int elements_per_rank, int h) {
+    if (cx().lc.tick_lane < 0) return true;
+    const int per = kTickPayload / (4 * shard_view().world);
+    return per >= 1 && (elements_per_rank + per - 1) / per <= h + 1;
+}
 
 int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     const ShardView v = shard_view();

@@ -387,7 +387,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // rounds over the shard bits (q[m .. m + gamma_tail)) -- on the gathered tables of 2^h * world entries: one gather
     // instead of h + 1 exchanged device rounds and the per-layer gather of phase 2.
     const bool sh_tail = collective && gamma_tail > 0 && did_gamma && cx().host_tail_sharded > 0 && m >= cx().host_tail_sharded + 2 &&
-                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0);
+                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0) &&
+                         sharded_tail_pays(2 * (2 << cx().host_tail_sharded), cx().host_tail_sharded);      // K and S: 2^(h+1) entries each
     const int h_want = collective ? (sh_tail ? cx().host_tail_sharded : 0) : (alone ? cx().host_tail_solo : cx().host_tail);
     const int h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
     if (did_gamma) *did_gamma = false;
@@ -929,7 +930,8 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     E r_prev = hfr::ZERO;
     // sharded host tail: see cipher_rounds
     const bool sh_tail = collective && gamma_tail > 0 && did_gamma && cx().host_tail_sharded > 0 && m >= cx().host_tail_sharded + 2 &&
-                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0);
+                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0) &&
+                         sharded_tail_pays(arity * (2 << cx().host_tail_sharded), cx().host_tail_sharded);
     const int h_want = collective ? (sh_tail ? cx().host_tail_sharded : 0) : cx().host_tail;
     const int h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
     if (did_gamma) *did_gamma = false;

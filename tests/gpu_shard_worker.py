@@ -178,6 +178,9 @@ def main():
         print("DIED rank %d" % rank)
         return
     circuit = os.environ.get("GKR_TEST_CIRCUIT", "mimc")
+    if os.environ.get("GKR_TEST_DELAY_RANK") == str(rank):
+        import time
+        time.sleep(float(os.environ.get("GKR_TEST_DELAY_S", "5")))      # this rank reaches its first exchange late
     if os.environ.get("GKR_TEST_DROP_RANK") == str(rank):
         # this rank withholds ONE challenge from its pre-launched round kernel: the kernel gives up after a second, the rank
         # votes for a retry in the round's exchange and every rank runs the layer's rounds again (same transcript)

@@ -171,7 +171,7 @@ def test_sharded_host_tail_off():
     _run_shards("shm", 4, "3,4,9,11", {"GKRHIP_HOST_TAIL": "0"})
 
 
-def _run_shards_expect_failure(world, sizes, env, within_s):
+def _run_shards_expect_failure(world, sizes, env, within_s, mode="shm"):
     """Rank GKR_TEST_DIE leaves before proving: every other rank must end with an error inside `within_s` seconds."""
     import os, subprocess, sys, time, uuid
     here = os.path.dirname(os.path.abspath(__file__))
@@ -179,7 +179,7 @@ def _run_shards_expect_failure(world, sizes, env, within_s):
     e = dict(os.environ, GKR_ORACLE_THREADS="2")
     e.update(env)
     t0 = time.time()
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), "shm", str(world), str(r), name, sizes],
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_shard_worker.py"), mode, str(world), str(r), name, sizes],
                               env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -190,7 +190,7 @@ def _run_shards_expect_failure(world, sizes, env, within_s):
                 q.kill()
             raise AssertionError("a rank hung after its peer left")
         outs.append(out)
-    die = int(env["GKR_TEST_DIE"])
+    die = int(env.get("GKR_TEST_DIE", "-1"))
     for r, (p, out) in enumerate(zip(procs, outs)):
         if r == die:
             continue
@@ -205,3 +205,12 @@ def test_peer_failure_is_an_error_not_a_hang():
     _run_shards_expect_failure(2, "9", {"GKR_TEST_DIE": "1"}, within_s=120)
     dt = _run_shards_expect_failure(4, "8", {"GKR_TEST_DIE": "2", "GKR_TEST_DIE_HARD": "1", "GKRHIP_COLL_TIMEOUT_S": "4"}, within_s=120)
     assert dt < 60
+
+
+def test_ticker_lane_timeout_fails_every_rank():
+    """a lane that gives up waiting in the ticker must not leave its words behind for a late peer to complete
+    ITS exchange against.  Rank 1 arrives after rank 0's collective time-out: rank 0 fails, its ticker stops, and rank 1
+    fails too (no proof on the stale payload of an abandoned round)."""
+    dt = _run_shards_expect_failure(2, "9", {"GKR_TEST_DELAY_RANK": "1", "GKR_TEST_DELAY_S": "9", "GKRHIP_COLL_TIMEOUT_S": "3"},
+                                    within_s=180, mode="tickshm")
+    assert dt < 120
