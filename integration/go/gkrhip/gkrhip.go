@@ -434,3 +434,53 @@ func FromRegular(s []fr.Element) { must(C.gkrhip_from_regular(ptr(s), C.size_t(l
 func MimcPermutationBatch(out, x, key []fr.Element) {
 	must(C.gkrhip_mimc_permutation_batch(ptr(out), ptr(x), ptr(key), C.size_t(len(x))))
 }
+
+// ---- G1 multi-scalar multiplication (include/gkrhip.h: gkrhip_msm_g1 and friends) ---------------------------------
+// A bn254.G1Affine is {X, Y fp.Element} = 8 uint64 in Montgomery form, infinity = (0, 0): the memory image the library
+// reads; scalars are fr.Elements in REGULAR form unless scalarsMont is set (ecc.MultiExpConfig.ScalarsMont).  This file
+// does not import gnark-crypto's bn254 package (it would only be needed for the type): the callers pass
+// unsafe.Pointer(&points[0]).
+
+// G1Bases is a proving-key vector (pk.G1.A, pk.G1.B, pk.G1.Z, pk.privKNotGkr) resident in HBM.
+type G1Bases struct{ h *C.gkrhip_g1_bases }
+
+// NewG1Bases uploads n points once; they stay on the device until Free.
+func NewG1Bases(points unsafe.Pointer, n int) *G1Bases {
+	b := &G1Bases{}
+	must(C.gkrhip_g1_bases_create(&b.h, (*C.uint64_t)(points), C.size_t(n)))
+	runtime.SetFinalizer(b, func(b *G1Bases) { b.Free() })
+	return b
+}
+
+func (b *G1Bases) Free() {
+	if b.h != nil {
+		C.gkrhip_g1_bases_destroy(b.h)
+		b.h = nil
+	}
+}
+
+func (b *G1Bases) Len() int { return int(C.gkrhip_g1_bases_len(b.h)) }
+
+// MultiExp writes sum_i [scalars[i]] bases[i] into out (a *bn254.G1Affine) for the first len(scalars) bases.
+func (b *G1Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont bool) {
+	flags := C.int(0)
+	if scalarsMont {
+		flags = C.GKRHIP_MSM_SCALARS_MONT
+	}
+	must(C.gkrhip_msm_g1((*C.uint64_t)(out), b.h, ptr(scalars), C.size_t(len(scalars)), flags))
+}
+
+// MultiExpG1 is (*G1Affine).MultiExp(points, scalars, config) in one call on host slices (bases uploaded per call).
+func MultiExpG1(out, points unsafe.Pointer, scalars []fr.Element, scalarsMont bool) {
+	flags := C.int(0)
+	if scalarsMont {
+		flags = C.GKRHIP_MSM_SCALARS_MONT
+	}
+	must(C.gkrhip_msm_g1_once((*C.uint64_t)(out), (*C.uint64_t)(points), ptr(scalars), C.size_t(len(scalars)), flags))
+}
+
+// BatchScalarMultiplicationG1 is bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out is a
+// []bn254.G1Affine of len(scalars) elements.
+func BatchScalarMultiplicationG1(out, base unsafe.Pointer, scalars []fr.Element) {
+	must(C.gkrhip_g1_batch_scalar_mul((*C.uint64_t)(out), (*C.uint64_t)(base), ptr(scalars), C.size_t(len(scalars)), 0))
+}

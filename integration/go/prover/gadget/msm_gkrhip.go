@@ -1,0 +1,58 @@
+//go:build gkrhip && (amd64 || arm64)
+
+// GPU bodies of the G1 multi-scalar multiplications of the Groth16 part of the gadget's prover
+// (prover/gadget/prove.go:76,91 krsNotGkr / KrsPrivNotGkr over pk.privKNotGkr; :189 bs1 over pk.G1.B; :202 ar over pk.G1.A;
+// :221 krs2 over pk.G1.Z with the h of computeH).  Drop into gkr-mimc/prover/gadget/ and replace the MultiExp calls named
+// below by these helpers (the G2 MSM of :277 stays on the CPU).  Uncompiled here (no Go toolchain in the build image); the
+// entry points are exercised through the C ABI by tests/test_gpu_msm.py.
+//
+// The bases of these calls are vectors of the proving key -- the same for every proof -- so they are uploaded once
+// (g1BasesOf caches a handle per slice) and an MSM moves only its scalars.  Scalars arrive in REGULAR form exactly as the
+// reference prepares them (FromMont at prove.go:66,116-120,355-357): no flag needed.
+package gadget
+
+import (
+	"sync"
+	"unsafe"
+
+	"github.com/consensys/gkr-mimc/gkrhip"
+	"github.com/consensys/gnark-crypto/ecc/bn254"
+	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
+)
+
+var (
+	g1BasesMu    sync.Mutex
+	g1BasesCache = map[*bn254.G1Affine]*gkrhip.G1Bases{} // keyed by the address of the slice's first point
+)
+
+// g1BasesOf returns the device-resident copy of a proving-key vector, uploading it on first use.
+func g1BasesOf(points []bn254.G1Affine) *gkrhip.G1Bases {
+	g1BasesMu.Lock()
+	defer g1BasesMu.Unlock()
+	key := &points[0]
+	if b, ok := g1BasesCache[key]; ok && b.Len() == len(points) {
+		return b
+	}
+	b := gkrhip.NewG1Bases(unsafe.Pointer(&points[0]), len(points))
+	g1BasesCache[key] = b
+	return b
+}
+
+// multiExpG1Affine replaces `res.MultiExp(points, scalars, ecc.MultiExpConfig{...})` for a bn254.G1Affine receiver
+// (prove.go:76,91).
+func multiExpG1Affine(res *bn254.G1Affine, points []bn254.G1Affine, scalars []fr.Element) {
+	if len(scalars) == 0 {
+		*res = bn254.G1Affine{}
+		return
+	}
+	g1BasesOf(points).MultiExp(unsafe.Pointer(res), scalars, false)
+}
+
+// multiExpG1Jac replaces `res.MultiExp(points, scalars, ecc.MultiExpConfig{...})` for a bn254.G1Jac receiver
+// (prove.go:189,202,221): the sum comes back affine and is lifted with Z = 1 -- every later use (AddMixed, AddAssign,
+// ScalarMultiplication, FromJacobian: prove.go:194-196,207-210,236-262) is independent of the Jacobian representative.
+func multiExpG1Jac(res *bn254.G1Jac, points []bn254.G1Affine, scalars []fr.Element) {
+	var aff bn254.G1Affine
+	multiExpG1Affine(&aff, points, scalars)
+	res.FromAffine(&aff)
+}
