@@ -172,7 +172,7 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         cur += slots * bN;
     }
     if (cur != proof_len(c, bN)) return fail("internal: flat proof length mismatch");
-    if (getenv("GKRHIP_TRACE_ROUNDS")) {       // where one proof's host time went (cumulative since the last profile reset)
+    if (getenv("GKRHIP_TRACE")) {       // where one proof's host time went (cumulative since the last profile reset)
         const Profile& p = cx().prof;
         fprintf(stderr, "rounds trace: hash %.2f wait %.2f launch %.2f other %.2f setup %.2f host-tail arithmetic %.2f ms\n", p.host_hash_ms,
                 p.host_wait_ms, p.host_launch_ms, p.host_other_ms, p.setup_ms, p.tail_ms);
@@ -715,7 +715,7 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
         }
         qprime = (const uint64_t*)qp_m.data();
     }
-    const bool trace = getenv("GKRHIP_TRACE_ONESHOT") != nullptr;     // stage times on stderr
+    const bool trace = getenv("GKRHIP_TRACE") != nullptr;     // stage times on stderr
     const double t_0 = now_ms();
     gkrhip_session* s = nullptr;
     CHK(gkrhip_mimc_session_create(&s, bN));
@@ -1406,33 +1406,6 @@ int gkrhip_comm_unique_id(uint8_t out[128]) {
     return 0;
 }
 
-// GKRHIP_COMM_CUS = n: confine the current (RCCL) lane's round kernels to all CUs but n reserved ones and give the
-// collective a stream of its own on the reserved ones (spread over the chip: one per XCD for n = 8)
-static int lane_reserve_comm_cus() {
-    static const int n_res = [] {
-        const char* e = getenv("GKRHIP_COMM_CUS");
-        return e ? std::max(0, std::min(64, atoi(e))) : 0;
-    }();
-    if (n_res == 0 || cx().lc.comm_stream) return 0;
-    const int ncu = cx().n_cu, words = (ncu + 31) / 32;
-    std::vector<uint32_t> res(words, 0u), rest(words, 0u);
-    for (int k = 0; k < n_res; k++) {
-        const int cu = (int)(((long long)k * ncu) / n_res);
-        res[cu / 32] |= 1u << (cu % 32);
-    }
-    for (int cu = 0; cu < ncu; cu++)
-        if (!((res[cu / 32] >> (cu % 32)) & 1u)) rest[cu / 32] |= 1u << (cu % 32);
-    HIPCHK(hipStreamSynchronize(cx().stream));
-    hipStream_t compute = nullptr, comm = nullptr;
-    HIPCHK(hipExtStreamCreateWithCUMask(&compute, (uint32_t)words, rest.data()));
-    HIPCHK(hipExtStreamCreateWithCUMask(&comm, (uint32_t)words, res.data()));
-    (void)hipStreamDestroy(cx().stream);
-    cx().stream = compute;
-    cx().lc.comm_stream = comm;
-    HIPCHK(hipEventCreateWithFlags(&cx().lc.comm_ev, hipEventDisableTiming));
-    return 0;
-}
-
 // lane k of the communicator set: lane 0 is the default lane, further lanes are created on demand
 static Ctx* comm_lane(int k) {
     while ((int)gc.lanes.size() <= k) {
@@ -1545,7 +1518,6 @@ int gkrhip_comm_init_lanes(int world, int rank, int nlanes, const uint8_t* ids /
         memcpy(&id, ids + (size_t)128 * k, 128);
         NCCLCHK(gc.p_init(&cx().lc.comm, world, id, rank));
         CHK(coll_buffers(4096));
-        CHK(lane_reserve_comm_cus());
     }
     comm_set(world, rank);
     return 0;
@@ -1783,16 +1755,9 @@ int gkrhip_comm_destroy(void) {
             if (l != &g0) ll = std::unique_lock<std::mutex>(l->mu);   // g0.mu is already held
             UseLane u(l);
             (void)hipStreamSynchronize(cx().stream);
-            if (cx().lc.comm_stream) (void)hipStreamSynchronize(cx().lc.comm_stream);
             if (cx().lc.comm) {
                 (void)gc.p_destroy(cx().lc.comm);
                 cx().lc.comm = nullptr;
-            }
-            if (cx().lc.comm_stream) {     // the lane keeps its (CU-masked) compute stream
-                (void)hipStreamDestroy(cx().lc.comm_stream);
-                (void)hipEventDestroy(cx().lc.comm_ev);
-                cx().lc.comm_stream = nullptr;
-                cx().lc.comm_ev = nullptr;
             }
             cx().lc.tick_lane = -1;
             if (cx().lc.shm) {

@@ -122,16 +122,13 @@ int coll_buffers(size_t words) {
         if (_r != ncclSuccess) return fail("%s failed: %s", #x, gc.p_errstr ? gc.p_errstr(_r) : "?"); \
     } while (0)
 
-// the stream the collective (and what follows it) runs on: the lane's, or its reserved-CU stream
-inline hipStream_t coll_stream() { return cx().lc.comm_stream ? cx().lc.comm_stream : cx().stream; }
+// the stream the collective (and what follows it) runs on: the lane's own (a reserved-CU stream for the collective was
+// measured in round 2 and removed: no gain)
+inline hipStream_t coll_stream() { return cx().stream; }
 
 // in-place sum over ranks of n u64 lanes in device memory, ordered after everything queued on the lane's stream
 int coll_allreduce(unsigned long long* d, int n) {
     if (cx().lc.comm) {
-        if (cx().lc.comm_stream) {
-            HIPCHK(hipEventRecord(cx().lc.comm_ev, cx().stream));
-            HIPCHK(hipStreamWaitEvent(cx().lc.comm_stream, cx().lc.comm_ev, 0));
-        }
         NCCLCHK(gc.p_allreduce(d, d, (size_t)n, ncclUint64, ncclSum, cx().lc.comm, coll_stream()));
         return 0;
     }
@@ -154,21 +151,11 @@ int coll_allreduce(unsigned long long* d, int n) {
     }
     return 0;
 }
-// The all-reduced words (device memory, lc.d_buf) reach the host like the un-sharded round sums: host-mapped buffer,
-// then the sequence flag the host polls.  GKRHIP_RCCL_PUBLISH=0: a one-block copy kernel (it has to find a free
-// workgroup slot behind the compute-bound rounds of the other lanes); 1: a copy + a stream memory operation
-// (hipStreamWriteValue32), both executed by the command processor / SDMA without occupying a CU.
+// The all-reduced words (device memory, lc.d_buf) reach the host like the un-sharded round sums: a one-block copy kernel
+// into the host-mapped buffer, then the sequence flag the host polls.  (A copy plus a stream memory operation executed by
+// the command processor instead of the kernel was measured in round 2: no faster, removed.)
 int coll_publish(int nwords, unsigned int seq) {
-    static const int mode = [] {
-        const char* e = getenv("GKRHIP_RCCL_PUBLISH");
-        return e ? atoi(e) : 0;
-    }();
-    if (mode == 1) {
-        HIPCHK(hipMemcpyAsync(cx().h_round, cx().lc.d_buf, sizeof(unsigned long long) * nwords, hipMemcpyDeviceToHost, coll_stream()));
-        HIPCHK(hipStreamWriteValue32(coll_stream(), cx().d_flag, seq, 0));
-        return 0;
-    }
-    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, coll_stream(), cx().lc.d_buf, cx().d_round, nwords, cx().d_flag, seq);
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, cx().stream, cx().lc.d_buf, cx().d_round, nwords, cx().d_flag, seq);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -481,10 +468,6 @@ int coll_allgather(const E* mine, int cnt, std::vector<E>& out) {
     CHK(coll_buffers(std::max<size_t>(words + mine_words, 256)));
     memcpy(cx().lc.h_buf, mine, mine_words * 8);
     HIPCHK(hipMemcpyAsync(cx().lc.d_buf + words, cx().lc.h_buf, mine_words * 8, hipMemcpyHostToDevice, cx().stream));
-    if (cx().lc.comm_stream) {
-        HIPCHK(hipEventRecord(cx().lc.comm_ev, cx().stream));
-        HIPCHK(hipStreamWaitEvent(cx().lc.comm_stream, cx().lc.comm_ev, 0));
-    }
     NCCLCHK(gc.p_allgather(cx().lc.d_buf + words, cx().lc.d_buf, mine_words, ncclUint64, cx().lc.comm, coll_stream()));
     HIPCHK(hipMemcpyAsync(cx().lc.h_buf, cx().lc.d_buf, words * 8, hipMemcpyDeviceToHost, coll_stream()));
     HIPCHK(hipStreamSynchronize(coll_stream()));

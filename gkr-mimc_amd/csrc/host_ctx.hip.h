@@ -70,11 +70,6 @@ struct LaneColl {
     size_t buf_words = 0;
     unsigned int* h_cflag = nullptr;       // host-mapped completion word of the RCCL path (written by a stream memory operation)
     unsigned int* d_cflag = nullptr;
-    // GKRHIP_COMM_CUS = n > 0 (RCCL lanes): the collective and its publish kernel run on a stream of their own that is
-    // confined to n reserved CUs, the round kernels on a stream confined to the others -- a 1-workgroup collective
-    // kernel then never queues for a workgroup slot behind the compute-bound rounds of the other lanes
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t comm_ev = nullptr;
     int tick_lane = -1;                    // >= 0: this lane exchanges through the process's ticker (host_coll.hip.h), slot tick_lane
 };
 
@@ -113,15 +108,12 @@ struct Ctx {
     bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
-    int g_lin = 0;                             // GKRHIP_GLIN: log2(max threads) of the linear-gate round kernel when above g_max (measured: no gain)
     int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
     int pyr_split = 12;                        // GKRHIP_PYR_SPLIT: the per-lane eq pyramid above 2^n entries in two launches (0: one launch)
-    int solo_med = 1;                          // GKRHIP_SOLO_MED: see threads_log2 in cipher_rounds
-    int lat_spread = 1;                        // GKRHIP_LAT_SPREAD: one workgroup per CU for small latency-bound launches
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     int host_tail = 5;                         // GKRHIP_HOST_TAIL: the rounds with at most 2^h pairs run on the host (0: never); measured: -5 % single-proof latency, +1.5 % throughput
-    int host_tail_solo = 4;                    // GKRHIP_HOST_TAIL_SOLO: the same for a proof that is alone on the GPU, whose small rounds are fast (cooperative kernel, pre-launched): bN = 20 107.6 ms against 110-112 with 5 and 111.5 with 3; GKRHIP_HOST_TAIL sets both
+    int host_tail_solo = 4;                    // the same for a proof that is alone on the GPU, whose small rounds are fast (cooperative kernel, pre-launched): bN = 20 107.6 ms against 110-112 with 5 and 111.5 with 3; GKRHIP_HOST_TAIL sets both
     int host_tail_sharded = 4;                 // GKRHIP_HOST_TAIL_SHARDED: sharded local rounds: the ranks gather the tables of the round with 2^(h+1) pairs and finish on the host (0: every local round exchanged)
     // ---- serial-latency measures of a proof that is alone on the GPU (round 3) -----------------------------------
     // pre-launched rounds: round k+1's kernel is queued before the host hashes round k and polls the challenge slot
@@ -139,9 +131,7 @@ struct Ctx {
     // speculative small rounds (cipher_spec.hip.h): round k runs for the eight candidate values 0..7 of r_{k-1} while the host
     // still hashes round k-1; the host interpolates at the true challenge
     int spec = 1;                              // GKRHIP_SPEC: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
-    int spec_max_m = 23;                       // GKRHIP_SPEC_MAX_M: spec == 1 takes layers of at most 2^n entries
-    int spec_poll = 1;                         // GKRHIP_SPEC_POLL: 1: a speculative launch is queued two rounds ahead and polls for its challenge; 0: it is launched with the challenge as an argument once the host has it
-    int spec_batch = 0;                        // GKRHIP_SPEC_BATCH: queue all speculative launches of a layer at once (0: one per round, two rounds ahead).  Same latency for one proof; with fourteen lanes the burst of launches blocked in the runtime for 20 s while a pre-launched kernel waited: off
+    int spec_max_m = 23;                       // spec == 1 takes layers of at most 2^n entries
     int spec_lg = 13;                          // GKRHIP_SPEC_LG: ... for rounds of at most 2^spec_lg pairs (eight lanes per pair: 2^16 lanes = one wave per SIMD)
     unsigned long long* h_spec = nullptr;      // host-mapped: two result buffers of GKR_SPEC_BUF_WORDS words (rounds alternate)
     unsigned long long* d_spec = nullptr;
@@ -153,7 +143,7 @@ struct Ctx {
     double dbg_defer_ms = 0;
     E spec_pts[8];                             // Montgomery forms of the candidate points 0..7
     E spec_invden[8];                          // 1 / prod_{j != i} (i - j): Lagrange denominators on the points 0..7
-    int pre_start_lg = 16;                     // GKRHIP_PRE_START_LG: the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
+    int pre_start_lg = 16;                     // the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
     hipStream_t aux = nullptr;                 // low-priority stream of the look-ahead kernel
     hipEvent_t pre_done = nullptr;
     DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()
@@ -339,28 +329,19 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_WIDE")) cx().wide_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WT_LATE_LJ")) cx().wt_late_lj = atoi(e);
     if (const char* e = getenv("GKRHIP_SOLO_BOOST")) cx().solo_boost = atoi(e);
-    if (const char* e = getenv("GKRHIP_GLIN")) cx().g_lin = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
-    if (const char* e = getenv("GKRHIP_FOLD_GRID")) cx().fold_grid = std::max(64, atoi(e));
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));   // an explicit setting holds for both
-    if (const char* e = getenv("GKRHIP_HOST_TAIL_SOLO")) cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("GKRHIP_HOST_TAIL_SHARDED")) cx().host_tail_sharded = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("GKRHIP_PYR_SPLIT")) cx().pyr_split = std::max(0, std::min(20, atoi(e)));
-    if (const char* e = getenv("GKRHIP_SOLO_MED")) cx().solo_med = atoi(e);
-    if (const char* e = getenv("GKRHIP_LAT_SPREAD")) cx().lat_spread = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
-    if (const char* e = getenv("GKRHIP_PRE_START_LG")) cx().pre_start_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_SPEC")) cx().spec = atoi(e);
-    if (const char* e = getenv("GKRHIP_SPEC_MAX_M")) cx().spec_max_m = std::max(0, std::min(40, atoi(e)));
-    if (const char* e = getenv("GKRHIP_SPEC_BATCH")) cx().spec_batch = atoi(e);
-    if (const char* e = getenv("GKRHIP_SPEC_POLL")) cx().spec_poll = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
-    if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));
+    if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));      // (the tests: several iterations per workgroup)
     cx().lag = new hfr::Lagrange();
     cx().device = dev;
     CHK(lane_alloc());
@@ -451,10 +432,6 @@ void lane_free() {
     if (cx().lc.h_buf) (void)hipHostFree(cx().lc.h_buf);
     if (cx().lc.h_tmp) (void)hipHostFree(cx().lc.h_tmp);
     if (cx().lc.h_cflag) (void)hipHostFree(cx().lc.h_cflag);
-    if (cx().lc.comm_stream) (void)hipStreamDestroy(cx().lc.comm_stream);
-    if (cx().lc.comm_ev) (void)hipEventDestroy(cx().lc.comm_ev);
-    cx().lc.comm_stream = nullptr;
-    cx().lc.comm_ev = nullptr;
     cx().lc.d_buf = cx().lc.h_buf = cx().lc.h_tmp = nullptr;
     cx().lc.h_cflag = cx().lc.d_cflag = nullptr;
     cx().lc.buf_words = 0;
@@ -478,23 +455,18 @@ void lane_configure(Ctx* l) {
     l->wide_mode = g0.wide_mode;
     l->wt_late_lj = g0.wt_late_lj;
     l->solo_boost = g0.solo_boost;
-    l->g_lin = g0.g_lin;
     l->claim_trick = g0.claim_trick;
     l->force_collective = g0.force_collective;
     l->host_tail = g0.host_tail;
     l->host_tail_solo = g0.host_tail_solo;
     l->host_tail_sharded = g0.host_tail_sharded;
     l->pyr_split = g0.pyr_split;
-    l->solo_med = g0.solo_med;
-    l->lat_spread = g0.lat_spread;
     l->prelaunch = g0.prelaunch;
     l->prelaunch_lg = g0.prelaunch_lg;
     l->pre_mode = g0.pre_mode;
     l->pre_start_lg = g0.pre_start_lg;
     l->spec = g0.spec;
     l->spec_lg = g0.spec_lg;
-    l->spec_batch = g0.spec_batch;
-    l->spec_poll = g0.spec_poll;
     l->spec_max_m = g0.spec_max_m;
     l->coop = g0.coop;
     l->coop_lg = g0.coop_lg;

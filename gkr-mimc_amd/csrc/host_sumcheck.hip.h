@@ -7,7 +7,7 @@ void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat, bool alon
     // a latency-bound launch of at most one workgroup per CU asks for enough (unused) dynamic LDS that two of its
     // workgroups cannot share a CU: the dispatcher otherwise packs some CUs with two lone-wave workgroups and leaves others idle
     // (only for a proof that is alone on the GPU: beside other proofs' kernels the extra LDS would keep the launch waiting)
-    const size_t spread = (cx().lat_spread && alone && grid <= cx().n_cu) ? (size_t)64 * 1024 : 0;
+    const size_t spread = (alone && grid <= cx().n_cu) ? (size_t)64 * 1024 : 0;
     if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), spread, cx().stream, a);
     else hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
 }
@@ -211,11 +211,8 @@ int launch_pre() {
     for (int i = 0; i < 6; i++) a.out[i] = cx().pre_t[i].planes();
     a.P = P;
     a.ark = to_dev(cx().req_ark);
-    static const size_t pre_lds = [] {            // GKRHIP_PRE_LDS_KB: the occupancy cap of the look-ahead kernel (60: two workgroups per CU)
-        const char* e = getenv("GKRHIP_PRE_LDS_KB");
-        return e ? (size_t)std::max(0, std::min(150, atoi(e))) * 1024 : (size_t)GKR_PRE_LDS;
-    }();
-    hipLaunchKernelGGL(k_cipher_pre, dim3(grid_for(P, 1 << 20)), dim3(GKR_BLOCK), pre_lds, cx().aux, a);
+    // (GKR_PRE_LDS bytes of unused dynamic LDS cap the look-ahead kernel at two workgroups per CU: it must not crowd out the round kernels)
+    hipLaunchKernelGGL(k_cipher_pre, dim3(grid_for(P, 1 << 20)), dim3(GKR_BLOCK), (size_t)GKR_PRE_LDS, cx().aux, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(cx().pre_done, cx().aux));
     cx().pre_K = K->base;
@@ -307,8 +304,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     const int g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
     auto threads_log2 = [&](int k) {                   // k = round
         const int rem = m - 1 - k;                     // log2(pairs of the round)
-        // solo_med: a proof alone on the GPU also runs the round with 2^g_big pairs one pair per lane (two waves per SIMD)
-        return rem >= g_big + (cx().solo_med ? 0 : 1) ? g_big : std::min(cx().g_max, rem);
+        // a proof alone on the GPU also runs the round with 2^g_big pairs one pair per lane (two waves per SIMD)
+        return rem >= g_big ? g_big : std::min(cx().g_max, rem);
     };
     const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
     CHK(stage_coords(q, (size_t)m));
@@ -533,7 +530,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     // 1 + (k & 1)) and store the tables of round k-1 in the other pair of buffers
     std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);      // by round
     bool spec_queued = false;                        // the layer's speculative launches are in the stream
-    auto launch_spec = [&](int k, const E* r_arg = nullptr) -> int {
+    auto launch_spec = [&](int k) -> int {
         const size_t P = n >> (k + 1);
         const int gk = m - 1 - k;
         const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
@@ -559,9 +556,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.need_m0 = claim ? 0u : 1u;
         a.prefolded = pref ? 1u : 0u;
         a.tail_tables = last ? cx().d_tail : nullptr;
-        if (!pref && r_arg) {
-            a.r = to_dev(*r_arg);                    // GKRHIP_SPEC_POLL=0: launched once r_{k-2} is known, no polling
-        } else if (!pref) {
+        if (!pref) {                                 // polls for r_{k-2} (launched with the challenge as an argument instead: measured equal or slower)
             const int slot = 1 + (k & 1);
             a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
             a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
@@ -601,14 +596,13 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
             if (next2_spec) {
-                // ALL speculative launches of the layer, now: behind R_{k+1}, whose tables the first one reads, each polling
-                // its own challenge in stream order -- and while the host is about to wait for a round of 2^(spec_lg+2) pairs
-                // anyway (launched one by one inside the speculative regime, their ~3 us each sat in the serial chain)
-                for (int kk = k + 2; kk <= (cx().spec_batch ? k_export : k + 2); kk++) CHK(launch_spec(kk));
+                // the first speculative launch of the layer: behind R_{k+1}, whose tables it reads (queueing ALL of a layer's
+                // speculative launches here was measured equal for one proof and blocked in the runtime with many lanes)
+                CHK(launch_spec(k + 2));
                 spec_queued = true;
             }
-        } else if (!cx().spec_batch && cx().spec_poll && next_spec && next2_spec) {
-            CHK(launch_spec(k + 2));                             // GKRHIP_SPEC_BATCH=0: one by one, two rounds ahead
+        } else if (next_spec && next2_spec) {
+            CHK(launch_spec(k + 2));                             // one by one, two rounds ahead: it polls for r_k
         }
         // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
         if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {
@@ -657,9 +651,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         const double t_h1 = now_ms();
         double t_l2 = t_h1;
         if (next_spec) {
-            if (next2_spec && !cx().spec_poll && !cx().spec_batch) {
-                CHK(launch_spec(k + 2, &r));                 // round k+2's speculative launch, with r_k as a launch argument
-            } else if (next2_spec) {                         // round k+2's speculative launch folds with r_k
+            if (next2_spec) {                                // round k+2's speculative launch folds with r_k
                 if (!test_fire(g_test_drop_round, k)) chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
                 chal_guard.armed = k + 2 < k_export;         // later speculative launches are still waiting for theirs
             }
@@ -893,7 +885,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
     const size_t n = (size_t)1 << m;
     const int arity = g.n_in;
     // HBM-bound rounds with a few dozen registers per lane: many more lanes than the compute-bound cipher rounds
-    const int g_lin = std::max(cx().g_max, cx().g_lin);
+    const int g_lin = cx().g_max;      // (more lanes for the HBM-bound linear rounds than for the cipher rounds: measured, no gain)
     const int gT = std::min(g_lin, m - 1);
     const int mU = m - 1 - gT;
     CHK(stage_coords(q, (size_t)m));
@@ -1019,9 +1011,9 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         return 0;
     };
     // the speculative launch of round k (see cipher_rounds): k == k_s reads the tables R_{k-1} leaves in `scratch`; later rounds
-    // read the tables of round k-2, fold them with r_{k-2} (slot 1 + (k & 1), or the launch argument) and store round k-1's
+    // read the tables of round k-2, fold them with r_{k-2} (polled from slot 1 + (k & 1)) and store round k-1's
     std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);
-    auto launch_spec = [&](int k, const E* r_arg) -> int {
+    auto launch_spec = [&](int k) -> int {
         const size_t P = n >> (k + 1);
         const int gk = m - 1 - k;
         const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
@@ -1044,9 +1036,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         a.need_m0 = claim ? 0u : 1u;
         a.prefolded = pref ? 1u : 0u;
         a.tail_tables = last ? cx().d_tail : nullptr;
-        if (!pref && r_arg) {
-            a.r = to_dev(*r_arg);
-        } else if (!pref) {
+        if (!pref) {
             const int slot = 1 + (k & 1);
             a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
             a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
@@ -1073,9 +1063,9 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         if (prelaunched && !collective) {      // see cipher_rounds
             CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
             g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
-            if (next2_spec) CHK(launch_spec(k + 2, nullptr));      // the first speculative round: behind R_{k+1}, no challenge of its own
-        } else if (cx().spec_poll && next_spec && next2_spec) {
-            CHK(launch_spec(k + 2, nullptr));                      // polls r_k
+            if (next2_spec) CHK(launch_spec(k + 2));      // the first speculative round: behind R_{k+1}, no challenge of its own
+        } else if (next_spec && next2_spec) {
+            CHK(launch_spec(k + 2));                      // polls r_k
         }
         if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {   // the next (cipher) layer's look-ahead
             CHK(launch_pre());
@@ -1111,9 +1101,7 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         co[2] = hfr::mul(a1, cm1);
         const E r = hfr::mimc_hash(co, 3);
         if (next_spec) {
-            if (next2_spec && !cx().spec_poll) {
-                CHK(launch_spec(k + 2, &r));                 // with r_k as a launch argument
-            } else if (next2_spec) {
+            if (next2_spec) {
                 chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
                 chal_guard.armed = false;
             }

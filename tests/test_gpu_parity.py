@@ -428,14 +428,12 @@ def test_speculative_small_rounds(gk):
     _run_case(dict(on, GKRHIP_HOST_TAIL="6"), "9,10,13")
     _run_case(dict(on, GKRHIP_CLAIM_TRICK="0"), "8,11")                   # M_0 from the candidates as well
     _run_case(dict(on, GKRHIP_COOP="0", GKRHIP_PRE="0"), "9,12")
-    _run_case(dict(on, GKRHIP_SPEC_POLL="0"), "8,10,13")                  # launched with the challenge as an argument instead of polling for it
-    _run_case(dict(on, GKRHIP_SPEC_BATCH="1"), "9,13")                    # all of a layer's speculative launches queued at once
     _run_case(dict(on, GKRHIP_PRE="2", GKRHIP_GMAX="8", GKRHIP_CASE_EXPECT="spec_rounds,lookahead_round0"), "11,13")
     # the GMiMC circuit: cipher layers and LINEAR layers (add, copy: k_linear_round_spec, two candidates -- their sums are linear in r)
     _run_case(dict(on, GKRHIP_HOST_TAIL="3"), "7,10", circuit="gmimc")
     _run_case(on, "9,12,13", circuit="gmimc")
     _run_case(dict(on, GKRHIP_HOST_TAIL="1", GKRHIP_SPEC_LG="6"), "5,6,8", circuit="gmimc")
-    _run_case(dict(on, GKRHIP_SPEC_POLL="0", GKRHIP_HOST_TAIL="2"), "7,11", circuit="gmimc")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="2"), "7,11", circuit="gmimc")
     _run_case(dict(on, GKRHIP_CLAIM_TRICK="0", GKRHIP_HOST_TAIL="4"), "8,10", circuit="gmimc")
     _run_case(dict(on, GKRHIP_SPEC="0", GKRHIP_CASE_EXPECT="", GKRHIP_CASE_EXPECT_NOT="spec_rounds"), "9", circuit="gmimc")
     _run_case({"GKRHIP_CASE_EXPECT": "spec_rounds,prelaunched_rounds,coop_rounds"}, "12,15")   # the defaults, alone on the GPU
@@ -453,7 +451,7 @@ def test_speculative_rounds_random_settings(gk):
     for _ in range(10):
         env = {"GKRHIP_SPEC": "2", "GKRHIP_CASE_EXPECT": "spec_rounds",
                "GKRHIP_HOST_TAIL": str(rng.randint(1, 6)), "GKRHIP_SPEC_LG": str(rng.randint(5, 16)),
-               "GKRHIP_GMAX": str(rng.choice([8, 10, 12, 16])), "GKRHIP_SPEC_POLL": str(rng.randint(0, 1)),
+               "GKRHIP_GMAX": str(rng.choice([8, 10, 12, 16])), "GKRHIP_PRELAUNCH_LG": str(rng.choice([16, 30])),
                "GKRHIP_COOP": str(rng.choice([0, 2])), "GKRHIP_PRE": str(rng.choice([0, 2])),
                "GKRHIP_CLAIM_TRICK": str(rng.choice([0, 1, 1]))}
         env["GKRHIP_SPEC_LG"] = str(max(int(env["GKRHIP_SPEC_LG"]), int(env["GKRHIP_HOST_TAIL"]) + 1))   # the export round itself qualifies

@@ -1,7 +1,7 @@
-"""One proof alone on the GPU with GKRHIP_TRACE_ROUNDS=1: the host's wait per round by round size (stderr).
+"""One proof alone on the GPU with GKRHIP_TRACE=1: the host's wait per round by round size (stderr).
 Usage: python tools/trace_rounds.py <bn> [reps]"""
 import importlib, os, sys, time
-os.environ["GKRHIP_TRACE_ROUNDS"] = "1"
+os.environ["GKRHIP_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
 import bench
@@ -10,9 +10,9 @@ gk.init(0)
 bn = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 s = gk.MimcSession(bn); s.synth_inputs(); s.assign()
 qp = bench.random_fr_array_np(bn)
-os.environ.pop("GKRHIP_TRACE_ROUNDS")
+os.environ.pop("GKRHIP_TRACE")
 for _ in range(2): s.prove(qp)
-os.environ["GKRHIP_TRACE_ROUNDS"] = "1"
+os.environ["GKRHIP_TRACE"] = "1"
 for _ in range(reps):
     gk.profile_reset(0)
     t0 = time.perf_counter(); s.prove(qp); print("prove %.2f ms" % (1e3 * (time.perf_counter() - t0)), file=sys.stderr)
