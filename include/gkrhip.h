@@ -222,7 +222,7 @@ int gkrhip_comm_init(int world, int rank, const uint8_t unique_id[128]);
 /* Same protocol with the exchange on the host: the round kernels hand their 576-byte sums to the host as in the
  * un-sharded case and the ranks add them through a POSIX shared-memory segment `name` (rank 0 creates it and
  * unlinks it once every rank has mapped it; use a name no earlier run can have left behind).  For the ranks of ONE
- * node this is the faster transport (no collective kernel queues behind the compute-bound rounds: DESIGN.md section 6);
+ * node this is the faster transport (no collective kernel queues behind the compute-bound rounds: DESIGN.md section 7);
  * it is also how several ranks time-share one GPU in the tests. */
 int gkrhip_comm_init_shm(int world, int rank, const char *name);
 /* Several lanes per rank (1..8): lane k owns its own stream, buffers and communicator (unique id k /
@@ -235,7 +235,7 @@ int gkrhip_comm_init_shm_lanes(int world, int rank, int nlanes, const char *name
 /* Several lanes over ONE RCCL communicator ("ticker"): a single thread per rank issues back-to-back all-reduces over
  * the concatenation of every lane's slot on one communicator and stream, so the order of collectives is the same on
  * every rank by construction whatever order the lanes' proofs reach their rounds in (no assumption about hardware
- * queues; DESIGN.md section 6 has the argument).  A lane's exchange completes in the first tick in which every rank
+ * queues; docs/DESIGN_rounds1-3.md section 6 has the argument).  A lane's exchange completes in the first tick in which every rank
  * contributed to its slot.  This is the multi-lane RCCL transport of bench.py. */
 int gkrhip_comm_init_tick(int world, int rank, int nlanes, const uint8_t unique_id[128]);
 /* The same ticker with the tick's all-reduce done on the host through a POSIX shared-memory segment `name` (ranks of one

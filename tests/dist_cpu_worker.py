@@ -1,5 +1,5 @@
 """Worker of the CPU multi-process test (torch.distributed, gloo, world_size >= 2): the SHARDED sumcheck
-protocol of DESIGN.md section 6 -- shard on the lowest index bits, per-round all-reduce of limb-split
+protocol of DESIGN.md section 7 -- shard on the lowest index bits, per-round all-reduce of limb-split
 lanes, gather + redundant tail rounds -- restated in Python with the oracle's arithmetic for the
 per-shard table work and the PRODUCT's host-side scalar helpers (libgkrhip.so loads without a GPU) for
 the shard weight, the lane reduction, the round coefficients and Fiat-Shamir.  Every rank checks its
