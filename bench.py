@@ -482,7 +482,10 @@ def orchestrate(args):
                 line["config"]["shm_exchange_beside"] = summary["shm"]
         sys.stdout.write(json.dumps(line) + "\n")
         sys.stdout.flush()
-    return code
+    # Only rank 0 carries the exit code.  The launcher (torch.distributed.run) kills every other rank as soon as ONE rank exits
+    # non-zero: with code 3 on all ranks the first one to get here took rank 0 down before it had printed the line (seen with
+    # eight ranks on one GPU, where every pass fails: profiles/r04_bench_8ranks_one_gpu_*).
+    return code if rank == 0 else 0
 
 
 def main():
@@ -873,7 +876,7 @@ def main():
                             "concurrent_proofs": cl, "single_proof_ms": sorted(lat)[1], "single_proof_samples_ms": lat,
                             "single_proof_hashes_per_s": float(1 << cbn) / (sorted(lat)[1] * 1e-3),
                             "proof_verified_by_native_gkr_verify": ok,
-                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES") or os.environ.get("GKRHIP_HW_QUEUES") or "16 (library default)",
                             "workload": ("gkr.Prove(MimcCircuit) at bN = 20 (BASELINE config 2)" if circ == "mimc" else
                                          "gkr.Prove(GMiMC t = 2 circuit: cipher, add and copy layers) at bN = 22 (BASELINE config 5); "
                                          "a hash here is one GMiMC compression")}

@@ -286,146 +286,327 @@ void spec_interpolate(const E* cand, const E& r, int j0, E* M) {
     }
 }
 
-// The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
-// q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
-// monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
-// eq(q_k, r_k) of every round, proof/chal hold m rounds, tail = the two remaining entries of each table
-// (K_lo, K_hi, S_lo, S_hi) and r_last the last challenge (the caller applies the final fold).
-int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, const E* q, const E& seed, bool collective,
-                  E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
-                  bool* claim_known, int gamma_tail = 0, bool* did_gamma = nullptr) {
-    const size_t n = (size_t)1 << m;
-    const double t_setup0 = now_ms();
-    // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the
-    // other lanes' kernels fill the second wave slot.  A proof that is alone on the GPU gets twice the threads for
-    // the rounds that still have two pairs per lane (two workgroups per CU instead of a lone wave per SIMD).
-    const bool solo = cx().solo_boost && !collective &&
-                      (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
-    const int g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
-    auto threads_log2 = [&](int k) {                   // k = round
-        const int rem = m - 1 - k;                     // log2(pairs of the round)
-        // a proof alone on the GPU also runs the round with 2^g_big pairs one pair per lane (two waves per SIMD)
-        return rem >= g_big ? g_big : std::min(cx().g_max, rem);
-    };
-    const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
-    CHK(stage_coords(q, (size_t)m));
-    ScopedTable pyrT, pyrU[2], pyrU2[2], ks, ss;          // pyrU[0]: split at g_max threads, pyrU[1]: at g_big; pyrU2: times 2^-128
-    const int gsplit[2] = {std::min(cx().g_max, m - 1), g_big};
-    CHK(table_alloc(&pyrT, (size_t)2 << gT));
-    CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
-    CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
-    // the per-lane pyramid (over all of q) and the per-iteration pyramids (one per thread split) in ONE launch
-    PyramidArgs3 pa3;
-    memset(&pa3, 0, sizeof pa3);
-    for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
-    // the per-lane pyramid in two steps when it is wide (GKRHIP_PYR_SPLIT, default 12): levels up to 2^12 entries and the small
-    // pyramid H over the next coordinates here, the upper levels by k_eq_pyramid_expand with one product per entry
-    const int gLow = (cx().pyr_split > 0 && gT > cx().pyr_split + 1) ? cx().pyr_split : gT;
-    ScopedTable pyrH;
-    pa3.p[0].out = pyrT.planes();
-    pa3.p[0].out2 = Planes{nullptr, nullptr};
-    pa3.p[0].q = cx().d_q;
-    pa3.p[0].nc = m;
-    pa3.p[0].max_level = gLow;
-    pa3.p[0].seed = to_dev(seed);
-    if (gLow < gT) {
-        CHK(table_alloc(&pyrH, (size_t)2 << (gT - gLow)));
-        pa3.p[3].out = pyrH.planes();
-        pa3.p[3].out2 = Planes{nullptr, nullptr};
-        pa3.p[3].q = cx().d_q;
-        pa3.p[3].nc = m - gLow;
-        pa3.p[3].max_level = gT - gLow;
-        pa3.p[3].seed = to_dev(hfr::ONE);
-    }
-    int widest = std::max(gLow, gT - gLow);            // the launch covers the widest of its pyramids
-    for (int v = 0; v < (g_big != gsplit[0] ? 2 : 1); v++) {
-        const int mU = m - 1 - gsplit[v];              // log2(iterations of round 0 at this split)
-        CHK(table_alloc(&pyrU[v], (size_t)2 << std::max(mU, 0)));
-        CHK(table_alloc(&pyrU2[v], (size_t)2 << std::max(mU, 0)));
-        if (mU > 0) {
-            PyramidArgs& pa = pa3.p[1 + v];
-            pa.out = pyrU[v].planes();
-            pa.out2 = pyrU2[v].planes();
-            pa.q = cx().d_q;
-            pa.nc = m - gsplit[v];                     // q[0 .. m-g-1]; level L = eq(q[nc-L .. nc-1], .)
-            pa.max_level = mU;
-            pa.seed = to_dev(hfr::ONE);
-            widest = std::max(widest, mU);
-        }
-    }
-    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 4), dim3(GKR_BLOCK), 0, cx().stream, pa3);
-    HIPCHK(hipGetLastError());
-    if (gLow < gT) {
-        PyramidExpandArgs xa;
-        xa.out = pyrT.planes();
-        xa.h = pyrH.cplanes();
-        xa.lo_level = gLow;
-        xa.hi_level = gT;
-        hipLaunchKernelGGL(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
-        HIPCHK(hipGetLastError());
-    }
-    // the shared accumulator and the arrival counter are zero between launches (the last workgroup of every launch
-    // resets them); only a call that failed half-way can leave them dirty
+// ---- the skeleton the two fused round loops share -------------------------------------------------------------------
+// cipher_rounds and linear_rounds differ in their kernels, in how a round's sums become coefficients and in what the host
+// tail computes; everything else -- which rounds run on the device, which kernel is queued ahead of its challenge, the
+// speculative schedule, the exchange, Fiat-Shamir, the claim, the publication of the challenge -- is this code.
+struct InFlight {
+    RoundTargets tg;
+    unsigned int seq;
+    bool derive_m0;
+};
+struct RoundPlan {
+    int m = 0;
+    int h_tail = 0;            // the host finishes the rounds with at most 2^h_tail pairs (0: every round on the device)
+    int k_export = -1;         // the round whose tables go to the host
+    int m_dev = 0;             // rounds on the device
+    int k_s = -1;              // first speculative round (-1: none); the speculative rounds are k_s .. k_export
+    bool collective = false, alone = false;
+    bool pl_on = false;        // pre-launched rounds: the next round's kernel is queued before this round is hashed and polls the challenge slot
+    bool pre_on = false;       // look-ahead of the next layer's round 0
+    bool sh_tail = false;      // sharded host tail: gather the exported tables, every rank finishes ALL remaining rounds on the host
+    bool is_spec(int k) const { return k_s >= 0 && k >= k_s && k <= k_export; }
+};
+// `tables`: tables the layer folds (what a sharded host tail gathers is tables * 2^(h+1) entries per rank);
+// `h_unsharded`: depth of the host tail of an un-sharded layer (GKRHIP_HOST_TAIL; the sharded local rounds exchange
+// device-produced words, so there the tail exists only as the gather of round 3: one gather instead of h + 1 exchanged rounds)
+inline RoundPlan plan_rounds(int m, bool collective, int gamma_tail, bool* did_gamma, int tables, int h_unsharded) {
+    RoundPlan p;
+    p.m = m;
+    p.collective = collective;
+    p.alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    const int hs = cx().host_tail_sharded;
+    p.sh_tail = collective && gamma_tail > 0 && did_gamma && hs > 0 && m >= hs + 2 && (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0) &&
+                sharded_tail_pays(tables * (2 << hs), hs);
+    const int h_want = collective ? (p.sh_tail ? hs : 0) : h_unsharded;
+    p.h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
+    if (did_gamma) *did_gamma = false;
+    p.k_export = p.h_tail ? m - 2 - p.h_tail : -1;
+    p.m_dev = p.h_tail ? p.k_export + 1 : m;
+    p.pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && p.alone));
+    p.pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && p.alone));
+    return p;
+}
+// Speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the candidate values of r_{k-1} while the host hashes
+// round k-1.  They need the pre-launched rounds (the launches they ride behind) and the host tail (their export), and start at
+// the first round of at most 2^spec_lg pairs that runs one pair per lane.
+// (spec == 1: only while the look-ahead kernel of the next layer is small -- at 2^24 entries it needs the whole idle time of the
+// small rounds: bN = 24 measured 279.5 -> 281..285 ms with speculation, bN = 23 200.4 -> 198.3, bN = 22 155 -> 150, bN = 20 109 -> 104)
+template <class F>
+void plan_speculation(RoundPlan& p, bool export_fits, F&& one_pair_per_lane) {
+    if (!((cx().spec >= 2 || (cx().spec == 1 && p.alone && p.m <= cx().spec_max_m)) && !p.collective && p.pl_on && p.h_tail > 0 && export_fits)) return;
+    for (int k = 2; k <= p.k_export && p.k_s < 0; k++)
+        if (p.m - 1 - k <= cx().spec_lg && one_pair_per_lane(k)) p.k_s = k;
+}
+// zero accumulators at the start of a round loop: they are zero between launches (the last workgroup of every launch resets
+// them); only a call that failed half-way can leave them dirty
+int rounds_begin(bool collective) {
     if (cx().racc_dirty) {
         HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
         HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
         if (cx().d_spec_racc) HIPCHK(hipMemsetAsync(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS, cx().stream));
     }
-    cx().racc_dirty = true;                            // until this call has run to its end
+    cx().racc_dirty = true;                            // until the loop has run to its end
     if (collective) CHK(coll_buffers(256));
+    return 0;
+}
+// the challenge slot of a kernel queued ahead of its challenge (slot 0: the pre-launched round kernels; 1, 2: the speculative ones)
+template <class A>
+void arm_challenge_wait(A& a, int slot, ChalGuard& guard) {
+    a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
+    a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
+    a.chal_seq = a.seq;
+    guard.armed = true;
+    cx().dbg_defer_seq = a.seq;
+    cx().dbg_defer_ms = now_ms();
+}
 
-    static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
+// The loop.  L supplies the layer's own parts:
+//   NCOEF                          coefficients of a round polynomial (9 | 3); NSUM / NTAIL: words exchanged / tail words of a hand-off
+//   launch_round(k, deferred, r, derive_m0, &out)   queue round k's kernel (deferred: it takes r_{k-1} from the challenge slot)
+//   launch_spec(k), spec_seq[k], spec_flag(k)       the speculative launch of round k and where its result lands
+//   coefficients(k, this_spec, derive_m0, sums, co) the round polynomial from the sums (or from the candidates at chal[k-1])
+//   finish_round(k, this_spec, r, &r_prev)          tail words of the last round; export + host tail at k == k_export
+template <class L>
+int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
+    const int m = pl.m;
+    const bool collective = pl.collective;
+    const E two128 = {{0, 0, 1, 0}};                 // the plain integer 2^128: a Montgomery product with it divides by 2^128
     E r_prev = hfr::ZERO;
-    // GKRHIP_HOST_TAIL = h > 0: the device runs the rounds down to 2^(h+1) pairs, exports that round's tables and the
-    // host finishes (un-sharded rounds only: the sharded local rounds exchange device-produced words)
-    const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
-    // Sharded (round 3): the host tail exists too.  The ranks gather the tables the export round leaves (2^h entries per
-    // table and rank after the fold) and every rank finishes ALL remaining rounds -- the h local ones and the log2(world)
-    // rounds over the shard bits (q[m .. m + gamma_tail)) -- on the gathered tables of 2^h * world entries: one gather
-    // instead of h + 1 exchanged device rounds and the per-layer gather of phase 2.
-    const bool sh_tail = collective && gamma_tail > 0 && did_gamma && cx().host_tail_sharded > 0 && m >= cx().host_tail_sharded + 2 &&
-                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0) &&
-                         sharded_tail_pays(2 * (2 << cx().host_tail_sharded), cx().host_tail_sharded);      // K and S: 2^(h+1) entries each
-    const int h_want = collective ? (sh_tail ? cx().host_tail_sharded : 0) : (alone ? cx().host_tail_solo : cx().host_tail);
-    const int h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
-    if (did_gamma) *did_gamma = false;
-    const int k_export = h_tail ? m - 2 - h_tail : -1;      // round whose tables go to the host
-    const int m_dev = h_tail ? k_export + 1 : m;             // rounds on the device
-    // pre-launched rounds: the next round's kernel is queued before this round is hashed and polls the challenge slot
-    const bool pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));
-    const bool pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone));
-    if (pre_on) CHK(pre_prepare());                  // nothing of this lane is waiting for the host yet
-    const bool coop_on = cx().coop >= 2 || (cx().coop == 1 && alone);
-    // speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the eight candidate values of r_{k-1} while the
-    // host hashes round k-1.  Needs the pre-launched rounds (the launches it rides behind) and the host tail (its export).
-    int k_s = -1;
-    // (spec == 1: only while the look-ahead kernel of the next layer is small -- at 2^24 entries it needs the whole idle
-    // time of the small rounds, and eight candidates' worth of lanes beside it cost what the waits they remove were worth,
-    // whenever the look-ahead starts: bN = 24 measured 279.5 -> 281..285 ms, bN = 23 200.4 -> 198.3, bN = 22 155 -> 150,
-    // bN = 20 109 -> 104)
-    if ((cx().spec >= 2 || (cx().spec == 1 && alone && m <= cx().spec_max_m)) && !collective && pl_on && h_tail > 0) {
-        for (int k = 2; k <= k_export && k_s < 0; k++) {
-            const int rem = m - 1 - k;               // log2(pairs of round k)
-            if (rem <= cx().spec_lg && threads_log2(k) == rem) k_s = k;     // one pair per lane
-        }
+    InFlight cur, nxt;
+    bool spec_queued = false;                        // the layer's first speculative launch is in the stream
+    {
+        const double t_l0 = now_ms();
+        cx().prof.setup_ms += t_l0 - t_setup0;
+        CHK(lp.launch_round(0, false, hfr::ZERO, lp.claim && *lp.claim_known, &cur));
+        cx().prof.host_launch_ms += now_ms() - t_l0;
     }
-    auto is_spec = [&](int k) { return k_s >= 0 && k >= k_s && k <= k_export; };
-    ScopedTable ks2, ss2;                            // the speculative launches alternate between (ks, ss) and these
-    if (k_s >= 0) {
-        CHK(spec_ensure());
-        if (k_s < k_export) {
-            CHK(table_alloc(&ks2, (size_t)4 << (m - 1 - (k_s + 1))));      // round k_s + 1 stores the tables of round k_s: 4 P entries
-            CHK(table_alloc(&ss2, (size_t)4 << (m - 1 - (k_s + 1))));
+    bool pre_requested = cx().req_K != nullptr && pl.pre_on;
+    for (int k = 0; k < pl.m_dev; k++) {
+        const size_t P = lp.n >> (k + 1);
+        const double t_l0 = now_ms();
+        // round k+1 queued now, behind round k's kernel: its dispatch overlaps the hash below
+        const bool have_next = k + 1 < pl.m_dev;
+        const bool this_spec = pl.is_spec(k), next_spec = pl.is_spec(k + 1), next2_spec = pl.is_spec(k + 2);
+        // (the round before the first speculative one is always pre-launched: the speculative launch rides behind it)
+        const bool prelaunched = have_next && !next_spec && pl.pl_on && ((P >> 1) <= ((size_t)1 << cx().prelaunch_lg) || next2_spec);
+        // Un-sharded: queued BEFORE waiting for round k (the launch call itself is hidden behind round k's kernel).
+        // Sharded: AFTER the exchange of round k -- the kernel then only ever spins for the duration of this rank's own
+        // hash, never for a peer that is seconds behind (ranks reach the first exchange of a proof at different times),
+        // and over RCCL it stays behind the all-reduce and the publish kernel in stream order.
+        if (prelaunched && !collective) {
+            CHK(lp.launch_round(k + 1, true, hfr::ZERO, lp.claim != nullptr, &nxt));
+            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+            if (next2_spec) {
+                // the first speculative launch of the layer: behind R_{k+1}, whose tables it reads; no challenge of its own
+                // (queueing ALL of a layer's speculative launches here was measured equal for one proof and blocked in the
+                // runtime with many lanes)
+                CHK(lp.launch_spec(k + 2));
+                spec_queued = true;
+            }
+        } else if (next_spec && next2_spec) {
+            CHK(lp.launch_spec(k + 2));                          // one by one, two rounds ahead: it polls for r_k
         }
+        // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
+        if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == pl.m_dev - 1)) {
+            CHK(launch_pre());
+            pre_requested = false;
+        }
+        // test hook: an error return while a kernel is waiting for its challenge -- the guard must tell it to leave, drain
+        // the stream and clear the abort tags
+        if ((prelaunched || (next_spec && next2_spec)) && test_fire(g_test_fail_round, k))   // (a speculative launch waits for r_k)
+            return fail("injected failure after a pre-launch (test hook)");
+        const double t_l1 = now_ms();
+        unsigned long long summed[GKR_CR_WORDS + 1];
+        static_assert(L::NSUM <= GKR_CR_WORDS, "exchange scratch");
+        const unsigned long long* sums = nullptr;
+        if (this_spec) CHK(wait_flag(lp.spec_seq[k], lp.spec_flag(k)));
+        else CHK(round_collect(collective, cur.tg, cur.seq, L::NSUM, L::NTAIL, summed, &sums));
+        const double t_w = now_ms();
+        if (prelaunched && collective) {
+            CHK(lp.launch_round(k + 1, true, hfr::ZERO, lp.claim != nullptr, &nxt));
+            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
+        }
+        const bool derive_m0 = this_spec ? lp.claim != nullptr : cur.derive_m0;
+        E* co = lp.proof + (size_t)k * L::NCOEF;
+        lp.coefficients(k, this_spec, derive_m0, sums, co);
+        const double t_h0 = now_ms();
+        const E r = hfr::mimc_hash(co, L::NCOEF);
+        const double t_h1 = now_ms();
+        double t_l2 = t_h1;
+        if (next_spec) {
+            if (next2_spec) {                                // round k+2's speculative launch folds with r_k
+                if (!test_fire(g_test_drop_round, k)) chal_publish(lp.spec_seq[k + 2], r, r, 1 + (k & 1));
+                lp.chal_guard.armed = k + 2 < pl.k_export;   // later speculative launches will still wait for theirs
+            }
+        } else if (prelaunched) {
+            if (!test_fire(g_test_drop_round, k)) chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
+            lp.chal_guard.armed = spec_queued && pl.k_s < pl.k_export;      // (the speculative launches behind it wait for their own)
+            cur = nxt;
+        } else if (have_next) {
+            CHK(lp.launch_round(k + 1, false, r, lp.claim != nullptr, &nxt));
+            cur = nxt;
+            t_l2 = now_ms();
+        }
+        lp.chal[k] = r;
+        lp.c = hfr::mul(lp.c, hfr::eval_eq(&lp.q[k], &r, 1));
+        r_prev = r;
+        if (lp.claim) {   // next round's claim = P_k(r_k)
+            *lp.claim = hfr::eval_univariate(co, L::NCOEF, r);
+            *lp.claim_known = true;
+        }
+        CHK(lp.finish_round(k, this_spec, r, &r_prev));
+        cx().prof.host_launch_ms += (t_l1 - t_l0) + (t_l2 - t_h1);
+        cx().prof.host_wait_ms += t_w - t_l1;
+        {
+            int lg = 0;
+            while (((size_t)1 << lg) < P) lg++;
+            cx().prof.wait_lg[lg] += t_w - t_l1;
+            cx().prof.cnt_lg[lg]++;
+        }
+        cx().prof.host_other_ms += t_h0 - t_w;
+        cx().prof.host_hash_ms += t_h1 - t_h0;
+        cx().prof.rounds++;
     }
+    if (pre_requested) CHK(launch_pre());      // no round was small enough: still ahead of the next layer's pyramids
+    lp.r_last = r_prev;
+    const double t_end0 = now_ms();
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    cx().racc_dirty = false;
+    cx().prof.setup_ms += now_ms() - t_end0;
+    (void)m;
+    return 0;
+}
+
+// The rounds of a single-point cipher sumcheck over tables K, S of 2^m entries (m >= 1) and coordinates
+// q[0:m].  `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the
+// monomial sums are all-reduced across ranks before the host reads them.  On return: c has absorbed
+// eq(q_k, r_k) of every round, proof/chal hold m rounds, tail = the two remaining entries of each table
+// (K_lo, K_hi, S_lo, S_hi) and r_last the last challenge (the caller applies the final fold).
+struct CipherLoop {
+    static const int NCOEF = 9, NSUM = GKR_CR_WORDS, NTAIL = 16;
+    // the call
+    const E& ark;
+    const int m;
+    const DevTable *K, *S;
+    const E* q;
+    const E& seed;
+    const bool collective;
+    E& c;
+    E *proof, *chal, *tail;
+    E& r_last;
+    E* claim;                  // running claim, or nullptr
+    bool* claim_known;
+    const int gamma_tail;
+    bool* did_gamma;
+    // the loop's state
+    const size_t n;
+    RoundPlan pl;
+    int g_big = 0, gsplit[2] = {0, 0};
+    ScopedTable pyrT, pyrH, pyrU[2], pyrU2[2], ks, ss, ks2, ss2;      // pyrU[0]: split at g_max threads, pyrU[1]: at g_big; pyrU2: times 2^-128; (ks2, ss2): the speculative launches alternate between (ks, ss) and these
     ChalGuard chal_guard;
-    struct InFlight {
-        RoundTargets tg;
-        unsigned int seq;
-        bool derive_m0;
-    };
+    std::vector<unsigned int> spec_seq;              // by round
+    bool coop_on = false;
+
+    CipherLoop(const E& ark_, int m_, const DevTable* K_, const DevTable* S_, const E* q_, const E& seed_, bool collective_, E& c_, E* proof_,
+               E* chal_, E* tail_, E& r_last_, E* claim_, bool* claim_known_, int gamma_tail_, bool* did_gamma_)
+        : ark(ark_), m(m_), K(K_), S(S_), q(q_), seed(seed_), collective(collective_), c(c_), proof(proof_), chal(chal_), tail(tail_),
+          r_last(r_last_), claim(claim_), claim_known(claim_known_), gamma_tail(gamma_tail_), did_gamma(did_gamma_), n((size_t)1 << m_),
+          spec_seq((size_t)m_ + 2, 0u) {}
+
+    void release_tables() {      // the stream is idle (run_rounds synchronised it)
+        for (ScopedTable* t : {&pyrT, &pyrH, &pyrU[0], &pyrU[1], &pyrU2[0], &pyrU2[1], &ks, &ss, &ks2, &ss2})
+            if (t->base) table_release(t);
+    }
+    // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the other lanes'
+    // kernels fill the second wave slot.  A proof that is alone on the GPU gets twice the threads for the rounds that still
+    // have two pairs per lane, and runs the round with 2^g_big pairs one pair per lane (two waves per SIMD).
+    int threads_log2(int k) const {
+        const int rem = m - 1 - k;                     // log2(pairs of the round)
+        return rem >= g_big ? g_big : std::min(cx().g_max, rem);
+    }
+    volatile unsigned int* spec_flag(int k) const {
+        return (volatile unsigned int*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS + GKR_SPEC_FLAG_WORD);
+    }
+
+    // pyramids (the eq weights, never a table of 2^m entries), scratch tables, accumulators, the plan of the rounds
+    int setup() {
+        const bool solo = cx().solo_boost && !collective &&
+                          (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
+        g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
+        const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
+        CHK(stage_coords(q, (size_t)m));
+        gsplit[0] = std::min(cx().g_max, m - 1);
+        gsplit[1] = g_big;
+        CHK(table_alloc(&pyrT, (size_t)2 << gT));
+        CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
+        CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
+        // the per-lane pyramid (over all of q) and the per-iteration pyramids (one per thread split) in ONE launch
+        PyramidArgs3 pa3;
+        memset(&pa3, 0, sizeof pa3);
+        for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
+        // the per-lane pyramid in two steps when it is wide (GKRHIP_PYR_SPLIT, default 12): levels up to 2^12 entries and the small
+        // pyramid H over the next coordinates here, the upper levels by k_eq_pyramid_expand with one product per entry
+        const int gLow = (cx().pyr_split > 0 && gT > cx().pyr_split + 1) ? cx().pyr_split : gT;
+        pa3.p[0].out = pyrT.planes();
+        pa3.p[0].out2 = Planes{nullptr, nullptr};
+        pa3.p[0].q = cx().d_q;
+        pa3.p[0].nc = m;
+        pa3.p[0].max_level = gLow;
+        pa3.p[0].seed = to_dev(seed);
+        if (gLow < gT) {
+            CHK(table_alloc(&pyrH, (size_t)2 << (gT - gLow)));
+            pa3.p[3].out = pyrH.planes();
+            pa3.p[3].out2 = Planes{nullptr, nullptr};
+            pa3.p[3].q = cx().d_q;
+            pa3.p[3].nc = m - gLow;
+            pa3.p[3].max_level = gT - gLow;
+            pa3.p[3].seed = to_dev(hfr::ONE);
+        }
+        int widest = std::max(gLow, gT - gLow);            // the launch covers the widest of its pyramids
+        for (int v = 0; v < (g_big != gsplit[0] ? 2 : 1); v++) {
+            const int mU = m - 1 - gsplit[v];              // log2(iterations of round 0 at this split)
+            CHK(table_alloc(&pyrU[v], (size_t)2 << std::max(mU, 0)));
+            CHK(table_alloc(&pyrU2[v], (size_t)2 << std::max(mU, 0)));
+            if (mU > 0) {
+                PyramidArgs& pa = pa3.p[1 + v];
+                pa.out = pyrU[v].planes();
+                pa.out2 = pyrU2[v].planes();
+                pa.q = cx().d_q;
+                pa.nc = m - gsplit[v];                     // q[0 .. m-g-1]; level L = eq(q[nc-L .. nc-1], .)
+                pa.max_level = mU;
+                pa.seed = to_dev(hfr::ONE);
+                widest = std::max(widest, mU);
+            }
+        }
+        hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 4), dim3(GKR_BLOCK), 0, cx().stream, pa3);
+        HIPCHK(hipGetLastError());
+        if (gLow < gT) {
+            PyramidExpandArgs xa;
+            xa.out = pyrT.planes();
+            xa.h = pyrH.cplanes();
+            xa.lo_level = gLow;
+            xa.hi_level = gT;
+            hipLaunchKernelGGL(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(rounds_begin(collective));
+        pl = plan_rounds(m, collective, gamma_tail, did_gamma, 2, g_proofs_in_flight.load(std::memory_order_relaxed) <= 1 ? cx().host_tail_solo : cx().host_tail);
+        if (pl.pre_on) CHK(pre_prepare());               // nothing of this lane is waiting for the host yet
+        coop_on = cx().coop >= 2 || (cx().coop == 1 && pl.alone);
+        plan_speculation(pl, true, [&](int k) { return threads_log2(k) == m - 1 - k; });
+        if (pl.k_s >= 0) {
+            CHK(spec_ensure());
+            if (pl.k_s < pl.k_export) {
+                CHK(table_alloc(&ks2, (size_t)4 << (m - 1 - (pl.k_s + 1))));      // round k_s + 1 stores the tables of round k_s: 4 P entries
+                CHK(table_alloc(&ss2, (size_t)4 << (m - 1 - (pl.k_s + 1))));
+            }
+        }
+        return 0;
+    }
+
     // queue round k's kernel; `deferred`: r_prev is not known yet, the kernel takes it from the challenge slot
-    auto launch_round = [&](int k, bool deferred, const E& r_in, bool derive_m0, InFlight* out) -> int {
+    int launch_round(int k, bool deferred, const E& r_in, bool derive_m0, InFlight* out) {
         const size_t P = n >> (k + 1);
         const int gk = threads_log2(k);
         const int lj = m - 1 - k - gk;                 // log2(iterations)
@@ -450,7 +631,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.ark = to_dev(ark);
         a.partials = cx().d_racc;
         a.counter = cx().d_counter;
-        a.tail_tables = k == k_export ? cx().d_tail : nullptr;
+        a.tail_tables = k == pl.k_export ? cx().d_tail : nullptr;
         out->tg = round_targets(collective);
         a.host_out = out->tg.out;
         a.host_flag = out->tg.flag;
@@ -458,13 +639,8 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         out->derive_m0 = derive_m0;
         a.need_m0 = derive_m0 ? 0u : 1u;
         if (deferred) {
-            a.chal = cx().d_chal;
-            a.chal_dev = cx().d_chal_dev;
-            a.chal_seq = a.seq;
-            a.chal_limit_s = collective && !host_exchange() ? 20u : 0u;          // no retry across ranks on the device-side exchange: a generous limit there
-            chal_guard.armed = true;
-            cx().dbg_defer_seq = a.seq;
-            cx().dbg_defer_ms = now_ms();
+            arm_challenge_wait(a, 0, chal_guard);
+            a.chal_limit_s = collective && !host_exchange() ? 20u : 0u;      // no retry across ranks on the device-side exchange: a generous limit there
         } else {
             const E two128 = {{0, 0, 1, 0}};                 // the plain integer 2^128: mul divides by 2^256
             a.r = to_dev(r_in);
@@ -475,7 +651,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         hipEvent_t e0 = nullptr, e1 = nullptr;
         // interleaved-pair (latency) variant for the rounds with one pair per lane; GKRHIP_LAT=0 never, 2 always
         const bool lat = cx().lat_mode == 2 || (cx().lat_mode == 1 && lj == 0);
-        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat && k != k_export;   // only the plain kernels export
+        const bool wide = cx().wide_mode && lj > 0 && derive_m0 && !lat && k != pl.k_export;   // only the plain kernels export
         const bool late = wide && lj >= cx().wt_late_lj;  // the lane weight multiplies the sums after the loop: 8 products per lane
         // small rounds of a proof that is alone on the GPU: eight lanes per pair (cipher_coop.hip.h)
         const bool coop = coop_on && lj == 0 && P <= ((size_t)1 << cx().coop_lg);
@@ -510,11 +686,11 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
                 else hipLaunchKernelGGL((k_cipher_round_wide<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             }
         } else if (fold) {
-            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat, alone);
-            else launch_cipher_round<true, false>(a, grid, lat, alone);
+            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat, pl.alone);
+            else launch_cipher_round<true, false>(a, grid, lat, pl.alone);
         } else {
-            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat, alone);
-            else launch_cipher_round<false, false>(a, grid, lat, alone);
+            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat, pl.alone);
+            else launch_cipher_round<false, false>(a, grid, lat, pl.alone);
         }
         HIPCHK(hipGetLastError());
         if (timed) {
@@ -524,16 +700,16 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
             cx().prof.peval_modmuls += ((derive_m0 ? 17.0 : 18.0) + (lj > 0 && !late ? 1.0 : 0.0) + (fold ? 4.0 : 0.0)) * (double)P;
         }
         return 0;
-    };
+    }
+
     // queue the speculative launch of round k (k_s <= k <= k_export).  k == k_s reads the tables R_{k-1} leaves in (ks, ss)
     // and needs no challenge; later rounds read the tables of round k-2, fold them with r_{k-2} (polled from slot
-    // 1 + (k & 1)) and store the tables of round k-1 in the other pair of buffers
-    std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);      // by round
-    bool spec_queued = false;                        // the layer's speculative launches are in the stream
-    auto launch_spec = [&](int k) -> int {
+    // 1 + (k & 1); launched with the challenge as an argument instead: measured equal or slower) and store the tables of
+    // round k-1 in the other pair of buffers
+    int launch_spec(int k) {
         const size_t P = n >> (k + 1);
         const int gk = m - 1 - k;
-        const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
+        const bool pref = k == pl.k_s, odd = ((k - pl.k_s) & 1) != 0, last = k == pl.k_export;
         CipherSpecArgs a;
         memset(&a, 0, sizeof a);
         const ScopedTable& srcK = (pref || odd) ? ks : ks2;
@@ -556,84 +732,26 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         a.need_m0 = claim ? 0u : 1u;
         a.prefolded = pref ? 1u : 0u;
         a.tail_tables = last ? cx().d_tail : nullptr;
-        if (!pref) {                                 // polls for r_{k-2} (launched with the challenge as an argument instead: measured equal or slower)
-            const int slot = 1 + (k & 1);
-            a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
-            a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
-            a.chal_seq = a.seq;
-            chal_guard.armed = true;
-            cx().dbg_defer_seq = a.seq;
-            cx().dbg_defer_ms = now_ms();
-        }
+        if (!pref) arm_challenge_wait(a, 1 + (k & 1), chal_guard);
         const int gx = (int)std::max<size_t>(P / GKR_BLOCK, 1);
         const bool row8 = !pref || last;             // the fold-and-store row (a plain copy to the host when the tables are folded already)
         hipLaunchKernelGGL(k_cipher_round_spec, dim3(gx, row8 ? GKR_SPEC_CAND + 1 : GKR_SPEC_CAND), dim3(GKR_BLOCK), 0, cx().stream, a);
         HIPCHK(hipGetLastError());
         g_cnt_spec.fetch_add(1, std::memory_order_relaxed);
         return 0;
-    };
-    InFlight cur, nxt;
-    {
-        const double t_l0 = now_ms();
-        cx().prof.setup_ms += t_l0 - t_setup0;
-        CHK(launch_round(0, false, hfr::ZERO, claim && *claim_known, &cur));
-        cx().prof.host_launch_ms += now_ms() - t_l0;
     }
-    bool pre_requested = cx().req_K != nullptr && pre_on;
-    for (int k = 0; k < m_dev; k++) {
-        const size_t P = n >> (k + 1);
-        const double t_l0 = now_ms();
-        // round k+1 queued now, behind round k's kernel: its dispatch overlaps the hash below
-        const bool have_next = k + 1 < m_dev;
-        const bool next_spec = is_spec(k + 1), next2_spec = is_spec(k + 2);
-        // (the round before the first speculative one is always pre-launched: the speculative launch rides behind it)
-        const bool prelaunched = have_next && !next_spec && pl_on && ((P >> 1) <= ((size_t)1 << cx().prelaunch_lg) || next2_spec);
-        // Un-sharded: queued BEFORE waiting for round k (the launch call itself is hidden behind round k's kernel).
-        // Sharded: AFTER the exchange of round k -- the kernel then only ever spins for the duration of this rank's own
-        // hash, never for a peer that is seconds behind (ranks reach the first exchange of a proof at different times),
-        // and over RCCL it stays behind the all-reduce and the publish kernel in stream order.
-        if (prelaunched && !collective) {
-            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
-            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
-            if (next2_spec) {
-                // the first speculative launch of the layer: behind R_{k+1}, whose tables it reads (queueing ALL of a layer's
-                // speculative launches here was measured equal for one proof and blocked in the runtime with many lanes)
-                CHK(launch_spec(k + 2));
-                spec_queued = true;
-            }
-        } else if (next_spec && next2_spec) {
-            CHK(launch_spec(k + 2));                             // one by one, two rounds ahead: it polls for r_k
-        }
-        // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
-        if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {
-            CHK(launch_pre());
-            pre_requested = false;
-        }
-        // test hook (GKRHIP_TEST_FAIL_AFTER_PRELAUNCH=k, once per process): an error return while a pre-launched kernel is
-        // waiting for its challenge -- the guard must tell it to leave, drain the stream and clear the abort tags
-        if ((prelaunched || (next_spec && next2_spec)) && test_fire(g_test_fail_round, k))   // (a speculative launch waits for r_k)
-            return fail("injected failure after a pre-launch (test hook)");
-        const double t_l1 = now_ms();
-        const unsigned long long* words = cx().h_round;
-        unsigned long long summed[GKR_CR_WORDS + 1];
-        const unsigned long long* sums = nullptr;
-        const bool this_spec = is_spec(k);
-        const unsigned long long* cand = cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS;
-        if (this_spec) CHK(wait_flag(spec_seq[k], (volatile unsigned int*)(cand + GKR_SPEC_FLAG_WORD)));
-        else CHK(round_collect(collective, cur.tg, cur.seq, GKR_CR_WORDS, 16, summed, &sums));
-        const double t_w = now_ms();
-        if (prelaunched && collective) {
-            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
-            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
-        }
-        const bool derive_m0 = this_spec ? claim != nullptr : cur.derive_m0;
-        // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
-        // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
-        // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
+
+    // S_k(t) = sum_j C(7,j) M_j t^j ;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t)
+    // csp[j] = c_k * C(7,j) * M_j.  With a known claim, P_k(0) + P_k(1) = claim_k gives
+    // c_k*M_0 = claim_k - q_k * sum_{j>=1} csp[j] (the verifier's round check, sumcheck/verifier.go:41-47).
+    void coefficients(int k, bool this_spec, bool derive_m0, const unsigned long long* sums, E* co) const {
+        static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
         E csp[8], Mj[8];
-        if (this_spec) spec_interpolate((const E*)cand, chal[k - 1], derive_m0 ? 1 : 0, Mj);      // the candidates at the true r_{k-1}
-        else
+        if (this_spec) {     // the candidates at the true r_{k-1}
+            spec_interpolate((const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS), chal[k - 1], derive_m0 ? 1 : 0, Mj);
+        } else {
             for (int j = derive_m0 ? 1 : 0; j < 8; j++) Mj[j] = limbs9_to_fr(sums + (size_t)j * GKR_ACC_WORDS);
+        }
         for (int j = derive_m0 ? 1 : 0; j < 8; j++) csp[j] = hfr::mul(c, hfr::mul(Mj[j], hfr::from_u64(binom7[j])));
         if (derive_m0) {
             E rest = csp[1];
@@ -642,115 +760,75 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
         }
         const E a0 = hfr::sub(hfr::ONE, q[k]);
         const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
-        E* co = proof + (size_t)k * 9;
         co[0] = hfr::mul(a0, csp[0]);
         for (int j = 1; j < 8; j++) co[j] = hfr::add(hfr::mul(a0, csp[j]), hfr::mul(a1, csp[j - 1]));
         co[8] = hfr::mul(a1, csp[7]);
-        const double t_h0 = now_ms();
-        const E r = hfr::mimc_hash(co, 9);
-        const double t_h1 = now_ms();
-        double t_l2 = t_h1;
-        if (next_spec) {
-            if (next2_spec) {                                // round k+2's speculative launch folds with r_k
-                if (!test_fire(g_test_drop_round, k)) chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
-                chal_guard.armed = k + 2 < k_export;         // later speculative launches are still waiting for theirs
+    }
+
+    // after round k's challenge: the tail words of the last device round; at k == k_export the exported tables folded with
+    // this round's challenge are the host's starting point (GKRHIP_HOST_TAIL)
+    int finish_round(int k, bool this_spec, const E& r, E* r_prev) {
+        const size_t P = n >> (k + 1);
+        if (k == m - 1) memcpy(tail, cx().h_round + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
+        if (k != pl.k_export) return 0;
+        const E* tt = (const E*)cx().h_tail;
+        std::vector<E> Kh(P), Sh(P);
+        if (this_spec) {
+            // the speculative launch exported the tables of round k-1 (4P entries each): two folds on the host
+            const E& r1 = chal[k - 1];
+            for (size_t x = 0; x < P; x++) {
+                Kh[x] = fold2(fold2(tt[x], tt[x + 2 * P], r1), fold2(tt[x + P], tt[x + 3 * P], r1), r);
+                Sh[x] = fold2(fold2(tt[4 * P + x], tt[4 * P + x + 2 * P], r1), fold2(tt[4 * P + x + P], tt[4 * P + x + 3 * P], r1), r);
             }
-        } else if (prelaunched) {
-            const E two128 = {{0, 0, 1, 0}};
-            if (!test_fire(g_test_drop_round, k))
-                chal_publish(nxt.seq, r, hfr::mul(r, two128));   // the waiting kernel starts its fold
-            chal_guard.armed = spec_queued && k_s < k_export;    // (the speculative launches behind it wait for their own)
-            cur = nxt;
-        } else if (have_next) {
-            CHK(launch_round(k + 1, false, r, claim != nullptr, &nxt));
-            cur = nxt;
-            t_l2 = now_ms();
-        }
-        chal[k] = r;
-        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
-        r_prev = r;
-        if (claim) {   // next round's claim = P_k(r_k)
-            *claim = hfr::eval_univariate(co, 9, r);
-            *claim_known = true;
-        }
-        if (k == m - 1) memcpy(tail, words + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
-        if (k == k_export) {
-            // the exported tables (2P entries each) folded with this round's challenge are the host's starting point
-            const E* tt = (const E*)cx().h_tail;
-            std::vector<E> Kh(P), Sh(P);
-            if (this_spec) {
-                // the speculative launch exported the tables of round k-1 (4P entries each): two folds on the host
-                const E& r1 = chal[k - 1];
-                for (size_t x = 0; x < P; x++) {
-                    Kh[x] = fold2(fold2(tt[x], tt[x + 2 * P], r1), fold2(tt[x + P], tt[x + 3 * P], r1), r);
-                    Sh[x] = fold2(fold2(tt[4 * P + x], tt[4 * P + x + 2 * P], r1), fold2(tt[4 * P + x + P], tt[4 * P + x + 3 * P], r1), r);
-                }
-            } else
+        } else {
             for (size_t x = 0; x < P; x++) {
                 Kh[x] = fold2(tt[x], tt[x + P], r);
                 Sh[x] = fold2(tt[2 * P + x], tt[3 * P + x], r);
             }
-            const int mm = m - 1 - k;                  // variables left
-            const double t_t0 = now_ms(), h_before = cx().prof.host_hash_ms;
-            if (sh_tail) {
-                // gather every rank's P + P folded entries; global index = local index * world + rank (the shard bits are
-                // the LOWEST index bits, bound last), eq weights over all remaining coordinates with seed 1
-                const ShardView sv = shard_view();
-                std::vector<E> mine(2 * P), all;
+        }
+        const int mm = m - 1 - k;                  // variables left
+        const double t_t0 = now_ms(), h_before = cx().prof.host_hash_ms;
+        if (pl.sh_tail) {
+            // gather every rank's P + P folded entries; global index = local index * world + rank (the shard bits are
+            // the LOWEST index bits, bound last), eq weights over all remaining coordinates with seed 1
+            const ShardView sv = shard_view();
+            std::vector<E> mine(2 * P), all;
+            for (size_t x = 0; x < P; x++) {
+                mine[x] = Kh[x];
+                mine[P + x] = Sh[x];
+            }
+            CHK(coll_allgather(mine.data(), (int)(2 * P), all));
+            std::vector<E> Kg(P * sv.world), Sg(P * sv.world);
+            for (int g = 0; g < sv.world; g++)
                 for (size_t x = 0; x < P; x++) {
-                    mine[x] = Kh[x];
-                    mine[P + x] = Sh[x];
+                    Kg[x * sv.world + g] = all[(size_t)g * 2 * P + x];
+                    Sg[x * sv.world + g] = all[(size_t)g * 2 * P + P + x];
                 }
-                CHK(coll_allgather(mine.data(), (int)(2 * P), all));
-                std::vector<E> Kg(P * sv.world), Sg(P * sv.world);
-                for (int g = 0; g < sv.world; g++)
-                    for (size_t x = 0; x < P; x++) {
-                        Kg[x * sv.world + g] = all[(size_t)g * 2 * P + x];
-                        Sg[x * sv.world + g] = all[(size_t)g * 2 * P + P + x];
-                    }
-                host_cipher_rounds(ark, mm + gamma_tail, Kg, Sg, q + k + 1, hfr::ONE, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim,
-                                   claim_known);
-                tail[0] = tail[1] = Kg[0];
-                tail[2] = tail[3] = Sg[0];
-                r_prev = chal[m + gamma_tail - 1];
-                *did_gamma = true;
-            } else {
+            host_cipher_rounds(ark, mm + gamma_tail, Kg, Sg, q + k + 1, hfr::ONE, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim,
+                               claim_known);
+            tail[0] = tail[1] = Kg[0];
+            tail[2] = tail[3] = Sg[0];
+            *r_prev = chal[m + gamma_tail - 1];
+            *did_gamma = true;
+        } else {
             host_cipher_rounds(ark, mm, Kh, Sh, q + k + 1, seed, c, proof + (size_t)9 * (k + 1), chal + k + 1, claim, claim_known);
             // hand back in the shape the device path uses: the caller folds (lo, hi) with r_last
             tail[0] = tail[1] = Kh[0];
             tail[2] = tail[3] = Sh[0];
-            r_prev = chal[m - 1];
-            }
-            cx().prof.tail_ms += (now_ms() - t_t0) - (cx().prof.host_hash_ms - h_before);
+            *r_prev = chal[m - 1];
         }
-        cx().prof.host_launch_ms += (t_l1 - t_l0) + (t_l2 - t_h1);
-        cx().prof.host_wait_ms += t_w - t_l1;
-        {
-            int lg = 0;
-            while (((size_t)1 << lg) < P) lg++;
-            cx().prof.wait_lg[lg] += t_w - t_l1;
-            cx().prof.cnt_lg[lg]++;
-        }
-        cx().prof.host_other_ms += t_h0 - t_w;
-        cx().prof.host_hash_ms += t_h1 - t_h0;
-        cx().prof.rounds++;
+        cx().prof.tail_ms += (now_ms() - t_t0) - (cx().prof.host_hash_ms - h_before);
+        return 0;
     }
-    if (pre_requested) CHK(launch_pre());      // no round was small enough: still ahead of the next layer's pyramids
-    r_last = r_prev;
-    const double t_end0 = now_ms();
-    HIPCHK(hipStreamSynchronize(cx().stream));
-    cx().racc_dirty = false;
-    cx().prof.setup_ms += now_ms() - t_end0;
-    table_release(&pyrT);
-    if (pyrH.base) table_release(&pyrH);
-    for (int v = 0; v < 2; v++) {
-        if (pyrU[v].base) table_release(&pyrU[v]);
-        if (pyrU2[v].base) table_release(&pyrU2[v]);
-    }
-    table_release(&ks);
-    table_release(&ss);
-    if (ks2.base) table_release(&ks2);
-    if (ss2.base) table_release(&ss2);
+};
+int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, const E* q, const E& seed, bool collective,
+                  E& c, E* proof, E* chal, E tail[4], E& r_last, E* claim /* running claim, or nullptr */,
+                  bool* claim_known, int gamma_tail = 0, bool* did_gamma = nullptr) {
+    const double t_setup0 = now_ms();
+    CipherLoop lp(ark, m, K, S, q, seed, collective, c, proof, chal, tail, r_last, claim, claim_known, gamma_tail, did_gamma);
+    CHK(lp.setup());
+    CHK(run_rounds(lp, lp.pl, t_setup0));
+    lp.release_tables();      // (scoped tables: an error return releases them too, after draining the stream)
     return 0;
 }
 
@@ -878,85 +956,91 @@ void host_linear_rounds(const GateDesc& g, const E& ark, int mm, std::vector<std
 // `seed` multiplies every eq weight (the shard weight; 1 on one GPU); with `collective` the two sums are added over the
 // ranks before the host reads them.  On return: c has absorbed eq(q_k, r_k) of every round, proof/chal hold m rounds
 // of 3 coefficients, tail[2t], tail[2t+1] = the two remaining entries of table t and r_last the last challenge (the
-// caller applies the final fold).
-int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const* X, const E* q, const E& seed, bool collective,
-                  E& c, E* proof, E* chal, E* tail, E& r_last, E* claim /* running claim, or nullptr */, bool* claim_known,
-                  int gamma_tail = 0, bool* did_gamma = nullptr) {
-    const size_t n = (size_t)1 << m;
-    const int arity = g.n_in;
-    // HBM-bound rounds with a few dozen registers per lane: many more lanes than the compute-bound cipher rounds
-    const int g_lin = cx().g_max;      // (more lanes for the HBM-bound linear rounds than for the cipher rounds: measured, no gain)
-    const int gT = std::min(g_lin, m - 1);
-    const int mU = m - 1 - gT;
-    CHK(stage_coords(q, (size_t)m));
-    ScopedTable pyrT, pyrU, scratch[GKR_MAX_ARITY];
-    CHK(table_alloc(&pyrT, (size_t)2 << gT));
-    CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
-    for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
-    PyramidArgs3 pa3;
-    memset(&pa3, 0, sizeof pa3);
-    for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
-    pa3.p[0].out = pyrT.planes();
-    pa3.p[0].q = cx().d_q;
-    pa3.p[0].nc = m;
-    pa3.p[0].max_level = gT;
-    pa3.p[0].seed = to_dev(seed);
-    if (mU > 0) {
-        pa3.p[1].out = pyrU.planes();
-        pa3.p[1].q = cx().d_q;
-        pa3.p[1].nc = m - gT;
-        pa3.p[1].max_level = mU;
-        pa3.p[1].seed = to_dev(hfr::ONE);
+// caller applies the final fold).  The loop itself is run_rounds (shared with the cipher rounds).
+struct LinearLoop {
+    static const int NCOEF = 3, NSUM = GKR_LR_WORDS, NTAIL = 8 * GKR_MAX_ARITY;
+    const GateDesc& g;
+    const E& ark;
+    const int m;
+    const DevTable* const* X;
+    const E* q;
+    const E& seed;
+    const bool collective;
+    E& c;
+    E *proof, *chal, *tail;
+    E& r_last;
+    E* claim;
+    bool* claim_known;
+    const int gamma_tail;
+    bool* did_gamma;
+    const size_t n;
+    const int arity;
+    RoundPlan pl;
+    int g_lin = 0;             // log2(max threads): as the cipher rounds (more lanes for these HBM-bound rounds: measured, no gain)
+    ScopedTable pyrT, pyrU, scratch[GKR_MAX_ARITY], scratch2[GKR_MAX_ARITY];
+    ChalGuard chal_guard;
+    std::vector<unsigned int> spec_seq;
+
+    LinearLoop(const GateDesc& g_, const E& ark_, int m_, const DevTable* const* X_, const E* q_, const E& seed_, bool collective_, E& c_,
+               E* proof_, E* chal_, E* tail_, E& r_last_, E* claim_, bool* claim_known_, int gamma_tail_, bool* did_gamma_)
+        : g(g_), ark(ark_), m(m_), X(X_), q(q_), seed(seed_), collective(collective_), c(c_), proof(proof_), chal(chal_), tail(tail_),
+          r_last(r_last_), claim(claim_), claim_known(claim_known_), gamma_tail(gamma_tail_), did_gamma(did_gamma_), n((size_t)1 << m_),
+          arity(g_.n_in), spec_seq((size_t)m_ + 2, 0u) {}
+
+    volatile unsigned int* spec_flag(int k) const {
+        return (volatile unsigned int*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS + GKR_SPEC_FLAG_WORD);
     }
-    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(gT, mU), 1 << 20), 3), dim3(GKR_BLOCK), 0,
-                       cx().stream, pa3);
-    HIPCHK(hipGetLastError());
-    if (cx().racc_dirty) {   // see cipher_rounds
-        HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
-        HIPCHK(hipMemsetAsync(cx().d_counter, 0, sizeof(unsigned int), cx().stream));
-        if (cx().d_spec_racc) HIPCHK(hipMemsetAsync(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS, cx().stream));
-    }
-    cx().racc_dirty = true;
-    if (collective) CHK(coll_buffers(256));
-    const E two128 = {{0, 0, 1, 0}};
-    E r_prev = hfr::ZERO;
-    // sharded host tail: see cipher_rounds
-    const bool sh_tail = collective && gamma_tail > 0 && did_gamma && cx().host_tail_sharded > 0 && m >= cx().host_tail_sharded + 2 &&
-                         (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0) &&
-                         sharded_tail_pays(arity * (2 << cx().host_tail_sharded), cx().host_tail_sharded);
-    const int h_want = collective ? (sh_tail ? cx().host_tail_sharded : 0) : cx().host_tail;
-    const int h_tail = (h_want > 0 && m >= h_want + 2) ? std::min(h_want, kHostTailMax) : 0;
-    if (did_gamma) *did_gamma = false;
-    const int k_export = h_tail ? m - 2 - h_tail : -1;      // see cipher_rounds
-    const int m_dev = h_tail ? k_export + 1 : m;
-    const bool alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
-    const bool pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && alone));   // see cipher_rounds
-    const bool pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && alone));
-    if (pre_on) CHK(pre_prepare());                  // see cipher_rounds
-    // speculative rounds (cipher_spec.hip.h, k_linear_round_spec): the two sums of a linear gate's round are linear in the
-    // previous challenge, so the candidates 0 and 1 -- the lower and the upper half of the previous round's tables -- suffice
-    int k_s = -1;
-    if ((cx().spec >= 2 || (cx().spec == 1 && alone && m <= cx().spec_max_m)) && !collective && pl_on && h_tail > 0 &&
-        (size_t)arity * 4 * 4 * ((size_t)2 << h_tail) <= kTailWords) {        // the export: 4P entries per table, P = 2^(h+1)
-        for (int k = 2; k <= k_export && k_s < 0; k++) {
-            const int rem = m - 1 - k;
-            if (rem <= cx().spec_lg && std::min(g_lin, rem) == rem) k_s = k;
+
+    void release_tables() {
+        table_release(&pyrT);
+        table_release(&pyrU);
+        for (int t = 0; t < arity; t++) {
+            table_release(&scratch[t]);
+            if (scratch2[t].base) table_release(&scratch2[t]);
         }
     }
-    auto is_spec = [&](int k) { return k_s >= 0 && k >= k_s && k <= k_export; };
-    ScopedTable scratch2[GKR_MAX_ARITY];
-    if (k_s >= 0) {
-        CHK(spec_ensure());
-        if (k_s < k_export)
-            for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch2[t], (size_t)4 << (m - 1 - (k_s + 1))));
+    int setup() {
+        g_lin = cx().g_max;
+        const int gT = std::min(g_lin, m - 1);
+        const int mU = m - 1 - gT;
+        CHK(stage_coords(q, (size_t)m));
+        CHK(table_alloc(&pyrT, (size_t)2 << gT));
+        CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
+        for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
+        PyramidArgs3 pa3;
+        memset(&pa3, 0, sizeof pa3);
+        for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
+        pa3.p[0].out = pyrT.planes();
+        pa3.p[0].q = cx().d_q;
+        pa3.p[0].nc = m;
+        pa3.p[0].max_level = gT;
+        pa3.p[0].seed = to_dev(seed);
+        if (mU > 0) {
+            pa3.p[1].out = pyrU.planes();
+            pa3.p[1].q = cx().d_q;
+            pa3.p[1].nc = m - gT;
+            pa3.p[1].max_level = mU;
+            pa3.p[1].seed = to_dev(hfr::ONE);
+        }
+        hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(gT, mU), 1 << 20), 3), dim3(GKR_BLOCK), 0,
+                           cx().stream, pa3);
+        HIPCHK(hipGetLastError());
+        CHK(rounds_begin(collective));
+        pl = plan_rounds(m, collective, gamma_tail, did_gamma, arity, cx().host_tail);
+        if (pl.pre_on) CHK(pre_prepare());
+        // speculative rounds (k_linear_round_spec): the two sums of a linear gate's round are linear in the previous challenge, so
+        // the candidates 0 and 1 -- the lower and the upper half of the previous round's tables -- suffice.  The export must fit
+        // the hand-off buffer: 4P entries per table, P = 2^(h+1)
+        plan_speculation(pl, (size_t)arity * 4 * 4 * ((size_t)2 << pl.h_tail) <= kTailWords, [&](int k) { return std::min(g_lin, m - 1 - k) == m - 1 - k; });
+        if (pl.k_s >= 0) {
+            CHK(spec_ensure());
+            if (pl.k_s < pl.k_export)
+                for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch2[t], (size_t)4 << (m - 1 - (pl.k_s + 1))));
+        }
+        return 0;
     }
-    ChalGuard chal_guard;
-    struct InFlight {
-        RoundTargets tg;
-        unsigned int seq;
-        bool derive_m0;
-    };
-    auto launch_round = [&](int k, bool deferred, const E& r_in, bool derive_m0, InFlight* out) -> int {
+
+    int launch_round(int k, bool deferred, const E& r_in, bool derive_m0, InFlight* out) {
         const size_t P = n >> (k + 1);
         const int gk = std::min(g_lin, m - 1 - k);
         const int lj = m - 1 - k - gk;
@@ -975,27 +1059,23 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         }
         a.P = P;
         a.lg_threads = (unsigned)gk;
-        if (deferred) {
-            chal_guard.armed = true;
-        } else {
-            a.r = to_dev(r_in);
-            a.r_lo = to_dev(hfr::mul(r_in, two128));
-        }
         a.ark = to_dev(ark);
         a.arity = arity;
         a.sum_mask = g.mask;
         a.racc = cx().d_racc;
         a.counter = cx().d_counter;
-        a.tail_tables = k == k_export ? cx().d_tail : nullptr;
+        a.tail_tables = k == pl.k_export ? cx().d_tail : nullptr;
         out->tg = round_targets(collective);
         a.host_out = out->tg.out;
         a.host_flag = out->tg.flag;
         a.seq = out->seq = ++cx().seq;
         if (deferred) {
-            a.chal = cx().d_chal;
-            a.chal_dev = cx().d_chal_dev;
-            a.chal_seq = a.seq;
-            a.chal_limit_s = collective && !host_exchange() ? 20u : 0u;
+            arm_challenge_wait(a, 0, chal_guard);
+            a.chal_limit_s = collective && !host_exchange() ? 20u : 0u;      // see CipherLoop::launch_round
+        } else {
+            const E two128 = {{0, 0, 1, 0}};
+            a.r = to_dev(r_in);
+            a.r_lo = to_dev(hfr::mul(r_in, two128));
         }
         out->derive_m0 = derive_m0;
         a.need_m0 = derive_m0 ? 0u : 1u;
@@ -1009,14 +1089,14 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         }
         HIPCHK(hipGetLastError());
         return 0;
-    };
-    // the speculative launch of round k (see cipher_rounds): k == k_s reads the tables R_{k-1} leaves in `scratch`; later rounds
-    // read the tables of round k-2, fold them with r_{k-2} (polled from slot 1 + (k & 1)) and store round k-1's
-    std::vector<unsigned int> spec_seq((size_t)m + 2, 0u);
-    auto launch_spec = [&](int k) -> int {
+    }
+
+    // the speculative launch of round k (see CipherLoop::launch_spec): k == k_s reads the tables R_{k-1} leaves in `scratch`; later
+    // rounds read the tables of round k-2, fold them with r_{k-2} (polled from slot 1 + (k & 1)) and store round k-1's
+    int launch_spec(int k) {
         const size_t P = n >> (k + 1);
         const int gk = m - 1 - k;
-        const bool pref = k == k_s, odd = ((k - k_s) & 1) != 0, last = k == k_export;
+        const bool pref = k == pl.k_s, odd = ((k - pl.k_s) & 1) != 0, last = k == pl.k_export;
         LinearSpecArgs a;
         memset(&a, 0, sizeof a);
         for (int t = 0; t < arity; t++) {
@@ -1036,54 +1116,20 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         a.need_m0 = claim ? 0u : 1u;
         a.prefolded = pref ? 1u : 0u;
         a.tail_tables = last ? cx().d_tail : nullptr;
-        if (!pref) {
-            const int slot = 1 + (k & 1);
-            a.chal = cx().d_chal + (size_t)slot * GKR_CHAL_WORDS;
-            a.chal_dev = cx().d_chal_dev + (size_t)slot * GKR_CHAL_WORDS;
-            a.chal_seq = a.seq;
-            chal_guard.armed = true;
-            cx().dbg_defer_seq = a.seq;
-            cx().dbg_defer_ms = now_ms();
-        }
+        if (!pref) arm_challenge_wait(a, 1 + (k & 1), chal_guard);
         const int gx = (int)std::max<size_t>(P / GKR_BLOCK, 1);
         hipLaunchKernelGGL(k_linear_round_spec, dim3(gx, (!pref || last) ? GKR_LSPEC_CAND + 1 : GKR_LSPEC_CAND), dim3(GKR_BLOCK), 0,
                            cx().stream, a);
         HIPCHK(hipGetLastError());
         g_cnt_spec.fetch_add(1, std::memory_order_relaxed);
         return 0;
-    };
-    InFlight cur, nxt;
-    CHK(launch_round(0, false, hfr::ZERO, claim && *claim_known, &cur));
-    bool pre_requested = cx().req_K != nullptr && pre_on;
-    for (int k = 0; k < m_dev; k++) {
-        const size_t P = n >> (k + 1);
-        const bool have_next = k + 1 < m_dev;
-        const bool next_spec = is_spec(k + 1), next2_spec = is_spec(k + 2), this_spec = is_spec(k);
-        const bool prelaunched = have_next && !next_spec && pl_on && ((P >> 1) <= ((size_t)1 << cx().prelaunch_lg) || next2_spec);
-        if (prelaunched && !collective) {      // see cipher_rounds
-            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
-            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
-            if (next2_spec) CHK(launch_spec(k + 2));      // the first speculative round: behind R_{k+1}, no challenge of its own
-        } else if (next_spec && next2_spec) {
-            CHK(launch_spec(k + 2));                      // polls r_k
-        }
-        if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == m_dev - 1)) {   // the next (cipher) layer's look-ahead
-            CHK(launch_pre());
-            pre_requested = false;
-        }
-        unsigned long long summed[GKR_LR_WORDS + 1];
-        const unsigned long long* sums = nullptr;
-        const E* cand = (const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS);      // M_0(0), M_1(0), M_0(1), M_1(1)
-        if (this_spec) CHK(wait_flag(spec_seq[k], (volatile unsigned int*)((const unsigned long long*)cand + GKR_SPEC_FLAG_WORD)));
-        else CHK(round_collect(collective, cur.tg, cur.seq, GKR_LR_WORDS, 8 * GKR_MAX_ARITY, summed, &sums));
-        if (prelaunched && collective) {
-            CHK(launch_round(k + 1, true, hfr::ZERO, claim != nullptr, &nxt));
-            g_cnt_prelaunched.fetch_add(1, std::memory_order_relaxed);
-        }
-        const bool derive_m0 = this_spec ? claim != nullptr : cur.derive_m0;
-        // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
+    }
+
+    // S_k(t) = M_0 + M_1 t;  P_k(t) = c_k * ((1-q_k) + (2 q_k - 1) t) * S_k(t);  c_k*M_0 = claim_k - q_k*c_k*M_1
+    void coefficients(int k, bool this_spec, bool derive_m0, const unsigned long long* sums, E* co) const {
         E M0 = hfr::ZERO, M1;
         if (this_spec) {                         // linear in the previous challenge: M(r) = M(0) + r (M(1) - M(0))
+            const E* cand = (const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS);      // M_0(0), M_1(0), M_0(1), M_1(1)
             const E& r1 = chal[k - 1];
             M1 = hfr::add(cand[1], hfr::mul(r1, hfr::sub(cand[3], cand[1])));
             if (!derive_m0) M0 = hfr::add(cand[0], hfr::mul(r1, hfr::sub(cand[2], cand[0])));
@@ -1095,77 +1141,59 @@ int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const*
         const E cm0 = derive_m0 ? hfr::sub(*claim, hfr::mul(q[k], cm1)) : hfr::mul(c, M0);
         const E a0 = hfr::sub(hfr::ONE, q[k]);
         const E a1 = hfr::sub(hfr::add(q[k], q[k]), hfr::ONE);
-        E* co = proof + (size_t)k * 3;
         co[0] = hfr::mul(a0, cm0);
         co[1] = hfr::add(hfr::mul(a0, cm1), hfr::mul(a1, cm0));
         co[2] = hfr::mul(a1, cm1);
-        const E r = hfr::mimc_hash(co, 3);
-        if (next_spec) {
-            if (next2_spec) {
-                chal_publish(spec_seq[k + 2], r, r, 1 + (k & 1));
-                chal_guard.armed = false;
-            }
-        } else if (prelaunched) {
-            chal_publish(nxt.seq, r, hfr::mul(r, two128));
-            chal_guard.armed = false;
-            cur = nxt;
-        } else if (have_next) {
-            CHK(launch_round(k + 1, false, r, claim != nullptr, &nxt));
-            cur = nxt;
-        }
-        chal[k] = r;
-        c = hfr::mul(c, hfr::eval_eq(&q[k], &r, 1));
-        r_prev = r;
-        if (claim) {
-            *claim = hfr::eval_univariate(co, 3, r);
-            *claim_known = true;
-        }
+    }
+
+    int finish_round(int k, bool this_spec, const E& r, E* r_prev) {
+        const size_t P = n >> (k + 1);
         if (k == m - 1) memcpy(tail, cx().h_round + GKR_LR_WORDS, (size_t)2 * arity * sizeof(E));   // written by the P == 1 launch
-        cx().prof.rounds++;
-        if (k == k_export) {
-            const E* tt = (const E*)cx().h_tail;
-            std::vector<std::vector<E>> Th(arity, std::vector<E>(P));
-            if (this_spec) {                     // the speculative launch exported the tables of round k-1 (4P entries each)
-                const E& r1 = chal[k - 1];
-                for (int t = 0; t < arity; t++) {
-                    const E* tb = tt + (size_t)t * 4 * P;
-                    for (size_t x = 0; x < P; x++)
-                        Th[t][x] = fold2(fold2(tb[x], tb[x + 2 * P], r1), fold2(tb[x + P], tb[x + 3 * P], r1), r);
-                }
-            } else
+        if (k != pl.k_export) return 0;
+        const E* tt = (const E*)cx().h_tail;
+        std::vector<std::vector<E>> Th(arity, std::vector<E>(P));
+        if (this_spec) {                     // the speculative launch exported the tables of round k-1 (4P entries each)
+            const E& r1 = chal[k - 1];
+            for (int t = 0; t < arity; t++) {
+                const E* tb = tt + (size_t)t * 4 * P;
+                for (size_t x = 0; x < P; x++)
+                    Th[t][x] = fold2(fold2(tb[x], tb[x + 2 * P], r1), fold2(tb[x + P], tb[x + 3 * P], r1), r);
+            }
+        } else {
             for (int t = 0; t < arity; t++)
                 for (size_t x = 0; x < P; x++) Th[t][x] = fold2(tt[(size_t)t * 2 * P + x], tt[(size_t)t * 2 * P + x + P], r);
-            if (sh_tail) {
-                const ShardView sv = shard_view();
-                std::vector<E> mine((size_t)arity * P), all;
+        }
+        if (pl.sh_tail) {
+            const ShardView sv = shard_view();
+            std::vector<E> mine((size_t)arity * P), all;
+            for (int t = 0; t < arity; t++)
+                for (size_t x = 0; x < P; x++) mine[(size_t)t * P + x] = Th[t][x];
+            CHK(coll_allgather(mine.data(), (int)((size_t)arity * P), all));
+            std::vector<std::vector<E>> Tg(arity, std::vector<E>(P * sv.world));
+            for (int gr = 0; gr < sv.world; gr++)
                 for (int t = 0; t < arity; t++)
-                    for (size_t x = 0; x < P; x++) mine[(size_t)t * P + x] = Th[t][x];
-                CHK(coll_allgather(mine.data(), (int)((size_t)arity * P), all));
-                std::vector<std::vector<E>> Tg(arity, std::vector<E>(P * sv.world));
-                for (int gr = 0; gr < sv.world; gr++)
-                    for (int t = 0; t < arity; t++)
-                        for (size_t x = 0; x < P; x++) Tg[t][x * sv.world + gr] = all[(size_t)gr * arity * P + (size_t)t * P + x];
-                host_linear_rounds(g, ark, m - 1 - k + gamma_tail, Tg, q + k + 1, hfr::ONE, c, proof + (size_t)3 * (k + 1), chal + k + 1, claim,
-                                   claim_known);
-                for (int t = 0; t < arity; t++) tail[2 * t] = tail[2 * t + 1] = Tg[t][0];
-                r_prev = chal[m + gamma_tail - 1];
-                *did_gamma = true;
-            } else {
+                    for (size_t x = 0; x < P; x++) Tg[t][x * sv.world + gr] = all[(size_t)gr * arity * P + (size_t)t * P + x];
+            host_linear_rounds(g, ark, m - 1 - k + gamma_tail, Tg, q + k + 1, hfr::ONE, c, proof + (size_t)3 * (k + 1), chal + k + 1, claim,
+                               claim_known);
+            for (int t = 0; t < arity; t++) tail[2 * t] = tail[2 * t + 1] = Tg[t][0];
+            *r_prev = chal[m + gamma_tail - 1];
+            *did_gamma = true;
+        } else {
             host_linear_rounds(g, ark, m - 1 - k, Th, q + k + 1, seed, c, proof + (size_t)3 * (k + 1), chal + k + 1, claim, claim_known);
             for (int t = 0; t < arity; t++) tail[2 * t] = tail[2 * t + 1] = Th[t][0];
-            r_prev = chal[m - 1];
-            }
+            *r_prev = chal[m - 1];
         }
+        return 0;
     }
-    if (pre_requested) CHK(launch_pre());
-    r_last = r_prev;
-    HIPCHK(hipStreamSynchronize(cx().stream));
-    cx().racc_dirty = false;
-    table_release(&pyrT);
-    table_release(&pyrU);
-    for (int t = 0; t < arity; t++) table_release(&scratch[t]);
-    for (int t = 0; t < arity; t++)
-        if (scratch2[t].base) table_release(&scratch2[t]);
+};
+int linear_rounds(const GateDesc& g, const E& ark, int m, const DevTable* const* X, const E* q, const E& seed, bool collective,
+                  E& c, E* proof, E* chal, E* tail, E& r_last, E* claim /* running claim, or nullptr */, bool* claim_known,
+                  int gamma_tail = 0, bool* did_gamma = nullptr) {
+    const double t_setup0 = now_ms();
+    LinearLoop lp(g, ark, m, X, q, seed, collective, c, proof, chal, tail, r_last, claim, claim_known, gamma_tail, did_gamma);
+    CHK(lp.setup());
+    CHK(run_rounds(lp, lp.pl, t_setup0));
+    lp.release_tables();
     return 0;
 }
 

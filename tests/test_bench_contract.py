@@ -55,6 +55,22 @@ def test_bench_line_contract():
         assert c["fr_mul_isolated_ns"]["nocarry_unrolled"]["independent"] > 0
         sp = d["single_proof"]
         assert sp["prelaunched_rounds"] > 0 and sp["lookahead_round0"] > 0 and sp["coop_rounds"] > 0
+    if "msm_g1_2p22" in d.get("micro", {}):      # round 4: the Groth16 pieces of SURVEY 8 f4 in the driver-run line
+        assert r["traffic"] is None or "not measured in this run" in r["traffic_source"]      # the PMC figure is labelled as the builder's
+        for key, lg in (("msm_g1_2p20", 20), ("msm_g1_2p22", 22)):
+            e = d["micro"][key]
+            assert abs(e["points_per_s"] - (1 << lg) / (e["ms"] * 1e-3)) / e["points_per_s"] < 1e-6
+            assert e["windows"] == -(-255 // e["window_bits"]) and abs(sum(e["phases_ms"].values()) - e["ms"]) < 0.1 * e["ms"]
+            acc = e["accumulate"]
+            lp = acc["loop_instructions_per_addition"]
+            assert lp["v_mad_u64_u32"] == 8 * 128 + 2 * 100        # one mixed addition: 8 products + 2 squarings, nothing else in the loop
+            assert lp["vector"] == lp["half_rate"] + lp["full_rate"] and 0 < acc["frac"] <= 1
+            assert acc["mixed_additions"] == e["windows"] * (1 << lg)
+        h = d["micro"]["compute_h_2p24"]
+        assert h["passes"] == 9 and 0 < h["frac_of_hbm_peak"] < 1 and h["ms"] <= 16.0          # <= 16 ms at 2^24
+        assert abs(h["field_products_per_s"] - h["field_products"] / (h["ms"] * 1e-3)) / h["field_products_per_s"] < 1e-6
+        for key in ("bn20", "gmimc_bn22"):
+            assert "hw_queues" in d["configs"][key]
         assert "spec_rounds" not in sp or sp["spec_rounds"] == 0       # bN = 24: the speculative rounds stay off by their size limit
 
 
