@@ -32,8 +32,8 @@ LOOP_KERNELS = {"round0": "k_cipher_round_wideILb0ELb1ELb0E", "fold_late": "k_ci
                 "fold_early": "k_cipher_round_wideILb1ELb0ELb0E", "round0_pre": "k_cipher_round_wideILb0ELb1ELb1E",
                 # the bucket accumulation of the MSM: its INNERMOST loop is one mixed addition in the common case (the first
                 # point of a bucket and the doubling / cancellation cases leave it: g1.hip.h)
-                "msm_accumulate": "16k_msm_accumulate7MsmArgs"}
-INNERMOST = ("msm_accumulate",)
+                "msm_accumulate": "k_msm_accumulateI3FpFE", "msm_accumulate_g2": "k_msm_accumulateI4Fp2FE"}
+INNERMOST = ("msm_accumulate", "msm_accumulate_g2")
 
 
 def source_sha():

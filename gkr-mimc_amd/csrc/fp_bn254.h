@@ -111,3 +111,28 @@ FR_HD bool fp_eq_raw(const Fp& a, const Fp& b) {
     for (int j = 0; j < 8; j++) d |= a.v[j] ^ b.v[j];
     return d == 0;
 }
+
+// ---- Fp2 = Fp[u] / (u^2 + 1): the coordinates of G2 (gnark-crypto's fptower.E2 {A0, A1}) ------------------------------
+// Components stay in the lazy range [0, 2p) like every Fp value here.
+struct Fp2 {
+    Fp a0, a1;
+};
+FR_HD Fp2 fp2_zero() { return Fp2{fp_zero(), fp_zero()}; }
+FR_HD Fp2 fp2_one() { return Fp2{fp_one(), fp_zero()}; }
+FR_HD Fp2 fp2_add(const Fp2& a, const Fp2& b) { return Fp2{fp_add(a.a0, b.a0), fp_add(a.a1, b.a1)}; }
+FR_HD Fp2 fp2_sub(const Fp2& a, const Fp2& b) { return Fp2{fp_sub(a.a0, b.a0), fp_sub(a.a1, b.a1)}; }
+FR_HD Fp2 fp2_dbl(const Fp2& a) { return Fp2{fp_dbl(a.a0), fp_dbl(a.a1)}; }
+FR_HD Fp2 fp2_neg(const Fp2& a) { return Fp2{fp_neg(a.a0), fp_neg(a.a1)}; }
+FR_HD Fp2 fp2_canon(const Fp2& a) { return Fp2{fp_canon(a.a0), fp_canon(a.a1)}; }
+FR_HD bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.a0) && fp_is_zero(a.a1); }
+// Karatsuba: three Fp products
+FR_HD Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
+    const Fp v0 = fp_mul(a.a0, b.a0), v1 = fp_mul(a.a1, b.a1);
+    const Fp s = fp_mul(fp_add(a.a0, a.a1), fp_add(b.a0, b.a1));
+    return Fp2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+}
+// (a0 + a1)(a0 - a1) + 2 a0 a1 u: two Fp products
+FR_HD Fp2 fp2_sqr(const Fp2& a) {
+    const Fp c0 = fp_mul(fp_add(a.a0, a.a1), fp_sub(a.a0, a.a1));
+    return Fp2{c0, fp_dbl(fp_mul(a.a0, a.a1))};
+}

@@ -110,58 +110,115 @@ static inline E inv(const E& a) {        // a^(p-2); 0 -> 0
     return r;
 }
 
-struct Aff {
-    E x, y;        // infinity = (0, 0), gnark-crypto's encoding
+// Fp2 = Fp[u] / (u^2 + 1): the coordinates of G2 (fptower.E2 {A0, A1})
+struct E2 {
+    E a0, a1;
+    bool operator==(const E2& o) const { return a0 == o.a0 && a1 == o.a1; }
 };
-struct XYZZ {
-    E x, y, zz, zzz;      // infinity: zz = 0
+// field policies of the curve code below (the host twins of FpF / Fp2F in g1.hip.h)
+struct HFp {
+    typedef E T;
+    static const int LIMBS64 = 4;
+    static T zero() { return ZERO; }
+    static T one() { return ONE; }
+    static T mul(const T& a, const T& b) { return hfp::mul(a, b); }
+    static T sqr(const T& a) { return hfp::sqr(a); }
+    static T add(const T& a, const T& b) { return hfp::add(a, b); }
+    static T sub(const T& a, const T& b) { return hfp::sub(a, b); }
+    static T dbl(const T& a) { return hfp::dbl(a); }
+    static bool is_zero(const T& a) { return hfp::is_zero(a); }
+    static T inv(const T& a) { return hfp::inv(a); }
+    static T b_curve() { return add(add(ONE, ONE), ONE); }      // y^2 = x^3 + 3
 };
-static inline XYZZ xyzz_inf() { return XYZZ{ZERO, ZERO, ZERO, ZERO}; }
-static inline bool is_inf(const XYZZ& p) { return is_zero(p.zz); }
-static inline void xyzz_dbl(XYZZ& p) {        // dbl-2008-s-1
+struct HFp2 {
+    typedef E2 T;
+    static const int LIMBS64 = 8;
+    static T zero() { return E2{ZERO, ZERO}; }
+    static T one() { return E2{ONE, ZERO}; }
+    static T mul(const T& a, const T& b) {
+        const E v0 = hfp::mul(a.a0, b.a0), v1 = hfp::mul(a.a1, b.a1);
+        const E s = hfp::mul(hfp::add(a.a0, a.a1), hfp::add(b.a0, b.a1));
+        return E2{hfp::sub(v0, v1), hfp::sub(hfp::sub(s, v0), v1)};
+    }
+    static T sqr(const T& a) { return mul(a, a); }
+    static T add(const T& a, const T& b) { return E2{hfp::add(a.a0, b.a0), hfp::add(a.a1, b.a1)}; }
+    static T sub(const T& a, const T& b) { return E2{hfp::sub(a.a0, b.a0), hfp::sub(a.a1, b.a1)}; }
+    static T dbl(const T& a) { return add(a, a); }
+    static bool is_zero(const T& a) { return hfp::is_zero(a.a0) && hfp::is_zero(a.a1); }
+    static T inv(const T& a) {      // conj(a) / (a0^2 + a1^2)
+        const E n = hfp::inv(hfp::add(hfp::sqr(a.a0), hfp::sqr(a.a1)));
+        return E2{hfp::mul(a.a0, n), hfp::sub(ZERO, hfp::mul(a.a1, n))};
+    }
+    static T b_curve() {            // the twist's constant 3 / (9 + u)
+        const E three = hfp::add(hfp::add(ONE, ONE), ONE);
+        E nine = ZERO;
+        for (int i = 0; i < 9; i++) nine = hfp::add(nine, ONE);
+        return mul(E2{three, ZERO}, inv(E2{nine, ONE}));
+    }
+};
+
+template <class F>
+struct AffH {
+    typename F::T x, y;        // infinity = (0, 0), gnark-crypto's encoding
+};
+template <class F>
+struct XyzzH {
+    typename F::T x, y, zz, zzz;      // infinity: zz = 0
+};
+template <class F>
+inline XyzzH<F> xyzz_inf() { return XyzzH<F>{F::zero(), F::zero(), F::zero(), F::zero()}; }
+template <class F>
+inline bool is_inf(const XyzzH<F>& p) { return F::is_zero(p.zz); }
+template <class F>
+inline void xyzz_dbl(XyzzH<F>& p) {        // dbl-2008-s-1
     if (is_inf(p)) return;
-    const E u = dbl(p.y), v = sqr(u), w = mul(u, v), s = mul(p.x, v);
-    const E xx = sqr(p.x), m = add(dbl(xx), xx);
-    const E x3 = sub(sqr(m), dbl(s));
-    p.y = sub(mul(m, sub(s, x3)), mul(w, p.y));
+    const typename F::T u = F::dbl(p.y), v = F::sqr(u), w = F::mul(u, v), s = F::mul(p.x, v);
+    const typename F::T xx = F::sqr(p.x), m = F::add(F::dbl(xx), xx);
+    const typename F::T x3 = F::sub(F::sqr(m), F::dbl(s));
+    p.y = F::sub(F::mul(m, F::sub(s, x3)), F::mul(w, p.y));
     p.x = x3;
-    p.zz = mul(v, p.zz);
-    p.zzz = mul(w, p.zzz);
+    p.zz = F::mul(v, p.zz);
+    p.zzz = F::mul(w, p.zzz);
 }
-static inline void xyzz_add(XYZZ& p, const XYZZ& q) {      // add-2008-s with the special cases
+template <class F>
+inline void xyzz_add(XyzzH<F>& p, const XyzzH<F>& q) {      // add-2008-s with the special cases
     if (is_inf(q)) return;
     if (is_inf(p)) {
         p = q;
         return;
     }
-    const E u1 = mul(p.x, q.zz), s1 = mul(p.y, q.zzz);
-    const E pp_ = sub(mul(q.x, p.zz), u1), r = sub(mul(q.y, p.zzz), s1);
-    if (is_zero(pp_)) {
-        if (is_zero(r)) xyzz_dbl(p);
-        else p = xyzz_inf();
+    const typename F::T u1 = F::mul(p.x, q.zz), s1 = F::mul(p.y, q.zzz);
+    const typename F::T pp_ = F::sub(F::mul(q.x, p.zz), u1), r = F::sub(F::mul(q.y, p.zzz), s1);
+    if (F::is_zero(pp_)) {
+        if (F::is_zero(r)) xyzz_dbl(p);
+        else p = xyzz_inf<F>();
         return;
     }
-    const E pp = sqr(pp_), ppp = mul(pp_, pp), qq = mul(u1, pp);
-    const E x3 = sub(sub(sqr(r), ppp), dbl(qq));
-    p.y = sub(mul(r, sub(qq, x3)), mul(s1, ppp));
+    const typename F::T pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(u1, pp);
+    const typename F::T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    p.y = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(s1, ppp));
     p.x = x3;
-    p.zz = mul(mul(p.zz, q.zz), pp);
-    p.zzz = mul(mul(p.zzz, q.zzz), ppp);
+    p.zz = F::mul(F::mul(p.zz, q.zz), pp);
+    p.zzz = F::mul(F::mul(p.zzz, q.zzz), ppp);
 }
-static inline Aff to_affine(const XYZZ& p) {
-    if (is_inf(p)) return Aff{ZERO, ZERO};
-    const E i = inv(mul(p.zz, p.zzz));
-    return Aff{mul(p.x, mul(i, p.zzz)), mul(p.y, mul(i, p.zz))};
+template <class F>
+inline AffH<F> to_affine(const XyzzH<F>& p) {
+    if (is_inf(p)) return AffH<F>{F::zero(), F::zero()};
+    const typename F::T i = F::inv(F::mul(p.zz, p.zzz));
+    return AffH<F>{F::mul(p.x, F::mul(i, p.zzz)), F::mul(p.y, F::mul(i, p.zz))};
 }
-static inline XYZZ from_affine(const Aff& a) {
-    if (is_zero(a.x) && is_zero(a.y)) return xyzz_inf();
-    return XYZZ{a.x, a.y, ONE, ONE};
+template <class F>
+inline XyzzH<F> from_affine(const AffH<F>& a) {
+    if (F::is_zero(a.x) && F::is_zero(a.y)) return xyzz_inf<F>();
+    return XyzzH<F>{a.x, a.y, F::one(), F::one()};
 }
-// y^2 == x^3 + 3 (or the infinity encoding)
-static inline bool on_curve(const Aff& a) {
-    if (is_zero(a.x) && is_zero(a.y)) return true;
-    const E three = add(add(ONE, ONE), ONE);
-    return sqr(a.y) == add(mul(sqr(a.x), a.x), three);
+// y^2 == x^3 + b (or the infinity encoding)
+template <class F>
+inline bool on_curve(const AffH<F>& a) {
+    if (F::is_zero(a.x) && F::is_zero(a.y)) return true;
+    return F::sqr(a.y) == F::add(F::mul(F::sqr(a.x), a.x), F::b_curve());
 }
+typedef AffH<HFp> Aff;
+typedef XyzzH<HFp> XYZZ;
 
 }  // namespace hfp

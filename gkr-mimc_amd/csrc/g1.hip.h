@@ -27,129 +27,13 @@
 #include "fp_bn254.h"
 #include "kernels.hip.h"
 
-struct G1Aff {
-    Fp x, y;
-};
-struct G1X {               // extended Jacobian: x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; infinity: ZZ = 0
-    Fp x, y, zz, zzz;
-};
-
+// ---- coordinate fields ------------------------------------------------------------------------------------------------
+// The curve code below is written once, over a field policy F: FpF for G1 (coordinates in Fp) and Fp2F for G2 (coordinates
+// in Fp2 = Fp[u]/(u^2 + 1), gnark-crypto's fptower.E2; the curve is the sextic twist y^2 = x^3 + 3/(9 + u), whose constant
+// the addition formulas never use).  F::W16 = 16-byte words per element in HBM.
 __device__ __forceinline__ Fp fp_from4(const uint4& a, const uint4& b) {
     Fp r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
     return r;
-}
-__device__ __forceinline__ G1Aff g1_ld_aff(const uint4* __restrict__ pts, size_t i) {
-    const uint4 a = pts[4 * i], b = pts[4 * i + 1], c = pts[4 * i + 2], d = pts[4 * i + 3];
-    G1Aff r;
-    r.x = fp_from4(a, b);
-    r.y = fp_from4(c, d);
-    return r;
-}
-__device__ __forceinline__ void g1_st_aff(uint4* __restrict__ pts, size_t i, const G1Aff& p) {
-    pts[4 * i] = make_uint4(p.x.v[0], p.x.v[1], p.x.v[2], p.x.v[3]);
-    pts[4 * i + 1] = make_uint4(p.x.v[4], p.x.v[5], p.x.v[6], p.x.v[7]);
-    pts[4 * i + 2] = make_uint4(p.y.v[0], p.y.v[1], p.y.v[2], p.y.v[3]);
-    pts[4 * i + 3] = make_uint4(p.y.v[4], p.y.v[5], p.y.v[6], p.y.v[7]);
-}
-// XYZZ points as eight planes of 16-byte words, plane k of element t at base[k * stride + t]
-struct G1XPlanes {
-    uint4* base;
-    size_t stride;
-};
-__device__ __forceinline__ G1X g1x_ld(const G1XPlanes& pl, size_t t) {
-    G1X r;
-    r.x = fp_from4(pl.base[t], pl.base[pl.stride + t]);
-    r.y = fp_from4(pl.base[2 * pl.stride + t], pl.base[3 * pl.stride + t]);
-    r.zz = fp_from4(pl.base[4 * pl.stride + t], pl.base[5 * pl.stride + t]);
-    r.zzz = fp_from4(pl.base[6 * pl.stride + t], pl.base[7 * pl.stride + t]);
-    return r;
-}
-__device__ __forceinline__ void g1x_st(const G1XPlanes& pl, size_t t, const G1X& p) {
-    const Fp* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        pl.base[(2 * k) * pl.stride + t] = make_uint4(f[k]->v[0], f[k]->v[1], f[k]->v[2], f[k]->v[3]);
-        pl.base[(2 * k + 1) * pl.stride + t] = make_uint4(f[k]->v[4], f[k]->v[5], f[k]->v[6], f[k]->v[7]);
-    }
-}
-
-__device__ __forceinline__ bool g1_aff_is_inf(const G1Aff& a) { return fp_is_zero(a.x) && fp_is_zero(a.y); }
-__device__ __forceinline__ void g1x_set_inf(G1X& p) { p.x = fp_zero(), p.y = fp_zero(), p.zz = fp_zero(), p.zzz = fp_zero(); }
-__device__ __forceinline__ bool g1x_is_inf(const G1X& p) { return fp_is_zero(p.zz); }
-
-// p = 2 a for an affine a != infinity (mdbl-2008-s-1; y = 0 does not occur on a curve of odd prime order)
-__device__ __forceinline__ void g1x_dbl_aff(G1X& p, const G1Aff& a) {
-    const Fp u = fp_dbl(a.y), v = fp_sqr(u), w = fp_mul(u, v), s = fp_mul(a.x, v);
-    const Fp xx = fp_sqr(a.x), m = fp_add(fp_dbl(xx), xx);
-    p.x = fp_sub(fp_sqr(m), fp_dbl(s));
-    p.y = fp_sub(fp_mul(m, fp_sub(s, p.x)), fp_mul(w, a.y));
-    p.zz = v;
-    p.zzz = w;
-}
-// p = 2 p (dbl-2008-s-1); infinity stays infinity (ZZ3 = V * 0)
-__device__ __forceinline__ void g1x_dbl(G1X& p) {
-    const Fp u = fp_dbl(p.y), v = fp_sqr(u), w = fp_mul(u, v), s = fp_mul(p.x, v);
-    const Fp xx = fp_sqr(p.x), m = fp_add(fp_dbl(xx), xx);
-    const Fp x3 = fp_sub(fp_sqr(m), fp_dbl(s));
-    p.y = fp_sub(fp_mul(m, fp_sub(s, x3)), fp_mul(w, p.y));
-    p.x = x3;
-    p.zz = fp_mul(v, p.zz);
-    p.zzz = fp_mul(w, p.zzz);
-}
-// p += a (madd-2008-s: 8 M + 2 S), every special case handled: a or p at infinity, a == p (doubling), a == -p
-__device__ __forceinline__ void g1x_madd(G1X& p, const G1Aff& a) {
-    if (g1_aff_is_inf(a)) return;         // gnark-crypto's g1JacExtended.addMixed skips the (0, 0) encoding the same way
-    if (g1x_is_inf(p)) {
-        p.x = a.x, p.y = a.y, p.zz = fp_one(), p.zzz = fp_one();
-        return;
-    }
-    const Fp pp_ = fp_sub(fp_mul(a.x, p.zz), p.x), r = fp_sub(fp_mul(a.y, p.zzz), p.y);
-    if (fp_is_zero(pp_)) {
-        if (fp_is_zero(r)) g1x_dbl_aff(p, a);
-        else g1x_set_inf(p);
-        return;
-    }
-    const Fp pp = fp_sqr(pp_), ppp = fp_mul(pp_, pp), q = fp_mul(p.x, pp);
-    const Fp x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(q));
-    p.y = fp_sub(fp_mul(r, fp_sub(q, x3)), fp_mul(p.y, ppp));
-    p.x = x3;
-    p.zz = fp_mul(p.zz, pp);
-    p.zzz = fp_mul(p.zzz, ppp);
-}
-// The common case alone, for the hot loop of the bucket accumulation: p += a when neither is infinity and a != +-p;
-// returns false and leaves p untouched otherwise (the caller then takes g1x_madd).  Keeping the doubling out of the loop
-// body keeps its 6 products out of the loop's instruction stream (and of the instruction cache's working set).
-__device__ __forceinline__ bool g1x_madd_fast(G1X& p, const G1Aff& a) {
-    const Fp pp_ = fp_sub(fp_mul(a.x, p.zz), p.x), r = fp_sub(fp_mul(a.y, p.zzz), p.y);
-    if (fp_is_zero(pp_) || g1x_is_inf(p) || g1_aff_is_inf(a)) return false;
-    const Fp pp = fp_sqr(pp_), ppp = fp_mul(pp_, pp), q = fp_mul(p.x, pp);
-    const Fp x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(q));
-    p.y = fp_sub(fp_mul(r, fp_sub(q, x3)), fp_mul(p.y, ppp));
-    p.x = x3;
-    p.zz = fp_mul(p.zz, pp);
-    p.zzz = fp_mul(p.zzz, ppp);
-    return true;
-}
-// p += q (add-2008-s: 12 M + 2 S), every special case handled
-__device__ __forceinline__ void g1x_add(G1X& p, const G1X& q) {
-    if (g1x_is_inf(q)) return;
-    if (g1x_is_inf(p)) {
-        p = q;
-        return;
-    }
-    const Fp u1 = fp_mul(p.x, q.zz), s1 = fp_mul(p.y, q.zzz);
-    const Fp pp_ = fp_sub(fp_mul(q.x, p.zz), u1), r = fp_sub(fp_mul(q.y, p.zzz), s1);
-    if (fp_is_zero(pp_)) {
-        if (fp_is_zero(r)) g1x_dbl(p);
-        else g1x_set_inf(p);
-        return;
-    }
-    const Fp pp = fp_sqr(pp_), ppp = fp_mul(pp_, pp), qq = fp_mul(u1, pp);
-    const Fp x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(qq));
-    p.y = fp_sub(fp_mul(r, fp_sub(qq, x3)), fp_mul(s1, ppp));
-    p.x = x3;
-    p.zz = fp_mul(fp_mul(p.zz, q.zz), pp);
-    p.zzz = fp_mul(fp_mul(p.zzz, q.zzz), ppp);
 }
 // a^(p-2) (Fermat): the exponent is a compile-time constant, the loop is uniform
 __device__ __forceinline__ Fp fp_inv(const Fp& a) {
@@ -161,16 +45,199 @@ __device__ __forceinline__ Fp fp_inv(const Fp& a) {
     }
     return r;
 }
+struct FpF {
+    typedef Fp T;
+    static const int W16 = 2;
+    static __device__ __forceinline__ T ld(const uint4* __restrict__ p, size_t stride) { return fp_from4(p[0], p[stride]); }
+    static __device__ __forceinline__ void st(uint4* __restrict__ p, size_t stride, const T& x) {
+        p[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        p[stride] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    }
+    static __device__ __forceinline__ T zero() { return fp_zero(); }
+    static __device__ __forceinline__ T one() { return fp_one(); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return fp_mul(a, b); }
+    static __device__ __forceinline__ T sqr(const T& a) { return fp_sqr(a); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return fp_add(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return fp_sub(a, b); }
+    static __device__ __forceinline__ T dbl(const T& a) { return fp_dbl(a); }
+    static __device__ __forceinline__ T neg(const T& a) { return fp_neg(a); }
+    static __device__ __forceinline__ T canon(const T& a) { return fp_canon(a); }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return fp_is_zero(a); }
+    static __device__ __forceinline__ T inv(const T& a) { return fp_inv(a); }
+};
+struct Fp2F {
+    typedef Fp2 T;
+    static const int W16 = 4;
+    static __device__ __forceinline__ T ld(const uint4* __restrict__ p, size_t stride) {
+        return Fp2{fp_from4(p[0], p[stride]), fp_from4(p[2 * stride], p[3 * stride])};
+    }
+    static __device__ __forceinline__ void st(uint4* __restrict__ p, size_t stride, const T& x) {
+        FpF::st(p, stride, x.a0);
+        FpF::st(p + 2 * stride, stride, x.a1);
+    }
+    static __device__ __forceinline__ T zero() { return fp2_zero(); }
+    static __device__ __forceinline__ T one() { return fp2_one(); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return fp2_mul(a, b); }
+    static __device__ __forceinline__ T sqr(const T& a) { return fp2_sqr(a); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return fp2_add(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return fp2_sub(a, b); }
+    static __device__ __forceinline__ T dbl(const T& a) { return fp2_dbl(a); }
+    static __device__ __forceinline__ T neg(const T& a) { return fp2_neg(a); }
+    static __device__ __forceinline__ T canon(const T& a) { return fp2_canon(a); }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return fp2_is_zero(a); }
+    static __device__ __forceinline__ T inv(const T& a) {        // conj(a) / (a0^2 + a1^2)
+        const Fp n = fp_inv(fp_add(fp_sqr(a.a0), fp_sqr(a.a1)));
+        return Fp2{fp_mul(a.a0, n), fp_neg(fp_mul(a.a1, n))};
+    }
+};
+
+template <class F>
+struct AffT {                  // gnark-crypto's G1Affine / G2Affine image: X, Y Montgomery, infinity = (0, 0)
+    typename F::T x, y;
+};
+template <class F>
+struct XyzzT {                 // extended Jacobian: x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; infinity: ZZ = 0
+    typename F::T x, y, zz, zzz;
+};
+typedef AffT<FpF> G1Aff;
+typedef XyzzT<FpF> G1X;
+typedef AffT<Fp2F> G2Aff;
+typedef XyzzT<Fp2F> G2X;
+
+// point i of an array of affine points (2 * W16 consecutive 16-byte words)
+template <class F>
+__device__ __forceinline__ AffT<F> ec_ld_aff(const uint4* __restrict__ pts, size_t i) {
+    const uint4* p = pts + 2 * F::W16 * i;
+    AffT<F> r;
+    r.x = F::ld(p, 1);
+    r.y = F::ld(p + F::W16, 1);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void ec_st_aff(uint4* __restrict__ pts, size_t i, const AffT<F>& a) {
+    uint4* p = pts + 2 * F::W16 * i;
+    F::st(p, 1, a.x);
+    F::st(p + F::W16, 1, a.y);
+}
+// XYZZ points as 4 * W16 planes of 16-byte words, plane k of element t at base[k * stride + t]
+struct XPlanes {
+    uint4* base;
+    size_t stride;
+};
+template <class F>
+__device__ __forceinline__ XyzzT<F> ecx_ld(const XPlanes& pl, size_t t) {
+    XyzzT<F> r;
+    r.x = F::ld(pl.base + t, pl.stride);
+    r.y = F::ld(pl.base + (size_t)F::W16 * pl.stride + t, pl.stride);
+    r.zz = F::ld(pl.base + (size_t)2 * F::W16 * pl.stride + t, pl.stride);
+    r.zzz = F::ld(pl.base + (size_t)3 * F::W16 * pl.stride + t, pl.stride);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void ecx_st(const XPlanes& pl, size_t t, const XyzzT<F>& p) {
+    F::st(pl.base + t, pl.stride, p.x);
+    F::st(pl.base + (size_t)F::W16 * pl.stride + t, pl.stride, p.y);
+    F::st(pl.base + (size_t)2 * F::W16 * pl.stride + t, pl.stride, p.zz);
+    F::st(pl.base + (size_t)3 * F::W16 * pl.stride + t, pl.stride, p.zzz);
+}
+
+template <class F>
+__device__ __forceinline__ bool ec_aff_is_inf(const AffT<F>& a) { return F::is_zero(a.x) && F::is_zero(a.y); }
+template <class F>
+__device__ __forceinline__ void ecx_set_inf(XyzzT<F>& p) { p.x = F::zero(), p.y = F::zero(), p.zz = F::zero(), p.zzz = F::zero(); }
+template <class F>
+__device__ __forceinline__ bool ecx_is_inf(const XyzzT<F>& p) { return F::is_zero(p.zz); }
+
+// p = 2 a for an affine a != infinity (mdbl-2008-s-1; y = 0 does not occur in a group of odd prime order)
+template <class F>
+__device__ __forceinline__ void ecx_dbl_aff(XyzzT<F>& p, const AffT<F>& a) {
+    const typename F::T u = F::dbl(a.y), v = F::sqr(u), w = F::mul(u, v), s = F::mul(a.x, v);
+    const typename F::T xx = F::sqr(a.x), m = F::add(F::dbl(xx), xx);
+    p.x = F::sub(F::sqr(m), F::dbl(s));
+    p.y = F::sub(F::mul(m, F::sub(s, p.x)), F::mul(w, a.y));
+    p.zz = v;
+    p.zzz = w;
+}
+// p = 2 p (dbl-2008-s-1); infinity stays infinity (ZZ3 = V * 0)
+template <class F>
+__device__ __forceinline__ void ecx_dbl(XyzzT<F>& p) {
+    const typename F::T u = F::dbl(p.y), v = F::sqr(u), w = F::mul(u, v), s = F::mul(p.x, v);
+    const typename F::T xx = F::sqr(p.x), m = F::add(F::dbl(xx), xx);
+    const typename F::T x3 = F::sub(F::sqr(m), F::dbl(s));
+    p.y = F::sub(F::mul(m, F::sub(s, x3)), F::mul(w, p.y));
+    p.x = x3;
+    p.zz = F::mul(v, p.zz);
+    p.zzz = F::mul(w, p.zzz);
+}
+// p += a (madd-2008-s: 8 M + 2 S), every special case handled: a or p at infinity, a == p (doubling), a == -p
+template <class F>
+__device__ __forceinline__ void ecx_madd(XyzzT<F>& p, const AffT<F>& a) {
+    if (ec_aff_is_inf(a)) return;         // gnark-crypto's g1JacExtended.addMixed skips the (0, 0) encoding the same way
+    if (ecx_is_inf(p)) {
+        p.x = a.x, p.y = a.y, p.zz = F::one(), p.zzz = F::one();
+        return;
+    }
+    const typename F::T pp_ = F::sub(F::mul(a.x, p.zz), p.x), r = F::sub(F::mul(a.y, p.zzz), p.y);
+    if (F::is_zero(pp_)) {
+        if (F::is_zero(r)) ecx_dbl_aff(p, a);
+        else ecx_set_inf(p);
+        return;
+    }
+    const typename F::T pp = F::sqr(pp_), ppp = F::mul(pp_, pp), q = F::mul(p.x, pp);
+    const typename F::T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(q));
+    p.y = F::sub(F::mul(r, F::sub(q, x3)), F::mul(p.y, ppp));
+    p.x = x3;
+    p.zz = F::mul(p.zz, pp);
+    p.zzz = F::mul(p.zzz, ppp);
+}
+// The common case alone, for the hot loop of the bucket accumulation: p += a when neither is infinity and a != +-p;
+// returns false and leaves p untouched otherwise (the caller then takes ecx_madd).  Keeping the doubling out of the loop
+// body keeps its 6 products out of the loop's instruction stream (and of the instruction cache's working set).
+template <class F>
+__device__ __forceinline__ bool ecx_madd_fast(XyzzT<F>& p, const AffT<F>& a) {
+    const typename F::T pp_ = F::sub(F::mul(a.x, p.zz), p.x), r = F::sub(F::mul(a.y, p.zzz), p.y);
+    if (F::is_zero(pp_) || ecx_is_inf(p) || ec_aff_is_inf(a)) return false;
+    const typename F::T pp = F::sqr(pp_), ppp = F::mul(pp_, pp), q = F::mul(p.x, pp);
+    const typename F::T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(q));
+    p.y = F::sub(F::mul(r, F::sub(q, x3)), F::mul(p.y, ppp));
+    p.x = x3;
+    p.zz = F::mul(p.zz, pp);
+    p.zzz = F::mul(p.zzz, ppp);
+    return true;
+}
+// p += q (add-2008-s: 12 M + 2 S), every special case handled
+template <class F>
+__device__ __forceinline__ void ecx_add(XyzzT<F>& p, const XyzzT<F>& q) {
+    if (ecx_is_inf(q)) return;
+    if (ecx_is_inf(p)) {
+        p = q;
+        return;
+    }
+    const typename F::T u1 = F::mul(p.x, q.zz), s1 = F::mul(p.y, q.zzz);
+    const typename F::T pp_ = F::sub(F::mul(q.x, p.zz), u1), r = F::sub(F::mul(q.y, p.zzz), s1);
+    if (F::is_zero(pp_)) {
+        if (F::is_zero(r)) ecx_dbl(p);
+        else ecx_set_inf(p);
+        return;
+    }
+    const typename F::T pp = F::sqr(pp_), ppp = F::mul(pp_, pp), qq = F::mul(u1, pp);
+    const typename F::T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    p.y = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(s1, ppp));
+    p.x = x3;
+    p.zz = F::mul(F::mul(p.zz, q.zz), pp);
+    p.zzz = F::mul(F::mul(p.zzz, q.zzz), ppp);
+}
 // affine image (canonical coordinates; infinity -> (0, 0)) of an XYZZ point: one inversion of ZZ * ZZZ
-__device__ __forceinline__ G1Aff g1x_to_aff(const G1X& p) {
-    G1Aff a;
-    if (g1x_is_inf(p)) {
-        a.x = fp_zero(), a.y = fp_zero();
+template <class F>
+__device__ __forceinline__ AffT<F> ecx_to_aff(const XyzzT<F>& p) {
+    AffT<F> a;
+    if (ecx_is_inf(p)) {
+        a.x = F::zero(), a.y = F::zero();
         return a;
     }
-    const Fp i = fp_inv(fp_mul(p.zz, p.zzz));
-    a.x = fp_canon(fp_mul(p.x, fp_mul(i, p.zzz)));      // X / ZZ
-    a.y = fp_canon(fp_mul(p.y, fp_mul(i, p.zz)));       // Y / ZZZ
+    const typename F::T i = F::inv(F::mul(p.zz, p.zzz));
+    a.x = F::canon(F::mul(p.x, F::mul(i, p.zzz)));      // X / ZZ
+    a.y = F::canon(F::mul(p.y, F::mul(i, p.zz)));       // Y / ZZZ
     return a;
 }
 
@@ -179,7 +246,7 @@ __device__ __forceinline__ G1Aff g1x_to_aff(const G1X& p) {
 // ------------------------------------------------------------------------------------------------
 struct MsmArgs {
     const uint4* scalars;     // n x 32 B, the image of []fr.Element (4 x u64 little-endian)
-    const uint4* points;      // n x 64 B, the image of []G1Affine
+    const uint4* points;      // n x 64 B (G1) or 128 B (G2): the image of []G1Affine / []G2Affine
     size_t n;
     int c, W;                 // window bits, number of windows
     unsigned int nb;          // buckets per window = 2^(c-1)
@@ -196,9 +263,9 @@ struct MsmArgs {
     unsigned int* entries;    // point index | sign << 31, sorted by (window, bucket)
     unsigned int* big;        // [0] = number of big buckets, [1 + k] = their ids, [big_cap + 1] = a scalar was not below 2^254
     unsigned int big_threshold, big_cap;
-    G1XPlanes buckets;        // W * nb
-    G1XPlanes parts;          // W * nchunk chunk sums
-    G1XPlanes wins;           // W window sums
+    XPlanes buckets;          // W * nb
+    XPlanes parts;            // W * nchunk chunk sums
+    XPlanes wins;             // W window sums
     int chunk;                // buckets per lane of k_msm_reduce_chunks (a power of two)
 };
 
@@ -406,80 +473,101 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
 // ------------------------------------------------------------------------------------------------
 // bucket accumulation
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ G1Aff msm_entry_point(const MsmArgs& a, unsigned int e) {
-    G1Aff p = g1_ld_aff(a.points, e & 0x7fffffffu);
-    if (e & 0x80000000u) p.y = fp_neg(p.y);
+template <class F>
+__device__ __forceinline__ AffT<F> msm_entry_point(const MsmArgs& a, unsigned int e) {
+    AffT<F> p = ec_ld_aff<F>(a.points, e & 0x7fffffffu);
+    if (e & 0x80000000u) p.y = F::neg(p.y);
     return p;
 }
-#ifndef MSM_ACC_MINBLOCKS
-#define MSM_ACC_MINBLOCKS 3      // workgroups per CU the register allocation must allow (4: 128 registers, spills, measured 8-12 % slower)
-#endif
-__global__ void __launch_bounds__(GKR_BLOCK, MSM_ACC_MINBLOCKS) k_msm_accumulate(MsmArgs a) {
+// Register budgets: the G1 loop needs 159 VGPRs (three waves per SIMD; forcing 128 spills and is 8-12 % slower); a G2 point is
+// twice as wide (the accumulator alone is 64 registers): one workgroup per CU may take the whole file.
+template <class F>
+struct MsmTune {
+    static const int ACC_MINBLOCKS = 3;
+    static const bool PREFETCH = true;
+};
+template <>
+struct MsmTune<Fp2F> {
+    static const int ACC_MINBLOCKS = 1;
+    static const bool PREFETCH = false;
+};
+template <class F>
+__global__ void __launch_bounds__(GKR_BLOCK, MsmTune<F>::ACC_MINBLOCKS) k_msm_accumulate(MsmArgs a) {
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= (size_t)a.W * a.nb) return;
     const size_t t = lane - lane % a.nb + a.order[lane];          // the lane's bucket: the (lane mod nb)-th largest of its window
     const unsigned int cnt = a.count[t], start = a.offset[t];
-    G1X acc;
-    g1x_set_inf(acc);
+    XyzzT<F> acc;
+    ecx_set_inf(acc);
     if (cnt && cnt <= a.big_threshold) {
-        // Software pipeline of a lane's chain index -> point -> 10 products: the index is loaded two points ahead and the
-        // point one ahead, so neither HBM round trip sits between two additions.  The inner loop is the common case only;
-        // the first point of a bucket and the rare doubling / cancellation leave it for the complete addition.
         const unsigned int* ent = a.entries + start;
-        G1Aff cur = msm_entry_point(a, ent[0]);
-        unsigned int k = 1;
-        unsigned int e_nxt = cnt > 1 ? ent[1] : 0u;
-        for (;;) {
-            bool done = false;
+        if (MsmTune<F>::PREFETCH) {
+            // Software pipeline of a lane's chain index -> point -> 10 products: the index is loaded two points ahead and the
+            // point one ahead, so neither HBM round trip sits between two additions.  The inner loop is the common case only;
+            // the first point of a bucket and the rare doubling / cancellation leave it for the complete addition.
+            AffT<F> cur = msm_entry_point<F>(a, ent[0]);
+            unsigned int k = 1;
+            unsigned int e_nxt = cnt > 1 ? ent[1] : 0u;
             for (;;) {
-                if (k >= cnt) {
-                    done = true;
-                    break;
+                bool done = false;
+                for (;;) {
+                    if (k >= cnt) {
+                        done = true;
+                        break;
+                    }
+                    const AffT<F> nxt = msm_entry_point<F>(a, e_nxt);
+                    const unsigned int e_nn = k + 1 < cnt ? ent[k + 1] : 0u;
+                    if (!ecx_madd_fast(acc, cur)) break;       // e_nxt still names point k: the slow path re-loads it
+                    cur = nxt;
+                    e_nxt = e_nn;
+                    k++;
                 }
-                const G1Aff nxt = msm_entry_point(a, e_nxt);
-                const unsigned int e_nn = k + 1 < cnt ? ent[k + 1] : 0u;
-                if (!g1x_madd_fast(acc, cur)) break;       // e_nxt still names point k: the slow path re-loads it
-                cur = nxt;
-                e_nxt = e_nn;
+                if (done) break;
+                ecx_madd(acc, cur);
+                cur = msm_entry_point<F>(a, e_nxt);
                 k++;
+                e_nxt = k < cnt ? ent[k] : 0u;
             }
-            if (done) break;
-            g1x_madd(acc, cur);
-            cur = msm_entry_point(a, e_nxt);
-            k++;
-            e_nxt = k < cnt ? ent[k] : 0u;
+            ecx_madd(acc, cur);
+        } else {
+            for (unsigned int k = 0; k < cnt; k++) {
+                const AffT<F> cur = msm_entry_point<F>(a, ent[k]);
+                if (!ecx_madd_fast(acc, cur)) ecx_madd(acc, cur);
+            }
         }
-        g1x_madd(acc, cur);
     }
-    g1x_st(a.buckets, t, acc);        // a big bucket is overwritten by k_msm_accumulate_big (launched after this kernel)
+    ecx_st<F>(a.buckets, t, acc);        // a big bucket is overwritten by k_msm_accumulate_big (launched after this kernel)
 }
 // LDS tree over the workgroup's XYZZ partial sums; the result is in sh[0]
-struct G1XShared {
-    G1X p[GKR_BLOCK];
+template <class F>
+struct XyzzShared {
+    XyzzT<F> p[GKR_BLOCK];
 };
-__device__ __forceinline__ void g1x_block_reduce(G1XShared& sh, G1X& mine) {
+template <class F>
+__device__ __forceinline__ void ecx_block_reduce(XyzzShared<F>& sh, XyzzT<F>& mine) {
     sh.p[threadIdx.x] = mine;
     __syncthreads();
     for (int d = GKR_BLOCK / 2; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) {
-            G1X x = sh.p[threadIdx.x];
-            g1x_add(x, sh.p[threadIdx.x + d]);
+            XyzzT<F> x = sh.p[threadIdx.x];
+            ecx_add(x, sh.p[threadIdx.x + d]);
             sh.p[threadIdx.x] = x;
         }
         __syncthreads();
     }
 }
+template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_accumulate_big(MsmArgs a) {
-    __shared__ G1XShared sh;
+    __shared__ XyzzShared<F> sh;
     const unsigned int nbig = min(a.big[0], a.big_cap);
     for (unsigned int k = blockIdx.x; k < nbig; k += gridDim.x) {
         const size_t t = a.big[1 + k];
         const unsigned int cnt = a.count[t], start = a.offset[t];
-        G1X acc;
-        g1x_set_inf(acc);
-        for (unsigned int i = threadIdx.x; i < cnt; i += GKR_BLOCK) g1x_madd(acc, msm_entry_point(a, a.entries[start + i]));
-        g1x_block_reduce(sh, acc);
-        if (threadIdx.x == 0) g1x_st(a.buckets, t, sh.p[0]);
+        XyzzT<F> acc;
+        ecx_set_inf(acc);
+        for (unsigned int i = threadIdx.x; i < cnt; i += GKR_BLOCK) ecx_madd(acc, msm_entry_point<F>(a, a.entries[start + i]));
+        ecx_block_reduce(sh, acc);
+        if (threadIdx.x == 0) ecx_st<F>(a.buckets, t, sh.p[0]);
         __syncthreads();
     }
 }
@@ -488,66 +576,70 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_accumulate_big(MsmArgs a) {
 // window sums:  sum_b (b + 1) B_b
 // ------------------------------------------------------------------------------------------------
 // [k] p for a small k by double-and-add (k < 2^16)
-__device__ __forceinline__ G1X g1x_mul_small(const G1X& p, unsigned int k) {
-    G1X r;
-    g1x_set_inf(r);
+template <class F>
+__device__ __forceinline__ XyzzT<F> ecx_mul_small(const XyzzT<F>& p, unsigned int k) {
+    XyzzT<F> r;
+    ecx_set_inf(r);
     for (int i = 31 - __clz(k | 1u); i >= 0; i--) {
-        g1x_dbl(r);
-        if ((k >> i) & 1u) g1x_add(r, p);
+        ecx_dbl(r);
+        if ((k >> i) & 1u) ecx_add(r, p);
     }
     return r;
 }
 // lane (j, ci): buckets [ci * chunk, (ci + 1) * chunk) of window j from the top down: running = sum B, acc = sum of the
 // running sums = sum (b - b0 + 1) B_b; the chunk's share of the window sum is acc + b0 * running
+template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_reduce_chunks(MsmArgs a) {
     const unsigned int nchunk = a.nb / a.chunk;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (size_t)a.W * nchunk) return;
     const unsigned int j = (unsigned int)(g / nchunk), ci = (unsigned int)(g % nchunk);
     const unsigned int b0 = ci * a.chunk;
-    G1X running, acc;
-    g1x_set_inf(running);
-    g1x_set_inf(acc);
+    XyzzT<F> running, acc;
+    ecx_set_inf(running);
+    ecx_set_inf(acc);
     for (int k = a.chunk - 1; k >= 0; k--) {
-        g1x_add(running, g1x_ld(a.buckets, (size_t)j * a.nb + b0 + k));
-        g1x_add(acc, running);
+        ecx_add(running, ecx_ld<F>(a.buckets, (size_t)j * a.nb + b0 + k));
+        ecx_add(acc, running);
     }
-    if (b0) g1x_add(acc, g1x_mul_small(running, b0));
-    g1x_st(a.parts, g, acc);
+    if (b0) ecx_add(acc, ecx_mul_small(running, b0));
+    ecx_st<F>(a.parts, g, acc);
 }
 // one workgroup per window: the sum of its chunk results
+template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_reduce_windows(MsmArgs a) {
-    __shared__ G1XShared sh;
+    __shared__ XyzzShared<F> sh;
     const unsigned int nchunk = a.nb / a.chunk;
     const unsigned int j = blockIdx.x;
-    G1X acc;
-    g1x_set_inf(acc);
-    for (unsigned int ci = threadIdx.x; ci < nchunk; ci += GKR_BLOCK) g1x_add(acc, g1x_ld(a.parts, (size_t)j * nchunk + ci));
-    g1x_block_reduce(sh, acc);
-    if (threadIdx.x == 0) g1x_st(a.wins, j, sh.p[0]);
+    XyzzT<F> acc;
+    ecx_set_inf(acc);
+    for (unsigned int ci = threadIdx.x; ci < nchunk; ci += GKR_BLOCK) ecx_add(acc, ecx_ld<F>(a.parts, (size_t)j * nchunk + ci));
+    ecx_block_reduce(sh, acc);
+    if (threadIdx.x == 0) ecx_st<F>(a.wins, j, sh.p[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out[i] = [s_i] base, affine.  One lane per scalar,
+// bn254.BatchScalarMultiplicationG1 / G2 (base, scalars) (prove.go:177): out[i] = [s_i] base, affine.  One lane per scalar,
 // left-to-right double-and-add with mixed additions, then the lane's own inversion (a tenth of its work).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GKR_BLOCK) k_g1_batch_scalar_mul(MsmArgs a, G1Aff base, uint4* out) {
+template <class F>
+__global__ void __launch_bounds__(GKR_BLOCK) k_ec_batch_scalar_mul(MsmArgs a, AffT<F> base, uint4* out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     u32 s[8];
     msm_load_scalar(a, i, s);
-    G1X acc;
-    g1x_set_inf(acc);
+    XyzzT<F> acc;
+    ecx_set_inf(acc);
     for (int limb = 7; limb >= 0; limb--) {
         u32 w = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) w = (j == limb) ? s[j] : w;        // no dynamic register indexing
         for (int b = 31; b >= 0; b--) {
-            g1x_dbl(acc);
-            if ((w >> b) & 1u) g1x_madd(acc, base);
+            ecx_dbl(acc);
+            if ((w >> b) & 1u) ecx_madd(acc, base);
         }
     }
-    g1_st_aff(out, i, g1x_to_aff(acc));
+    ec_st_aff<F>(out, i, ecx_to_aff(acc));
 }
 
 // synthetic scalars of the benchmark: pseudo-random canonical values below q, out[i] = limbs of (mix(i, seed))^7

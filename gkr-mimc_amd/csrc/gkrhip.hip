@@ -1056,123 +1056,99 @@ int gkrhip_bench_compute_h(int logn, int warmup, int iters, double* avg_ms, int*
     return 0;
 }
 
-// ---- G1 multi-scalar multiplication (gnark-crypto's MultiExp at prover/gadget/prove.go:76,91,189,202,221) ----------
-int gkrhip_g1_bases_create(gkrhip_g1_bases** out, const uint64_t* points, size_t n) {
-    if (!out || (n && !points)) return fail("g1_bases_create: null argument");
+// ---- multi-scalar multiplications (gnark-crypto's MultiExp at prover/gadget/prove.go:76,91,189,202,221 on G1, :277 on G2) -----
+// One implementation over the group (F: the device field policy of g1.hip.h, HF: its host twin, B: the handle type).
+}  // extern "C"
+namespace {
+template <class B>
+int abi_bases_create(B** out, const uint64_t* points, size_t n, int w16) {
+    if (!out || (n && !points)) return fail("bases_create: null argument");
     LEASE_LANE();
-    CHK(msm_check_points(points, n));
-    gkrhip_g1_bases* b = nullptr;
-    CHK(g1_bases_alloc(&b, n));
-    if (n) {
-        hipError_t e = hipMemcpyAsync(b->d_points, points, n * 64, hipMemcpyHostToDevice, cx().stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(cx().stream);
-        if (e != hipSuccess) {
-            g1_bases_free(b);
-            return fail("upload of %zu G1 points failed: %s", n, hipGetErrorString(e));
-        }
-    }
-    *out = b;
-    return 0;
+    return bases_upload(out, points, n, w16);
 }
-int gkrhip_g1_bases_generate(gkrhip_g1_bases** out, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
-    if (!out || !base || (n && !scalars)) return fail("g1_bases_generate: null argument");
+template <class F, class B>
+int abi_bases_generate(B** out, const uint64_t* base, const uint64_t* scalars, size_t n, int flags) {
+    if (!out || !base || (n && !scalars)) return fail("bases_generate: null argument");
     LEASE_LANE();
-    gkrhip_g1_bases* b = nullptr;
-    CHK(g1_bases_alloc(&b, n));
-    const int rc = g1_batch_mul_dev(b->d_points, base, scalars, n, flags);
+    B* b = nullptr;
+    CHK(bases_alloc(&b, n, F::W16));
+    const int rc = batch_mul_dev<F>(b->d_points, base, scalars, n, flags);
     if (rc) {
-        g1_bases_free(b);
+        bases_free(b);
         return rc;
     }
     *out = b;
     return 0;
 }
-size_t gkrhip_g1_bases_len(const gkrhip_g1_bases* b) { return b ? b->n : 0; }
-int gkrhip_g1_bases_read(const gkrhip_g1_bases* b, uint64_t* out, size_t first, size_t count) {
-    if (!b || !out) return fail("g1_bases_read: null argument");
-    if (first > b->n || count > b->n - first) return fail("g1_bases_read: [%zu, %zu) outside %zu points", first, first + count, b->n);
+int abi_bases_read(const MsmBases* b, uint64_t* out, size_t first, size_t count) {
+    if (!b || !out) return fail("bases_read: null argument");
+    if (first > b->n || count > b->n - first) return fail("bases_read: [%zu, %zu) outside %zu points", first, first + count, b->n);
     LEASE_LANE();
     if (count) {
-        HIPCHK(hipMemcpyAsync(out, b->d_points + 4 * first, count * 64, hipMemcpyDeviceToHost, cx().stream));
+        HIPCHK(hipMemcpyAsync(out, b->d_points + (size_t)2 * b->w16 * first, count * 32 * b->w16, hipMemcpyDeviceToHost, cx().stream));
         HIPCHK(hipStreamSynchronize(cx().stream));
     }
     return 0;
 }
-void gkrhip_g1_bases_destroy(gkrhip_g1_bases* b) { g1_bases_free(b); }
-int gkrhip_msm_g1_set_window(gkrhip_g1_bases* b, int c) {
-    if (!b) return fail("msm_g1_set_window: null handle");
+int abi_set_window(MsmBases* b, int c) {
+    if (!b) return fail("msm_set_window: null handle");
     if (c != 0 && (c < 2 || c > 16)) return fail("msm: window size %d outside 2..16 (0 = automatic)", c);
     std::lock_guard<std::mutex> lk(b->mu);
     b->c_forced = c;
     return 0;
 }
-int gkrhip_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* b, const uint64_t* scalars, size_t n, int flags) {
-    if (!out_affine || !b || (n && !scalars)) return fail("msm_g1: null argument");
+template <class F, class HF>
+int abi_msm(uint64_t* out_affine, MsmBases* b, const uint64_t* scalars, size_t n, int flags) {
+    if (!out_affine || !b || (n && !scalars)) return fail("msm: null argument");
     LEASE_LANE();
-    return msm_run(b, scalars, n, flags, out_affine);
+    return msm_run<F, HF>(b, scalars, n, flags, out_affine);
 }
-int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t* points, const uint64_t* scalars, size_t n, int flags) {
-    gkrhip_g1_bases* b = nullptr;
-    CHK(gkrhip_g1_bases_create(&b, points, n));
-    const int rc = gkrhip_msm_g1(out_affine, b, scalars, n, flags);
-    gkrhip_g1_bases_destroy(b);
-    return rc;
-}
-int gkrhip_g1_batch_scalar_mul(uint64_t* out, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
-    if (!base || (n && (!out || !scalars))) return fail("g1_batch_scalar_mul: null argument");
-    gkrhip_g1_bases* b = nullptr;
-    CHK(gkrhip_g1_bases_generate(&b, base, scalars, n, flags));
-    const int rc = gkrhip_g1_bases_read(b, out, 0, n);
-    gkrhip_g1_bases_destroy(b);
-    return rc;
-}
-int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
-                        double* host_tail_ms, uint64_t result_or_null[8]) {
-    if (logn < 0 || logn > 26 || iters < 1 || !avg_ms) return fail("bench_msm_g1: bad arguments");
+// MSM of 2^logn synthetic device-resident bases [k_i] G and scalars (both pseudo-random below q), timed with HIP events
+template <class F, class HF, class B>
+int abi_bench_msm(const uint64_t* gen_image, int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
+                  double* host_tail_ms, uint64_t* result_or_null) {
+    if (logn < 0 || logn > 26 || iters < 1 || !avg_ms) return fail("bench_msm: bad arguments");
     LEASE_LANE();
     const size_t n = (size_t)1 << logn;
-    gkrhip_g1_bases* b = nullptr;
-    CHK(g1_bases_alloc(&b, n));
+    B* b = nullptr;
+    CHK(bases_alloc(&b, n, F::W16));
     struct Guard {
-        gkrhip_g1_bases* b;
+        B* b;
         uint4* s = nullptr;
         MsmTimes tm;
         ~Guard() {
             for (hipEvent_t e : tm.ev)
                 if (e) (void)hipEventDestroy(e);
             if (s) (void)hipFree(s);
-            g1_bases_free(b);
+            bases_free(b);
         }
     } g{b};
     b->c_forced = c_or_0;
-    CHK(msm_work_prepare(&b->w, n, c_or_0));
+    CHK(msm_work_prepare(&b->w, n, c_or_0, F::W16));
     HIPCHK(hipMalloc((void**)&g.s, n * 32));
-    // bases [k_i] G, G = (1, 2), k_i pseudo-random; scalars pseudo-random below q
     hipLaunchKernelGGL(k_msm_synth_scalars, dim3(grid_for(n, 4096)), dim3(GKR_BLOCK), 0, cx().stream, g.s, n, 0x1234567u);
     {
         MsmArgs a;
         memset(&a, 0, sizeof a);
         a.scalars = g.s;
         a.n = n;
-        G1Aff gen;
-        const Fp one = fp_one();
-        gen.x = one;
-        gen.y = fp_add(one, one);
-        hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream, a, gen, b->d_points);
+        AffT<F> gen;
+        memcpy(&gen, gen_image, sizeof gen);
+        hipLaunchKernelGGL(k_ec_batch_scalar_mul<F>, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream, a, gen, b->d_points);
     }
     hipLaunchKernelGGL(k_msm_synth_scalars, dim3(grid_for(n, 4096)), dim3(GKR_BLOCK), 0, cx().stream, g.s, n, 0x7654321u);
     HIPCHK(hipGetLastError());
     for (hipEvent_t& e : g.tm.ev) HIPCHK(hipEventCreate(&e));
-    for (int i = 0; i < warmup; i++) CHK(msm_dev(b, g.s, n, 0, nullptr));
+    for (int i = 0; i < warmup; i++) CHK(msm_dev<F>(b, g.s, n, 0, nullptr));
     HIPCHK(hipStreamSynchronize(cx().stream));
     double tot = 0, ph[5] = {0, 0, 0, 0, 0}, tail = 0;
     g.tm.on = true;
-    hfp::Aff r{hfp::ZERO, hfp::ZERO};
+    hfp::AffH<HF> r{HF::zero(), HF::zero()};
     for (int i = 0; i < iters; i++) {
-        CHK(msm_dev(b, g.s, n, 0, &g.tm));
+        CHK(msm_dev<F>(b, g.s, n, 0, &g.tm));
         HIPCHK(hipEventSynchronize(g.tm.ev[5]));
         const double t0 = now_ms();
-        r = msm_host_tail(&b->w);
+        r = msm_host_tail<HF>(&b->w);
         tail += now_ms() - t0;
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, g.tm.ev[0], g.tm.ev[5]));
@@ -1187,10 +1163,97 @@ int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double* avg
         for (int k = 0; k < 5; k++) phase_ms[k] = ph[k] / iters;
     if (c_used) *c_used = b->w.c;
     if (host_tail_ms) *host_tail_ms = tail / iters;
-    if (result_or_null) {
-        memcpy(result_or_null, r.x.l, 32);
-        memcpy(result_or_null + 4, r.y.l, 32);
-    }
+    if (result_or_null) memcpy(result_or_null, &r, sizeof r);
+    return 0;
+}
+// the generators gnark-crypto uses (bn254.Generators): g1Gen = (1, 2); g2Gen below (regular form, converted at first use)
+const uint64_t* g1_generator() {
+    static const hfp::E two = hfp::add(hfp::ONE, hfp::ONE);
+    static const hfp::AffH<hfp::HFp> g{hfp::ONE, two};
+    return (const uint64_t*)&g;
+}
+const uint64_t* g2_generator() {
+    static const hfp::AffH<hfp::HFp2> g = [] {
+        // X = 10857046999023057135944570762232829481370756359578518086990519993285655852781
+        //   + 11559732032986387107991004021392285783925812861821192530917403151452391805634 u,
+        // Y = 8495653923123431417604973247489272438418190587263600148770280649306958101930
+        //   + 4082367875863433681332203403145435568316851327593401208105741076214120093531 u   (little-endian 64-bit words)
+        const hfp::E x0 = {{0x46debd5cd992f6edull, 0x674322d4f75edaddull, 0x426a00665e5c4479ull, 0x1800deef121f1e76ull}};
+        const hfp::E x1 = {{0x97e485b7aef312c2ull, 0xf1aa493335a9e712ull, 0x7260bfb731fb5d25ull, 0x198e9393920d483aull}};
+        const hfp::E y0 = {{0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull}};
+        const hfp::E y1 = {{0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull}};
+        auto mont = [](const hfp::E& v) { return hfp::mul(v, hfp::R2); };
+        return hfp::AffH<hfp::HFp2>{hfp::E2{mont(x0), mont(x1)}, hfp::E2{mont(y0), mont(y1)}};
+    }();
+    return (const uint64_t*)&g;
+}
+}  // namespace
+extern "C" {
+int gkrhip_g1_bases_create(gkrhip_g1_bases** out, const uint64_t* points, size_t n) { return abi_bases_create(out, points, n, 2); }
+int gkrhip_g2_bases_create(gkrhip_g2_bases** out, const uint64_t* points, size_t n) { return abi_bases_create(out, points, n, 4); }
+int gkrhip_g1_bases_generate(gkrhip_g1_bases** out, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
+    return abi_bases_generate<FpF>(out, base, scalars, n, flags);
+}
+int gkrhip_g2_bases_generate(gkrhip_g2_bases** out, const uint64_t base[16], const uint64_t* scalars, size_t n, int flags) {
+    return abi_bases_generate<Fp2F>(out, base, scalars, n, flags);
+}
+size_t gkrhip_g1_bases_len(const gkrhip_g1_bases* b) { return b ? b->n : 0; }
+size_t gkrhip_g2_bases_len(const gkrhip_g2_bases* b) { return b ? b->n : 0; }
+int gkrhip_g1_bases_read(const gkrhip_g1_bases* b, uint64_t* out, size_t first, size_t count) { return abi_bases_read(b, out, first, count); }
+int gkrhip_g2_bases_read(const gkrhip_g2_bases* b, uint64_t* out, size_t first, size_t count) { return abi_bases_read(b, out, first, count); }
+void gkrhip_g1_bases_destroy(gkrhip_g1_bases* b) { bases_free(b); }
+void gkrhip_g2_bases_destroy(gkrhip_g2_bases* b) { bases_free(b); }
+int gkrhip_msm_g1_set_window(gkrhip_g1_bases* b, int c) { return abi_set_window(b, c); }
+int gkrhip_msm_g2_set_window(gkrhip_g2_bases* b, int c) { return abi_set_window(b, c); }
+int gkrhip_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* b, const uint64_t* scalars, size_t n, int flags) {
+    return abi_msm<FpF, hfp::HFp>(out_affine, b, scalars, n, flags);
+}
+int gkrhip_msm_g2(uint64_t out_affine[16], gkrhip_g2_bases* b, const uint64_t* scalars, size_t n, int flags) {
+    return abi_msm<Fp2F, hfp::HFp2>(out_affine, b, scalars, n, flags);
+}
+int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t* points, const uint64_t* scalars, size_t n, int flags) {
+    gkrhip_g1_bases* b = nullptr;
+    CHK(gkrhip_g1_bases_create(&b, points, n));
+    const int rc = gkrhip_msm_g1(out_affine, b, scalars, n, flags);
+    gkrhip_g1_bases_destroy(b);
+    return rc;
+}
+int gkrhip_msm_g2_once(uint64_t out_affine[16], const uint64_t* points, const uint64_t* scalars, size_t n, int flags) {
+    gkrhip_g2_bases* b = nullptr;
+    CHK(gkrhip_g2_bases_create(&b, points, n));
+    const int rc = gkrhip_msm_g2(out_affine, b, scalars, n, flags);
+    gkrhip_g2_bases_destroy(b);
+    return rc;
+}
+int gkrhip_g1_batch_scalar_mul(uint64_t* out, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
+    if (!base || (n && (!out || !scalars))) return fail("g1_batch_scalar_mul: null argument");
+    gkrhip_g1_bases* b = nullptr;
+    CHK(gkrhip_g1_bases_generate(&b, base, scalars, n, flags));
+    const int rc = gkrhip_g1_bases_read(b, out, 0, n);
+    gkrhip_g1_bases_destroy(b);
+    return rc;
+}
+int gkrhip_g2_batch_scalar_mul(uint64_t* out, const uint64_t base[16], const uint64_t* scalars, size_t n, int flags) {
+    if (!base || (n && (!out || !scalars))) return fail("g2_batch_scalar_mul: null argument");
+    gkrhip_g2_bases* b = nullptr;
+    CHK(gkrhip_g2_bases_generate(&b, base, scalars, n, flags));
+    const int rc = gkrhip_g2_bases_read(b, out, 0, n);
+    gkrhip_g2_bases_destroy(b);
+    return rc;
+}
+int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
+                        double* host_tail_ms, uint64_t result_or_null[8]) {
+    return abi_bench_msm<FpF, hfp::HFp, gkrhip_g1_bases>(g1_generator(), logn, c_or_0, warmup, iters, avg_ms, phase_ms, c_used, host_tail_ms,
+                                                         result_or_null);
+}
+int gkrhip_bench_msm_g2(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
+                        double* host_tail_ms, uint64_t result_or_null[16]) {
+    return abi_bench_msm<Fp2F, hfp::HFp2, gkrhip_g2_bases>(g2_generator(), logn, c_or_0, warmup, iters, avg_ms, phase_ms, c_used, host_tail_ms,
+                                                           result_or_null);
+}
+int gkrhip_g2_generator(uint64_t out[16]) {
+    if (!out) return fail("g2_generator: null argument");
+    memcpy(out, g2_generator(), 128);
     return 0;
 }
 

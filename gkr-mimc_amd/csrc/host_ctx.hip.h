@@ -361,7 +361,10 @@ int lane_alloc() {
     HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));
     static_assert(kRaccWords == GKR_RACC_STRIDE, "one accumulator copy per stride");
     HIPCHK(hipMalloc(&cx().d_racc, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS));
-    HIPCHK(hipMemset(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS));
+    // (stream-ordered zeroing: the lane's stream is non-blocking, so a null-stream hipMemset -- asynchronous to the host for device
+    // memory -- is NOT ordered before the lane's first kernels; with 16 hardware queues the first proof of a new lane lost that
+    // race about once in ten runs of the solo soak: a wrong first transcript, caught by the native verifier)
+    HIPCHK(hipMemsetAsync(cx().d_racc, 0, sizeof(unsigned long long) * kRaccWords * GKR_RACC_SLOTS, cx().stream));
     HIPCHK(hipHostMalloc(&cx().h_sums, sizeof(unsigned long long) * nwords, hipHostMallocDefault));
     HIPCHK(hipMalloc(&cx().d_small, sizeof(uint4) * 2 * 8));
     HIPCHK(hipHostMalloc(&cx().h_small, sizeof(uint4) * 2 * 8, hipHostMallocDefault));
@@ -372,7 +375,7 @@ int lane_alloc() {
     *cx().h_flag = 0;
     cx().seq = 0;
     HIPCHK(hipMalloc(&cx().d_counter, 64));
-    HIPCHK(hipMemset(cx().d_counter, 0, 64));
+    HIPCHK(hipMemsetAsync(cx().d_counter, 0, 64, cx().stream));
     HIPCHK(hipHostMalloc(&cx().h_tail, kTailWords * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_tail, cx().h_tail, 0));
     HIPCHK(hipHostMalloc(&cx().h_bad, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -382,7 +385,7 @@ int lane_alloc() {
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_chal, cx().h_chal, 0));
     memset(cx().h_chal, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots);
     HIPCHK(hipMalloc(&cx().d_chal_dev, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots));
-    HIPCHK(hipMemset(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots));
+    HIPCHK(hipMemsetAsync(cx().d_chal_dev, 0, sizeof(unsigned long long) * GKR_CHAL_WORDS * kChalSlots, cx().stream));
     return 0;
 }
 // the look-ahead tables go back to the arena (end of a proof, lane teardown)

@@ -35,8 +35,9 @@ struct MsmWork {
     unsigned int* big = nullptr;
     uint4* scalars = nullptr;            // n_cap x 32 B staging of host scalars
     uint4* xyzz = nullptr;               // buckets | parts | wins planes
-    uint4* h_wins = nullptr;             // pinned: 8 planes x W
+    uint4* h_wins = nullptr;             // pinned: 4 * w16 planes x W, then the error word
     size_t nparts = 0;
+    int w16 = 2;                         // planes of a bucket: 4 * w16
     void release() {
         if (counts) (void)hipFree(counts);
         if (entries) (void)hipFree(entries);
@@ -47,22 +48,26 @@ struct MsmWork {
         *this = MsmWork();
     }
 };
-}  // namespace (the handle type is part of the C ABI)
-struct gkrhip_g1_bases {
-    uint4* d_points = nullptr;     // n x 64 B
+struct MsmBases {
+    uint4* d_points = nullptr;     // n x 64 B (G1) or 128 B (G2)
     size_t n = 0;
+    int w16 = 2;                   // 16-byte words per coordinate: 2 (Fp: G1) | 4 (Fp2: G2)
     std::mutex mu;                 // one MSM at a time per handle (they share the work buffers)
     int c_forced = 0;              // gkrhip_msm_g1_set_window
     MsmWork w;
 };
+}  // namespace (the handle types are part of the C ABI)
+struct gkrhip_g1_bases : MsmBases {};
+struct gkrhip_g2_bases : MsmBases {};
 namespace {
 
-int msm_work_prepare(MsmWork* w, size_t n, int c_forced) {
+int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     const int c = c_forced > 0 ? c_forced : msm_pick_c(n);
     if (c < 2 || c > 16) return fail("msm: window size %d outside 2..16", c);
-    if (w->counts && w->c == c && w->n_cap >= n) return 0;
+    if (w->counts && w->c == c && w->n_cap >= n && w->w16 == w16) return 0;
     w->release();
     w->c = c;
+    w->w16 = w16;
     w->W = msm_windows(c);
     w->nb = 1u << (c - 1);
     w->n_cap = n;
@@ -92,8 +97,8 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced) {
     HIPCHK(hipMalloc((void**)&w->entries, std::max<size_t>(1, (size_t)w->W * n) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->big, ((size_t)w->big_cap + 2) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
-    HIPCHK(hipMalloc((void**)&w->xyzz, 8 * (nbk + w->nparts + (size_t)w->W) * sizeof(uint4)));
-    HIPCHK(hipHostMalloc((void**)&w->h_wins, (8 * (size_t)w->W + 1) * sizeof(uint4)));      // + the error word
+    HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W) * sizeof(uint4)));
+    HIPCHK(hipHostMalloc((void**)&w->h_wins, ((size_t)4 * w16 * w->W + 1) * sizeof(uint4)));      // + the error word
     return 0;
 }
 
@@ -110,7 +115,8 @@ struct MsmTimes {      // HIP-event split of one MSM (bench only)
 
 // The device part: the W window sums of sum_{i<n} [s_i] P_i land in w->h_wins (the caller synchronises the stream).
 // d_scalars: n x 32 B on the device.
-int msm_dev(gkrhip_g1_bases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm) {
+template <class F>
+int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm) {
     MsmWork* w = &b->w;
     hipStream_t st = cx().stream;
     const size_t nbk = (size_t)w->W * w->nb;
@@ -137,9 +143,10 @@ int msm_dev(gkrhip_g1_bases* b, const uint4* d_scalars, size_t n, int flags, Msm
     // a bucket far above the mean (n / nb points per bucket and window for uniform digits) gets a workgroup of its own
     a.big_threshold = (unsigned int)std::max<size_t>(128, 4 * (n / w->nb));
     a.big_cap = w->big_cap;
-    a.buckets = G1XPlanes{w->xyzz, nbk};
-    a.parts = G1XPlanes{w->xyzz + 8 * nbk, w->nparts};
-    a.wins = G1XPlanes{w->xyzz + 8 * (nbk + w->nparts), (size_t)w->W};
+    const size_t npl = (size_t)4 * F::W16;      // planes of an XYZZ point
+    a.buckets = XPlanes{w->xyzz, nbk};
+    a.parts = XPlanes{w->xyzz + npl * nbk, w->nparts};
+    a.wins = XPlanes{w->xyzz + npl * (nbk + w->nparts), (size_t)w->W};
     a.chunk = w->chunk;
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
@@ -163,78 +170,111 @@ int msm_dev(gkrhip_g1_bases* b, const uint4* d_scalars, size_t n, int flags, Msm
     }
     HIPCHK(hipGetLastError());
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[1], st));
-    hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)((nbk + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_msm_accumulate<F>, dim3((unsigned)((nbk + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[2], st));
-    hipLaunchKernelGGL(k_msm_accumulate_big, dim3(1024), dim3(GKR_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_msm_accumulate_big<F>, dim3(1024), dim3(GKR_BLOCK), 0, st, a);
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[3], st));
-    hipLaunchKernelGGL(k_msm_reduce_chunks, dim3((unsigned)((w->nparts + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(k_msm_reduce_windows, dim3(w->W), dim3(GKR_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((unsigned)((w->nparts + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_msm_reduce_windows<F>, dim3(w->W), dim3(GKR_BLOCK), 0, st, a);
     HIPCHK(hipGetLastError());
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[4], st));
-    HIPCHK(hipMemcpyAsync(w->h_wins, a.wins.base, 8 * (size_t)w->W * sizeof(uint4), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(w->h_wins + 8 * (size_t)w->W, a.big + a.big_cap + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(w->h_wins, a.wins.base, npl * w->W * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(w->h_wins + npl * w->W, a.big + a.big_cap + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[5], st));
     return 0;
 }
 
+// coordinate j of plane group g (0: x, 1: y, 2: zz, 3: zzz) of the window sums
+inline void msm_read_coord(const MsmWork* w, int g, int j, hfp::E* out) {
+    const size_t W = (size_t)w->W, base = (size_t)g * w->w16;
+    *out = fp_from_words(w->h_wins[base * W + j], w->h_wins[(base + 1) * W + j]);
+}
+inline void msm_read_coord(const MsmWork* w, int g, int j, hfp::E2* out) {
+    const size_t W = (size_t)w->W, base = (size_t)g * w->w16;
+    out->a0 = fp_from_words(w->h_wins[base * W + j], w->h_wins[(base + 1) * W + j]);
+    out->a1 = fp_from_words(w->h_wins[(base + 2) * W + j], w->h_wins[(base + 3) * W + j]);
+}
 // sum_j 2^(c j) win_j by Horner's rule, then affine (infinity -> (0, 0), gnark-crypto's encoding)
-hfp::Aff msm_host_tail(const MsmWork* w) {
-    hfp::XYZZ acc = hfp::xyzz_inf();
-    const size_t W = (size_t)w->W;
+template <class HF>
+hfp::AffH<HF> msm_host_tail(const MsmWork* w) {
+    hfp::XyzzH<HF> acc = hfp::xyzz_inf<HF>();
     for (int j = w->W - 1; j >= 0; j--) {
         for (int k = 0; k < w->c; k++) hfp::xyzz_dbl(acc);
-        hfp::XYZZ p;
-        p.x = fp_from_words(w->h_wins[0 * W + j], w->h_wins[1 * W + j]);
-        p.y = fp_from_words(w->h_wins[2 * W + j], w->h_wins[3 * W + j]);
-        p.zz = fp_from_words(w->h_wins[4 * W + j], w->h_wins[5 * W + j]);
-        p.zzz = fp_from_words(w->h_wins[6 * W + j], w->h_wins[7 * W + j]);
+        hfp::XyzzH<HF> p;
+        msm_read_coord(w, 0, j, &p.x);
+        msm_read_coord(w, 1, j, &p.y);
+        msm_read_coord(w, 2, j, &p.zz);
+        msm_read_coord(w, 3, j, &p.zzz);
         hfp::xyzz_add(acc, p);
     }
     return hfp::to_affine(acc);
 }
+inline bool msm_scalar_error(const MsmWork* w) { return w->h_wins[(size_t)4 * w->w16 * w->W].x != 0; }
 
-int msm_check_points(const uint64_t* points, size_t n) {
+int msm_check_points(const uint64_t* points, size_t n, int w16) {
     // every coordinate must be a canonical fp.Element: the lazy range of the kernels starts from values below p
-    for (size_t i = 0; i < 2 * n; i++)
-        if (hfp::geq_p(points + 4 * i)) return fail("msm: coordinate %zu of point %zu is not a canonical fp.Element", i & 1, i >> 1);
+    const size_t per = (size_t)w16;         // fp.Elements per point: 2 (G1) | 4 (G2)
+    for (size_t i = 0; i < per * n; i++)
+        if (hfp::geq_p(points + 4 * i)) return fail("msm: element %zu of point %zu is not a canonical fp.Element", i % per, i / per);
     return 0;
 }
 
-int msm_run(gkrhip_g1_bases* b, const uint64_t* scalars, size_t n, int flags, uint64_t out_affine[8]) {
+template <class F, class HF>
+int msm_run(MsmBases* b, const uint64_t* scalars, size_t n, int flags, uint64_t* out_affine) {
     if (n > b->n) return fail("msm: %zu scalars for %zu bases", n, b->n);
     std::lock_guard<std::mutex> lk(b->mu);
-    CHK(msm_work_prepare(&b->w, std::max<size_t>(b->n, 1), b->c_forced));
+    CHK(msm_work_prepare(&b->w, std::max<size_t>(b->n, 1), b->c_forced, F::W16));
     if (n) HIPCHK(hipMemcpyAsync(b->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
-    CHK(msm_dev(b, b->w.scalars, n, flags, nullptr));
+    CHK(msm_dev<F>(b, b->w.scalars, n, flags, nullptr));
     HIPCHK(hipStreamSynchronize(cx().stream));
-    if (b->w.h_wins[8 * (size_t)b->w.W].x) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
-    const hfp::Aff r = msm_host_tail(&b->w);
-    memcpy(out_affine, r.x.l, 32);
-    memcpy(out_affine + 4, r.y.l, 32);
+    if (msm_scalar_error(&b->w)) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
+    const hfp::AffH<HF> r = msm_host_tail<HF>(&b->w);
+    memcpy(out_affine, &r, sizeof r);        // {X, Y} as consecutive fp.Elements: the G1Affine / G2Affine image
     return 0;
 }
 
-int g1_bases_alloc(gkrhip_g1_bases** out, size_t n) {
+template <class B>
+int bases_alloc(B** out, size_t n, int w16) {
     if (n > kMsmMaxPoints) return fail("msm: %zu points (at most 2^26)", n);
-    gkrhip_g1_bases* b = new gkrhip_g1_bases();
+    B* b = new B();
     b->n = n;
-    hipError_t e = hipMalloc((void**)&b->d_points, std::max<size_t>(n, 1) * 64);
+    b->w16 = w16;
+    hipError_t e = hipMalloc((void**)&b->d_points, std::max<size_t>(n, 1) * 32 * w16);
     if (e != hipSuccess) {
         delete b;
-        return fail("hipMalloc of %zu G1 points failed: %s", n, hipGetErrorString(e));
+        return fail("hipMalloc of %zu points failed: %s", n, hipGetErrorString(e));
     }
     *out = b;
     return 0;
 }
-void g1_bases_free(gkrhip_g1_bases* b) {
+template <class B>
+void bases_free(B* b) {
     if (!b) return;
     b->w.release();
     if (b->d_points) (void)hipFree(b->d_points);
     delete b;
 }
+template <class B>
+int bases_upload(B** out, const uint64_t* points, size_t n, int w16) {
+    CHK(msm_check_points(points, n, w16));
+    B* b = nullptr;
+    CHK(bases_alloc(&b, n, w16));
+    if (n) {
+        hipError_t e = hipMemcpyAsync(b->d_points, points, n * 32 * w16, hipMemcpyHostToDevice, cx().stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(cx().stream);
+        if (e != hipSuccess) {
+            bases_free(b);
+            return fail("upload of %zu points failed: %s", n, hipGetErrorString(e));
+        }
+    }
+    *out = b;
+    return 0;
+}
 // out_dev[i] = [s_i] base on the device (affine, canonical); scalars on the host
-int g1_batch_mul_dev(uint4* out_dev, const uint64_t base[8], const uint64_t* scalars, size_t n, int flags) {
-    if (hfp::geq_p(base) || hfp::geq_p(base + 4)) return fail("g1: the base point's coordinates are not canonical fp.Elements");
+template <class F>
+int batch_mul_dev(uint4* out_dev, const uint64_t* base, const uint64_t* scalars, size_t n, int flags) {
+    for (int k = 0; k < F::W16; k++)
+        if (hfp::geq_p(base + 4 * k)) return fail("the base point's coordinates are not canonical fp.Elements");
     if (!n) return 0;
     uint4* d_s = nullptr;
     HIPCHK(hipMalloc((void**)&d_s, n * 32));
@@ -245,14 +285,14 @@ int g1_batch_mul_dev(uint4* out_dev, const uint64_t base[8], const uint64_t* sca
         a.scalars = d_s;
         a.n = n;
         a.scalars_mont = (flags & GKRHIP_MSM_SCALARS_MONT) ? 1 : 0;
-        G1Aff bp;
-        memcpy(bp.x.v, base, 32);
-        memcpy(bp.y.v, base + 4, 32);
-        hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream, a, bp, out_dev);
+        AffT<F> bp;
+        static_assert(sizeof(bp) == (size_t)32 * F::W16, "affine image");
+        memcpy(&bp, base, sizeof bp);
+        hipLaunchKernelGGL(k_ec_batch_scalar_mul<F>, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream, a, bp, out_dev);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(cx().stream);
     }
     (void)hipFree(d_s);
-    if (e != hipSuccess) return fail("g1 batch scalar multiplication failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail("batch scalar multiplication failed: %s", hipGetErrorString(e));
     return 0;
 }

@@ -258,7 +258,7 @@ int spec_ensure() {
     HIPCHK(hipHostGetDevicePointer((void**)&cx().d_spec, cx().h_spec, 0));
     memset(cx().h_spec, 0, sizeof(unsigned long long) * 2 * GKR_SPEC_BUF_WORDS);
     HIPCHK(hipMalloc(&cx().d_spec_racc, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS));
-    HIPCHK(hipMemset(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS));
+    HIPCHK(hipMemsetAsync(cx().d_spec_racc, 0, sizeof(unsigned long long) * GKR_SPEC_CAND * GKR_SPEC_SET_WORDS, cx().stream));      // stream-ordered: see lane_alloc
     for (int i = 0; i < GKR_SPEC_CAND; i++) cx().spec_pts[i] = hfr::from_u64((hfr::u64)i);
     for (int i = 0; i < GKR_SPEC_CAND; i++) {      // 1 / prod_{j != i} (i - j)
         E den = hfr::ONE;

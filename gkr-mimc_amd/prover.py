@@ -102,6 +102,17 @@ ABI = {
     "gkrhip_msm_g1_set_window": (_I, [_P, _I]),
     "gkrhip_g1_batch_scalar_mul": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_bench_msm_g1": (_I, [_I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), C.POINTER(_D), _P]),
+    "gkrhip_g2_bases_create": (_I, [C.POINTER(_P), _P, _SZ]),
+    "gkrhip_g2_bases_generate": (_I, [C.POINTER(_P), _P, _P, _SZ, _I]),
+    "gkrhip_g2_bases_len": (_SZ, [_P]),
+    "gkrhip_g2_bases_read": (_I, [_P, _P, _SZ, _SZ]),
+    "gkrhip_g2_bases_destroy": (None, [_P]),
+    "gkrhip_msm_g2": (_I, [_P, _P, _P, _SZ, _I]),
+    "gkrhip_msm_g2_once": (_I, [_P, _P, _P, _SZ, _I]),
+    "gkrhip_msm_g2_set_window": (_I, [_P, _I]),
+    "gkrhip_g2_batch_scalar_mul": (_I, [_P, _P, _P, _SZ, _I]),
+    "gkrhip_g2_generator": (_I, [_P]),
+    "gkrhip_bench_msm_g2": (_I, [_I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), C.POINTER(_D), _P]),
     "gkrhip_profile_reset": (_I, [_SZ]),
     "gkrhip_profile_get": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
@@ -636,52 +647,56 @@ def bench_compute_h(logn, warmup=1, iters=3):
 MSM_SCALARS_MONT = 1
 
 
-def _g1(a):
-    """(n, 8) uint64: the memory image of a Go []bn254.G1Affine."""
+def _pts(a, words):
+    """(n, words) uint64: the memory image of a Go []bn254.G1Affine (8 words per point) or []bn254.G2Affine (16)."""
     a = np.ascontiguousarray(a, dtype=np.uint64)
     if a.ndim == 1:
-        a = a.reshape(1, 8)
-    assert a.ndim == 2 and a.shape[1] == 8
+        a = a.reshape(1, words)
+    assert a.ndim == 2 and a.shape[1] == words
     return a
 
 
-class G1Bases:
+class _Bases:
     """Bases of a multi-scalar multiplication resident in HBM (a proving-key vector such as pk.G1.A, fixed across proofs)."""
+    GROUP, WORDS = "g1", 8
 
     def __init__(self, points=None, base=None, scalars=None, scalars_mont=False):
         self._h = _P()
         lib = load()
         if points is not None:
-            points = _g1(points)
-            _check(lib.gkrhip_g1_bases_create(C.byref(self._h), _ptr(points), points.shape[0]))
+            points = _pts(points, self.WORDS)
+            _check(self._f("%s_bases_create")(C.byref(self._h), _ptr(points), points.shape[0]))
         else:       # bases[i] = [scalars[i]] base, generated on the device
-            base, scalars = _g1(base), _fr(scalars)
-            _check(lib.gkrhip_g1_bases_generate(C.byref(self._h), _ptr(base), _ptr(scalars), scalars.shape[0],
+            base, scalars = _pts(base, self.WORDS), _fr(scalars)
+            _check(self._f("%s_bases_generate")(C.byref(self._h), _ptr(base), _ptr(scalars), scalars.shape[0],
                                                 MSM_SCALARS_MONT if scalars_mont else 0))
 
+    def _f(self, pattern):
+        return getattr(load(), "gkrhip_" + pattern % self.GROUP)
+
     def __len__(self):
-        return int(load().gkrhip_g1_bases_len(self._h))
+        return int(self._f("%s_bases_len")(self._h))
 
     def read(self, first=0, count=None):
         count = len(self) - first if count is None else count
-        out = np.zeros((count, 8), dtype=np.uint64)
-        _check(load().gkrhip_g1_bases_read(self._h, _ptr(out), first, count))
+        out = np.zeros((count, self.WORDS), dtype=np.uint64)
+        _check(self._f("%s_bases_read")(self._h, _ptr(out), first, count))
         return out
 
     def set_window(self, c):
-        _check(load().gkrhip_msm_g1_set_window(self._h, int(c)))
+        _check(self._f("msm_%s_set_window")(self._h, int(c)))
 
     def multi_exp(self, scalars, scalars_mont=False):
-        """sum_i [scalars[i]] bases[i] as a G1Affine image (8,): (*G1Affine).MultiExp(points, scalars, config)."""
+        """sum_i [scalars[i]] bases[i] as an affine image: (*G1Affine).MultiExp / (*G2Affine).MultiExp(points, scalars, config)."""
         scalars = _fr(scalars) if len(scalars) else np.zeros((0, 4), dtype=np.uint64)
-        out = np.zeros(8, dtype=np.uint64)
-        _check(load().gkrhip_msm_g1(_ptr(out), self._h, _ptr(scalars) if scalars.shape[0] else None, scalars.shape[0],
-                                    MSM_SCALARS_MONT if scalars_mont else 0))
+        out = np.zeros(self.WORDS, dtype=np.uint64)
+        _check(self._f("msm_%s")(_ptr(out), self._h, _ptr(scalars) if scalars.shape[0] else None, scalars.shape[0],
+                                 MSM_SCALARS_MONT if scalars_mont else 0))
         return out
 
     def close(self):
         if self._h:
-            load().gkrhip_g1_bases_destroy(self._h)
+            self._f("%s_bases_destroy")(self._h)
             self._h = _P()
 
     def __del__(self):
@@ -691,35 +706,75 @@ class G1Bases:
             pass
 
 
-def multi_exp_g1(points, scalars, scalars_mont=False):
-    """(*G1Affine).MultiExp(points, scalars, config) in one call on host buffers."""
-    points = _g1(points) if len(points) else np.zeros((0, 8), dtype=np.uint64)
+class G1Bases(_Bases):
+    GROUP, WORDS = "g1", 8
+
+
+class G2Bases(_Bases):
+    GROUP, WORDS = "g2", 16
+
+
+def _multi_exp(group, words, points, scalars, scalars_mont):
+    points = _pts(points, words) if len(points) else np.zeros((0, words), dtype=np.uint64)
     scalars = _fr(scalars) if len(scalars) else np.zeros((0, 4), dtype=np.uint64)
     assert points.shape[0] == scalars.shape[0]
-    out = np.zeros(8, dtype=np.uint64)
+    out = np.zeros(words, dtype=np.uint64)
     n = points.shape[0]
-    _check(load().gkrhip_msm_g1_once(_ptr(out), _ptr(points) if n else None, _ptr(scalars) if n else None, n,
-                                     MSM_SCALARS_MONT if scalars_mont else 0))
+    _check(getattr(load(), "gkrhip_msm_%s_once" % group)(_ptr(out), _ptr(points) if n else None, _ptr(scalars) if n else None, n,
+                                                          MSM_SCALARS_MONT if scalars_mont else 0))
+    return out
+
+
+def multi_exp_g1(points, scalars, scalars_mont=False):
+    """(*G1Affine).MultiExp(points, scalars, config) in one call on host buffers."""
+    return _multi_exp("g1", 8, points, scalars, scalars_mont)
+
+
+def multi_exp_g2(points, scalars, scalars_mont=False):
+    """(*G2Affine).MultiExp(points, scalars, config) (prove.go:277) in one call on host buffers."""
+    return _multi_exp("g2", 16, points, scalars, scalars_mont)
+
+
+def _batch_mul(group, words, base, scalars, scalars_mont):
+    base, scalars = _pts(base, words), _fr(scalars)
+    out = np.zeros((scalars.shape[0], words), dtype=np.uint64)
+    _check(getattr(load(), "gkrhip_%s_batch_scalar_mul" % group)(_ptr(out), _ptr(base), _ptr(scalars), scalars.shape[0],
+                                                                 MSM_SCALARS_MONT if scalars_mont else 0))
     return out
 
 
 def batch_scalar_multiplication_g1(base, scalars, scalars_mont=False):
     """bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): (n, 8) G1Affine images."""
-    base, scalars = _g1(base), _fr(scalars)
-    out = np.zeros((scalars.shape[0], 8), dtype=np.uint64)
-    _check(load().gkrhip_g1_batch_scalar_mul(_ptr(out), _ptr(base), _ptr(scalars), scalars.shape[0],
-                                             MSM_SCALARS_MONT if scalars_mont else 0))
+    return _batch_mul("g1", 8, base, scalars, scalars_mont)
+
+
+def batch_scalar_multiplication_g2(base, scalars, scalars_mont=False):
+    """bn254.BatchScalarMultiplicationG2(base, scalars): (n, 16) G2Affine images."""
+    return _batch_mul("g2", 16, base, scalars, scalars_mont)
+
+
+def g2_generator():
+    out = np.zeros(16, dtype=np.uint64)
+    _check(load().gkrhip_g2_generator(_ptr(out)))
     return out
+
+
+def _bench_msm(group, words, logn, c, warmup, iters):
+    ms, tail, cu = C.c_double(0), C.c_double(0), C.c_int(0)
+    ph = (C.c_double * 5)()
+    res = np.zeros(words, dtype=np.uint64)
+    _check(getattr(load(), "gkrhip_bench_msm_%s" % group)(logn, c, warmup, iters, C.byref(ms), ph, C.byref(cu), C.byref(tail), _ptr(res)))
+    return {"ms": ms.value, "c": cu.value, "host_tail_ms": tail.value, "result": res,
+            "phases_ms": dict(zip(("sort", "accumulate", "big_buckets", "reduce", "copy"), list(ph)))}
 
 
 def bench_msm_g1(logn, c=0, warmup=1, iters=3):
     """MSM of 2^logn synthetic device-resident bases and scalars: dict(ms, phases_ms, c, host_tail_ms, result)."""
-    ms, tail, cu = C.c_double(0), C.c_double(0), C.c_int(0)
-    ph = (C.c_double * 5)()
-    res = np.zeros(8, dtype=np.uint64)
-    _check(load().gkrhip_bench_msm_g1(logn, c, warmup, iters, C.byref(ms), ph, C.byref(cu), C.byref(tail), _ptr(res)))
-    return {"ms": ms.value, "c": cu.value, "host_tail_ms": tail.value, "result": res,
-            "phases_ms": dict(zip(("sort", "accumulate", "big_buckets", "reduce", "copy"), list(ph)))}
+    return _bench_msm("g1", 8, logn, c, warmup, iters)
+
+
+def bench_msm_g2(logn, c=0, warmup=1, iters=3):
+    return _bench_msm("g2", 16, logn, c, warmup, iters)
 
 
 def bench_partial_eval(bn, warmup=10, iters=200):

@@ -285,7 +285,8 @@ int gkrhip_bench_compute_h(int logn, int warmup, int iters, double *avg_ms, int 
  * the one-call form with the exact shape of MultiExp(points, scalars, config).
  * gnark-crypto is an un-vendored dependency (v0.6.1-0.20220110145513-493bb1c180d9): the result is a group element whose
  * affine coordinates are unique, pinned by the test oracle's big-integer arithmetic, not by bytes of the Go binary
- * ("parity unpinned").  n <= 2^26.  G2 (prove.go:277) is not built. */
+ * ("parity unpinned").  n <= 2^26.  The G2 MSM of the same function (prove.go:277, Bs over pk.G2.B) is the gkrhip_*_g2 family
+ * below: the same kernels over Fp2 coordinates; a bn254.G2Affine is {X, Y fptower.E2} = {X.A0, X.A1, Y.A0, Y.A1} = 16 uint64. */
 #define GKRHIP_MSM_SCALARS_MONT 1
 typedef struct gkrhip_g1_bases gkrhip_g1_bases;
 int gkrhip_g1_bases_create(gkrhip_g1_bases **out, const uint64_t *points /* n x 8 */, size_t n);
@@ -302,6 +303,20 @@ int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t *points, const uin
 int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
 /* bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out[i] = [scalars[i]] base as G1Affine */
 int gkrhip_g1_batch_scalar_mul(uint64_t *out /* n x 8 */, const uint64_t base[8], const uint64_t *scalars, size_t n, int flags);
+/* G2: (*G2Jac).MultiExp(points, scalars, config) (prove.go:277) and BatchScalarMultiplicationG2; same conventions, 16 uint64 per point */
+typedef struct gkrhip_g2_bases gkrhip_g2_bases;
+int gkrhip_g2_bases_create(gkrhip_g2_bases **out, const uint64_t *points /* n x 16 */, size_t n);
+int gkrhip_g2_bases_generate(gkrhip_g2_bases **out, const uint64_t base[16], const uint64_t *scalars /* n x 4 */, size_t n, int flags);
+size_t gkrhip_g2_bases_len(const gkrhip_g2_bases *b);
+int gkrhip_g2_bases_read(const gkrhip_g2_bases *b, uint64_t *out /* count x 16 */, size_t first, size_t count);
+void gkrhip_g2_bases_destroy(gkrhip_g2_bases *b);
+int gkrhip_msm_g2(uint64_t out_affine[16], gkrhip_g2_bases *b, const uint64_t *scalars /* n x 4 */, size_t n, int flags);
+int gkrhip_msm_g2_once(uint64_t out_affine[16], const uint64_t *points, const uint64_t *scalars, size_t n, int flags);
+int gkrhip_msm_g2_set_window(gkrhip_g2_bases *b, int c);
+int gkrhip_g2_batch_scalar_mul(uint64_t *out /* n x 16 */, const uint64_t base[16], const uint64_t *scalars, size_t n, int flags);
+int gkrhip_g2_generator(uint64_t out[16]);      /* gnark-crypto's g2Gen (bn254.Generators), Montgomery image */
+int gkrhip_bench_msm_g2(int logn, int c_or_0, int warmup, int iters, double *avg_ms, double phase_ms[5], int *c_used,
+                        double *host_tail_ms, uint64_t result_or_null[16]);
 /* MSM of 2^logn synthetic device-resident bases ([k_i] G, k_i pseudo-random) and scalars (pseudo-random below q):
  * *avg_ms = HIP-event time per MSM up to the window sums' arrival on the host (no scalar upload); phase_ms[5] = digit sort,
  * bucket accumulation, big buckets, window reduction, copy of the window sums; *c_used = the window size; result_or_null = the

@@ -112,3 +112,98 @@ def scalars_to_image(ss):
 
 def scalar_from_limbs(l):
     return sum(int(l[i]) << (64 * i) for i in range(4))
+
+
+# ---- G2: the same textbook law over Fp2 = Fp[u] / (u^2 + 1) on the twist y^2 = x^3 + 3 / (9 + u) ---------------------------
+# (gnark-crypto's bn254.G2Affine {X, Y fptower.E2{A0, A1}}; MultiExp on G2 at prover/gadget/prove.go:277.)  Elements of Fp2 are
+# pairs (a0, a1) of Python integers.  Pinned in tests/test_oracle_ec.py: generator on the twist, [r] G2 = infinity, group axioms.
+def f2_add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def f2_sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2_inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, P)
+    return (a[0] * n % P, (-a[1] * n) % P)
+
+
+def f2_small(k):
+    return (k % P, 0)
+
+
+B2 = f2_mul(f2_small(3), f2_inv((9, 1)))
+G2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+       11559732032986387107991004021392285783925812861821192530917403151452391805634),
+      (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+       4082367875863433681332203403145435568316851327593401208105741076214120093531))      # gnark-crypto's g2Gen
+
+
+def g2_on_curve(pt):
+    if pt is INF:
+        return True
+    x, y = pt
+    return f2_mul(y, y) == f2_add(f2_mul(f2_mul(x, x), x), B2)
+
+
+def g2_neg(pt):
+    return INF if pt is INF else (pt[0], f2_sub((0, 0), pt[1]))
+
+
+def g2_add(a, b):
+    if a is INF:
+        return b
+    if b is INF:
+        return a
+    x1, y1 = a
+    x2, y2 = b
+    if x1 == x2:
+        if f2_add(y1, y2) == (0, 0):
+            return INF
+        lam = f2_mul(f2_mul(f2_small(3), f2_mul(x1, x1)), f2_inv(f2_add(y1, y1)))
+    else:
+        lam = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam), x1), x2)
+    return (x3, f2_sub(f2_mul(lam, f2_sub(x1, x3)), y1))
+
+
+def g2_mul(k, pt):
+    acc = INF
+    while k:
+        if k & 1:
+            acc = g2_add(acc, pt)
+        pt = g2_add(pt, pt)
+        k >>= 1
+    return acc
+
+
+def g2_msm(points, scalars):
+    acc = INF
+    for p, s in zip(points, scalars):
+        acc = g2_add(acc, g2_mul(s, p))
+    return acc
+
+
+def g2_point_to_image(pt):
+    """(16,) uint64: gnark-crypto's G2Affine {X.A0, X.A1, Y.A0, Y.A1} (Montgomery; infinity = zeros)."""
+    if pt is INF:
+        return np.zeros(16, dtype=np.uint64)
+    (x0, x1), (y0, y1) = pt
+    return np.array(fp_to_limbs(x0) + fp_to_limbs(x1) + fp_to_limbs(y0) + fp_to_limbs(y1), dtype=np.uint64)
+
+
+def g2_point_from_image(img):
+    img = np.asarray(img, dtype=np.uint64).reshape(16)
+    if not img.any():
+        return INF
+    return ((fp_from_limbs(img[0:4]), fp_from_limbs(img[4:8])), (fp_from_limbs(img[8:12]), fp_from_limbs(img[12:16])))
+
+
+def g2_points_to_image(pts):
+    return np.stack([g2_point_to_image(p) for p in pts]) if len(pts) else np.zeros((0, 16), dtype=np.uint64)

@@ -95,6 +95,37 @@ int main() {
         if (memcmp(got.x.l, w3, 32) || memcmp(got.y.l, w3 + 4, 32)) bad++;
         n++;
     }
+    // Fp2 (the coordinates of G2): the lazy device-portable ops against the host policy, then the host curve code on the twist
+    for (int it = 0; it < 20000; it++) {
+        const Fp2 a = {below2p(it % 4), below2p((it / 4) % 4)}, b = {below2p((it / 16) % 4), below2p(it % 3)};
+        const hfp::E2 ha = {to_host(a.a0), to_host(a.a1)}, hb = {to_host(b.a0), to_host(b.a1)};
+        const Fp2 m = fp2_mul(a, b), q2 = fp2_sqr(a);
+        const hfp::E2 hm = hfp::HFp2::mul(ha, hb), hq = hfp::HFp2::sqr(ha);
+        if (!same(m.a0, hm.a0) || !same(m.a1, hm.a1) || !same(q2.a0, hq.a0) || !same(q2.a1, hq.a1)) bad++;
+        n++;
+    }
+    {
+        // gnark-crypto's g2Gen (regular form, little-endian words) on y^2 = x^3 + 3/(9 + u); 2G + G == G + 2G; results on the twist
+        const hfp::E x0 = {{0x46debd5cd992f6edull, 0x674322d4f75edaddull, 0x426a00665e5c4479ull, 0x1800deef121f1e76ull}};
+        const hfp::E x1 = {{0x97e485b7aef312c2ull, 0xf1aa493335a9e712ull, 0x7260bfb731fb5d25ull, 0x198e9393920d483aull}};
+        const hfp::E y0 = {{0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull}};
+        const hfp::E y1 = {{0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull}};
+        const hfp::AffH<hfp::HFp2> g2 = {hfp::E2{hfp::mul(x0, hfp::R2), hfp::mul(x1, hfp::R2)}, hfp::E2{hfp::mul(y0, hfp::R2), hfp::mul(y1, hfp::R2)}};
+        if (!hfp::on_curve(g2)) bad++;
+        hfp::XyzzH<hfp::HFp2> d = hfp::from_affine(g2), t = hfp::from_affine(g2);
+        hfp::xyzz_dbl(d);                                    // 2G
+        hfp::XyzzH<hfp::HFp2> a3 = d;
+        hfp::xyzz_add(a3, hfp::from_affine(g2));             // 2G + G
+        hfp::xyzz_add(t, d);                                 // G + 2G
+        const hfp::AffH<hfp::HFp2> r1 = hfp::to_affine(a3), r2 = hfp::to_affine(t);
+        if (!(r1.x == r2.x) || !(r1.y == r2.y) || !hfp::on_curve(r1)) bad++;
+        hfp::XyzzH<hfp::HFp2> z = a3;
+        hfp::XyzzH<hfp::HFp2> neg = a3;
+        neg.y = hfp::HFp2::sub(hfp::HFp2::zero(), neg.y);
+        hfp::xyzz_add(z, neg);                               // P + (-P) = infinity
+        if (!hfp::is_inf(z)) bad++;
+        n++;
+    }
     printf("cases=%ld bad=%ld skip_overflows=%ld\n", n, bad, fr_skip_overflows);
     return bad ? 1 : 0;
 }

@@ -1,0 +1,130 @@
+"""GPU parity tests of the G2 multi-scalar multiplication ((*G2Jac).MultiExp at prover/gadget/prove.go:277, Bs over pk.G2.B)
+through the C ABI: bit-exact (affine images) against the big-integer oracle of oracle/pyoracle_ec.py ("parity unpinned" against
+Go bytes: gnark-crypto is un-vendored; pinned by tests/test_oracle_ec.py on the twist equation, the generator, [r] G2 = infinity
+and the group axioms).  Sizes the Python oracle does not reach in seconds are checked through the bases' known discrete
+logarithms: MSM over [k_i] G2 with scalars s_i must be [sum k_i s_i] G2 -- one scalar multiplication for the oracle."""
+import importlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import coracle as c  # noqa: E402
+import pyoracle_ec as ec  # noqa: E402
+from test_gpu_msm import rand_scalars, _synth_scalars  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+Q = ec.R_ORDER
+G2IMG = ec.g2_point_to_image(ec.G2)
+
+
+@pytest.fixture(scope="module")
+def gk():
+    g = importlib.import_module("gkr-mimc_amd")
+    g.init(0)
+    return g
+
+
+def ints(arr):
+    return [sum(int(row[k]) << (64 * k) for k in range(4)) for row in np.asarray(arr).reshape(-1, 4)]
+
+
+def test_g2_generator_and_batch_scalar_mul(gk):
+    assert gk.g2_generator().tolist() == G2IMG.tolist()
+    rng = random.Random(3)
+    sc = rand_scalars(rng, 24)
+    got = gk.batch_scalar_multiplication_g2(G2IMG, sc)
+    for row, k in zip(got, ints(sc)):
+        assert row.tolist() == ec.g2_point_to_image(ec.g2_mul(k, ec.G2)).tolist(), k
+    assert not gk.batch_scalar_multiplication_g2(np.zeros(16, dtype=np.uint64), sc[:3]).any()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 100])
+def test_msm_g2_vs_oracle(gk, n):
+    rng = random.Random(200 + n)
+    ks = [rng.randrange(Q) for _ in range(n)]
+    pts = [ec.g2_mul(k, ec.G2) for k in ks]
+    if n >= 17:
+        pts[3] = ec.INF                     # gnark-crypto's (0, 0): skipped
+        pts[5] = pts[4]                     # repeated point
+        pts[11] = ec.g2_neg(pts[10])        # a point and its negative
+    img = ec.g2_points_to_image(pts)
+    sc = rand_scalars(rng, n)
+    if n >= 17:
+        sc[5] = sc[4]                       # same point, same scalar: the bucket meets P + P (doubling branch)
+        sc[11] = sc[10]                     # P and -P in one bucket
+    want = ec.g2_point_to_image(ec.g2_msm(pts, ints(sc)))
+    assert gk.multi_exp_g2(img, sc).tolist() == want.tolist()
+    if n:
+        b = gk.G2Bases(points=img)
+        assert len(b) == n and b.multi_exp(sc).tolist() == want.tolist()
+        m = n // 2
+        assert b.multi_exp(sc[:m]).tolist() == ec.g2_point_to_image(ec.g2_msm(pts[:m], ints(sc[:m]))).tolist()
+        b.close()
+
+
+def _dlog_check(gk, n, seed, cw=0, skew=False):
+    """bases [k_i] G2 generated on the device, MSM(s) against [sum k_i s_i] G2 (the oracle's single scalar multiplication)."""
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    b = gk.G2Bases(base=G2IMG, scalars=k)
+    if cw:
+        b.set_window(cw)
+    if skew:
+        r = random.Random(seed)
+        s = ec.scalars_to_image([r.choice([0, 1, 1, 1, 2, Q - 1]) for _ in range(n)])
+    else:
+        s = rand_scalars(random.Random(seed), n)
+    tot = sum(x * y for x, y in zip(ints(k), ints(s))) % Q
+    assert b.multi_exp(s).tolist() == ec.g2_point_to_image(ec.g2_mul(tot, ec.G2)).tolist(), (n, seed, cw, skew)
+    head = b.read(0, 2)
+    assert head[1].tolist() == ec.g2_point_to_image(ec.g2_mul(ints(k[1:2])[0], ec.G2)).tolist()
+    b.close()
+
+
+@pytest.mark.parametrize("cw", [2, 5, 8, 11, 13, 16])
+def test_msm_g2_window_sizes(gk, cw):
+    _dlog_check(gk, 700, 40 + cw, cw=cw)
+
+
+def test_msm_g2_larger_sizes_and_skew(gk):
+    _dlog_check(gk, 1 << 12, 1)
+    _dlog_check(gk, 1 << 16, 2)
+    _dlog_check(gk, 5000, 3, skew=True)          # the 0/1 wires of a real witness: the workgroup-per-bucket path
+    # all-cancelling input: the point at infinity, encoded as zeros
+    k = rand_scalars(random.Random(9), 50)
+    pts = gk.batch_scalar_multiplication_g2(G2IMG, k)
+    pm = np.concatenate([pts, pts])
+    sc = ec.scalars_to_image([7] * 50 + [Q - 7] * 50)
+    assert not gk.multi_exp_g2(pm, sc).any()
+
+
+def test_msm_g2_errors_and_montgomery_scalars(gk):
+    rng = random.Random(5)
+    k = rand_scalars(rng, 6)
+    pts = gk.batch_scalar_multiplication_g2(G2IMG, k)
+    bad = pts.copy()
+    bad[2, 7] = np.uint64(0xFFFFFFFFFFFFFFFF)            # X.A1 >= p
+    with pytest.raises(gk.GkrHipError, match="canonical"):
+        gk.multi_exp_g2(bad, k)
+    vals = [rng.randrange(Q) for _ in range(6)]
+    want = gk.multi_exp_g2(pts, ec.scalars_to_image(vals))
+    assert gk.multi_exp_g2(pts, c.from_ints(vals), scalars_mont=True).tolist() == want.tolist()
+    assert want.tolist() == ec.g2_point_to_image(ec.g2_mul(sum(a * b for a, b in zip(ints(k), vals)) % Q, ec.G2)).tolist()
+
+
+def test_bench_msm_g2_result(gk):
+    """The G2 micro-benchmark computes a real MSM (same synthetic scalars as the G1 one, bases [k_i] G2)."""
+    logn = 8
+    n = 1 << logn
+    r = gk.bench_msm_g2(logn, warmup=1, iters=2)
+    tot = sum(a * b for a, b in zip(_synth_scalars(n, 0x1234567), _synth_scalars(n, 0x7654321))) % Q
+    assert r["result"].tolist() == ec.g2_point_to_image(ec.g2_mul(tot, ec.G2)).tolist()
+    assert r["ms"] > 0

@@ -97,6 +97,21 @@ def test_c_oracle_batch_and_linearity():
     assert got.tolist() == c.g1_scalar_mul(c.G1_GEN, ec.scalar_to_limbs(tot)).tolist()
 
 
+def test_g2_curve_facts_python():
+    """G2 of the oracle: gnark-crypto's generator on the twist y^2 = x^3 + 3/(9 + u), order r, group axioms, images."""
+    assert ec.g2_on_curve(ec.G2)
+    assert ec.g2_mul(ec.R_ORDER, ec.G2) is ec.INF
+    assert ec.g2_mul(ec.R_ORDER - 1, ec.G2) == ec.g2_neg(ec.G2)
+    rng = random.Random(6)
+    a, b = rng.randrange(ec.R_ORDER), rng.randrange(ec.R_ORDER)
+    pa, pb = ec.g2_mul(a, ec.G2), ec.g2_mul(b, ec.G2)
+    assert ec.g2_on_curve(pa) and ec.g2_add(pa, pb) == ec.g2_mul((a + b) % ec.R_ORDER, ec.G2) == ec.g2_add(pb, pa)
+    assert ec.g2_mul(b, pa) == ec.g2_mul(a * b % ec.R_ORDER, ec.G2)
+    assert ec.g2_add(pa, ec.g2_neg(pa)) is ec.INF and ec.g2_add(pa, pa) == ec.g2_mul(2, pa)
+    assert ec.g2_point_from_image(ec.g2_point_to_image(pa)) == pa
+    assert ec.g2_msm([pa, pb, ec.INF], [3, 5, 7]) == ec.g2_mul((3 * a + 5 * b) % ec.R_ORDER, ec.G2)
+
+
 def test_fp_schedule_and_host_g1_on_cpu():
     """The generated Fp schedules (portable branch, every untracked multiply-add checked for wrap-around) and the host curve
     code of the MSM's scalar tail against the oracle."""
