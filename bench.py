@@ -925,6 +925,13 @@ def main():
                                                          "8 M + 2 S) at its measured issue cost (%.1f / %.1f cycles per wave), every lane busy, "
                                                          "nominal %.1f GHz" % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ)}
             micro["msm_g1_2p%d" % lg] = e
+        r = gk.bench_msm_g2(20, warmup=1, iters=3)
+        micro["msm_g2_2p20"] = {"ms": r["ms"], "points_per_s": float(1 << 20) / (r["ms"] * 1e-3), "window_bits": r["c"], "phases_ms": r["phases_ms"],
+                                "host_tail_ms": r["host_tail_ms"],
+                                "field_products_per_s": 28.0 * (-(-255 // r["c"])) * (1 << 20) / (r["phases_ms"]["accumulate"] * 1e-3),
+                                "mirrors": "(*G2Jac).MultiExp(points, scalars, cfg) (prover/gadget/prove.go:277): 2^20 random points [k_i]G2, "
+                                           "random scalars; the same kernels as G1 over Fp2 coordinates (a mixed addition is 28 Fp products "
+                                           "instead of 10)"}
         ms, npass, by = gk.bench_compute_h(24, warmup=1, iters=3)
         micro["compute_h_2p24"] = {"ms": ms, "passes": npass, "GB_per_s": by / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "field_products": COMPUTE_H_PRODUCTS(24), "field_products_per_s": COMPUTE_H_PRODUCTS(24) / (ms * 1e-3),

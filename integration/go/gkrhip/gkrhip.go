@@ -484,3 +484,34 @@ func MultiExpG1(out, points unsafe.Pointer, scalars []fr.Element, scalarsMont bo
 func BatchScalarMultiplicationG1(out, base unsafe.Pointer, scalars []fr.Element) {
 	must(C.gkrhip_g1_batch_scalar_mul((*C.uint64_t)(out), (*C.uint64_t)(base), ptr(scalars), C.size_t(len(scalars)), 0))
 }
+
+// ---- G2: (*G2Jac).MultiExp (prove.go:277) ---------------------------------------------------------------------------
+// A bn254.G2Affine is {X, Y fptower.E2{A0, A1 fp.Element}} = 16 uint64 in Montgomery form, infinity = zeros.
+
+// G2Bases is a proving-key vector on G2 (pk.G2.B) resident in HBM.
+type G2Bases struct{ h *C.gkrhip_g2_bases }
+
+func NewG2Bases(points unsafe.Pointer, n int) *G2Bases {
+	b := &G2Bases{}
+	must(C.gkrhip_g2_bases_create(&b.h, (*C.uint64_t)(points), C.size_t(n)))
+	runtime.SetFinalizer(b, func(b *G2Bases) { b.Free() })
+	return b
+}
+
+func (b *G2Bases) Free() {
+	if b.h != nil {
+		C.gkrhip_g2_bases_destroy(b.h)
+		b.h = nil
+	}
+}
+
+func (b *G2Bases) Len() int { return int(C.gkrhip_g2_bases_len(b.h)) }
+
+// MultiExp writes sum_i [scalars[i]] bases[i] into out (a *bn254.G2Affine).
+func (b *G2Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont bool) {
+	flags := C.int(0)
+	if scalarsMont {
+		flags = C.GKRHIP_MSM_SCALARS_MONT
+	}
+	must(C.gkrhip_msm_g2((*C.uint64_t)(out), b.h, ptr(scalars), C.size_t(len(scalars)), flags))
+}

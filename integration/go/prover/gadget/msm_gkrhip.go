@@ -3,7 +3,7 @@
 // GPU bodies of the G1 multi-scalar multiplications of the Groth16 part of the gadget's prover
 // (prover/gadget/prove.go:76,91 krsNotGkr / KrsPrivNotGkr over pk.privKNotGkr; :189 bs1 over pk.G1.B; :202 ar over pk.G1.A;
 // :221 krs2 over pk.G1.Z with the h of computeH).  Drop into gkr-mimc/prover/gadget/ and replace the MultiExp calls named
-// below by these helpers (the G2 MSM of :277 stays on the CPU).  Uncompiled here (no Go toolchain in the build image); the
+// below by these helpers; multiExpG2Jac does the same for the G2 MSM of :277 (Bs over pk.G2.B).  Uncompiled here (no Go toolchain in the build image); the
 // entry points are exercised through the C ABI by tests/test_gpu_msm.py.
 //
 // The bases of these calls are vectors of the proving key -- the same for every proof -- so they are uploaded once
@@ -54,5 +54,32 @@ func multiExpG1Affine(res *bn254.G1Affine, points []bn254.G1Affine, scalars []fr
 func multiExpG1Jac(res *bn254.G1Jac, points []bn254.G1Affine, scalars []fr.Element) {
 	var aff bn254.G1Affine
 	multiExpG1Affine(&aff, points, scalars)
+	res.FromAffine(&aff)
+}
+
+var (
+	g2BasesMu    sync.Mutex
+	g2BasesCache = map[*bn254.G2Affine]*gkrhip.G2Bases{}
+)
+
+func g2BasesOf(points []bn254.G2Affine) *gkrhip.G2Bases {
+	g2BasesMu.Lock()
+	defer g2BasesMu.Unlock()
+	key := &points[0]
+	if b, ok := g2BasesCache[key]; ok && b.Len() == len(points) {
+		return b
+	}
+	b := gkrhip.NewG2Bases(unsafe.Pointer(&points[0]), len(points))
+	g2BasesCache[key] = b
+	return b
+}
+
+// multiExpG2Jac replaces `Bs.MultiExp(pk.G2.B, wireValuesB, ecc.MultiExpConfig{...})` (prove.go:277): the affine sum lifted
+// with Z = 1 (the later AddAssign / AddMixed / FromJacobian, prove.go:281-285, do not depend on the representative).
+func multiExpG2Jac(res *bn254.G2Jac, points []bn254.G2Affine, scalars []fr.Element) {
+	var aff bn254.G2Affine
+	if len(scalars) > 0 {
+		g2BasesOf(points).MultiExp(unsafe.Pointer(&aff), scalars, false)
+	}
 	res.FromAffine(&aff)
 }

@@ -3,8 +3,8 @@
 // GPU body of computeH (prover/gadget/prove.go:308-359), the H part of Groth16's Krs.  Drop into gkr-mimc/prover/gadget/ and
 // move the pure-Go computeH into a file of its own tagged `//go:build !gkrhip` (Prove and its goroutines stay where they are:
 // they call computeH by name).  Uncompiled here (no Go toolchain in the build image); the entry point is exercised through
-// the C ABI by tests/test_gpu_compute_h.py.  The G1 MSMs of Prove (prove.go:76,91,189,202,221) are in msm_gkrhip.go; the G2 MSM
-// (prove.go:277) stays on the CPU.
+// the C ABI by tests/test_gpu_compute_h.py.  The G1 MSMs of Prove (prove.go:76,91,189,202,221) and the G2 MSM (prove.go:277) are in
+// msm_gkrhip.go.
 package gadget
 
 import (
