@@ -217,3 +217,17 @@ def test_bench_msm_result(gk):
     assert r["ms"] > 0 and r["c"] >= 2 and abs(sum(r["phases_ms"].values()) - r["ms"]) < 0.2 * r["ms"] + 0.05
     r12 = gk.bench_msm_g1(logn, c=12, warmup=0, iters=1)
     assert r12["c"] == 12 and r12["result"].tolist() == r["result"].tolist()
+
+
+def test_cpp_abi_msm_harness(gk, tmp_path):
+    """tests/cpp/test_abi_msm.cpp: the MSM entry points from compiled code with plain arrays (the cgo shim's shape), one handle
+    shared by four host threads and four handles of their own at once, errors by code -- against the oracle library."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    exe = str(tmp_path / "test_abi_msm")
+    lib, orc = os.path.join(ROOT, "gkr-mimc_amd"), os.path.join(ROOT, "oracle")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_abi_msm.cpp"),
+                           "-L" + lib, "-lgkrhip", "-L" + orc, "-lgkr_oracle", "-Wl,-rpath," + lib, "-Wl,-rpath," + orc,
+                           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-L/opt/rocm/lib", "-fopenmp", "-pthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "abi-msm fails=0" in out.stdout, out.stdout + out.stderr

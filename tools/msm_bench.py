@@ -1,4 +1,4 @@
-"""MSM micro-benchmark on device-resident synthetic data (gkrhip_bench_msm_g1): python tools/msm_bench.py [logn...] [c=N]"""
+"""MSM micro-benchmark on device-resident synthetic data (gkrhip_bench_msm_g1 / _g2): python tools/msm_bench.py [g2] [logn...] [c=N]"""
 import importlib
 import json
 import os
@@ -7,11 +7,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gk = importlib.import_module("gkr-mimc_amd")
 gk.init(0)
-args = [a for a in sys.argv[1:] if not a.startswith("c=")]
+g2 = "g2" in sys.argv[1:]
+args = [a for a in sys.argv[1:] if not a.startswith("c=") and a != "g2"]
 cs = [int(a[2:]) for a in sys.argv[1:] if a.startswith("c=")] or [0]
 for logn in [int(a) for a in args] or [16, 18, 20, 22]:
     for cw in cs:
-        r = gk.bench_msm_g1(logn, c=cw, warmup=1, iters=3)
+        r = (gk.bench_msm_g2 if g2 else gk.bench_msm_g1)(logn, c=cw, warmup=1, iters=3)
+        r["group"] = "G2" if g2 else "G1"
         r.pop("result")
         r["logn"] = logn
         r["points_per_s"] = (1 << logn) / (r["ms"] * 1e-3)
