@@ -933,7 +933,22 @@ def main():
                                            "random scalars; the same kernels as G1 over Fp2 coordinates (a mixed addition is 28 Fp products "
                                            "instead of 10)"}
         ms, npass, by = gk.bench_compute_h(24, warmup=1, iters=3)
+        # issue ceiling from the ISA of this build: the innermost loop of the tile kernels is one sub-pass of two stages on a lane's
+        # four elements (four butterflies with their LDS traffic and twiddle loads); 4 inverse DIF and 3 forward DIT transforms
+        # of 24 * 2^23 butterflies each, plus the 10 products per position of the factors and the pointwise step priced as a
+        # butterfly's product each (an under-count: no adds)
+        h_ceiling = None
+        if "ntt_dif" in loops and "ntt_dit" in loops:
+            def cyc(lp):
+                return HALF_RATE_CYCLES * lp["half_rate"] + FULL_RATE_CYCLES * lp["full_rate"]
+            per_bfly = {k: cyc(loops[k]) / 4.0 for k in ("ntt_dif", "ntt_dit")}
+            n24 = float(1 << 24)
+            cycles = (4 * per_bfly["ntt_dif"] + 3 * per_bfly["ntt_dit"]) * 12 * n24 + 10 * n24 * HALF_RATE_CYCLES * 230
+            h_ceiling = cycles / (N_SIMD * 64) / (NOMINAL_GHZ * 1e9) * 1e3
         micro["compute_h_2p24"] = {"ms": ms, "passes": npass, "GB_per_s": by / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "bound": "integer VALU issue (no MFMA: modular arithmetic); HBM at 0.2 of its peak is not the limit",
+                                   "issue_ceiling_ms": h_ceiling, "frac_of_issue_ceiling": (h_ceiling / ms) if h_ceiling else None,
+                                   "subpass_loop_instructions_per_4_butterflies": {k: loops.get(k) for k in ("ntt_dif", "ntt_dit")},
                                    "field_products": COMPUTE_H_PRODUCTS(24), "field_products_per_s": COMPUTE_H_PRODUCTS(24) / (ms * 1e-3),
                                    "mirrors": "computeH (prover/gadget/prove.go:308-359) on three device-resident vectors of 2^24 elements: "
                                               "three inverse FFTs, three coset FFTs, the pointwise step, one inverse coset FFT, FromMont"}

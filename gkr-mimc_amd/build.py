@@ -32,8 +32,11 @@ LOOP_KERNELS = {"round0": "k_cipher_round_wideILb0ELb1ELb0E", "fold_late": "k_ci
                 "fold_early": "k_cipher_round_wideILb1ELb0ELb0E", "round0_pre": "k_cipher_round_wideILb0ELb1ELb1E",
                 # the bucket accumulation of the MSM: its INNERMOST loop is one mixed addition in the common case (the first
                 # point of a bucket and the doubling / cancellation cases leave it: g1.hip.h)
-                "msm_accumulate": "k_msm_accumulateI3FpFE", "msm_accumulate_g2": "k_msm_accumulateI4Fp2FE"}
-INNERMOST = ("msm_accumulate", "msm_accumulate_g2")
+                "msm_accumulate": "k_msm_accumulateI3FpFE",
+                # computeH's tile kernels: the innermost loop is one sub-pass of two stages on a lane's four elements
+                # (four butterflies, their LDS traffic and twiddle loads)
+                "ntt_dif": "k_ntt_tileILb0ELb1EE", "ntt_dit": "k_ntt_tileILb1ELb0EE"}
+INNERMOST = ("msm_accumulate", "ntt_dif", "ntt_dit")
 
 
 def source_sha():
