@@ -245,7 +245,8 @@ __device__ __forceinline__ AffT<F> ecx_to_aff(const XyzzT<F>& p) {
 // scalars -> signed window digits
 // ------------------------------------------------------------------------------------------------
 struct MsmArgs {
-    const uint4* scalars;     // n x 32 B, the image of []fr.Element (4 x u64 little-endian)
+    const uint4* scalars;     // n x 32 B, the image of []fr.Element (4 x u64 little-endian) ...
+    const uint4* scalars_hi;  // ... or, when not null, limb planes: scalar i = {scalars[i], scalars_hi[i]} (a device table, e.g. computeH's h)
     const uint4* points;      // n x 64 B (G1) or 128 B (G2): the image of []G1Affine / []G2Affine
     size_t n;
     int c, W;                 // window bits, number of windows
@@ -270,7 +271,7 @@ struct MsmArgs {
 };
 
 __device__ __forceinline__ void msm_load_scalar(const MsmArgs& a, size_t i, u32 (&s)[8]) {
-    const uint4 lo = a.scalars[2 * i], hi = a.scalars[2 * i + 1];
+    const uint4 lo = a.scalars_hi ? a.scalars[i] : a.scalars[2 * i], hi = a.scalars_hi ? a.scalars_hi[i] : a.scalars[2 * i + 1];
     Fr x = {{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
     if (a.scalars_mont) {
         Fr one = fr_zero();

@@ -1241,6 +1241,50 @@ int gkrhip_g2_batch_scalar_mul(uint64_t* out, const uint64_t base[16], const uin
     gkrhip_g2_bases_destroy(b);
     return rc;
 }
+// computeH (prove.go:308-359) followed by krs2.MultiExp(pk.G1.Z, h) (prove.go:221) with h never leaving the device: the
+// transforms leave H in a device table (limb planes, regular form, the reference's bit-reversed order) and the MSM reads its
+// scalars from those planes.  h_or_null (optional): the `cardinality` values of H, for the caller that also wants them.
+int gkrhip_compute_h_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* bases_z, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                            size_t n, size_t cardinality, uint64_t* h_or_null) {
+    if (!out_affine || !bases_z || !a || !b || !c) return fail("compute_h_msm_g1: null argument");
+    LEASE_LANE();
+    if (n < 1) return fail("computeH: empty vectors");
+    size_t card = cardinality;
+    if (card == 0) {
+        card = 1;
+        while (card < n) card <<= 1;
+    }
+    if ((card & (card - 1)) || card < n || card < 2) return fail("computeH: domain cardinality %zu is not a power of two >= max(%zu, 2)", card, n);
+    if (card > bases_z->n) return fail("compute_h_msm_g1: %zu values of H for %zu bases", card, bases_z->n);
+    int logn = 0;
+    while (((size_t)1 << logn) < card) logn++;
+    ScopedTable t[3];
+    DevTable* tp[3];
+    const uint64_t* src[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) {
+        CHK(table_alloc(&t[i], card));
+        CHK(upload_table(&t[i], src[i], n));
+        if (card > n) {
+            hipLaunchKernelGGL(k_ntt_zero, dim3(grid_for(card - n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, t[i].planes(), n, card);
+            HIPCHK(hipGetLastError());
+        }
+        tp[i] = &t[i];
+    }
+    CHK(compute_h_dev(tp, logn, nullptr));
+    {
+        std::lock_guard<std::mutex> lk(bases_z->mu);
+        CHK(msm_work_prepare(&bases_z->w, std::max<size_t>(bases_z->n, 1), bases_z->c_forced, FpF::W16));
+        const CPlanes hp = t[0].cplanes();
+        CHK(msm_dev<FpF>(bases_z, hp.lo, card, 0, nullptr, hp.hi));
+        HIPCHK(hipStreamSynchronize(cx().stream));
+        if (msm_scalar_error(&bases_z->w)) return fail("msm: a value of H is not below 2^254");
+        const hfp::Aff r = msm_host_tail<hfp::HFp>(&bases_z->w);
+        memcpy(out_affine, &r, sizeof r);
+    }
+    if (h_or_null) CHK(download_table(&t[0], h_or_null, card));
+    for (int i = 0; i < 3; i++) table_release(&t[i]);
+    return 0;
+}
 int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
                         double* host_tail_ms, uint64_t result_or_null[8]) {
     return abi_bench_msm<FpF, hfp::HFp, gkrhip_g1_bases>(g1_generator(), logn, c_or_0, warmup, iters, avg_ms, phase_ms, c_used, host_tail_ms,

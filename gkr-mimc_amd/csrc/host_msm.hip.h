@@ -116,13 +116,14 @@ struct MsmTimes {      // HIP-event split of one MSM (bench only)
 // The device part: the W window sums of sum_{i<n} [s_i] P_i land in w->h_wins (the caller synchronises the stream).
 // d_scalars: n x 32 B on the device.
 template <class F>
-int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm) {
+int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi = nullptr) {
     MsmWork* w = &b->w;
     hipStream_t st = cx().stream;
     const size_t nbk = (size_t)w->W * w->nb;
     MsmArgs a;
     memset(&a, 0, sizeof a);
     a.scalars = d_scalars;
+    a.scalars_hi = d_scalars_hi;
     a.points = b->d_points;
     a.n = n;
     a.c = w->c;

@@ -102,6 +102,7 @@ ABI = {
     "gkrhip_msm_g1_set_window": (_I, [_P, _I]),
     "gkrhip_g1_batch_scalar_mul": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_bench_msm_g1": (_I, [_I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), C.POINTER(_D), _P]),
+    "gkrhip_compute_h_msm_g1": (_I, [_P, _P, _P, _P, _P, _SZ, _SZ, _P]),
     "gkrhip_g2_bases_create": (_I, [C.POINTER(_P), _P, _SZ]),
     "gkrhip_g2_bases_generate": (_I, [C.POINTER(_P), _P, _P, _SZ, _I]),
     "gkrhip_g2_bases_len": (_SZ, [_P]),
@@ -708,6 +709,18 @@ class _Bases:
 
 class G1Bases(_Bases):
     GROUP, WORDS = "g1", 8
+
+    def compute_h_multi_exp(self, a, b, c, cardinality=0, want_h=False):
+        """h = computeH(a, b, c, domain); krs2.MultiExp(self, h) (prove.go:128,221) with H never leaving the device.
+        Returns the G1Affine image (and H, regular form, when want_h)."""
+        a, b, c = _fr(a), _fr(b), _fr(c)
+        n = a.shape[0]
+        assert b.shape[0] == n and c.shape[0] == n and n >= 1
+        card = cardinality or max(2, 1 << (n - 1).bit_length())
+        out = np.zeros(8, dtype=np.uint64)
+        h = np.zeros((card, 4), np.uint64) if want_h else None
+        _check(load().gkrhip_compute_h_msm_g1(_ptr(out), self._h, _ptr(a), _ptr(b), _ptr(c), n, card, _ptr(h) if want_h else None))
+        return (out, h) if want_h else out
 
 
 class G2Bases(_Bases):

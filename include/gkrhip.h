@@ -303,6 +303,11 @@ int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t *points, const uin
 int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
 /* bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out[i] = [scalars[i]] base as G1Affine */
 int gkrhip_g1_batch_scalar_mul(uint64_t *out /* n x 8 */, const uint64_t base[8], const uint64_t *scalars, size_t n, int flags);
+/* h = computeH(a, b, c, domain) (prove.go:128, 308-359) followed by krs2.MultiExp(pk.G1.Z, h, cfg) (prove.go:221) in one call with H
+ * never leaving the device: out = sum_i [h[i]] bases_z[i] over the `cardinality` values of H (the reference passes all of h;
+ * gkrhip_g1_bases_len(bases_z) >= cardinality).  h_or_null also returns H itself (regular form, the reference's order). */
+int gkrhip_compute_h_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases *bases_z, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+                            size_t n, size_t cardinality, uint64_t *h_or_null);
 /* G2: (*G2Jac).MultiExp(points, scalars, config) (prove.go:277) and BatchScalarMultiplicationG2; same conventions, 16 uint64 per point */
 typedef struct gkrhip_g2_bases gkrhip_g2_bases;
 int gkrhip_g2_bases_create(gkrhip_g2_bases **out, const uint64_t *points /* n x 16 */, size_t n);

@@ -515,3 +515,9 @@ func (b *G2Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont
 	}
 	must(C.gkrhip_msm_g2((*C.uint64_t)(out), b.h, ptr(scalars), C.size_t(len(scalars)), flags))
 }
+
+// ComputeHMultiExp is `h := computeH(a, b, c, domain)` followed by `krs2.MultiExp(pk.G1.Z, h, cfg)` (prover/gadget/prove.go:128,221)
+// in one call with H never leaving the device.  out is a *bn254.G1Affine; h (optional, len = cardinality) also receives H.
+func (b *G1Bases) ComputeHMultiExp(out unsafe.Pointer, a, bb, c []fr.Element, cardinality uint64, h []fr.Element) {
+	must(C.gkrhip_compute_h_msm_g1((*C.uint64_t)(out), b.h, ptr(a), ptr(bb), ptr(c), C.size_t(len(a)), C.size_t(cardinality), ptr(h)))
+}

@@ -231,3 +231,23 @@ def test_cpp_abi_msm_harness(gk, tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-L/opt/rocm/lib", "-fopenmp", "-pthread"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "abi-msm fails=0" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n,card", [(3, 4), (100, 0), (1000, 2048), (4096, 0), (1 << 14, 0)])
+def test_compute_h_then_multi_exp_on_the_device(gk, n, card):
+    """h = computeH(a, b, c) then krs2.MultiExp(pk.G1.Z, h) (prove.go:128,221) with H never leaving the device: the same
+    point as computeH to the host followed by the MSM on host scalars, and as the oracle's MSM over the returned H."""
+    rng = random.Random(7 * n + card)
+    a = c.from_ints([rng.randrange(Q) for _ in range(n)])
+    b = c.from_ints([rng.randrange(Q) for _ in range(n)])
+    cc = c.from_ints([rng.randrange(Q) for _ in range(n)])
+    cardinality = card or max(2, 1 << (n - 1).bit_length())
+    bases = gk.G1Bases(points=rand_points(n + 3, cardinality))
+    got, h = bases.compute_h_multi_exp(a, b, cc, card, want_h=True)
+    h_ref = gk.compute_h(a, b, cc, cardinality)
+    assert np.array_equal(h, h_ref)
+    assert got.tolist() == bases.multi_exp(h_ref).tolist()
+    if cardinality <= 4096:
+        assert got.tolist() == c.g1_msm(bases.read(), h_ref).tolist()
+    assert bases.compute_h_multi_exp(a, b, cc, card).tolist() == got.tolist()
+    bases.close()
