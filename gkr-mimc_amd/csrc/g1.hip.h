@@ -14,8 +14,8 @@
 //      (k_msm_hist, k_msm_totals, k_msm_scan, k_msm_chunk_off, k_msm_scatter) -- never an atomic on a point;
 //   3. ONE LANE PER BUCKET adds its run of points with mixed additions into an extended-Jacobian (XYZZ) accumulator
 //      (k_msm_accumulate: 8 M + 2 S per point, the bulk of the work: W * n additions); the few buckets far above the mean
-//      (skewed scalars: the 0/1 wires of a real witness put most points of window 0 into bucket 1) are summed by a whole
-//      workgroup each (k_msm_accumulate_big);
+//      (skewed scalars: the 0/1 wires of a real witness put most points of window 0 into bucket 1) are cut into segments,
+//      a workgroup per segment (k_msm_accumulate_big, k_msm_big_combine);
 //   4. sum_b (b + 1) B_b per window by running sums over chunks of consecutive buckets, one lane per chunk, the chunk's
 //      offset applied by a short double-and-add (k_msm_reduce_chunks), then a workgroup tree per window (k_msm_reduce_windows);
 //   5. the W window sums go to the host, which combines them by Horner's rule (c doublings per window) and converts to
@@ -262,8 +262,10 @@ struct MsmArgs {
     size_t chunk_len;
     u32 bias[8];              // H: half a window added to every window but the top one
     unsigned int* entries;    // point index | sign << 31, sorted by (window, bucket)
-    unsigned int* big;        // [0] = number of big buckets, [1 + k] = their ids, [big_cap + 1] = a scalar was not below 2^254
+    unsigned int* big;        // [0] = number of segments of big buckets, [1 + k] = bucket id | segment << 20, [big_cap + 1] = a scalar was not below 2^254
     unsigned int big_threshold, big_cap;
+    unsigned int seg;         // points per SEGMENT of a big bucket (a power of two): one workgroup sums one segment
+    XPlanes bigparts;         // partial sums of the segments of multi-segment buckets, indexed like the segment list
     XPlanes buckets;          // W * nb
     XPlanes parts;            // W * nchunk chunk sums
     XPlanes wins;             // W window sums
@@ -407,9 +409,10 @@ __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
         const size_t t = t0 + h;
         if (t >= total) break;
         a.offset[t] = run;
-        if (c[h] > a.big_threshold) {
-            const unsigned int k = atomicAdd(&a.big[0], 1u);
-            if (k < a.big_cap) a.big[1 + k] = (unsigned int)t;
+        if (c[h] > a.big_threshold) {        // a big bucket: one list entry per segment of a.seg points (consecutive entries)
+            const unsigned int nseg = (c[h] + a.seg - 1) / a.seg;
+            const unsigned int k0 = atomicAdd(&a.big[0], nseg);
+            for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << 20);
         }
         const size_t j = t / a.nb, b = t % a.nb;
         unsigned int r2 = run;
@@ -557,16 +560,45 @@ __device__ __forceinline__ void ecx_block_reduce(XyzzShared<F>& sh, XyzzT<F>& mi
         __syncthreads();
     }
 }
+// Buckets far above the mean -- the 0/1 wires of a real witness put a large share of ALL points into bucket 1 of window 0; a
+// short top window holds n / 4 points per bucket -- are cut into segments of a.seg points and a workgroup sums a segment
+// (one workgroup per bucket, the first version, took 8 ms for four buckets of 2^18 points: 1024 additions in a row per lane).
+// A bucket of one segment is finished here; the partial sums of the others are combined by k_msm_big_combine.
 template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_accumulate_big(MsmArgs a) {
     __shared__ XyzzShared<F> sh;
     const unsigned int nbig = min(a.big[0], a.big_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.big[0] > a.big_cap) a.big[a.big_cap + 1] = 2u;      // the list overflowed (cannot happen by its sizing): an error, not a wrong sum
     for (unsigned int k = blockIdx.x; k < nbig; k += gridDim.x) {
-        const size_t t = a.big[1 + k];
+        const unsigned int e = a.big[1 + k];
+        const size_t t = e & 0xfffffu;
+        const unsigned int sg = e >> 20;
         const unsigned int cnt = a.count[t], start = a.offset[t];
+        const unsigned int lo = sg * a.seg, hi = min(cnt, lo + a.seg);
         XyzzT<F> acc;
         ecx_set_inf(acc);
-        for (unsigned int i = threadIdx.x; i < cnt; i += GKR_BLOCK) ecx_madd(acc, msm_entry_point<F>(a, a.entries[start + i]));
+        for (unsigned int i = lo + threadIdx.x; i < hi; i += GKR_BLOCK) ecx_madd(acc, msm_entry_point<F>(a, a.entries[start + i]));
+        ecx_block_reduce(sh, acc);
+        if (threadIdx.x == 0) {
+            if (cnt <= a.seg) ecx_st<F>(a.buckets, t, sh.p[0]);
+            else ecx_st<F>(a.bigparts, k, sh.p[0]);
+        }
+        __syncthreads();
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(GKR_BLOCK) k_msm_big_combine(MsmArgs a) {
+    __shared__ XyzzShared<F> sh;
+    const unsigned int nbig = min(a.big[0], a.big_cap);
+    for (unsigned int k = blockIdx.x; k < nbig; k += gridDim.x) {
+        const unsigned int e = a.big[1 + k];
+        const size_t t = e & 0xfffffu;
+        const unsigned int cnt = a.count[t];
+        if ((e >> 20) != 0 || cnt <= a.seg) continue;          // (uniform over the workgroup) the entry of segment 0 speaks for its bucket
+        const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
+        XyzzT<F> acc;
+        ecx_set_inf(acc);
+        for (unsigned int i = threadIdx.x; i < nseg; i += GKR_BLOCK) ecx_add(acc, ecx_ld<F>(a.bigparts, k + i));
         ecx_block_reduce(sh, acc);
         if (threadIdx.x == 0) ecx_st<F>(a.buckets, t, sh.p[0]);
         __syncthreads();

@@ -9,16 +9,18 @@ const size_t kMsmMaxPoints = (size_t)1 << 26;      // entries are 31-bit point i
 
 // number of windows for c-bit signed digits of a scalar below 2^254 (the top window absorbs the last carry: g1.hip.h)
 inline int msm_windows(int c) { return (255 + c - 1) / c; }
-// Window size: W * n mixed additions (8 M + 2 S) against W * 2^(c-1) buckets that each cost two full additions (12 M + 2 S)
-// plus their share of the chunk offsets in the reduction -- about 3.5 mixed additions per bucket.
+// Window size, from the measured sweep (tools/msm_window_sweep.py, G1 and G2 alike): W * n mixed additions against
+// W * 2^(c-1) buckets whose reduction is latency-bound (a bucket costs ~9 mixed additions there, not the 3.5 its arithmetic
+// suggests), more buckets meaning more lanes for the accumulation, and c = 15 and 16 leaving no short top window
+// (255 = 17 * 15; a top window of a few bits puts n / 4 points into each of its buckets):
+//     n <= 2^13: c = log2(n) - 2 (2^10: 8, 2^12: 10)     2^14 .. 2^21: c = 15     from 2^22: c = 16
+// (2^20 points: 3.44 / 2.66 / 2.80 ms with c = 14 / 15 / 16; 2^16: 0.87 / 0.83 with 13 / 15; 2^22: 9.66 with 16.)
 inline int msm_pick_c(size_t n) {
-    int best = 4;
-    double best_cost = 1e300;
-    for (int c = 4; c <= 16; c++) {
-        const double cost = (double)msm_windows(c) * ((double)n + 3.5 * (double)((size_t)1 << (c - 1)));
-        if (cost < best_cost) best_cost = cost, best = c;
-    }
-    return best;
+    int logn = 0;
+    while (((size_t)1 << (logn + 1)) <= n) logn++;
+    if (logn >= 22) return 16;
+    if (logn >= 14) return 15;
+    return std::max(4, logn - 2);
 }
 
 struct MsmWork {
@@ -26,7 +28,7 @@ struct MsmWork {
     int c = 0, W = 0;
     unsigned int nb = 0;
     int chunk = 0;
-    unsigned int big_cap = 0;
+    unsigned int big_cap = 0, seg = 4096;
     unsigned int* counts = nullptr;      // count | offset | order (W * nb words each) | chunk histograms (W * nchunk * nb)
     unsigned int nchunk = 0, ntiles = 0;
     size_t chunk_len = 0;
@@ -80,7 +82,12 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     w->chunk = chunk;
     w->nparts = (size_t)w->W * (w->nb / chunk);
     const size_t nbk = (size_t)w->W * w->nb;
-    w->big_cap = (unsigned int)std::min<size_t>((size_t)w->W * n / 128 + 16, (size_t)1 << 25);
+    if (nbk >= ((size_t)1 << 20)) return fail("msm: %zu buckets do not fit the 20-bit ids of the big-bucket list", nbk);
+    // segments of big buckets: a bucket is big above max(128, 4 n / nb) points, so there are at most W * min(n / 128, nb / 4) of
+    // them, and cutting them into segments of `seg` points adds at most W * n / seg entries
+    w->seg = 4096;
+    while ((size_t)w->seg * 2048 < n) w->seg <<= 1;           // at most 2048 segments per bucket (11 bits of the list entry)
+    w->big_cap = (unsigned int)(std::min<size_t>((size_t)w->W * n / 128, (size_t)w->W * w->nb / 4) + (size_t)w->W * n / w->seg + 16);
     // sorting workgroups: one per window and chunk of the scalars; a chunk is long enough to amortise the workgroup's
     // histogram traffic (2^(c-1) words in and out) and short enough that W * nchunk workgroups cover the CUs several times
     // (one workgroup per CU at c = 16: measured 2.72 / 1.96 / 1.96 ms of sorting at 2^22 points with 8 / 16..32 / 64 chunks,
@@ -97,7 +104,7 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     HIPCHK(hipMalloc((void**)&w->entries, std::max<size_t>(1, (size_t)w->W * n) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->big, ((size_t)w->big_cap + 2) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
-    HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W) * sizeof(uint4)));
+    HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W + w->big_cap) * sizeof(uint4)));
     HIPCHK(hipHostMalloc((void**)&w->h_wins, ((size_t)4 * w16 * w->W + 1) * sizeof(uint4)));      // + the error word
     return 0;
 }
@@ -148,6 +155,8 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     a.buckets = XPlanes{w->xyzz, nbk};
     a.parts = XPlanes{w->xyzz + npl * nbk, w->nparts};
     a.wins = XPlanes{w->xyzz + npl * (nbk + w->nparts), (size_t)w->W};
+    a.bigparts = XPlanes{w->xyzz + npl * (nbk + w->nparts + (size_t)w->W), (size_t)w->big_cap};
+    a.seg = w->seg;
     a.chunk = w->chunk;
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
@@ -174,6 +183,7 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3((unsigned)((nbk + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[2], st));
     hipLaunchKernelGGL(k_msm_accumulate_big<F>, dim3(1024), dim3(GKR_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_msm_big_combine<F>, dim3(256), dim3(GKR_BLOCK), 0, st, a);
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[3], st));
     hipLaunchKernelGGL(k_msm_reduce_chunks<F>, dim3((unsigned)((w->nparts + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_msm_reduce_windows<F>, dim3(w->W), dim3(GKR_BLOCK), 0, st, a);
@@ -210,7 +220,7 @@ hfp::AffH<HF> msm_host_tail(const MsmWork* w) {
     }
     return hfp::to_affine(acc);
 }
-inline bool msm_scalar_error(const MsmWork* w) { return w->h_wins[(size_t)4 * w->w16 * w->W].x != 0; }
+inline bool msm_scalar_error(const MsmWork* w) { return w->h_wins[(size_t)4 * w->w16 * w->W].x != 0; }      // (2: the big-bucket list overflowed)
 
 int msm_check_points(const uint64_t* points, size_t n, int w16) {
     // every coordinate must be a canonical fp.Element: the lazy range of the kernels starts from values below p

@@ -107,6 +107,26 @@ def test_msm_skewed_scalars(gk):
     assert gk.multi_exp_g1(pm, scm).tolist() == [0] * 8
 
 
+def test_msm_huge_buckets_are_split(gk):
+    """A witness-like scalar vector at a size where one bucket holds a large share of all points (2^17 points, 70 % of the
+    scalars equal to 1): the bucket is cut into segments, one workgroup each, and the partial sums combined; and a window
+    size whose top window is two bits wide (four buckets of n / 4 points)."""
+    n = 1 << 17
+    pts = rand_points(17, n)
+    rng = random.Random(17)
+    sc = ec.scalars_to_image([1 if rng.random() < 0.7 else rng.choice([0, 2, 3, Q - 1, rng.randrange(Q)]) for _ in range(n)])
+    want = c.g1_msm(pts, sc)
+    b = gk.G1Bases(points=pts)
+    assert b.multi_exp(sc).tolist() == want.tolist()
+    full = rand_scalars(rng, n)
+    want_full = c.g1_msm(pts, full)
+    for cw in (14, 11):                        # 254 = 18 * 14 + 2 = 23 * 11 + 1: a top window of two bits / one bit
+        b.set_window(cw)
+        assert b.multi_exp(full).tolist() == want_full.tolist(), cw
+        assert b.multi_exp(sc).tolist() == want.tolist(), cw
+    b.close()
+
+
 def test_msm_montgomery_scalars(gk):
     """MultiExpConfig.ScalarsMont: the same scalars handed over as fr.Elements (Montgomery form)."""
     rng = random.Random(21)

@@ -98,6 +98,8 @@ def test_msm_g2_larger_sizes_and_skew(gk):
     _dlog_check(gk, 1 << 12, 1)
     _dlog_check(gk, 1 << 16, 2)
     _dlog_check(gk, 5000, 3, skew=True)          # the 0/1 wires of a real witness: the workgroup-per-bucket path
+    _dlog_check(gk, 1 << 15, 4, skew=True)       # ... with buckets of several segments
+    _dlog_check(gk, 1 << 14, 5, cw=14)           # a top window of two bits: four buckets of n / 4 points
     # all-cancelling input: the point at infinity, encoded as zeros
     k = rand_scalars(random.Random(9), 50)
     pts = gk.batch_scalar_multiplication_g2(G2IMG, k)
