@@ -1,0 +1,55 @@
+"""The device side of ComputeGroth16Proof (prover/gadget/prove.go:100-306) at one size: computeH, then the MSMs over pk.G1.A,
+pk.G1.B, pk.G1.Z (with h), pk.privKNotGkr and pk.G2.B -- one after the other and from five host threads at once (every call
+leases a lane of its own).  Bases resident, scalars from host memory; synthetic data ([k_i]G bases, random scalars).
+python tools/groth16_backhalf.py [logn]"""
+import importlib
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gk = importlib.import_module("gkr-mimc_amd")
+gk.init(0)
+G1 = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f,
+               0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+n = 1 << logn
+rng = np.random.default_rng(1)
+
+
+def rnd():
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    return a
+
+
+k = rnd()
+bases = {name: gk.G1Bases(base=G1, scalars=k) for name in ("A", "B1", "Z", "K")}
+b2 = gk.G2Bases(base=gk.g2_generator(), scalars=k)
+wires, a, b, c = rnd(), rnd(), rnd(), rnd()
+jobs = {
+    "computeH + krs2 (pk.G1.Z)": lambda: bases["Z"].compute_h_multi_exp(a, b, c),
+    "ar (pk.G1.A)": lambda: bases["A"].multi_exp(wires),
+    "bs1 (pk.G1.B)": lambda: bases["B1"].multi_exp(wires),
+    "krs (pk.privKNotGkr)": lambda: bases["K"].multi_exp(wires),
+    "Bs (pk.G2.B)": lambda: b2.multi_exp(wires),
+}
+for f in jobs.values():
+    f()                                         # warm: work buffers, NTT domain
+t_all = time.perf_counter()
+for name, f in jobs.items():
+    t0 = time.perf_counter()
+    f()
+    print("%-28s %.2f ms" % (name, 1e3 * (time.perf_counter() - t0)))
+serial = time.perf_counter() - t_all
+ths = [threading.Thread(target=f) for f in jobs.values()]
+t0 = time.perf_counter()
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+par = time.perf_counter() - t0
+print("2^%d: one after the other %.1f ms, five host threads at once %.1f ms (uploads of the scalars and of a, b, c included)" % (logn, 1e3 * serial, 1e3 * par))
