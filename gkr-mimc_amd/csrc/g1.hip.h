@@ -1,7 +1,7 @@
-// g1.hip.h -- BN254 G1 arithmetic and the kernels of the multi-scalar multiplication sum_i [s_i] P_i on gfx950: what
-// gnark-crypto's (*G1Jac).MultiExp / (*G1Affine).MultiExp compute for the reference's Groth16 prover
-// (prover/gadget/prove.go:76,91 krsNotGkr / KrsPrivNotGkr; :189 bs1, :202 ar, :221 krs2) and
-// bn254.BatchScalarMultiplicationG1 (prove.go:177).  gnark-crypto is an un-vendored dependency of the reference
+// g1.hip.h -- BN254 G1 and G2 arithmetic and the kernels of the multi-scalar multiplication sum_i [s_i] P_i on gfx950: what
+// gnark-crypto's (*G1Jac).MultiExp / (*G1Affine).MultiExp / (*G2Jac).MultiExp compute for the reference's Groth16 prover
+// (prover/gadget/prove.go:76,91 krsNotGkr / KrsPrivNotGkr; :189 bs1, :202 ar, :221 krs2; :277 Bs on G2; SURVEY section 8 row
+// f4) and bn254.BatchScalarMultiplicationG1 (prove.go:177).  gnark-crypto is an un-vendored dependency of the reference
 // (v0.6.1-0.20220110145513-493bb1c180d9): the RESULT is a group element, so parity is defined by the mathematics -- the
 // affine coordinates of the sum are unique -- and pinned by the test oracle's big-integer double-and-add ("parity
 // unpinned" against bytes of the Go binary, like computeH).
@@ -11,9 +11,10 @@
 //      (d in [-2^(c-1), 2^(c-1)]: half the buckets, the sign negates the point's y);
 //   2. the (window, |digit|) pairs are counting-sorted with every atomic in LDS: a workgroup owns one window of one chunk
 //      of the scalars and keeps that window's whole histogram (128 KiB at c = 16) in gfx950's 160 KiB LDS
-//      (k_msm_hist, k_msm_totals, k_msm_scan, k_msm_chunk_off, k_msm_scatter) -- never an atomic on a point;
-//   3. ONE LANE PER BUCKET adds its run of points with mixed additions into an extended-Jacobian (XYZZ) accumulator
-//      (k_msm_accumulate: 8 M + 2 S per point, the bulk of the work: W * n additions); the few buckets far above the mean
+//      (k_msm_hist, k_msm_totals, k_msm_scan, k_msm_offsets, k_msm_scatter) -- never an atomic on a point;
+//   3. ONE LANE PER BUCKET (the buckets of a window handed out in order of size: k_msm_order) adds its run of points with
+//      mixed additions into an extended-Jacobian (XYZZ) accumulator (k_msm_accumulate: 8 M + 2 S per point, the bulk of the
+//      work: W * n additions); the few buckets far above the mean
 //      (skewed scalars: the 0/1 wires of a real witness put most points of window 0 into bucket 1) are cut into segments,
 //      a workgroup per segment (k_msm_accumulate_big, k_msm_big_combine);
 //   4. sum_b (b + 1) B_b per window by running sums over chunks of consecutive buckets, one lane per chunk, the chunk's
@@ -23,6 +24,7 @@
 // Coordinates live in the lazy range [0, 2p) of fp_bn254.h.  No MFMA: exact 254-bit modular arithmetic.
 // Points in HBM keep gnark's G1Affine image (X, Y: 2 x 32 B Montgomery, infinity = (0, 0)): a lane gathers one point as four
 // 16-byte loads of one 64-byte line; buckets and partial sums are limb planes (coalesced across lanes).
+// Everything from the point arithmetic down is written once over a coordinate-field policy: Fp for G1, Fp2 for G2.
 #pragma once
 #include "fp_bn254.h"
 #include "kernels.hip.h"
