@@ -125,3 +125,51 @@ def test_bench_rendezvous_over_tcp():
     outs = [p.communicate(timeout=120)[0] for p in ps]
     for k, (p, o) in enumerate(zip(ps, outs)):
         assert p.returncode == 0 and "RDV-OK %d" % k in o, o
+
+
+def test_rendezvous_frames_are_data_and_strangers_are_ignored():
+    """bench.py's torch-free bootstrap: frames are JSON -- nothing a peer sends is executed --, a connection
+    without the run's token or with a rank that is out of range or already present is dropped, frame lengths are capped."""
+    import importlib.util
+    import socket
+    import struct
+    import threading
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    world, res, errs = 3, {}, []
+
+    def run(r, delay):
+        try:
+            time.sleep(delay)
+            d = bench.Rendezvous(r, world, "127.0.0.1", port, timeout=30)
+            blob = bytes(range(256)) * 4
+            res[r] = (d.allreduce(r + 1, max), d.allreduce(2.5 * r + 1, min), d.broadcast(blob if r == 0 else None),
+                      d.broadcast("tag" if r == 0 else None), d.broadcast(None))
+            d.barrier()
+            d.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(r, 0.0 if r == 0 else 0.6)) for r in range(world)]
+    for t in ths:
+        t.start()
+    time.sleep(0.2)       # rank 0 is listening; the real ranks arrive later
+    for hello in (struct.pack("<i", 1) + b"x" * 16,          # right rank, wrong token
+                  b"garbage",                                # short hello
+                  struct.pack("<i", 99) + b"y" * 16):        # rank out of range
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=5) as c:
+                c.sendall(hello)
+                time.sleep(0.05)
+        except OSError:
+            pass
+    for t in ths:
+        t.join(60)
+    assert not errs, errs
+    assert all(res[r] == (3, 1.0, bytes(range(256)) * 4, "tag", None) for r in range(world)), res
+    assert "pickle" not in open(os.path.join(ROOT, "bench.py")).read().split("class LocalRendezvous")[0].split("class Rendezvous")[1]
