@@ -272,7 +272,22 @@ struct MsmArgs {
     XPlanes parts;            // W * nchunk chunk sums
     XPlanes wins;             // W window sums
     int chunk;                // buckets per lane of k_msm_reduce_chunks (a power of two)
+    unsigned int* err;        // error word: 1 = a scalar was not below 2^254, 2 = a list overflowed
+    // two-level sort (large n): the sorting kernels above run as a COARSE pass that files a point under bucket >> lowbits and
+    // keeps the low bits in the entry; the refine kernels finish the order inside every coarse bin
+    int lowbits;                       // coarse pass: > 0
+    unsigned int* bin_first;           // coarse pass: first slice-list entry of every nonempty bin
+    const unsigned int* c_entries;     // refine: the coarse pass's entries (index | sign << ib | low << (ib + 1), ib = 31 - lowbits) ...
+    const unsigned int* c_count;       // ... its bin sizes, offsets, first list entries and the slice list (big[] of the coarse pass)
+    const unsigned int* c_offset;
+    const unsigned int* c_first;
+    const unsigned int* slices;        // [0] = number of slices, [1 + k] = bin | slice << 20 (slice_len entries each)
+    unsigned int slice_cap, slice_len;
+    int rbits;                         // refine: the coarse pass's lowbits
+    unsigned int* slice_hist;          // [slice][2^rbits] counts, then write cursors
 };
+// bins of the sorting kernels: the buckets themselves, or the coarse bins of a two-level sort
+__device__ __forceinline__ unsigned int msm_sort_bins(const MsmArgs& a) { return a.nb >> a.lowbits; }
 
 __device__ __forceinline__ void msm_load_scalar(const MsmArgs& a, size_t i, u32 (&s)[8]) {
     const uint4 lo = a.scalars_hi ? a.scalars[i] : a.scalars[2 * i], hi = a.scalars_hi ? a.scalars_hi[i] : a.scalars[2 * i + 1];
@@ -328,7 +343,8 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(MsmArgs a) {
     extern __shared__ unsigned int hist[];
     const int j = blockIdx.x;
     const unsigned int k = blockIdx.y;
-    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) hist[b] = 0;
+    const unsigned int nbs = msm_sort_bins(a);
+    for (unsigned int b = threadIdx.x; b < nbs; b += MSM_SORT_THREADS) hist[b] = 0;
     __syncthreads();
     const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
     bool bad = false;
@@ -339,12 +355,12 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(MsmArgs a) {
         bool neg;
         const u32 b = msm_digit(a, s, j, &neg);
         if (b == MSM_DIGIT_BAD || !fits) bad = true;
-        else if (b != MSM_DIGIT_NONE) atomicAdd(&hist[b], 1u);
+        else if (b != MSM_DIGIT_NONE) atomicAdd(&hist[b >> a.lowbits], 1u);
     }
-    if (bad) a.big[a.big_cap + 1] = 1u;      // error word behind the big-bucket list
+    if (bad) *a.err = 1u;
     __syncthreads();
-    unsigned int* out = a.chist + ((size_t)j * a.nchunk + k) * a.nb;
-    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) out[b] = hist[b];
+    unsigned int* out = a.chist + ((size_t)j * a.nchunk + k) * nbs;
+    for (unsigned int b = threadIdx.x; b < nbs; b += MSM_SORT_THREADS) out[b] = hist[b];
 }
 // Exclusive scan of the W * nb bucket sizes in tiles of MSM_SCAN_TILE buckets, every access coalesced:
 //   k_msm_totals:   count[t] = sum_k chist[.][k][.], tile sums                       (one workgroup per tile)
@@ -366,15 +382,16 @@ __device__ __forceinline__ unsigned int msm_block_scan(unsigned int* sh, unsigne
 }
 __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_totals(MsmArgs a) {
     __shared__ unsigned int sh[MSM_SCAN_THREADS];
-    const size_t total = (size_t)a.W * a.nb;
+    const unsigned int nbs = msm_sort_bins(a);
+    const size_t total = (size_t)a.W * nbs;
     unsigned int mine = 0;
 #pragma unroll
     for (int h = 0; h < MSM_SCAN_TILE / MSM_SCAN_THREADS; h++) {
         const size_t t = (size_t)blockIdx.x * MSM_SCAN_TILE + h * MSM_SCAN_THREADS + threadIdx.x;
         if (t < total) {
-            const size_t j = t / a.nb, b = t % a.nb;
+            const size_t j = t / nbs, b = t % nbs;
             unsigned int s = 0;
-            for (unsigned int k = 0; k < a.nchunk; k++) s += a.chist[(j * a.nchunk + k) * a.nb + b];
+            for (unsigned int k = 0; k < a.nchunk; k++) s += a.chist[(j * a.nchunk + k) * nbs + b];
             a.count[t] = s;
             mine += s;
         }
@@ -397,7 +414,8 @@ __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_scan(MsmArgs a) {     
 }
 __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
     __shared__ unsigned int sh[MSM_SCAN_THREADS];
-    const size_t total = (size_t)a.W * a.nb;
+    const unsigned int nbs = msm_sort_bins(a);
+    const size_t total = (size_t)a.W * nbs;
     const size_t t0 = (size_t)blockIdx.x * MSM_SCAN_TILE + (size_t)threadIdx.x * (MSM_SCAN_TILE / MSM_SCAN_THREADS);   // consecutive buckets per lane
     unsigned int c[MSM_SCAN_TILE / MSM_SCAN_THREADS], mine = 0;
 #pragma unroll
@@ -415,11 +433,12 @@ __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
             const unsigned int nseg = (c[h] + a.seg - 1) / a.seg;
             const unsigned int k0 = atomicAdd(&a.big[0], nseg);
             for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << 20);
+            if (a.bin_first) a.bin_first[t] = k0;
         }
-        const size_t j = t / a.nb, b = t % a.nb;
+        const size_t j = t / nbs, b = t % nbs;
         unsigned int r2 = run;
         for (unsigned int k = 0; k < a.nchunk; k++) {
-            unsigned int* p = &a.chist[(j * a.nchunk + k) * a.nb + b];
+            unsigned int* p = &a.chist[(j * a.nchunk + k) * nbs + b];
             const unsigned int x = *p;
             *p = r2;
             r2 += x;
@@ -442,6 +461,212 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(MsmArgs a) {
         bool neg;
         const u32 b = msm_digit(a, s, j, &neg);
         if (b < MSM_DIGIT_BAD) a.entries[atomicAdd(&cursor[b], 1u)] = (u32)i | (neg ? 0x80000000u : 0u);
+    }
+}
+// LDS counter update of a wave: when every active lane of the wave names the same counter (a slice of the bin that holds the
+// 0/1 wires of a witness) one lane adds the population count; returns the lane's position
+__device__ __forceinline__ unsigned int msm_wave_counter_add(unsigned int* ctr, unsigned int idx) {
+    const unsigned int first = __builtin_amdgcn_readfirstlane(idx);
+    const unsigned long long same = __ballot(idx == first), act = __ballot(true);
+    if (same == act) {
+        const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
+        unsigned int base = 0;
+        if (rank == 0) base = atomicAdd(&ctr[first], (unsigned int)__popcll(act));
+        return __builtin_amdgcn_readfirstlane(base) + rank;
+    }
+    return atomicAdd(&ctr[idx], 1u);
+}
+// ---- scatter through LDS ---------------------------------------------------------------------------------------------------
+// A lane that writes its 4-byte entry wherever its bin's cursor points costs one memory request per lane (64 lines per wave
+// store): the two scatters of the two-level sort were bound by that request rate, not by bytes.  Both therefore sort a batch
+// of MSM_STAGE entries inside LDS first -- count per bin, scan, place -- and write the batch out in order, so that
+// consecutive lanes write the consecutive entries of a bin's run.
+#define MSM_STAGE 8192
+#define MSM_STAGE_PER (MSM_STAGE / MSM_SORT_THREADS)
+#define MSM_STAGE_MAXBINS 1024
+struct MsmStage {
+    u32 staged[MSM_STAGE];
+    unsigned short sbin[MSM_STAGE];
+    unsigned int cursor[MSM_STAGE_MAXBINS];      // the workgroup's write position of every bin in the output
+    unsigned int lcnt[MSM_STAGE_MAXBINS];        // entries of the batch per bin, then (output position - staged position) of the bin
+    unsigned int lstart[MSM_STAGE_MAXBINS];
+    unsigned int wsum[MSM_SORT_THREADS / 64];
+    unsigned int total;
+};
+// exclusive scan over the workgroup's MSM_SORT_THREADS values
+__device__ __forceinline__ unsigned int msm_stage_scan(MsmStage& sh, unsigned int v) {
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) sh.wsum[wave] = x;
+    __syncthreads();
+    unsigned int base = 0;
+    for (unsigned int w = 0; w < wave; w++) base += sh.wsum[w];
+    return base + x - v;
+}
+// One batch: the lane's MSM_STAGE_PER entries e[r] for the bins bin[r] (0xffffffff: none) go to out[] at the bins' cursors.
+__device__ __forceinline__ void msm_stage_batch(MsmStage& sh, unsigned int nbins, const u32 (&e)[MSM_STAGE_PER], const u32 (&bin)[MSM_STAGE_PER],
+                                                unsigned int* out) {
+    unsigned int rank[MSM_STAGE_PER];
+    if (threadIdx.x < nbins) sh.lcnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MSM_STAGE_PER; r++)
+        if (bin[r] != 0xffffffffu) rank[r] = msm_wave_counter_add(sh.lcnt, bin[r]);
+    __syncthreads();
+    const unsigned int mine = threadIdx.x < nbins ? sh.lcnt[threadIdx.x] : 0u;
+    const unsigned int start = msm_stage_scan(sh, mine);
+    if (threadIdx.x < nbins) {
+        sh.lstart[threadIdx.x] = start;
+        sh.lcnt[threadIdx.x] = sh.cursor[threadIdx.x] - start;
+        sh.cursor[threadIdx.x] += mine;
+        if (threadIdx.x == nbins - 1) sh.total = start + mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MSM_STAGE_PER; r++)
+        if (bin[r] != 0xffffffffu) {
+            const unsigned int p = sh.lstart[bin[r]] + rank[r];
+            sh.staged[p] = e[r];
+            sh.sbin[p] = (unsigned short)bin[r];
+        }
+    __syncthreads();
+    const unsigned int total = sh.total;
+    for (unsigned int p = threadIdx.x; p < total; p += MSM_SORT_THREADS) out[sh.lcnt[sh.sbin[p]] + p] = sh.staged[p];
+    __syncthreads();
+}
+// the coarse pass's scatter: workgroup (j, k) files the entries of window j of chunk k under their coarse bins
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs a) {
+    __shared__ MsmStage sh;
+    const int j = blockIdx.x;
+    const unsigned int k = blockIdx.y;
+    const unsigned int nbs = msm_sort_bins(a);
+    const unsigned int* in = a.chist + ((size_t)j * a.nchunk + k) * nbs;
+    if (threadIdx.x < nbs) sh.cursor[threadIdx.x] = in[threadIdx.x];
+    __syncthreads();
+    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
+    const int ib = 31 - a.lowbits;
+    const u32 lowmask = (1u << a.lowbits) - 1u;
+    for (size_t i0 = lo; i0 < hi; i0 += MSM_STAGE) {
+        u32 e[MSM_STAGE_PER], bin[MSM_STAGE_PER];
+#pragma unroll
+        for (int r = 0; r < MSM_STAGE_PER; r++) {
+            const size_t i = i0 + (size_t)r * MSM_SORT_THREADS + threadIdx.x;
+            bin[r] = 0xffffffffu;
+            e[r] = 0;
+            if (i < hi) {
+                u32 s[8];
+                msm_load_scalar(a, i, s);
+                (void)msm_bias_scalar(a, s);
+                bool neg;
+                const u32 b = msm_digit(a, s, j, &neg);
+                if (b < MSM_DIGIT_BAD) {
+                    bin[r] = b >> a.lowbits;
+                    e[r] = (u32)i | ((neg ? 1u : 0u) << ib) | ((b & lowmask) << (ib + 1));
+                }
+            }
+        }
+        msm_stage_batch(sh, nbs, e, bin, a.entries);
+    }
+}
+// ---- second level of the sort -------------------------------------------------------------------------------------------
+// Above ~2^20 points the single pass above is bound by its writes: a workgroup scatters 4-byte entries over all 2^(c-1)
+// buckets of its window, 2 MiB of open 64-byte lines per workgroup and 64 MiB per XCD against 4 MiB of L2, so nearly every
+// entry costs a partial-line write in HBM (2^24 points: 6.4 ms of scatter for 1 GiB of entries).  Two levels keep the open
+// lines in L2 at both: the coarse pass writes 2^(c-1-lowbits) streams per workgroup, then every SLICE (slice_len consecutive
+// entries of one coarse bin; the bins of skewed scalars are cut into many) is counted, and scattered over the 2^lowbits
+// buckets of its bin, whose runs are adjacent in the output.
+//   k_msm_refine_count:    slice_hist[slice][low]                                          (one workgroup per slice)
+//   k_msm_refine_offsets:  count / offset of every bucket, the slices' write cursors, the big-bucket list (one lane per bucket)
+//   k_msm_refine_scatter:  entries[cursor[low]++] = index | sign << 31                     (one workgroup per slice)
+#define MSM_REFINE_THREADS 512
+#define MSM_REFINE_MAXLOW 128
+__device__ __forceinline__ bool msm_slice_range(const MsmArgs& a, unsigned int* bin, unsigned int* lo, unsigned int* hi) {
+    if (blockIdx.x >= min(a.slices[0], a.slice_cap)) return false;
+    const unsigned int e = a.slices[1 + blockIdx.x];
+    *bin = e & 0xfffffu;
+    const unsigned int base = a.c_offset[*bin], cnt = a.c_count[*bin], s0 = (e >> 20) * a.slice_len;
+    *lo = base + s0;
+    *hi = base + min(cnt, s0 + a.slice_len);
+    return true;
+}
+__global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_count(MsmArgs a) {
+    __shared__ unsigned int hist[MSM_REFINE_MAXLOW];
+    unsigned int bin, lo, hi;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.slices[0] > a.slice_cap) *a.err = 2u;      // cannot happen by the list's sizing
+    if (!msm_slice_range(a, &bin, &lo, &hi)) return;
+    const unsigned int nlow = 1u << a.rbits;
+    if (threadIdx.x < nlow) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned int i = lo + threadIdx.x; i < hi; i += MSM_REFINE_THREADS) (void)msm_wave_counter_add(hist, a.c_entries[i] >> (32 - a.rbits));
+    __syncthreads();
+    if (threadIdx.x < nlow) a.slice_hist[(size_t)blockIdx.x * nlow + threadIdx.x] = hist[threadIdx.x];
+}
+__global__ void __launch_bounds__(GKR_BLOCK) k_msm_refine_offsets(MsmArgs a) {
+    __shared__ unsigned int sh[GKR_BLOCK];
+    const size_t t = (size_t)blockIdx.x * GKR_BLOCK + threadIdx.x;       // W * nb is a multiple of the block or smaller than it
+    const size_t total = (size_t)a.W * a.nb;
+    const unsigned int nlow = 1u << a.rbits, low = (unsigned int)t & (nlow - 1u);
+    const size_t bin = t >> a.rbits;
+    unsigned int cnt = 0, nsl = 0, k0 = 0, cb = 0;
+    if (t < total) {
+        cb = a.c_count[bin];
+        nsl = (cb + a.slice_len - 1) / a.slice_len;
+        k0 = nsl ? a.c_first[bin] : 0u;
+        for (unsigned int s = 0; s < nsl; s++) cnt += a.slice_hist[(size_t)(k0 + s) * nlow + low];
+    }
+    sh[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int d = 1; d < GKR_BLOCK; d <<= 1) {            // inclusive scan over the block
+        const unsigned int x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    if (t >= total) return;
+    const unsigned int g0 = threadIdx.x & ~(nlow - 1u);                  // first lane of the bucket's bin in this block
+    unsigned int run = a.c_offset[bin] + sh[threadIdx.x] - cnt - (g0 ? sh[g0 - 1] : 0u);
+    a.count[t] = cnt;
+    a.offset[t] = run;
+    if (cnt > a.big_threshold) {
+        const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
+        const unsigned int b0 = atomicAdd(&a.big[0], nseg);
+        for (unsigned int sg = 0; sg < nseg && b0 + sg < a.big_cap; sg++) a.big[1 + b0 + sg] = (unsigned int)t | (sg << 20);
+    }
+    for (unsigned int s = 0; s < nsl; s++) {
+        unsigned int* p = &a.slice_hist[(size_t)(k0 + s) * nlow + low];
+        const unsigned int x = *p;
+        *p = run;
+        run += x;
+    }
+}
+__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_refine_scatter(MsmArgs a) {
+    __shared__ MsmStage sh;
+    unsigned int bin, lo, hi;
+    if (!msm_slice_range(a, &bin, &lo, &hi)) return;
+    const unsigned int nlow = 1u << a.rbits;
+    if (threadIdx.x < nlow) sh.cursor[threadIdx.x] = a.slice_hist[(size_t)blockIdx.x * nlow + threadIdx.x];
+    __syncthreads();
+    const int ib = 31 - a.rbits;
+    const u32 idxmask = (1u << ib) - 1u;
+    for (unsigned int i0 = lo; i0 < hi; i0 += MSM_STAGE) {
+        u32 e[MSM_STAGE_PER], low[MSM_STAGE_PER];
+#pragma unroll
+        for (int r = 0; r < MSM_STAGE_PER; r++) {
+            const unsigned int i = i0 + (unsigned int)r * MSM_SORT_THREADS + threadIdx.x;
+            low[r] = 0xffffffffu;
+            e[r] = 0;
+            if (i < hi) {
+                const u32 x = a.c_entries[i];
+                low[r] = x >> (32 - a.rbits);
+                e[r] = (x & idxmask) | (((x >> ib) & 1u) << 31);
+            }
+        }
+        msm_stage_batch(sh, nlow, e, low, a.entries);
     }
 }
 // Lanes of a wave run for as long as their longest bucket: the buckets of a window are handed to the lanes in order of
@@ -570,7 +795,7 @@ template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_accumulate_big(MsmArgs a) {
     __shared__ XyzzShared<F> sh;
     const unsigned int nbig = min(a.big[0], a.big_cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.big[0] > a.big_cap) a.big[a.big_cap + 1] = 2u;      // the list overflowed (cannot happen by its sizing): an error, not a wrong sum
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.big[0] > a.big_cap) *a.err = 2u;      // the list overflowed (cannot happen by its sizing): an error, not a wrong sum
     for (unsigned int k = blockIdx.x; k < nbig; k += gridDim.x) {
         const unsigned int e = a.big[1 + k];
         const size_t t = e & 0xfffffu;

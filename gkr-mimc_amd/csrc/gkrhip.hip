@@ -314,6 +314,10 @@ int gkrhip_set_option(const char* key, long value) {
         g_test_drop_round.store((int)value);
         return 0;
     }
+    if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
+        g_msm_sort_levels.store((int)value);
+        return 0;
+    }
     bool known = false;
     for (const char* k : keys) known = known || !strcmp(key, k);
     if (!known) return fail("unknown option %s", key);

@@ -40,8 +40,15 @@ struct MsmWork {
     uint4* h_wins = nullptr;             // pinned: 4 * w16 planes x W, then the error word
     size_t nparts = 0;
     int w16 = 2;                         // planes of a bucket: 4 * w16
+    // two-level sort (lowbits > 0): coarse bins of 2^lowbits buckets, slices of slice_len entries
+    int lowbits = 0;
+    unsigned int slice_len = 0, slice_cap = 0, ctiles = 0;
+    unsigned int* lvl2 = nullptr;        // coarse count | offset | first slice (W * nbc each) | chunk histograms | tile sums | slice list | slice histograms
+    unsigned int* c_entries = nullptr;   // the coarse pass's entries
     void release() {
         if (counts) (void)hipFree(counts);
+        if (lvl2) (void)hipFree(lvl2);
+        if (c_entries) (void)hipFree(c_entries);
         if (entries) (void)hipFree(entries);
         if (big) (void)hipFree(big);
         if (scalars) (void)hipFree(scalars);
@@ -63,12 +70,26 @@ struct gkrhip_g1_bases : MsmBases {};
 struct gkrhip_g2_bases : MsmBases {};
 namespace {
 
+// Levels of the counting sort (g1.hip.h): one pass up to 2^19 points, two from 2^20 (the single pass is bound by partial-line
+// writes there); gkrhip_set_option("msm_sort_levels", 1 | 2) forces either for the tests and the A/B.
+std::atomic<int> g_msm_sort_levels{0};
+inline int msm_pick_lowbits(size_t n, int c) {
+    const int forced = g_msm_sort_levels.load();
+    if (forced == 1 || c < 3) return 0;
+    if (forced != 2 && n < ((size_t)1 << 20)) return 0;
+    int logn = 0;
+    while (((size_t)1 << logn) < n) logn++;
+    return std::max(1, std::min(std::min(7, 31 - logn), (c - 1) / 2));      // the entry keeps index, sign and low bits in 32 bits
+}
+
 int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     const int c = c_forced > 0 ? c_forced : msm_pick_c(n);
     if (c < 2 || c > 16) return fail("msm: window size %d outside 2..16", c);
-    if (w->counts && w->c == c && w->n_cap >= n && w->w16 == w16) return 0;
+    const int lowbits = msm_pick_lowbits(n, c);
+    if (w->counts && w->c == c && w->n_cap >= n && w->w16 == w16 && w->lowbits == lowbits) return 0;
     w->release();
     w->c = c;
+    w->lowbits = lowbits;
     w->w16 = w16;
     w->W = msm_windows(c);
     w->nb = 1u << (c - 1);
@@ -100,7 +121,18 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
         w->bias[bit >> 5] |= 1u << (bit & 31);
     }
     w->ntiles = (unsigned int)((nbk + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE);
-    HIPCHK(hipMalloc((void**)&w->counts, ((3 + (size_t)w->nchunk) * nbk + w->ntiles) * sizeof(unsigned int)));
+    if (lowbits) {
+        const size_t nbc = (size_t)w->W * (w->nb >> lowbits);      // coarse bins
+        w->slice_len = 8192;
+        while ((size_t)w->slice_len * 4096 < n) w->slice_len <<= 1;           // at most 4096 slices per bin (12 bits of the list entry)
+        w->slice_cap = (unsigned int)((size_t)w->W * n / w->slice_len + nbc + 16);
+        w->ctiles = (unsigned int)((nbc + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE);
+        const size_t words = (3 + (size_t)w->nchunk) * nbc + w->ctiles + ((size_t)w->slice_cap + 2) + ((size_t)w->slice_cap << lowbits);
+        HIPCHK(hipMalloc((void**)&w->lvl2, words * sizeof(unsigned int)));
+        HIPCHK(hipMalloc((void**)&w->c_entries, std::max<size_t>(1, (size_t)w->W * n) * sizeof(unsigned int)));
+        HIPCHK(hipMalloc((void**)&w->counts, (3 * nbk) * sizeof(unsigned int)));
+    } else
+        HIPCHK(hipMalloc((void**)&w->counts, ((3 + (size_t)w->nchunk) * nbk + w->ntiles) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->entries, std::max<size_t>(1, (size_t)w->W * n) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->big, ((size_t)w->big_cap + 2) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
@@ -159,9 +191,51 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     a.seg = w->seg;
     a.chunk = w->chunk;
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
+    a.err = a.big + a.big_cap + 1;
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
-    HIPCHK(hipMemsetAsync(a.big + a.big_cap + 1, 0, sizeof(unsigned int), st));
-    {
+    HIPCHK(hipMemsetAsync(a.err, 0, sizeof(unsigned int), st));
+    if (w->lowbits) {
+        // coarse pass: the same five kernels over W * nbc bins; its "big bucket" list (threshold 0: every nonempty bin, cut
+        // into segments of slice_len entries) is the slice list of the refine kernels
+        const unsigned int nbc1 = w->nb >> w->lowbits;
+        const size_t nbc = (size_t)w->W * nbc1;
+        MsmArgs ca = a;
+        ca.lowbits = w->lowbits;
+        ca.count = w->lvl2;
+        ca.offset = w->lvl2 + nbc;
+        ca.bin_first = w->lvl2 + 2 * nbc;
+        ca.chist = w->lvl2 + 3 * nbc;
+        ca.tile_sum = ca.chist + (size_t)w->nchunk * nbc;
+        ca.ntiles = w->ctiles;
+        ca.big = ca.tile_sum + w->ctiles;
+        ca.big_cap = w->slice_cap;
+        ca.big_threshold = 0;
+        ca.seg = w->slice_len;
+        ca.entries = w->c_entries;
+        a.c_entries = w->c_entries;
+        a.c_count = ca.count;
+        a.c_offset = ca.offset;
+        a.c_first = ca.bin_first;
+        a.slices = ca.big;
+        a.slice_cap = w->slice_cap;
+        a.slice_len = w->slice_len;
+        a.rbits = w->lowbits;
+        a.slice_hist = ca.big + w->slice_cap + 2;
+        a.chist = nullptr;
+        a.tile_sum = nullptr;
+        HIPCHK(hipMemsetAsync(ca.big, 0, sizeof(unsigned int), st));
+        const dim3 sgrid(w->W, w->nchunk), sblock(MSM_SORT_THREADS);
+        const size_t lds = (size_t)nbc1 * sizeof(unsigned int);
+        hipLaunchKernelGGL(k_msm_hist, sgrid, sblock, lds, st, ca);
+        hipLaunchKernelGGL(k_msm_totals, dim3(w->ctiles), dim3(MSM_SCAN_THREADS), 0, st, ca);
+        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(MSM_SCAN_THREADS), 0, st, ca);
+        hipLaunchKernelGGL(k_msm_offsets, dim3(w->ctiles), dim3(MSM_SCAN_THREADS), 0, st, ca);
+        hipLaunchKernelGGL(k_msm_scatter_coarse, sgrid, sblock, 0, st, ca);
+        hipLaunchKernelGGL(k_msm_refine_count, dim3(w->slice_cap), dim3(MSM_REFINE_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_msm_refine_offsets, dim3((unsigned)((nbk + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_msm_refine_scatter, dim3(w->slice_cap), dim3(MSM_SORT_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_msm_order, dim3(w->W), sblock, 0, st, a);
+    } else {
         static std::once_flag once;       // histograms above 64 KiB of dynamic LDS need the attribute (gfx950: 160 KiB per CU)
         std::call_once(once, [] {
             (void)hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
@@ -190,7 +264,7 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     HIPCHK(hipGetLastError());
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[4], st));
     HIPCHK(hipMemcpyAsync(w->h_wins, a.wins.base, npl * w->W * sizeof(uint4), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(w->h_wins + npl * w->W, a.big + a.big_cap + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(w->h_wins + npl * w->W, a.err, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[5], st));
     return 0;
 }

@@ -271,3 +271,89 @@ def test_compute_h_then_multi_exp_on_the_device(gk, n, card):
         assert got.tolist() == c.g1_msm(bases.read(), h_ref).tolist()
     assert bases.compute_h_multi_exp(a, b, cc, card).tolist() == got.tolist()
     bases.close()
+
+
+# ---- the two-level sort (host_msm.hip.h: from 2^20 points by default; forced here at sizes the oracle reaches) ----------
+@pytest.fixture
+def two_level(gk):
+    gk.set_option("msm_sort_levels", 2)
+    yield
+    gk.set_option("msm_sort_levels", 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 100, 1000, 4096, 1 << 14])
+def test_msm_two_level_sort_vs_oracle(gk, two_level, n):
+    rng = random.Random(300 + n)
+    pts = rand_points(n + 2, n)
+    sc = rand_scalars(rng, n)
+    if n >= 100:
+        pts[3] = 0
+        pts[5] = pts[4]
+        sc[5] = sc[4]
+    want = c.g1_msm(pts, sc)
+    b = gk.G1Bases(points=pts)
+    assert b.multi_exp(sc).tolist() == want.tolist()
+    assert b.multi_exp(sc).tolist() == want.tolist()
+    assert b.multi_exp(sc[: n // 2]).tolist() == c.g1_msm(pts[: n // 2], sc[: n // 2]).tolist()
+    b.close()
+
+
+@pytest.mark.parametrize("cw", [3, 4, 5, 7, 8, 11, 13, 14, 15, 16])
+def test_msm_two_level_sort_every_split(gk, two_level, cw):
+    """Coarse bins of 2^lowbits buckets for every split the window sizes give (lowbits = 1 .. 7)."""
+    rng = random.Random(cw)
+    n = 3000
+    pts = rand_points(78, n)
+    sc = rand_scalars(rng, n)
+    b = gk.G1Bases(points=pts)
+    b.set_window(cw)
+    assert b.multi_exp(sc).tolist() == c.g1_msm(pts, sc).tolist()
+    b.close()
+
+
+def test_msm_two_level_sort_skew_and_long_bins(gk, two_level):
+    """Witness-like scalars at 2^17 points: one coarse bin holds 70 % of a window's entries and is cut into many slices (every
+    lane of a wave then names the same counter: the aggregated update), big buckets are listed by the refine pass; window
+    sizes with a short top window (a few bins of n / 4 entries); the same vector gives the same point with either sort."""
+    n = 1 << 17
+    pts = rand_points(17, n)
+    rng = random.Random(18)
+    sc = ec.scalars_to_image([1 if rng.random() < 0.7 else rng.choice([0, 2, 3, Q - 1, rng.randrange(Q)]) for _ in range(n)])
+    want = c.g1_msm(pts, sc)
+    full = rand_scalars(rng, n)
+    want_full = c.g1_msm(pts, full)
+    b = gk.G1Bases(points=pts)
+    assert b.multi_exp(sc).tolist() == want.tolist()
+    assert b.multi_exp(full).tolist() == want_full.tolist()
+    for cw in (14, 11):
+        b.set_window(cw)
+        assert b.multi_exp(full).tolist() == want_full.tolist(), cw
+        assert b.multi_exp(sc).tolist() == want.tolist(), cw
+    gk.set_option("msm_sort_levels", 1)
+    b.set_window(0)
+    assert b.multi_exp(sc).tolist() == want.tolist()
+    b.close()
+
+
+def test_msm_sort_levels_agree_at_2p20(gk):
+    """2^20 points (two levels by default): the forced single-level sort gives the same point, and a non-reduced scalar is
+    still refused."""
+    n = 1 << 20
+    rng = np.random.default_rng(77)
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    s = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 61) - 1)
+    b = gk.G1Bases(base=c.G1_GEN, scalars=k)
+    r2 = b.multi_exp(s)
+    bad = s.copy()
+    bad[12345] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with pytest.raises(gk.GkrHipError):
+        b.multi_exp(bad)
+    try:
+        gk.set_option("msm_sort_levels", 1)
+        r1 = b.multi_exp(s)
+    finally:
+        gk.set_option("msm_sort_levels", 0)
+    assert c.g1_on_curve(r2) and r1.tolist() == r2.tolist()
+    b.close()

@@ -130,3 +130,15 @@ def test_bench_msm_g2_result(gk):
     tot = sum(a * b for a, b in zip(_synth_scalars(n, 0x1234567), _synth_scalars(n, 0x7654321))) % Q
     assert r["result"].tolist() == ec.g2_point_to_image(ec.g2_mul(tot, ec.G2)).tolist()
     assert r["ms"] > 0
+
+
+def test_msm_g2_two_level_sort(gk):
+    """The two-level sort (default from 2^20 points) forced at sizes the oracle reaches: the sorting kernels are shared with G1."""
+    gk.set_option("msm_sort_levels", 2)
+    try:
+        _dlog_check(gk, 700, 61)
+        _dlog_check(gk, 1 << 14, 62)
+        _dlog_check(gk, 1 << 15, 63, skew=True)
+        _dlog_check(gk, 1 << 14, 64, cw=14)
+    finally:
+        gk.set_option("msm_sort_levels", 0)
