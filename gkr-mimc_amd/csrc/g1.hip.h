@@ -726,7 +726,12 @@ template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK, MsmTune<F>::ACC_MINBLOCKS) k_msm_accumulate(MsmArgs a) {
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= (size_t)a.W * a.nb) return;
-    const size_t t = lane - lane % a.nb + a.order[lane];          // the lane's bucket: the (lane mod nb)-th largest of its window
+    // The lane's bucket: the (lane mod nb)-th largest of its window, the TOP window first: a scalar below q < 2^254 leaves the
+    // top digit few values (q >> 240 = 12 388 of the 32 768 buckets at c = 16), so its buckets hold 2.6 times the points of the
+    // others -- launched last they were the kernel's tail (2^24 points: 26.9 ms, against 22 ms for 16 windows at the rate of
+    // the first 14).
+    const size_t jw = (size_t)(a.W - 1) - lane / a.nb;
+    const size_t t = jw * a.nb + a.order[jw * a.nb + lane % a.nb];
     const unsigned int cnt = a.count[t], start = a.offset[t];
     XyzzT<F> acc;
     ecx_set_inf(acc);
