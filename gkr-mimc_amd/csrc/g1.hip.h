@@ -272,6 +272,8 @@ struct MsmArgs {
     XPlanes parts;            // W * nchunk chunk sums
     XPlanes wins;             // W window sums
     int chunk;                // buckets per lane of k_msm_reduce_chunks (a power of two)
+    unsigned short* digits;   // [W][dstride] raw c-bit windows of the biased scalars (k_msm_digits)
+    size_t dstride;           // n rounded up to a multiple of eight
     unsigned int* err;        // error word: 1 = a scalar was not below 2^254, 2 = a list overflowed
     // two-level sort (large n): the sorting kernels above run as a COARSE pass that files a point under bucket >> lowbits and
     // keeps the low bits in the entry; the refine kernels finish the order inside every coarse bin
@@ -313,7 +315,8 @@ __device__ __forceinline__ bool msm_bias_scalar(const MsmArgs& a, u32 (&s)[8]) {
     for (int l = 0; l < 8; l++) s[l] = fr_addc(s[l], a.bias[l], cy, &cy);
     return cy == 0;
 }
-__device__ __forceinline__ u32 msm_digit(const MsmArgs& a, const u32 (&sb)[8], int j, bool* neg) {
+// the plain c-bit window j of the biased scalar
+__device__ __forceinline__ u32 msm_window_raw(const MsmArgs& a, const u32 (&sb)[8], int j) {
     const int bit = j * a.c, limb = bit >> 5, sh = bit & 31;      // uniform across the workgroup: selects, not indexed registers
     u32 lo = 0, hi = 0;
 #pragma unroll
@@ -321,7 +324,9 @@ __device__ __forceinline__ u32 msm_digit(const MsmArgs& a, const u32 (&sb)[8], i
         lo = (l == limb) ? sb[l] : lo;
         hi = (l == limb + 1) ? sb[l] : hi;
     }
-    const u32 dp = (u32)((((u64)hi << 32) | lo) >> sh) & ((1u << a.c) - 1u);
+    return (u32)((((u64)hi << 32) | lo) >> sh) & ((1u << a.c) - 1u);
+}
+__device__ __forceinline__ u32 msm_digit(const MsmArgs& a, u32 dp, int j, bool* neg) {
     const u32 half = a.nb;
     if (j == a.W - 1) {
         *neg = false;
@@ -330,6 +335,38 @@ __device__ __forceinline__ u32 msm_digit(const MsmArgs& a, const u32 (&sb)[8], i
     *neg = dp < half;
     const u32 mag = *neg ? half - dp : dp - half;
     return mag ? mag - 1u : MSM_DIGIT_NONE;
+}
+// Every scalar is decoded ONCE (Montgomery conversion included) into W planes of 16-bit raw windows, digits[j][i], rows padded
+// to a multiple of eight: the sorting kernels then read 2 bytes per point and window instead of the 32-byte scalar (which
+// every one of the 2 W workgroups over a chunk used to decode again).  Padding holds the raw value of a zero digit.
+__global__ void __launch_bounds__(GKR_BLOCK) k_msm_digits(MsmArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.dstride) return;
+    if (i >= a.n) {
+        for (int j = 0; j < a.W; j++) a.digits[(size_t)j * a.dstride + i] = (unsigned short)(j == a.W - 1 ? 0u : a.nb);
+        return;
+    }
+    u32 s[8];
+    msm_load_scalar(a, i, s);
+    bool bad = !msm_bias_scalar(a, s);
+    for (int j = 0; j < a.W; j++) {
+        const u32 dp = msm_window_raw(a, s, j);
+        if (j == a.W - 1 && dp > a.nb) bad = true;
+        a.digits[(size_t)j * a.dstride + i] = (unsigned short)dp;
+    }
+    if (bad) *a.err = 1u;
+}
+// the eight raw windows of points i .. i + 7 (i a multiple of eight) of window j
+__device__ __forceinline__ void msm_load_digits8(const MsmArgs& a, int j, size_t i, u32 (&dp)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(a.digits + (size_t)j * a.dstride + i);
+    dp[0] = v.x & 0xffffu;
+    dp[1] = v.x >> 16;
+    dp[2] = v.y & 0xffffu;
+    dp[3] = v.y >> 16;
+    dp[4] = v.z & 0xffffu;
+    dp[5] = v.z >> 16;
+    dp[6] = v.w & 0xffffu;
+    dp[7] = v.w >> 16;
 }
 
 // Counting sort of the (window, bucket) pairs with every atomic in LDS.  Workgroup (j, k) owns window j of the k-th chunk
@@ -346,18 +383,17 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(MsmArgs a) {
     const unsigned int nbs = msm_sort_bins(a);
     for (unsigned int b = threadIdx.x; b < nbs; b += MSM_SORT_THREADS) hist[b] = 0;
     __syncthreads();
-    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
-    bool bad = false;
-    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
-        u32 s[8];
-        msm_load_scalar(a, i, s);
-        const bool fits = msm_bias_scalar(a, s);
-        bool neg;
-        const u32 b = msm_digit(a, s, j, &neg);
-        if (b == MSM_DIGIT_BAD || !fits) bad = true;
-        else if (b != MSM_DIGIT_NONE) atomicAdd(&hist[b >> a.lowbits], 1u);
+    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);      // chunk_len is a multiple of eight
+    for (size_t i = lo + 8 * (size_t)threadIdx.x; i < hi; i += 8 * MSM_SORT_THREADS) {
+        u32 dp[8];
+        msm_load_digits8(a, j, i, dp);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            bool neg;
+            const u32 b = msm_digit(a, dp[r], j, &neg);
+            if (i + r < hi && b < MSM_DIGIT_BAD) atomicAdd(&hist[b >> a.lowbits], 1u);
+        }
     }
-    if (bad) *a.err = 1u;
     __syncthreads();
     unsigned int* out = a.chist + ((size_t)j * a.nchunk + k) * nbs;
     for (unsigned int b = threadIdx.x; b < nbs; b += MSM_SORT_THREADS) out[b] = hist[b];
@@ -454,13 +490,15 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(MsmArgs a) {
     for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) cursor[b] = in[b];
     __syncthreads();
     const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
-    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
-        u32 s[8];
-        msm_load_scalar(a, i, s);
-        (void)msm_bias_scalar(a, s);
-        bool neg;
-        const u32 b = msm_digit(a, s, j, &neg);
-        if (b < MSM_DIGIT_BAD) a.entries[atomicAdd(&cursor[b], 1u)] = (u32)i | (neg ? 0x80000000u : 0u);
+    for (size_t i = lo + 8 * (size_t)threadIdx.x; i < hi; i += 8 * MSM_SORT_THREADS) {
+        u32 dp[8];
+        msm_load_digits8(a, j, i, dp);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            bool neg;
+            const u32 b = msm_digit(a, dp[r], j, &neg);
+            if (i + r < hi && b < MSM_DIGIT_BAD) a.entries[atomicAdd(&cursor[b], 1u)] = (u32)(i + r) | (neg ? 0x80000000u : 0u);
+        }
     }
 }
 // LDS counter update of a wave: when every active lane of the wave names the same counter (a slice of the bin that holds the
@@ -552,21 +590,20 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs
     const int ib = 31 - a.lowbits;
     const u32 lowmask = (1u << a.lowbits) - 1u;
     for (size_t i0 = lo; i0 < hi; i0 += MSM_STAGE) {
-        u32 e[MSM_STAGE_PER], bin[MSM_STAGE_PER];
+        u32 e[MSM_STAGE_PER], bin[MSM_STAGE_PER], dp[8];
+        static_assert(MSM_STAGE_PER == 8, "a lane takes the eight points of one 16-byte load");
+        const size_t i = i0 + 8 * (size_t)threadIdx.x;
+        if (i < hi) msm_load_digits8(a, j, i, dp);
 #pragma unroll
-        for (int r = 0; r < MSM_STAGE_PER; r++) {
-            const size_t i = i0 + (size_t)r * MSM_SORT_THREADS + threadIdx.x;
+        for (int r = 0; r < 8; r++) {
             bin[r] = 0xffffffffu;
             e[r] = 0;
-            if (i < hi) {
-                u32 s[8];
-                msm_load_scalar(a, i, s);
-                (void)msm_bias_scalar(a, s);
+            if (i + r < hi) {
                 bool neg;
-                const u32 b = msm_digit(a, s, j, &neg);
+                const u32 b = msm_digit(a, dp[r], j, &neg);
                 if (b < MSM_DIGIT_BAD) {
                     bin[r] = b >> a.lowbits;
-                    e[r] = (u32)i | ((neg ? 1u : 0u) << ib) | ((b & lowmask) << (ib + 1));
+                    e[r] = (u32)(i + r) | ((neg ? 1u : 0u) << ib) | ((b & lowmask) << (ib + 1));
                 }
             }
         }

@@ -34,6 +34,7 @@ struct MsmWork {
     size_t chunk_len = 0;
     uint32_t bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int* entries = nullptr;
+    unsigned short* digits = nullptr;    // W planes of 16-bit raw windows
     unsigned int* big = nullptr;
     uint4* scalars = nullptr;            // n_cap x 32 B staging of host scalars
     uint4* xyzz = nullptr;               // buckets | parts | wins planes
@@ -50,6 +51,7 @@ struct MsmWork {
         if (lvl2) (void)hipFree(lvl2);
         if (c_entries) (void)hipFree(c_entries);
         if (entries) (void)hipFree(entries);
+        if (digits) (void)hipFree(digits);
         if (big) (void)hipFree(big);
         if (scalars) (void)hipFree(scalars);
         if (xyzz) (void)hipFree(xyzz);
@@ -114,7 +116,7 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     // (one workgroup per CU at c = 16: measured 2.72 / 1.96 / 1.96 ms of sorting at 2^22 points with 8 / 16..32 / 64 chunks,
     // 10.6 / 8.9 / 6.9 ms at 2^24 with 8 / 16 / 64)
     w->nchunk = (unsigned int)std::min<size_t>(128, std::max<size_t>(1, n / 131072));
-    w->chunk_len = (n + w->nchunk - 1) / w->nchunk;
+    w->chunk_len = ((n + w->nchunk - 1) / w->nchunk + 7) & ~(size_t)7;      // the sorting kernels read eight 16-bit digits per load
     memset(w->bias, 0, sizeof w->bias);
     for (int j = 0; j + 1 < w->W; j++) {
         const int bit = j * c + c - 1;
@@ -134,6 +136,7 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     } else
         HIPCHK(hipMalloc((void**)&w->counts, ((3 + (size_t)w->nchunk) * nbk + w->ntiles) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->entries, std::max<size_t>(1, (size_t)w->W * n) * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&w->digits, std::max<size_t>(8, (size_t)w->W * ((n + 7) & ~(size_t)7)) * sizeof(unsigned short)));
     HIPCHK(hipMalloc((void**)&w->big, ((size_t)w->big_cap + 2) * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
     HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W + w->big_cap) * sizeof(uint4)));
@@ -192,8 +195,11 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     a.chunk = w->chunk;
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
     a.err = a.big + a.big_cap + 1;
+    a.digits = w->digits;
+    a.dstride = (n + 7) & ~(size_t)7;
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
     HIPCHK(hipMemsetAsync(a.err, 0, sizeof(unsigned int), st));
+    if (n) hipLaunchKernelGGL(k_msm_digits, dim3((unsigned)((a.dstride + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
     if (w->lowbits) {
         // coarse pass: the same five kernels over W * nbc bins; its "big bucket" list (threshold 0: every nonempty bin, cut
         // into segments of slice_len entries) is the slice list of the refine kernels
