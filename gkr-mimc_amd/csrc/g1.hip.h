@@ -517,22 +517,22 @@ __device__ __forceinline__ unsigned int msm_wave_counter_add(unsigned int* ctr, 
 // ---- scatter through LDS ---------------------------------------------------------------------------------------------------
 // A lane that writes its 4-byte entry wherever its bin's cursor points costs one memory request per lane (64 lines per wave
 // store): the two scatters of the two-level sort were bound by that request rate, not by bytes.  Both therefore sort a batch
-// of MSM_STAGE entries inside LDS first -- count per bin, scan, place -- and write the batch out in order, so that
+// (eight entries per lane) inside LDS first -- count per bin, scan, place -- and write the batch out in order, so that
 // consecutive lanes write the consecutive entries of a bin's run.
-#define MSM_STAGE 8192
-#define MSM_STAGE_PER (MSM_STAGE / MSM_SORT_THREADS)
-#define MSM_STAGE_MAXBINS 1024
+// T lanes take batches of 8 T entries; at most T bins.
+template <int T>
 struct MsmStage {
-    u32 staged[MSM_STAGE];
-    unsigned short sbin[MSM_STAGE];
-    unsigned int cursor[MSM_STAGE_MAXBINS];      // the workgroup's write position of every bin in the output
-    unsigned int lcnt[MSM_STAGE_MAXBINS];        // entries of the batch per bin, then (output position - staged position) of the bin
-    unsigned int lstart[MSM_STAGE_MAXBINS];
-    unsigned int wsum[MSM_SORT_THREADS / 64];
+    u32 staged[8 * T];
+    unsigned short sbin[8 * T];
+    unsigned int cursor[T];      // the workgroup's write position of every bin in the output
+    unsigned int lcnt[T];        // entries of the batch per bin, then (output position - staged position) of the bin
+    unsigned int lstart[T];
+    unsigned int wsum[T / 64];
     unsigned int total;
 };
-// exclusive scan over the workgroup's MSM_SORT_THREADS values
-__device__ __forceinline__ unsigned int msm_stage_scan(MsmStage& sh, unsigned int v) {
+// exclusive scan over the workgroup's T values
+template <int T>
+__device__ __forceinline__ unsigned int msm_stage_scan(MsmStage<T>& sh, unsigned int v) {
     const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned int x = v;
 #pragma unroll
@@ -546,14 +546,14 @@ __device__ __forceinline__ unsigned int msm_stage_scan(MsmStage& sh, unsigned in
     for (unsigned int w = 0; w < wave; w++) base += sh.wsum[w];
     return base + x - v;
 }
-// One batch: the lane's MSM_STAGE_PER entries e[r] for the bins bin[r] (0xffffffff: none) go to out[] at the bins' cursors.
-__device__ __forceinline__ void msm_stage_batch(MsmStage& sh, unsigned int nbins, const u32 (&e)[MSM_STAGE_PER], const u32 (&bin)[MSM_STAGE_PER],
-                                                unsigned int* out) {
-    unsigned int rank[MSM_STAGE_PER];
+// One batch: the lane's eight entries e[r] for the bins bin[r] (0xffffffff: none) go to out[] at the bins' cursors.
+template <int T>
+__device__ __forceinline__ void msm_stage_batch(MsmStage<T>& sh, unsigned int nbins, const u32 (&e)[8], const u32 (&bin)[8], unsigned int* out) {
+    unsigned int rank[8];
     if (threadIdx.x < nbins) sh.lcnt[threadIdx.x] = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < MSM_STAGE_PER; r++)
+    for (int r = 0; r < 8; r++)
         if (bin[r] != 0xffffffffu) rank[r] = msm_wave_counter_add(sh.lcnt, bin[r]);
     __syncthreads();
     const unsigned int mine = threadIdx.x < nbins ? sh.lcnt[threadIdx.x] : 0u;
@@ -566,7 +566,7 @@ __device__ __forceinline__ void msm_stage_batch(MsmStage& sh, unsigned int nbins
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < MSM_STAGE_PER; r++)
+    for (int r = 0; r < 8; r++)
         if (bin[r] != 0xffffffffu) {
             const unsigned int p = sh.lstart[bin[r]] + rank[r];
             sh.staged[p] = e[r];
@@ -574,12 +574,12 @@ __device__ __forceinline__ void msm_stage_batch(MsmStage& sh, unsigned int nbins
         }
     __syncthreads();
     const unsigned int total = sh.total;
-    for (unsigned int p = threadIdx.x; p < total; p += MSM_SORT_THREADS) out[sh.lcnt[sh.sbin[p]] + p] = sh.staged[p];
+    for (unsigned int p = threadIdx.x; p < total; p += T) out[sh.lcnt[sh.sbin[p]] + p] = sh.staged[p];
     __syncthreads();
 }
 // the coarse pass's scatter: workgroup (j, k) files the entries of window j of chunk k under their coarse bins
 __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs a) {
-    __shared__ MsmStage sh;
+    __shared__ MsmStage<MSM_SORT_THREADS> sh;
     const int j = blockIdx.x;
     const unsigned int k = blockIdx.y;
     const unsigned int nbs = msm_sort_bins(a);
@@ -589,9 +589,8 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs
     const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
     const int ib = 31 - a.lowbits;
     const u32 lowmask = (1u << a.lowbits) - 1u;
-    for (size_t i0 = lo; i0 < hi; i0 += MSM_STAGE) {
-        u32 e[MSM_STAGE_PER], bin[MSM_STAGE_PER], dp[8];
-        static_assert(MSM_STAGE_PER == 8, "a lane takes the eight points of one 16-byte load");
+    for (size_t i0 = lo; i0 < hi; i0 += 8 * MSM_SORT_THREADS) {      // a lane takes the eight points of one 16-byte load
+        u32 e[8], bin[8], dp[8];
         const size_t i = i0 + 8 * (size_t)threadIdx.x;
         if (i < hi) msm_load_digits8(a, j, i, dp);
 #pragma unroll
@@ -620,7 +619,7 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs
 //   k_msm_refine_count:    slice_hist[slice][low]                                          (one workgroup per slice)
 //   k_msm_refine_offsets:  count / offset of every bucket, the slices' write cursors, the big-bucket list (one lane per bucket)
 //   k_msm_refine_scatter:  entries[cursor[low]++] = index | sign << 31                     (one workgroup per slice)
-#define MSM_REFINE_THREADS 512
+#define MSM_REFINE_THREADS 256
 #define MSM_REFINE_MAXLOW 128
 __device__ __forceinline__ bool msm_slice_range(const MsmArgs& a, unsigned int* bin, unsigned int* lo, unsigned int* hi) {
     if (blockIdx.x >= min(a.slices[0], a.slice_cap)) return false;
@@ -639,7 +638,17 @@ __global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_count(MsmArgs
     const unsigned int nlow = 1u << a.rbits;
     if (threadIdx.x < nlow) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (unsigned int i = lo + threadIdx.x; i < hi; i += MSM_REFINE_THREADS) (void)msm_wave_counter_add(hist, a.c_entries[i] >> (32 - a.rbits));
+    for (unsigned int i0 = lo; i0 < hi; i0 += 4 * MSM_REFINE_THREADS) {      // four loads in flight per lane
+        u32 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned int i = i0 + (unsigned int)r * MSM_REFINE_THREADS + threadIdx.x;
+            x[r] = i < hi ? a.c_entries[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (i0 + (unsigned int)r * MSM_REFINE_THREADS + threadIdx.x < hi) (void)msm_wave_counter_add(hist, x[r] >> (32 - a.rbits));
+    }
     __syncthreads();
     if (threadIdx.x < nlow) a.slice_hist[(size_t)blockIdx.x * nlow + threadIdx.x] = hist[threadIdx.x];
 }
@@ -681,8 +690,8 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_refine_offsets(MsmArgs a) {
         run += x;
     }
 }
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_refine_scatter(MsmArgs a) {
-    __shared__ MsmStage sh;
+__global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_scatter(MsmArgs a) {
+    __shared__ MsmStage<MSM_REFINE_THREADS> sh;
     unsigned int bin, lo, hi;
     if (!msm_slice_range(a, &bin, &lo, &hi)) return;
     const unsigned int nlow = 1u << a.rbits;
@@ -690,11 +699,11 @@ __global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_refine_scatter(MsmArgs
     __syncthreads();
     const int ib = 31 - a.rbits;
     const u32 idxmask = (1u << ib) - 1u;
-    for (unsigned int i0 = lo; i0 < hi; i0 += MSM_STAGE) {
-        u32 e[MSM_STAGE_PER], low[MSM_STAGE_PER];
+    for (unsigned int i0 = lo; i0 < hi; i0 += 8 * MSM_REFINE_THREADS) {
+        u32 e[8], low[8];
 #pragma unroll
-        for (int r = 0; r < MSM_STAGE_PER; r++) {
-            const unsigned int i = i0 + (unsigned int)r * MSM_SORT_THREADS + threadIdx.x;
+        for (int r = 0; r < 8; r++) {
+            const unsigned int i = i0 + (unsigned int)r * MSM_REFINE_THREADS + threadIdx.x;
             low[r] = 0xffffffffu;
             e[r] = 0;
             if (i < hi) {

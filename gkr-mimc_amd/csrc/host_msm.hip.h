@@ -239,7 +239,7 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
         hipLaunchKernelGGL(k_msm_scatter_coarse, sgrid, sblock, 0, st, ca);
         hipLaunchKernelGGL(k_msm_refine_count, dim3(w->slice_cap), dim3(MSM_REFINE_THREADS), 0, st, a);
         hipLaunchKernelGGL(k_msm_refine_offsets, dim3((unsigned)((nbk + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
-        hipLaunchKernelGGL(k_msm_refine_scatter, dim3(w->slice_cap), dim3(MSM_SORT_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_msm_refine_scatter, dim3(w->slice_cap), dim3(MSM_REFINE_THREADS), 0, st, a);
         hipLaunchKernelGGL(k_msm_order, dim3(w->W), sblock, 0, st, a);
     } else {
         static std::once_flag once;       // histograms above 64 KiB of dynamic LDS need the attribute (gfx950: 160 KiB per CU)
