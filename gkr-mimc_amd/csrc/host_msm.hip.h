@@ -10,17 +10,18 @@ const size_t kMsmMaxPoints = (size_t)1 << 26;      // entries are 31-bit point i
 // number of windows for c-bit signed digits of a scalar below 2^254 (the top window absorbs the last carry: g1.hip.h)
 inline int msm_windows(int c) { return (255 + c - 1) / c; }
 // Window size, from the measured sweep (tools/msm_window_sweep.py, G1 and G2 alike): W * n mixed additions against
-// W * 2^(c-1) buckets whose reduction is latency-bound (a bucket costs ~9 mixed additions there, not the 3.5 its arithmetic
-// suggests), more buckets meaning more lanes for the accumulation, and c = 15 and 16 leaving no short top window
-// (255 = 17 * 15; a top window of a few bits puts n / 4 points into each of its buckets):
-//     n <= 2^13: c = log2(n) - 2 (2^10: 8, 2^12: 10)     2^14 .. 2^21: c = 15     from 2^22: c = 16
-// (2^20 points: 3.44 / 2.66 / 2.80 ms with c = 14 / 15 / 16; 2^16: 0.87 / 0.83 with 13 / 15; 2^22: 9.66 with 16.)
+// W * 2^(c-1) buckets whose reduction is latency-bound (~0.4 ms whatever c: a chain of ~45 group operations per lane), more
+// buckets meaning more lanes for the accumulation, and c = 15 and 16 leaving no short top window (255 = 17 * 15; a top window
+// of a few bits puts n / 4 points into each of its buckets):
+//     n < 2^11: c = 8     2^11 .. 2^13: c = log2(n) - 2     2^14 .. 2^18: c = 15     from 2^19: c = 16
+// (G1, ms with c = 14 / 15 / 16: 2^18 1.51 / 1.16 / 1.20, 2^19 2.14 / 1.56 / 1.54, 2^20 3.42 / 2.49 / 2.30,
+//  2^21 6.05 / 4.39 / 3.79, 2^22 11.1 / 8.1 / 6.9; 2^8: 0.33 with c = 8 against 0.81 with 6.)
 inline int msm_pick_c(size_t n) {
     int logn = 0;
     while (((size_t)1 << (logn + 1)) <= n) logn++;
-    if (logn >= 22) return 16;
+    if (logn >= 19) return 16;
     if (logn >= 14) return 15;
-    return std::max(4, logn - 2);
+    return std::max(8, logn - 2);
 }
 
 struct MsmWork {
