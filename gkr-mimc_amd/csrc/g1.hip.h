@@ -8,11 +8,12 @@
 //
 // Pippenger's bucket method laid out for a GPU instead of gnark-crypto's one-goroutine-per-window loop:
 //   1. every scalar (regular form, < q < 2^254) is cut into W = ceil(255 / c) SIGNED digits of c bits
-//      (d in [-2^(c-1), 2^(c-1)]: half the buckets, the sign negates the point's y);
+//      (d in [-2^(c-1), 2^(c-1)]: half the buckets, the sign negates the point's y), once, into 16-bit planes (k_msm_digits);
 //   2. the (window, |digit|) pairs are counting-sorted with every atomic in LDS: a workgroup owns one window of one chunk
 //      of the scalars and keeps that window's whole histogram (128 KiB at c = 16) in gfx950's 160 KiB LDS
-//      (k_msm_hist, k_msm_totals, k_msm_scan, k_msm_offsets, k_msm_scatter) -- never an atomic on a point;
-//   3. ONE LANE PER BUCKET (the buckets of a window handed out in order of size: k_msm_order) adds its run of points with
+//      (k_msm_hist, k_msm_totals, k_msm_scan, k_msm_offsets, k_msm_scatter) -- never an atomic on a point; from 2^20 points
+//      in two levels (coarse bins, then slices of a bin: k_msm_scatter_coarse, k_msm_refine_*), each scatter staged in LDS;
+//   3. ONE LANE PER BUCKET (the buckets of a window handed out in order of size, the top window first: k_msm_order) adds its run of points with
 //      mixed additions into an extended-Jacobian (XYZZ) accumulator (k_msm_accumulate: 8 M + 2 S per point, the bulk of the
 //      work: W * n additions); the few buckets far above the mean
 //      (skewed scalars: the 0/1 wires of a real witness put most points of window 0 into bucket 1) are cut into segments,
