@@ -357,3 +357,16 @@ def test_msm_sort_levels_agree_at_2p20(gk):
         gk.set_option("msm_sort_levels", 0)
     assert c.g1_on_curve(r2) and r1.tolist() == r2.tolist()
     b.close()
+
+
+def test_msm_sort_levels_agree_at_the_largest_size(gk):
+    """2^26 points (the ABI's maximum: 26-bit indices leave five low bits in a coarse entry, 1 024 coarse bins per window, slices
+    of 16 384 entries): the two sorts give the same point on the micro-benchmark's device-generated data."""
+    res = {}
+    try:
+        for lv in (1, 2):
+            gk.set_option("msm_sort_levels", lv)
+            res[lv] = gk.bench_msm_g1(26, warmup=0, iters=1)["result"].tolist()
+    finally:
+        gk.set_option("msm_sort_levels", 0)
+    assert res[1] == res[2] and any(res[1]) and c.g1_on_curve(np.array(res[1], dtype=np.uint64))
