@@ -1215,6 +1215,11 @@ int gkrhip_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* b, const uint64_t* sc
 int gkrhip_msm_g2(uint64_t out_affine[16], gkrhip_g2_bases* b, const uint64_t* scalars, size_t n, int flags) {
     return abi_msm<Fp2F, hfp::HFp2>(out_affine, b, scalars, n, flags);
 }
+int gkrhip_msm_g1_g2(uint64_t out_g1[8], uint64_t out_g2[16], gkrhip_g1_bases* b1, gkrhip_g2_bases* b2, const uint64_t* scalars, size_t n, int flags) {
+    if (!out_g1 || !out_g2 || !b1 || !b2 || (n && !scalars)) return fail("msm: null argument");
+    LEASE_LANE();
+    return msm_run_pair(b1, b2, scalars, n, flags, out_g1, out_g2);
+}
 int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t* points, const uint64_t* scalars, size_t n, int flags) {
     gkrhip_g1_bases* b = nullptr;
     CHK(gkrhip_g1_bases_create(&b, points, n));

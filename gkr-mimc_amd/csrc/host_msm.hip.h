@@ -156,18 +156,17 @@ struct MsmTimes {      // HIP-event split of one MSM (bench only)
     bool on = false;
 };
 
-// The device part: the W window sums of sum_{i<n} [s_i] P_i land in w->h_wins (the caller synchronises the stream).
+// The device part in two steps.  msm_sort_dev: digits and the counting sort of the (window, bucket) pairs -- a function of the
+// scalars and the window size alone, so two MSMs over the same scalars (bs1 and Bs of prove.go:189,277) share it; fills *out.
+// msm_sum_dev<F>: bucket sums, window sums; the W window sums land in w->h_wins (the caller synchronises the stream).
 // d_scalars: n x 32 B on the device.
-template <class F>
-int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi = nullptr) {
-    MsmWork* w = &b->w;
+int msm_sort_dev(MsmWork* w, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi, MsmArgs* out) {
     hipStream_t st = cx().stream;
     const size_t nbk = (size_t)w->W * w->nb;
     MsmArgs a;
     memset(&a, 0, sizeof a);
     a.scalars = d_scalars;
     a.scalars_hi = d_scalars_hi;
-    a.points = b->d_points;
     a.n = n;
     a.c = w->c;
     a.W = w->W;
@@ -187,11 +186,6 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     // a bucket far above the mean (n / nb points per bucket and window for uniform digits) gets a workgroup of its own
     a.big_threshold = (unsigned int)std::max<size_t>(128, 4 * (n / w->nb));
     a.big_cap = w->big_cap;
-    const size_t npl = (size_t)4 * F::W16;      // planes of an XYZZ point
-    a.buckets = XPlanes{w->xyzz, nbk};
-    a.parts = XPlanes{w->xyzz + npl * nbk, w->nparts};
-    a.wins = XPlanes{w->xyzz + npl * (nbk + w->nparts), (size_t)w->W};
-    a.bigparts = XPlanes{w->xyzz + npl * (nbk + w->nparts + (size_t)w->W), (size_t)w->big_cap};
     a.seg = w->seg;
     a.chunk = w->chunk;
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
@@ -260,6 +254,19 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
         hipLaunchKernelGGL(k_msm_order, dim3(w->W), sblock, 0, st, a);
     }
     HIPCHK(hipGetLastError());
+    *out = a;
+    return 0;
+}
+template <class F>
+int msm_sum_dev(MsmWork* w, const uint4* d_points, MsmArgs a, MsmTimes* tm) {
+    hipStream_t st = cx().stream;
+    const size_t nbk = (size_t)w->W * w->nb;
+    a.points = d_points;
+    const size_t npl = (size_t)4 * F::W16;      // planes of an XYZZ point
+    a.buckets = XPlanes{w->xyzz, nbk};
+    a.parts = XPlanes{w->xyzz + npl * nbk, w->nparts};
+    a.wins = XPlanes{w->xyzz + npl * (nbk + w->nparts), (size_t)w->W};
+    a.bigparts = XPlanes{w->xyzz + npl * (nbk + w->nparts + (size_t)w->W), (size_t)w->big_cap};
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[1], st));
     hipLaunchKernelGGL(k_msm_accumulate<F>, dim3((unsigned)((nbk + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[2], st));
@@ -274,6 +281,12 @@ int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* 
     HIPCHK(hipMemcpyAsync(w->h_wins + npl * w->W, a.err, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[5], st));
     return 0;
+}
+template <class F>
+int msm_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi = nullptr) {
+    MsmArgs a;
+    CHK(msm_sort_dev(&b->w, d_scalars, n, flags, tm, d_scalars_hi, &a));
+    return msm_sum_dev<F>(&b->w, b->d_points, a, tm);
 }
 
 // coordinate j of plane group g (0: x, 1: y, 2: zz, 3: zzz) of the window sums
@@ -322,6 +335,29 @@ int msm_run(MsmBases* b, const uint64_t* scalars, size_t n, int flags, uint64_t*
     if (msm_scalar_error(&b->w)) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
     const hfp::AffH<HF> r = msm_host_tail<HF>(&b->w);
     memcpy(out_affine, &r, sizeof r);        // {X, Y} as consecutive fp.Elements: the G1Affine / G2Affine image
+    return 0;
+}
+
+// bs1 = MultiExp(pk.G1.B, wireValuesB) and Bs = MultiExp(pk.G2.B, wireValuesB) (prove.go:189,277) are over the SAME scalars: one
+// upload, one decoding and one sort serve both sums (the sort does not depend on the bases).  Both handles must hold the same
+// number of points (pk.G1.B and pk.G2.B are filtered by the same pk.InfinityB).
+int msm_run_pair(MsmBases* b1, MsmBases* b2, const uint64_t* scalars, size_t n, int flags, uint64_t* out_g1, uint64_t* out_g2) {
+    if (b1->n != b2->n) return fail("msm pair: %zu G1 bases and %zu G2 bases (the two vectors must have one length)", b1->n, b2->n);
+    if (n > b1->n) return fail("msm: %zu scalars for %zu bases", n, b1->n);
+    std::lock_guard<std::mutex> lk1(b1->mu), lk2(b2->mu);      // always G1 before G2: no cycle
+    CHK(msm_work_prepare(&b1->w, std::max<size_t>(b1->n, 1), b1->c_forced, FpF::W16));
+    CHK(msm_work_prepare(&b2->w, std::max<size_t>(b2->n, 1), b1->w.c, Fp2F::W16));      // the G1 handle's window size for both
+    if (n) HIPCHK(hipMemcpyAsync(b1->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
+    MsmArgs a;
+    CHK(msm_sort_dev(&b1->w, b1->w.scalars, n, flags, nullptr, nullptr, &a));
+    CHK(msm_sum_dev<FpF>(&b1->w, b1->d_points, a, nullptr));
+    CHK(msm_sum_dev<Fp2F>(&b2->w, b2->d_points, a, nullptr));      // same sort, same window geometry, its own bucket planes
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    if (msm_scalar_error(&b1->w)) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
+    const hfp::AffH<hfp::HFp> r1 = msm_host_tail<hfp::HFp>(&b1->w);
+    const hfp::AffH<hfp::HFp2> r2 = msm_host_tail<hfp::HFp2>(&b2->w);
+    memcpy(out_g1, &r1, sizeof r1);
+    memcpy(out_g2, &r2, sizeof r2);
     return 0;
 }
 

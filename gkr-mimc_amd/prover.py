@@ -109,6 +109,7 @@ ABI = {
     "gkrhip_g2_bases_read": (_I, [_P, _P, _SZ, _SZ]),
     "gkrhip_g2_bases_destroy": (None, [_P]),
     "gkrhip_msm_g2": (_I, [_P, _P, _P, _SZ, _I]),
+    "gkrhip_msm_g1_g2": (_I, [_P, _P, _P, _P, _P, _SZ, _I]),
     "gkrhip_msm_g2_once": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_msm_g2_set_window": (_I, [_P, _I]),
     "gkrhip_g2_batch_scalar_mul": (_I, [_P, _P, _P, _SZ, _I]),
@@ -736,6 +737,16 @@ def _multi_exp(group, words, points, scalars, scalars_mont):
     _check(getattr(load(), "gkrhip_msm_%s_once" % group)(_ptr(out), _ptr(points) if n else None, _ptr(scalars) if n else None, n,
                                                           MSM_SCALARS_MONT if scalars_mont else 0))
     return out
+
+
+def multi_exp_g1_g2(g1_bases, g2_bases, scalars, scalars_mont=False):
+    """bs1.MultiExp(pk.G1.B, wireValuesB) and Bs.MultiExp(pk.G2.B, wireValuesB) (prove.go:189,277) in one call: the two sums share
+    the upload, the decoding and the sort of the scalars.  Returns (G1 affine image, G2 affine image)."""
+    scalars = _fr(scalars) if len(scalars) else np.zeros((0, 4), dtype=np.uint64)
+    o1, o2 = np.zeros(8, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+    _check(load().gkrhip_msm_g1_g2(_ptr(o1), _ptr(o2), g1_bases._h, g2_bases._h, _ptr(scalars) if scalars.shape[0] else None,
+                                   scalars.shape[0], MSM_SCALARS_MONT if scalars_mont else 0))
+    return o1, o2
 
 
 def multi_exp_g1(points, scalars, scalars_mont=False):

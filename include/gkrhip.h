@@ -317,6 +317,11 @@ int gkrhip_g2_bases_read(const gkrhip_g2_bases *b, uint64_t *out /* count x 16 *
 void gkrhip_g2_bases_destroy(gkrhip_g2_bases *b);
 int gkrhip_msm_g2(uint64_t out_affine[16], gkrhip_g2_bases *b, const uint64_t *scalars /* n x 4 */, size_t n, int flags);
 int gkrhip_msm_g2_once(uint64_t out_affine[16], const uint64_t *points, const uint64_t *scalars, size_t n, int flags);
+/* bs1.MultiExp(pk.G1.B, wireValuesB, cfg) and Bs.MultiExp(pk.G2.B, wireValuesB, cfg) (prove.go:189,277) are over the same scalars:
+ * one upload, one decoding and one sort of the scalars serve both sums.  The two handles must hold the same number of points;
+ * the G1 handle's window size is used for both. */
+int gkrhip_msm_g1_g2(uint64_t out_g1[8], uint64_t out_g2[16], gkrhip_g1_bases *b1, gkrhip_g2_bases *b2,
+                     const uint64_t *scalars /* n x 4 */, size_t n, int flags);
 int gkrhip_msm_g2_set_window(gkrhip_g2_bases *b, int c);
 int gkrhip_g2_batch_scalar_mul(uint64_t *out /* n x 16 */, const uint64_t base[16], const uint64_t *scalars, size_t n, int flags);
 int gkrhip_g2_generator(uint64_t out[16]);      /* gnark-crypto's g2Gen (bn254.Generators), Montgomery image */

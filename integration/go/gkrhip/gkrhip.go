@@ -516,6 +516,17 @@ func (b *G2Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont
 	must(C.gkrhip_msm_g2((*C.uint64_t)(out), b.h, ptr(scalars), C.size_t(len(scalars)), flags))
 }
 
+// MultiExpG1G2 is `bs1.MultiExp(pk.G1.B, wireValuesB, cfg)` and `Bs.MultiExp(pk.G2.B, wireValuesB, cfg)` (prover/gadget/prove.go:189,277)
+// in one call: both sums are over the same scalars, which are uploaded, decoded and sorted once.  outG1 is a *bn254.G1Affine,
+// outG2 a *bn254.G2Affine; the two handles hold the same number of points (both vectors are filtered by pk.InfinityB).
+func MultiExpG1G2(outG1, outG2 unsafe.Pointer, b1 *G1Bases, b2 *G2Bases, scalars []fr.Element, scalarsMont bool) {
+	flags := C.int(0)
+	if scalarsMont {
+		flags = C.GKRHIP_MSM_SCALARS_MONT
+	}
+	must(C.gkrhip_msm_g1_g2((*C.uint64_t)(outG1), (*C.uint64_t)(outG2), b1.h, b2.h, ptr(scalars), C.size_t(len(scalars)), flags))
+}
+
 // ComputeHMultiExp is `h := computeH(a, b, c, domain)` followed by `krs2.MultiExp(pk.G1.Z, h, cfg)` (prover/gadget/prove.go:128,221)
 // in one call with H never leaving the device.  out is a *bn254.G1Affine; h (optional, len = cardinality) also receives H.
 func (b *G1Bases) ComputeHMultiExp(out unsafe.Pointer, a, bb, c []fr.Element, cardinality uint64, h []fr.Element) {

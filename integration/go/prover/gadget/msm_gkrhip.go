@@ -83,3 +83,17 @@ func multiExpG2Jac(res *bn254.G2Jac, points []bn254.G2Affine, scalars []fr.Eleme
 	}
 	res.FromAffine(&aff)
 }
+
+// multiExpG1G2Jac replaces the PAIR `bs1.MultiExp(pk.G1.B, wireValuesB, cfg)` (prove.go:189) and
+// `Bs.MultiExp(pk.G2.B, wireValuesB, cfg)` (prove.go:277): both are over wireValuesB, so one call uploads, decodes and sorts
+// the scalars once and runs both bucket sums on that order.  In ComputeGroth16Proof computeBS1 and computeBS2 then wait on one
+// shared sync.Once around this call instead of issuing an MSM each.
+func multiExpG1G2Jac(res1 *bn254.G1Jac, res2 *bn254.G2Jac, points1 []bn254.G1Affine, points2 []bn254.G2Affine, scalars []fr.Element) {
+	var a1 bn254.G1Affine
+	var a2 bn254.G2Affine
+	if len(scalars) > 0 {
+		gkrhip.MultiExpG1G2(unsafe.Pointer(&a1), unsafe.Pointer(&a2), g1BasesOf(points1), g2BasesOf(points2), scalars, false)
+	}
+	res1.FromAffine(&a1)
+	res2.FromAffine(&a2)
+}

@@ -142,3 +142,41 @@ def test_msm_g2_two_level_sort(gk):
         _dlog_check(gk, 1 << 14, 64, cw=14)
     finally:
         gk.set_option("msm_sort_levels", 0)
+
+
+def test_msm_g1_g2_pair_shares_the_sort(gk):
+    """bs1 and Bs of prove.go:189,277 run over the same scalars: gkrhip_msm_g1_g2 gives exactly the two separate results (oracle
+    at a small size, the separate calls at 2^16 and with skewed scalars; prefixes; mismatched handles are refused)."""
+    import coracle as c
+    for n, seed, skew in ((0, 1, False), (1, 2, False), (300, 3, False), (1 << 16, 4, False), (1 << 15, 5, True)):
+        rng = np.random.default_rng(seed)
+        k = rng.integers(0, 1 << 63, size=(max(n, 1), 4), dtype=np.uint64)
+        k[:, 3] &= np.uint64((1 << 60) - 1)
+        b1 = gk.G1Bases(base=c.G1_GEN, scalars=k)
+        b2 = gk.G2Bases(base=G2IMG, scalars=k)
+        if skew:
+            r = random.Random(seed)
+            s = ec.scalars_to_image([r.choice([0, 1, 1, 1, 2, Q - 1]) for _ in range(n)])
+        else:
+            s = rand_scalars(random.Random(seed), n)
+        o1, o2 = gk.multi_exp_g1_g2(b1, b2, s[:n])
+        assert o1.tolist() == b1.multi_exp(s[:n]).tolist() and o2.tolist() == b2.multi_exp(s[:n]).tolist(), n
+        if n == 300:
+            assert o1.tolist() == c.g1_msm(b1.read(0, n), s).tolist()
+            tot = sum(x * y for x, y in zip(ints(k), ints(s))) % Q
+            assert o2.tolist() == ec.g2_point_to_image(ec.g2_mul(tot, ec.G2)).tolist()
+            h1, h2 = gk.multi_exp_g1_g2(b1, b2, s[:100])
+            assert h1.tolist() == b1.multi_exp(s[:100]).tolist() and h2.tolist() == b2.multi_exp(s[:100]).tolist()
+            b1.set_window(11)                       # the G1 handle's window serves both
+            p1, p2 = gk.multi_exp_g1_g2(b1, b2, s)
+            assert p1.tolist() == o1.tolist() and p2.tolist() == o2.tolist()
+            b3 = gk.G2Bases(base=G2IMG, scalars=k[:200])
+            with pytest.raises(gk.GkrHipError):
+                gk.multi_exp_g1_g2(b1, b3, s[:100])
+            bad = s.copy()
+            bad[7] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            with pytest.raises(gk.GkrHipError):
+                gk.multi_exp_g1_g2(b1, b2, bad)
+            b3.close()
+        b1.close()
+        b2.close()

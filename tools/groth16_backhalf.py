@@ -53,3 +53,13 @@ for t in ths:
     t.join()
 par = time.perf_counter() - t0
 print("2^%d: one after the other %.1f ms, five host threads at once %.1f ms (uploads of the scalars and of a, b, c included)" % (logn, 1e3 * serial, 1e3 * par))
+# bs1 and Bs share wireValuesB (prove.go:189,277): one upload, one sort
+pair = {k: v for k, v in jobs.items() if not k.startswith(("bs1", "Bs"))}
+pair["bs1 + Bs (pk.G1.B, pk.G2.B), one sort"] = lambda: gk.multi_exp_g1_g2(bases["B1"], b2, wires)
+pair["bs1 + Bs (pk.G1.B, pk.G2.B), one sort"]()
+t_all = time.perf_counter()
+for name, f in pair.items():
+    t0 = time.perf_counter()
+    f()
+    print("%-40s %.2f ms" % (name, 1e3 * (time.perf_counter() - t0)))
+print("2^%d with the paired call: %.1f ms" % (logn, 1e3 * (time.perf_counter() - t_all)))
