@@ -39,6 +39,8 @@ ABI = {
     "gkrhip_build_id": (C.c_char_p, []),
     "gkrhip_device_synchronize": (_I, []),
     "gkrhip_mem_info": (_I, [C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "gkrhip_host_alloc": (_I, [C.POINTER(C.c_void_p), _SZ]),
+    "gkrhip_host_free": (None, [C.c_void_p]),
     "gkrhip_set_option": (_I, [C.c_char_p, C.c_long]),
     "gkrhip_fold": (_I, [_P, _SZ, _P]),
     "gkrhip_evaluate": (_I, [_P, _P, _SZ, _P, _I]),
@@ -188,6 +190,35 @@ def mem_info():
     f, t = C.c_size_t(0), C.c_size_t(0)
     _check(load().gkrhip_mem_info(C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+class PinnedArray:
+    """A (rows, words) uint64 array in page-locked host memory (gkrhip_host_alloc): `.a` is the numpy view; uploads from it are
+    plain DMA transfers.  Keep the object alive while the view is in use; close() (or the context manager) frees the memory."""
+
+    def __init__(self, rows, words=4):
+        self._p = C.c_void_p()
+        _check(load().gkrhip_host_alloc(C.byref(self._p), int(rows) * int(words) * 8))
+        buf = (C.c_uint64 * (max(1, int(rows) * int(words)))).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=np.uint64)[: int(rows) * int(words)].reshape(int(rows), int(words))
+
+    def close(self):
+        if self._p:
+            self.a = None
+            load().gkrhip_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def synchronize():

@@ -67,6 +67,11 @@ const char *gkrhip_version(void);
 const char *gkrhip_build_id(void);
 int gkrhip_device_synchronize(void);      /* waits for every lane's stream */
 int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* Page-locked host memory for vectors handed over on every call (the scalars of an MSM, the a / b / c of computeH, the inputs of a
+ * proof): uploads from these buffers are plain DMA transfers instead of staged copies of pageable memory.  Optional: every
+ * entry point accepts ordinary memory. */
+int gkrhip_host_alloc(void **out, size_t bytes);
+void gkrhip_host_free(void *p);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
  * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
  * "coop", "spec", "spec_lg" -- applied to every existing lane,

@@ -516,6 +516,22 @@ func (b *G2Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont
 	must(C.gkrhip_msm_g2((*C.uint64_t)(out), b.h, ptr(scalars), C.size_t(len(scalars)), flags))
 }
 
+// PinnedElements returns a []fr.Element of length n in page-locked host memory (gkrhip_host_alloc): uploads from it are plain
+// DMA transfers instead of staged copies of pageable memory.  Meant for the vectors handed over on every proof (wireValues and
+// its filtered copies, the a / b / c of computeH).  The memory is not known to Go's collector: release it with FreePinned.
+func PinnedElements(n int) []fr.Element {
+	var p unsafe.Pointer
+	must(C.gkrhip_host_alloc(&p, C.size_t(n)*C.size_t(unsafe.Sizeof(fr.Element{}))))
+	return unsafe.Slice((*fr.Element)(p), n)
+}
+
+// FreePinned releases a slice obtained from PinnedElements.
+func FreePinned(s []fr.Element) {
+	if len(s) > 0 {
+		C.gkrhip_host_free(unsafe.Pointer(&s[0]))
+	}
+}
+
 // MultiExpG1G2 is `bs1.MultiExp(pk.G1.B, wireValuesB, cfg)` and `Bs.MultiExp(pk.G2.B, wireValuesB, cfg)` (prover/gadget/prove.go:189,277)
 // in one call: both sums are over the same scalars, which are uploaded, decoded and sorted once.  outG1 is a *bn254.G1Affine,
 // outG2 a *bn254.G2Affine; the two handles hold the same number of points (both vectors are filtered by pk.InfinityB).

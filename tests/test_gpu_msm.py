@@ -370,3 +370,21 @@ def test_msm_sort_levels_agree_at_the_largest_size(gk):
     finally:
         gk.set_option("msm_sort_levels", 0)
     assert res[1] == res[2] and any(res[1]) and c.g1_on_curve(np.array(res[1], dtype=np.uint64))
+
+
+def test_page_locked_scalars(gk):
+    """gkrhip_host_alloc: the same MSM from page-locked memory (a plain DMA upload) and from pageable memory."""
+    n = 5000
+    rng = random.Random(41)
+    pts = rand_points(41, n)
+    sc = rand_scalars(rng, n)
+    b = gk.G1Bases(points=pts)
+    want = c.g1_msm(pts, sc)
+    with gk.PinnedArray(n, 4) as pin:
+        assert pin.a.shape == (n, 4) and pin.a.dtype == np.uint64
+        pin.a[:] = sc
+        assert b.multi_exp(pin.a).tolist() == want.tolist()
+        assert b.multi_exp(pin.a[:100]).tolist() == c.g1_msm(pts[:100], sc[:100]).tolist()
+    with gk.PinnedArray(0, 4) as empty:
+        assert empty.a.shape == (0, 4)
+    b.close()

@@ -1,5 +1,6 @@
-"""The MSM as the cgo shim calls it: bases resident (uploaded once), scalars from pageable host memory every call
-(gkrhip_msm_g1 / gkrhip_msm_g2).  Wall clock per call, PCIe-inclusive.  python tools/msm_pcie_inclusive.py [logn...]"""
+"""The MSM as the cgo shim calls it: bases resident (uploaded once), scalars from host memory every call (gkrhip_msm_g1 /
+gkrhip_msm_g2) -- pageable memory, and page-locked memory of gkrhip_host_alloc.  Wall clock per call, PCIe-inclusive.
+python tools/msm_pcie_inclusive.py [logn...]"""
 import importlib
 import os
 import sys
@@ -23,13 +24,16 @@ for logn in [int(a) for a in sys.argv[1:]] or [20, 22]:
         t0 = time.perf_counter()
         b = cls(base=base, scalars=k)
         t_gen = time.perf_counter() - t0
-        b.multi_exp(s)
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            b.multi_exp(s)
-            ts.append(time.perf_counter() - t0)
-        ts.sort()
-        print("%s 2^%d: %.2f ms per call incl. the scalars' upload (median of 5; min %.2f) = %.0f M points/s; bases generated on the device in %.0f ms"
-              % (name, logn, 1e3 * ts[2], 1e3 * ts[0], n / ts[2] / 1e6, 1e3 * t_gen))
+        with gk.PinnedArray(n, 4) as pin:
+            pin.a[:] = s
+            for kind, sv in (("pageable", s), ("page-locked", pin.a)):
+                b.multi_exp(sv)
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    b.multi_exp(sv)
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                print("%s 2^%d, %s scalars: %.2f ms per call incl. the upload (median of 5; min %.2f) = %.0f M points/s; bases generated on the device in %.0f ms"
+                      % (name, logn, kind, 1e3 * ts[2], 1e3 * ts[0], n / ts[2] / 1e6, 1e3 * t_gen))
         b.close()
