@@ -1233,7 +1233,19 @@ int gkrhip_msm_g2(uint64_t out_affine[16], gkrhip_g2_bases* b, const uint64_t* s
 int gkrhip_msm_g1_g2(uint64_t out_g1[8], uint64_t out_g2[16], gkrhip_g1_bases* b1, gkrhip_g2_bases* b2, const uint64_t* scalars, size_t n, int flags) {
     if (!out_g1 || !out_g2 || !b1 || !b2 || (n && !scalars)) return fail("msm: null argument");
     LEASE_LANE();
-    return msm_run_pair(b1, b2, scalars, n, flags, out_g1, out_g2);
+    MsmBases* g1[1] = {b1};
+    MsmBases* g2[1] = {b2};
+    return msm_run_shared(g1, 1, g2, 1, scalars, n, flags, out_g1, out_g2);
+}
+int gkrhip_msm_shared(uint64_t* out_g1, uint64_t* out_g2, gkrhip_g1_bases* const* g1, size_t k1, gkrhip_g2_bases* const* g2, size_t k2,
+                      const uint64_t* scalars, size_t n, int flags) {
+    if ((k1 && (!out_g1 || !g1)) || (k2 && (!out_g2 || !g2)) || (n && !scalars)) return fail("msm: null argument");
+    if (k1 + k2 > 64) return fail("msm: %zu handles in one shared call (at most 64)", k1 + k2);
+    LEASE_LANE();
+    std::vector<MsmBases*> a(k1), b(k2);
+    for (size_t i = 0; i < k1; i++) a[i] = g1[i];
+    for (size_t i = 0; i < k2; i++) b[i] = g2[i];
+    return msm_run_shared(a.data(), k1, b.data(), k2, scalars, n, flags, out_g1, out_g2);
 }
 int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t* points, const uint64_t* scalars, size_t n, int flags) {
     gkrhip_g1_bases* b = nullptr;
@@ -1301,7 +1313,7 @@ int gkrhip_compute_h_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* bases_z, co
         const CPlanes hp = t[0].cplanes();
         CHK(msm_dev<FpF>(bases_z, hp.lo, card, 0, nullptr, hp.hi));
         HIPCHK(hipStreamSynchronize(cx().stream));
-        if (msm_scalar_error(&bases_z->w)) return fail("msm: a value of H is not below 2^254");
+        CHK(msm_check_error(&bases_z->w, "a value of H"));
         const hfp::Aff r = msm_host_tail<hfp::HFp>(&bases_z->w);
         memcpy(out_affine, &r, sizeof r);
     }

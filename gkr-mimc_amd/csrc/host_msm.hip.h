@@ -314,7 +314,13 @@ hfp::AffH<HF> msm_host_tail(const MsmWork* w) {
     }
     return hfp::to_affine(acc);
 }
-inline bool msm_scalar_error(const MsmWork* w) { return w->h_wins[(size_t)4 * w->w16 * w->W].x != 0; }      // (2: the big-bucket list overflowed)
+// the device's error word: 0 | 1 (a scalar is not below 2^254) | 2 (a segment or slice list overflowed: excluded by their sizing)
+inline int msm_check_error(const MsmWork* w, const char* what) {
+    const unsigned int e = w->h_wins[(size_t)4 * w->w16 * w->W].x;
+    if (e == 0) return 0;
+    if (e == 1) return fail("msm: %s is not below 2^254 (not a reduced fr.Element)", what);
+    return fail("msm: internal list overflow (error word %u)", e);
+}
 
 int msm_check_points(const uint64_t* points, size_t n, int w16) {
     // every coordinate must be a canonical fp.Element: the lazy range of the kernels starts from values below p
@@ -332,32 +338,54 @@ int msm_run(MsmBases* b, const uint64_t* scalars, size_t n, int flags, uint64_t*
     if (n) HIPCHK(hipMemcpyAsync(b->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
     CHK(msm_dev<F>(b, b->w.scalars, n, flags, nullptr));
     HIPCHK(hipStreamSynchronize(cx().stream));
-    if (msm_scalar_error(&b->w)) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
+    CHK(msm_check_error(&b->w, "a scalar"));
     const hfp::AffH<HF> r = msm_host_tail<HF>(&b->w);
     memcpy(out_affine, &r, sizeof r);        // {X, Y} as consecutive fp.Elements: the G1Affine / G2Affine image
     return 0;
 }
 
-// bs1 = MultiExp(pk.G1.B, wireValuesB) and Bs = MultiExp(pk.G2.B, wireValuesB) (prove.go:189,277) are over the SAME scalars: one
-// upload, one decoding and one sort serve both sums (the sort does not depend on the bases).  Both handles must hold the same
-// number of points (pk.G1.B and pk.G2.B are filtered by the same pk.InfinityB).
-int msm_run_pair(MsmBases* b1, MsmBases* b2, const uint64_t* scalars, size_t n, int flags, uint64_t* out_g1, uint64_t* out_g2) {
-    if (b1->n != b2->n) return fail("msm pair: %zu G1 bases and %zu G2 bases (the two vectors must have one length)", b1->n, b2->n);
-    if (n > b1->n) return fail("msm: %zu scalars for %zu bases", n, b1->n);
-    std::lock_guard<std::mutex> lk1(b1->mu), lk2(b2->mu);      // always G1 before G2: no cycle
-    CHK(msm_work_prepare(&b1->w, std::max<size_t>(b1->n, 1), b1->c_forced, FpF::W16));
-    CHK(msm_work_prepare(&b2->w, std::max<size_t>(b2->n, 1), b1->w.c, Fp2F::W16));      // the G1 handle's window size for both
-    if (n) HIPCHK(hipMemcpyAsync(b1->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
+// Several MSMs over the SAME scalars -- bs1 = MultiExp(pk.G1.B, wireValuesB) and Bs = MultiExp(pk.G2.B, wireValuesB) of
+// prove.go:189,277; with the proving key's vectors expanded by points at infinity where pk.InfinityA / pk.InfinityB filter them,
+// also ar = MultiExp(pk.G1.A, .) of :202 over the unfiltered wireValues -- share one upload, one decoding and one sort: the
+// sort depends on the scalars and the window size only.  Every handle holds the same number of points; the first handle's
+// window size serves all.  out_g1: k1 x 8 words, out_g2: k2 x 16 words.
+int msm_run_shared(MsmBases* const* g1, size_t k1, MsmBases* const* g2, size_t k2, const uint64_t* scalars, size_t n, int flags,
+                   uint64_t* out_g1, uint64_t* out_g2) {
+    std::vector<MsmBases*> all(g1, g1 + k1);
+    all.insert(all.end(), g2, g2 + k2);
+    if (all.empty()) return 0;
+    for (MsmBases* b : all) {
+        if (!b) return fail("msm: null bases handle");
+        if (b->n != all[0]->n) return fail("msm: bases of %zu and %zu points in one shared call (one length required)", all[0]->n, b->n);
+    }
+    for (size_t i = 0; i < k1; i++)
+        if (g1[i]->w16 != FpF::W16) return fail("msm: handle %zu of the G1 list is not a G1 handle", i);
+    for (size_t i = 0; i < k2; i++)
+        if (g2[i]->w16 != Fp2F::W16) return fail("msm: handle %zu of the G2 list is not a G2 handle", i);
+    if (n > all[0]->n) return fail("msm: %zu scalars for %zu bases", n, all[0]->n);
+    std::vector<MsmBases*> order(all);
+    std::sort(order.begin(), order.end());           // one locking order for every caller
+    if (std::adjacent_find(order.begin(), order.end()) != order.end()) return fail("msm: a bases handle appears twice in one shared call");
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (MsmBases* b : order) locks.emplace_back(b->mu);
+    MsmBases* first = all[0];
+    CHK(msm_work_prepare(&first->w, std::max<size_t>(first->n, 1), first->c_forced, first->w16));
+    for (size_t i = 1; i < all.size(); i++) CHK(msm_work_prepare(&all[i]->w, std::max<size_t>(all[i]->n, 1), first->w.c, all[i]->w16));
+    if (n) HIPCHK(hipMemcpyAsync(first->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
     MsmArgs a;
-    CHK(msm_sort_dev(&b1->w, b1->w.scalars, n, flags, nullptr, nullptr, &a));
-    CHK(msm_sum_dev<FpF>(&b1->w, b1->d_points, a, nullptr));
-    CHK(msm_sum_dev<Fp2F>(&b2->w, b2->d_points, a, nullptr));      // same sort, same window geometry, its own bucket planes
+    CHK(msm_sort_dev(&first->w, first->w.scalars, n, flags, nullptr, nullptr, &a));
+    for (size_t i = 0; i < k1; i++) CHK(msm_sum_dev<FpF>(&g1[i]->w, g1[i]->d_points, a, nullptr));      // same sort, same window geometry,
+    for (size_t i = 0; i < k2; i++) CHK(msm_sum_dev<Fp2F>(&g2[i]->w, g2[i]->d_points, a, nullptr));     // its own bucket planes
     HIPCHK(hipStreamSynchronize(cx().stream));
-    if (msm_scalar_error(&b1->w)) return fail("msm: a scalar is not below 2^254 (not a reduced fr.Element)");
-    const hfp::AffH<hfp::HFp> r1 = msm_host_tail<hfp::HFp>(&b1->w);
-    const hfp::AffH<hfp::HFp2> r2 = msm_host_tail<hfp::HFp2>(&b2->w);
-    memcpy(out_g1, &r1, sizeof r1);
-    memcpy(out_g2, &r2, sizeof r2);
+    CHK(msm_check_error(&all.back()->w, "a scalar"));      // the error word is read back with every sum
+    for (size_t i = 0; i < k1; i++) {
+        const hfp::AffH<hfp::HFp> r = msm_host_tail<hfp::HFp>(&g1[i]->w);
+        memcpy(out_g1 + 8 * i, &r, sizeof r);
+    }
+    for (size_t i = 0; i < k2; i++) {
+        const hfp::AffH<hfp::HFp2> r = msm_host_tail<hfp::HFp2>(&g2[i]->w);
+        memcpy(out_g2 + 16 * i, &r, sizeof r);
+    }
     return 0;
 }
 

@@ -112,6 +112,7 @@ ABI = {
     "gkrhip_g2_bases_destroy": (None, [_P]),
     "gkrhip_msm_g2": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_msm_g1_g2": (_I, [_P, _P, _P, _P, _P, _SZ, _I]),
+    "gkrhip_msm_shared": (_I, [_P, _P, _P, _SZ, _P, _SZ, _P, _SZ, _I]),
     "gkrhip_msm_g2_once": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_msm_g2_set_window": (_I, [_P, _I]),
     "gkrhip_g2_batch_scalar_mul": (_I, [_P, _P, _P, _SZ, _I]),
@@ -778,6 +779,19 @@ def multi_exp_g1_g2(g1_bases, g2_bases, scalars, scalars_mont=False):
     _check(load().gkrhip_msm_g1_g2(_ptr(o1), _ptr(o2), g1_bases._h, g2_bases._h, _ptr(scalars) if scalars.shape[0] else None,
                                    scalars.shape[0], MSM_SCALARS_MONT if scalars_mont else 0))
     return o1, o2
+
+
+def multi_exp_shared(g1_bases, g2_bases, scalars, scalars_mont=False):
+    """Several MSMs over one scalar vector (gkrhip_msm_shared): one upload, one sort.  g1_bases / g2_bases: lists of handles of
+    equal length.  Returns (list of G1 affine images, list of G2 affine images)."""
+    scalars = _fr(scalars) if len(scalars) else np.zeros((0, 4), dtype=np.uint64)
+    k1, k2 = len(g1_bases), len(g2_bases)
+    o1, o2 = np.zeros((max(k1, 1), 8), dtype=np.uint64), np.zeros((max(k2, 1), 16), dtype=np.uint64)
+    h1 = (C.c_void_p * max(k1, 1))(*[b._h for b in g1_bases])
+    h2 = (C.c_void_p * max(k2, 1))(*[b._h for b in g2_bases])
+    _check(load().gkrhip_msm_shared(_ptr(o1), _ptr(o2), h1, k1, h2, k2, _ptr(scalars) if scalars.shape[0] else None, scalars.shape[0],
+                                    MSM_SCALARS_MONT if scalars_mont else 0))
+    return [o1[i] for i in range(k1)], [o2[i] for i in range(k2)]
 
 
 def multi_exp_g1(points, scalars, scalars_mont=False):

@@ -327,6 +327,11 @@ int gkrhip_msm_g2_once(uint64_t out_affine[16], const uint64_t *points, const ui
  * the G1 handle's window size is used for both. */
 int gkrhip_msm_g1_g2(uint64_t out_g1[8], uint64_t out_g2[16], gkrhip_g1_bases *b1, gkrhip_g2_bases *b2,
                      const uint64_t *scalars /* n x 4 */, size_t n, int flags);
+/* The general form: k1 G1 sums (out_g1: k1 x 8) and k2 G2 sums (out_g2: k2 x 16) over one scalar vector.  With the proving key's
+ * vectors expanded by points at infinity where pk.InfinityA / pk.InfinityB drop wires (prove.go:136-160), ar (:202), bs1 (:189) and
+ * Bs (:277) all run over the unfiltered wireValues and share its upload and sort.  A point at infinity (0, 0) adds nothing. */
+int gkrhip_msm_shared(uint64_t *out_g1, uint64_t *out_g2, gkrhip_g1_bases *const *g1, size_t k1, gkrhip_g2_bases *const *g2, size_t k2,
+                      const uint64_t *scalars /* n x 4 */, size_t n, int flags);
 int gkrhip_msm_g2_set_window(gkrhip_g2_bases *b, int c);
 int gkrhip_g2_batch_scalar_mul(uint64_t *out /* n x 16 */, const uint64_t base[16], const uint64_t *scalars, size_t n, int flags);
 int gkrhip_g2_generator(uint64_t out[16]);      /* gnark-crypto's g2Gen (bn254.Generators), Montgomery image */

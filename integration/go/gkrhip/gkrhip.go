@@ -516,6 +516,39 @@ func (b *G2Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont
 	must(C.gkrhip_msm_g2((*C.uint64_t)(out), b.h, ptr(scalars), C.size_t(len(scalars)), flags))
 }
 
+// MultiExpShared runs len(g1) G1 sums and len(g2) G2 sums over ONE scalar vector (gkrhip_msm_shared): one upload, one sort.
+// outG1[i] is a *bn254.G1Affine, outG2[i] a *bn254.G2Affine.  Every handle holds the same number of points; vectors that the
+// proving key stores filtered (pk.G1.A by pk.InfinityA, pk.G1.B / pk.G2.B by pk.InfinityB) are uploaded expanded, with the
+// point at infinity at the dropped positions, so that all of them line up with the unfiltered wireValues.
+func MultiExpShared(outG1 []unsafe.Pointer, g1 []*G1Bases, outG2 []unsafe.Pointer, g2 []*G2Bases, scalars []fr.Element) {
+	h1 := make([]*C.gkrhip_g1_bases, len(g1))
+	h2 := make([]*C.gkrhip_g2_bases, len(g2))
+	o1 := make([]C.uint64_t, 8*len(g1))
+	o2 := make([]C.uint64_t, 16*len(g2))
+	for i, b := range g1 {
+		h1[i] = b.h
+	}
+	for i, b := range g2 {
+		h2[i] = b.h
+	}
+	var p1 **C.gkrhip_g1_bases
+	var p2 **C.gkrhip_g2_bases
+	var q1, q2 *C.uint64_t
+	if len(g1) > 0 {
+		p1, q1 = &h1[0], &o1[0]
+	}
+	if len(g2) > 0 {
+		p2, q2 = &h2[0], &o2[0]
+	}
+	must(C.gkrhip_msm_shared(q1, q2, p1, C.size_t(len(g1)), p2, C.size_t(len(g2)), ptr(scalars), C.size_t(len(scalars)), 0))
+	for i := range g1 {
+		copy(unsafe.Slice((*C.uint64_t)(outG1[i]), 8), o1[8*i:8*i+8])
+	}
+	for i := range g2 {
+		copy(unsafe.Slice((*C.uint64_t)(outG2[i]), 16), o2[16*i:16*i+16])
+	}
+}
+
 // PinnedElements returns a []fr.Element of length n in page-locked host memory (gkrhip_host_alloc): uploads from it are plain
 // DMA transfers instead of staged copies of pageable memory.  Meant for the vectors handed over on every proof (wireValues and
 // its filtered copies, the a / b / c of computeH).  The memory is not known to Go's collector: release it with FreePinned.

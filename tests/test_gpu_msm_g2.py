@@ -180,3 +180,43 @@ def test_msm_g1_g2_pair_shares_the_sort(gk):
             b3.close()
         b1.close()
         b2.close()
+
+
+def test_msm_shared_over_unfiltered_wires(gk):
+    """gkrhip_msm_shared: ar, bs1 (G1) and Bs (G2) over the UNFILTERED wire vector, the key's vectors expanded with points at
+    infinity where pk.InfinityA / pk.InfinityB drop wires (prove.go:136-160): one sort serves the three sums, and each equals
+    the reference's filtered MSM."""
+    import coracle as c
+    n = 3000
+    rng = np.random.default_rng(90)
+    k = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    pa = c.g1_batch_scalar_mul(c.G1_GEN, k)
+    pb1 = pa.copy()
+    pb2 = gk.batch_scalar_multiplication_g2(G2IMG, k)
+    inf_a = rng.random(n) < 0.1
+    inf_b = rng.random(n) < 0.3
+    pa[inf_a] = 0
+    pb1[inf_b] = 0
+    pb2[inf_b] = 0
+    wires = rand_scalars(random.Random(90), n)
+    ba, bb1, bb2 = gk.G1Bases(points=pa), gk.G1Bases(points=pb1), gk.G2Bases(points=pb2)
+    (ar, bs1), (bs2,) = gk.multi_exp_shared([ba, bb1], [bb2], wires)
+    # the reference's calls: filtered bases, filtered scalars
+    assert ar.tolist() == c.g1_msm(pa[~inf_a], wires[~inf_a]).tolist()
+    assert bs1.tolist() == c.g1_msm(pb1[~inf_b], wires[~inf_b]).tolist()
+    tot = sum(x * y for x, y, dead in zip(ints(k), ints(wires), inf_b) if not dead) % Q
+    assert bs2.tolist() == ec.g2_point_to_image(ec.g2_mul(tot, ec.G2)).tolist()
+    assert bs2.tolist() == bb2.multi_exp(wires).tolist()
+    # G1 only, G2 only, nothing; a handle twice and a G2 handle in the G1 list are refused
+    (x,), none = gk.multi_exp_shared([ba], [], wires)
+    assert x.tolist() == ar.tolist() and none == []
+    none, (y,) = gk.multi_exp_shared([], [bb2], wires[:100])
+    assert y.tolist() == bb2.multi_exp(wires[:100]).tolist()
+    assert gk.multi_exp_shared([], [], wires) == ([], [])
+    with pytest.raises(gk.GkrHipError, match="twice"):
+        gk.multi_exp_shared([ba, ba], [], wires)
+    with pytest.raises(gk.GkrHipError, match="not a G1 handle"):
+        gk.multi_exp_shared([bb2], [], wires)
+    for b in (ba, bb1, bb2):
+        b.close()

@@ -82,6 +82,12 @@ for name, f in pinned.items():
     f()
     print("%-40s %.2f ms (page-locked inputs)" % (name, 1e3 * (time.perf_counter() - t0)))
 serial = time.perf_counter() - t_all
+# ar too on the shared sort (pk.G1.A expanded with points at infinity so that it lines up with the unfiltered wireValues)
+shared3 = lambda: gk.multi_exp_shared([bases["A"], bases["B1"]], [b2], pw)      # noqa: E731
+shared3()
+t0 = time.perf_counter()
+shared3()
+print("%-40s %.2f ms (page-locked inputs)" % ("ar + bs1 + Bs, one sort", 1e3 * (time.perf_counter() - t0)))
 ths = [threading.Thread(target=f) for f in pinned.values()]
 t0 = time.perf_counter()
 for t in ths:
