@@ -76,7 +76,7 @@ void gkrhip_host_free(void *p);
  * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
  * "coop", "spec", "spec_lg" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
- * gkrhip_init) */
+ * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums) */
 int gkrhip_set_option(const char *key, long value);
 
 /* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
