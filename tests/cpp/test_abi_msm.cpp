@@ -83,6 +83,41 @@ int main() {
         rc = gkrhip_msm_g1(got, b, more.data(), n + 1, 0);
         if (rc > -16 || gkrhip_last_error_r(rc, buf, sizeof buf) == 0 || !strstr(buf, "scalars for")) { printf("FAIL error path 2: %d %s\n", rc, buf); fails++; }
     }
+    // the scalars shared by several sums (bs1 and Bs of prove.go:189,277; with expanded key vectors also ar of :202): one call,
+    // scalars in page-locked memory of gkrhip_host_alloc; every result equals the separate call's
+    {
+        uint64_t G2[16];
+        if (gkrhip_g2_generator(G2) != 0) fails++;
+        gkrhip_g2_bases* b2 = nullptr;
+        gkrhip_g1_bases* ba = nullptr;
+        std::vector<uint64_t> pa(pts);
+        for (size_t i = 0; i < n; i += 7) memset(&pa[8 * i], 0, 64);          // pk.InfinityA-like holes
+        if (gkrhip_g2_bases_generate(&b2, G2, k.data(), n, 0) != 0 || gkrhip_g1_bases_create(&ba, pa.data(), n) != 0) { printf("FAIL bases for the shared call\n"); fails++; }
+        void* pin = nullptr;
+        if (gkrhip_host_alloc(&pin, 32 * n) != 0 || !pin) { printf("FAIL host_alloc: %s\n", gkrhip_last_error()); fails++; }
+        else {
+            memcpy(pin, s.data(), 32 * n);
+            const uint64_t* ps = (const uint64_t*)pin;
+            uint64_t w1[8], w2[16], wa[8], r1[8], r2[16], o1[16], o2[16];
+            oracle_g1_msm(wa, pa.data(), s.data(), n);
+            if (gkrhip_msm_g1(w1, b, ps, n, 0) != 0 || memcmp(w1, want, 64)) { printf("FAIL msm_g1 from page-locked scalars\n"); fails++; }
+            if (gkrhip_msm_g2(w2, b2, ps, n, 0) != 0) { printf("FAIL msm_g2\n"); fails++; }
+            if (gkrhip_msm_g1_g2(r1, r2, b, b2, ps, n, 0) != 0 || memcmp(r1, want, 64) || memcmp(r2, w2, 128)) { printf("FAIL msm_g1_g2\n"); fails++; }
+            gkrhip_g1_bases* g1s[2] = {ba, b};
+            gkrhip_g2_bases* g2s[1] = {b2};
+            if (gkrhip_msm_shared(o1, o2, g1s, 2, g2s, 1, ps, n, 0) != 0 || memcmp(o1, wa, 64) || memcmp(o1 + 8, want, 64) || memcmp(o2, w2, 128)) {
+                printf("FAIL msm_shared: %s\n", gkrhip_last_error());
+                fails++;
+            }
+            gkrhip_g1_bases* twice[2] = {b, b};
+            char buf[256];
+            const int rc = gkrhip_msm_shared(o1, o2, twice, 2, nullptr, 0, ps, n, 0);
+            if (rc > -16 || gkrhip_last_error_r(rc, buf, sizeof buf) == 0 || !strstr(buf, "twice")) { printf("FAIL shared error path: %d %s\n", rc, buf); fails++; }
+            gkrhip_host_free(pin);
+        }
+        gkrhip_g1_bases_destroy(ba);
+        gkrhip_g2_bases_destroy(b2);
+    }
     gkrhip_g1_bases_destroy(b);
     printf("abi-msm fails=%d\n", fails);
     return fails ? 1 : 0;
