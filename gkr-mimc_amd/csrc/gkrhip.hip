@@ -324,7 +324,10 @@ int gkrhip_set_option(const char* key, long value) {
     return for_each_lane([&](Ctx* l) {
         if (!strcmp(key, "fold_grid")) l->fold_grid = (int)std::max(64L, value);
         else if (!strcmp(key, "fold_split")) l->fold_split = value != 0;
-        else if (!strcmp(key, "g_max")) l->g_max = (int)std::max(8L, std::min(20L, value));
+        else if (!strcmp(key, "g_max")) {
+            l->g_max = (int)std::max(8L, std::min(20L, value));
+            l->g_max_auto = false;
+        }
         else if (!strcmp(key, "lat_mode")) l->lat_mode = (int)value;
         else if (!strcmp(key, "wide_mode")) l->wide_mode = (int)value;
         else if (!strcmp(key, "wt_late_lj")) l->wt_late_lj = (int)value;

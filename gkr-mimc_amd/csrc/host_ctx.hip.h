@@ -103,7 +103,8 @@ struct Ctx {
     unsigned int* d_flag = nullptr;
     unsigned int* d_counter = nullptr;         // block arrival counter
     unsigned int seq = 0;
-    int g_max = 16;                            // log2(max threads of the round kernel): 16 measured best with 4 proofs in flight (17 for one proof alone)
+    int g_max = 16;                            // log2(max threads of a round kernel) ...
+    bool g_max_auto = true;                    // ... chosen per layer from the proofs in flight (round_threads_log2_max) unless GKRHIP_GMAX / "g_max" set it
     bool force_generic = false;
     bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
@@ -144,7 +145,7 @@ struct Ctx {
     E spec_pts[8];                             // Montgomery forms of the candidate points 0..7
     E spec_invden[8];                          // 1 / prod_{j != i} (i - j): Lagrange denominators on the points 0..7
     int pre_start_lg = 16;                     // the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
-    hipStream_t aux = nullptr;                 // low-priority stream of the look-ahead kernel
+    hipStream_t aux = nullptr;                 // stream of the look-ahead kernel (normal priority: see pre_prepare)
     hipEvent_t pre_done = nullptr;
     DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()
     const uint4* pre_K = nullptr;              // what pre_t was computed from (valid when pre_K != nullptr)
@@ -224,6 +225,13 @@ struct Waiter {                                 // one per wait: call step() in 
         }
     }
 };
+// log2 of the threads a round kernel may use.  Measured (profiles/r04_gmax_by_lanes.txt): 2^16 (one workgroup per CU) with a few
+// proofs in flight (bN = 24, five: 84.7 M hashes/s against 81.9 with 2^15), 2^15 with many (bN = 20, 24 in flight: 57.8 against
+// 54.4; GMiMC bN = 22, 12 in flight: 101.9 against 97.3): the more lanes, the more the other lanes' kernels fill the CUs.
+inline int round_threads_log2_max() {
+    if (!cx().g_max_auto) return cx().g_max;
+    return g_proofs_in_flight.load(std::memory_order_relaxed) >= 10 ? 15 : 16;
+}
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
     ~ProofInFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -323,7 +331,10 @@ int ctx_init(int dev) {
         return fail("device %d is %s; libgkrhip is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
     cx().n_cu = prop.multiProcessorCount;
     cx().max_grid = cx().n_cu * 32;   // streaming kernels: 8192 workgroups measured best for the fold (profiles/)
-    if (const char* e = getenv("GKRHIP_GMAX")) cx().g_max = std::max(0, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_GMAX")) {
+        cx().g_max = std::max(0, std::min(20, atoi(e)));
+        cx().g_max_auto = false;
+    }
     if (const char* e = getenv("GKRHIP_GENERIC")) cx().force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) cx().lat_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WIDE")) cx().wide_mode = atoi(e);
@@ -453,6 +464,7 @@ void lane_configure(Ctx* l) {
     l->fold_grid = g0.fold_grid;
     l->fold_split = g0.fold_split;
     l->g_max = g0.g_max;
+    l->g_max_auto = g0.g_max_auto;
     l->force_generic = g0.force_generic;
     l->lat_mode = g0.lat_mode;
     l->wide_mode = g0.wide_mode;

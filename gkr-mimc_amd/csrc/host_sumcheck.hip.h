@@ -184,9 +184,12 @@ int pre_prepare() {
     if (!cx().req_K || !cx().req_S || cx().req_m < 2) return 0;
     const size_t P = (size_t)1 << (cx().req_m - 1);
     if (!cx().aux) {
-        int least = 0, greatest = 0;               // lowest priority: the look-ahead kernel must never delay a round kernel
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&cx().aux, hipStreamNonBlocking, least));
+        // NORMAL priority.  The stream used to have the lowest priority (the look-ahead kernel must not delay a round kernel; its
+        // LDS request caps it at two workgroups per CU anyway) -- and with a dozen lanes forced to use it, behind pre-launched
+        // kernels spinning for their challenges, 4 % of the proofs were wrong (57 of 1 440 at bN = 18; 0 of 1 440 at normal or high
+        // priority, 0 with the products computed but not consumed): kernels of a lowest-priority queue that the other queues' work
+        // keeps displacing did not always leave complete output.  One proof alone: 277.6 ms against 275.1 at bN = 24.
+        HIPCHK(hipStreamCreateWithFlags(&cx().aux, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
     }
     for (auto& t : cx().pre_t)
@@ -502,7 +505,7 @@ struct CipherLoop {
     // the loop's state
     const size_t n;
     RoundPlan pl;
-    int g_big = 0, gsplit[2] = {0, 0};
+    int g_m = 16, g_big = 0, gsplit[2] = {0, 0};
     ScopedTable pyrT, pyrH, pyrU[2], pyrU2[2], ks, ss, ks2, ss2;      // pyrU[0]: split at g_max threads, pyrU[1]: at g_big; pyrU2: times 2^-128; (ks2, ss2): the speculative launches alternate between (ks, ss) and these
     ChalGuard chal_guard;
     std::vector<unsigned int> spec_seq;              // by round
@@ -523,7 +526,7 @@ struct CipherLoop {
     // have two pairs per lane, and runs the round with 2^g_big pairs one pair per lane (two waves per SIMD).
     int threads_log2(int k) const {
         const int rem = m - 1 - k;                     // log2(pairs of the round)
-        return rem >= g_big ? g_big : std::min(cx().g_max, rem);
+        return rem >= g_big ? g_big : std::min(g_m, rem);
     }
     volatile unsigned int* spec_flag(int k) const {
         return (volatile unsigned int*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS + GKR_SPEC_FLAG_WORD);
@@ -533,10 +536,11 @@ struct CipherLoop {
     int setup() {
         const bool solo = cx().solo_boost && !collective &&
                           (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
-        g_big = solo ? std::min(cx().g_max + 1, 17) : cx().g_max;
-        const int gT = std::max(threads_log2(0), std::min(cx().g_max, m - 1));   // highest level of the per-lane pyramid
+        g_m = round_threads_log2_max();                // fixed for the layer: the number of proofs in flight may change under it
+        g_big = solo ? std::min(g_m + 1, 17) : g_m;
+        const int gT = std::max(threads_log2(0), std::min(g_m, m - 1));   // highest level of the per-lane pyramid
         CHK(stage_coords(q, (size_t)m));
-        gsplit[0] = std::min(cx().g_max, m - 1);
+        gsplit[0] = std::min(g_m, m - 1);
         gsplit[1] = g_big;
         CHK(table_alloc(&pyrT, (size_t)2 << gT));
         CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
@@ -1000,7 +1004,7 @@ struct LinearLoop {
         }
     }
     int setup() {
-        g_lin = cx().g_max;
+        g_lin = round_threads_log2_max();
         const int gT = std::min(g_lin, m - 1);
         const int mU = m - 1 - gT;
         CHK(stage_coords(q, (size_t)m));

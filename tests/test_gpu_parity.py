@@ -1232,6 +1232,22 @@ def test_soak_one_proof_at_a_time(gk):
     assert all(v > 0 for v in counts.values()), counts
 
 
+def test_twelve_lanes_of_one_size_with_the_solo_paths_forced_on(gk):
+    """Twelve lanes proving bN = 18 at once with the look-ahead kernel and the pre-launched rounds forced on, for the thread caps
+    2^15 (the library's choice from ten proofs in flight) and 2^16: the load under which the look-ahead kernel's former
+    lowest-priority stream left incomplete products (4 % wrong proofs, tools/stress_one_size.py); now every proof is byte-equal."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gmax in ("15", "16", None):
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRE="2", GKRHIP_COOP="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC="0")
+        if gmax:
+            env["GKRHIP_GMAX"] = gmax
+        for rep in range(2):
+            out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_one_size.py"), "18", "12", "20"], capture_output=True,
+                                 text=True, timeout=600, env=env)
+            assert out.returncode == 0 and "mismatches (lane, proof, last differing row): []" in out.stdout, (gmax, rep, out.stdout + out.stderr)
+
+
 def test_soak_lanes_with_the_solo_paths_forced_on(gk):
     """The same soak with the round-3 serial-latency paths forced on for EVERY lane (pre-launched rounds polling their
     challenge, look-ahead kernels on second streams, the cooperative kernel): many spinning kernels, look-ahead launches and
