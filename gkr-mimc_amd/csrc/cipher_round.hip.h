@@ -596,11 +596,12 @@ struct CipherPreArgs {
     size_t P;
     Fr ark;
 };
-// The launch asks for GKR_PRE_LDS bytes of (unused) dynamic LDS so that at most two of its workgroups share a CU: two
-// waves per SIMD are enough for its VALU-bound chains, and the round kernels of the proof (up to 243 VGPRs, 21 KB of LDS)
-// always find room beside it.  Without the cap its small waves refill every slot a finished wave frees and the
-// 243-VGPR round kernel starves until the look-ahead is done (measured: the whole gain lost).
-#define GKR_PRE_LDS (60 * 1024)
+// The launch asks for GKR_PRE_LDS bytes of (unused) dynamic LDS so that ONE of its workgroups fits a CU, beside one workgroup
+// of a round kernel (up to 243 VGPRs, 54.5 KB of LDS): without a cap its small waves refill every slot a finished wave frees
+// and the round kernels of the proof starve until the look-ahead is done (measured: the whole gain lost).  The kernel's stream
+// has normal priority (host_sumcheck.hip.h: a lowest-priority stream left incomplete products under load); one proof alone at
+// bN = 24 with 60 KB (two workgroups per CU) / 100 KB: 279.5 / 272.4 ms (lowest priority and 60 KB, as it was: 275.1).
+#define GKR_PRE_LDS (100 * 1024)
 __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_pre(CipherPreArgs a) {
     const size_t P = a.P;
     const Fr negark = fr_sub(fr_zero(), a.ark);

@@ -214,7 +214,11 @@ int launch_pre() {
     for (int i = 0; i < 6; i++) a.out[i] = cx().pre_t[i].planes();
     a.P = P;
     a.ark = to_dev(cx().req_ark);
-    // (GKR_PRE_LDS bytes of unused dynamic LDS cap the look-ahead kernel at two workgroups per CU: it must not crowd out the round kernels)
+    // (GKR_PRE_LDS bytes of unused dynamic LDS cap the look-ahead kernel at one workgroup per CU: it must not crowd out the round kernels)
+    {
+        static std::once_flag once;       // more than 64 KiB of dynamic LDS needs the attribute
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)k_cipher_pre, hipFuncAttributeMaxDynamicSharedMemorySize, GKR_PRE_LDS); });
+    }
     hipLaunchKernelGGL(k_cipher_pre, dim3(grid_for(P, 1 << 20)), dim3(GKR_BLOCK), (size_t)GKR_PRE_LDS, cx().aux, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(cx().pre_done, cx().aux));
