@@ -904,7 +904,7 @@ def main():
         # The Groth16 pieces of SURVEY 8 f4 on device-resident synthetic data: the G1 multi-scalar multiplication
         # (gnark-crypto's MultiExp at prover/gadget/prove.go:76,91,189,202,221) and computeH (prove.go:308-359)
         lp = loops.get("msm_accumulate")
-        for lg in (20, 22):
+        for lg in (20, 22, 24):
             r = gk.bench_msm_g1(lg, warmup=1, iters=3)
             nwin = -(-255 // r["c"])
             madds = float(nwin) * (1 << lg)          # one mixed addition per scalar and window (zero digits are 2^-c of them)
