@@ -899,12 +899,17 @@ __device__ __forceinline__ XyzzT<F> ecx_mul_small(const XyzzT<F>& p, unsigned in
     return r;
 }
 // lane (j, ci): buckets [ci * chunk, (ci + 1) * chunk) of window j from the top down: running = sum B, acc = sum of the
-// running sums = sum (b - b0 + 1) B_b; the chunk's share of the window sum is acc + b0 * running
+// running sums = sum (b - b0 + 1) B_b; the chunk's share of the window sum is acc + b0 * running.  When the chunks of a window
+// fill whole workgroups (every window size from 2^11 buckets up) the workgroup sums its lanes' shares at once (LDS tree) and
+// k_msm_reduce_windows is left with a handful of terms per window instead of sixteen additions in a row per lane: the window
+// sums are a CHAIN of group operations on one lane (~9 us each with one wave per SIMD), 62 of them before, 50 now.
 template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_reduce_chunks(MsmArgs a) {
+    __shared__ XyzzShared<F> sh;
     const unsigned int nchunk = a.nb / a.chunk;
+    const bool fused = nchunk % GKR_BLOCK == 0;         // uniform over the launch
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)a.W * nchunk) return;
+    if (!fused && g >= (size_t)a.W * nchunk) return;
     const unsigned int j = (unsigned int)(g / nchunk), ci = (unsigned int)(g % nchunk);
     const unsigned int b0 = ci * a.chunk;
     XyzzT<F> running, acc;
@@ -915,17 +920,23 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_reduce_chunks(MsmArgs a) {
         ecx_add(acc, running);
     }
     if (b0) ecx_add(acc, ecx_mul_small(running, b0));
-    ecx_st<F>(a.parts, g, acc);
+    if (!fused) {
+        ecx_st<F>(a.parts, g, acc);
+        return;
+    }
+    ecx_block_reduce(sh, acc);
+    if (threadIdx.x == 0) ecx_st<F>(a.parts, blockIdx.x, sh.p[0]);
 }
-// one workgroup per window: the sum of its chunk results
+// one workgroup per window: the sum of its chunk results (of its workgroups' results when k_msm_reduce_chunks summed them)
 template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK) k_msm_reduce_windows(MsmArgs a) {
     __shared__ XyzzShared<F> sh;
     const unsigned int nchunk = a.nb / a.chunk;
+    const unsigned int per = nchunk % GKR_BLOCK == 0 ? nchunk / GKR_BLOCK : nchunk;
     const unsigned int j = blockIdx.x;
     XyzzT<F> acc;
     ecx_set_inf(acc);
-    for (unsigned int ci = threadIdx.x; ci < nchunk; ci += GKR_BLOCK) ecx_add(acc, ecx_ld<F>(a.parts, (size_t)j * nchunk + ci));
+    for (unsigned int ci = threadIdx.x; ci < per; ci += GKR_BLOCK) ecx_add(acc, ecx_ld<F>(a.parts, (size_t)j * per + ci));
     ecx_block_reduce(sh, acc);
     if (threadIdx.x == 0) ecx_st<F>(a.wins, j, sh.p[0]);
 }
