@@ -1246,6 +1246,11 @@ def test_twelve_lanes_of_one_size_with_the_solo_paths_forced_on(gk):
             out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_one_size.py"), "18", "12", "20"], capture_output=True,
                                  text=True, timeout=600, env=env)
             assert out.returncode == 0 and "mismatches (lane, proof, last differing row): []" in out.stdout, (gmax, rep, out.stdout + out.stderr)
+    # the same load with the library's own choices (no path forced), and twenty-four lanes of the size of BASELINE config 2
+    for bn, lanes, per in (("18", "12", "20"), ("20", "24", "6")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_one_size.py"), bn, lanes, per], capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0 and "mismatches (lane, proof, last differing row): []" in out.stdout, (bn, out.stdout + out.stderr)
 
 
 def test_soak_lanes_with_the_solo_paths_forced_on(gk):
