@@ -45,13 +45,25 @@ for name, f in jobs.items():
     f()
     print("%-28s %.2f ms" % (name, 1e3 * (time.perf_counter() - t0)))
 serial = time.perf_counter() - t_all
-ths = [threading.Thread(target=f) for f in jobs.values()]
-t0 = time.perf_counter()
-for t in ths:
-    t.start()
-for t in ths:
-    t.join()
-par = time.perf_counter() - t0
+
+
+def at_once(fs):
+    """wall time of the calls from one host thread each; the first round creates the lanes the calls lease (untimed)"""
+    best = None
+    for _ in range(3):
+        ths = [threading.Thread(target=f) for f in fs]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        if _:                       # rounds 1 and 2 count
+            best = dt if best is None else min(best, dt)
+    return best
+
+
+par = at_once(list(jobs.values()))
 print("2^%d: one after the other %.1f ms, five host threads at once %.1f ms (uploads of the scalars and of a, b, c included)" % (logn, 1e3 * serial, 1e3 * par))
 # bs1 and Bs share wireValuesB (prove.go:189,277): one upload, one sort
 pair = {k: v for k, v in jobs.items() if not k.startswith(("bs1", "Bs"))}
@@ -88,10 +100,7 @@ shared3()
 t0 = time.perf_counter()
 shared3()
 print("%-40s %.2f ms (page-locked inputs)" % ("ar + bs1 + Bs, one sort", 1e3 * (time.perf_counter() - t0)))
-ths = [threading.Thread(target=f) for f in pinned.values()]
-t0 = time.perf_counter()
-for t in ths:
-    t.start()
-for t in ths:
-    t.join()
-print("2^%d, paired call, page-locked inputs: one after the other %.1f ms, four host threads at once %.1f ms" % (logn, 1e3 * serial, 1e3 * (time.perf_counter() - t0)))
+par = at_once(list(pinned.values()))
+print("2^%d, paired call, page-locked inputs: one after the other %.1f ms, four host threads at once %.1f ms" % (logn, 1e3 * serial, 1e3 * par))
+par3 = at_once([pinned["computeH + krs2 (pk.G1.Z)"], pinned["krs (pk.privKNotGkr)"], shared3])
+print("2^%d, ar + bs1 + Bs on one sort, page-locked inputs, three host threads at once: %.1f ms" % (logn, 1e3 * par3))
