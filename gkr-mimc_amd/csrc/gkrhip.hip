@@ -353,6 +353,29 @@ int gkrhip_mem_info(size_t* free_bytes, size_t* total_bytes) {
     return 0;
 }
 
+// Lanes (stream, hand-off buffers, accumulators: ~3 ms to create) are leased per call from a pool that grows on demand: the first
+// burst of concurrent calls -- the goroutines of ComputeGroth16Proof -- would pay for its lanes (12 ms for four, measured).  A host
+// that knows its concurrency creates them ahead.
+int gkrhip_reserve_lanes(int n) {
+    if (n < 0 || n > (int)kLanePoolMax) return fail("gkrhip_reserve_lanes: %d lanes (0..%d, the size of the pool)", n, (int)kLanePoolMax);
+    std::vector<Ctx*> got;
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> g(g0.mu);
+        CHK(ensure_ctx());
+        for (int i = 0; i < n; i++) {
+            Ctx* l = lane_create();       // pooled lanes first: the pool ends up holding at least n
+            if (!l) {
+                rc = fail("cannot create lane %d of %d: %s", i, n, g_err.c_str());
+                break;
+            }
+            got.push_back(l);
+        }
+    }
+    for (Ctx* l : got) lane_destroy(l);
+    return rc;
+}
+
 // Page-locked host memory for the vectors a caller hands over on every proof (scalars of the MSMs, the a, b, c of computeH):
 // an upload from pageable memory is staged by the runtime (measured 38 GB/s), one from these buffers is a plain DMA.
 int gkrhip_host_alloc(void** out, size_t bytes) {

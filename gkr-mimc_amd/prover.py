@@ -41,6 +41,7 @@ ABI = {
     "gkrhip_mem_info": (_I, [C.POINTER(_SZ), C.POINTER(_SZ)]),
     "gkrhip_host_alloc": (_I, [C.POINTER(C.c_void_p), _SZ]),
     "gkrhip_host_free": (None, [C.c_void_p]),
+    "gkrhip_reserve_lanes": (_I, [_I]),
     "gkrhip_set_option": (_I, [C.c_char_p, C.c_long]),
     "gkrhip_fold": (_I, [_P, _SZ, _P]),
     "gkrhip_evaluate": (_I, [_P, _P, _SZ, _P, _I]),
@@ -224,6 +225,11 @@ class PinnedArray:
 
 def synchronize():
     _check(load().gkrhip_device_synchronize())
+
+
+def reserve_lanes(n):
+    """Create n lanes ahead of the first burst of concurrent calls (a lane takes ~3 ms to create)."""
+    _check(load().gkrhip_reserve_lanes(int(n)))
 
 
 def _fr(a):

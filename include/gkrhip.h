@@ -72,6 +72,9 @@ int gkrhip_mem_info(size_t *free_bytes, size_t *total_bytes);
  * entry point accepts ordinary memory. */
 int gkrhip_host_alloc(void **out, size_t bytes);
 void gkrhip_host_free(void *p);
+/* Every call leases a lane (stream, hand-off buffers) from a pool that grows on demand; creating one takes ~3 ms.  A host that will
+ * issue n calls at once (the goroutines of ComputeGroth16Proof, several gkr.Prove) can create the lanes ahead (n <= 16).  Optional. */
+int gkrhip_reserve_lanes(int n);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
  * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
  * "coop", "spec", "spec_lg" -- applied to every existing lane,

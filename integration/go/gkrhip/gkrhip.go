@@ -549,6 +549,10 @@ func MultiExpShared(outG1 []unsafe.Pointer, g1 []*G1Bases, outG2 []unsafe.Pointe
 	}
 }
 
+// ReserveLanes creates n lanes ahead of the first burst of concurrent calls (the goroutines of ComputeGroth16Proof lease one
+// each; a lane takes ~3 ms to create).  Optional.
+func ReserveLanes(n int) { must(C.gkrhip_reserve_lanes(C.int(n))) }
+
 // PinnedElements returns a []fr.Element of length n in page-locked host memory (gkrhip_host_alloc): uploads from it are plain
 // DMA transfers instead of staged copies of pageable memory.  Meant for the vectors handed over on every proof (wireValues and
 // its filtered copies, the a / b / c of computeH).  The memory is not known to Go's collector: release it with FreePinned.

@@ -388,3 +388,31 @@ def test_page_locked_scalars(gk):
     with gk.PinnedArray(0, 4) as empty:
         assert empty.a.shape == (0, 4)
     b.close()
+
+
+def test_reserved_lanes_serve_a_burst_of_calls(gk):
+    """gkrhip_reserve_lanes: lanes created ahead; a burst of concurrent MSMs (each leases one) gives the same points as one
+    call after the other."""
+    import threading
+    gk.reserve_lanes(4)
+    with pytest.raises(gk.GkrHipError):
+        gk.reserve_lanes(17)
+    n = 4000
+    rng = random.Random(77)
+    pts = rand_points(77, n)
+    bs = [gk.G1Bases(points=pts) for _ in range(4)]
+    scs = [rand_scalars(rng, n) for _ in range(4)]
+    want = [c.g1_msm(pts, s).tolist() for s in scs]
+    got = [None] * 4
+
+    def work(i):
+        got[i] = bs[i].multi_exp(scs[i]).tolist()
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert got == want
+    for b in bs:
+        b.close()

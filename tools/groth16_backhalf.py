@@ -13,6 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gk = importlib.import_module("gkr-mimc_amd")
 gk.init(0)
+gk.reserve_lanes(5)      # the five calls at once lease a lane each
 G1 = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f,
                0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 22
