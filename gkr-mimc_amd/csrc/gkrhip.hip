@@ -314,6 +314,36 @@ int gkrhip_set_option(const char* key, long value) {
         g_test_drop_round.store((int)value);
         return 0;
     }
+    if (!strcmp(key, "test_corrupt_sum")) {
+        g_test_corrupt_left.store(1);
+        g_test_corrupt_skip.store(0);
+        g_test_corrupt_round.store((int)value);
+        return 0;
+    }
+    if (!strcmp(key, "test_corrupt_skip")) {
+        g_test_corrupt_skip.store((int)std::max(0L, value));
+        return 0;
+    }
+    if (!strcmp(key, "test_corrupt_times")) {
+        g_test_corrupt_left.store((int)std::max(1L, value));
+        return 0;
+    }
+    if (!strcmp(key, "test_corrupt_tail")) {
+        g_test_corrupt_tail.store((int)value);
+        return 0;
+    }
+    // the prover's own checks (host_sumcheck.hip.h: sumcheck_closes).  layer_check (default 1): every sumcheck is held against
+    // the verifier's identities before it is returned, and run again in safe mode if it does not close.  verify_after_prove
+    // (default 0): the one-shot calls run gkr.Verify on their proof before returning it, as the reference's hint does in debug
+    // builds (prover/gadget/hints.go:224-228) -- three more passes over the input and output tables.
+    if (!strcmp(key, "layer_check")) {
+        g_layer_check.store(value != 0);
+        return 0;
+    }
+    if (!strcmp(key, "verify_after_prove")) {
+        g_verify_after_prove.store(value != 0);
+        return 0;
+    }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
         g_msm_sort_levels.store((int)value);
         return 0;
@@ -796,6 +826,12 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
         // the proof every host value is a Montgomery element -- a sharded proof uploads gathered elements (small_table)
         RegularIO inside(false);
         rc = gkrhip_mimc_session_prove(s, qprime, flat);
+        // hints.go:224-228 (`if debug`): the hint verifies its own proof -- the claims on the input and output tables included,
+        // which the per-layer checks inside Prove cannot see
+        if (rc == 0 && g_verify_after_prove.load(std::memory_order_relaxed)) {
+            rc = gkrhip_mimc_session_verify(s, qprime, flat);
+            if (rc > 0) rc = fail("GKR proof was wrong - Bug in proof generation - gkr.Verify rejected it (code %d)", rc);
+        }
     }
     const double t_p = now_ms();
     if (dl.joinable()) {
@@ -841,6 +877,10 @@ int gkrhip_gkr_prove(const gkrhip_layer* layers, int n_layers, int bN, const uin
     for (int k = 0; k < n_inputs && rc == 0; k++) rc = gkrhip_session_load_input(s, k, inputs[k]);
     if (rc == 0) rc = gkrhip_mimc_session_assign(s);
     if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
+    if (rc == 0 && g_verify_after_prove.load(std::memory_order_relaxed)) {      // see prove_mimc_oneshot
+        rc = gkrhip_mimc_session_verify(s, qprime, flat);
+        if (rc > 0) rc = fail("GKR proof was wrong - Bug in proof generation - gkr.Verify rejected it (code %d)", rc);
+    }
     if (rc == 0 && outputs_or_null) rc = gkrhip_mimc_session_outputs(s, outputs_or_null);
     const std::string err = g_err;
     gkrhip_mimc_session_destroy(s);
@@ -1526,6 +1566,8 @@ int gkrhip_profile_reset(size_t min_n) {
     g_cnt_coop = 0;
     g_cnt_spec = 0;
     g_cnt_retries = 0;
+    g_cnt_layer_checks = 0;
+    g_cnt_layer_check_failures = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
         prof_clear(l->prof);
@@ -2007,6 +2049,8 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "coop_rounds") *value = g_cnt_coop.load();
     else if (n == "spec_rounds") *value = g_cnt_spec.load();
     else if (n == "chal_retries") *value = g_cnt_retries.load();
+    else if (n == "layer_checks") *value = g_cnt_layer_checks.load();
+    else if (n == "layer_check_failures") *value = g_cnt_layer_check_failures.load();
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);
     return 0;
 }

@@ -19,6 +19,10 @@ static inline double now_ms() {
 // challenge, round-0 launches on look-ahead products, rounds of the cooperative kernel.  Not per lane: the lanes of
 // one-shot calls go back to the pool (and are cleared) before anybody can ask.
 std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0}, g_cnt_spec{0}, g_cnt_retries{0};
+// the prover's own check of every sumcheck it produces (host_sumcheck.hip.h, sumcheck_closes): sumchecks checked, sumchecks
+// that did not close and were run again, and gkrhip_set_option("layer_check", 0 | 1) / ("verify_after_prove", 0 | 1)
+std::atomic<uint64_t> g_cnt_layer_checks{0}, g_cnt_layer_check_failures{0};
+std::atomic<int> g_layer_check{1}, g_verify_after_prove{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
     uint64_t rounds = 0;
@@ -633,6 +637,7 @@ thread_local bool g_regular_io = false;
 // the layer's inputs are untouched by the rounds, so the retry produces the same transcript.
 thread_local bool g_chal_timeout = false;
 thread_local bool g_safe_mode = false;
+thread_local bool g_corrupt_collect = false;      // fault injection (test_corrupt_sum): armed by the round loop for the hand-off it is about to collect
 struct RegularIO {
     bool prev;
     explicit RegularIO(bool on = true) : prev(g_regular_io) { g_regular_io = on; }

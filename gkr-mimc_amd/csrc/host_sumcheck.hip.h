@@ -38,9 +38,14 @@ int round_collect(bool collective, const RoundTargets& t, unsigned int seq, int 
     if (t.on_device) {
         CHK(coll_allreduce(cx().lc.d_buf, nsum));     // exact integer sum of limb-split lanes; the tail words are rank-local
         CHK(coll_publish(nsum + ntail, seq));
-        return wait_flag(seq, nullptr, coll_timeout_ms(), coll_stream());
+        const int rcd = wait_flag(seq, nullptr, coll_timeout_ms(), coll_stream());
+        if (g_corrupt_collect && rcd == 0) cx().h_round[GKR_ACC_WORDS] ^= 1ull;      // (after the device-side exchange: set the hook on every rank)
+        g_corrupt_collect = false;
+        return rcd;
     }
     const int rc = wait_flag(seq);
+    if (g_corrupt_collect && rc == 0) cx().h_round[GKR_ACC_WORDS] ^= 1ull;           // test_corrupt_sum: this rank's M_1, before the exchange
+    g_corrupt_collect = false;
     if (collective && host_exchange()) {
         // The ranks exchange one word more than the sums: a vote.  A rank whose round kernel gave up waiting for its challenge
         // (recoverable: g_chal_timeout) still takes part in the exchange, with zero sums and vote 1; any vote makes EVERY rank
@@ -169,10 +174,24 @@ struct ChalGuard {
 //   test_fail_after_prelaunch = k: an error return in round k while a pre-launched kernel is waiting for its challenge;
 //   test_drop_challenge = k: the challenge of round k is NOT published -- the kernel waiting for it runs out of time, the round
 //   loop fails with g_chal_timeout and rounds_with_retry runs the layer again in safe mode.
-std::atomic<int> g_test_fail_round{-1}, g_test_drop_round{-1};
+//   test_corrupt_sum = k: one bit of a sum of round k (the monomial sum M_1 / the evaluation at t = 1) is flipped on its way
+//   from the device to the host -- BEFORE the ranks add their words when the exchange is host-side --, and
+//   test_corrupt_tail = 1: one bit of the table entries the last device round of a fused loop hands to the host.  Either
+//   stands for any slip of the device side (a race, an incomplete look-ahead, a bad fold): the sumcheck no longer closes,
+//   sumcheck_prove_dev notices and runs the layer again (counter "layer_check_failures").
+//   test_corrupt_times = n (set after test_corrupt_sum): the flip fires n times instead of once -- twice makes the retry fail too;
+//   test_corrupt_skip = j: the first j round loops that reach round k are left alone (j selects the layer of a proof).
+std::atomic<int> g_test_fail_round{-1}, g_test_drop_round{-1}, g_test_corrupt_round{-1}, g_test_corrupt_tail{-1}, g_test_corrupt_left{1},
+    g_test_corrupt_skip{0};
 inline bool test_fire(std::atomic<int>& hook, int k) {
     int want = k;
     return hook.load(std::memory_order_relaxed) == k && hook.compare_exchange_strong(want, -1);
+}
+inline bool test_fire_corrupt(int k) {
+    if (g_test_corrupt_round.load(std::memory_order_relaxed) != k) return false;
+    if (g_test_corrupt_skip.load(std::memory_order_relaxed) > 0 && g_test_corrupt_skip.fetch_sub(1) > 0) return false;
+    if (g_test_corrupt_left.fetch_sub(1) <= 1) return test_fire(g_test_corrupt_round, k);      // the last time disarms
+    return true;
 }
 
 // The slow parts of the look-ahead -- the second stream (created on first use: a lane that never looks ahead holds one
@@ -427,8 +446,14 @@ int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
         unsigned long long summed[GKR_CR_WORDS + 1];
         static_assert(L::NSUM <= GKR_CR_WORDS, "exchange scratch");
         const unsigned long long* sums = nullptr;
-        if (this_spec) CHK(wait_flag(lp.spec_seq[k], lp.spec_flag(k)));
-        else CHK(round_collect(collective, cur.tg, cur.seq, L::NSUM, L::NTAIL, summed, &sums));
+        const bool corrupt = test_fire_corrupt(k);
+        if (this_spec) {
+            CHK(wait_flag(lp.spec_seq[k], lp.spec_flag(k)));
+            if (corrupt) cx().h_spec[(size_t)(k & 1) * GKR_SPEC_BUF_WORDS + 4] ^= 1ull;      // candidate 0's M_1
+        } else {
+            g_corrupt_collect = corrupt;
+            CHK(round_collect(collective, cur.tg, cur.seq, L::NSUM, L::NTAIL, summed, &sums));
+        }
         const double t_w = now_ms();
         if (prelaunched && collective) {
             CHK(lp.launch_round(k + 1, true, hfr::ZERO, lp.claim != nullptr, &nxt));
@@ -777,8 +802,12 @@ struct CipherLoop {
     // this round's challenge are the host's starting point (GKRHIP_HOST_TAIL)
     int finish_round(int k, bool this_spec, const E& r, E* r_prev) {
         const size_t P = n >> (k + 1);
-        if (k == m - 1) memcpy(tail, cx().h_round + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
+        if (k == m - 1) {
+            memcpy(tail, cx().h_round + GKR_CR_WORDS, 4 * sizeof(E));  // written by the P == 1 launch
+            if (test_fire(g_test_corrupt_tail, 1)) tail[0].l[0] ^= 1ull;
+        }
         if (k != pl.k_export) return 0;
+        if (test_fire(g_test_corrupt_tail, 1)) cx().h_tail[0] ^= 1ull;
         const E* tt = (const E*)cx().h_tail;
         std::vector<E> Kh(P), Sh(P);
         if (this_spec) {
@@ -1156,8 +1185,12 @@ struct LinearLoop {
 
     int finish_round(int k, bool this_spec, const E& r, E* r_prev) {
         const size_t P = n >> (k + 1);
-        if (k == m - 1) memcpy(tail, cx().h_round + GKR_LR_WORDS, (size_t)2 * arity * sizeof(E));   // written by the P == 1 launch
+        if (k == m - 1) {
+            memcpy(tail, cx().h_round + GKR_LR_WORDS, (size_t)2 * arity * sizeof(E));   // written by the P == 1 launch
+            if (test_fire(g_test_corrupt_tail, 1)) tail[0].l[0] ^= 1ull;
+        }
         if (k != pl.k_export) return 0;
+        if (test_fire(g_test_corrupt_tail, 1)) cx().h_tail[0] ^= 1ull;
         const E* tt = (const E*)cx().h_tail;
         std::vector<std::vector<E>> Th(arity, std::vector<E>(P));
         if (this_spec) {                     // the speculative launch exported the tables of round k-1 (4P entries each)
@@ -1276,6 +1309,7 @@ int generic_rounds(const GateDesc& g, const E& ark, int m, DevTable* eq, const D
         const size_t mid = n >> (k + 1);
         E evals[GKR_MAX_EVALS];
         CHK(partial_evals(g, eq, cur, mid, ark, evals, nev, collective));
+        if (test_fire_corrupt(k)) evals[1].l[0] ^= 1ull;      // (after the exchange: set the hook on every rank)
         E* coeffs = proof + (size_t)k * nev;
         cx().lag->interpolate(coeffs, evals, nev);
         const E r = hfr::mimc_hash(coeffs, (size_t)nev);
@@ -1306,8 +1340,8 @@ int generic_rounds(const GateDesc& g, const E& ark, int m, DevTable* eq, const D
 // sumcheck's output).  The single-point cipher path then derives one monomial sum per round from the running
 // claim instead of computing it.  Entry points that take claims from outside never set it: for them the
 // output must be the reference's whatever the claims are (they only feed Fiat-Shamir there).
-int sumcheck_prove_dev(int gate, const E& ark_in, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
-                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims, bool trust_claims = false) {
+int sumcheck_prove_once(int gate, const E& ark_in, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
+                        const E* claims, int nclaims, E* proof, E* challenges, E* final_claims, bool trust_claims, E* rho_out) {
     GateDesc g;
     CHK(gate_resolve(gate, arity, &g));
     const E ark = gate == GKRHIP_GATE_IDENTITY ? hfr::ZERO : ark_in;   // IdentityGate has no Ark
@@ -1324,6 +1358,7 @@ int sumcheck_prove_dev(int gate, const E& ark_in, int arity, int bN, const DevTa
     int nq_used = 1;
     if (nclaims >= 1) {
         const E rho = hfr::mimc_hash(claims, (size_t)nclaims);  // computed even when unused, as the reference
+        *rho_out = rho;
         E mlt = rho;
         for (int j = 1; j < nq; j++) {
             seeds[j] = mlt;
@@ -1368,6 +1403,80 @@ int sumcheck_prove_dev(int gate, const E& ark_in, int arity, int bN, const DevTa
         for (int t = 0; t < arity; t++) table_release(&x2[t]);
     }
     for (int t = 0; t <= arity; t++) final_claims[t] = last[t];
+    return 0;
+}
+
+// ---- the prover checks what it is about to return ---------------------------------------------------------------------
+// The verifier's side of one sumcheck on the prover's own output: sumcheck.Verify's round checks P_i(0) + P_i(1) == expected
+// (sumcheck/verifier.go:28-55) with the challenges the prover already hashed -- no second hash --, then testSumcheck's closing
+// identity Gate.Eval(finalClaims[1:]) * sum_j rho^j EvalEq(q_j, r) == P_last(r_last) (gkr/verifier.go:93-114,
+// poly/eq.go:19-32), and finalClaims[0] against that eq value.  bN * (deg + 9) products, 2 * bN more per point: microseconds.
+// Why it is not redundant: inside gkr.Prove the fused round loops DERIVE one sum of every round from the running claim
+// (trust_claims), so a wrong device sum -- or a wrong fold, or incomplete look-ahead products -- yields rounds that are
+// consistent with each other and a transcript that is simply wrong.  By the soundness of the sumcheck itself such a run
+// closes with probability ~ bN * deg / q.  Returns 0 = closes, 1 + i = round i, -1 = the closing identity, -2 = finalClaims[0].
+// `claims_are_sums`: the claims are known to be the sums (gkr.Prove); claims from outside only feed Fiat-Shamir
+// (sumcheck/prover.go:128) and say nothing about round 0.
+int sumcheck_closes(const GateDesc& g, const E& ark, int bN, const E* qprimes, int nq_used, const E* claims, int nclaims,
+                    bool claims_are_sums, const E& rho, const E* proof, const E* chal, const E* fin) {
+    const int nev = g.power + 2;
+    bool have = false;
+    E expected = hfr::ZERO;
+    if (claims_are_sums && nclaims >= 1) {
+        expected = nclaims == 1 ? claims[0] : hfr::eval_univariate(claims, nclaims, rho);      // recombineMultiClaims, verifier.go:58-65
+        have = true;
+    }
+    for (int i = 0; i < bN; i++) {
+        const E* p = proof + (size_t)i * nev;
+        if (have) {
+            E s01 = hfr::add(p[0], p[0]);            // P(0) + P(1) = 2 c_0 + c_1 + ... + c_deg+1
+            for (int j = 1; j < nev; j++) s01 = hfr::add(s01, p[j]);
+            if (s01 != expected) return 1 + i;
+        }
+        expected = hfr::eval_univariate(p, nev, chal[i]);
+        have = true;
+    }
+    if (!have) return 0;                             // no round and no claim to hold the final values against
+    E eq_eval = hfr::ZERO, w = hfr::ONE;
+    for (int j = 0; j < nq_used; j++) {
+        eq_eval = hfr::add(eq_eval, hfr::mul(w, hfr::eval_eq(qprimes + (size_t)j * bN, chal, bN)));
+        w = hfr::mul(w, rho);
+    }
+    if (hfr::mul(gate_eval_host(g, ark, fin + 1), eq_eval) != expected) return -1;
+    if (fin[0] != eq_eval) return -2;
+    return 0;
+}
+
+// sumcheck.Prove, checked: a sumcheck that does not close is run ONCE more in safe mode -- nothing queued ahead of its
+// challenge, no look-ahead products, every sum of every round computed (no claim trick) -- and checked again; only a second
+// failure is an error.  The retry rests on the invariant of rounds_with_retry (the rounds read the layer's tables and write
+// scratch), produces the same transcript as any other path, and is deterministic in data every rank of a sharded proof
+// holds identically (the exchanged sums, the gathered final values): the ranks reach the same verdict without a vote.
+int sumcheck_prove_dev(int gate, const E& ark_in, int arity, int bN, const DevTable* const* X, const E* qprimes, int nq,
+                       const E* claims, int nclaims, E* proof, E* challenges, E* final_claims, bool trust_claims = false) {
+    E rho = hfr::ZERO;
+    CHK(sumcheck_prove_once(gate, ark_in, arity, bN, X, qprimes, nq, claims, nclaims, proof, challenges, final_claims, trust_claims, &rho));
+    if (!g_layer_check.load(std::memory_order_relaxed)) return 0;
+    GateDesc g;
+    CHK(gate_resolve(gate, arity, &g));
+    const E ark = gate == GKRHIP_GATE_IDENTITY ? hfr::ZERO : ark_in;
+    const int nq_used = nclaims >= 1 ? nq : 1;
+    g_cnt_layer_checks.fetch_add(1, std::memory_order_relaxed);
+    int bad = sumcheck_closes(g, ark, bN, qprimes, nq_used, claims, nclaims, trust_claims, rho, proof, challenges, final_claims);
+    if (!bad) return 0;
+    g_cnt_layer_check_failures.fetch_add(1, std::memory_order_relaxed);
+    if (getenv("GKRHIP_TRACE")) fprintf(stderr, "sumcheck (gate %s, bN %d) does not close (%d): running it again in safe mode\n", g.id.c_str(), bN, bad);
+    struct SafeScope {
+        const bool prev = g_safe_mode;
+        SafeScope() { g_safe_mode = true; }
+        ~SafeScope() { g_safe_mode = prev; }
+    } safe;
+    CHK(sumcheck_prove_once(gate, ark_in, arity, bN, X, qprimes, nq, claims, nclaims, proof, challenges, final_claims, false, &rho));
+    bad = sumcheck_closes(g, ark, bN, qprimes, nq_used, claims, nclaims, trust_claims, rho, proof, challenges, final_claims);
+    if (bad)
+        return fail("sumcheck.Prove (gate %s, bN %d): the prover's own check failed twice (%s), the second time in safe mode: "
+                    "no proof is returned", g.id.c_str(), bN,
+                    bad > 0 ? "a round's P(0) + P(1) is not the running claim" : bad == -1 ? "the final claims do not close the last round" : "finalClaims[0] is not the eq value");
     return 0;
 }
 

@@ -79,7 +79,14 @@ int gkrhip_reserve_lanes(int n);
  * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
  * "coop", "spec", "spec_lg" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
- * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums) */
+ * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums).
+ * Integrity (process-wide): "layer_check" (default 1) -- every sumcheck the library produces is held against the verifier's own
+ * identities before it is returned (sumcheck/verifier.go:41-47 per round, the closing identity of gkr/verifier.go:93-114; host
+ * scalar work, microseconds) and run once more in safe mode if it does not close; a second failure is an error, never a
+ * wrong proof.  "verify_after_prove" (default 0) -- the one-shot calls (gkrhip_gkr_prove_mimc{,_regular}, gkrhip_gkr_prove) run
+ * gkr.Verify on their proof before returning it, as the reference's hint does in debug builds (prover/gadget/hints.go:224-228).
+ * Fault injection for the tests, each firing once: "test_fail_after_prelaunch", "test_drop_challenge", "test_corrupt_sum" = k
+ * (flip one bit of a device sum of round k; "test_corrupt_times" = n afterwards: n times instead of once; "test_corrupt_skip" = j: in the (j+1)-th sumcheck that reaches round k), "test_corrupt_tail" = 1 (flip one bit of the table entries handed to the host). */
 int gkrhip_set_option(const char *key, long value);
 
 /* ---- poly.MultiLin (poly/multilin.go) -------------------------------------------------------- */
@@ -383,7 +390,9 @@ int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_rou
  * sums were computed speculatively for the eight candidate values 0..7 of the previous challenge while the host was still
  * hashing, and interpolated at the true challenge), and "chal_retries": layers whose rounds were run a second time, nothing
  * queued ahead of its challenge, because a waiting kernel's time (1 s) ran out -- the result is the same, the proof is merely
- * late.  Unknown name: error. */
+ * late; "layer_checks": sumchecks held against the verifier's identities before they were returned; "layer_check_failures":
+ * those that did not close and were run a second time in safe mode (see gkrhip_set_option, "layer_check") -- any value
+ * other than 0 outside the fault-injection tests means the device side slipped and deserves a report.  Unknown name: error. */
 int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus

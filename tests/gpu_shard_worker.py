@@ -185,7 +185,13 @@ def main():
         # this rank withholds ONE challenge from its pre-launched round kernel: the kernel gives up after a second, the rank
         # votes for a retry in the round's exchange and every rank runs the layer's rounds again (same transcript)
         gk.set_option("test_drop_challenge", int(os.environ.get("GKR_TEST_DROP_ROUND", "3")))
-    if os.environ.get("GKR_TEST_EXPECT_RETRIES"):
+    if os.environ.get("GKR_TEST_CORRUPT_RANK") in (str(rank), "all"):
+        # one bit of this rank's sums of one round flips before the ranks add them (GKR_TEST_CORRUPT_RANK=all: on every rank, for
+        # the device-side exchange, whose words are flipped after the all-reduce): every rank sees a sumcheck that does not
+        # close and every rank runs the layer again -- no vote needed, the verdict is a function of exchanged data
+        gk.set_option("test_corrupt_sum", int(os.environ.get("GKR_TEST_CORRUPT_ROUND", "2")))
+        gk.set_option("test_corrupt_skip", int(os.environ.get("GKR_TEST_CORRUPT_LAYER", "3")))
+    if os.environ.get("GKR_TEST_EXPECT_RETRIES") or os.environ.get("GKR_TEST_EXPECT_LAYER_FAILURES"):
         gk.profile_reset(0)
     if os.environ.get("GKR_TEST_REGULAR"):
         return regular_oneshot(gk, world, rank, sizes)
@@ -222,6 +228,9 @@ def main():
     if os.environ.get("GKR_TEST_EXPECT_RETRIES"):
         got = gk.profile_get()["chal_retries"]
         assert got == int(os.environ["GKR_TEST_EXPECT_RETRIES"]), ("chal_retries", rank, got)
+    if os.environ.get("GKR_TEST_EXPECT_LAYER_FAILURES"):
+        got = gk.profile_get()["layer_check_failures"]
+        assert got == int(os.environ["GKR_TEST_EXPECT_LAYER_FAILURES"]), ("layer_check_failures", rank, got)
     gk.comm_destroy()
     print("SHARD-OK rank %d/%d %s" % (rank, world, sizes))
 

@@ -71,6 +71,18 @@ def test_sharded_retry_after_a_missed_challenge():
     _run_shards("tickshm", 2, "11", dict(env, GKR_TEST_DROP_RANK="1"))
 
 
+def test_sharded_layer_rerun_after_a_corrupted_sum():
+    """One bit of ONE rank's sums of one round flips before the exchange (test hook): the summed words are wrong on every
+    rank, every rank's check of the finished sumcheck fails (it is a function of exchanged data: no vote), every rank runs
+    the layer again in safe mode -- the oracle's transcript, one failure counted per rank.  Shared memory (4 ranks), the
+    ticker (2 ranks), and a 1-rank RCCL communicator with every round through ncclAllReduce."""
+    env = {"GKR_TEST_CORRUPT_RANK": "2", "GKR_TEST_CORRUPT_ROUND": "2", "GKR_TEST_EXPECT_LAYER_FAILURES": "1"}
+    _run_shards("shm", 4, "12", env)
+    _run_shards("shm", 4, "11", dict(env, GKR_TEST_CORRUPT_RANK="all", GKR_TEST_CORRUPT_LAYER="91"))     # the 91-claim key-copy layer (reference-shaped rounds: flipped after the exchange, so on every rank)
+    _run_shards("tickshm", 2, "11", dict(env, GKR_TEST_CORRUPT_RANK="1", GKR_TEST_CORRUPT_ROUND="0"))
+    _run_shards("rccl", 1, "10", dict(env, GKR_TEST_CORRUPT_RANK="all", GKRHIP_FORCE_COLLECTIVE="1"))
+
+
 def test_sharded_oneshot_on_regular_form_buffers():
     """gkrhip_gkr_prove_mimc_regular with a communicator installed: the regular-form scope covers the boundary images
     only, the gathered Montgomery elements of the sharded phase 2 (multi-claim key-copy layer, host tail off) are uploaded
