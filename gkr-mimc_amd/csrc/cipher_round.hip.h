@@ -166,6 +166,16 @@ __device__ __forceinline__ bool wait_challenge(const unsigned long long* slot, u
             const u32 s = (u32)(v >> 32);
             if (s == seq) break;
             if (s == GKR_CHAL_ABORT || wall_clock64() - t0 > (unsigned long long)(limit_s ? limit_s : 1u) * 100000000ull) {
+                if (s != GKR_CHAL_ABORT) {
+                    // The time ran out -- by the wall clock, which also runs while a wave is switched out (more hardware queues than the
+                    // chip has slots: the scheduler time-slices them) or stalled behind a slow read: the word this lane last saw may be
+                    // older than the verdict.  One more look at the source before giving up.
+                    v = __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((u32)(v >> 32) == seq) {
+                        from_host = true;
+                        break;
+                    }
+                }
                 bad = 1;
                 if (diag && threadIdx.x == 0) {          // why the launch was abandoned (the host's error message quotes it)
                     diag[0] = ((unsigned long long)blockIdx.x << 32) | (s == GKR_CHAL_ABORT ? 1u : 2u);

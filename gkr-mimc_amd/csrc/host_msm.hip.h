@@ -47,6 +47,7 @@ struct MsmWork {
     unsigned int slice_len = 0, slice_cap = 0, ctiles = 0;
     unsigned int* lvl2 = nullptr;        // coarse count | offset | first slice (W * nbc each) | chunk histograms | tile sums | slice list | slice histograms
     unsigned int* c_entries = nullptr;   // the coarse pass's entries
+    bool ready = false;                  // every buffer below is allocated (set last by msm_work_prepare)
     void release() {
         if (counts) (void)hipFree(counts);
         if (lvl2) (void)hipFree(lvl2);
@@ -89,8 +90,16 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     const int c = c_forced > 0 ? c_forced : msm_pick_c(n);
     if (c < 2 || c > 16) return fail("msm: window size %d outside 2..16", c);
     const int lowbits = msm_pick_lowbits(n, c);
-    if (w->counts && w->c == c && w->n_cap >= n && w->w16 == w16 && w->lowbits == lowbits) return 0;
+    if (w->ready && w->c == c && w->n_cap >= n && w->w16 == w16 && w->lowbits == lowbits) return 0;
     w->release();
+    // an allocation that fails half-way (several GiB per handle at 2^24 points) must not leave a half-prepared handle behind:
+    // the next MSM would take the fast path above and launch its kernels on null pointers
+    struct Guard {
+        MsmWork* w;
+        ~Guard() {
+            if (w) w->release();
+        }
+    } guard{w};
     w->c = c;
     w->lowbits = lowbits;
     w->w16 = w16;
@@ -142,6 +151,8 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
     HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W + w->big_cap) * sizeof(uint4)));
     HIPCHK(hipHostMalloc((void**)&w->h_wins, ((size_t)4 * w16 * w->W + 1) * sizeof(uint4)));      // + the error word
+    w->ready = true;
+    guard.w = nullptr;
     return 0;
 }
 

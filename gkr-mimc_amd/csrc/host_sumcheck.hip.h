@@ -197,17 +197,19 @@ inline bool test_fire_corrupt(int k) {
 // The slow parts of the look-ahead -- the second stream (created on first use: a lane that never looks ahead holds one
 // hardware queue, not two) and the six scratch tables (a miss in the arena is a hipMalloc behind the arena's lock) -- are done
 // at the START of the round loop, where no kernel of the lane is waiting for the host: a pre-launched or speculative kernel
-// gives up after 20 s without its challenge, and nothing that can block for an unbounded time (another lane holding the arena's
+// gives up after a second without its challenge (20 s on the device-side exchange of a sharded proof), and nothing that can block for an unbounded time (another lane holding the arena's
 // lock across its own hipMalloc) belongs between a pre-launch and the publication of its challenge.
 int pre_prepare() {
     if (!cx().req_K || !cx().req_S || cx().req_m < 2) return 0;
     const size_t P = (size_t)1 << (cx().req_m - 1);
     if (!cx().aux) {
         // NORMAL priority.  The stream used to have the lowest priority (the look-ahead kernel must not delay a round kernel; its
-        // LDS request caps it at two workgroups per CU anyway) -- and with a dozen lanes forced to use it, behind pre-launched
-        // kernels spinning for their challenges, 4 % of the proofs were wrong (57 of 1 440 at bN = 18; 0 of 1 440 at normal or high
-        // priority, 0 with the products computed but not consumed): kernels of a lowest-priority queue that the other queues' work
-        // keeps displacing did not always leave complete output.  One proof alone: 277.6 ms against 275.1 at bN = 24.
+        // LDS request caps it at one workgroup per CU anyway) -- and with a dozen lanes forced to use it 4 % of the proofs were wrong
+        // (57 of 1 440 at bN = 18; 0 of 1 440 at normal priority).  Round 5 reproduced that WITHOUT the library
+        // (tools/prio_event_probe.hip, profiles/r05_anomalies.md): with 16 hardware queues, hipStreamWaitEvent on an event recorded in
+        // a lowest-priority stream sometimes lets the waiting stream go while one to three XCDs have not finished their share of the
+        // producer (16 of 122 036 iterations; 0 of 331 149 at normal priority).  Runtime behaviour, not ours to fix; and whatever still
+        // slips through is caught by sumcheck_closes below.  One proof alone: 277.6 ms against 275.1 at bN = 24.
         HIPCHK(hipStreamCreateWithFlags(&cx().aux, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
     }
