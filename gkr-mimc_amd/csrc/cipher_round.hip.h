@@ -124,6 +124,9 @@ struct CipherRoundArgs {
     unsigned int chal_limit_s;         // give up after this many seconds without the challenge (0: one second)
     // PRE (k_cipher_round_wide<false, ., true>): the q-independent products of round 0, computed ahead by k_cipher_pre
     CPlanes pre[6];                    // u^4, d^4, u^3, u^2 d, u d^2, d^3 at every pair
+    // AHEAD (k_cipher_round_wide<false, true, ., true>): round 0 of the NEXT layer, queued before that layer's last ahead_t
+    // coordinates exist -- see the comment above ahead_publish
+    unsigned int ahead_t;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -390,6 +393,86 @@ __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(CipherRoundAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 0 AHEAD of its evaluation point.  Round 0 of a layer needs the layer's whole point q -- the challenges of the layer
+// proven before it, the last of which the host draws at the very end of that layer (its host-tail rounds: 5 serial hashes,
+// ~180 us during which the GPU has nothing to do).  But the weights factorise over index bits, the LAST coordinates
+// belonging to the LOWEST bits of the pair index x = (x_hi, y), y = the low t bits:
+//     M_j = sum_x eq(q[1:], x) m_j(x) = sum_y eq(q[m-t:], y) * S_j(y),     S_j(y) = sum_{x_hi} eq(q[1:m-t], x_hi) m_j(x_hi, y),
+// and S_j needs only the coordinates known when the host tail STARTS.  So the previous layer queues this kernel at that point:
+// the wide round-0 kernel with the lane weight over the known bits only (wt indexed by gtid >> t) and an epilogue that sums
+// lanes of equal y = gtid mod 2^t instead of all lanes: 7 x 2^t class sums (t <= 6), reduced to canonical elements by the last
+// workgroup and handed to the host, which contracts them with eq(q[m-t:], .) once the tail has produced those coordinates
+// (7 * 2^t products) -- round 0's kernel, its hand-off and its pyramids leave the critical path of every layer.
+// Accumulators: GKR_RACC_SLOTS stripes of (63 << t) words, word (j, w) of class y at ((j * 9 + w) << t) + y.
+// ------------------------------------------------------------------------------------------------
+#define GKR_AHEAD_TMAX 6
+#define GKR_AHEAD_STRIPE (7 * GKR_ACC_WORDS << GKR_AHEAD_TMAX)                 // words per stripe
+#define GKR_AHEAD_OUT_WORDS (7 * 4 << GKR_AHEAD_TMAX)                          // canonical elements to the host: S_j(y) at (j * 2^t + y) * 4
+#define GKR_AHEAD_FLAG_WORD GKR_AHEAD_OUT_WORDS
+#define GKR_AHEAD_BUF_WORDS (GKR_AHEAD_OUT_WORDS + 16)
+__device__ __forceinline__ void ahead_publish(unsigned long long* racc, unsigned int* counter, unsigned long long* host_out,
+                                              unsigned int* host_flag, unsigned int seq, unsigned int t, unsigned int* s_last) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = atomicAdd(counter, 1u);
+        const unsigned int last = (prev == gridDim.x - 1) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last) {
+        const unsigned nval = 7u << t;
+        for (unsigned v = threadIdx.x; v < nval; v += blockDim.x) {
+            const unsigned j = v >> t, y = v & ((1u << t) - 1);
+            unsigned long long w[GKR_ACC_WORDS];
+#pragma unroll
+            for (int k = 0; k < GKR_ACC_WORDS; k++) {
+                unsigned long long* p = racc + (((size_t)j * GKR_ACC_WORDS + k) << t) + y;
+                unsigned long long sum = 0;
+#pragma unroll
+                for (int sl = 0; sl < GKR_RACC_SLOTS; sl++) {
+                    sum += __hip_atomic_load(p + (size_t)sl * GKR_AHEAD_STRIPE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    p[(size_t)sl * GKR_AHEAD_STRIPE] = 0;
+                }
+                w[k] = sum;
+            }
+            // value = sum_k w[k] 2^(32 k): carry into eight 32-bit limbs and a top part (as spec_publish, cipher_spec.hip.h)
+            Fr lo;
+            unsigned long long c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                c += w[k] & 0xffffffffull;
+                lo.v[k] = (u32)c;
+                c = (c >> 32) + (w[k] >> 32);
+            }
+            c += w[8];
+            Fr top = fr_zero();
+            top.v[0] = (u32)c;
+            top.v[1] = (u32)(c >> 32);
+            const Fr r2 = {{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}};   // R^2 mod q
+            Fr a0, a1;
+            fr_mont_mul2_raw(a0, a1, lo, fr_one(), top, r2);
+            const Fr x = fr_add(fr_reduce_once(a0), fr_reduce_once(a1));
+#pragma unroll
+            for (int l = 0; l < 4; l++) host_out[4 * (size_t)v + l] = (unsigned long long)x.v[2 * l] | ((unsigned long long)x.v[2 * l + 1] << 32);
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *counter = 0;
+            __threadfence_system();
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Deferred-reduction variant for the large rounds (several pairs per lane, M_0 derived from the claim).
 // The seven products W u^(7-j) d^j that only feed the sums M_1..M_7 are accumulated as plain 512-bit
 // integers (fr_mac_wide: 79 limb products instead of the 136 of a Montgomery product) into 17-limb
@@ -436,9 +519,10 @@ __device__ __forceinline__ void wide_lds_store(WideShared& sh, int slot, const u
 // PRE (round 0 only, FOLD = false): u^4, d^4 and the four cubics were computed ahead of time by k_cipher_pre -- they do
 // not depend on the layer's evaluation point -- so the launch on the critical path is two products by the launch-wide
 // weight and the seven wide MACs, reading 192 bytes per pair instead of computing eight products.
-template <bool FOLD, bool WT_LATE, bool PRE = false>
+template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false>
 __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
     static_assert(!(FOLD && PRE), "the precomputed products exist for round 0 only");
+    static_assert(!AHEAD || (WT_LATE && !FOLD), "round 0 ahead of its point: late lane weights, no fold");
     __shared__ WideShared sh;
     __shared__ unsigned int s_last;
     u32 R[GKR_CR_NSUM - 1 - GKR_WIDE_LDS][FR_WIDE_LIMBS];     // M_4 .. M_7
@@ -559,7 +643,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     for (int j = 0; j < GKR_ACC_WORDS; j++) acc[0].w[j] = 0;      // M_0: derived by the host from the claim
     // s = lo + top*2^256 (9 limbs) times Wt, as a Montgomery product: s*Wt/2^256 = mont(lo, Wt) + top*Wt
     Fr wtl = fr_zero();
-    if (WT_LATE && gtid < threads) wtl = ld_fr(a.wt.lo, a.wt.hi, gtid);
+    if (WT_LATE && gtid < threads) wtl = ld_fr(a.wt.lo, a.wt.hi, AHEAD ? (gtid >> a.ahead_t) : gtid);
     auto finish = [&](Acc9& dst, const u32 (&T)[FR_WIDE_LIMBS]) {
         fr_redc_wide(dst.w, T);
         if (WT_LATE) {
@@ -586,6 +670,26 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
     }
 #pragma unroll
     for (int t = 0; t < GKR_CR_NSUM - 1 - GKR_WIDE_LDS; t++) finish(acc[1 + GKR_WIDE_LDS + t], R[t]);
+    if (AHEAD) {
+        // class sums: lanes of equal y = gtid mod 2^t.  Inside a wave the lanes of a class are 2^t apart: a butterfly over the
+        // upper lane bits leaves every lane with its class's sum, lanes below 2^t add it to the launch's accumulators (t >= 6:
+        // the 64 lanes of a wave are 64 different classes)
+        const unsigned t = a.ahead_t, lane = threadIdx.x & 63u;
+        const unsigned y = (unsigned)gtid & ((1u << t) - 1);
+        unsigned long long* dst = a.partials + (size_t)(blockIdx.x % GKR_RACC_SLOTS) * GKR_AHEAD_STRIPE + y;
+        const bool live = gtid < threads;
+#pragma unroll
+        for (int j = 1; j < GKR_CR_NSUM; j++)
+#pragma unroll
+            for (int w = 0; w < GKR_ACC_WORDS; w++) {
+                unsigned long long v = live ? (unsigned long long)acc[j].w[w] : 0ull;
+                for (unsigned off = 32; off >= (1u << t) && off > 0; off >>= 1) v += __shfl_xor(v, (int)off);
+                if ((t >= 6 || lane < (1u << t)) && v)
+                    (void)__hip_atomic_fetch_add(dst + (((size_t)(j - 1) * GKR_ACC_WORDS + w) << t), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        ahead_publish(a.partials, a.counter, a.host_out, a.host_flag, a.seq, t, &s_last);
+        return;
+    }
     __syncthreads();                                                // tr aliases the LDS accumulators
     block_reduce_acc_buf<GKR_CR_NSUM, 18, true>(acc, a.partials, sh.tr, sh.red);
     cipher_round_publish(a, &s_last);

@@ -116,15 +116,18 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         ~PreScope() { pre_release(); }
     } pre_scope;
 
+    g_laps.start();
     for (int layer = L - 1; layer >= 0; layer--) {
         const Layer& lay = c[layer];
         if (lay.gate < 0) break;
+        LAP("session: between layers");
         const int arity = (int)lay.in.size();
         const DevTable* X[GKR_MAX_ARITY];
         for (int k = 0; k < arity; k++) X[k] = session_table(s, lay.in[k]);
         // Look-ahead: the layer proven next.  If it is a single-point cipher layer, the products of its round 0 that
         // do not depend on its evaluation point are computed while this layer's small rounds leave the GPU idle.
         cx().req_K = cx().req_S = nullptr;
+        cx().nxt_K = cx().nxt_S = nullptr;
         if (layer >= 1 && c[layer - 1].gate >= 0 && c[layer - 1].out.size() == 1 && c[layer - 1].in.size() == 2) {
             GateDesc gn;
             if (gate_get(c[layer - 1].gate, &gn) && gate_is_cipher2(gn)) {
@@ -132,6 +135,8 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
                 cx().req_S = session_table(s, c[layer - 1].in[1]);
                 cx().req_ark = c[layer - 1].ark;
                 cx().req_m = bN - shard_view().gamma;
+                cx().nxt_K = cx().req_K;
+                cx().nxt_S = cx().req_S;
             }
         }
         const int nev = gate_degree(lay.gate) + 2;
@@ -140,8 +145,10 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         E fin[GKR_MAX_ARITY + 1];
         const int nq = layer == L - 1 ? 1 : (int)lay.out.size();
         const int ncl = has_claims[layer] ? (int)lay.out.size() : 0;
+        LAP("session: layer prologue");
         CHK(sumcheck_prove_dev(lay.gate, lay.ark, arity, bN, X, qps[layer].data(), nq, claims[layer].data(), ncl,
                                sc[layer].data(), next_q.data(), fin, /*trust_claims=*/true));
+        LAP("session: sumcheck returned");
         for (int i = 1; i <= arity; i++) {  // updateWithSumcheck, prover.go:66-90
             const int inp = lay.in[i - 1];
             const std::vector<int>& o = c[inp].out;
@@ -176,6 +183,7 @@ int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.
         const Profile& p = cx().prof;
         fprintf(stderr, "rounds trace: hash %.2f wait %.2f launch %.2f other %.2f setup %.2f host-tail arithmetic %.2f ms\n", p.host_hash_ms,
                 p.host_wait_ms, p.host_launch_ms, p.host_other_ms, p.setup_ms, p.tail_ms);
+        g_laps.dump();
         for (int lg = 39; lg >= 0; lg--)
             if (p.cnt_lg[lg]) fprintf(stderr, "  2^%-2d pairs: %5llu rounds, wait %.1f us each\n", lg, (unsigned long long)p.cnt_lg[lg], 1e3 * p.wait_lg[lg] / p.cnt_lg[lg]);
     }
@@ -304,7 +312,7 @@ const char* gkrhip_build_id(void) {
 
 int gkrhip_set_option(const char* key, long value) {
     static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
-                                 "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg"};
+                                 "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg", "ahead"};
     // fault injection of the tests (host_sumcheck.hip.h): process-wide, fires once, -1 disarms
     if (!strcmp(key, "test_fail_after_prelaunch")) {
         g_test_fail_round.store((int)value);
@@ -362,7 +370,8 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "wide_mode")) l->wide_mode = (int)value;
         else if (!strcmp(key, "wt_late_lj")) l->wt_late_lj = (int)value;
         else if (!strcmp(key, "claim_trick")) l->claim_trick = value != 0;
-        else if (!strcmp(key, "host_tail")) l->host_tail = l->host_tail_solo = (int)std::max(0L, std::min(6L, value));
+        else if (!strcmp(key, "host_tail")) l->host_tail = l->host_tail_solo = (int)std::max(0L, std::min((long)kHostTailMax, value));
+        else if (!strcmp(key, "ahead")) l->ahead_mode = (int)value;
         else if (!strcmp(key, "prelaunch")) l->prelaunch = (int)value;
         else if (!strcmp(key, "prelaunch_lg")) l->prelaunch_lg = (int)std::max(0L, std::min(30L, value));
         else if (!strcmp(key, "lookahead")) l->pre_mode = (int)value;
@@ -1567,6 +1576,7 @@ int gkrhip_profile_reset(size_t min_n) {
     g_cnt_spec = 0;
     g_cnt_retries = 0;
     g_cnt_layer_checks = 0;
+    g_cnt_ahead = 0;
     g_cnt_layer_check_failures = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
@@ -2049,6 +2059,7 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "coop_rounds") *value = g_cnt_coop.load();
     else if (n == "spec_rounds") *value = g_cnt_spec.load();
     else if (n == "chal_retries") *value = g_cnt_retries.load();
+    else if (n == "ahead_round0") *value = g_cnt_ahead.load();
     else if (n == "layer_checks") *value = g_cnt_layer_checks.load();
     else if (n == "layer_check_failures") *value = g_cnt_layer_check_failures.load();
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);

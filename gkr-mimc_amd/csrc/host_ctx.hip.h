@@ -15,13 +15,45 @@ static inline double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+// GKRHIP_TRACE: where the host's time goes between the categories of Profile, by named lap (thread-local: one proof traced at a time)
+struct Laps {
+    static const int N = 40;
+    const char* name[N] = {nullptr};
+    double acc[N] = {0};
+    double last = 0;
+    bool on = false;
+    void start() {
+        on = getenv("GKRHIP_TRACE") != nullptr;
+        for (int i = 0; i < N; i++) acc[i] = 0, name[i] = nullptr;
+        last = now_ms();
+    }
+    void lap(const char* what) {
+        if (!on) return;
+        const double t = now_ms();
+        for (int i = 0; i < N; i++) {
+            if (name[i] == what || name[i] == nullptr) {
+                name[i] = what;
+                acc[i] += t - last;
+                break;
+            }
+        }
+        last = t;
+    }
+    void dump() const {
+        if (!on) return;
+        for (int i = 0; i < N && name[i]; i++) fprintf(stderr, "  lap %-38s %8.3f ms\n", name[i], acc[i]);
+    }
+};
+thread_local Laps g_laps;
+#define LAP(what) g_laps.lap(what)
+
 // process-wide counts of the serial-latency paths (gkrhip_profile_latency): rounds whose kernel was queued ahead of its
 // challenge, round-0 launches on look-ahead products, rounds of the cooperative kernel.  Not per lane: the lanes of
 // one-shot calls go back to the pool (and are cleared) before anybody can ask.
 std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0}, g_cnt_spec{0}, g_cnt_retries{0};
 // the prover's own check of every sumcheck it produces (host_sumcheck.hip.h, sumcheck_closes): sumchecks checked, sumchecks
 // that did not close and were run again, and gkrhip_set_option("layer_check", 0 | 1) / ("verify_after_prove", 0 | 1)
-std::atomic<uint64_t> g_cnt_layer_checks{0}, g_cnt_layer_check_failures{0};
+std::atomic<uint64_t> g_cnt_layer_checks{0}, g_cnt_layer_check_failures{0}, g_cnt_ahead{0};
 std::atomic<int> g_layer_check{1}, g_verify_after_prove{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
@@ -156,6 +188,21 @@ struct Ctx {
     const uint4* pre_S = nullptr;
     E pre_ark;
     int pre_m = 0;
+    // round 0 ahead of its point (cipher_round.hip.h, ahead_publish): queued by the layer before, at the start of its host tail
+    int ahead_mode = 1;                        // GKRHIP_AHEAD: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
+    unsigned long long* h_ahead = nullptr;     // host-mapped: 7 * 2^t canonical class sums, then the flag word
+    unsigned long long* d_ahead = nullptr;
+    unsigned long long* d_ahead_racc = nullptr;   // GKR_RACC_SLOTS stripes of GKR_AHEAD_STRIPE words, zero between launches
+    unsigned int* d_ahead_counter = nullptr;
+    DevTable ahead_pyrU, ahead_pyrU2, ahead_pyrTh;   // arena tables, released by pre_release()
+    const uint4* ahead_K = nullptr;            // what the class sums in flight were computed from (valid when ahead_K != nullptr)
+    const uint4* ahead_S = nullptr;
+    E ahead_ark;
+    int ahead_m = 0, ahead_t = 0;
+    unsigned int ahead_seq = 0;
+    std::vector<E> ahead_q;                    // the coordinates it used: q[0 .. m-1-t]
+    const DevTable* nxt_K = nullptr;           // the layer gkr.Prove proves next, when it is a single-point cipher layer (as req_K, but not consumed by launch_pre)
+    const DevTable* nxt_S = nullptr;
     const DevTable* req_K = nullptr;           // look-ahead request of gkr.Prove for the layer it will prove next
     const DevTable* req_S = nullptr;
     E req_ark;
@@ -296,7 +343,7 @@ bool error_lookup(int code, std::string* out) {
     } while (0)
 
 const int kPartialBlocks = 1024;  // max blocks of the partial-evaluation kernel
-const int kHostTailMax = 6;       // the host can take over from 2^6 pairs on (GKRHIP_HOST_TAIL <= 6)
+const int kHostTailMax = 10;      // the host can take over from 2^10 pairs on (GKRHIP_HOST_TAIL <= 10)
 const size_t kTailWords = (size_t)GKR_MAX_ARITY * 4 * 2 * (2 << kHostTailMax);   // up to four tables of 2P entries, P <= 2^(kHostTailMax+1), 4 u64 each
 const int kChalSlots = 3;
 const int kRaccWords = 128;       // shared accumulator / host hand-off buffer: 72 (fused rounds) or up to 81 (nine evaluations) + 16 tail words
@@ -346,13 +393,14 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_SOLO_BOOST")) cx().solo_boost = atoi(e);
     if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
-    if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(6, atoi(e)));   // an explicit setting holds for both
-    if (const char* e = getenv("GKRHIP_HOST_TAIL_SHARDED")) cx().host_tail_sharded = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(kHostTailMax, atoi(e)));   // an explicit setting holds for both
+    if (const char* e = getenv("GKRHIP_HOST_TAIL_SHARDED")) cx().host_tail_sharded = std::max(0, std::min(kHostTailMax, atoi(e)));
     if (const char* e = getenv("GKRHIP_PYR_SPLIT")) cx().pyr_split = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
     if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC")) cx().spec = atoi(e);
+    if (const char* e = getenv("GKRHIP_AHEAD")) cx().ahead_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
@@ -406,9 +454,13 @@ int lane_alloc() {
 // the look-ahead tables go back to the arena (end of a proof, lane teardown)
 void pre_release() {
     if (cx().aux) (void)hipStreamSynchronize(cx().aux);
+    if (cx().ahead_K) (void)hipStreamSynchronize(cx().stream);      // class sums nobody took: their kernel may still be running
     for (auto& t : cx().pre_t) table_release_fwd(&t);
+    for (DevTable* t : {&cx().ahead_pyrU, &cx().ahead_pyrU2, &cx().ahead_pyrTh}) table_release_fwd(t);
     cx().pre_K = cx().pre_S = nullptr;
+    cx().ahead_K = cx().ahead_S = nullptr;
     cx().req_K = cx().req_S = nullptr;
+    cx().nxt_K = cx().nxt_S = nullptr;
 }
 void lane_free() {
     (void)hipStreamSynchronize(cx().stream);
@@ -417,6 +469,11 @@ void lane_free() {
     if (cx().pre_done) (void)hipEventDestroy(cx().pre_done);
     cx().aux = nullptr;
     cx().pre_done = nullptr;
+    if (cx().h_ahead) (void)hipHostFree(cx().h_ahead);
+    if (cx().d_ahead_racc) (void)hipFree(cx().d_ahead_racc);
+    if (cx().d_ahead_counter) (void)hipFree(cx().d_ahead_counter);
+    cx().h_ahead = cx().d_ahead = cx().d_ahead_racc = nullptr;
+    cx().d_ahead_counter = nullptr;
     if (cx().h_chal) (void)hipHostFree(cx().h_chal);
     cx().h_chal = cx().d_chal = nullptr;
     if (cx().d_chal_dev) (void)hipFree(cx().d_chal_dev);
@@ -486,6 +543,7 @@ void lane_configure(Ctx* l) {
     l->pre_start_lg = g0.pre_start_lg;
     l->spec = g0.spec;
     l->spec_lg = g0.spec_lg;
+    l->ahead_mode = g0.ahead_mode;
     l->spec_max_m = g0.spec_max_m;
     l->coop = g0.coop;
     l->coop_lg = g0.coop_lg;

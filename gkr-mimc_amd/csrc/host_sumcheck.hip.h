@@ -314,6 +314,108 @@ void spec_interpolate(const E* cand, const E& r, int j0, E* M) {
     }
 }
 
+// ---- round 0 ahead of its point (cipher_round.hip.h, ahead_publish) -------------------------------------------------
+// buffers of the lane, allocated the first time a proof takes the path
+int ahead_ensure() {
+    if (cx().h_ahead) return 0;
+    HIPCHK(hipHostMalloc(&cx().h_ahead, sizeof(unsigned long long) * GKR_AHEAD_BUF_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&cx().d_ahead, cx().h_ahead, 0));
+    memset(cx().h_ahead, 0, sizeof(unsigned long long) * GKR_AHEAD_BUF_WORDS);
+    HIPCHK(hipMalloc(&cx().d_ahead_racc, sizeof(unsigned long long) * GKR_RACC_SLOTS * GKR_AHEAD_STRIPE));
+    HIPCHK(hipMemsetAsync(cx().d_ahead_racc, 0, sizeof(unsigned long long) * GKR_RACC_SLOTS * GKR_AHEAD_STRIPE, cx().stream));      // stream-ordered: see lane_alloc
+    HIPCHK(hipMalloc(&cx().d_ahead_counter, 64));
+    HIPCHK(hipMemsetAsync(cx().d_ahead_counter, 0, 64, cx().stream));
+    return 0;
+}
+inline volatile unsigned int* ahead_flag() { return (volatile unsigned int*)(cx().h_ahead + GKR_AHEAD_FLAG_WORD); }
+// eq(q[0:n], .) over 2^n entries, q[0] <-> the most significant index bit (poly/eq.go:41-59)
+inline void eq_table_host(const E* q, int n, std::vector<E>& W) {
+    W.assign((size_t)1 << n, hfr::ZERO);
+    W[0] = hfr::ONE;
+    for (int i = 0; i < n; i++)
+        for (size_t t = 0; t < ((size_t)1 << i); t++) {
+            const size_t J = t << (n - i), JN = J + ((size_t)1 << (n - 1 - i));
+            W[JN] = hfr::mul(q[i], W[J]);
+            W[J] = hfr::sub(W[J], W[JN]);
+        }
+}
+// Queue round 0 of the layer gkr.Prove proves next (cx().nxt_*), whose point is THIS layer's challenges: chal[0 .. k_known]
+// exist, the last t = m - 1 - k_known are still to come (this layer's host tail).  Called where the host tail starts; the
+// stream is idle from here to the end of the layer.  The products of k_cipher_pre are used when they exist for that layer.
+int ahead_launch(int m, const E* chal, int k_known, bool solo) {
+    const DevTable* K = cx().nxt_K;
+    const DevTable* S = cx().nxt_S;
+    const int t = m - 1 - k_known;
+    if (!K || !S || cx().req_m != m || t < 1 || t > GKR_AHEAD_TMAX || !cx().wide_mode) return 0;
+    const int g_m = round_threads_log2_max();
+    const int g = std::min(solo ? std::min(g_m + 1, 17) : g_m, m - 2);      // threads = 2^g, at least two pairs per lane
+    if (g < t || g < 8) return 0;
+    const int lj = m - 1 - g;
+    CHK(ahead_ensure());
+    for (auto tc : {std::make_pair(&cx().ahead_pyrU, (size_t)2 << lj), std::make_pair(&cx().ahead_pyrU2, (size_t)2 << lj),
+                    std::make_pair(&cx().ahead_pyrTh, (size_t)2 << (g - t))})
+        if (tc.first->cap != tc.second) {
+            if (tc.first->base) table_release(tc.first);
+            CHK(table_alloc(tc.first, tc.second));
+        }
+    CHK(stage_coords(chal, (size_t)(m - t)));
+    PyramidArgs3 pa3;
+    memset(&pa3, 0, sizeof pa3);
+    for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
+    pa3.p[0].out = cx().ahead_pyrTh.planes();      // lane weight over the known low bits: level g - t = eq(q[m-g .. m-t-1], gtid >> t)
+    pa3.p[0].out2 = Planes{nullptr, nullptr};
+    pa3.p[0].q = cx().d_q;
+    pa3.p[0].nc = m - t;
+    pa3.p[0].max_level = g - t;
+    pa3.p[0].seed = to_dev(hfr::ONE);
+    pa3.p[1].out = cx().ahead_pyrU.planes();       // iteration weight: level lj = eq(q[1 .. m-g-1], j)
+    pa3.p[1].out2 = cx().ahead_pyrU2.planes();
+    pa3.p[1].q = cx().d_q;
+    pa3.p[1].nc = m - g;
+    pa3.p[1].max_level = lj;
+    pa3.p[1].seed = to_dev(hfr::ONE);
+    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(g - t, lj), 1 << 20), 2), dim3(GKR_BLOCK), 0, cx().stream, pa3);
+    HIPCHK(hipGetLastError());
+    CipherRoundArgs a;
+    memset(&a, 0, sizeof a);
+    a.k_src = K->cplanes();
+    a.s_src = S->cplanes();
+    const size_t offT = ((size_t)1 << (g - t)) - 1, offU = ((size_t)1 << lj) - 1;
+    a.wt = CPlanes{cx().ahead_pyrTh.base + offT, cx().ahead_pyrTh.base + cx().ahead_pyrTh.cap + offT};
+    a.wj = CPlanes{cx().ahead_pyrU.base + offU, cx().ahead_pyrU.base + cx().ahead_pyrU.cap + offU};
+    a.wj2 = CPlanes{cx().ahead_pyrU2.base + offU, cx().ahead_pyrU2.base + cx().ahead_pyrU2.cap + offU};
+    a.P = (size_t)1 << (m - 1);
+    a.lg_threads = (unsigned)g;
+    a.ark = to_dev(cx().req_ark);
+    a.partials = cx().d_ahead_racc;
+    a.counter = cx().d_ahead_counter;
+    a.host_out = cx().d_ahead;
+    a.host_flag = (unsigned int*)(cx().d_ahead + GKR_AHEAD_FLAG_WORD);
+    a.seq = cx().ahead_seq = ++cx().seq;
+    a.need_m0 = 0;
+    a.ahead_t = (unsigned)t;
+    const bool pre = cx().pre_K && cx().pre_K == K->base && cx().pre_S == S->base && cx().pre_m == m && cx().pre_ark == cx().req_ark;
+    const int grid = (int)(((size_t)1 << g) / GKR_BLOCK);
+    if (pre) {
+        HIPCHK(hipStreamWaitEvent(cx().stream, cx().pre_done, 0));
+        for (int i = 0; i < 6; i++) a.pre[i] = cx().pre_t[i].cplanes();
+        cx().pre_K = cx().pre_S = nullptr;             // consumed
+        hipLaunchKernelGGL((k_cipher_round_wide<false, true, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+        g_cnt_lookahead.fetch_add(1, std::memory_order_relaxed);
+    } else {
+        hipLaunchKernelGGL((k_cipher_round_wide<false, true, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    cx().ahead_K = K->base;
+    cx().ahead_S = S->base;
+    cx().ahead_ark = cx().req_ark;
+    cx().ahead_m = m;
+    cx().ahead_t = t;
+    cx().ahead_q.assign(chal, chal + (m - t));
+    cx().nxt_K = cx().nxt_S = nullptr;
+    return 0;
+}
+
 // ---- the skeleton the two fused round loops share -------------------------------------------------------------------
 // cipher_rounds and linear_rounds differ in their kernels, in how a round's sums become coefficients and in what the host
 // tail computes; everything else -- which rounds run on the device, which kernel is queued ahead of its challenge, the
@@ -406,8 +508,15 @@ int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
     {
         const double t_l0 = now_ms();
         cx().prof.setup_ms += t_l0 - t_setup0;
-        CHK(lp.launch_round(0, false, hfr::ZERO, lp.claim && *lp.claim_known, &cur));
+        if (lp.ahead_round0()) {      // round 0's sums were queued by the layer before this one (ahead_launch): nothing to launch
+            cur.tg = round_targets(collective);
+            cur.seq = cx().ahead_seq;
+            cur.derive_m0 = true;
+        } else {
+            CHK(lp.launch_round(0, false, hfr::ZERO, lp.claim && *lp.claim_known, &cur));
+        }
         cx().prof.host_launch_ms += now_ms() - t_l0;
+        LAP("rounds: launch round 0");
     }
     bool pre_requested = cx().req_K != nullptr && pl.pre_on;
     for (int k = 0; k < pl.m_dev; k++) {
@@ -452,6 +561,10 @@ int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
         if (this_spec) {
             CHK(wait_flag(lp.spec_seq[k], lp.spec_flag(k)));
             if (corrupt) cx().h_spec[(size_t)(k & 1) * GKR_SPEC_BUF_WORDS + 4] ^= 1ull;      // candidate 0's M_1
+        } else if (k == 0 && lp.ahead_round0()) {
+            CHK(wait_flag(cx().ahead_seq, ahead_flag()));
+            if (corrupt) cx().h_ahead[0] ^= 1ull;                                               // S_1(0)
+            g_cnt_ahead.fetch_add(1, std::memory_order_relaxed);
         } else {
             g_corrupt_collect = corrupt;
             CHK(round_collect(collective, cur.tg, cur.seq, L::NSUM, L::NTAIL, summed, &sums));
@@ -505,7 +618,12 @@ int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
     if (pre_requested) CHK(launch_pre());      // no round was small enough: still ahead of the next layer's pyramids
     lp.r_last = r_prev;
     const double t_end0 = now_ms();
-    HIPCHK(hipStreamSynchronize(cx().stream));
+    LAP("rounds: the loop");
+    // Un-sharded, every kernel this loop queued has been waited for through its own flag, which its LAST workgroup raises after
+    // all workgroups have arrived with their stores drained (publish_sums): nothing of the layer is running or has memory
+    // traffic in flight, the scratch tables can go back to the arena without a stream synchronisation (19 us per layer).
+    if (collective) HIPCHK(hipStreamSynchronize(cx().stream));
+    LAP("rounds: final synchronize");
     cx().racc_dirty = false;
     cx().prof.setup_ms += now_ms() - t_end0;
     (void)m;
@@ -541,6 +659,8 @@ struct CipherLoop {
     ChalGuard chal_guard;
     std::vector<unsigned int> spec_seq;              // by round
     bool coop_on = false;
+    bool use_ahead = false;                          // round 0's class sums are in flight (queued by the layer before)
+    bool ahead_round0() const { return use_ahead; }
 
     CipherLoop(const E& ark_, int m_, const DevTable* K_, const DevTable* S_, const E* q_, const E& seed_, bool collective_, E& c_, E* proof_,
                E* chal_, E* tail_, E& r_last_, E* claim_, bool* claim_known_, int gamma_tail_, bool* did_gamma_)
@@ -565,12 +685,20 @@ struct CipherLoop {
 
     // pyramids (the eq weights, never a table of 2^m entries), scratch tables, accumulators, the plan of the rounds
     int setup() {
+        // class sums of this layer's round 0 queued by the layer before (ahead_launch): they are ours if they were computed from
+        // these tables, this Ark and the first m - t coordinates of this point; taken or not, they are spent
+        use_ahead = cx().ahead_K && cx().ahead_K == K->base && cx().ahead_S == S->base && cx().ahead_m == m && cx().ahead_ark == ark &&
+                    !collective && !g_safe_mode && claim && *claim_known && seed == hfr::ONE &&
+                    memcmp(q, cx().ahead_q.data(), sizeof(E) * (size_t)(m - cx().ahead_t)) == 0;
+        cx().ahead_K = cx().ahead_S = nullptr;
         const bool solo = cx().solo_boost && !collective &&
                           (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
         g_m = round_threads_log2_max();                // fixed for the layer: the number of proofs in flight may change under it
         g_big = solo ? std::min(g_m + 1, 17) : g_m;
         const int gT = std::max(threads_log2(0), std::min(g_m, m - 1));   // highest level of the per-lane pyramid
+        LAP("setup: enter");
         CHK(stage_coords(q, (size_t)m));
+        LAP("setup: stage_coords");
         gsplit[0] = std::min(g_m, m - 1);
         gsplit[1] = g_big;
         CHK(table_alloc(&pyrT, (size_t)2 << gT));
@@ -614,6 +742,7 @@ struct CipherLoop {
                 widest = std::max(widest, mU);
             }
         }
+        LAP("setup: table allocs");
         hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 4), dim3(GKR_BLOCK), 0, cx().stream, pa3);
         HIPCHK(hipGetLastError());
         if (gLow < gT) {
@@ -625,9 +754,11 @@ struct CipherLoop {
             hipLaunchKernelGGL(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
             HIPCHK(hipGetLastError());
         }
+        LAP("setup: pyramid launches");
         CHK(rounds_begin(collective));
         pl = plan_rounds(m, collective, gamma_tail, did_gamma, 2, g_proofs_in_flight.load(std::memory_order_relaxed) <= 1 ? cx().host_tail_solo : cx().host_tail);
         if (pl.pre_on) CHK(pre_prepare());               // nothing of this lane is waiting for the host yet
+        LAP("setup: begin, plan, pre_prepare");
         coop_on = cx().coop >= 2 || (cx().coop == 1 && pl.alone);
         plan_speculation(pl, true, [&](int k) { return threads_log2(k) == m - 1 - k; });
         if (pl.k_s >= 0) {
@@ -637,6 +768,7 @@ struct CipherLoop {
                 CHK(table_alloc(&ss2, (size_t)4 << (m - 1 - (pl.k_s + 1))));
             }
         }
+        LAP("setup: speculation tables");
         return 0;
     }
 
@@ -782,7 +914,18 @@ struct CipherLoop {
     void coefficients(int k, bool this_spec, bool derive_m0, const unsigned long long* sums, E* co) const {
         static const hfr::u64 binom7[8] = {1, 7, 21, 35, 35, 21, 7, 1};
         E csp[8], Mj[8];
-        if (this_spec) {     // the candidates at the true r_{k-1}
+        if (k == 0 && use_ahead) {
+            // M_j = sum_y eq(q[m-t:], y) S_j(y): the class sums contracted with the coordinates the layer before drew last
+            const int t = cx().ahead_t;
+            std::vector<E> Wy;
+            eq_table_host(q + (m - t), t, Wy);
+            const E* S_ = (const E*)cx().h_ahead;
+            for (int j = 1; j < 8; j++) {
+                E acc = hfr::ZERO;
+                for (size_t y = 0; y < Wy.size(); y++) acc = hfr::add(acc, hfr::mul(Wy[y], S_[((size_t)(j - 1) << t) + y]));
+                Mj[j] = acc;
+            }
+        } else if (this_spec) {     // the candidates at the true r_{k-1}
             spec_interpolate((const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS), chal[k - 1], derive_m0 ? 1 : 0, Mj);
         } else {
             for (int j = derive_m0 ? 1 : 0; j < 8; j++) Mj[j] = limbs9_to_fr(sums + (size_t)j * GKR_ACC_WORDS);
@@ -826,6 +969,9 @@ struct CipherLoop {
             }
         }
         const int mm = m - 1 - k;                  // variables left
+        // the host tail starts: the GPU has nothing more to do for this layer -- round 0 of the next one, ahead of its last coordinates
+        if (!collective && !g_safe_mode && claim && (cx().ahead_mode >= 2 || (cx().ahead_mode == 1 && pl.alone)))
+            CHK(ahead_launch(m, chal, k, g_big > g_m));
         const double t_t0 = now_ms(), h_before = cx().prof.host_hash_ms;
         if (pl.sh_tail) {
             // gather every rank's P + P folded entries; global index = local index * world + rank (the shard bits are
@@ -868,6 +1014,7 @@ int cipher_rounds(const E& ark, int m, const DevTable* K, const DevTable* S, con
     CHK(lp.setup());
     CHK(run_rounds(lp, lp.pl, t_setup0));
     lp.release_tables();      // (scoped tables: an error return releases them too, after draining the stream)
+    LAP("rounds: release tables");
     return 0;
 }
 
@@ -1029,6 +1176,7 @@ struct LinearLoop {
     volatile unsigned int* spec_flag(int k) const {
         return (volatile unsigned int*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS + GKR_SPEC_FLAG_WORD);
     }
+    bool ahead_round0() const { return false; }
 
     void release_tables() {
         table_release(&pyrT);
@@ -1206,6 +1354,9 @@ struct LinearLoop {
             for (int t = 0; t < arity; t++)
                 for (size_t x = 0; x < P; x++) Th[t][x] = fold2(tt[(size_t)t * 2 * P + x], tt[(size_t)t * 2 * P + x + P], r);
         }
+        // (as CipherLoop::finish_round: round 0 of the next layer, when that is a cipher layer, ahead of its last coordinates)
+        if (!collective && !g_safe_mode && claim && (cx().ahead_mode >= 2 || (cx().ahead_mode == 1 && pl.alone)))
+            CHK(ahead_launch(m, chal, k, cx().solo_boost && pl.alone));
         if (pl.sh_tail) {
             const ShardView sv = shard_view();
             std::vector<E> mine((size_t)arity * P), all;
@@ -1359,7 +1510,11 @@ int sumcheck_prove_once(int gate, const E& ark_in, int arity, int bN, const DevT
     std::vector<E> seeds(nq, hfr::ONE);
     int nq_used = 1;
     if (nclaims >= 1) {
-        const E rho = hfr::mimc_hash(claims, (size_t)nclaims);  // computed even when unused, as the reference
+        LAP("once: gate_resolve etc");
+        // (the reference draws it for a single claim too, sumcheck/prover.go:128, and never uses it: nothing observable depends on
+        // it, and it is 364 serial products per layer on the critical path)
+        const E rho = (nclaims > 1 || nq > 1) ? hfr::mimc_hash(claims, (size_t)nclaims) : hfr::ZERO;
+        LAP("once: rho hash");
         *rho_out = rho;
         E mlt = rho;
         for (int j = 1; j < nq; j++) {
@@ -1464,7 +1619,9 @@ int sumcheck_prove_dev(int gate, const E& ark_in, int arity, int bN, const DevTa
     const E ark = gate == GKRHIP_GATE_IDENTITY ? hfr::ZERO : ark_in;
     const int nq_used = nclaims >= 1 ? nq : 1;
     g_cnt_layer_checks.fetch_add(1, std::memory_order_relaxed);
+    LAP("checked: before the check");
     int bad = sumcheck_closes(g, ark, bN, qprimes, nq_used, claims, nclaims, trust_claims, rho, proof, challenges, final_claims);
+    LAP("checked: sumcheck_closes");
     if (!bad) return 0;
     g_cnt_layer_check_failures.fetch_add(1, std::memory_order_relaxed);
     if (getenv("GKRHIP_TRACE")) fprintf(stderr, "sumcheck (gate %s, bN %d) does not close (%d): running it again in safe mode\n", g.id.c_str(), bN, bad);

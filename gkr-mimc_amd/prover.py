@@ -879,7 +879,9 @@ def profile_get():
     lc, lf = C.c_uint64(0), C.c_uint64(0)
     _check(load().gkrhip_profile_counter(b"layer_checks", C.byref(lc)))
     _check(load().gkrhip_profile_counter(b"layer_check_failures", C.byref(lf)))
-    return {"layer_checks": lc.value, "layer_check_failures": lf.value, "spec_rounds": sp.value, "chal_retries": rt.value, "fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
+    ah = C.c_uint64(0)
+    _check(load().gkrhip_profile_counter(b"ahead_round0", C.byref(ah)))
+    return {"ahead_round0": ah.value, "layer_checks": lc.value, "layer_check_failures": lf.value, "spec_rounds": sp.value, "chal_retries": rt.value, "fold_launches": fl.value, "fold_ms": fm.value, "fold_bytes": fb.value,
             "peval_launches": pl.value, "peval_ms": pm.value, "peval_modmuls": pmm.value,
             "rounds": r.value, "host_hash_ms": hh.value, "host_wait_ms": hw.value, "host_launch_ms": hl.value,
             "host_other_ms": ho.value, "prelaunched_rounds": a.value, "lookahead_round0": b.value, "coop_rounds": c.value}

@@ -540,6 +540,24 @@ def test_lookahead_round0(gk):
     _run_case({"GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT": "lookahead_round0,prelaunched_rounds"}, "12")   # the defaults, alone on the GPU
 
 
+def test_round0_ahead_of_its_point(gk):
+    """Round 0 of a cipher layer queued by the layer before it, at the start of that layer's host tail, when the last t
+    coordinates of its point do not exist yet (k_cipher_round_wide<false, true, ., true>: class sums over the low t index bits,
+    contracted on the host): same transcript with early and late host tails (t = 2 .. 6), small and large thread budgets, with
+    and without the products of k_cipher_pre, MiMC and GMiMC circuits, forced for every lane, and switched off."""
+    on = {"GKRHIP_AHEAD": "2", "GKRHIP_CASE_EXPECT": "ahead_round0"}
+    _run_case(dict(on, GKRHIP_GMAX="8"), "11,12,14,15")
+    _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_PRE="2", GKRHIP_CASE_EXPECT="ahead_round0,lookahead_round0"), "11,13")
+    _run_case(dict(on, GKRHIP_GMAX="10", GKRHIP_PRE="0"), "13,16")
+    for h in ("1", "2", "3", "5"):
+        _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_HOST_TAIL=h), "11,12")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="6", GKRHIP_CASE_EXPECT=""), "12,17")          # t = 7: not taken
+    _run_case(dict(on, GKRHIP_GMAX="9", GKRHIP_PRELAUNCH="0", GKRHIP_SPEC="0", GKRHIP_COOP="0"), "12,14")
+    _run_case(dict(on, GKRHIP_GMAX="8"), "11,12", circuit="gmimc")
+    _run_case({"GKRHIP_AHEAD": "0", "GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT_NOT": "ahead_round0"}, "11,13")
+    _run_case({"GKRHIP_CASE_EXPECT": "ahead_round0,prelaunched_rounds"}, "19")   # the defaults, alone on the GPU
+
+
 def test_round_kernel_deferred_reduction_carry_corners(gk):
     """Tables made of the carry-corner values (limbs of 0xFFFFFFFF, q-1, 0, 1) through gkr.Prove with a small
     thread budget, so that every lane accumulates many wide products of extreme operands."""
