@@ -99,6 +99,79 @@ int session_assign(gkrhip_session* s) {  // circuit/assignment.go:12-32
     return 0;
 }
 
+// The upload of the input tables and Circuit.Assign in one pipeline (what GkrProverHint.Call runs before Prove,
+// prover/gadget/hints.go:219-220).  Every layer is element-wise, so the tables are cut into slices: while slice i's layers
+// run, slice i + 1 crosses PCIe on the lane's second stream (and its pageable source is staged by this thread) -- the ~45 ms
+// of upload at bN = 24 hide behind the ~46 ms of the 91 layers instead of preceding them.
+int session_load_assign_sliced(gkrhip_session* s, const uint64_t* const* host, int n_in) {
+    const size_t n = s->n;
+    const int S = n >= ((size_t)1 << 22) ? 8 : n >= ((size_t)1 << 20) ? 4 : 1;
+    if (S == 1 || n_in > GKR_MAX_ARITY * 2) {
+        for (int k = 0; k < n_in; k++) CHK(upload_table(&s->a[k], host[k], n));
+        s->have_inputs = true;
+        return session_assign(s);
+    }
+    const size_t cnt = n / S;
+    if (!cx().aux) {
+        HIPCHK(hipStreamCreateWithFlags(&cx().aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
+    }
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() {
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        }
+    } up, tr;
+    up.ev.resize(S, nullptr);
+    tr.ev.resize(2, nullptr);
+    for (auto& e : up.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : tr.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::vector<ScopedTable> stage((size_t)2 * n_in);       // AoS staging of one slice per input, two sets
+    for (auto& t : stage) CHK(table_alloc(&t, cnt));
+    struct Drain {                                           // an error return must not leave copies in flight into the staging tables
+        ~Drain() { (void)hipStreamSynchronize(cx().aux); }
+    } drain;
+    const bool regular = g_regular_io;
+    for (int sl = 0; sl < S; sl++) {
+        const size_t off = (size_t)sl * cnt;
+        const int set = sl & 1;
+        if (sl >= 2) HIPCHK(hipStreamWaitEvent(cx().aux, tr.ev[set], 0));      // the transposition of slice sl - 2 has read this staging set
+        for (int k = 0; k < n_in; k++)
+            HIPCHK(hipMemcpyAsync(stage[(size_t)set * n_in + k].base, host[k] + 4 * off, 32 * cnt, hipMemcpyHostToDevice, cx().aux));
+        HIPCHK(hipEventRecord(up.ev[sl], cx().aux));
+        HIPCHK(hipStreamWaitEvent(cx().stream, up.ev[sl], 0));
+        for (int k = 0; k < n_in; k++) {
+            const Planes dst{s->a[k].base + off, s->a[k].base + s->a[k].cap + off};
+            if (regular)
+                hipLaunchKernelGGL(k_aos_to_planes<true>, dim3(grid_for(cnt, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream,
+                                   stage[(size_t)set * n_in + k].base, dst, cnt, cx().d_bad, to_dev(hfr::R2));
+            else
+                hipLaunchKernelGGL(k_aos_to_planes<false>, dim3(grid_for(cnt, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream,
+                                   stage[(size_t)set * n_in + k].base, dst, cnt, cx().d_bad, to_dev(hfr::ZERO));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(tr.ev[set], cx().stream));
+        for (size_t l = 0; l < s->c.size(); l++) {           // circuit/assignment.go:12-32 on the slice
+            const Layer& lay = s->c[l];
+            if (lay.gate < 0 || s->alias[l] != (int)l) continue;
+            const DevTable* in[GKR_MAX_ARITY];
+            for (size_t k = 0; k < lay.in.size(); k++) in[k] = session_table(s, lay.in[k]);
+            CHK(gate_eval_dev(lay.gate, lay.ark, in, (int)lay.in.size(), &s->a[l], cnt, off));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    if (*(volatile unsigned int*)cx().h_bad) {
+        *cx().h_bad = 0;
+        return fail(regular ? "input table holds a value that is not below q"
+                            : "input table holds an element that is not a canonical fr.Element (limbs >= q)");
+    }
+    for (auto& t : stage) table_release(&t);
+    s->have_inputs = true;
+    s->inputs_loaded = ~0ull;
+    s->assigned = true;
+    return 0;
+}
+
 int session_prove(gkrhip_session* s, const E* qprime, E* flat) {  // gkr/prover.go:21-91
     if (!s->assigned) return fail("session is not assigned");
     ProofInFlight in_flight;
@@ -695,6 +768,11 @@ static int session_create_for(gkrhip_session** out, const Circuit& circ, int bN)
     std::lock_guard<std::mutex> lk((s)->lane->mu);        \
     UseLane ul((s)->lane)
 
+static int session_load_assign(gkrhip_session* s, const uint64_t* const* host, int n_in) {
+    SESSION_ENTER(s);
+    return session_load_assign_sliced(s, host, n_in);
+}
+
 int gkrhip_mimc_session_load_inputs(gkrhip_session* s, const uint64_t* in0, const uint64_t* in1) {
     SESSION_ENTER(s);
     if (s->c.size() < 2 || s->c[0].gate >= 0 || s->c[1].gate >= 0 || (s->c.size() > 2 && s->c[2].gate < 0))
@@ -804,9 +882,12 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
     gkrhip_session* s = nullptr;
     CHK(gkrhip_mimc_session_create(&s, bN));
     const double t_c = now_ms();
-    int rc = gkrhip_mimc_session_load_inputs(s, in0, in1);
+    int rc;
+    {
+        const uint64_t* ins[2] = {in0, in1};
+        rc = session_load_assign(s, ins, 2);
+    }
     const double t_l = now_ms();
-    if (rc == 0) rc = gkrhip_mimc_session_assign(s);
     if (trace && rc == 0) (void)hipStreamSynchronize(s->lane->stream);
     const double t_a = now_ms();
     // The output table is final once the assignment is: its download (transposition + 2^bN x 32 bytes over PCIe into
@@ -883,8 +964,7 @@ int gkrhip_gkr_prove(const gkrhip_layer* layers, int n_layers, int bN, const uin
     CHK(gkrhip_session_create(&s, layers, n_layers, bN));
     int rc = 0;
     if (gkrhip_session_num_inputs(s) != n_inputs) rc = fail("gkr.Prove: the circuit has %d input layers, %d tables were given", gkrhip_session_num_inputs(s), n_inputs);
-    for (int k = 0; k < n_inputs && rc == 0; k++) rc = gkrhip_session_load_input(s, k, inputs[k]);
-    if (rc == 0) rc = gkrhip_mimc_session_assign(s);
+    if (rc == 0) rc = session_load_assign(s, inputs, n_inputs);
     if (rc == 0) rc = gkrhip_mimc_session_prove(s, qprime, flat);
     if (rc == 0 && g_verify_after_prove.load(std::memory_order_relaxed)) {      // see prove_mimc_oneshot
         rc = gkrhip_mimc_session_verify(s, qprime, flat);

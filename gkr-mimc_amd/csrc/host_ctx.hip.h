@@ -180,7 +180,7 @@ struct Ctx {
     double dbg_defer_ms = 0;
     E spec_pts[8];                             // Montgomery forms of the candidate points 0..7
     E spec_invden[8];                          // 1 / prod_{j != i} (i - j): Lagrange denominators on the points 0..7
-    int pre_start_lg = 16;                     // the look-ahead kernel is queued when the layer's rounds reach 2^n pairs
+    int pre_start_lg = 20;                     // the look-ahead kernel is queued when the layer's rounds reach 2^n pairs (16 before round 0 ran ahead of its point: its products are now wanted at the START of the host tail; bN = 24 alone 269.3 -> 262.1 ms, bN = 22 137.5 -> 134.9)
     hipStream_t aux = nullptr;                 // stream of the look-ahead kernel (normal priority: see pre_prepare)
     hipEvent_t pre_done = nullptr;
     DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()

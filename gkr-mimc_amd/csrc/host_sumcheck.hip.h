@@ -455,6 +455,10 @@ inline RoundPlan plan_rounds(int m, bool collective, int gamma_tail, bool* did_g
     p.m_dev = p.h_tail ? p.k_export + 1 : m;
     p.pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && p.alone));
     p.pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && p.alone));
+    // with round 0 running ahead of its point during the host tail (ahead_launch) the look-ahead products only pay from 2^22 entries
+    // on: below, the whole round 0 fits the tail (bN = 18 / 20 / 21 alone: 75.9 / 92.9 / 107.7 ms without against 77.0 / 93.8 / 108.9 with
+    // the products; bN = 22: 140.0 against 136.4)
+    if (cx().pre_mode == 1 && !collective && m < 22 && p.h_tail > 0 && (cx().ahead_mode >= 2 || (cx().ahead_mode == 1 && p.alone))) p.pre_on = false;
     return p;
 }
 // Speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the candidate values of r_{k-1} while the host hashes
@@ -916,6 +920,7 @@ struct CipherLoop {
         E csp[8], Mj[8];
         if (k == 0 && use_ahead) {
             // M_j = sum_y eq(q[m-t:], y) S_j(y): the class sums contracted with the coordinates the layer before drew last
+            LAP("ahead: before contraction");
             const int t = cx().ahead_t;
             std::vector<E> Wy;
             eq_table_host(q + (m - t), t, Wy);
@@ -925,6 +930,7 @@ struct CipherLoop {
                 for (size_t y = 0; y < Wy.size(); y++) acc = hfr::add(acc, hfr::mul(Wy[y], S_[((size_t)(j - 1) << t) + y]));
                 Mj[j] = acc;
             }
+            LAP("ahead: contraction");
         } else if (this_spec) {     // the candidates at the true r_{k-1}
             spec_interpolate((const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS), chal[k - 1], derive_m0 ? 1 : 0, Mj);
         } else {
@@ -1643,13 +1649,14 @@ template <int POWER, int ARITY>
 void launch_gate_eval(const AssignArgs& a) {
     hipLaunchKernelGGL((k_gate_eval_batch<POWER, ARITY>), dim3(grid_for(a.n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, a);
 }
-int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, const DevTable* out, size_t n) {
+// (off, n): the slice of the tables the launch covers -- every layer of Circuit.Assign is element-wise (circuit/circuit.go:48-64)
+int gate_eval_dev(int gate, const E& ark, const DevTable* const* in, int arity, const DevTable* out, size_t n, size_t off = 0) {
     GateDesc g;
     CHK(gate_resolve(gate, arity, &g));
     AssignArgs a;
     memset(&a, 0, sizeof a);
-    for (int k = 0; k < arity; k++) a.in[k] = in[k]->cplanes();
-    a.out = out->planes();
+    for (int k = 0; k < arity; k++) a.in[k] = CPlanes{in[k]->base + off, in[k]->base + in[k]->cap + off};
+    a.out = Planes{out->base + off, out->base + out->cap + off};
     a.arity = arity;
     a.mask = g.mask;
     a.n = n;

@@ -334,17 +334,23 @@ def mimc_proof_len(bN):
     return load().gkrhip_mimc_proof_len(bN)
 
 
-def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True, regular=False):
+def gkr_prove_mimc(in0, in1, q_prime, want_outputs=True, regular=False, out=None):
     """Circuit.Assign(in0, in1) + gkr.Prove(MimcCircuit, a, qPrime); returns (flat proof, outputs).  regular=True: every
     buffer holds regular-form values (the hint interface's big.Int words) instead of Montgomery fr.Elements.  With a
-    communicator installed in0/in1/outputs are this rank's shard and bN (= len(q_prime)) is the global size."""
+    communicator installed in0/in1/outputs are this rank's shard and bN (= len(q_prime)) is the global size.
+    out=(flat, outputs): caller-allocated result arrays, as the hint's pre-allocated `oups` (prover/gadget/hints.go:197)."""
     in0, in1 = _fr(in0), _fr(in1)
     n = in0.shape[0]
     q_prime = _fr(q_prime).reshape(-1, 4)
     bN = q_prime.shape[0] if q_prime.shape[0] else n.bit_length() - 1
     assert n & (n - 1) == 0 and n <= 1 << bN and in1.shape[0] == n
-    flat = np.zeros((mimc_proof_len(bN), 4), np.uint64)
-    outs = np.zeros((n, 4), np.uint64) if want_outputs else None
+    if out is not None:
+        flat, outs = out
+        assert flat.shape == (mimc_proof_len(bN), 4) and flat.dtype == np.uint64 and flat.flags.c_contiguous
+        assert outs is None or (outs.shape == (n, 4) and outs.dtype == np.uint64 and outs.flags.c_contiguous)
+    else:
+        flat = np.zeros((mimc_proof_len(bN), 4), np.uint64)
+        outs = np.zeros((n, 4), np.uint64) if want_outputs else None
     fn = load().gkrhip_gkr_prove_mimc_regular if regular else load().gkrhip_gkr_prove_mimc
     _check(fn(bN, _ptr(in0), _ptr(in1), _ptr(q_prime) if bN else None, _ptr(flat), _ptr(outs)))
     return flat, outs

@@ -537,7 +537,10 @@ def test_lookahead_round0(gk):
     _run_case(dict(on, GKRHIP_WT_LATE_LJ="1", GKRHIP_SOLO_BOOST="0", GKRHIP_PRELAUNCH="0"), "10,12")
     _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "11,12", circuit="gmimc")
     _run_case({"GKRHIP_PRE": "0", "GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT_NOT": "lookahead_round0"}, "11,13")
-    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT": "lookahead_round0,prelaunched_rounds"}, "12")   # the defaults, alone on the GPU
+    # the defaults, alone on the GPU: below 2^22 entries round 0 runs AHEAD of its point during the previous layer's host tail
+    # and the products are not computed (plan_rounds); from 2^22 on both (the bN = 22 / 24 digest tests take that path)
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT": "ahead_round0,prelaunched_rounds", "GKRHIP_CASE_EXPECT_NOT": "lookahead_round0"}, "12")
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_AHEAD": "0", "GKRHIP_CASE_EXPECT": "lookahead_round0,prelaunched_rounds"}, "12")
 
 
 def test_round0_ahead_of_its_point(gk):
@@ -1107,6 +1110,37 @@ def test_gkr_bn22_accepted_by_oracle_verifier(gk):
     bad = flat.copy()
     bad[12345, 1] ^= np.uint64(4)
     assert c.gkr_verify_mimc(bn, bad, i0, i0, outs, qp) != 0
+
+
+@pytest.mark.parametrize("bn", [20, 22])
+def test_oneshot_upload_and_assignment_in_slices(gk, bn):
+    """gkrhip_gkr_prove_mimc on host buffers from 2^20 entries on: the inputs cross PCIe in slices on the lane's second stream
+    while the 91 element-wise layers of Circuit.Assign run on the slices that have landed (4 slices at bN = 20, 8 at 22).
+    Transcript and output table against the committed digests of the C oracle; in1 != in0 and the regular-form variant
+    against the session path (whole-table upload, whole-table layers)."""
+    want = [e for e in load("gkr_mimc_big_digests.json") if e["bn"] == bn][0]
+    i0 = c.random_fr_array(1 << bn)
+    qp = c.random_fr_array(bn)
+    flat, outs = gk.gkr_prove_mimc(i0, i0.copy(), qp)
+    assert hashlib.sha256(flat.astype("<u8").tobytes()).hexdigest() == want["sha256_flat"]
+    assert hashlib.sha256(outs.astype("<u8").tobytes()).hexdigest() == want["sha256_outputs"]
+    if bn > 20:
+        return
+    i1 = i0[::-1].copy()
+    i1[12345] = nasty(1, 7)[0]
+    s = gk.MimcSession(bn)
+    s.load_inputs(i0, i1)
+    s.assign()
+    sflat, souts = s.prove(qp), s.outputs()
+    s.close()
+    flat, outs = gk.gkr_prove_mimc(i0, i1, qp)
+    assert np.array_equal(flat, sflat) and np.array_equal(outs, souts)
+    bad = i1.copy()
+    bad[(1 << bn) - 3] = np.array([0xFFFFFFFFFFFFFFFF] * 4, dtype=np.uint64)      # not a canonical element, in the last slice
+    with pytest.raises(gk.GkrHipError):
+        gk.gkr_prove_mimc(i0, bad, qp)
+    flat2, _ = gk.gkr_prove_mimc(i0, i1, qp)                                        # the lane is usable afterwards
+    assert np.array_equal(flat2, sflat)
 
 
 # ---------------------------------------------------------------- verifier and wire-format helpers
