@@ -427,13 +427,23 @@ def orchestrate(args):
         # pass NEEDS one queue per lane stream: the collective kernels of different lanes must be able to run side by side,
         # whatever order the ranks issue them in
         env.setdefault("GPU_MAX_HW_QUEUES", "16")
+        # First contact with a real multi-rank communicator happens on the driver's 8-GPU node, where nobody can re-run by hand:
+        # RCCL's own warnings (silent unless something fails) are captured with the child's stderr and, if the pass fails, their
+        # tail goes into the JSON line (passes.<name>.rccl_log) instead of only "invalid usage"
+        if name.startswith("rccl") and env.get("NCCL_DEBUG", "").upper() not in ("WARN", "INFO", "TRACE"):
+            env["NCCL_DEBUG"] = "WARN"
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--pass", name]
         t0 = time.time()
+        err = ""
         try:
-            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit_s)
-            out, rc = cp.stdout.decode(errors="replace"), cp.returncode
+            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+            out, rc, err = cp.stdout.decode(errors="replace"), cp.returncode, cp.stderr.decode(errors="replace")
         except subprocess.TimeoutExpired as e:
             out, rc = (e.stdout or b"").decode(errors="replace"), None       # the child (and its spinning kernels) was killed
+            err = (e.stderr or b"").decode(errors="replace")
+        if err:
+            sys.stderr.write(err)                                             # (the driver's log keeps everything)
+            sys.stderr.flush()
         res = None
         for line in out.strip().splitlines()[::-1]:
             try:
@@ -447,6 +457,22 @@ def orchestrate(args):
             why = ("did not finish within %.0f s (killed)" % limit_s) if rc is None else \
                   ((res or {}).get("error") or "exit code %s" % rc)
             results[name] = {"error": why, "seconds": time.time() - t0}
+            lines = [l[-300:] for l in err.splitlines() if ("NCCL WARN" in l or "RCCL version" in l or "Error" in l or "error" in l)
+                     and "bench.py: pass" not in l]
+            # warnings that repeat (this image: "Could not read node # k" for every topology node it may not read) once, with a count
+            seen, log = {}, []
+            for l in lines:
+                key = "".join(ch for ch in l.split("] ", 2)[-1] if not ch.isdigit())
+                if key in seen:
+                    seen[key][1] += 1
+                else:
+                    seen[key] = [len(log), 1]
+                    log.append(l)
+            for idx, cnt in seen.values():
+                if cnt > 1:
+                    log[idx] += "   (x%d)" % cnt
+            if name.startswith("rccl") and log:
+                results[name]["rccl_log"] = "\n".join(log[-15:])[-3000:]
             print("bench.py: pass %s failed on rank %d: %s" % (name, rank, why), file=sys.stderr)
             if name == "rccl_tick":     # every rank fails alike: the same follow-up passes everywhere
                 for extra in ("rccl_tick_dev", "rccl_lanes"):      # the ticker on device staging buffers; one communicator per lane
@@ -458,7 +484,7 @@ def orchestrate(args):
         summary = {}
         for n in passes:
             r = results[n]
-            summary[n] = ({"error": r["error"]} if "error" in r else
+            summary[n] = ({k: r[k] for k in ("error", "rccl_log") if k in r} if "error" in r else
                           {k: r[k] for k in ("value", "ms_per_step", "concurrent_proofs", "single_proof_latency_ms", "transport",
                                               "proof_verified_by_native_gkr_verify", "tick_stats") if k in r})
         head_name = max(ok_rccl, key=lambda n: results[n]["value"]) if ok_rccl else \
@@ -636,13 +662,15 @@ def main():
         # once more alone with the look-ahead off: round 0 as the ONE fused launch the proofs in flight run (all ten
         # products and the seven multiply-accumulates) -- the VALU-bound kernel the issue ceilings are quoted for
         ph["solo_fused"] = None
-        if ph["solo"]["lookahead_round0"] and not multi:
+        if (ph["solo"]["lookahead_round0"] or ph["solo"].get("ahead_round0")) and not multi:
             gk.set_option("lookahead", 0)
+            gk.set_option("ahead", 0)          # (round 0 as the layer's own first launch, not queued ahead by the layer before)
             gk.profile_reset(1 << bn_local)
             job.sessions[0].prove(job.qprime)
             sync_all()
             ph["solo_fused"] = gk.profile_get()
             gk.set_option("lookahead", int(os.environ.get("GKRHIP_PRE", "1")))      # back to what the library was started with
+            gk.set_option("ahead", int(os.environ.get("GKRHIP_AHEAD", "1")))
         gk.profile_reset(1 << bn_local)        # HIP-event accounting of the round-0 fold / partial-eval launches
         with ClockSampler(dev) as clk:
             ph["dt"] = timed(job, steps)
@@ -708,6 +736,14 @@ def main():
                                "host_launch_ms": solo["host_launch_ms"], "host_other_ms": solo["host_other_ms"],
                                "prelaunched_rounds": solo["prelaunched_rounds"], "lookahead_round0": solo["lookahead_round0"],
                                "coop_rounds": solo["coop_rounds"], "spec_rounds": solo.get("spec_rounds", 0),
+                               "ahead_round0": solo.get("ahead_round0", 0),
+                               "layer_checks": solo.get("layer_checks", 0), "layer_check_failures": solo.get("layer_check_failures", 0),
+                               "note_round5": "ahead_round0: cipher layers whose round 0 was queued by the layer BEFORE them, at the start of "
+                                              "that layer's host tail, as class sums over the index bits whose coordinates did not exist yet "
+                                              "(contracted on the host afterwards): round 0 leaves the critical path.  layer_checks: sumchecks "
+                                              "held against the verifier's identities before they were returned (every one); "
+                                              "layer_check_failures: those that did not close and were run again in safe mode (0 unless "
+                                              "the device side slipped)",
                                "note": "one gkr.Prove alone on the GPU (BenchmarkGkr's shape): the serial chain of rounds -- "
                                        "Fiat-Shamir hash on the host, then the next round kernel.  Round 3: the next round's kernel "
                                        "is queued before the hash and polls a host-mapped challenge slot (prelaunched_rounds), the "
@@ -826,6 +862,11 @@ def main():
                 "round0_pre", solo["peval_launches"], solo["peval_ms"], solo["peval_modmuls"],
                 "k_cipher_round_wide<false,true,true> (round 0 on look-ahead products: 192 B read per pair, 2 products by the "
                 "launch-wide weight and 7 multiply-accumulates)", with_clock=False)
+    out["integrity"] = {"layer_checks": prof.get("layer_checks", 0), "layer_check_failures": prof.get("layer_check_failures", 0),
+                        "chal_retries": prof.get("chal_retries", 0),
+                        "note": "of the K timed steps: every sumcheck is checked on the host against the verifier's round identities and "
+                                "closing identity (gkr/verifier.go:93-114) before gkr.Prove returns it; a sumcheck that does not close is run "
+                                "again in safe mode (layer_check_failures) -- inside the timed region, as is every proof's cost of the checks"}
     if prof.get("rounds"):
         out["host_split_ms_per_step"] = {k: prof[k] / args.steps for k in
                                          ("host_hash_ms", "host_wait_ms", "host_launch_ms", "host_other_ms")}

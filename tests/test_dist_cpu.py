@@ -1,4 +1,4 @@
-"""CPU multi-process tests (gloo): the sharded sumcheck protocol (world_size 2 and 4) reproduces the
+"""CPU multi-process tests (gloo): the sharded sumcheck protocol (world_size 2, 4 and 8) reproduces the
 un-sharded oracle transcript; the product's host-side shard helpers agree with the oracle."""
 import importlib
 import os
@@ -14,7 +14,7 @@ import pyoracle as o
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_protocol_gloo(world):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
