@@ -670,7 +670,7 @@ def main():
             sync_all()
             ph["solo_fused"] = gk.profile_get()
             gk.set_option("lookahead", int(os.environ.get("GKRHIP_PRE", "1")))      # back to what the library was started with
-            gk.set_option("ahead", int(os.environ.get("GKRHIP_AHEAD", "1")))
+            gk.set_option("ahead", int(os.environ.get("GKRHIP_AHEAD", "2")))
         gk.profile_reset(1 << bn_local)        # HIP-event accounting of the round-0 fold / partial-eval launches
         with ClockSampler(dev) as clk:
             ph["dt"] = timed(job, steps)
@@ -917,7 +917,9 @@ def main():
                             "concurrent_proofs": cl, "single_proof_ms": sorted(lat)[1], "single_proof_samples_ms": lat,
                             "single_proof_hashes_per_s": float(1 << cbn) / (sorted(lat)[1] * 1e-3),
                             "proof_verified_by_native_gkr_verify": ok,
-                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES") or os.environ.get("GKRHIP_HW_QUEUES") or "16 (library default)",
+                            "hw_queues": {"set_by_library": gk.profile_counter("hw_queues_set_by_library"),
+                                          "found_in_environment": gk.profile_counter("hw_queues_from_environment"),
+                                          "note": "GPU_MAX_HW_QUEUES as gkrhip_init left it; bench.py's process makes its first HIP call through the library (no torch import before it), so the runtime reads this value"},
                             "workload": ("gkr.Prove(MimcCircuit) at bN = 20 (BASELINE config 2)" if circ == "mimc" else
                                          "gkr.Prove(GMiMC t = 2 circuit: cipher, add and copy layers) at bN = 22 (BASELINE config 5); "
                                          "a hash here is one GMiMC compression")}

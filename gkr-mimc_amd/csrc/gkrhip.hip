@@ -2140,6 +2140,8 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "spec_rounds") *value = g_cnt_spec.load();
     else if (n == "chal_retries") *value = g_cnt_retries.load();
     else if (n == "ahead_round0") *value = g_cnt_ahead.load();
+    else if (n == "hw_queues_set_by_library") *value = (uint64_t)g_hwq_set_by_library.load();
+    else if (n == "hw_queues_from_environment") *value = (uint64_t)g_hwq_from_env.load();
     else if (n == "layer_checks") *value = g_cnt_layer_checks.load();
     else if (n == "layer_check_failures") *value = g_cnt_layer_check_failures.load();
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);

@@ -55,6 +55,9 @@ std::atomic<uint64_t> g_cnt_prelaunched{0}, g_cnt_lookahead{0}, g_cnt_coop{0}, g
 // that did not close and were run again, and gkrhip_set_option("layer_check", 0 | 1) / ("verify_after_prove", 0 | 1)
 std::atomic<uint64_t> g_cnt_layer_checks{0}, g_cnt_layer_check_failures{0}, g_cnt_ahead{0};
 std::atomic<int> g_layer_check{1}, g_verify_after_prove{0};
+// what gkrhip_init did about the runtime's hardware queues: the count it put into GPU_MAX_HW_QUEUES (0: it left the variable alone), or the
+// count it found there.  Whether the runtime honoured it depends on who made the process's first HIP call (gkrhip_profile_counter).
+std::atomic<int> g_hwq_set_by_library{0}, g_hwq_from_env{0};
 struct Profile {
     double host_hash_ms = 0, host_wait_ms = 0, host_launch_ms = 0, host_other_ms = 0;
     uint64_t rounds = 0;
@@ -189,7 +192,7 @@ struct Ctx {
     E pre_ark;
     int pre_m = 0;
     // round 0 ahead of its point (cipher_round.hip.h, ahead_publish): queued by the layer before, at the start of its host tail
-    int ahead_mode = 1;                        // GKRHIP_AHEAD: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only)
+    int ahead_mode = 2;                        // GKRHIP_AHEAD: 0 never, 1 when the proof is alone on the GPU, 2 always (un-sharded rounds only; the default: with lanes too the host tail is time the lane's stream has nothing to do -- bN = 20 x 24 lanes +1.3 %, bN = 24 x 5 +1.0 %, GMiMC bN = 22 x 12 +1.2 %)
     unsigned long long* h_ahead = nullptr;     // host-mapped: 7 * 2^t canonical class sums, then the flag word
     unsigned long long* d_ahead = nullptr;
     unsigned long long* d_ahead_racc = nullptr;   // GKR_RACC_SLOTS stripes of GKR_AHEAD_STRIPE words, zero between launches
@@ -368,7 +371,12 @@ int ctx_init(int dev) {
     if (!getenv("GPU_MAX_HW_QUEUES")) {
         const char* hq = getenv("GKRHIP_HW_QUEUES");
         const int nq = hq ? atoi(hq) : 16;
-        if (nq > 0) setenv("GPU_MAX_HW_QUEUES", std::to_string(std::min(nq, 64)).c_str(), 0);
+        if (nq > 0) {
+            setenv("GPU_MAX_HW_QUEUES", std::to_string(std::min(nq, 64)).c_str(), 0);
+            g_hwq_set_by_library.store(std::min(nq, 64));      // (a process-wide side effect: INTEGRATION.md)
+        }
+    } else {
+        g_hwq_from_env.store(atoi(getenv("GPU_MAX_HW_QUEUES")));
     }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -866,6 +866,12 @@ def bench_partial_eval(bn, warmup=10, iters=200):
     return us.value, e0
 
 
+def profile_counter(name):
+    v = C.c_uint64(0)
+    _check(load().gkrhip_profile_counter(name.encode(), C.byref(v)))
+    return v.value
+
+
 def profile_reset(min_n):
     _check(load().gkrhip_profile_reset(min_n))
 

@@ -392,7 +392,11 @@ int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_rou
  * queued ahead of its challenge, because a waiting kernel's time (1 s) ran out -- the result is the same, the proof is merely
  * late; "layer_checks": sumchecks held against the verifier's identities before they were returned; "layer_check_failures":
  * those that did not close and were run a second time in safe mode (see gkrhip_set_option, "layer_check") -- any value
- * other than 0 outside the fault-injection tests means the device side slipped and deserves a report.  Unknown name: error. */
+ * other than 0 outside the fault-injection tests means the device side slipped and deserves a report; "ahead_round0": cipher
+ * layers whose round 0 was queued by the layer before them; "hw_queues_set_by_library": the count gkrhip_init put into the
+ * process's GPU_MAX_HW_QUEUES (0: it found the variable set -- "hw_queues_from_environment" -- or was told to leave it
+ * alone); the runtime reads the variable when it initialises, so the setting only takes effect if the library made the
+ * process's first HIP call.  Unknown name: error. */
 int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus

@@ -553,6 +553,26 @@ func MultiExpShared(outG1 []unsafe.Pointer, g1 []*G1Bases, outG2 []unsafe.Pointe
 // each; a lane takes ~3 ms to create).  Optional.
 func ReserveLanes(n int) { must(C.gkrhip_reserve_lanes(C.int(n))) }
 
+// SetOption: gkrhip_set_option.  Of interest to a host: "layer_check" (default 1: every sumcheck is held against the
+// verifier's identities before it is returned and re-run in safe mode if it does not close) and "verify_after_prove"
+// (default 0: the one-shot calls run gkr.Verify on their proof first, as the reference's hint does in debug builds,
+// prover/gadget/hints.go:224-228).
+func SetOption(key string, value int) {
+	k := C.CString(key)
+	defer C.free(unsafe.Pointer(k))
+	must(C.gkrhip_set_option(k, C.long(value)))
+}
+
+// Counter: gkrhip_profile_counter, e.g. "layer_check_failures" (sumchecks that did not close and were run again: anything
+// but 0 means the device side slipped), "chal_retries", "ahead_round0", "hw_queues_set_by_library".
+func Counter(name string) uint64 {
+	k := C.CString(name)
+	defer C.free(unsafe.Pointer(k))
+	var v C.uint64_t
+	must(C.gkrhip_profile_counter(k, &v))
+	return uint64(v)
+}
+
 // PinnedElements returns a []fr.Element of length n in page-locked host memory (gkrhip_host_alloc): uploads from it are plain
 // DMA transfers instead of staged copies of pageable memory.  Meant for the vectors handed over on every proof (wireValues and
 // its filtered copies, the a / b / c of computeH).  The memory is not known to Go's collector: release it with FreePinned.

@@ -44,7 +44,10 @@ def main():
         t.start()
     for t in th:
         t.join()
-    print("bN = %d, %d lanes x %d proofs, mismatches (lane, proof, last differing row): %s" % (bn, lanes, per, bad))
+    p = gk.profile_get()
+    print("bN = %d, %d lanes x %d proofs, mismatches (lane, proof, last differing row): %s; sumchecks checked %d, not closing %d, "
+          "layers retried after a missed challenge %d, round 0 ahead %d"
+          % (bn, lanes, per, bad, p["layer_checks"], p["layer_check_failures"], p["chal_retries"], p["ahead_round0"]))
     sys.exit(1 if bad else 0)
 
 

@@ -41,8 +41,10 @@ def main():
                 bad.append((bn, n))
             n += 1
     p = gk.profile_get()
-    print("solo soak: %d proofs of sizes %s one at a time, mismatches: %s; speculative rounds %d, cooperative %d, pre-launched %d, look-ahead %d"
-          % (n, sizes, bad, p["spec_rounds"], p["coop_rounds"], p["prelaunched_rounds"], p["lookahead_round0"]))
+    print("solo soak: %d proofs of sizes %s one at a time, mismatches: %s; speculative rounds %d, cooperative %d, pre-launched %d, look-ahead %d, "
+          "round 0 ahead %d; sumchecks checked %d, not closing %d, layers retried after a missed challenge %d"
+          % (n, sizes, bad, p["spec_rounds"], p["coop_rounds"], p["prelaunched_rounds"], p["lookahead_round0"], p["ahead_round0"],
+             p["layer_checks"], p["layer_check_failures"], p["chal_retries"]))
     sys.exit(1 if bad else 0)
 
 main()
