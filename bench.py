@@ -764,7 +764,7 @@ def main():
         # HBM bytes per launch from the PMC counters need rocprofv3 around the process (separate --pmc passes): they are NOT
         # of this run -- the number is read from the committed builder-side pass and labelled as such
         traffic, traffic_source = None, None
-        for name in ("r04_pmc_fold_traffic.json", "r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # tools/pmc_bench.sh
+        for name in ("r05_pmc_fold_traffic.json", "r04_pmc_fold_traffic.json", "r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # tools/pmc_bench.sh
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pm.get("bn") == bn_gpu:
@@ -968,13 +968,14 @@ def main():
                                                          "8 M + 2 S) at its measured issue cost (%.1f / %.1f cycles per wave), every lane busy, "
                                                          "nominal %.1f GHz" % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ)}
             micro["msm_g1_2p%d" % lg] = e
-        r = gk.bench_msm_g2(20, warmup=1, iters=3)
-        micro["msm_g2_2p20"] = {"ms": r["ms"], "points_per_s": float(1 << 20) / (r["ms"] * 1e-3), "window_bits": r["c"], "phases_ms": r["phases_ms"],
-                                "host_tail_ms": r["host_tail_ms"],
-                                "field_products_per_s": 28.0 * (-(-255 // r["c"])) * (1 << 20) / (r["phases_ms"]["accumulate"] * 1e-3),
-                                "mirrors": "(*G2Jac).MultiExp(points, scalars, cfg) (prover/gadget/prove.go:277): 2^20 random points [k_i]G2, "
-                                           "random scalars; the same kernels as G1 over Fp2 coordinates (a mixed addition is 28 Fp products "
-                                           "instead of 10)"}
+        for lg in (20, 22):
+            r = gk.bench_msm_g2(lg, warmup=1, iters=3)
+            micro["msm_g2_2p%d" % lg] = {"ms": r["ms"], "points_per_s": float(1 << lg) / (r["ms"] * 1e-3), "window_bits": r["c"], "phases_ms": r["phases_ms"],
+                                         "host_tail_ms": r["host_tail_ms"],
+                                         "field_products_per_s": 28.0 * (-(-255 // r["c"])) * (1 << lg) / (r["phases_ms"]["accumulate"] * 1e-3),
+                                         "mirrors": "(*G2Jac).MultiExp(points, scalars, cfg) (prover/gadget/prove.go:277): 2^%d random points [k_i]G2, "
+                                                    "random scalars; the same kernels as G1 over Fp2 coordinates (a mixed addition is 28 Fp products "
+                                                    "instead of 10)" % lg}
         ms, npass, by = gk.bench_compute_h(24, warmup=1, iters=3)
         # issue ceiling from the ISA of this build: the innermost loop of the tile kernels is one sub-pass of two stages on a lane's
         # four elements (four butterflies with their LDS traffic and twiddle loads); 4 inverse DIF and 3 forward DIT transforms
