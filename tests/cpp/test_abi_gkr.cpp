@@ -244,6 +244,40 @@ int main(int argc, char** argv) {
         check_proof_structure(c, degree, bN, a, qp, flat, "GMiMC t=4");
         gkrhip_mimc_session_destroy(s);
     }
+    // The hint's own safety net (prover/gadget/hints.go:224-228 `if debug`), as a compiled caller would use it: every sumcheck
+    // of gkr.Prove is checked before it is returned and re-run if it does not close (a flipped bit of a device sum: same
+    // transcript, one re-run counted); with that check off, verify_after_prove turns the wrong proof into an error.
+    {
+        const int bN = 9;
+        const size_t n = (size_t)1 << bN, len = gkrhip_mimc_proof_len(bN);
+        std::vector<ofr_t> in0(n), qp(bN), flat(len), outs(n), oflat(len), oouts(n);
+        oracle_random_fr_array(in0.data(), n);
+        oracle_random_fr_array(qp.data(), bN);
+        CHECK(oracle_gkr_prove_mimc(bN, in0.data(), in0.data(), qp.data(), oflat.data(), oouts.data(), nullptr) == 0, "oracle prove");
+        uint64_t fails0 = 0, fails1 = 0, checks = 0;
+        OK(gkrhip_profile_counter("layer_check_failures", &fails0));
+        OK(gkrhip_set_option("test_corrupt_sum", 1));
+        OK(gkrhip_set_option("test_corrupt_skip", 40));
+        OK(gkrhip_gkr_prove_mimc(bN, (const uint64_t*)in0.data(), (const uint64_t*)in0.data(), (const uint64_t*)qp.data(),
+                                 (uint64_t*)flat.data(), (uint64_t*)outs.data()));
+        CHECK(memcmp(flat.data(), oflat.data(), len * sizeof(ofr_t)) == 0, "transcript after a corrupted sum differs");
+        OK(gkrhip_profile_counter("layer_check_failures", &fails1));
+        OK(gkrhip_profile_counter("layer_checks", &checks));
+        CHECK(fails1 == fails0 + 1 && checks >= 92, "layer_check_failures %llu -> %llu, checks %llu", (unsigned long long)fails0,
+              (unsigned long long)fails1, (unsigned long long)checks);
+        OK(gkrhip_set_option("layer_check", 0));
+        OK(gkrhip_set_option("verify_after_prove", 1));
+        OK(gkrhip_set_option("test_corrupt_sum", 1));
+        const int rc = gkrhip_gkr_prove_mimc(bN, (const uint64_t*)in0.data(), (const uint64_t*)in0.data(), (const uint64_t*)qp.data(),
+                                             (uint64_t*)flat.data(), (uint64_t*)outs.data());
+        CHECK(rc != 0 && strstr(gkrhip_last_error(), "GKR proof was wrong") != nullptr, "a wrong proof was returned (rc %d, %s)", rc, gkrhip_last_error());
+        OK(gkrhip_set_option("layer_check", 1));
+        OK(gkrhip_gkr_prove_mimc(bN, (const uint64_t*)in0.data(), (const uint64_t*)in0.data(), (const uint64_t*)qp.data(),
+                                 (uint64_t*)flat.data(), (uint64_t*)outs.data()));
+        CHECK(memcmp(flat.data(), oflat.data(), len * sizeof(ofr_t)) == 0, "transcript with verify_after_prove differs");
+        OK(gkrhip_set_option("verify_after_prove", 0));
+        CHECK(gkrhip_set_option("no_such_option", 1) != 0, "unknown option accepted");
+    }
     // the gate table refuses what the kernels cannot evaluate
     {
         gkrhip_gate_desc bad_gate;
