@@ -2124,6 +2124,31 @@ int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t* M, const u
     return 0;
 }
 
+/* The prover's own check of a finished sumcheck (sumcheck_closes, host_sumcheck.hip.h), on host data alone. */
+int gkrhip_host_sumcheck_closes(int gate, const uint64_t* ark_or_null, int arity, int bN, const uint64_t* qprimes, int nq,
+                                const uint64_t* claims, int nclaims, int claims_are_sums, const uint64_t* proof,
+                                const uint64_t* challenges, const uint64_t* final_claims, int* verdict) {
+    if (!verdict || !proof || !final_claims || (bN > 0 && (!challenges || !qprimes))) return fail("host_sumcheck_closes: null argument");
+    if (bN < 0 || bN > 40 || nq < 1) return fail("host_sumcheck_closes: bad shape");
+    GateDesc g;
+    CHK(gate_resolve(gate, arity, &g));
+    E ark = hfr::ZERO;
+    if (ark_or_null && gate != GKRHIP_GATE_IDENTITY) memcpy(ark.l, ark_or_null, 32);
+    const E rho = (nclaims > 1 || nq > 1) && nclaims >= 1 ? hfr::mimc_hash((const E*)claims, (size_t)nclaims) : hfr::ZERO;
+    *verdict = sumcheck_closes(g, ark, bN, (const E*)qprimes, nclaims >= 1 ? nq : 1, (const E*)claims, nclaims, claims_are_sums != 0, rho,
+                               (const E*)proof, (const E*)challenges, (const E*)final_claims);
+    return 0;
+}
+/* Round 0 ahead of its point, the host's part (CipherLoop::coefficients): M_j = sum_y eq(q_low, y) S_j(y), j = 1..7, from the
+ * 7 * 2^t class sums S (S_j(y) at (j - 1) * 2^t + y) and the t coordinates the layer before drew last. */
+int gkrhip_host_ahead_contract(uint64_t out[28], const uint64_t* class_sums, const uint64_t* q_low, int t) {
+    if (!out || !class_sums || t < 0 || t > 12 || (t > 0 && !q_low)) return fail("host_ahead_contract: bad argument");
+    E M[7];
+    ahead_contract((const E*)class_sums, (const E*)q_low, t, M);
+    memcpy(out, M, sizeof M);
+    return 0;
+}
+
 int gkrhip_profile_latency(uint64_t* prelaunched_rounds, uint64_t* lookahead_round0, uint64_t* coop_rounds) {
     if (prelaunched_rounds) *prelaunched_rounds = g_cnt_prelaunched.load();
     if (lookahead_round0) *lookahead_round0 = g_cnt_lookahead.load();

@@ -339,6 +339,17 @@ inline void eq_table_host(const E* q, int n, std::vector<E>& W) {
             W[J] = hfr::sub(W[J], W[JN]);
         }
 }
+// M_j = sum_y eq(q_low, y) S_j(y), j = 1..7 (out[0..6]): the class sums S (S_j(y) at (j - 1) * 2^t + y) contracted with the t
+// coordinates that did not exist when they were computed
+inline void ahead_contract(const E* S, const E* q_low, int t, E* out) {
+    std::vector<E> Wy;
+    eq_table_host(q_low, t, Wy);
+    for (int j = 0; j < 7; j++) {
+        E acc = hfr::ZERO;
+        for (size_t y = 0; y < Wy.size(); y++) acc = hfr::add(acc, hfr::mul(Wy[y], S[((size_t)j << t) + y]));
+        out[j] = acc;
+    }
+}
 // Queue round 0 of the layer gkr.Prove proves next (cx().nxt_*), whose point is THIS layer's challenges: chal[0 .. k_known]
 // exist, the last t = m - 1 - k_known are still to come (this layer's host tail).  Called where the host tail starts; the
 // stream is idle from here to the end of the layer.  The products of k_cipher_pre are used when they exist for that layer.
@@ -922,14 +933,7 @@ struct CipherLoop {
             // M_j = sum_y eq(q[m-t:], y) S_j(y): the class sums contracted with the coordinates the layer before drew last
             LAP("ahead: before contraction");
             const int t = cx().ahead_t;
-            std::vector<E> Wy;
-            eq_table_host(q + (m - t), t, Wy);
-            const E* S_ = (const E*)cx().h_ahead;
-            for (int j = 1; j < 8; j++) {
-                E acc = hfr::ZERO;
-                for (size_t y = 0; y < Wy.size(); y++) acc = hfr::add(acc, hfr::mul(Wy[y], S_[((size_t)(j - 1) << t) + y]));
-                Mj[j] = acc;
-            }
+            ahead_contract((const E*)cx().h_ahead, q + (m - t), t, Mj + 1);
             LAP("ahead: contraction");
         } else if (this_spec) {     // the candidates at the true r_{k-1}
             spec_interpolate((const E*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS), chal[k - 1], derive_m0 ? 1 : 0, Mj);

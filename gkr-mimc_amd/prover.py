@@ -124,6 +124,8 @@ ABI = {
     "gkrhip_profile_host": (_I, [C.POINTER(_U64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
     "gkrhip_profile_latency": (_I, [C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
     "gkrhip_profile_counter": (_I, [C.c_char_p, C.POINTER(_U64)]),
+    "gkrhip_host_sumcheck_closes": (_I, [_I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_int)]),
+    "gkrhip_host_ahead_contract": (_I, [_P, _P, _P, _I]),
 }
 
 
@@ -651,6 +653,26 @@ def host_mimc_hash(arr):
 def host_cipher_round_coeffs(M, c, qk):
     out = np.zeros((9, 4), np.uint64)
     _check(load().gkrhip_host_cipher_round_coeffs(_ptr(out), _ptr(_fr(M)), _ptr(_fr(c)), _ptr(_fr(qk))))
+    return out
+
+
+def host_sumcheck_closes(gate, ark, arity, q_primes, claims, proof, challenges, final_claims, claims_are_sums=True):
+    """The prover's own check of a finished sumcheck on host data (no GPU): 0 closes, 1 + i round i, -1 closing identity,
+    -2 finalClaims[0]."""
+    q_primes = _fr(q_primes)
+    nq, bN = q_primes.shape[0], q_primes.shape[1]
+    claims = _fr(claims).reshape(-1, 4)
+    v = C.c_int(0)
+    _check(load().gkrhip_host_sumcheck_closes(gate, _ptr(_fr(ark)) if ark is not None else None, arity, bN, _ptr(q_primes) if bN else None, nq,
+                                              _ptr(claims) if claims.shape[0] else None, claims.shape[0], 1 if claims_are_sums else 0,
+                                              _ptr(_fr(proof)), _ptr(_fr(challenges)) if bN else None, _ptr(_fr(final_claims)), C.byref(v)))
+    return v.value
+
+
+def host_ahead_contract(class_sums, q_low):
+    q_low = _fr(q_low).reshape(-1, 4)
+    out = np.zeros((7, 4), np.uint64)
+    _check(load().gkrhip_host_ahead_contract(_ptr(out), _ptr(_fr(class_sums)), _ptr(q_low) if q_low.shape[0] else None, q_low.shape[0]))
     return out
 
 

@@ -270,6 +270,19 @@ int gkrhip_host_shard_seed(uint64_t out[4], const uint64_t *q_tail, int gamma, i
 int gkrhip_host_limbsplit_reduce(uint64_t out[4], const uint64_t *lanes, int nlanes);
 int gkrhip_host_mimc_hash(uint64_t out[4], const uint64_t *in, size_t n);
 int gkrhip_host_cipher_round_coeffs(uint64_t out[36], const uint64_t *M, const uint64_t c[4], const uint64_t qk[4]);
+/* The prover's own check of a finished sumcheck, on host data alone (what gkr.Prove / sumcheck.Prove run on every sumcheck
+ * before returning it): the round checks P_i(0) + P_i(1) == expected of sumcheck.Verify (sumcheck/verifier.go:41-47) with the
+ * given challenges (no hash), then testSumcheck's closing identity Gate.Eval(finalClaims[1:]) * sum_j rho^j EvalEq(q_j, r) ==
+ * P_last(r_last) (gkr/verifier.go:93-114) and finalClaims[0] against that eq value.  claims_are_sums != 0: the claims are
+ * the sums (inside gkr.Prove); 0: they only feed Fiat-Shamir (sumcheck/prover.go:128) and round 0 is not held against them.
+ * *verdict: 0 closes | 1 + i round i | -1 the closing identity | -2 finalClaims[0]. */
+int gkrhip_host_sumcheck_closes(int gate, const uint64_t *ark_or_null, int arity, int bN, const uint64_t *qprimes, int nq,
+                                const uint64_t *claims, int nclaims, int claims_are_sums, const uint64_t *proof,
+                                const uint64_t *challenges, const uint64_t *final_claims, int *verdict);
+/* Round 0 queued ahead of its evaluation point, the host's part: M_j = sum_y eq(q_low, y) S_j(y), j = 1..7,
+ * from the 7 * 2^t class sums (S_j(y) at element (j - 1) * 2^t + y) and the t coordinates drawn last (q_low[0] <-> the most
+ * significant of the t low index bits). */
+int gkrhip_host_ahead_contract(uint64_t out[28], const uint64_t *class_sums, const uint64_t *q_low, int t);
 
 /* ---- computeH: the H part of Groth16's Krs (prover/gadget/prove.go:308-359) --------------------------------------
  * The next prover cost once GKR is fast: three inverse FFTs, three coset FFTs, the pointwise

@@ -247,3 +247,73 @@ def test_header_is_plain_c():
     """include/gkrhip.h is what a cgo preamble includes: it must be valid C99 on its own."""
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
                            os.path.join(ROOT, "include", "gkrhip.h")])
+
+
+# ---------------------------------------------------------------- round 5: the prover's own check and round 0 ahead, host parts
+def test_host_sumcheck_closes_on_oracle_proofs(gk):
+    """gkrhip_host_sumcheck_closes (what gkr.Prove runs on every sumcheck before returning it) accepts the oracle's sumchecks --
+    cipher gate at one point, identity gate at five points -- and names what is wrong with a corrupted one: a round, the
+    closing identity, finalClaims[0]; a claim that is not the sum fails round 0 only when the caller vouches for the claims."""
+    import numpy as np
+    import coracle as c
+    bn = 6
+    n = 1 << bn
+    rng = np.random.default_rng(5)
+    X = [c.random_fr_array(n), c.from_ints([int(v) for v in rng.integers(0, 1 << 62, n)])]
+    ark = c.from_u64(145646)
+    qs = c.random_fr_array(bn).reshape(1, bn, 4)
+    claims = c.evaluation(c.GATE_CIPHER, ark, qs, c.fr(0), X)
+    proof, chal, fin = c.sumcheck_prove(c.GATE_CIPHER, ark, X, qs, claims)
+    args = (gk.GATE_CIPHER, ark, 2, qs, claims)
+    assert gk.host_sumcheck_closes(*args, proof, chal, fin) == 0
+    for (i, j), want in (((0, 0), 1), ((3, 4), 4), ((5, 8), 6)):      # a coefficient of round i breaks round i's check (or the next one's)
+        bad = proof.copy()
+        bad[i, j, 0] ^= np.uint64(1)
+        assert gk.host_sumcheck_closes(*args, bad, chal, fin) in (want, want + 1, -1), (i, j)
+    bad = fin.copy(); bad[1, 0] ^= np.uint64(2)
+    assert gk.host_sumcheck_closes(*args, proof, chal, bad) == -1
+    bad = fin.copy(); bad[0, 1] ^= np.uint64(2)
+    assert gk.host_sumcheck_closes(*args, proof, chal, bad) == -2
+    bad = chal.copy(); bad[bn - 1, 0] ^= np.uint64(1)
+    assert gk.host_sumcheck_closes(*args, proof, bad, fin) != 0
+    wrong = claims.copy(); wrong[0, 0] ^= np.uint64(1)
+    assert gk.host_sumcheck_closes(gk.GATE_CIPHER, ark, 2, qs, wrong, proof, chal, fin) == 1
+    assert gk.host_sumcheck_closes(gk.GATE_CIPHER, ark, 2, qs, wrong, proof, chal, fin, claims_are_sums=False) == 0
+    # the output layer of gkr.Prove: no claim at all (sumcheck/prover.go:121), the chain starts at P_0(r_0)
+    p0, c0, f0 = c.sumcheck_prove(c.GATE_CIPHER, ark, X, qs, c.fr(0))
+    assert gk.host_sumcheck_closes(gk.GATE_CIPHER, ark, 2, qs, c.fr(0), p0, c0, f0) == 0
+    # identity gate, five claims on one table: the recombination challenge and the eq values weighted by its powers
+    ninst = 5
+    Xi = [c.random_fr_array(n)]
+    qm = np.stack([c.from_ints([(i * j + i + 1) for j in range(bn)]).reshape(bn, 4) for i in range(ninst)])
+    cl = np.concatenate([c.evaluation(c.GATE_IDENTITY, None, qm[i:i + 1], c.fr(0), Xi) for i in range(ninst)])
+    pm, cm, fm = c.sumcheck_prove(c.GATE_IDENTITY, None, Xi, qm, cl)
+    assert gk.host_sumcheck_closes(gk.GATE_IDENTITY, None, 1, qm, cl, pm, cm, fm) == 0
+    bad = cl.copy(); bad[3, 2] ^= np.uint64(1)
+    assert gk.host_sumcheck_closes(gk.GATE_IDENTITY, None, 1, qm, bad, pm, cm, fm) != 0
+    bad = pm.copy(); bad[2, 1, 0] ^= np.uint64(4)
+    assert gk.host_sumcheck_closes(gk.GATE_IDENTITY, None, 1, qm, cl, bad, cm, fm) in (3, 4)
+
+
+def test_round0_ahead_factorisation(gk):
+    """The identity round 0 ahead of its point rests on, in Python integers: with the pair index x = (x_hi, y),
+    y the low t bits, sum_x eq(q[1:], x) m(x) = sum_y eq(q[m-t:], y) S(y), S(y) = sum_{x_hi} eq(q[1:m-t], x_hi) m(x_hi, y) -- and
+    the library's host-side contraction (gkrhip_host_ahead_contract) of seven such class-sum tables."""
+    import numpy as np
+    import coracle as c
+    import pyoracle as o
+    Q = o.Q
+    m, t = 7, 3
+    P = 1 << (m - 1)
+    q = [int(v) for v in o.random_fr_array(m)]
+    rng = np.random.default_rng(11)
+    ms = [[int(v) % Q for v in rng.integers(1, 1 << 62, P)] for _ in range(7)]        # seven monomial tables m_j(x)
+    full = o.folded_eq_table(q[1:])                              # eq(q[1:], x), q[1] <-> the most significant bit of x
+    hi = o.folded_eq_table(q[1:m - t])
+    lo = o.folded_eq_table(q[m - t:])
+    want = [sum(full[x] * mj[x] for x in range(P)) % Q for mj in ms]
+    S = [[sum(hi[xh] * mj[(xh << t) | y] for xh in range(1 << (m - 1 - t))) % Q for y in range(1 << t)] for mj in ms]
+    assert [sum(lo[y] * Sj[y] for y in range(1 << t)) % Q for Sj in S] == want
+    flat = c.from_ints([v for Sj in S for v in Sj])
+    got = gk.host_ahead_contract(flat, c.from_ints(q[m - t:]))
+    assert c.to_ints(got) == want
