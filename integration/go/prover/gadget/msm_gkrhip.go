@@ -26,6 +26,11 @@ var (
 )
 
 // g1BasesOf returns the device-resident copy of a proving-key vector, uploading it on first use.
+//
+// The cache is keyed by the address and length of the slice: it is meant for proving-key vectors, which are written once
+// when the key is loaded and never again.  A key that is RELOADED into the same backing array, or mutated in place, must be
+// announced with ForgetBases (below) -- the device copy would otherwise be stale and the proofs wrong without any error.
+// Entries hold HBM (64 B per point, 128 B for G2) until forgotten.
 func g1BasesOf(points []bn254.G1Affine) *gkrhip.G1Bases {
 	g1BasesMu.Lock()
 	defer g1BasesMu.Unlock()
@@ -38,9 +43,43 @@ func g1BasesOf(points []bn254.G1Affine) *gkrhip.G1Bases {
 	return b
 }
 
+// ForgetBases drops the device copies of the given proving-key vectors (and frees their HBM): call it when a key is unloaded,
+// reloaded or changed in place.  The next MSM over such a slice uploads it again.
+func ForgetBases(g1 [][]bn254.G1Affine, g2 [][]bn254.G2Affine) {
+	g1BasesMu.Lock()
+	for _, p := range g1 {
+		if len(p) > 0 {
+			if b, ok := g1BasesCache[&p[0]]; ok {
+				b.Free()
+				delete(g1BasesCache, &p[0])
+			}
+		}
+	}
+	g1BasesMu.Unlock()
+	g2BasesMu.Lock()
+	for _, p := range g2 {
+		if len(p) > 0 {
+			if b, ok := g2BasesCache[&p[0]]; ok {
+				b.Free()
+				delete(g2BasesCache, &p[0])
+			}
+		}
+	}
+	g2BasesMu.Unlock()
+}
+
+// sameLength is gnark-crypto's own precondition (MultiExp returns "len(points) != len(scalars)"): the helpers below have no
+// error return -- their call sites discard MultiExp's -- so a mismatch panics, as every other misuse of the shims does.
+func sameLength(points, scalars int) {
+	if points != scalars {
+		panic("MultiExp: len(points) != len(scalars)")
+	}
+}
+
 // multiExpG1Affine replaces `res.MultiExp(points, scalars, ecc.MultiExpConfig{...})` for a bn254.G1Affine receiver
 // (prove.go:76,91).
 func multiExpG1Affine(res *bn254.G1Affine, points []bn254.G1Affine, scalars []fr.Element) {
+	sameLength(len(points), len(scalars))
 	if len(scalars) == 0 {
 		*res = bn254.G1Affine{}
 		return
@@ -78,6 +117,7 @@ func g2BasesOf(points []bn254.G2Affine) *gkrhip.G2Bases {
 // with Z = 1 (the later AddAssign / AddMixed / FromJacobian, prove.go:281-285, do not depend on the representative).
 func multiExpG2Jac(res *bn254.G2Jac, points []bn254.G2Affine, scalars []fr.Element) {
 	var aff bn254.G2Affine
+	sameLength(len(points), len(scalars))
 	if len(scalars) > 0 {
 		g2BasesOf(points).MultiExp(unsafe.Pointer(&aff), scalars, false)
 	}
@@ -91,6 +131,8 @@ func multiExpG2Jac(res *bn254.G2Jac, points []bn254.G2Affine, scalars []fr.Eleme
 func multiExpG1G2Jac(res1 *bn254.G1Jac, res2 *bn254.G2Jac, points1 []bn254.G1Affine, points2 []bn254.G2Affine, scalars []fr.Element) {
 	var a1 bn254.G1Affine
 	var a2 bn254.G2Affine
+	sameLength(len(points1), len(scalars))
+	sameLength(len(points2), len(scalars))
 	if len(scalars) > 0 {
 		gkrhip.MultiExpG1G2(unsafe.Pointer(&a1), unsafe.Pointer(&a2), g1BasesOf(points1), g2BasesOf(points2), scalars, false)
 	}
