@@ -47,7 +47,9 @@ struct MsmWork {
     unsigned int slice_len = 0, slice_cap = 0, ctiles = 0;
     unsigned int* lvl2 = nullptr;        // coarse count | offset | first slice (W * nbc each) | chunk histograms | tile sums | slice list | slice histograms
     unsigned int* c_entries = nullptr;   // the coarse pass's entries
-    bool ready = false;                  // every buffer below is allocated (set last by msm_work_prepare)
+    bool ready = false;                  // every buffer this handle needs is allocated (set last by msm_work_prepare)
+    bool has_sort = false;               // ... the sort's buffers among them (a handle that only ever SUMS on another handle's sort, in
+                                         // a shared call, holds buckets, partial sums and the pinned window sums only: 3+ GiB less at 2^24)
     void release() {
         if (counts) (void)hipFree(counts);
         if (lvl2) (void)hipFree(lvl2);
@@ -86,11 +88,11 @@ inline int msm_pick_lowbits(size_t n, int c) {
     return std::max(1, std::min(std::min(7, 31 - logn), (c - 1) / 2));      // the entry keeps index, sign and low bits in 32 bits
 }
 
-int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
+int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16, bool sum_only = false) {
     const int c = c_forced > 0 ? c_forced : msm_pick_c(n);
     if (c < 2 || c > 16) return fail("msm: window size %d outside 2..16", c);
     const int lowbits = msm_pick_lowbits(n, c);
-    if (w->ready && w->c == c && w->n_cap >= n && w->w16 == w16 && w->lowbits == lowbits) return 0;
+    if (w->ready && w->c == c && w->n_cap >= n && w->w16 == w16 && w->lowbits == lowbits && (sum_only || w->has_sort)) return 0;
     w->release();
     // an allocation that fails half-way (several GiB per handle at 2^24 points) must not leave a half-prepared handle behind:
     // the next MSM would take the fast path above and launch its kernels on null pointers
@@ -133,6 +135,13 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
         w->bias[bit >> 5] |= 1u << (bit & 31);
     }
     w->ntiles = (unsigned int)((nbk + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE);
+    if (sum_only) {
+        HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W + w->big_cap) * sizeof(uint4)));
+        HIPCHK(hipHostMalloc((void**)&w->h_wins, ((size_t)4 * w16 * w->W + 1) * sizeof(uint4)));
+        w->ready = true;
+        guard.w = nullptr;
+        return 0;
+    }
     if (lowbits) {
         const size_t nbc = (size_t)w->W * (w->nb >> lowbits);      // coarse bins
         w->slice_len = 8192;
@@ -151,7 +160,7 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16) {
     HIPCHK(hipMalloc((void**)&w->scalars, std::max<size_t>(1, n) * 32));
     HIPCHK(hipMalloc((void**)&w->xyzz, (size_t)4 * w16 * (nbk + w->nparts + (size_t)w->W + w->big_cap) * sizeof(uint4)));
     HIPCHK(hipHostMalloc((void**)&w->h_wins, ((size_t)4 * w16 * w->W + 1) * sizeof(uint4)));      // + the error word
-    w->ready = true;
+    w->ready = w->has_sort = true;
     guard.w = nullptr;
     return 0;
 }
@@ -381,7 +390,9 @@ int msm_run_shared(MsmBases* const* g1, size_t k1, MsmBases* const* g2, size_t k
     for (MsmBases* b : order) locks.emplace_back(b->mu);
     MsmBases* first = all[0];
     CHK(msm_work_prepare(&first->w, std::max<size_t>(first->n, 1), first->c_forced, first->w16));
-    for (size_t i = 1; i < all.size(); i++) CHK(msm_work_prepare(&all[i]->w, std::max<size_t>(all[i]->n, 1), first->w.c, all[i]->w16));
+    // (the other handles sum on the first one's sort: buckets, partial sums and window sums only -- unless they already hold
+    // the sort's buffers of a call of their own with this geometry)
+    for (size_t i = 1; i < all.size(); i++) CHK(msm_work_prepare(&all[i]->w, std::max<size_t>(all[i]->n, 1), first->w.c, all[i]->w16, /*sum_only=*/true));
     if (n) HIPCHK(hipMemcpyAsync(first->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
     MsmArgs a;
     CHK(msm_sort_dev(&first->w, first->w.scalars, n, flags, nullptr, nullptr, &a));
