@@ -191,6 +191,8 @@ def main():
         # close and every rank runs the layer again -- no vote needed, the verdict is a function of exchanged data
         gk.set_option("test_corrupt_sum", int(os.environ.get("GKR_TEST_CORRUPT_ROUND", "2")))
         gk.set_option("test_corrupt_skip", int(os.environ.get("GKR_TEST_CORRUPT_LAYER", "3")))
+    if os.environ.get("GKR_TEST_VERIFY_AFTER"):
+        gk.set_option("verify_after_prove", 1)      # the one-shot calls run gkr.Verify on the (sharded) proof before returning it
     if os.environ.get("GKR_TEST_EXPECT_RETRIES") or os.environ.get("GKR_TEST_EXPECT_LAYER_FAILURES"):
         gk.profile_reset(0)
     if os.environ.get("GKR_TEST_REGULAR"):

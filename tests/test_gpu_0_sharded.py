@@ -89,6 +89,8 @@ def test_sharded_oneshot_on_regular_form_buffers():
     as they are."""
     _run_shards("shm", 2, "1,2,5,9", {"GKR_TEST_REGULAR": "1"})
     _run_shards("shm", 4, "2,6,10", {"GKR_TEST_REGULAR": "1", "GKRHIP_HOST_TAIL": "0"})
+    # with the hint's debug-mode check (hints.go:224-228): every rank verifies the sharded proof against its shards before returning
+    _run_shards("shm", 2, "3,8", {"GKR_TEST_REGULAR": "1", "GKR_TEST_VERIFY_AFTER": "1"})
 
 
 def test_rccl_ticker_world1_forced():
