@@ -116,13 +116,12 @@ __device__ __forceinline__ void spec_publish(unsigned long long* racc, unsigned 
 #pragma unroll
             for (int l = 0; l < 4; l++) host_out[4 * threadIdx.x + l] = (unsigned long long)v.v[2 * l] | ((unsigned long long)v.v[2 * l + 1] << 32);
         }
+        // (the arrival counter is reset with the accumulators, in front of the ONE fence every writing lane needs anyway; the flag's
+        // release store orders lane 0 behind the barrier: a second system-scope fence here cost every round ~1.5 us)
+        if (threadIdx.x == 0) *counter = 0;
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) {
-            *counter = 0;
-            __threadfence_system();
-            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
