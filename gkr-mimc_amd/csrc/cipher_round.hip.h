@@ -77,6 +77,9 @@ struct PyramidExpandArgs {
     int lo_level, hi_level;
 };
 __global__ void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandArgs a) {
+    // a few products per lane in front of a layer's first round: ahead of the other lanes' big rounds on a shared SIMD (same-box
+    // A/B, profiles/r05_prio_pyramids.txt: bN = 20 x 24 lanes +0.7 %, bN = 24 x 5 +0.5 %, GMiMC bN = 22 x 12 +1.0 %)
+    __builtin_amdgcn_s_setprio(3);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ((size_t)1 << a.hi_level)) return;
     const size_t lo_mask = ((size_t)1 << a.lo_level) - 1;
@@ -89,6 +92,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandAr
     }
 }
 __global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a) {
+    __builtin_amdgcn_s_setprio(3);      // (as k_eq_pyramid_expand)
     const PyramidArgs& p = a.p[blockIdx.y];
     if (p.max_level < 0) return;
     eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
