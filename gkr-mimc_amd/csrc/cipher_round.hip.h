@@ -131,6 +131,7 @@ struct CipherRoundArgs {
     // AHEAD (k_cipher_round_wide<false, true, ., true>): round 0 of the NEXT layer, queued before that layer's last ahead_t
     // coordinates exist -- see the comment above ahead_publish
     unsigned int ahead_t;
+    unsigned int prio;                 // wave priority (round_wave_priority, kernels.hip.h): min(round index, 3)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -249,6 +250,7 @@ template <bool FOLD, bool HAS_WJ, bool LAT>
 __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
     __shared__ unsigned int s_last;
     if (LAT) __builtin_amdgcn_s_setprio(3);      // a latency-bound round goes first when it shares a SIMD with the look-ahead kernel
+    else round_wave_priority(a.prio);
     Acc9 acc[GKR_CR_NSUM];
 #pragma unroll
     for (int t = 0; t < GKR_CR_NSUM; t++)
@@ -526,6 +528,7 @@ template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false>
 __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
     static_assert(!(FOLD && PRE), "the precomputed products exist for round 0 only");
     static_assert(!AHEAD || (WT_LATE && !FOLD), "round 0 ahead of its point: late lane weights, no fold");
+    round_wave_priority(a.prio);
     __shared__ WideShared sh;
     __shared__ unsigned int s_last;
     u32 R[GKR_CR_NSUM - 1 - GKR_WIDE_LDS][FR_WIDE_LIMBS];     // M_4 .. M_7

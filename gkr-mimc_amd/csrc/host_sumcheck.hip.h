@@ -795,6 +795,7 @@ struct CipherLoop {
         CipherRoundArgs a;
         memset(&a, 0, sizeof a);
         const bool fold = k > 0;
+        a.prio = (unsigned)std::min(k, 3);             // wave priority rises with the round index (round_wave_priority, kernels.hip.h)
         a.k_src = (k <= 1 ? K : &ks)->cplanes();
         a.s_src = (k <= 1 ? S : &ss)->cplanes();
         a.k_dst = ks.planes();
@@ -1244,6 +1245,7 @@ struct LinearLoop {
         LinearRoundArgs a;
         memset(&a, 0, sizeof a);
         const bool fold = k > 0;
+        a.prio = (unsigned)std::min(k, 3);
         for (int t = 0; t < arity; t++) {
             a.src[t] = (k <= 1 ? X[t] : &scratch[t])->cplanes();
             a.dst[t] = scratch[t].planes();

@@ -26,6 +26,18 @@
 #define GKR_RACC_STRIDE 128
 
 
+// Wave priority of a round kernel: 0 for round 0, rising with the round index (capped at 3).  With several proofs in flight the
+// lanes' kernels share SIMDs; the later -- shorter -- rounds of a layer going first ("shortest job first") lets a lane reach its
+// next hash sooner while the long round 0 of another lane fills the gaps.  Same-box A/B, three interleaved runs each
+// (profiles/r05_prio_rounds.txt): bN = 24 x 5 lanes 85.7 -> 89.0 M hashes/s, GMiMC bN = 22 x 12 104.1 -> 115.0, bN = 22 x 8 71.0 -> 78.1,
+// bN = 20 x 24 60.8 -> 61.2; one proof alone unchanged.  Other mappings of the four levels (0233, 0333, 0112, 0223: profiles/
+// r05_prio_rounds_mappings.txt) are equal or worse.
+__device__ __forceinline__ void round_wave_priority(unsigned int p) {
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 struct Planes {
     uint4* lo;
     uint4* hi;

@@ -37,11 +37,13 @@ struct LinearRoundArgs {
     unsigned long long* chal_dev;
     unsigned int chal_seq;
     unsigned int chal_limit_s;     // see CipherRoundArgs
+    unsigned int prio;             // wave priority (round_wave_priority): min(round index, 3)
 };
 
 template <bool FOLD, bool HAS_WJ>
 __global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
     __shared__ unsigned int s_last;
+    round_wave_priority(a.prio);
     u32 T0[FR_WIDE_LIMBS], T1[FR_WIDE_LIMBS];      // wide sums of W*u and W*d: reduced once per lane
 #pragma unroll
     for (int j = 0; j < FR_WIDE_LIMBS; j++) T0[j] = T1[j] = 0;
