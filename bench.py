@@ -371,6 +371,7 @@ def parse_args():
                     help="N > 1: comma-separated passes to run instead of the default sequence "
                          "(shm, rccl_one_lane, rccl_tick, rccl_lanes)")
     ap.add_argument("--pass", dest="pass_name", default=None, help=argparse.SUPPRESS)    # one pass of an N > 1 run (child process)
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)               # the measuring process of an N = 1 run (see supervise)
     ap.add_argument("--device", type=int, default=None,
                     help="GPU ordinal of this rank (default LOCAL_RANK); several ranks on ONE GPU is how the multi-rank "
                          "control flow is exercised on a single-GPU box (only the shared-memory pass can succeed there)")
@@ -514,8 +515,61 @@ def orchestrate(args):
     return code if rank == 0 else 0
 
 
+def profiler_present():
+    """A profiler's preloaded tool (rocprofv3) initialises the GPU in THIS process before main(): a process that has done so must
+    not start another program, so the measurement then runs in-process as it always did."""
+    return any(os.environ.get(k) for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH"))
+
+
+def supervise():
+    """N = 1: the measurement runs in a child process (this one never touches the GPU).  A child that dies without printing its line
+    -- round 5 saw ONE abort in nineteen runs of the default line, never reproduced, stderr not kept -- is run once more, and the line
+    says so (`bench_attempts`, `first_attempt`): a rare crash must cost a minute, not the round's number."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
+    first = None
+    for attempt in (1, 2):
+        cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        err = cp.stderr.decode(errors="replace")
+        sys.stderr.write(err)
+        sys.stderr.flush()
+        line = None
+        for l in cp.stdout.decode(errors="replace").strip().splitlines()[::-1]:
+            try:
+                line = json.loads(l)
+                break
+            except Exception:
+                continue
+        if line is not None and cp.returncode == 0:
+            if first is not None:
+                line["bench_attempts"] = attempt
+                line["first_attempt"] = first
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+            return 0
+        died = cp.returncode < 0 or cp.returncode in (134, 137, 139)      # killed by a signal (abort, kill, segmentation fault)
+        first = {"returncode": cp.returncode, "printed_a_line": line is not None, "stderr_tail": err[-2500:]}
+        if line is not None and not died:          # a line with a failing exit code (degraded runs): pass both on, no second attempt
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+            return cp.returncode
+        if not died or attempt == 2:               # an ordinary failure (an exception, a refused configuration) is not retried
+            return cp.returncode if cp.returncode else 1
+        print("bench.py: the measuring process died with code %s; running it once more" % cp.returncode, file=sys.stderr)
+    return 1
+
+
 def main():
     args = parse_args()
+
+    if args.gpus == 1 and "RANK" not in os.environ and not args.pass_name and not args.child and \
+            os.environ.get("GKRHIP_BENCH_SUPERVISE", "1") != "0" and not profiler_present():
+        raise SystemExit(supervise())
+
+    flag = os.environ.get("GKRHIP_BENCH_SELFTEST_ABORT_ONCE")      # tests/test_bench_contract.py: the first measuring process dies
+    if args.child and flag and not os.path.exists(flag):
+        open(flag, "w").close()
+        os.abort()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started by hand without a launcher: start the ranks as children (one process per GPU, rendezvous on 127.0.0.1) and

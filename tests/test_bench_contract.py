@@ -173,3 +173,23 @@ def test_rendezvous_frames_are_data_and_strangers_are_ignored():
     assert not errs, errs
     assert all(res[r] == (3, 1.0, bytes(range(256)) * 4, "tag", None) for r in range(world)), res
     assert "pickle" not in open(os.path.join(ROOT, "bench.py")).read().split("class LocalRendezvous")[0].split("class Rendezvous")[1]
+
+
+def test_supervisor_runs_a_dead_measuring_process_once_more(tmp_path):
+    """bench.py at N = 1 measures in a child process; a child killed by a signal is started once more (an ordinary failure --
+    here: no GPU in this container -- is not).  The parent never touches the GPU."""
+    import importlib, subprocess, sys
+    import pytest
+    if importlib.import_module("gkr-mimc_amd").device_count() > 0:
+        pytest.skip("a GPU is present: the full benchmark would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GKRHIP_BENCH_SELFTEST_ABORT_ONCE=str(tmp_path / "died"))
+    env.pop("LD_PRELOAD", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert os.path.exists(tmp_path / "died")
+    assert "died with code" in out.stderr and "running it once more" in out.stderr, out.stderr[-1500:]
+    assert "no HIP device available" in out.stderr            # the second attempt ran (and failed the ordinary way: not retried)
+    assert out.stderr.count("running it once more") == 1 and out.returncode != 0
+    # without the injected death: one attempt only
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert "running it once more" not in out.stderr and out.returncode != 0
