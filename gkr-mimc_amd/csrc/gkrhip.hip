@@ -23,6 +23,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gkrhip.h"
@@ -340,7 +341,8 @@ void gkrhip_shutdown(void) {
     ntt_domains_free();
     {
         std::lock_guard<std::mutex> pl(g_pool.mu);
-        for (auto& f : g_pool.free_list) (void)hipFree(f.second);
+        for (auto& f : g_pool.free_list)
+            for (uint4* b : f.second) (void)hipFree(b);
         g_pool.free_list.clear();
     }
     {
