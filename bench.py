@@ -954,7 +954,7 @@ def main():
         # 16 / 24 / 32 / 48), GMiMC bN = 22 78.7 / 85.5 with 5 / 8 (later: 85.8 / 89.3 / 89.2 with 8 / 12 / 16)
         # Round 5, with the round kernels' wave priorities (kernels.hip.h: round_wave_priority): bN = 20 60.5 / 63.5 / 63.3 / 65.0 / 64.4 / 65.2 M
         # with 24 / 40 / 48 / 56 / 64 / 80 lanes (profiles/r05_lanes20.txt) -> 56; GMiMC bN = 22 101.8 / 115.0 / 107.7 with 8 / 12 / 16 -> 12
-        for key, circ, cbn, csteps, clanes in (("gmimc_bn22", "gmimc", 22, 48, 12), ("bn20", "mimc", 20, 168, 56)):       # (config 5 first: behind the 56-lane job -- 5 000 buffers allocated and freed -- it ran at 103.6 M hashes/s against 113.9 before it, same box; not the arena's search, which round 5 also made a lookup; the job of 56 is unaffected by the order)      # three / four proofs per lane: two leave the start (every lane in its round 0 at once) and the ragged end a third of the timed region
+        for key, circ, cbn, csteps, clanes in (("bn20", "mimc", 20, 168, 56), ("gmimc_bn22", "gmimc", 22, 48, 12)):      # three / four proofs per lane in the timed region
             cl = lanes_that_fit(circ, cbn, max(args.concurrent, clanes) if args.concurrent > 1 else 1, csteps)
             cj = Job(gk, cbn, cl, gk.gmimc_t2_circuit() if circ == "gmimc" else None)
             cj.run_steps(max(2, cl))

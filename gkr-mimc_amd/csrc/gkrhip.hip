@@ -64,6 +64,13 @@ struct gkrhip_session {
     bool have_inputs = false, assigned = false;
     unsigned long long inputs_loaded = 0;
     Ctx* lane = nullptr;         // &g0 for sharded sessions, otherwise a lane of its own
+    // Where the lane goes when the session is destroyed.  The one-shot calls (a session per call: the hint) hand theirs back to
+    // the pool -- the next call finds it there instead of paying ~3 ms.  A session the caller created keeps its lane to the end
+    // and then FREES it: lanes that survived a job of many proofs and were handed to a later job of a dozen ran that job 10 %
+    // slower than lanes created for it (GMiMC bN = 22 x 12 behind bN = 20 x 56: 102 against 115 M hashes/s, same process, same
+    // box; fresh buffers and a fresh stream for the pooled lanes do not help, taking the OLDEST pooled lanes helps once:
+    // profiles/r05_order_probe.txt -- the runtime's assignment of streams to hardware queues is the suspect, not proven).
+    bool pool_lane = false;
 };
 
 namespace {
@@ -857,7 +864,7 @@ void gkrhip_mimc_session_destroy(gkrhip_session* s) {
         }
         bool owned = s->lane != &g0;
         for (Ctx* l : gc.lanes) owned = owned && l != s->lane;   // communicator lanes outlive their sessions
-        if (owned) lane_destroy(s->lane);
+        if (owned) lane_destroy(s->lane, s->pool_lane);
     }
     delete s;
 }
@@ -883,6 +890,7 @@ static int prove_mimc_oneshot(int bN, const uint64_t* in0, const uint64_t* in1, 
     const double t_0 = now_ms();
     gkrhip_session* s = nullptr;
     CHK(gkrhip_mimc_session_create(&s, bN));
+    s->pool_lane = true;
     const double t_c = now_ms();
     int rc;
     {
@@ -964,6 +972,7 @@ int gkrhip_gkr_prove(const gkrhip_layer* layers, int n_layers, int bN, const uin
                      const uint64_t* qprime, uint64_t* flat, uint64_t* outputs_or_null) {
     gkrhip_session* s = nullptr;
     CHK(gkrhip_session_create(&s, layers, n_layers, bN));
+    s->pool_lane = true;
     int rc = 0;
     if (gkrhip_session_num_inputs(s) != n_inputs) rc = fail("gkr.Prove: the circuit has %d input layers, %d tables were given", gkrhip_session_num_inputs(s), n_inputs);
     if (rc == 0) rc = session_load_assign(s, inputs, n_inputs);
