@@ -211,8 +211,15 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes l
         int s = 0;
         while (s + 1 <= logn - 1 && g >= n - (n >> (s + 1)) + (s + 1)) s++;       // the table this entry belongs to
         const size_t j = g - (n - (n >> s) + s), i = j << s;
-        st_fr(tw.lo, tw.hi, g, i == (n >> 1) ? fr_sub(fr_zero(), fr_one())
-                                             : fr_mul(ld_fr(hi.lo, hi.hi, i >> l0), ld_fr(lo.lo, lo.hi, i & (((size_t)1 << l0) - 1))));
+        // The tables hold n + logn - 1 entries; entry n + logn - 1 is padding (j = 2 of the last table: i = n).  Until round 5 it
+        // was computed like the others and read hi[n >> l0], TWICE the length of that table away: harmless where the bytes behind
+        // the table are mapped, "Memory access fault by GPU" where they are not -- one run of the default bench line in ~12,
+        // located with tools/alloc_trace.c (profiles/r05_anomalies.md (c)).
+        Fr w;
+        if (i < (n >> 1)) w = fr_mul(ld_fr(hi.lo, hi.hi, i >> l0), ld_fr(lo.lo, lo.hi, i & (((size_t)1 << l0) - 1)));
+        else if (i == (n >> 1)) w = fr_sub(fr_zero(), fr_one());
+        else w = fr_zero();
+        st_fr(tw.lo, tw.hi, g, w);
     }
 }
 // The per-position factors of the coset transforms, as gnark-crypto's fft.Domain precomputes its CosetTable / CosetTableInv

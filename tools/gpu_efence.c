@@ -1,0 +1,159 @@
+/* gpu_efence -- LD_PRELOAD shim that turns reads and writes past the END of a device buffer into a deterministic
+ * "Memory access fault by GPU" (an electric fence for hipMalloc).  Diagnostic only; not part of the product.
+ *
+ * Why: round 5's one-in-twelve abort of the default bench line was a kernel reading 64 KiB behind a 64 KiB table
+ * (k_ntt_twiddles' padding entry, profiles/r05_anomalies.md (c)).  Behind a hipMalloc'ed buffer there is nearly always more
+ * mapped memory, so such a read is silent; it faults only when the buffer happens to end a mapped range.  Under this shim EVERY
+ * buffer ends a mapped range: hipMalloc(n) reserves virtual addresses for the rounded-up size PLUS one unmapped granule, maps
+ * physical memory over the first part only, and returns a pointer placed so that the buffer's last byte (rounded up to 256 B,
+ * hipMalloc's alignment) is the last mapped byte.  hipFree waits for the device, unmaps and releases.
+ *
+ *   gcc -O2 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o /tmp/gpu_efence.so tools/gpu_efence.c -ldl -lpthread
+ *   LD_PRELOAD="$LD_PRELOAD:/tmp/gpu_efence.so" python -m pytest tests -m gpu ...
+ * GPU_EFENCE_MIN (bytes, default 0): smaller requests go to the real hipMalloc.  GPU_EFENCE_LOG=1: one line per call on stderr. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+typedef hipError_t (*fn_malloc)(void**, size_t);
+typedef hipError_t (*fn_free)(void*);
+
+static void* rt(const char* name) {
+    static void* h = 0;
+    void* f = dlsym(RTLD_NEXT, name);
+    if (!f) {
+        if (!h) h = dlopen("libamdhip64.so", RTLD_LAZY | RTLD_NOLOAD);
+        if (!h) h = dlopen("libamdhip64.so.7", RTLD_LAZY | RTLD_NOLOAD);
+        if (!h) h = dlopen("libamdhip64.so", RTLD_LAZY);
+        if (h) f = dlsym(h, name);
+    }
+    if (!f) {
+        fprintf(stderr, "gpu_efence: %s not found in the HIP runtime\n", name);
+        _exit(97);
+    }
+    return f;
+}
+#define RT(name) ((__typeof__(&name))rt(#name))
+
+struct rec {
+    void* user;      /* what hipMalloc returned */
+    void* va;        /* start of the reservation */
+    size_t mapped, reserved;
+    hipMemGenericAllocationHandle_t h;
+};
+static struct rec* recs = 0;
+static size_t nrecs = 0, caprecs = 0;
+static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+static size_t gran = 0, min_bytes = 0;
+static int logging = 0, n_fenced = 0, n_plain = 0;
+
+static void setup(void) {
+    if (gran) return;
+    const char* e = getenv("GPU_EFENCE_MIN");
+    if (e) min_bytes = strtoull(e, 0, 0);
+    logging = getenv("GPU_EFENCE_LOG") != 0;
+    int dev = 0;
+    (void)RT(hipGetDevice)(&dev);
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t g = 0;
+    if (RT(hipMemGetAllocationGranularity)(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g == 0) g = 2u << 20;
+    gran = g;
+    fprintf(stderr, "gpu_efence: active, granule %zu bytes, fencing requests >= %zu bytes\n", gran, min_bytes);
+}
+
+hipError_t hipMalloc(void** out, size_t n) {
+    pthread_mutex_lock(&mu);
+    setup();
+    pthread_mutex_unlock(&mu);
+    if (n == 0 || n < min_bytes) {
+        __sync_fetch_and_add(&n_plain, 1);
+        return ((fn_malloc)rt("hipMalloc"))(out, n);
+    }
+    int dev = 0;
+    (void)RT(hipGetDevice)(&dev);
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    const size_t n256 = (n + 255) & ~(size_t)255;
+    const size_t mapped = (n256 + gran - 1) / gran * gran, reserved = mapped + gran;
+    void* va = 0;
+    hipMemGenericAllocationHandle_t h;
+    hipError_t e = RT(hipMemAddressReserve)(&va, reserved, gran, 0, 0);
+    if (e != hipSuccess) return hipErrorOutOfMemory;
+    e = RT(hipMemCreate)(&h, mapped, &prop, 0);
+    if (e != hipSuccess) {
+        (void)RT(hipMemAddressFree)(va, reserved);
+        (void)RT(hipGetLastError)();
+        return hipErrorOutOfMemory;
+    }
+    e = RT(hipMemMap)(va, mapped, 0, h, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc;
+        memset(&acc, 0, sizeof acc);
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = RT(hipMemSetAccess)(va, mapped, &acc, 1);
+        if (e != hipSuccess) (void)RT(hipMemUnmap)(va, mapped);
+    }
+    if (e != hipSuccess) {
+        (void)RT(hipMemRelease)(h);
+        (void)RT(hipMemAddressFree)(va, reserved);
+        (void)RT(hipGetLastError)();
+        return hipErrorOutOfMemory;
+    }
+    void* user = (char*)va + (mapped - n256);
+    pthread_mutex_lock(&mu);
+    if (nrecs == caprecs) {
+        caprecs = caprecs ? 2 * caprecs : 1024;
+        recs = (struct rec*)realloc(recs, caprecs * sizeof *recs);
+    }
+    recs[nrecs].user = user;
+    recs[nrecs].va = va;
+    recs[nrecs].mapped = mapped;
+    recs[nrecs].reserved = reserved;
+    recs[nrecs].h = h;
+    nrecs++;
+    n_fenced++;
+    pthread_mutex_unlock(&mu);
+    if (logging) fprintf(stderr, "gpu_efence: malloc %zu -> %p (mapped %p + %zu)\n", n, user, va, mapped);
+    *out = user;
+    return hipSuccess;
+}
+
+hipError_t hipFree(void* p) {
+    if (!p) return hipSuccess;
+    struct rec r;
+    int found = 0;
+    pthread_mutex_lock(&mu);
+    for (size_t i = nrecs; i-- > 0;)
+        if (recs[i].user == p) {
+            r = recs[i];
+            recs[i] = recs[--nrecs];
+            found = 1;
+            break;
+        }
+    pthread_mutex_unlock(&mu);
+    if (!found) return ((fn_free)rt("hipFree"))(p);
+    (void)RT(hipDeviceSynchronize)();      /* hipFree's implicit wait for every stream */
+    hipError_t e = RT(hipMemUnmap)(r.va, r.mapped);
+    (void)RT(hipMemRelease)(r.h);
+    (void)RT(hipMemAddressFree)(r.va, r.reserved);
+    if (logging) fprintf(stderr, "gpu_efence: free %p\n", p);
+    return e;
+}
+
+__attribute__((destructor)) static void report(void) {
+    if (gran) fprintf(stderr, "gpu_efence: %d fenced allocations, %d passed through, %zu still live at exit\n", n_fenced, n_plain, nrecs);
+}
