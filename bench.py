@@ -536,7 +536,8 @@ def profiler_present():
 
 def supervise():
     """N = 1: the measurement runs in a child process (this one never touches the GPU).  A child that dies without printing its line
-    -- round 5 saw ONE abort in nineteen runs of the default line, never reproduced, stderr not kept -- is run once more, and the line
+    -- round 5 saw one abort in about twelve runs of the default line (an out-of-bounds read in k_ntt_twiddles, since fixed:
+    profiles/r05_anomalies.md (c)) -- is run once more, and the line
     says so (`bench_attempts`, `first_attempt`): a rare crash must cost a minute, not the round's number."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]

@@ -434,6 +434,11 @@ int gkrhip_set_option(const char* key, long value) {
         g_verify_after_prove.store(value != 0);
         return 0;
     }
+    if (!strcmp(key, "arena_check")) {          // host_ctx.hip.h: table_release
+        g_arena_check.store((int)value);
+        if (value) g_cnt_busy_releases.store(0);
+        return 0;
+    }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
         g_msm_sort_levels.store((int)value);
         return 0;
@@ -2180,6 +2185,7 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "hw_queues_from_environment") *value = (uint64_t)g_hwq_from_env.load();
     else if (n == "layer_checks") *value = g_cnt_layer_checks.load();
     else if (n == "layer_check_failures") *value = g_cnt_layer_check_failures.load();
+    else if (n == "arena_busy_releases") *value = g_cnt_busy_releases.load();
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);
     return 0;
 }

@@ -186,6 +186,7 @@ struct Ctx {
     int pre_start_lg = 20;                     // the look-ahead kernel is queued when the layer's rounds reach 2^n pairs (16 before round 0 ran ahead of its point: its products are now wanted at the START of the host tail; bN = 24 alone 269.3 -> 262.1 ms, bN = 22 137.5 -> 134.9)
     hipStream_t aux = nullptr;                 // stream of the look-ahead kernel (normal priority: see pre_prepare)
     hipEvent_t pre_done = nullptr;
+    hipEvent_t chk_fence = nullptr;            // arena_check: recorded in front of everything queued AHEAD for the next layer (ahead_launch)
     DevTable pre_t[6];                         // u^4, d^4, u^3, u^2 d, u d^2, d^3 (P entries each); arena tables, released by pre_release()
     const uint4* pre_K = nullptr;              // what pre_t was computed from (valid when pre_K != nullptr)
     const uint4* pre_S = nullptr;
@@ -478,8 +479,10 @@ void lane_free() {
     pre_release();
     if (cx().aux) (void)hipStreamDestroy(cx().aux);
     if (cx().pre_done) (void)hipEventDestroy(cx().pre_done);
+    if (cx().chk_fence) (void)hipEventDestroy(cx().chk_fence);
     cx().aux = nullptr;
     cx().pre_done = nullptr;
+    cx().chk_fence = nullptr;
     if (cx().h_ahead) (void)hipHostFree(cx().h_ahead);
     if (cx().d_ahead_racc) (void)hipFree(cx().d_ahead_racc);
     if (cx().d_ahead_counter) (void)hipFree(cx().d_ahead_counter);
@@ -652,15 +655,50 @@ int table_alloc(DevTable* t, size_t cap) {
     t->cap = cap;
     return 0;
 }
-void table_release(DevTable* t) {
+// gkrhip_set_option("arena_check", 1) (tests): a buffer handed back goes to the NEXT caller of its size class, which may be
+// another lane with another stream, so nothing of the releasing lane may still be using it.  With the option on, every release
+// asks the lane's streams whether they are idle; a release with work still queued is counted (`arena_busy_releases`) and its
+// call site named once on stderr.  An idle stream proves the release safe; a busy one is a site to look at.
+std::atomic<int> g_arena_check{0};
+std::atomic<unsigned long long> g_cnt_busy_releases{0};
+std::mutex g_busy_mu;
+std::vector<std::pair<std::string, int>> g_busy_lines;
+void table_release(DevTable* t, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
     if (t->base) {
+        if (g_arena_check.load(std::memory_order_relaxed)) {
+            // (the look-ahead stream only ever holds k_cipher_pre: it reads the NEXT layer's assignment tables and writes pre_t,
+            // which pre_release hands back behind a synchronisation of that stream.  Round 0 of the next layer queued ahead of
+            // its point -- ahead_launch -- legitimately runs past the end of THIS layer on the lane's own stream: it touches the
+            // next layer's tables and the lane's ahead_* tables only, so what has to be idle is everything queued in front of it.)
+            // (un-sharded round loops wait for each kernel through the flag its LAST workgroup raises once every workgroup has
+            // arrived with its stores drained, not through the stream: the runtime may retire that kernel microseconds after the
+            // host has seen the flag.  A stream that drains within 2 ms was in that tail; one that does not -- a kernel still
+            // polling for a challenge, a launch nobody waited for -- is the finding.)
+            auto idle = [&]() {
+                if (!cx().stream || hipStreamQuery(cx().stream) != hipErrorNotReady) return true;
+                return cx().ahead_K && cx().chk_fence && hipEventQuery(cx().chk_fence) == hipSuccess;
+            };
+            bool busy = !idle();
+            for (const double t0 = now_ms(); busy && now_ms() - t0 < 2.0;) busy = !idle();
+            (void)hipGetLastError();
+            if (busy) {
+                g_cnt_busy_releases.fetch_add(1, std::memory_order_relaxed);
+                std::lock_guard<std::mutex> lk(g_busy_mu);
+                const char* base = strrchr(file, '/');
+                const std::pair<std::string, int> site(base ? base + 1 : file, line);
+                if (std::find(g_busy_lines.begin(), g_busy_lines.end(), site) == g_busy_lines.end()) {
+                    g_busy_lines.push_back(site);
+                    fprintf(stderr, "gkrhip arena_check: a table is released at %s:%d while its lane's stream still has work queued\n", site.first.c_str(), line);
+                }
+            }
+        }
         std::lock_guard<std::mutex> lk(g_pool.mu);
         g_pool.free_list[t->cap].push_back(t->base);
     }
     t->base = nullptr;
     t->cap = 0;
 }
-void table_release_fwd(DevTable* t) { table_release(t); }
+void table_release_fwd(DevTable* t) { table_release(t, -1, "pre_release"); }
 void table_free(DevTable* t) {
     if (t->base) (void)hipFree(t->base);
     t->base = nullptr;

@@ -370,6 +370,10 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
             CHK(table_alloc(tc.first, tc.second));
         }
     CHK(stage_coords(chal, (size_t)(m - t)));
+    if (g_arena_check.load(std::memory_order_relaxed)) {      // table_release: everything in front of this point must be done when this layer's scratch goes back
+        if (!cx().chk_fence) HIPCHK(hipEventCreateWithFlags(&cx().chk_fence, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(cx().chk_fence, cx().stream));
+    }
     PyramidArgs3 pa3;
     memset(&pa3, 0, sizeof pa3);
     for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;

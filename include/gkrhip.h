@@ -85,6 +85,8 @@ int gkrhip_reserve_lanes(int n);
  * scalar work, microseconds) and run once more in safe mode if it does not close; a second failure is an error, never a
  * wrong proof.  "verify_after_prove" (default 0) -- the one-shot calls (gkrhip_gkr_prove_mimc{,_regular}, gkrhip_gkr_prove) run
  * gkr.Verify on their proof before returning it, as the reference's hint does in debug builds (prover/gadget/hints.go:224-228).
+ * "arena_check" (default 0; tests) -- every table handed back to the device arena asks its lane's streams whether they are
+ * idle; a release with work still queued is counted ("arena_busy_releases") and its call site named once on stderr.
  * Fault injection for the tests, each firing once: "test_fail_after_prelaunch", "test_drop_challenge", "test_corrupt_sum" = k
  * (flip one bit of a device sum of round k; "test_corrupt_times" = n afterwards: n times instead of once; "test_corrupt_skip" = j: in the (j+1)-th sumcheck that reaches round k), "test_corrupt_tail" = 1 (flip one bit of the table entries handed to the host). */
 int gkrhip_set_option(const char *key, long value);
@@ -409,7 +411,7 @@ int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_rou
  * layers whose round 0 was queued by the layer before them; "hw_queues_set_by_library": the count gkrhip_init put into the
  * process's GPU_MAX_HW_QUEUES (0: it found the variable set -- "hw_queues_from_environment" -- or was told to leave it
  * alone); the runtime reads the variable when it initialises, so the setting only takes effect if the library made the
- * process's first HIP call.  Unknown name: error. */
+ * process's first HIP call; "arena_busy_releases": see gkrhip_set_option, "arena_check".  Unknown name: error. */
 int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus

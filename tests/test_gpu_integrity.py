@@ -241,3 +241,44 @@ def test_gmimc_circuit_linear_layers():
                 assert gk.profile_get()["layer_check_failures"] == 1, (k, layer, gk.profile_get())
         print("INTEGRITY-OK")
     """)
+
+
+ARENA = """
+    gk.set_option("arena_check", 1)
+    bn, lanes = %d, %d
+    qp = c.random_fr_array(bn)
+    i0 = c.random_fr_array(1 << bn)
+    want, wouts, _ = c.gkr_prove_mimc(bn, i0, i0.copy(), qp)
+    ss = []
+    for _ in range(lanes):
+        s = gk.MimcSession(bn); s.synth_inputs(); s.assign(); ss.append(s)
+    bad = []
+    def work(k):
+        for rep in range(3):
+            if not np.array_equal(ss[k].prove(qp), want):
+                bad.append((k, rep))
+        # the one-shot call of the hint (a session, a lane and a download lane per call) between the resident proofs
+        flat, outs = gk.gkr_prove_mimc(i0, i0.copy(), qp)
+        if not (np.array_equal(flat, want) and np.array_equal(outs, wouts)):
+            bad.append((k, "oneshot"))
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(lanes)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for s in ss:
+        s.close()
+    assert not bad, bad
+    n = gk.profile_counter("arena_busy_releases")
+    assert n == 0, "%%d tables went back to the arena while their lane's stream still had work queued (sites on stderr)" %% n
+    print("INTEGRITY-OK")
+"""
+
+
+def test_no_table_goes_back_to_the_arena_while_its_lane_is_busy():
+    """The arena hands a released buffer to the next caller of its size class -- since round 5 the most recently released one
+    first, often another lane with another stream.  With arena_check on, every release asks the releasing lane's streams
+    whether they are idle: one proof alone (everything queued ahead), the solo paths forced on for eight lanes, the
+    reference-shaped evaluator, and one-shot calls in between; transcripts against the oracle as everywhere."""
+    _run(ARENA % (12, 1))
+    _run(ARENA % (13, 8), {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRE": "2", "GKRHIP_SPEC": "2"})
+    _run(ARENA % (13, 8))
+    _run(ARENA % (11, 4), {"GKRHIP_GENERIC": "1"})

@@ -10,7 +10,15 @@
  *
  *   gcc -O2 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o /tmp/gpu_efence.so tools/gpu_efence.c -ldl -lpthread
  *   LD_PRELOAD="$LD_PRELOAD:/tmp/gpu_efence.so" python -m pytest tests -m gpu ...
- * GPU_EFENCE_MIN (bytes, default 0): smaller requests go to the real hipMalloc.  GPU_EFENCE_LOG=1: one line per call on stderr. */
+ * Which requests are fenced.  By default only those whose size (rounded to 256 B) is a whole number of granules (4 KiB on
+ * gfx950): the returned pointer is then the START of the mapping.  GPU_EFENCE_INTERIOR=1 fences every request, returning a pointer
+ * INSIDE a mapping for the others -- tighter, but ROCm 7.2's copy and fill paths do not all cope with interior pointers of
+ * virtual-memory mappings (wrong results, "Memobj map does not have ptr", host heap corruption: profiles/r05_efence.txt), so
+ * failures in that mode are not evidence against the program under test.
+ * GPU_EFENCE_MIN (bytes, default 0): smaller requests go to the real hipMalloc.  GPU_EFENCE_LOG=1: one line per call on stderr.
+ * GPU_EFENCE_POISON=<byte, e.g. 0xff>: every buffer, fenced or not, is filled with that byte before it is handed out, so a
+ * kernel that reads memory nobody wrote (and got away with it because fresh device memory is zero) computes with garbage
+ * and its test fails.  GPU_EFENCE_MIN=-1 with a poison byte: poisoning only, no fences. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -49,14 +57,25 @@ struct rec {
 static struct rec* recs = 0;
 static size_t nrecs = 0, caprecs = 0;
 static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t vmm = PTHREAD_MUTEX_INITIALIZER;      /* the virtual-memory calls, one at a time (GPU_EFENCE_PARALLEL=1: not) */
+static int serial = 1, interior = 0, poison = -1;
+static hipError_t fill(void* p, size_t n) {
+    if (poison < 0) return hipSuccess;
+    hipError_t e = RT(hipMemset)(p, poison, n);
+    if (e == hipSuccess) e = RT(hipDeviceSynchronize)();
+    return e;
+}
 static size_t gran = 0, min_bytes = 0;
 static int logging = 0, n_fenced = 0, n_plain = 0;
 
 static void setup(void) {
     if (gran) return;
     const char* e = getenv("GPU_EFENCE_MIN");
-    if (e) min_bytes = strtoull(e, 0, 0);
+    if (e) min_bytes = strtoull(e, 0, 0);      /* -1: nothing is fenced */
     logging = getenv("GPU_EFENCE_LOG") != 0;
+    serial = getenv("GPU_EFENCE_PARALLEL") == 0;
+    interior = getenv("GPU_EFENCE_INTERIOR") != 0;
+    if (getenv("GPU_EFENCE_POISON")) poison = (int)(strtoul(getenv("GPU_EFENCE_POISON"), 0, 0) & 255);
     int dev = 0;
     (void)RT(hipGetDevice)(&dev);
     hipMemAllocationProp prop;
@@ -67,16 +86,18 @@ static void setup(void) {
     size_t g = 0;
     if (RT(hipMemGetAllocationGranularity)(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g == 0) g = 2u << 20;
     gran = g;
-    fprintf(stderr, "gpu_efence: active, granule %zu bytes, fencing requests >= %zu bytes\n", gran, min_bytes);
+    fprintf(stderr, "gpu_efence: active, granule %zu bytes, fencing %s requests >= %zu bytes, poison %d\n", gran, interior ? "all" : "granule-sized", min_bytes, poison);
 }
 
 hipError_t hipMalloc(void** out, size_t n) {
     pthread_mutex_lock(&mu);
     setup();
     pthread_mutex_unlock(&mu);
-    if (n == 0 || n < min_bytes) {
+    if (n == 0 || n < min_bytes || (!interior && ((n + 255) & ~(size_t)255) % gran != 0)) {
         __sync_fetch_and_add(&n_plain, 1);
-        return ((fn_malloc)rt("hipMalloc"))(out, n);
+        hipError_t e0 = ((fn_malloc)rt("hipMalloc"))(out, n);
+        if (e0 == hipSuccess && n) (void)fill(*out, n);
+        return e0;
     }
     int dev = 0;
     (void)RT(hipGetDevice)(&dev);
@@ -89,12 +110,17 @@ hipError_t hipMalloc(void** out, size_t n) {
     const size_t mapped = (n256 + gran - 1) / gran * gran, reserved = mapped + gran;
     void* va = 0;
     hipMemGenericAllocationHandle_t h;
+    if (serial) pthread_mutex_lock(&vmm);
     hipError_t e = RT(hipMemAddressReserve)(&va, reserved, gran, 0, 0);
-    if (e != hipSuccess) return hipErrorOutOfMemory;
+    if (e != hipSuccess) {
+        if (serial) pthread_mutex_unlock(&vmm);
+        return hipErrorOutOfMemory;
+    }
     e = RT(hipMemCreate)(&h, mapped, &prop, 0);
     if (e != hipSuccess) {
         (void)RT(hipMemAddressFree)(va, reserved);
         (void)RT(hipGetLastError)();
+        if (serial) pthread_mutex_unlock(&vmm);
         return hipErrorOutOfMemory;
     }
     e = RT(hipMemMap)(va, mapped, 0, h, 0);
@@ -111,8 +137,10 @@ hipError_t hipMalloc(void** out, size_t n) {
         (void)RT(hipMemRelease)(h);
         (void)RT(hipMemAddressFree)(va, reserved);
         (void)RT(hipGetLastError)();
+        if (serial) pthread_mutex_unlock(&vmm);
         return hipErrorOutOfMemory;
     }
+    if (serial) pthread_mutex_unlock(&vmm);
     void* user = (char*)va + (mapped - n256);
     pthread_mutex_lock(&mu);
     if (nrecs == caprecs) {
@@ -128,6 +156,7 @@ hipError_t hipMalloc(void** out, size_t n) {
     n_fenced++;
     pthread_mutex_unlock(&mu);
     if (logging) fprintf(stderr, "gpu_efence: malloc %zu -> %p (mapped %p + %zu)\n", n, user, va, mapped);
+    (void)fill(user, n);
     *out = user;
     return hipSuccess;
 }
@@ -146,11 +175,14 @@ hipError_t hipFree(void* p) {
         }
     pthread_mutex_unlock(&mu);
     if (!found) return ((fn_free)rt("hipFree"))(p);
+    if (logging) fprintf(stderr, "gpu_efence: free %p ...\n", p);
     (void)RT(hipDeviceSynchronize)();      /* hipFree's implicit wait for every stream */
+    if (serial) pthread_mutex_lock(&vmm);
     hipError_t e = RT(hipMemUnmap)(r.va, r.mapped);
     (void)RT(hipMemRelease)(r.h);
     (void)RT(hipMemAddressFree)(r.va, r.reserved);
-    if (logging) fprintf(stderr, "gpu_efence: free %p\n", p);
+    if (serial) pthread_mutex_unlock(&vmm);
+    if (logging) fprintf(stderr, "gpu_efence: ... freed %p\n", p);
     return e;
 }
 
