@@ -428,6 +428,7 @@ def orchestrate(args):
         # pass NEEDS one queue per lane stream: the collective kernels of different lanes must be able to run side by side,
         # whatever order the ranks issue them in
         env.setdefault("GPU_MAX_HW_QUEUES", "16")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the pool's host driver supports dmabuf IPC only: without it RCCL's hipIpcGetMemHandle fails
         # First contact with a real multi-rank communicator happens on the driver's 8-GPU node, where nobody can re-run by hand:
         # RCCL's own warnings (silent unless something fails) are captured with the child's stderr and, if the pass fails, their
         # tail goes into the JSON line (passes.<name>.rccl_log) instead of only "invalid usage"
