@@ -300,6 +300,11 @@ struct Pool {
     // per layer and lane: GMiMC bN = 22 with 12 lanes 103.8 M hashes/s behind such a job against 113.9 before it.)
     std::unordered_map<size_t, std::vector<uint4*>> free_list;
 } g_pool;
+// arena_check (table_release): 0 off, 1 count releases with the lane still busy, 2 also poison what is released
+std::atomic<int> g_arena_check{0};
+std::atomic<unsigned long long> g_cnt_busy_releases{0};
+std::mutex g_busy_mu;
+std::vector<std::pair<std::string, int>> g_busy_lines;
 thread_local std::string g_err;
 // Every failure gets a code of its own (<= -16) and its message is kept under that code in a process-wide ring, so that a
 // caller whose thread has changed between the failing call and the question (a goroutine that migrated to another OS
@@ -413,6 +418,7 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC")) cx().spec = atoi(e);
     if (const char* e = getenv("GKRHIP_AHEAD")) cx().ahead_mode = atoi(e);
+    if (const char* e = getenv("GKRHIP_ARENA_CHECK")) g_arena_check.store(atoi(e));      // debugging aid, see table_release
     if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
@@ -659,10 +665,6 @@ int table_alloc(DevTable* t, size_t cap) {
 // another lane with another stream, so nothing of the releasing lane may still be using it.  With the option on, every release
 // asks the lane's streams whether they are idle; a release with work still queued is counted (`arena_busy_releases`) and its
 // call site named once on stderr.  An idle stream proves the release safe; a busy one is a site to look at.
-std::atomic<int> g_arena_check{0};
-std::atomic<unsigned long long> g_cnt_busy_releases{0};
-std::mutex g_busy_mu;
-std::vector<std::pair<std::string, int>> g_busy_lines;
 void table_release(DevTable* t, int line = __builtin_LINE(), const char* file = __builtin_FILE()) {
     if (t->base) {
         if (g_arena_check.load(std::memory_order_relaxed)) {
@@ -681,6 +683,13 @@ void table_release(DevTable* t, int line = __builtin_LINE(), const char* file = 
             bool busy = !idle();
             for (const double t0 = now_ms(); busy && now_ms() - t0 < 2.0;) busy = !idle();
             (void)hipGetLastError();
+            // arena_check = 2: the buffer is also filled with 0xff behind everything queued on the lane's stream before the next
+            // owner can have it -- whoever still reads it afterwards, or relies on what a recycled buffer used to hold, computes
+            // with values above q and its proof differs from the oracle's (GKRHIP_ARENA_CHECK=2 over the whole GPU suite)
+            if (g_arena_check.load(std::memory_order_relaxed) >= 2 && cx().stream) {
+                (void)hipMemsetAsync(t->base, 0xff, sizeof(uint4) * 2 * t->cap, cx().stream);
+                (void)hipStreamSynchronize(cx().stream);
+            }
             if (busy) {
                 g_cnt_busy_releases.fetch_add(1, std::memory_order_relaxed);
                 std::lock_guard<std::mutex> lk(g_busy_mu);

@@ -86,7 +86,8 @@ int gkrhip_reserve_lanes(int n);
  * wrong proof.  "verify_after_prove" (default 0) -- the one-shot calls (gkrhip_gkr_prove_mimc{,_regular}, gkrhip_gkr_prove) run
  * gkr.Verify on their proof before returning it, as the reference's hint does in debug builds (prover/gadget/hints.go:224-228).
  * "arena_check" (default 0; tests) -- every table handed back to the device arena asks its lane's streams whether they are
- * idle; a release with work still queued is counted ("arena_busy_releases") and its call site named once on stderr.
+ * idle; a release with work still queued is counted ("arena_busy_releases") and its call site named once on stderr; 2: the
+ * released table is also filled with 0xff behind the lane's queued work (environment: GKRHIP_ARENA_CHECK).
  * Fault injection for the tests, each firing once: "test_fail_after_prelaunch", "test_drop_challenge", "test_corrupt_sum" = k
  * (flip one bit of a device sum of round k; "test_corrupt_times" = n afterwards: n times instead of once; "test_corrupt_skip" = j: in the (j+1)-th sumcheck that reaches round k), "test_corrupt_tail" = 1 (flip one bit of the table entries handed to the host). */
 int gkrhip_set_option(const char *key, long value);
