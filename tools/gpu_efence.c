@@ -10,11 +10,12 @@
  *
  *   gcc -O2 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o /tmp/gpu_efence.so tools/gpu_efence.c -ldl -lpthread
  *   LD_PRELOAD="$LD_PRELOAD:/tmp/gpu_efence.so" python -m pytest tests -m gpu ...
- * Which requests are fenced.  By default only those whose size (rounded to 256 B) is a whole number of granules (4 KiB on
- * gfx950): the returned pointer is then the START of the mapping.  GPU_EFENCE_INTERIOR=1 fences every request, returning a pointer
- * INSIDE a mapping for the others -- tighter, but ROCm 7.2's copy and fill paths do not all cope with interior pointers of
- * virtual-memory mappings (wrong results, "Memobj map does not have ptr", host heap corruption: profiles/r05_efence.txt), so
- * failures in that mode are not evidence against the program under test.
+ * Every request is fenced; one whose size (rounded to 256 B) is not a whole number of granules (4 KiB on gfx950) gets a pointer
+ * INSIDE its mapping.  GPU_EFENCE_ALIGNED=1 fences only the granule-sized requests (pointer = start of the mapping).
+ * Address ranges are NEVER given back (hipFree unmaps and releases the memory, the reservation stays): on ROCm 7.2.0 a range that
+ * is freed and handed out again by the next hipMemAddressReserve reads and writes the wrong memory (tools/vmm_interior_probe.hip:
+ * 103 of 600 iterations right when ranges are recycled, 600 of 600 when they are kept) -- the first version of this shim freed
+ * them and produced wrong sums, "Memobj map does not have ptr" and host heap corruption in the program under test.
  * GPU_EFENCE_MIN (bytes, default 0): smaller requests go to the real hipMalloc.  GPU_EFENCE_LOG=1: one line per call on stderr.
  * GPU_EFENCE_POISON=<byte, e.g. 0xff>: every buffer, fenced or not, is filled with that byte before it is handed out, so a
  * kernel that reads memory nobody wrote (and got away with it because fresh device memory is zero) computes with garbage
@@ -74,7 +75,7 @@ static void setup(void) {
     if (e) min_bytes = strtoull(e, 0, 0);      /* -1: nothing is fenced */
     logging = getenv("GPU_EFENCE_LOG") != 0;
     serial = getenv("GPU_EFENCE_PARALLEL") == 0;
-    interior = getenv("GPU_EFENCE_INTERIOR") != 0;
+    interior = getenv("GPU_EFENCE_ALIGNED") == 0;
     if (getenv("GPU_EFENCE_POISON")) poison = (int)(strtoul(getenv("GPU_EFENCE_POISON"), 0, 0) & 255);
     int dev = 0;
     (void)RT(hipGetDevice)(&dev);
@@ -179,8 +180,7 @@ hipError_t hipFree(void* p) {
     (void)RT(hipDeviceSynchronize)();      /* hipFree's implicit wait for every stream */
     if (serial) pthread_mutex_lock(&vmm);
     hipError_t e = RT(hipMemUnmap)(r.va, r.mapped);
-    (void)RT(hipMemRelease)(r.h);
-    (void)RT(hipMemAddressFree)(r.va, r.reserved);
+    (void)RT(hipMemRelease)(r.h);      /* the address range stays reserved: see the header */
     if (serial) pthread_mutex_unlock(&vmm);
     if (logging) fprintf(stderr, "gpu_efence: ... freed %p\n", p);
     return e;
