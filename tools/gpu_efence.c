@@ -16,6 +16,10 @@
  * is freed and handed out again by the next hipMemAddressReserve reads and writes the wrong memory (tools/vmm_interior_probe.hip:
  * 103 of 600 iterations right when ranges are recycled, 600 of 600 when they are kept) -- the first version of this shim freed
  * them and produced wrong sums, "Memobj map does not have ptr" and host heap corruption in the program under test.
+ * The price: while a range stays reserved the runtime does not give the unmapped, released memory back either
+ * (tools/vmm_release_probe.hip: 4 GiB less free memory per iteration), so a process under the shim can only allocate 288 GB in
+ * TOTAL -- enough for the GPU suite (4 441 allocations), not for bench.py's default line.  GPU_EFENCE_FREE_RANGES=1 frees the
+ * ranges again (memory comes back, recycled ranges may misbehave): what the bench-sized run of profiles/r05_efence.txt used.
  * GPU_EFENCE_MIN (bytes, default 0): smaller requests go to the real hipMalloc.  GPU_EFENCE_LOG=1: one line per call on stderr.
  * GPU_EFENCE_POISON=<byte, e.g. 0xff>: every buffer, fenced or not, is filled with that byte before it is handed out, so a
  * kernel that reads memory nobody wrote (and got away with it because fresh device memory is zero) computes with garbage
@@ -59,7 +63,7 @@ static struct rec* recs = 0;
 static size_t nrecs = 0, caprecs = 0;
 static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_mutex_t vmm = PTHREAD_MUTEX_INITIALIZER;      /* the virtual-memory calls, one at a time (GPU_EFENCE_PARALLEL=1: not) */
-static int serial = 1, interior = 0, poison = -1;
+static int serial = 1, interior = 0, poison = -1, free_ranges = 0;
 static hipError_t fill(void* p, size_t n) {
     if (poison < 0) return hipSuccess;
     hipError_t e = RT(hipMemset)(p, poison, n);
@@ -76,6 +80,7 @@ static void setup(void) {
     logging = getenv("GPU_EFENCE_LOG") != 0;
     serial = getenv("GPU_EFENCE_PARALLEL") == 0;
     interior = getenv("GPU_EFENCE_ALIGNED") == 0;
+    free_ranges = getenv("GPU_EFENCE_FREE_RANGES") != 0;
     if (getenv("GPU_EFENCE_POISON")) poison = (int)(strtoul(getenv("GPU_EFENCE_POISON"), 0, 0) & 255);
     int dev = 0;
     (void)RT(hipGetDevice)(&dev);
@@ -181,6 +186,7 @@ hipError_t hipFree(void* p) {
     if (serial) pthread_mutex_lock(&vmm);
     hipError_t e = RT(hipMemUnmap)(r.va, r.mapped);
     (void)RT(hipMemRelease)(r.h);      /* the address range stays reserved: see the header */
+    if (free_ranges) (void)RT(hipMemAddressFree)(r.va, r.reserved);
     if (serial) pthread_mutex_unlock(&vmm);
     if (logging) fprintf(stderr, "gpu_efence: ... freed %p\n", p);
     return e;

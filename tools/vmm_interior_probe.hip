@@ -8,7 +8,7 @@
 //   hipMemsetAsync(p, 0x5a), p -> host, compare
 //   synchronise, unmap, release, free the address range
 // with `threads` host threads at once, each on a stream of its own.
-//   hipcc --offload-arch=gfx950 -O2 -o /tmp/vmm_probe tools/vmm_interior_probe.hip && /tmp/vmm_probe <threads> <iterations> <interior 0|1> <keep 0|1|2>
+//   hipcc --offload-arch=gfx950 -O2 -o /tmp/vmm_probe tools/vmm_interior_probe.hip && /tmp/vmm_probe <threads> <iterations> <interior 0|1> <keep 0|1|2|3|4>
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -29,7 +29,11 @@ __global__ void k_inc(Args a) {
 static std::atomic<long> n_api{0}, n_copy{0}, n_fill{0}, n_ok{0};
 static size_t gran = 4096;
 
-static int g_keep = 0;      // 0: unmap, release, free the address range (it comes back); 1: unmap and release, the range stays reserved; 2: nothing is given back
+static int g_keep = 0;      // 0: unmap, release, free the address range (it comes back); 1: unmap and release, the range stays reserved; 2: nothing is given back;
+                            // 3: unmap and release, the range stays reserved AND the next request of that size maps new memory into it;
+                            // 4: everything is freed, but every reservation ASKS for an address never used before (a cursor that only grows)
+static std::atomic<unsigned long long> g_cursor{0x200000000000ull};      // 32 TiB
+static std::atomic<long> n_hint_ignored{0};
 static void worker(int tid, int iters, bool interior) {
     (void)hipSetDevice(0);
     hipStream_t st;
@@ -40,6 +44,7 @@ static void worker(int tid, int iters, bool interior) {
     const size_t sizes[] = {648, 2872, 8192, 96000, 118800, 131072, 348000, 663552, 1283200};
     unsigned int seed = 12345u + 977u * (unsigned)tid;
     std::vector<unsigned int> src, back;
+    std::vector<std::pair<size_t, void*>> mine;      // keep 3: this thread's reserved, unmapped ranges
     for (int it = 0; it < iters; it++) {
         seed = seed * 1664525u + 1013904223u;
         size_t n = sizes[(seed >> 8) % (sizeof sizes / sizeof sizes[0])];
@@ -52,10 +57,19 @@ static void worker(int tid, int iters, bool interior) {
         prop.location.id = 0;
         void* va = nullptr;
         hipMemGenericAllocationHandle_t h;
-        if (hipMemAddressReserve(&va, reserved, gran, nullptr, 0) != hipSuccess) {
+        for (size_t i = 0; g_keep == 3 && i < mine.size(); i++)
+            if (mine[i].first == reserved) {
+                va = mine[i].second;
+                mine.erase(mine.begin() + i);
+                break;
+            }
+        void* hint = nullptr;
+        if (g_keep == 4) hint = (void*)g_cursor.fetch_add((reserved + (2u << 20) - 1) & ~(unsigned long long)((2u << 20) - 1));
+        if (!va && hipMemAddressReserve(&va, reserved, gran, hint, 0) != hipSuccess) {
             n_api++;
             continue;
         }
+        if (hint && va != hint) n_hint_ignored++;
         if (hipMemCreate(&h, mapped, &prop, 0) != hipSuccess) {
             n_api++;
             (void)hipMemAddressFree(va, reserved);
@@ -99,7 +113,8 @@ static void worker(int tid, int iters, bool interior) {
             (void)hipMemUnmap(va, mapped);
             (void)hipMemRelease(h);
         }
-        if (g_keep < 1) (void)hipMemAddressFree(va, reserved);
+        if (g_keep < 1 || g_keep == 4) (void)hipMemAddressFree(va, reserved);
+        if (g_keep == 3) mine.emplace_back(reserved, va);
     }
     (void)hipStreamDestroy(st);
 }
@@ -117,7 +132,7 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++) th.emplace_back(worker, t, iters, interior);
     for (auto& t : th) t.join();
-    printf("vmm probe: keep %d, %d thread(s) x %d iterations, %s pointers, granule %zu: ok %ld, api errors %ld, wrong after copy+kernel %ld, wrong after fill %ld\n",
-           g_keep, threads, iters, interior ? "INTERIOR" : "start-of-mapping", gran, n_ok.load(), n_api.load(), n_copy.load(), n_fill.load());
+    printf("vmm probe: keep %d, %d thread(s) x %d iterations, %s pointers, granule %zu: ok %ld, api errors %ld, wrong after copy+kernel %ld, wrong after fill %ld, address hints ignored %ld\n",
+           g_keep, threads, iters, interior ? "INTERIOR" : "start-of-mapping", gran, n_ok.load(), n_api.load(), n_copy.load(), n_fill.load(), n_hint_ignored.load());
     return 0;
 }
