@@ -20,6 +20,8 @@
  * (tools/vmm_release_probe.hip: 4 GiB less free memory per iteration), so a process under the shim can only allocate 288 GB in
  * TOTAL -- enough for the GPU suite (4 441 allocations), not for bench.py's default line.  GPU_EFENCE_FREE_RANGES=1 frees the
  * ranges again (memory comes back, recycled ranges may misbehave): what the bench-sized run of profiles/r05_efence.txt used.
+ * GPU_EFENCE_UNDER=1: the fence goes IN FRONT of the buffer instead (one unmapped granule, then the mapping, the pointer at its
+ * start): accesses before the first byte fault; accesses behind the last byte are then only caught from the next granule on.
  * GPU_EFENCE_MIN (bytes, default 0): smaller requests go to the real hipMalloc.  GPU_EFENCE_LOG=1: one line per call on stderr.
  * GPU_EFENCE_POISON=<byte, e.g. 0xff>: every buffer, fenced or not, is filled with that byte before it is handed out, so a
  * kernel that reads memory nobody wrote (and got away with it because fresh device memory is zero) computes with garbage
@@ -63,7 +65,7 @@ static struct rec* recs = 0;
 static size_t nrecs = 0, caprecs = 0;
 static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_mutex_t vmm = PTHREAD_MUTEX_INITIALIZER;      /* the virtual-memory calls, one at a time (GPU_EFENCE_PARALLEL=1: not) */
-static int serial = 1, interior = 0, poison = -1, free_ranges = 0;
+static int serial = 1, interior = 0, poison = -1, free_ranges = 0, under = 0;
 static hipError_t fill(void* p, size_t n) {
     if (poison < 0) return hipSuccess;
     hipError_t e = RT(hipMemset)(p, poison, n);
@@ -81,6 +83,7 @@ static void setup(void) {
     serial = getenv("GPU_EFENCE_PARALLEL") == 0;
     interior = getenv("GPU_EFENCE_ALIGNED") == 0;
     free_ranges = getenv("GPU_EFENCE_FREE_RANGES") != 0;
+    under = getenv("GPU_EFENCE_UNDER") != 0;
     if (getenv("GPU_EFENCE_POISON")) poison = (int)(strtoul(getenv("GPU_EFENCE_POISON"), 0, 0) & 255);
     int dev = 0;
     (void)RT(hipGetDevice)(&dev);
@@ -92,7 +95,7 @@ static void setup(void) {
     size_t g = 0;
     if (RT(hipMemGetAllocationGranularity)(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g == 0) g = 2u << 20;
     gran = g;
-    fprintf(stderr, "gpu_efence: active, granule %zu bytes, fencing %s requests >= %zu bytes, poison %d\n", gran, interior ? "all" : "granule-sized", min_bytes, poison);
+    fprintf(stderr, "gpu_efence: active, granule %zu bytes, fencing %s requests >= %zu bytes, poison %d%s\n", gran, interior ? "all" : "granule-sized", min_bytes, poison, under ? ", fence IN FRONT of the buffers" : "");
 }
 
 hipError_t hipMalloc(void** out, size_t n) {
@@ -129,15 +132,16 @@ hipError_t hipMalloc(void** out, size_t n) {
         if (serial) pthread_mutex_unlock(&vmm);
         return hipErrorOutOfMemory;
     }
-    e = RT(hipMemMap)(va, mapped, 0, h, 0);
+    char* const at = (char*)va + (under ? gran : 0);      /* where the mapping starts inside the reservation */
+    e = RT(hipMemMap)(at, mapped, 0, h, 0);
     if (e == hipSuccess) {
         hipMemAccessDesc acc;
         memset(&acc, 0, sizeof acc);
         acc.location.type = hipMemLocationTypeDevice;
         acc.location.id = dev;
         acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = RT(hipMemSetAccess)(va, mapped, &acc, 1);
-        if (e != hipSuccess) (void)RT(hipMemUnmap)(va, mapped);
+        e = RT(hipMemSetAccess)(at, mapped, &acc, 1);
+        if (e != hipSuccess) (void)RT(hipMemUnmap)(at, mapped);
     }
     if (e != hipSuccess) {
         (void)RT(hipMemRelease)(h);
@@ -147,7 +151,7 @@ hipError_t hipMalloc(void** out, size_t n) {
         return hipErrorOutOfMemory;
     }
     if (serial) pthread_mutex_unlock(&vmm);
-    void* user = (char*)va + (mapped - n256);
+    void* user = under ? (void*)at : (void*)((char*)va + (mapped - n256));
     pthread_mutex_lock(&mu);
     if (nrecs == caprecs) {
         caprecs = caprecs ? 2 * caprecs : 1024;
@@ -184,7 +188,7 @@ hipError_t hipFree(void* p) {
     if (logging) fprintf(stderr, "gpu_efence: free %p ...\n", p);
     (void)RT(hipDeviceSynchronize)();      /* hipFree's implicit wait for every stream */
     if (serial) pthread_mutex_lock(&vmm);
-    hipError_t e = RT(hipMemUnmap)(r.va, r.mapped);
+    hipError_t e = RT(hipMemUnmap)((char*)r.va + (under ? gran : 0), r.mapped);
     (void)RT(hipMemRelease)(r.h);      /* the address range stays reserved: see the header */
     if (free_ranges) (void)RT(hipMemAddressFree)(r.va, r.reserved);
     if (serial) pthread_mutex_unlock(&vmm);
