@@ -218,3 +218,65 @@ def test_supervisor_is_not_fooled_by_an_unrelated_preload(tmp_path):
     env = dict(env, LD_PRELOAD=prof, GKRHIP_BENCH_SELFTEST_ABORT_ONCE=str(tmp_path / "died2"))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert "running it once more" not in out.stderr, out.stderr[-1500:]
+
+
+def test_measuring_process_dies_with_the_supervisor_and_its_stderr_is_live(tmp_path):
+    """a driver that kills bench.py (SIGTERM or SIGKILL) must not leave the measuring child behind with the GPU and its
+    HBM; and the child's stderr reaches the log while it runs, not when it ends."""
+    import signal, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        pidfile = tmp_path / ("pid_%d" % int(sig))
+        env = dict(os.environ, GKRHIP_BENCH_SELFTEST_HANG=str(pidfile))
+        for k in [k for k in env if k.startswith(("ROCPROF", "ROCPROFILER_")) or k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCP_TOOL_LIBRARIES")]:
+            env.pop(k)
+        errlog = open(tmp_path / ("err_%d" % int(sig)), "wb")
+        parent = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], env=env,
+                                  stdout=subprocess.DEVNULL, stderr=errlog)
+        t0 = time.time()
+        while not (pidfile.exists() and pidfile.read_text().strip()) and time.time() - t0 < 120:
+            time.sleep(0.1)
+        child = int(pidfile.read_text())
+        time.sleep(0.3)
+        assert b"measuring process %d stalls" % child in open(errlog.name, "rb").read()      # live, while the child still runs
+        os.kill(child, 0)                                                                     # (it does)
+        parent.send_signal(sig)
+        parent.wait(30)
+        gone = False
+        for _ in range(100):
+            try:
+                os.kill(child, 0)
+                # a zombie of a reparented child counts as gone
+                if open("/proc/%d/stat" % child).read().split(")")[-1].split()[0] == "Z":
+                    gone = True
+                    break
+            except (ProcessLookupError, FileNotFoundError):
+                gone = True
+                break
+            time.sleep(0.1)
+        assert gone, "the measuring process survived its supervisor (signal %d)" % int(sig)
+
+
+def test_config_summary_carries_the_second_tier_results():
+    """the driver's record keeps `config` whole and drops `configs` / `micro` / `integrity`: the compact summary
+    must name them all, and stay None-filled (not absent) when a part was skipped."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    empty = b.config_summary({})
+    assert set(empty) == set(b.SUMMARY_KEYS) and empty["bn20"] is None and empty["bench_attempts"] == 1
+    out = {"configs": {"bn20": {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "concurrent_proofs": 56, "proof_verified_by_native_gkr_verify": True},
+                       "gmimc_bn22": {"hashes_per_s": 1.1e8, "single_proof_ms": 117.0, "concurrent_proofs": 12, "proof_verified_by_native_gkr_verify": True}},
+           "micro": {"msm_g1_2p24": {"ms": 19.5}, "msm_g1_2p22": {"ms": 5.4}, "msm_g1_2p20": {"ms": 1.9}, "msm_g2_2p22": {"ms": 19.0},
+                     "compute_h_2p24": {"ms": 12.7}, "msm_g1_fixed_base_2p24": {"ms": 18.0}},
+           "oneshot_including_pcie": {"one_call_s": 0.31}, "roofline": {"frac": 0.79}, "partial_eval": {"frac": 0.86},
+           "integrity": {"layer_checks": 920, "layer_check_failures": 0, "chal_retries": 0}}
+    sm = b.config_summary(out)
+    assert sm["bn20"] == {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "lanes": 56, "verified": True}
+    assert sm["msm_g1_2p24_ms"] == 19.5 and sm["compute_h_2p24_ms"] == 12.7 and sm["oneshot_s"] == 0.31
+    assert sm["msm_g1_fixed_base_ms"] == {"2p24": 18.0} and sm["layer_checks"] == 920 and sm["chal_retries"] == 0
+    assert len(json.dumps(sm)) < 900          # compact: it must survive where the 2 000-character tail does not
+    latest = _latest()
+    if "summary" in latest["config"]:         # lines of round 6 on
+        assert set(latest["config"]["summary"]) >= set(b.SUMMARY_KEYS) - {"msm_g1_fixed_base_ms"}

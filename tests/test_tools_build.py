@@ -21,7 +21,7 @@ def test_preload_shims_build(tmp_path, src, extra):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
-@pytest.mark.parametrize("src", ["vmm_interior_probe.hip", "vmm_release_probe.hip", "vmm_reserve_limit.hip"])
+@pytest.mark.parametrize("src", ["vmm_interior_probe.hip", "vmm_release_probe.hip", "vmm_reserve_limit.hip", "prio_event_probe.hip"])
 def test_vmm_probes_build(tmp_path, src):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-o", str(tmp_path / "probe"), os.path.join(ROOT, "tools", src)],
                           stderr=subprocess.DEVNULL)
