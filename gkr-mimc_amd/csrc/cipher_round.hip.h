@@ -58,7 +58,7 @@ __device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, siz
         }
     }
 }
-__global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
     eq_suffix_pyramid_body(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 // up to four pyramids of a layer in one launch (blockIdx.y selects; unused slots have max_level < 0)
@@ -76,7 +76,7 @@ struct PyramidExpandArgs {
     CPlanes h;           // H pyramid (levels 1 .. hi_level - lo_level)
     int lo_level, hi_level;
 };
-__global__ void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandArgs a) {
     // a few products per lane in front of a layer's first round: ahead of the other lanes' big rounds on a shared SIMD (same-box
     // A/B, profiles/r05_prio_pyramids.txt: bN = 20 x 24 lanes +0.7 %, bN = 24 x 5 +0.5 %, GMiMC bN = 22 x 12 +1.0 %)
     __builtin_amdgcn_s_setprio(3);
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandAr
         st_fr(a.out.lo, a.out.hi, (((size_t)1 << s) - 1) + idx, fr_mul(base, hv));
     }
 }
-__global__ void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a) {
     __builtin_amdgcn_s_setprio(3);      // (as k_eq_pyramid_expand)
     const PyramidArgs& p = a.p[blockIdx.y];
     if (p.max_level < 0) return;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void cipher_round_publish(const CipherRoundArgs& a, u
 }
 
 // sharded prover: after the all-reduce the summed words go to the host the same way (host-mapped buffer + flag)
-__global__ void __launch_bounds__(128) k_publish_words(const unsigned long long* __restrict__ src, unsigned long long* host_dst,
+GKR_KERNEL void __launch_bounds__(128) k_publish_words(const unsigned long long* __restrict__ src, unsigned long long* host_dst,
                                                        int n, unsigned int* host_flag, unsigned int seq) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) host_dst[i] = src[i];
     __threadfence_system();
@@ -494,15 +494,20 @@ __device__ __forceinline__ void ahead_publish(unsigned long long* racc, unsigned
 #else
 #define GKR_SQR(x) fr_mont_sqr_raw(x)
 #endif
+// (the block reduction's transpose buffer AND its per-wave sums alias the accumulators, which are dead by then: 52 224 B per
+// workgroup + the challenge words -- three workgroups fit a CU's 160 KiB; with the per-wave sums beside the union it was 54 856 B
+// and the third missed by 728 B)
 struct WideShared {
     union {
         struct {
             uint4 q[GKR_WIDE_LDS][4][GKR_BLOCK];
             u32 w[GKR_WIDE_LDS][GKR_BLOCK];
         } acc;
-        u32 tr[18][GKR_BLOCK + 1];
+        struct {
+            u32 tr[18][GKR_BLOCK + 1];
+            unsigned long long red[GKR_BLOCK / 64][GKR_CR_WORDS];
+        } rd;
     };
-    unsigned long long red[GKR_BLOCK / 64][GKR_CR_WORDS];
 };
 
 __device__ __forceinline__ void wide_lds_load(u32 (&T)[FR_WIDE_LIMBS], const WideShared& sh, int slot) {
@@ -524,8 +529,12 @@ __device__ __forceinline__ void wide_lds_store(WideShared& sh, int slot, const u
 // PRE (round 0 only, FOLD = false): u^4, d^4 and the four cubics were computed ahead of time by k_cipher_pre -- they do
 // not depend on the layer's evaluation point -- so the launch on the critical path is two products by the launch-wide
 // weight and the seven wide MACs, reading 192 bytes per pair instead of computing eight products.
-template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false>
-__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
+// WAVES: the waves per SIMD the register budget is set for.  2: 212 VGPRs, nothing spilled.  3: 168 VGPRs -- hipcc spills ~90 VGPRs,
+// but only ~30 scratch instructions of them sit inside the per-pair loop (of ~5 000): a third workgroup per CU for the proofs in flight
+// (with the LDS trimmed to 52.5 KB above) against a slightly longer loop.  The host picks per launch (wide_waves, host_sumcheck.hip.h);
+// measured: profiles/r06_wide3_ab.txt.
+template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false, int WAVES = 2>
+__global__ void __launch_bounds__(GKR_BLOCK, WAVES) k_cipher_round_wide(CipherRoundArgs a) {
     static_assert(!(FOLD && PRE), "the precomputed products exist for round 0 only");
     static_assert(!AHEAD || (WT_LATE && !FOLD), "round 0 ahead of its point: late lane weights, no fold");
     round_wave_priority(a.prio);
@@ -697,7 +706,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundA
         return;
     }
     __syncthreads();                                                // tr aliases the LDS accumulators
-    block_reduce_acc_buf<GKR_CR_NSUM, 18, true>(acc, a.partials, sh.tr, sh.red);
+    block_reduce_acc_buf<GKR_CR_NSUM, 18, true>(acc, a.partials, sh.rd.tr, sh.rd.red);
     cipher_round_publish(a, &s_last);
 }
 
@@ -722,7 +731,7 @@ struct CipherPreArgs {
 // has normal priority (host_sumcheck.hip.h: a lowest-priority stream left incomplete products under load); one proof alone at
 // bN = 24 with 60 KB (two workgroups per CU) / 100 KB: 279.5 / 272.4 ms (lowest priority and 60 KB, as it was: 275.1).
 #define GKR_PRE_LDS (100 * 1024)
-__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_pre(CipherPreArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK, 2) k_cipher_pre(CipherPreArgs a) {
     const size_t P = a.P;
     const Fr negark = fr_sub(fr_zero(), a.ark);
     for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < P; x += (size_t)gridDim.x * blockDim.x) {

@@ -125,7 +125,7 @@ __device__ __forceinline__ void spec_publish(unsigned long long* racc, unsigned 
     }
 }
 
-__global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_spec(CipherSpecArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_spec(CipherSpecArgs a) {
     __shared__ unsigned int s_last;
     __builtin_amdgcn_s_setprio(3);
     const size_t P = a.P;
@@ -246,7 +246,7 @@ struct LinearSpecArgs {
     unsigned int chal_seq;
 };
 
-__global__ void __launch_bounds__(GKR_BLOCK) k_linear_round_spec(LinearSpecArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_linear_round_spec(LinearSpecArgs a) {
     __shared__ unsigned int s_last;
     __builtin_amdgcn_s_setprio(3);
     const size_t P = a.P;

@@ -340,7 +340,7 @@ __device__ __forceinline__ u32 msm_digit(const MsmArgs& a, u32 dp, int j, bool* 
 // Every scalar is decoded ONCE (Montgomery conversion included) into W planes of 16-bit raw windows, digits[j][i], rows padded
 // to a multiple of eight: the sorting kernels then read 2 bytes per point and window instead of the 32-byte scalar (which
 // every one of the 2 W workgroups over a chunk used to decode again).  Padding holds the raw value of a zero digit.
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_digits(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_digits(MsmArgs a) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.dstride) return;
     if (i >= a.n) {
@@ -377,7 +377,7 @@ __device__ __forceinline__ void msm_load_digits8(const MsmArgs& a, int j, size_t
 //   k_msm_totals / k_msm_scan / k_msm_offsets:   bucket sizes, their exclusive scan, the chunks' write positions
 //   k_msm_scatter:   the chunk again, cursors in LDS initialised from chist: entries[cursor[b]++] = index | sign
 #define MSM_SORT_THREADS 1024
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_hist(MsmArgs a) {
     extern __shared__ unsigned int hist[];
     const int j = blockIdx.x;
     const unsigned int k = blockIdx.y;
@@ -417,7 +417,7 @@ __device__ __forceinline__ unsigned int msm_block_scan(unsigned int* sh, unsigne
     }
     return sh[threadIdx.x];
 }
-__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_totals(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_msm_totals(MsmArgs a) {
     __shared__ unsigned int sh[MSM_SCAN_THREADS];
     const unsigned int nbs = msm_sort_bins(a);
     const size_t total = (size_t)a.W * nbs;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_totals(MsmArgs a) {
     const unsigned int incl = msm_block_scan(sh, mine);
     if (threadIdx.x == MSM_SCAN_THREADS - 1) a.tile_sum[blockIdx.x] = incl;
 }
-__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_scan(MsmArgs a) {      // ntiles <= MSM_SCAN_THREADS * 8 (host checks)
+GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_msm_scan(MsmArgs a) {      // ntiles <= MSM_SCAN_THREADS * 8 (host checks)
     __shared__ unsigned int sh[MSM_SCAN_THREADS];
     const unsigned int per = (a.ntiles + MSM_SCAN_THREADS - 1) / MSM_SCAN_THREADS;
     const unsigned int lo = min(a.ntiles, per * threadIdx.x), hi = min(a.ntiles, lo + per);
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_scan(MsmArgs a) {     
         run += c;
     }
 }
-__global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
     __shared__ unsigned int sh[MSM_SCAN_THREADS];
     const unsigned int nbs = msm_sort_bins(a);
     const size_t total = (size_t)a.W * nbs;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
         run += c[h];
     }
 }
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter(MsmArgs a) {
     extern __shared__ unsigned int cursor[];
     const int j = blockIdx.x;
     const unsigned int k = blockIdx.y;
@@ -579,7 +579,7 @@ __device__ __forceinline__ void msm_stage_batch(MsmStage<T>& sh, unsigned int nb
     __syncthreads();
 }
 // the coarse pass's scatter: workgroup (j, k) files the entries of window j of chunk k under their coarse bins
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs a) {
     __shared__ MsmStage<MSM_SORT_THREADS> sh;
     const int j = blockIdx.x;
     const unsigned int k = blockIdx.y;
@@ -631,7 +631,7 @@ __device__ __forceinline__ bool msm_slice_range(const MsmArgs& a, unsigned int* 
     *hi = base + min(cnt, s0 + a.slice_len);
     return true;
 }
-__global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_count(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_count(MsmArgs a) {
     __shared__ unsigned int hist[MSM_REFINE_MAXLOW];
     unsigned int bin, lo, hi;
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.slices[0] > a.slice_cap) *a.err = 2u;      // cannot happen by the list's sizing
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_count(MsmArgs
     __syncthreads();
     if (threadIdx.x < nlow) a.slice_hist[(size_t)blockIdx.x * nlow + threadIdx.x] = hist[threadIdx.x];
 }
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_refine_offsets(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_refine_offsets(MsmArgs a) {
     __shared__ unsigned int sh[GKR_BLOCK];
     const size_t t = (size_t)blockIdx.x * GKR_BLOCK + threadIdx.x;       // W * nb is a multiple of the block or smaller than it
     const size_t total = (size_t)a.W * a.nb;
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_refine_offsets(MsmArgs a) {
         run += x;
     }
 }
-__global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_scatter(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_scatter(MsmArgs a) {
     __shared__ MsmStage<MSM_REFINE_THREADS> sh;
     unsigned int bin, lo, hi;
     if (!msm_slice_range(a, &bin, &lo, &hi)) return;
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_scatter(MsmAr
 // window's 2^(c-1) bucket ids by their counts, one workgroup per window, everything in LDS).  Big buckets sort as empty:
 // they belong to k_msm_accumulate_big.
 #define MSM_ORDER_BINS 1024
-__global__ void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
+GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
     __shared__ unsigned int bin[MSM_ORDER_BINS + 1];
     const unsigned int j = blockIdx.x;
     const unsigned int* cnt = a.count + (size_t)j * a.nb;
@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_ec_batch_scalar_mul(MsmArgs a, Af
 }
 
 // synthetic scalars of the benchmark: pseudo-random canonical values below q, out[i] = limbs of (mix(i, seed))^7
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_synth_scalars(uint4* out, size_t n, u32 seed) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_synth_scalars(uint4* out, size_t n, u32 seed) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr x = {{(u32)i ^ 0x9df123fu, (u32)(i >> 32) + 0xf45cu, seed, 0x2545f491u, (u32)i * 0x9e3779b9u, 3u, seed ^ 0x5bd1e995u, 0u}};   // < 2^224 < q
         x = fr_pow7(x);

@@ -36,6 +36,11 @@
 #include "ntt.hip.h"
 #include "fp_host.h"
 #include "g1.hip.h"
+// the heavy template kernels are instantiated in units of their own (kern_unit.hip, one per group of kernel_groups.h)
+#define GKR_INST extern
+#define GKR_INST_EXTERN
+#include "kernel_groups.h"
+#undef GKR_INST
 
 using hfr::E;
 
@@ -121,7 +126,7 @@ int session_load_assign_sliced(gkrhip_session* s, const uint64_t* const* host, i
     }
     const size_t cnt = n / S;
     if (!cx().aux) {
-        HIPCHK(hipStreamCreateWithFlags(&cx().aux, hipStreamNonBlocking));
+        CHK(lane_stream_create(&cx().aux, cx().cu_group));
         HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
     }
     struct Events {
@@ -383,14 +388,7 @@ size_t gkrhip_last_error_r(int code, char* buf, size_t cap) {
     return m.size();
 }
 const char* gkrhip_version(void) { return "gkrhip 0.3 (gfx950)"; }
-#ifndef GKRHIP_SOURCE_SHA
-#define GKRHIP_SOURCE_SHA "unrecorded"
-#endif
-// the SHA-256 of the sources and flags this binary was built from (gkr-mimc_amd/build.py finds the marker in the file)
-const char* gkrhip_build_id(void) {
-    static const char id[] = "GKRHIP_SOURCE_SHA=" GKRHIP_SOURCE_SHA;
-    return id + sizeof("GKRHIP_SOURCE_SHA=") - 1;
-}
+// (gkrhip_build_id lives in build_id.cpp, a unit of its own)
 
 int gkrhip_set_option(const char* key, long value) {
     static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
@@ -437,6 +435,20 @@ int gkrhip_set_option(const char* key, long value) {
     if (!strcmp(key, "arena_check")) {          // host_ctx.hip.h: table_release
         g_arena_check.store((int)value);
         if (value) g_cnt_busy_releases.store(0);
+        return 0;
+    }
+    if (!strcmp(key, "wide_waves")) {           // host_ctx.hip.h: wide_three_waves (2 | 3 | 0 = by the proofs in flight)
+        g_wide_waves.store(value == 3 ? 3 : value == 0 ? 0 : 2);
+        return 0;
+    }
+    if (!strcmp(key, "wide3_from")) {
+        g_wide3_from.store((int)std::max(1L, value));
+        return 0;
+    }
+    if (!strcmp(key, "lane_cu_groups")) {       // host_ctx.hip.h: lane_stream_create; lanes created from now on (the pooled ones are dropped)
+        g_lane_cu_groups.store((int)std::max(0L, std::min(32L, value)));
+        g_lane_cu_next.store(0);
+        lane_pool_drain();
         return 0;
     }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle

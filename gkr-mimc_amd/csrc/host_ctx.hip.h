@@ -116,6 +116,7 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    int cu_group = -1;                         // GKRHIP_LANE_CU_GROUPS: the group of compute units this lane's streams are masked to (-1: all)
     unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums (reference-shaped evaluator)
     bool racc_dirty = false;                   // a call that uses d_racc / d_counter is under way or failed half-way
     unsigned long long* d_racc = nullptr;      // GKR_CR_WORDS-word accumulator of the fused round kernels (zero between launches)
@@ -287,6 +288,18 @@ inline int round_threads_log2_max() {
     if (!cx().g_max_auto) return cx().g_max;
     return g_proofs_in_flight.load(std::memory_order_relaxed) >= 10 ? 15 : 16;
 }
+// Which register budget the wide round kernel is launched with (cipher_round.hip.h: WAVES): `wide_waves` 2 or 3 as set, 0 = by the
+// proofs in flight (three waves per SIMD -- a third workgroup per CU, at ~30 scratch instructions per pair -- from `wide3_from` proofs
+// in flight on; a proof alone keeps the spill-free kernel).  GKRHIP_WIDE_WAVES / set_option("wide_waves").
+std::atomic<int> g_lane_cu_groups{0};             // GKRHIP_LANE_CU_GROUPS (lane_stream_create below)
+std::atomic<unsigned> g_lane_cu_next{0};
+std::atomic<int> g_wide_waves{2};
+std::atomic<int> g_wide3_from{8};
+inline bool wide_three_waves() {
+    const int w = g_wide_waves.load(std::memory_order_relaxed);
+    if (w) return w == 3;
+    return g_proofs_in_flight.load(std::memory_order_relaxed) >= g_wide3_from.load(std::memory_order_relaxed);
+}
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
     ~ProofInFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }
@@ -422,6 +435,8 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
+    if (const char* e = getenv("GKRHIP_WIDE_WAVES")) g_wide_waves.store(atoi(e) == 3 ? 3 : atoi(e) == 0 ? 0 : 2);
+    if (const char* e = getenv("GKRHIP_LANE_CU_GROUPS")) g_lane_cu_groups.store(std::max(0, std::min(32, atoi(e))));
     if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));      // (the tests: several iterations per workgroup)
     cx().lag = new hfr::Lagrange();
     cx().device = dev;
@@ -434,9 +449,35 @@ int ctx_init(int dev) {
     return 0;
 }
 
+// ---- spatial partitioning of the lanes (round 6 experiment; off by default) ------------------------------
+// GKRHIP_LANE_CU_GROUPS=G: the lanes are dealt round-robin to G groups and every stream of a lane (round kernels, look-ahead) is
+// created with hipExtStreamCreateWithCUMask on its group's 256/G compute units, so a lane's small rounds never wait for a CU slot
+// behind a wide round of a lane of ANOTHER group.  A CU-mask bit i names CU (i / 8) of XCD (i mod 8) (the driver deals the mask's
+// bits round-robin to the XCDs), so a group of 256/G consecutive bits holds the same number of CUs of every XCD -- the dispatcher
+// deals a launch's workgroups round-robin to the XCDs and a mask that left an XCD without CUs would stall it.
+// A masked stream owns a hardware queue of its own (the mask is a property of the queue): G x lanes queues on top of the pool's.
+// Measured (profiles/r06_cu_groups_ab.txt): see DESIGN 6.
+int lane_stream_create(hipStream_t* st, int group) {
+    const int G = g_lane_cu_groups.load();
+    const int ncu = g0.n_cu > 0 ? g0.n_cu : 256;
+    if (G <= 1 || group < 0 || ncu % G != 0 || (ncu / G) % 8 != 0) {
+        HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        return 0;
+    }
+    const int per = ncu / G;
+    uint32_t mask[16] = {0};
+    for (int b = group * per; b < (group + 1) * per; b++) mask[b >> 5] |= 1u << (b & 31);
+    HIPCHK(hipExtStreamCreateWithCUMask(st, (uint32_t)((ncu + 31) / 32), mask));
+    return 0;
+}
+
 // stream + buffers of the current lane
 int lane_alloc() {
-    HIPCHK(hipStreamCreateWithFlags(&cx().stream, hipStreamNonBlocking));
+    {
+        const int G = g_lane_cu_groups.load();
+        cx().cu_group = (G > 1 && &cx() != &g0) ? (int)(g_lane_cu_next.fetch_add(1) % (unsigned)G) : -1;
+    }
+    CHK(lane_stream_create(&cx().stream, cx().cu_group));
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&cx().d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
     HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));

@@ -13,6 +13,16 @@
 
 #include "fr_bn254.h"
 
+// The library is built from several translation units (gkr-mimc_amd/build.py): gkrhip.hip holds the host code and every
+// non-template kernel; the heavy TEMPLATE kernels are instantiated in units of their own (kern_*.hip; the list is
+// kernel_groups.h, `extern template` in gkrhip.hip), which include the same headers with GKR_KERNEL_TU defined -- there a
+// non-template kernel becomes a template nobody instantiates (no second definition, no device code).
+#ifdef GKR_KERNEL_TU
+#define GKR_KERNEL template <int GKR_NEVER_INSTANTIATED = 0> __global__
+#else
+#define GKR_KERNEL __global__
+#endif
+
 #ifndef GKR_BLOCK
 #define GKR_BLOCK 256   // threads per workgroup of every grid-shaped kernel (a build parameter for A/B runs: 128 or 256)
 #endif
@@ -170,7 +180,7 @@ struct EqSmallArgs {
     int nbits, q_stride, q_off;
     size_t tab_stride;
 };
-__global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
+GKR_KERNEL void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
     const int j = blockIdx.x;
     uint4* lo = a.out.lo + (size_t)j * a.tab_stride;
     uint4* hi = a.out.hi + (size_t)j * a.tab_stride;
@@ -199,7 +209,7 @@ struct EqExpandArgs {
     int nclaims, nlo;    // i_lo has nlo bits
     size_t n;
 };
-__global__ void __launch_bounds__(GKR_BLOCK) k_eq_expand(EqExpandArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_expand(EqExpandArgs a) {
     const size_t mask = ((size_t)1 << a.nlo) - 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t ih = i >> a.nlo, il = i & mask;
@@ -429,7 +439,7 @@ __global__ void __launch_bounds__(GKR_BLOCK, 2) k_partial_eval(PartialEvalArgs a
 }
 
 // sum the per-block partials: out[k] = sum_b partials[b][k],  k < nwords
-__global__ void __launch_bounds__(GKR_BLOCK) k_reduce_partials(const unsigned long long* __restrict__ partials,
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_reduce_partials(const unsigned long long* __restrict__ partials,
                                                                unsigned long long* __restrict__ out, int nblocks,
                                                                int nwords) {
     __shared__ unsigned long long red[GKR_BLOCK];
@@ -453,7 +463,7 @@ struct Gather0Args {
     int ntab;
     uint4* out;  // AoS: 2 x uint4 per element
 };
-__global__ void k_gather0(Gather0Args a) {
+GKR_KERNEL void k_gather0(Gather0Args a) {
     const int t = threadIdx.x;
     if (t < a.ntab) {
         a.out[2 * t] = a.t[t].lo[0];
@@ -467,7 +477,7 @@ __global__ void k_gather0(Gather0Args a) {
 // bulk Montgomery <-> regular conversion on the boundary (AoS) layout: x <- x * factor / 2^256 mod q.
 // factor = 1 (as a plain integer): fr.Element.FromMont / ToBigIntRegular (hints.go:141,231-268);
 // factor = R^2: SetBigInt of a reduced value (hints.go:136-137,202-205).
-__global__ void __launch_bounds__(GKR_BLOCK) k_convert_aos(uint4* __restrict__ data, size_t n, Fr factor) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_convert_aos(uint4* __restrict__ data, size_t n, Fr factor) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 a = data[2 * i], b = data[2 * i + 1];
         const Fr x = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
@@ -495,7 +505,7 @@ __device__ __forceinline__ Fr ark_fr(int i) {
 }
 // batched hash.MimcKeyedPermutation(x[i], key[i]) (hash/mimc.go:31-39): the body of HashHint.Call
 // (hints.go:134-145), which the solver invokes once per hash
-__global__ void __launch_bounds__(GKR_BLOCK) k_mimc_permutation(CPlanes x, CPlanes key, Planes out, size_t n) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_mimc_permutation(CPlanes x, CPlanes key, Planes out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr res = ld_fr(x.lo, x.hi, i);
         const Fr k = ld_fr(key.lo, key.hi, i);

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(GKR_NTT_WG, 2) k_ntt_tile(NttPassArgs a) {
 
 // twiddle tables: omega^i = hi[i >> l0] * lo[i & (2^l0 - 1)] for i < n/2 (the two small tables computed on the host), -1 for
 // i = n/2; entry (s, j) of the per-stage layout is omega^(j << s)
-__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes lo, CPlanes hi, int l0, int logn) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes lo, CPlanes hi, int l0, int logn) {
     const size_t n = (size_t)1 << logn, total = n + logn;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
         int s = 0;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes l
 // The per-position factors of the coset transforms, as gnark-crypto's fft.Domain precomputes its CosetTable / CosetTableInv
 // (here indexed by the position in the bit-reversed vector the factor is applied to, with the 1/n folded in):
 //     fwd[p] = u^rev(p) * k0        inv[p] = u^-rev(p) * k0'         (u^e = omega^(e >> 1) * (e odd ? u : 1); k1 = k0 * u, k1' = k0' / u)
-__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_coset_table(Planes out, CPlanes tw, int logn, int inverse, Fr k0, Fr k1) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_ntt_coset_table(Planes out, CPlanes tw, int logn, int inverse, Fr k0, Fr k1) {
     const size_t n = (size_t)1 << logn;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
         const size_t e = ntt_rev(p, logn);
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_ntt_coset_table(Planes out, CPlan
     }
 }
 // zero padding of an array from n to the domain size
-__global__ void __launch_bounds__(GKR_BLOCK) k_ntt_zero(Planes d, size_t from, size_t to) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_ntt_zero(Planes d, size_t from, size_t to) {
     for (size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += (size_t)gridDim.x * blockDim.x)
         st_fr(d.lo, d.hi, i, fr_zero());
 }

@@ -63,6 +63,28 @@ def main():
         flat, outs = gk.gkr_prove_mimc(i0, X[1], qp)
         oflat, oouts, _ = c.gkr_prove_mimc(bn, i0, X[1], qp)
         assert np.array_equal(flat, oflat) and np.array_equal(outs, oouts), ("gkr", bn)
+        nsess = int(os.environ.get("GKRHIP_CASE_SESSIONS", "0"))
+        if nsess:       # several resident sessions (a lane and stream each) proving at once, every transcript against the oracle's
+            import threading
+            ss = []
+            for _ in range(nsess):
+                sn = gk.MimcSession(bn)
+                sn.load_inputs(i0, X[1])
+                sn.assign()
+                ss.append(sn)
+            res = [None] * nsess
+
+            def work(k):
+                for _ in range(3):
+                    res[k] = ss[k].prove(qp)
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(nsess)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            for k in range(nsess):
+                assert np.array_equal(res[k], oflat), ("session", k, bn)
+                ss[k].close()
     check_expected_paths(gk)
     print("CASE-OK", sizes)
 

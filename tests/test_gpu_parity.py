@@ -342,6 +342,24 @@ def test_round_kernel_small_thread_budget(gk):
     _run_case({"GKRHIP_GMAX": "10"}, "11,12,14")
 
 
+def test_wide_round_kernel_at_three_waves_per_simd(gk):
+    """Round 6: the wide round kernel built for three waves per SIMD (168 VGPRs, hipcc spills to scratch) is the same arithmetic:
+    forced on (GKRHIP_WIDE_WAVES=3) with small thread budgets so that every variant it has (fold / round 0, early / late lane
+    weights, round 0 ahead of its point) runs at sizes the oracle reaches, MiMC and GMiMC; 0 = chosen by the proofs in flight."""
+    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "8"}, "9,10,12,14")
+    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "99"}, "10,13")
+    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "10", "GKRHIP_AHEAD": "2"}, "13,15")
+    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "8"}, "9,12", circuit="gmimc")
+    _run_case({"GKRHIP_WIDE_WAVES": "0", "GKRHIP_GMAX": "8"}, "9,12")
+
+
+def test_lanes_on_disjoint_compute_unit_groups(gk):
+    """Round 6 experiment switch GKRHIP_LANE_CU_GROUPS: every stream of a lane is masked to its group's compute units
+    (hipExtStreamCreateWithCUMask); same transcripts (a session proves on a lane of its own, i.e. on a masked stream)."""
+    _run_case({"GKRHIP_LANE_CU_GROUPS": "8", "GKRHIP_CASE_SESSIONS": "3"}, "9,12")
+    _run_case({"GKRHIP_LANE_CU_GROUPS": "4", "GKRHIP_GMAX": "8"}, "10", circuit="gmimc")
+
+
 def test_eq_pyramid_in_two_launches(gk):
     """The per-lane eq pyramid built in two launches (levels up to 2^n entries with short chains, the upper levels with one
     product per entry from a small second pyramid) and in one: same weights, same transcript, for splits below, at and above
