@@ -43,7 +43,9 @@ def COMPUTE_H_PRODUCTS(logn):
     per-element factors (coset shift and 1/n on the three forward loads: 2 products; the last store's factor: 2), the
     pointwise step (2).  The products that derive a group's twiddles from the loaded ones are overhead, not counted."""
     n = float(1 << logn)
-    return 7 * logn * n / 2 + 3 * 2 * n + 2 * n + 2 * n
+    # (round 6: the sub-pass at element stride 1 -- twiddles omega^0 and the 4th root of unity -- issues one product per group of
+    # four instead of four: 1.5 of a transform's stages carry no product)
+    return 7 * (logn - 1.5) * n / 2 + 3 * 2 * n + 2 * n + 2 * n
 BN_TOTAL_MULTI = 26       # BASELINE config 4
 
 
@@ -90,8 +92,7 @@ def cpu_baseline(target_seconds=40.0):
                       "multiplication alone; not the Go binary" % (b, secs)}
 
 
-SUMMARY_KEYS = ("bn20", "gmimc_bn22", "oneshot_s", "msm_g1_2p20_ms", "msm_g1_2p22_ms", "msm_g1_2p24_ms", "msm_g1_fixed_base_ms",
-                "msm_g2_2p22_ms", "compute_h_2p24_ms", "fold_frac_of_hbm_peak", "partial_eval_frac_of_issue_ceiling", "layer_checks",
+SUMMARY_KEYS = ("bn20", "gmimc_bn22", "oneshot_s", "msm_g1_2p20_ms", "msm_g1_2p22_ms", "msm_g1_2p24_ms", "msm_g2_2p22_ms", "compute_h_2p24_ms", "fold_frac_of_hbm_peak", "partial_eval_frac_of_issue_ceiling", "layer_checks",
                 "layer_check_failures", "chal_retries", "bench_attempts")
 
 
@@ -113,8 +114,6 @@ def config_summary(out):
     for lg in (20, 22, 24):
         m = mi.get("msm_g1_2p%d" % lg)
         sm["msm_g1_2p%d_ms" % lg] = r(m["ms"]) if m else None
-    fb = {("2p%d" % lg): r(mi["msm_g1_fixed_base_2p%d" % lg]["ms"]) for lg in (20, 22, 24) if mi.get("msm_g1_fixed_base_2p%d" % lg)}
-    sm["msm_g1_fixed_base_ms"] = fb or None
     sm["msm_g2_2p22_ms"] = r(mi["msm_g2_2p22"]["ms"]) if mi.get("msm_g2_2p22") else None
     sm["compute_h_2p24_ms"] = r(mi["compute_h_2p24"]["ms"]) if mi.get("compute_h_2p24") else None
     sm["fold_frac_of_hbm_peak"] = r((out.get("roofline") or {}).get("frac"), 4)
@@ -481,6 +480,14 @@ def orchestrate(args):
         # tail goes into the JSON line (passes.<name>.rccl_log) instead of only "invalid usage"
         if name.startswith("rccl") and env.get("NCCL_DEBUG", "").upper() not in ("WARN", "INFO", "TRACE"):
             env["NCCL_DEBUG"] = "WARN"
+        # RCCL writes its log through C stdio to stdout, which is a pipe here (block-buffered): a pass that ends through os._exit, or
+        # is killed at its time limit, used to take its warnings with it -- the record of round 5 held none.  So the log goes to a
+        # file of this pass and rank (read back below whatever way the child ended), and the child flushes C stdio before _exit.
+        dbg_dir = None
+        if name.startswith("rccl") and not env.get("NCCL_DEBUG_FILE"):
+            import tempfile
+            dbg_dir = tempfile.mkdtemp(prefix="gkrhip_rccl_%s_r%d_" % (name, rank))
+            env["NCCL_DEBUG_FILE"] = os.path.join(dbg_dir, "rccl.%h.%p.log")
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--pass", name]
         t0 = time.time()
         err = ""
@@ -490,6 +497,14 @@ def orchestrate(args):
         except subprocess.TimeoutExpired as e:
             out, rc = (e.stdout or b"").decode(errors="replace"), None       # the child (and its spinning kernels) was killed
             err = (e.stderr or b"").decode(errors="replace")
+        if dbg_dir:
+            import shutil
+            for fn in sorted(os.listdir(dbg_dir)):
+                try:
+                    err += open(os.path.join(dbg_dir, fn), errors="replace").read()
+                except OSError:
+                    pass
+            shutil.rmtree(dbg_dir, ignore_errors=True)
         if err:
             sys.stderr.write(err)                                             # (the driver's log keeps everything)
             sys.stderr.flush()
@@ -890,6 +905,11 @@ def main():
             if rank == 0:
                 emit({"error": str(e)})
             print("bench.py: pass %s failed on rank %d: %s" % (pass_name, rank, e), file=sys.stderr)
+            try:                  # what libraries (RCCL's log) left in C stdio buffers goes out before _exit drops it
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:     # noqa: BLE001
+                pass
             os._exit(4)           # collective kernels may still be spinning on the device: no orderly teardown
         raise
     dt, latency_ms = head["dt"], head["latency_ms"]
@@ -1196,7 +1216,9 @@ def main():
                 return HALF_RATE_CYCLES * lp["half_rate"] + FULL_RATE_CYCLES * lp["full_rate"]
             per_bfly = {k: cyc(loops[k]) / 4.0 for k in ("ntt_dif", "ntt_dit")}
             n24 = float(1 << 24)
-            cycles = (4 * per_bfly["ntt_dif"] + 3 * per_bfly["ntt_dit"]) * 12 * n24 + 10 * n24 * HALF_RATE_CYCLES * 230
+            # 24 stages of 2^23 butterflies per transform, 1.5 of them without a product (the sub-pass at element stride 1: priced at
+            # nothing, an under-count: their additions remain)
+            cycles = (4 * per_bfly["ntt_dif"] + 3 * per_bfly["ntt_dit"]) * (12 - 0.75) * n24 + 10 * n24 * HALF_RATE_CYCLES * 230
             h_ceiling = cycles / (N_SIMD * 64) / (NOMINAL_GHZ * 1e9) * 1e3
         micro["compute_h_2p24"] = {"ms": ms, "passes": npass, "GB_per_s": by / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "bound": "integer VALU issue (no MFMA: modular arithmetic); HBM at 0.2 of its peak is not the limit",

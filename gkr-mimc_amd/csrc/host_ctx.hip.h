@@ -200,6 +200,8 @@ struct Ctx {
     unsigned long long* d_ahead_racc = nullptr;   // GKR_RACC_SLOTS stripes of GKR_AHEAD_STRIPE words, zero between launches
     unsigned int* d_ahead_counter = nullptr;
     DevTable ahead_pyrU, ahead_pyrU2, ahead_pyrTh;   // arena tables, released by pre_release()
+    bool ahead_in_flight = false;              // the class-sum kernel was queued and nobody has waited for it yet (its flag, or a stream
+                                               // synchronisation): it may still be reading ahead_pyr* -- which then must not go back to the arena
     const uint4* ahead_K = nullptr;            // what the class sums in flight were computed from (valid when ahead_K != nullptr)
     const uint4* ahead_S = nullptr;
     E ahead_ark;
@@ -513,7 +515,10 @@ int lane_alloc() {
 // the look-ahead tables go back to the arena (end of a proof, lane teardown)
 void pre_release() {
     if (cx().aux) (void)hipStreamSynchronize(cx().aux);
-    if (cx().ahead_K) (void)hipStreamSynchronize(cx().stream);      // class sums nobody took: their kernel may still be running
+    // class sums nobody waited for (a layer that found them unusable marks them spent WITHOUT waiting; an error return between the
+    // launch and the wait): their kernel may still be running and reads the pyramids released below
+    if (cx().ahead_in_flight || cx().ahead_K) (void)hipStreamSynchronize(cx().stream);
+    cx().ahead_in_flight = false;
     for (auto& t : cx().pre_t) table_release_fwd(&t);
     for (DevTable* t : {&cx().ahead_pyrU, &cx().ahead_pyrU2, &cx().ahead_pyrTh}) table_release_fwd(t);
     cx().pre_K = cx().pre_S = nullptr;

@@ -366,6 +366,10 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
     for (auto tc : {std::make_pair(&cx().ahead_pyrU, (size_t)2 << lj), std::make_pair(&cx().ahead_pyrU2, (size_t)2 << lj),
                     std::make_pair(&cx().ahead_pyrTh, (size_t)2 << (g - t))})
         if (tc.first->cap != tc.second) {
+            if (tc.first->base && cx().ahead_in_flight) {      // an earlier class-sum kernel nobody waited for may still read it
+                HIPCHK(hipStreamSynchronize(cx().stream));
+                cx().ahead_in_flight = false;
+            }
             if (tc.first->base) table_release(tc.first);
             CHK(table_alloc(tc.first, tc.second));
         }
@@ -423,6 +427,7 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
         hipLaunchKernelGGL((k_cipher_round_wide<false, true, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
     }
     HIPCHK(hipGetLastError());
+    cx().ahead_in_flight = true;
     cx().ahead_K = K->base;
     cx().ahead_S = S->base;
     cx().ahead_ark = cx().req_ark;
@@ -584,6 +589,7 @@ int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
             if (corrupt) cx().h_spec[(size_t)(k & 1) * GKR_SPEC_BUF_WORDS + 4] ^= 1ull;      // candidate 0's M_1
         } else if (k == 0 && lp.ahead_round0()) {
             CHK(wait_flag(cx().ahead_seq, ahead_flag()));
+            cx().ahead_in_flight = false;              // its last workgroup has raised the flag: nothing of it is running
             if (corrupt) cx().h_ahead[0] ^= 1ull;                                               // S_1(0)
             g_cnt_ahead.fetch_add(1, std::memory_order_relaxed);
         } else {

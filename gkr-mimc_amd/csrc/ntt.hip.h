@@ -109,7 +109,12 @@ __device__ __forceinline__ Fr ntt_store_value(const NttPassArgs& a, size_t p, co
 // with zeta the primitive 4th root of unity of the direction: omega^(e + n/4) sits a quarter of the stage's table further, so a
 // group of four loads its three twiddles, all coalesced (deriving the third by a product with the constant zeta instead:
 // 16.3 against 13.8 ms per computeH at 2^24).
-template <int R, bool DIT, bool INV>
+// TRIV (round 6): the group sits at position stride 1 with low = 0 -- the FIRST sub-pass of a DIT transform, the LAST of a DIF
+// transform.  Every twiddle of such a group is omega^0 except the second one of the two-twiddle stage (the 4th root of unity):
+// a butterfly by omega^0 is an addition and a subtraction, whatever the direction (forward: (x + y, (x - y) * 1); inverse: the
+// loaded -omega^0 = -1 with the swapped subtraction gives the same pair), so three of the four products of a two-stage group
+// -- or the only one of a one-stage group -- and their twiddle loads are not issued: 1.5 of a transform's 24 stages at 2^24.
+template <int R, bool DIT, bool INV, bool TRIV = false>
 __device__ __forceinline__ void ntt_stages(const NttPassArgs& a, int lgn, size_t low, int lg_q, Fr (&x)[1 << R]) {
     static_assert(R == 1 || R == 2, "sub-passes of one or two stages");
     constexpr int E = 1 << R;
@@ -119,12 +124,19 @@ __device__ __forceinline__ void ntt_stages(const NttPassArgs& a, int lgn, size_t
         const bool two = DIT ? (r == 1) : (R == 2 && r == 0);                  // the stage with two distinct twiddles
         const int shift = DIT ? lgn - 1 - lg_q - r : lgn - lg_q - R + r;       // the twiddle exponents of this stage are (low + ...) << shift
         Fr w[2];
-        w[0] = ntt_twiddle(a.tw, lgn, INV, shift, low);
+        if (!TRIV) w[0] = ntt_twiddle(a.tw, lgn, INV, shift, low);
         if (two) w[1] = ntt_twiddle(a.tw, lgn, INV, shift, low + ((size_t)1 << (lgn - shift - 2)));      // times the 4th root of unity: a quarter of T_s further
 #pragma unroll
         for (int t = 0; t < E; t++) {
             if (t & dist) continue;
-            const Fr& wk = w[two ? (t & (dist - 1)) : 0];
+            const int wi = two ? (t & (dist - 1)) : 0;
+            if (TRIV && wi == 0) {                                       // twiddle omega^0
+                const Fr s = ntt_add2q(x[t], x[t + dist]), d = ntt_sub2q(x[t], x[t + dist]);
+                x[t] = s;
+                x[t + dist] = d;
+                continue;
+            }
+            const Fr& wk = w[wi];
             if (DIT) {
                 const Fr y = fr_mont_mul_raw(x[t + dist], wk);           // inverse: -(x_hi * omega^-e)
                 const Fr s = ntt_add2q(x[t], y), d = ntt_sub2q(x[t], y);
@@ -159,7 +171,7 @@ __device__ __forceinline__ void ntt_lds_st(NttTileShared& sh, int i, const Fr& x
 }
 // R stages on the row index of the tile, starting at the pass's local stage ls0; tile_low = the tile's column offset
 // (global position bits below lgQ that all its elements share, plus the column)
-template <int R, bool DIT, bool INV>
+template <int R, bool DIT, bool INV, bool TRIV = false>
 __device__ __forceinline__ void ntt_tile_subpass(const NttPassArgs& a, NttTileShared& sh, int ls0, size_t tile_low) {
     constexpr int E = 1 << R;
     const int lgqr = DIT ? ls0 : a.lrows - ls0 - R;            // log2 of the element stride of a group, in rows
@@ -172,7 +184,7 @@ __device__ __forceinline__ void ntt_tile_subpass(const NttPassArgs& a, NttTileSh
         Fr x[E];
 #pragma unroll
         for (int t = 0; t < E; t++) x[t] = ntt_lds_ld(sh, ((r_base + (t << lgqr)) << a.lcols) | c);
-        ntt_stages<R, DIT, INV>(a, a.logn, ((size_t)low_r << a.lgQ) | tile_low | (size_t)c, a.lgQ + lgqr, x);
+        ntt_stages<R, DIT, INV, TRIV>(a, a.logn, ((size_t)low_r << a.lgQ) | tile_low | (size_t)c, a.lgQ + lgqr, x);
 #pragma unroll
         for (int t = 0; t < E; t++) ntt_lds_st(sh, ((r_base + (t << lgqr)) << a.lcols) | c, x[t]);
     }
@@ -192,9 +204,26 @@ __global__ void __launch_bounds__(GKR_NTT_WG, 2) k_ntt_tile(NttPassArgs a) {
         ntt_lds_st(sh, i, ntt_load(a, d, p));
     }
     __syncthreads();
-    for (int ls0 = 0; ls0 < a.lrows; ls0 += 2) {
-        if (a.lrows - ls0 >= 2) ntt_tile_subpass<2, DIT, INV>(a, sh, ls0, cblk << a.lcols);
-        else ntt_tile_subpass<1, DIT, INV>(a, sh, ls0, cblk << a.lcols);
+    // The contiguous tile (stride 1, one column: the transform's first DIT / last DIF stages) has one sub-pass whose groups sit at
+    // element stride 1 -- twiddles omega^0 and the 4th root of unity only (ntt_stages: TRIV).  A DIF tile with an odd number of
+    // stages runs its single stage FIRST, so that this last sub-pass is a two-stage one (three of four products saved, not one of two).
+    const bool contiguous = a.lgQ == 0 && a.lcols == 0;        // uniform over the launch
+    int ls0 = 0;
+    if (!DIT && (a.lrows & 1)) {
+        if (contiguous && a.lrows == 1) ntt_tile_subpass<1, DIT, INV, true>(a, sh, 0, cblk << a.lcols);
+        else ntt_tile_subpass<1, DIT, INV>(a, sh, 0, cblk << a.lcols);
+        __syncthreads();
+        ls0 = 1;
+    }
+    for (; ls0 < a.lrows; ls0 += 2) {
+        const bool triv = contiguous && (DIT ? ls0 == 0 : ls0 + 2 >= a.lrows);
+        if (a.lrows - ls0 >= 2) {
+            if (triv) ntt_tile_subpass<2, DIT, INV, true>(a, sh, ls0, cblk << a.lcols);
+            else ntt_tile_subpass<2, DIT, INV>(a, sh, ls0, cblk << a.lcols);
+        } else {            // (DIT only: an odd number of stages ends with the single one)
+            if (triv) ntt_tile_subpass<1, DIT, INV, true>(a, sh, ls0, cblk << a.lcols);
+            else ntt_tile_subpass<1, DIT, INV>(a, sh, ls0, cblk << a.lcols);
+        }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < (1 << lt); i += GKR_NTT_WG) {

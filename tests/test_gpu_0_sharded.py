@@ -176,6 +176,7 @@ def test_sharded_host_tail_gather():
     # the fused linear rounds (add / copy layers of the GMiMC circuit, registered 1-, 3- and 4-input gates) gather as well
     _run_shards("shm", 4, "8,10", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_HOST_TAIL_SHARDED": "2"})
     _run_shards("shm", 2, "9", {"GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_HOST_TAIL_SHARDED": "6"})
+    _run_shards("shm", 2, "13,14", {"GKRHIP_HOST_TAIL_SHARDED": "10"})                          # the raised maximum
     _run_shards("shm", 4, "9,10", {"GKR_TEST_CIRCUIT": "variadic", "GKRHIP_HOST_TAIL_SHARDED": "3"})
     _run_shards("tick", 1, "9", {"GKRHIP_FORCE_COLLECTIVE": "1", "GKR_TEST_CIRCUIT": "gmimc", "GKRHIP_HOST_TAIL_SHARDED": "4"})
 
@@ -228,3 +229,36 @@ def test_ticker_lane_timeout_fails_every_rank():
     dt = _run_shards_expect_failure(2, "9", {"GKR_TEST_DELAY_RANK": "1", "GKR_TEST_DELAY_S": "9", "GKRHIP_COLL_TIMEOUT_S": "3"},
                                     within_s=180, mode="tickshm")
     assert dt < 120
+
+
+def test_bench_captures_rccl_warnings_of_a_failed_pass(tmp_path):
+    """first contact with a real multi-rank communicator happens on the driver's 8-GPU node, where nobody can
+    re-run by hand -- so the one RCCL failure this pool CAN provoke (two ranks of one communicator on ONE GPU: "Duplicate GPU
+    detected", ncclInvalidUsage) must leave RCCL's own warning in the bench line (`passes.rccl_one_lane.rccl_log`), not only
+    "invalid usage".  bench.py as the driver launches it for N = 2, both ranks on device 0, the RCCL pass alone."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, GKRHIP_BENCH_PASS_LIMIT_S="240")
+    env.pop("NCCL_DEBUG", None)
+    env.pop("NCCL_DEBUG_FILE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--device", "0", "--bn", "16", "--steps", "2",
+           "--warmup", "1", "--passes", "rccl_one_lane", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    line = None
+    for l in out.stdout.strip().splitlines()[::-1]:
+        try:
+            line = json.loads(l)
+            break
+        except Exception:
+            continue
+    assert line is not None, out.stdout[-1500:] + out.stderr[-3000:]
+    p = line["passes"]["rccl_one_lane"]
+    assert "error" in p and out.returncode == 3, (p, out.returncode)          # one GPU cannot host two ranks of a communicator
+    assert line.get("degraded") == "all_passes_failed" and line["n_gpus_rccl"] == 0
+    log = p.get("rccl_log", "")
+    assert "NCCL WARN" in log, "no RCCL warning captured:\n%s\n--- stderr\n%s" % (json.dumps(p)[:1500], out.stderr[-3000:])
+    assert "bench.py: pass" not in log                                        # RCCL's words, not bench.py's own

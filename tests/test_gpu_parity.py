@@ -388,6 +388,12 @@ def test_host_tail_rounds(gk):
     _run_case({"GKRHIP_HOST_TAIL": "0"}, "2,9", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "3"}, "3,9,11", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "5", "GKRHIP_LAT": "0"}, "7,8,11")
+    # h = 7..10 (kHostTailMax was raised from 6 to 10 in round 5: 2^8..2^11 pairs per table through h_tail, the speculative export
+    # and, for t > 6, without round 0 ahead of its point): against the oracle, not only a bench sweep with the native verifier
+    _run_case({"GKRHIP_HOST_TAIL": "8", "GKRHIP_LAT": "0"}, "9,10,12,14")
+    _run_case({"GKRHIP_HOST_TAIL": "10", "GKRHIP_LAT": "0"}, "11,12,13,15")
+    _run_case({"GKRHIP_HOST_TAIL": "8", "GKRHIP_LAT": "0"}, "10,12", circuit="gmimc")
+    _run_case({"GKRHIP_HOST_TAIL": "10", "GKRHIP_LAT": "0"}, "12,13", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "2", "GKRHIP_GMAX": "8", "GKRHIP_CLAIM_TRICK": "0"}, "4,10,13")
 
 
