@@ -37,13 +37,13 @@ LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-
 FLAGS = CFLAGS + LDFLAGS                     # (what the recorded hash covers)
 # (name, source, extra flags): gkrhip.hip first -- the longest single compilation starts first
 UNITS = [("host", "gkrhip.hip", [])] + \
-        [(g.lower(), "kern_unit.hip", ["-DGKR_GROUP_" + g]) for g in ("MSM_G2A", "MSM_G2B", "MSM_G1", "WIDE2", "WIDEPRE", "WIDE3", "ROUND", "NTT")]
+        [(g.lower(), "kern_unit.hip", ["-DGKR_GROUP_" + g]) for g in ("MSM_G2A", "MSM_G2B", "MSM_G1", "WIDE2", "WIDEPRE", "ROUND", "NTT")]
 
 # half-rate vector instructions on gfx950 (4.2-4.4 cycles per wave: profiles/r01_ubench_*.txt); the others issue in 2.4
 HALF = ("v_mad_u64", "v_addc", "v_subb", "v_add_co", "v_sub_co", "v_subrev_co", "v_mul_lo", "v_mul_hi", "v_lshl_add_u64",
         "v_lshrrev_b64", "v_lshlrev_b64", "v_alignbit", "v_fma_f64", "v_add_f64", "v_mul_f64")
-LOOP_KERNELS = {"round0": "k_cipher_round_wideILb0ELb1ELb0ELb0ELi2E", "fold_late": "k_cipher_round_wideILb1ELb1ELb0ELb0ELi2E",
-                "fold_early": "k_cipher_round_wideILb1ELb0ELb0ELb0ELi2E", "round0_pre": "k_cipher_round_wideILb0ELb1ELb1E",
+LOOP_KERNELS = {"round0": "k_cipher_round_wideILb0ELb1ELb0E", "fold_late": "k_cipher_round_wideILb1ELb1ELb0E",
+                "fold_early": "k_cipher_round_wideILb1ELb0ELb0E", "round0_pre": "k_cipher_round_wideILb0ELb1ELb1E",
                 # the bucket accumulation of the MSM: its INNERMOST loop is one mixed addition in the common case (the first
                 # point of a bucket and the doubling / cancellation cases leave it: g1.hip.h)
                 "msm_accumulate": "k_msm_accumulateI3FpFE",

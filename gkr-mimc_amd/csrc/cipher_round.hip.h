@@ -529,12 +529,12 @@ __device__ __forceinline__ void wide_lds_store(WideShared& sh, int slot, const u
 // PRE (round 0 only, FOLD = false): u^4, d^4 and the four cubics were computed ahead of time by k_cipher_pre -- they do
 // not depend on the layer's evaluation point -- so the launch on the critical path is two products by the launch-wide
 // weight and the seven wide MACs, reading 192 bytes per pair instead of computing eight products.
-// WAVES: the waves per SIMD the register budget is set for.  2: 212 VGPRs, nothing spilled.  3: 168 VGPRs -- hipcc spills ~90 VGPRs,
-// but only ~30 scratch instructions of them sit inside the per-pair loop (of ~5 000): a third workgroup per CU for the proofs in flight
-// (with the LDS trimmed to 52.5 KB above) against a slightly longer loop.  The host picks per launch (wide_waves, host_sumcheck.hip.h);
-// measured: profiles/r06_wide3_ab.txt.
-template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false, int WAVES = 2>
-__global__ void __launch_bounds__(GKR_BLOCK, WAVES) k_cipher_round_wide(CipherRoundArgs a) {
+// (Round 6 measured the same kernel built for three waves per SIMD -- __launch_bounds__(256, 3): 168 VGPRs, hipcc spills 84-101 of
+// them, ~30 scratch instructions per pair inside the loop; with the LDS trimmed to 52.5 KB three workgroups fit a CU -- and it lost
+// everywhere: bN = 20 x 24 / x 56 lanes -8.6 / -9.3 %, GMiMC bN = 22 x 12 -5.5 %, bN = 24 x 5 -6.4 %, one proof alone 2-6 % slower
+// (profiles/r06_occupancy_ab.txt, commit 69ae821 has the variant and the switch).  Two waves, nothing spilled, stays.)
+template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false>
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
     static_assert(!(FOLD && PRE), "the precomputed products exist for round 0 only");
     static_assert(!AHEAD || (WT_LATE && !FOLD), "round 0 ahead of its point: late lane weights, no fold");
     round_wave_priority(a.prio);

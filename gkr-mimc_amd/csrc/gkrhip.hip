@@ -126,7 +126,7 @@ int session_load_assign_sliced(gkrhip_session* s, const uint64_t* const* host, i
     }
     const size_t cnt = n / S;
     if (!cx().aux) {
-        CHK(lane_stream_create(&cx().aux, cx().cu_group));
+        HIPCHK(hipStreamCreateWithFlags(&cx().aux, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
     }
     struct Events {
@@ -392,7 +392,8 @@ const char* gkrhip_version(void) { return "gkrhip 0.3 (gfx950)"; }
 
 int gkrhip_set_option(const char* key, long value) {
     static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
-                                 "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg", "ahead"};
+                                 "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg", "ahead", "solo_boost", "pyr_split",
+                                 "coop_wgs", "coop_lg"};
     // fault injection of the tests (host_sumcheck.hip.h): process-wide, fires once, -1 disarms
     if (!strcmp(key, "test_fail_after_prelaunch")) {
         g_test_fail_round.store((int)value);
@@ -437,18 +438,8 @@ int gkrhip_set_option(const char* key, long value) {
         if (value) g_cnt_busy_releases.store(0);
         return 0;
     }
-    if (!strcmp(key, "wide_waves")) {           // host_ctx.hip.h: wide_three_waves (2 | 3 | 0 = by the proofs in flight)
-        g_wide_waves.store(value == 3 ? 3 : value == 0 ? 0 : 2);
-        return 0;
-    }
-    if (!strcmp(key, "wide3_from")) {
-        g_wide3_from.store((int)std::max(1L, value));
-        return 0;
-    }
-    if (!strcmp(key, "lane_cu_groups")) {       // host_ctx.hip.h: lane_stream_create; lanes created from now on (the pooled ones are dropped)
-        g_lane_cu_groups.store((int)std::max(0L, std::min(32L, value)));
-        g_lane_cu_next.store(0);
-        lane_pool_drain();
+    if (!strcmp(key, "wait_spin_us")) {         // host_ctx.hip.h: how host threads wait (-2: by the CPUs available; -1: always spin; n: spin n us, then sleep)
+        g_wait_override.store((int)std::max(-2L, value));
         return 0;
     }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
@@ -477,6 +468,10 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "coop")) l->coop = (int)value;
         else if (!strcmp(key, "spec")) l->spec = (int)value;
         else if (!strcmp(key, "spec_lg")) l->spec_lg = (int)std::max(5L, std::min(16L, value));
+        else if (!strcmp(key, "solo_boost")) l->solo_boost = (int)value;
+        else if (!strcmp(key, "pyr_split")) l->pyr_split = (int)std::max(0L, std::min(20L, value));
+        else if (!strcmp(key, "coop_wgs")) l->coop_wgs = (int)std::max(1L, std::min(4096L, value));      // (the tests: several iterations per workgroup)
+        else if (!strcmp(key, "coop_lg")) l->coop_lg = (int)std::max(0L, std::min(20L, value));
         return 0;
     });
 }

@@ -116,7 +116,6 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
-    int cu_group = -1;                         // GKRHIP_LANE_CU_GROUPS: the group of compute units this lane's streams are masked to (-1: all)
     unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums (reference-shaped evaluator)
     bool racc_dirty = false;                   // a call that uses d_racc / d_counter is under way or failed half-way
     unsigned long long* d_racc = nullptr;      // GKR_CR_WORDS-word accumulator of the fused round kernels (zero between launches)
@@ -146,11 +145,11 @@ struct Ctx {
     int g_max = 16;                            // log2(max threads of a round kernel) ...
     bool g_max_auto = true;                    // ... chosen per layer from the proofs in flight (round_threads_log2_max) unless GKRHIP_GMAX / "g_max" set it
     bool force_generic = false;
-    bool claim_trick = true;                   // GKRHIP_CLAIM_TRICK=0: always compute all eight monomial sums
+    bool claim_trick = true;                   // option claim_trick = 0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
-    int solo_boost = 1;                        // GKRHIP_SOLO_BOOST: twice the threads for the big rounds of a proof that is alone on the GPU
-    int pyr_split = 12;                        // GKRHIP_PYR_SPLIT: the per-lane eq pyramid above 2^n entries in two launches (0: one launch)
+    int solo_boost = 1;                        // option solo_boost: twice the threads for the big rounds of a proof that is alone on the GPU
+    int pyr_split = 12;                        // option pyr_split: the per-lane eq pyramid above 2^n entries in two launches (0: one launch)
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
     bool force_collective = false;             // GKRHIP_FORCE_COLLECTIVE: take the collective path even at world == 1
     int host_tail = 5;                         // GKRHIP_HOST_TAIL: the rounds with at most 2^h pairs run on the host (0: never); measured: -5 % single-proof latency, +1.5 % throughput
@@ -237,7 +236,7 @@ struct UseLane {
 // Spinning is the lowest-latency wait and is what un-sharded runs use: a handful of lanes on a many-core host.
 // A sharded run has (ranks on this node) x (lanes) waiting threads; when they outnumber the CPUs the container may
 // use (affinity mask and cgroup quota), spinning starves the threads that hash and burns the quota, so the wait
-// spins only briefly and then sleeps in short steps.  GKRHIP_WAIT_SPIN_US overrides (-1 = always spin).
+// spins only briefly and then sleeps in short steps.  gkrhip_set_option("wait_spin_us", n) overrides (-1 = always spin).
 inline int usable_cpus() {
     cpu_set_t set;
     int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
@@ -252,16 +251,11 @@ inline int usable_cpus() {
     }
     return std::max(n, 1);
 }
-std::atomic<int> g_wait_override{-2};           // GKRHIP_WAIT_SPIN_US (-2: not set; -1: always spin; n: spin n us, then sleep)
+std::atomic<int> g_wait_override{-2};           // option wait_spin_us (-2: not set; -1: always spin; n: spin n us, then sleep)
 std::atomic<int> g_wait_ranks{1};               // ranks assumed to share this host (set with the communicator)
 std::atomic<int> g_proofs_in_flight{0};          // gkr.Prove calls currently running in this process (any lane)
 inline int wait_spin_limit_us() {
     static const int cpus = usable_cpus();
-    static const bool init = [] {
-        if (const char* e = getenv("GKRHIP_WAIT_SPIN_US")) g_wait_override.store(atoi(e), std::memory_order_relaxed);
-        return true;
-    }();
-    (void)init;
     const int ov = g_wait_override.load(std::memory_order_relaxed);
     if (ov > -2) return ov;
     // one waiting host thread per proof in flight and rank
@@ -289,18 +283,6 @@ struct Waiter {                                 // one per wait: call step() in 
 inline int round_threads_log2_max() {
     if (!cx().g_max_auto) return cx().g_max;
     return g_proofs_in_flight.load(std::memory_order_relaxed) >= 10 ? 15 : 16;
-}
-// Which register budget the wide round kernel is launched with (cipher_round.hip.h: WAVES): `wide_waves` 2 or 3 as set, 0 = by the
-// proofs in flight (three waves per SIMD -- a third workgroup per CU, at ~30 scratch instructions per pair -- from `wide3_from` proofs
-// in flight on; a proof alone keeps the spill-free kernel).  GKRHIP_WIDE_WAVES / set_option("wide_waves").
-std::atomic<int> g_lane_cu_groups{0};             // GKRHIP_LANE_CU_GROUPS (lane_stream_create below)
-std::atomic<unsigned> g_lane_cu_next{0};
-std::atomic<int> g_wide_waves{2};
-std::atomic<int> g_wide3_from{8};
-inline bool wide_three_waves() {
-    const int w = g_wide_waves.load(std::memory_order_relaxed);
-    if (w) return w == 3;
-    return g_proofs_in_flight.load(std::memory_order_relaxed) >= g_wide3_from.load(std::memory_order_relaxed);
 }
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
@@ -421,25 +403,16 @@ int ctx_init(int dev) {
     if (const char* e = getenv("GKRHIP_GENERIC")) cx().force_generic = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_LAT")) cx().lat_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_WIDE")) cx().wide_mode = atoi(e);
-    if (const char* e = getenv("GKRHIP_WT_LATE_LJ")) cx().wt_late_lj = atoi(e);
-    if (const char* e = getenv("GKRHIP_SOLO_BOOST")) cx().solo_boost = atoi(e);
-    if (const char* e = getenv("GKRHIP_CLAIM_TRICK")) cx().claim_trick = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_FORCE_COLLECTIVE")) cx().force_collective = atoi(e) != 0;
     if (const char* e = getenv("GKRHIP_HOST_TAIL")) cx().host_tail = cx().host_tail_solo = std::max(0, std::min(kHostTailMax, atoi(e)));   // an explicit setting holds for both
     if (const char* e = getenv("GKRHIP_HOST_TAIL_SHARDED")) cx().host_tail_sharded = std::max(0, std::min(kHostTailMax, atoi(e)));
-    if (const char* e = getenv("GKRHIP_PYR_SPLIT")) cx().pyr_split = std::max(0, std::min(20, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRELAUNCH")) cx().prelaunch = atoi(e);
-    if (const char* e = getenv("GKRHIP_PRELAUNCH_LG")) cx().prelaunch_lg = std::max(0, std::min(30, atoi(e)));
     if (const char* e = getenv("GKRHIP_PRE")) cx().pre_mode = atoi(e);
     if (const char* e = getenv("GKRHIP_SPEC")) cx().spec = atoi(e);
     if (const char* e = getenv("GKRHIP_AHEAD")) cx().ahead_mode = atoi(e);
-    if (const char* e = getenv("GKRHIP_ARENA_CHECK")) g_arena_check.store(atoi(e));      // debugging aid, see table_release
     if (const char* e = getenv("GKRHIP_SPEC_LG")) cx().spec_lg = std::max(5, std::min(16, atoi(e)));
     if (const char* e = getenv("GKRHIP_COOP")) cx().coop = atoi(e);
     if (const char* e = getenv("GKRHIP_COOP_LG")) cx().coop_lg = std::max(0, std::min(20, atoi(e)));
-    if (const char* e = getenv("GKRHIP_WIDE_WAVES")) g_wide_waves.store(atoi(e) == 3 ? 3 : atoi(e) == 0 ? 0 : 2);
-    if (const char* e = getenv("GKRHIP_LANE_CU_GROUPS")) g_lane_cu_groups.store(std::max(0, std::min(32, atoi(e))));
-    if (const char* e = getenv("GKRHIP_COOP_WGS")) cx().coop_wgs = std::max(1, std::min(4096, atoi(e)));      // (the tests: several iterations per workgroup)
     cx().lag = new hfr::Lagrange();
     cx().device = dev;
     CHK(lane_alloc());
@@ -451,35 +424,9 @@ int ctx_init(int dev) {
     return 0;
 }
 
-// ---- spatial partitioning of the lanes (round 6 experiment; off by default) ------------------------------
-// GKRHIP_LANE_CU_GROUPS=G: the lanes are dealt round-robin to G groups and every stream of a lane (round kernels, look-ahead) is
-// created with hipExtStreamCreateWithCUMask on its group's 256/G compute units, so a lane's small rounds never wait for a CU slot
-// behind a wide round of a lane of ANOTHER group.  A CU-mask bit i names CU (i / 8) of XCD (i mod 8) (the driver deals the mask's
-// bits round-robin to the XCDs), so a group of 256/G consecutive bits holds the same number of CUs of every XCD -- the dispatcher
-// deals a launch's workgroups round-robin to the XCDs and a mask that left an XCD without CUs would stall it.
-// A masked stream owns a hardware queue of its own (the mask is a property of the queue): G x lanes queues on top of the pool's.
-// Measured (profiles/r06_cu_groups_ab.txt): see DESIGN 6.
-int lane_stream_create(hipStream_t* st, int group) {
-    const int G = g_lane_cu_groups.load();
-    const int ncu = g0.n_cu > 0 ? g0.n_cu : 256;
-    if (G <= 1 || group < 0 || ncu % G != 0 || (ncu / G) % 8 != 0) {
-        HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-        return 0;
-    }
-    const int per = ncu / G;
-    uint32_t mask[16] = {0};
-    for (int b = group * per; b < (group + 1) * per; b++) mask[b >> 5] |= 1u << (b & 31);
-    HIPCHK(hipExtStreamCreateWithCUMask(st, (uint32_t)((ncu + 31) / 32), mask));
-    return 0;
-}
-
 // stream + buffers of the current lane
 int lane_alloc() {
-    {
-        const int G = g_lane_cu_groups.load();
-        cx().cu_group = (G > 1 && &cx() != &g0) ? (int)(g_lane_cu_next.fetch_add(1) % (unsigned)G) : -1;
-    }
-    CHK(lane_stream_create(&cx().stream, cx().cu_group));
+    HIPCHK(hipStreamCreateWithFlags(&cx().stream, hipStreamNonBlocking));
     const size_t nwords = (size_t)GKR_MAX_EVALS * GKR_ACC_WORDS;
     HIPCHK(hipMalloc(&cx().d_partials, sizeof(unsigned long long) * nwords * kPartialBlocks));
     HIPCHK(hipMalloc(&cx().d_sums, sizeof(unsigned long long) * nwords));
@@ -731,7 +678,7 @@ void table_release(DevTable* t, int line = __builtin_LINE(), const char* file = 
             (void)hipGetLastError();
             // arena_check = 2: the buffer is also filled with 0xff behind everything queued on the lane's stream before the next
             // owner can have it -- whoever still reads it afterwards, or relies on what a recycled buffer used to hold, computes
-            // with values above q and its proof differs from the oracle's (GKRHIP_ARENA_CHECK=2 over the whole GPU suite)
+            // with values above q and its proof differs from the oracle's (arena_check = 2 over the whole GPU suite)
             if (g_arena_check.load(std::memory_order_relaxed) >= 2 && cx().stream) {
                 (void)hipMemsetAsync(t->base, 0xff, sizeof(uint4) * 2 * t->cap, cx().stream);
                 (void)hipStreamSynchronize(cx().stream);

@@ -210,7 +210,7 @@ int pre_prepare() {
         // a lowest-priority stream sometimes lets the waiting stream go while one to three XCDs have not finished their share of the
         // producer (16 of 122 036 iterations; 0 of 331 149 at normal priority).  Runtime behaviour, not ours to fix; and whatever still
         // slips through is caught by sumcheck_closes below.  One proof alone: 277.6 ms against 275.1 at bN = 24.
-        CHK(lane_stream_create(&cx().aux, cx().cu_group));
+        HIPCHK(hipStreamCreateWithFlags(&cx().aux, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&cx().pre_done, hipEventDisableTiming));
     }
     for (auto& t : cx().pre_t)
@@ -421,8 +421,6 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
         cx().pre_K = cx().pre_S = nullptr;             // consumed
         hipLaunchKernelGGL((k_cipher_round_wide<false, true, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
         g_cnt_lookahead.fetch_add(1, std::memory_order_relaxed);
-    } else if (wide_three_waves()) {
-        hipLaunchKernelGGL((k_cipher_round_wide<false, true, false, true, 3>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
     } else {
         hipLaunchKernelGGL((k_cipher_round_wide<false, true, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
     }
@@ -735,7 +733,7 @@ struct CipherLoop {
         PyramidArgs3 pa3;
         memset(&pa3, 0, sizeof pa3);
         for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
-        // the per-lane pyramid in two steps when it is wide (GKRHIP_PYR_SPLIT, default 12): levels up to 2^12 entries and the small
+        // the per-lane pyramid in two steps when it is wide (option pyr_split, default 12): levels up to 2^12 entries and the small
         // pyramid H over the next coordinates here, the upper levels by k_eq_pyramid_expand with one product per entry
         const int gLow = (cx().pyr_split > 0 && gT > cx().pyr_split + 1) ? cx().pyr_split : gT;
         pa3.p[0].out = pyrT.planes();
@@ -872,14 +870,6 @@ struct CipherLoop {
             if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             else hipLaunchKernelGGL((k_cipher_round_wide<false, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             g_cnt_lookahead.fetch_add(1, std::memory_order_relaxed);
-        } else if (wide && wide_three_waves()) {
-            if (fold) {
-                if (late) hipLaunchKernelGGL((k_cipher_round_wide<true, true, false, false, 3>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-                else hipLaunchKernelGGL((k_cipher_round_wide<true, false, false, false, 3>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-            } else {
-                if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true, false, false, 3>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-                else hipLaunchKernelGGL((k_cipher_round_wide<false, false, false, false, 3>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-            }
         } else if (wide) {
             if (fold) {
                 if (late) hipLaunchKernelGGL((k_cipher_round_wide<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);

@@ -7,7 +7,7 @@
 #include "g1.hip.h"
 #elif defined(GKR_GROUP_NTT)
 #include "ntt.hip.h"
-#elif defined(GKR_GROUP_WIDE2) || defined(GKR_GROUP_WIDEPRE) || defined(GKR_GROUP_WIDE3)
+#elif defined(GKR_GROUP_WIDE2) || defined(GKR_GROUP_WIDEPRE)
 #include "cipher_round.hip.h"
 #elif defined(GKR_GROUP_ROUND)
 #include "cipher_round.hip.h"

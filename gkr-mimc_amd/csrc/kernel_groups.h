@@ -11,23 +11,16 @@
 #error "define GKR_INST (extern | nothing) before including kernel_groups.h"
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_WIDE2)
-GKR_INST template __global__ void k_cipher_round_wide<false, false, false, false, 2>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, false, false, 2>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<true, false, false, false, 2>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<true, true, false, false, 2>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, false, false, false>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, false, false>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<true, false, false, false>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<true, true, false, false>(CipherRoundArgs);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_WIDEPRE)
-GKR_INST template __global__ void k_cipher_round_wide<false, false, true, false, 2>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, true, false, 2>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, false, true, 2>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, true, true, 2>(CipherRoundArgs);
-#endif
-#if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_WIDE3)
-GKR_INST template __global__ void k_cipher_round_wide<false, false, false, false, 3>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, false, false, 3>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<true, false, false, false, 3>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<true, true, false, false, 3>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, false, true, 3>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, false, true, false>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, true, false>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, false, true>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, true, true>(CipherRoundArgs);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_ROUND)
 GKR_INST template __global__ void k_cipher_round<false, false>(CipherRoundArgs);

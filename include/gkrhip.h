@@ -77,9 +77,10 @@ void gkrhip_host_free(void *p);
 int gkrhip_reserve_lanes(int n);
 /* tuning knobs (measurement only; every setting yields the same transcript): "fold_grid", "fold_split",
  * "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail", "prelaunch", "prelaunch_lg", "lookahead",
- * "coop", "spec", "spec_lg" -- applied to every existing lane,
+ * "coop", "coop_lg", "coop_wgs", "spec", "spec_lg", "ahead", "solo_boost", "pyr_split" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
- * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums).
+ * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums);
+ * "wait_spin_us" (how host threads wait for a round kernel: -2 by the CPUs available -- the default --, -1 always spin, n: spin n us, then sleep).
  * Integrity (process-wide): "layer_check" (default 1) -- every sumcheck the library produces is held against the verifier's own
  * identities before it is returned (sumcheck/verifier.go:41-47 per round, the closing identity of gkr/verifier.go:93-114; host
  * scalar work, microseconds) and run once more in safe mode if it does not close; a second failure is an error, never a
@@ -87,7 +88,7 @@ int gkrhip_reserve_lanes(int n);
  * gkr.Verify on their proof before returning it, as the reference's hint does in debug builds (prover/gadget/hints.go:224-228).
  * "arena_check" (default 0; tests) -- every table handed back to the device arena asks its lane's streams whether they are
  * idle; a release with work still queued is counted ("arena_busy_releases") and its call site named once on stderr; 2: the
- * released table is also filled with 0xff behind the lane's queued work (environment: GKRHIP_ARENA_CHECK).
+ * released table is also filled with 0xff behind the lane's queued work.
  * Fault injection for the tests, each firing once: "test_fail_after_prelaunch", "test_drop_challenge", "test_corrupt_sum" = k
  * (flip one bit of a device sum of round k; "test_corrupt_times" = n afterwards: n times instead of once; "test_corrupt_skip" = j: in the (j+1)-th sumcheck that reaches round k), "test_corrupt_tail" = 1 (flip one bit of the table entries handed to the host). */
 int gkrhip_set_option(const char *key, long value);

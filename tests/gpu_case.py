@@ -28,6 +28,10 @@ def main():
     circuit = sys.argv[2] if len(sys.argv) > 2 else "mimc"
     gk = importlib.import_module("gkr-mimc_amd")
     gk.init(0)
+    # knobs that are library OPTIONS, not environment switches (round 6 folded eight of them): "key=value,key=value"
+    for kv in filter(None, os.environ.get("GKR_CASE_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        gk.set_option(k, int(v))
     gk.profile_reset(0)
     if circuit == "gmimc":      # the build-defined GMiMC (t = 2) circuit: cipher, add and identity layers
         import pyoracle as o

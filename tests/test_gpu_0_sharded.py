@@ -65,7 +65,7 @@ def test_sharded_retry_after_a_missed_challenge():
     gkrhip_set_option): the kernel gives up after a second, the rank votes in the round's exchange, EVERY rank leaves the
     layer's rounds at that exchange and runs them again in safe mode -- same transcript as the oracle, one retry per rank.
     Over both host-side exchanges: shared memory and the ticker."""
-    env = {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRELAUNCH_LG": "30", "GKR_TEST_DROP_RANK": "2", "GKR_TEST_DROP_ROUND": "3",
+    env = {"GKRHIP_PRELAUNCH": "2", "GKR_TEST_DROP_RANK": "2", "GKR_TEST_DROP_ROUND": "3",
            "GKR_TEST_EXPECT_RETRIES": "1"}
     _run_shards("shm", 4, "12", env)
     _run_shards("tickshm", 2, "11", dict(env, GKR_TEST_DROP_RANK="1"))

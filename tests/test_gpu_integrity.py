@@ -25,6 +25,9 @@ PRELUDE = textwrap.dedent("""
     import coracle as c
     gk = importlib.import_module("gkr-mimc_amd")
     gk.init(0)
+    import os
+    for kv in filter(None, os.environ.get("GKR_CASE_OPTIONS", "").split(",")):      # library options (not environment switches)
+        gk.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 """) % (ROOT, os.path.join(ROOT, "oracle"))
 
 
@@ -73,10 +76,10 @@ def test_corrupted_sum_or_fold_is_caught_and_the_layer_rerun():
     reference-shaped evaluator, a small thread budget: a flipped bit in round 0, in a middle round and in the last device
     round, then a flipped bit in the exported tables."""
     _run(SOLO % "(0, 1, 4)")
-    _run(SOLO % "(0, 3, 5)", {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRELAUNCH_LG": "30", "GKRHIP_SPEC": "2", "GKRHIP_PRE": "2"})
-    _run(SOLO % "(0, 2, 5)", {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRELAUNCH_LG": "30", "GKRHIP_SPEC": "0", "GKRHIP_COOP": "2"})
+    _run(SOLO % "(0, 3, 5)", {"GKRHIP_PRELAUNCH": "2", "GKRHIP_SPEC": "2", "GKRHIP_PRE": "2"})
+    _run(SOLO % "(0, 2, 5)", {"GKRHIP_PRELAUNCH": "2", "GKRHIP_SPEC": "0", "GKRHIP_COOP": "2"})
     _run(SOLO % "(0, 2, 11)", {"GKRHIP_PRELAUNCH": "0", "GKRHIP_PRE": "0", "GKRHIP_SPEC": "0", "GKRHIP_COOP": "0", "GKRHIP_HOST_TAIL": "0"})
-    _run(SOLO % "(0, 3)", {"GKRHIP_GMAX": "8", "GKRHIP_CLAIM_TRICK": "0"})
+    _run(SOLO % "(0, 3)", {"GKRHIP_GMAX": "8", "GKR_CASE_OPTIONS": "claim_trick=0"})
 
 
 def test_corrupted_sum_in_the_reference_shaped_rounds():

@@ -342,40 +342,22 @@ def test_round_kernel_small_thread_budget(gk):
     _run_case({"GKRHIP_GMAX": "10"}, "11,12,14")
 
 
-def test_wide_round_kernel_at_three_waves_per_simd(gk):
-    """Round 6: the wide round kernel built for three waves per SIMD (168 VGPRs, hipcc spills to scratch) is the same arithmetic:
-    forced on (GKRHIP_WIDE_WAVES=3) with small thread budgets so that every variant it has (fold / round 0, early / late lane
-    weights, round 0 ahead of its point) runs at sizes the oracle reaches, MiMC and GMiMC; 0 = chosen by the proofs in flight."""
-    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "8"}, "9,10,12,14")
-    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "99"}, "10,13")
-    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "10", "GKRHIP_AHEAD": "2"}, "13,15")
-    _run_case({"GKRHIP_WIDE_WAVES": "3", "GKRHIP_GMAX": "8"}, "9,12", circuit="gmimc")
-    _run_case({"GKRHIP_WIDE_WAVES": "0", "GKRHIP_GMAX": "8"}, "9,12")
-
-
-def test_lanes_on_disjoint_compute_unit_groups(gk):
-    """Round 6 experiment switch GKRHIP_LANE_CU_GROUPS: every stream of a lane is masked to its group's compute units
-    (hipExtStreamCreateWithCUMask); same transcripts (a session proves on a lane of its own, i.e. on a masked stream)."""
-    _run_case({"GKRHIP_LANE_CU_GROUPS": "8", "GKRHIP_CASE_SESSIONS": "3"}, "9,12")
-    _run_case({"GKRHIP_LANE_CU_GROUPS": "4", "GKRHIP_GMAX": "8"}, "10", circuit="gmimc")
-
-
 def test_eq_pyramid_in_two_launches(gk):
     """The per-lane eq pyramid built in two launches (levels up to 2^n entries with short chains, the upper levels with one
     product per entry from a small second pyramid) and in one: same weights, same transcript, for splits below, at and above
     the pyramid's height, with shard-like thread budgets."""
-    _run_case({"GKRHIP_PYR_SPLIT": "3", "GKRHIP_GMAX": "8"}, "9,11,13")
-    _run_case({"GKRHIP_PYR_SPLIT": "1"}, "5,10,14")
-    _run_case({"GKRHIP_PYR_SPLIT": "0"}, "9,14")
-    _run_case({"GKRHIP_PYR_SPLIT": "12"}, "14,15,16")
-    _run_case({"GKRHIP_PYR_SPLIT": "5", "GKRHIP_GMAX": "10"}, "12", circuit="gmimc")
+    _run_case({"GKRHIP_GMAX": "8", "GKR_CASE_OPTIONS": "pyr_split=3"}, "9,11,13")
+    _run_case({"GKR_CASE_OPTIONS": "pyr_split=1"}, "5,10,14")
+    _run_case({"GKR_CASE_OPTIONS": "pyr_split=0"}, "9,14")
+    _run_case({"GKR_CASE_OPTIONS": "pyr_split=12"}, "14,15,16")
+    _run_case({"GKRHIP_GMAX": "10", "GKR_CASE_OPTIONS": "pyr_split=5"}, "12", circuit="gmimc")
 
 
 def test_round_kernel_variants(gk):
     """The throughput kernel everywhere (GKRHIP_LAT=0) and the interleaved-pair kernel everywhere
     (GKRHIP_LAT=2, with and without the per-iteration eq factor) give the same transcript."""
     _run_case({"GKRHIP_LAT": "0"}, "1,4,9,12")
-    _run_case({"GKRHIP_CLAIM_TRICK": "0"}, "1,2,7,12")   # all eight monomial sums computed on the device
+    _run_case({"GKR_CASE_OPTIONS": "claim_trick=0"}, "1,2,7,12")   # all eight monomial sums computed on the device
     _run_case({"GKRHIP_LAT": "2", "GKRHIP_GMAX": "8"}, "1,4,9,12,13")
 
 
@@ -394,33 +376,33 @@ def test_host_tail_rounds(gk):
     _run_case({"GKRHIP_HOST_TAIL": "10", "GKRHIP_LAT": "0"}, "11,12,13,15")
     _run_case({"GKRHIP_HOST_TAIL": "8", "GKRHIP_LAT": "0"}, "10,12", circuit="gmimc")
     _run_case({"GKRHIP_HOST_TAIL": "10", "GKRHIP_LAT": "0"}, "12,13", circuit="gmimc")
-    _run_case({"GKRHIP_HOST_TAIL": "2", "GKRHIP_GMAX": "8", "GKRHIP_CLAIM_TRICK": "0"}, "4,10,13")
+    _run_case({"GKRHIP_HOST_TAIL": "2", "GKRHIP_GMAX": "8", "GKR_CASE_OPTIONS": "claim_trick=0"}, "4,10,13")
 
 
 def test_round_kernel_deferred_reduction_variants(gk):
     """The deferred-reduction round kernel (wide LDS/VGPR accumulators, one reduction per lane and sum) against the
     oracle with the lane weight applied after the loop from 2 pairs per lane on, never, and with the kernel
     switched off (every product reduced) -- the same transcript each time."""
-    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "1"}, "9,10,12,14")
-    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_WT_LATE_LJ": "99"}, "9,10,13")
+    _run_case({"GKRHIP_GMAX": "8", "GKR_CASE_OPTIONS": "wt_late_lj=1"}, "9,10,12,14")
+    _run_case({"GKRHIP_GMAX": "8", "GKR_CASE_OPTIONS": "wt_late_lj=99"}, "9,10,13")
     _run_case({"GKRHIP_GMAX": "9", "GKRHIP_WIDE": "0"}, "10,12,13")
-    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_LAT": "0", "GKRHIP_WT_LATE_LJ": "3"}, "11,15")
+    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_LAT": "0", "GKR_CASE_OPTIONS": "wt_late_lj=3"}, "11,15")
     # a proof alone on the GPU doubles the threads of its big rounds (two eq-weight splits in one sumcheck); off:
-    _run_case({"GKRHIP_GMAX": "8", "GKRHIP_SOLO_BOOST": "0"}, "10,11,12")
+    _run_case({"GKRHIP_GMAX": "8", "GKR_CASE_OPTIONS": "solo_boost=0"}, "10,11,12")
 
 
 def test_prelaunched_rounds(gk):
     """Round k+1's kernel queued before round k is hashed (it polls the host-mapped challenge slot): the same transcript
     with the pre-launch forced on for every round size, off, and combined with the other round variants; the counter
     proves the path ran."""
-    on = {"GKRHIP_PRELAUNCH": "2", "GKRHIP_PRELAUNCH_LG": "30", "GKRHIP_CASE_EXPECT": "prelaunched_rounds"}
+    on = {"GKRHIP_PRELAUNCH": "2", "GKRHIP_CASE_EXPECT": "prelaunched_rounds"}
     _run_case(on, "1,2,3,5,9,12,14")
     _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "2,6,10")
     _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_HOST_TAIL="3"), "9,11,13")
-    _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_LAT="0", GKRHIP_CLAIM_TRICK="0"), "8,12")
+    _run_case(dict(on, GKRHIP_GMAX="8", GKRHIP_LAT="0", GKR_CASE_OPTIONS="claim_trick=0"), "8,12")
     _run_case(dict(on, GKRHIP_GMAX="8"), "3,9,11", circuit="gmimc")           # the linear rounds too
     _run_case({"GKRHIP_PRELAUNCH": "0", "GKRHIP_CASE_EXPECT_NOT": "prelaunched_rounds"}, "2,9,12")
-    _run_case({"GKRHIP_PRELAUNCH": "1", "GKRHIP_PRELAUNCH_LG": "4", "GKRHIP_HOST_TAIL": "0", "GKRHIP_CASE_EXPECT": "prelaunched_rounds"}, "7,10")
+    _run_case({"GKRHIP_PRELAUNCH": "1", "GKRHIP_HOST_TAIL": "0", "GKRHIP_CASE_EXPECT": "prelaunched_rounds", "GKR_CASE_OPTIONS": "prelaunch_lg=4"}, "7,10")
 
 
 def test_cooperative_small_rounds(gk):
@@ -430,9 +412,9 @@ def test_cooperative_small_rounds(gk):
     on = {"GKRHIP_COOP": "2", "GKRHIP_SPEC": "0", "GKRHIP_CASE_EXPECT": "coop_rounds"}   # (the speculative rounds would take the small ones)
     _run_case(on, "1,2,3,5,6,9,12,14")
     _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "1,2,4,7,10,13")               # the P = 1 round and its tail words
-    _run_case(dict(on, GKRHIP_HOST_TAIL="3", GKRHIP_COOP_WGS="2"), "6,9,11")  # export + several iterations per workgroup
-    _run_case(dict(on, GKRHIP_CLAIM_TRICK="0", GKRHIP_PRELAUNCH="0"), "3,8,12")
-    _run_case(dict(on, GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_HOST_TAIL="1"), "5,10,14")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="3", GKR_CASE_OPTIONS="coop_wgs=2"), "6,9,11")  # export + several iterations per workgroup
+    _run_case(dict(on, GKRHIP_PRELAUNCH="0", GKR_CASE_OPTIONS="claim_trick=0"), "3,8,12")
+    _run_case(dict(on, GKRHIP_PRELAUNCH="2", GKRHIP_HOST_TAIL="1"), "5,10,14")
     _run_case(dict(on, GKRHIP_COOP_LG="6", GKRHIP_GMAX="8"), "9,12")
     _run_case(dict(on, GKRHIP_HOST_TAIL="2"), "4,9", circuit="gmimc")
     _run_case({"GKRHIP_COOP": "0", "GKRHIP_CASE_EXPECT_NOT": "coop_rounds"}, "3,9,12")
@@ -450,7 +432,7 @@ def test_speculative_small_rounds(gk):
     _run_case(dict(on, GKRHIP_SPEC_LG="16", GKRHIP_GMAX="16"), "9,13,15")  # from round 2 on
     _run_case(dict(on, GKRHIP_HOST_TAIL="1"), "5,6,9,12")
     _run_case(dict(on, GKRHIP_HOST_TAIL="6"), "9,10,13")
-    _run_case(dict(on, GKRHIP_CLAIM_TRICK="0"), "8,11")                   # M_0 from the candidates as well
+    _run_case(dict(on, GKR_CASE_OPTIONS="claim_trick=0"), "8,11")                   # M_0 from the candidates as well
     _run_case(dict(on, GKRHIP_COOP="0", GKRHIP_PRE="0"), "9,12")
     _run_case(dict(on, GKRHIP_PRE="2", GKRHIP_GMAX="8", GKRHIP_CASE_EXPECT="spec_rounds,lookahead_round0"), "11,13")
     # the GMiMC circuit: cipher layers and LINEAR layers (add, copy: k_linear_round_spec, two candidates -- their sums are linear in r)
@@ -458,7 +440,7 @@ def test_speculative_small_rounds(gk):
     _run_case(on, "9,12,13", circuit="gmimc")
     _run_case(dict(on, GKRHIP_HOST_TAIL="1", GKRHIP_SPEC_LG="6"), "5,6,8", circuit="gmimc")
     _run_case(dict(on, GKRHIP_HOST_TAIL="2"), "7,11", circuit="gmimc")
-    _run_case(dict(on, GKRHIP_CLAIM_TRICK="0", GKRHIP_HOST_TAIL="4"), "8,10", circuit="gmimc")
+    _run_case(dict(on, GKRHIP_HOST_TAIL="4", GKR_CASE_OPTIONS="claim_trick=0"), "8,10", circuit="gmimc")
     _run_case(dict(on, GKRHIP_SPEC="0", GKRHIP_CASE_EXPECT="", GKRHIP_CASE_EXPECT_NOT="spec_rounds"), "9", circuit="gmimc")
     _run_case({"GKRHIP_CASE_EXPECT": "spec_rounds,prelaunched_rounds,coop_rounds"}, "12,15")   # the defaults, alone on the GPU
     _run_case({"GKRHIP_SPEC": "0", "GKRHIP_CASE_EXPECT_NOT": "spec_rounds"}, "9,12")
@@ -475,9 +457,9 @@ def test_speculative_rounds_random_settings(gk):
     for _ in range(10):
         env = {"GKRHIP_SPEC": "2", "GKRHIP_CASE_EXPECT": "spec_rounds",
                "GKRHIP_HOST_TAIL": str(rng.randint(1, 6)), "GKRHIP_SPEC_LG": str(rng.randint(5, 16)),
-               "GKRHIP_GMAX": str(rng.choice([8, 10, 12, 16])), "GKRHIP_PRELAUNCH_LG": str(rng.choice([16, 30])),
+               "GKRHIP_GMAX": str(rng.choice([8, 10, 12, 16])),
                "GKRHIP_COOP": str(rng.choice([0, 2])), "GKRHIP_PRE": str(rng.choice([0, 2])),
-               "GKRHIP_CLAIM_TRICK": str(rng.choice([0, 1, 1]))}
+               "GKR_CASE_OPTIONS": "prelaunch_lg=%d,claim_trick=%d" % (rng.choice([16, 30]), rng.choice([0, 1, 1]))}
         env["GKRHIP_SPEC_LG"] = str(max(int(env["GKRHIP_SPEC_LG"]), int(env["GKRHIP_HOST_TAIL"]) + 1))   # the export round itself qualifies
         sizes = sorted(rng.sample(range(int(env["GKRHIP_HOST_TAIL"]) + 4, 15), 2))
         _run_case(env, ",".join(map(str, sizes)))
@@ -514,7 +496,7 @@ def test_error_while_a_prelaunched_kernel_waits(gk):
     """ % (root, os.path.join(root, "oracle")))
     # the kernel left waiting is a pre-launched round kernel (GKRHIP_SPEC=0) or a speculative launch two rounds ahead
     for spec in ("0", "2"):
-        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_SPEC=spec)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "ABORT-PATH-OK" in out.stdout, (spec, out.stdout + out.stderr)
 
@@ -546,7 +528,7 @@ def test_layer_retried_after_a_missed_challenge(gk):
         print("RETRY-OK")
     """ % (root, os.path.join(root, "oracle")))
     for spec in ("0", "2"):
-        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_SPEC=spec)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "RETRY-OK" in out.stdout, (spec, out.stdout + out.stderr)
 
@@ -557,8 +539,8 @@ def test_lookahead_round0(gk):
     weights, MiMC and GMiMC circuits, and with the look-ahead switched off."""
     on = {"GKRHIP_PRE": "2", "GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT": "lookahead_round0"}
     _run_case(on, "11,12,14,15")
-    _run_case(dict(on, GKRHIP_WT_LATE_LJ="99"), "11,13")
-    _run_case(dict(on, GKRHIP_WT_LATE_LJ="1", GKRHIP_SOLO_BOOST="0", GKRHIP_PRELAUNCH="0"), "10,12")
+    _run_case(dict(on, GKR_CASE_OPTIONS="wt_late_lj=99"), "11,13")
+    _run_case(dict(on, GKRHIP_PRELAUNCH="0", GKR_CASE_OPTIONS="wt_late_lj=1,solo_boost=0"), "10,12")
     _run_case(dict(on, GKRHIP_HOST_TAIL="0"), "11,12", circuit="gmimc")
     _run_case({"GKRHIP_PRE": "0", "GKRHIP_GMAX": "8", "GKRHIP_CASE_EXPECT_NOT": "lookahead_round0"}, "11,13")
     # the defaults, alone on the GPU: below 2^22 entries round 0 runs AHEAD of its point during the previous layer's host tail
@@ -1315,7 +1297,7 @@ def test_twelve_lanes_of_one_size_with_the_solo_paths_forced_on(gk):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for gmax in ("15", "16", None):
-        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRE="2", GKRHIP_COOP="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC="0")
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRE="2", GKRHIP_COOP="2", GKRHIP_SPEC="0")
         if gmax:
             env["GKRHIP_GMAX"] = gmax
         for rep in range(2):
@@ -1338,7 +1320,7 @@ def test_soak_lanes_with_the_solo_paths_forced_on(gk):
     # GKRHIP_SPEC=0: the cooperative kernel takes the small rounds; 2: the speculative launches (two kernels queued per lane, three
     # challenge slots and mailboxes per lane) take them
     for spec, secs in (("0", "15"), ("2", "12")):
-        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRE="2", GKRHIP_COOP="2", GKRHIP_PRELAUNCH_LG="30", GKRHIP_SPEC=spec)
+        env = dict(os.environ, GKRHIP_PRELAUNCH="2", GKRHIP_PRE="2", GKRHIP_COOP="2", GKRHIP_SPEC=spec)
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), secs], capture_output=True, text=True,
                              timeout=900, env=env)
         assert out.returncode == 0 and "mismatches: []" in out.stdout, (spec, out.stdout + out.stderr)
