@@ -478,7 +478,9 @@ inline RoundPlan plan_rounds(int m, bool collective, int gamma_tail, bool* did_g
     // with round 0 running ahead of its point during the host tail (ahead_launch) the look-ahead products only pay from 2^22 entries
     // on: below, the whole round 0 fits the tail (bN = 18 / 20 / 21 alone: 75.9 / 92.9 / 107.7 ms without against 77.0 / 93.8 / 108.9 with
     // the products; bN = 22: 140.0 against 136.4)
-    if (cx().pre_mode == 1 && !collective && m < 22 && p.h_tail > 0 && (cx().ahead_mode >= 2 || (cx().ahead_mode == 1 && p.alone))) p.pre_on = false;
+    // ... and up to 2^24: at 2^25 the look-ahead kernel (2.7 ms at one workgroup per CU) no longer fits the small rounds it overlaps
+    // (bN = 25 alone: 488 ms with, 479 without; bN = 22 / 23 / 24: 133 / 182 / 266 with against 138 / 192 / 291 without: profiles/r06_pre_ab.txt)
+    if (cx().pre_mode == 1 && !collective && (m < 22 || m > 24) && p.h_tail > 0 && (cx().ahead_mode >= 2 || (cx().ahead_mode == 1 && p.alone))) p.pre_on = false;
     return p;
 }
 // Speculative rounds (cipher_spec.hip.h): rounds k_s .. k_export run for the candidate values of r_{k-1} while the host hashes
