@@ -92,7 +92,7 @@ def cpu_baseline(target_seconds=40.0):
                       "multiplication alone; not the Go binary" % (b, secs)}
 
 
-SUMMARY_KEYS = ("bn20", "gmimc_bn22", "oneshot_s", "msm_g1_2p20_ms", "msm_g1_2p22_ms", "msm_g1_2p24_ms", "msm_g2_2p22_ms", "compute_h_2p24_ms", "fold_frac_of_hbm_peak", "partial_eval_frac_of_issue_ceiling", "layer_checks",
+SUMMARY_KEYS = ("bn20", "gmimc_bn22", "oneshot_s", "msm_g1_2p20_ms", "msm_g1_2p22_ms", "msm_g1_2p24_ms", "msm_g1_fixed_base_ms", "msm_g2_2p22_ms", "compute_h_2p24_ms", "fold_frac_of_hbm_peak", "partial_eval_frac_of_issue_ceiling", "layer_checks",
                 "layer_check_failures", "chal_retries", "bench_attempts")
 
 
@@ -114,6 +114,8 @@ def config_summary(out):
     for lg in (20, 22, 24):
         m = mi.get("msm_g1_2p%d" % lg)
         sm["msm_g1_2p%d_ms" % lg] = r(m["ms"]) if m else None
+    fb = {("2p%d" % lg): r(mi["msm_g1_fixed_base_2p%d" % lg]["ms"]) for lg in (20, 22, 24) if mi.get("msm_g1_fixed_base_2p%d" % lg)}
+    sm["msm_g1_fixed_base_ms"] = fb or None
     sm["msm_g2_2p22_ms"] = r(mi["msm_g2_2p22"]["ms"]) if mi.get("msm_g2_2p22") else None
     sm["compute_h_2p24_ms"] = r(mi["compute_h_2p24"]["ms"]) if mi.get("compute_h_2p24") else None
     sm["fold_frac_of_hbm_peak"] = r((out.get("roofline") or {}).get("frac"), 4)
@@ -1197,6 +1199,26 @@ def main():
                                                          "8 M + 2 S) at its measured issue cost (%.1f / %.1f cycles per wave), every lane busy, "
                                                          "nominal %.1f GHz" % (HALF_RATE_CYCLES, FULL_RATE_CYCLES, NOMINAL_GHZ)}
             micro["msm_g1_2p%d" % lg] = e
+        # the same MSMs on fixed-base tables (round 6; gkrhip_msm_g1_precompute): the bases of the reference's MultiExp calls are
+        # proving-key vectors, the same for every proof -- [2^(c j)] P_i once per key, then one bucket space for all windows
+        for lg in (20, 22, 24):
+            r = gk.bench_msm_g1_fixed_base(lg, warmup=1, iters=3)
+            nwin = -(-255 // r["c"])
+            e = {"ms": r["ms"], "points_per_s": float(1 << lg) / (r["ms"] * 1e-3), "window_bits": r["c"], "windows": nwin,
+                 "phases_ms": r["phases_ms"], "host_tail_ms": r["host_tail_ms"], "precompute_ms": r["precompute_ms"],
+                 "table_bytes": float(nwin) * (1 << lg) * 64,
+                 "vs_per_window_sort": r["ms"] / micro["msm_g1_2p%d" % lg]["ms"],
+                 "measured": "as msm_g1_2p%d, on tables [2^(c j)] P_i computed once (precompute_ms, host clock, outside ms): %d additions "
+                             "per scalar instead of %d, one bucket space of 2^%d buckets; phases_ms.sort = digits + rocPRIM radix sort of "
+                             "(bucket, entry) pairs + run boundaries" % (lg, nwin, micro["msm_g1_2p%d" % lg]["windows"], r["c"] - 1),
+                 "mirrors": "(*G1Jac).MultiExp(pk.G1.*, scalars, cfg) with the key's points fixed across proofs (prove.go:76,91,189,202,221)"}
+            if lp:
+                issue_cycles = HALF_RATE_CYCLES * lp["half_rate"] + FULL_RATE_CYCLES * lp["full_rate"]
+                madds = float(nwin) * (1 << lg)
+                ceil_ms = madds / (N_SIMD * 64) * issue_cycles / (NOMINAL_GHZ * 1e9) * 1e3
+                e["accumulate"] = {"kernel": "k_msm_accumulate", "mixed_additions": madds, "ceiling_ms": ceil_ms, "ms": r["phases_ms"]["accumulate"],
+                                   "frac": ceil_ms / r["phases_ms"]["accumulate"]}
+            micro["msm_g1_fixed_base_2p%d" % lg] = e
         for lg in (20, 22):
             r = gk.bench_msm_g2(lg, warmup=1, iters=3)
             micro["msm_g2_2p%d" % lg] = {"ms": r["ms"], "points_per_s": float(1 << lg) / (r["ms"] * 1e-3), "window_bits": r["c"], "phases_ms": r["phases_ms"],

@@ -265,7 +265,7 @@ struct MsmArgs {
     size_t chunk_len;
     u32 bias[8];              // H: half a window added to every window but the top one
     unsigned int* entries;    // point index | sign << 31, sorted by (window, bucket)
-    unsigned int* big;        // [0] = number of segments of big buckets, [1 + k] = bucket id | segment << 20, [big_cap + 1] = a scalar was not below 2^254
+    unsigned int* big;        // [0] = number of segments of big buckets, [1 + k] = bucket id | segment << MSM_LIST_ID_BITS, [big_cap + 1] = a scalar was not below 2^254
     unsigned int big_threshold, big_cap;
     unsigned int seg;         // points per SEGMENT of a big bucket (a power of two): one workgroup sums one segment
     XPlanes bigparts;         // partial sums of the segments of multi-segment buckets, indexed like the segment list
@@ -284,11 +284,24 @@ struct MsmArgs {
     const unsigned int* c_count;       // ... its bin sizes, offsets, first list entries and the slice list (big[] of the coarse pass)
     const unsigned int* c_offset;
     const unsigned int* c_first;
-    const unsigned int* slices;        // [0] = number of slices, [1 + k] = bin | slice << 20 (slice_len entries each)
+    const unsigned int* slices;        // [0] = number of slices, [1 + k] = bin | slice << MSM_LIST_ID_BITS (slice_len entries each)
     unsigned int slice_cap, slice_len;
     int rbits;                         // refine: the coarse pass's lowbits
     unsigned int* slice_hist;          // [slice][2^rbits] counts, then write cursors
+    // fixed-base MSM (k_msm_fb_*): ONE bucket space for all windows; W here is the number of windows of a scalar, the sums run with W = 1
+    unsigned int* fb_keys;             // [W][n] bucket of (window, point), nb for a zero digit (sorts behind every bucket)
+    unsigned int* fb_vals;             // [W][n] entry: index into the table array (window * n + point) | sign << 31
+    // the size ordering (k_msm_order) and the bucket sums (k_msm_accumulate) see the fixed-base MSM's one bucket space as acc_W
+    // ranges of acc_nb consecutive buckets (a workgroup orders one range in LDS); 0: the windows themselves
+    unsigned int acc_W, acc_nb;
 };
+__device__ __forceinline__ unsigned int msm_acc_windows(const MsmArgs& a) { return a.acc_W ? a.acc_W : (unsigned int)a.W; }
+__device__ __forceinline__ unsigned int msm_acc_nb(const MsmArgs& a) { return a.acc_nb ? a.acc_nb : a.nb; }
+// entries of the big-bucket list and of the slice list: id (bucket or coarse bin) in the low MSM_LIST_ID_BITS bits, the segment /
+// slice number above (at most 2^11 of either per id: host_msm.hip.h sizes seg and slice_len for that).  21 bits: the one bucket
+// space of a fixed-base MSM at c = 22 holds 2^21 buckets (20 bits until round 6).
+#define MSM_LIST_ID_BITS 21
+#define MSM_LIST_ID_MASK ((1u << MSM_LIST_ID_BITS) - 1u)
 // bins of the sorting kernels: the buckets themselves, or the coarse bins of a two-level sort
 __device__ __forceinline__ unsigned int msm_sort_bins(const MsmArgs& a) { return a.nb >> a.lowbits; }
 
@@ -469,7 +482,7 @@ GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_msm_offsets(MsmArgs a) {
         if (c[h] > a.big_threshold) {        // a big bucket: one list entry per segment of a.seg points (consecutive entries)
             const unsigned int nseg = (c[h] + a.seg - 1) / a.seg;
             const unsigned int k0 = atomicAdd(&a.big[0], nseg);
-            for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << 20);
+            for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
             if (a.bin_first) a.bin_first[t] = k0;
         }
         const size_t j = t / nbs, b = t % nbs;
@@ -625,8 +638,8 @@ GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_scatter_coarse(MsmArgs
 __device__ __forceinline__ bool msm_slice_range(const MsmArgs& a, unsigned int* bin, unsigned int* lo, unsigned int* hi) {
     if (blockIdx.x >= min(a.slices[0], a.slice_cap)) return false;
     const unsigned int e = a.slices[1 + blockIdx.x];
-    *bin = e & 0xfffffu;
-    const unsigned int base = a.c_offset[*bin], cnt = a.c_count[*bin], s0 = (e >> 20) * a.slice_len;
+    *bin = e & MSM_LIST_ID_MASK;
+    const unsigned int base = a.c_offset[*bin], cnt = a.c_count[*bin], s0 = (e >> MSM_LIST_ID_BITS) * a.slice_len;
     *lo = base + s0;
     *hi = base + min(cnt, s0 + a.slice_len);
     return true;
@@ -682,7 +695,7 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_refine_offsets(MsmArgs a) {
     if (cnt > a.big_threshold) {
         const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
         const unsigned int b0 = atomicAdd(&a.big[0], nseg);
-        for (unsigned int sg = 0; sg < nseg && b0 + sg < a.big_cap; sg++) a.big[1 + b0 + sg] = (unsigned int)t | (sg << 20);
+        for (unsigned int sg = 0; sg < nseg && b0 + sg < a.big_cap; sg++) a.big[1 + b0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
     }
     for (unsigned int s = 0; s < nsl; s++) {
         unsigned int* p = &a.slice_hist[(size_t)(k0 + s) * nlow + low];
@@ -724,10 +737,11 @@ GKR_KERNEL void __launch_bounds__(MSM_REFINE_THREADS) k_msm_refine_scatter(MsmAr
 GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
     __shared__ unsigned int bin[MSM_ORDER_BINS + 1];
     const unsigned int j = blockIdx.x;
-    const unsigned int* cnt = a.count + (size_t)j * a.nb;
+    const unsigned int nb = msm_acc_nb(a);
+    const unsigned int* cnt = a.count + (size_t)j * nb;
     for (unsigned int i = threadIdx.x; i <= MSM_ORDER_BINS; i += MSM_SORT_THREADS) bin[i] = 0;
     __syncthreads();
-    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) {
+    for (unsigned int b = threadIdx.x; b < nb; b += MSM_SORT_THREADS) {
         const unsigned int c = cnt[b];
         atomicAdd(&bin[c > a.big_threshold ? 0u : min(c, (unsigned int)MSM_ORDER_BINS)], 1u);
     }
@@ -741,10 +755,74 @@ GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
         }
     }
     __syncthreads();
-    for (unsigned int b = threadIdx.x; b < a.nb; b += MSM_SORT_THREADS) {
+    for (unsigned int b = threadIdx.x; b < nb; b += MSM_SORT_THREADS) {
         const unsigned int c = cnt[b];
         const unsigned int pos = atomicAdd(&bin[c > a.big_threshold ? 0u : min(c, (unsigned int)MSM_ORDER_BINS)], 1u);
-        a.order[(size_t)j * a.nb + pos] = b;
+        a.order[(size_t)j * nb + pos] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-base MSM (round 6).  The bases of the reference's MSMs are proving-key vectors, fixed across proofs (prove.go:76,91,189,
+// 202,221,277 all name pk.*): with the multiples T_j[i] = [2^(c j)] P_i computed ONCE (k_msm_fb_precompute; W x the key's size in
+// HBM), window j of scalar i contributes d_ij * T_j[i] and every window shares ONE bucket space -- so the window can be wide
+// (c = 20..22: 13 or 12 additions per scalar instead of 16) without paying 2^(c-1) buckets per window in the reduction.  The sort
+// then has 21-bit keys and 28-bit table indices, which the counting sort above (16-bit digit planes, 32-bit entries with the low
+// bucket bits inside) does not hold: it is a radix sort of (bucket, entry) pairs (fb_sort.hip: rocPRIM), followed by the run
+// boundaries.  Bucket sums, big buckets and the window sum are the kernels below with W = 1 and the table array as `points`.
+// ------------------------------------------------------------------------------------------------
+// tables[j * n + i] = [2^(c j)] points[i], affine, canonical (infinity stays (0, 0)); one lane per point, one inversion per entry
+template <class F>
+__global__ void __launch_bounds__(GKR_BLOCK) k_msm_fb_precompute(const uint4* __restrict__ points, uint4* __restrict__ tables, size_t n, int c, int W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffT<F> p = ec_ld_aff<F>(points, i);
+    ec_st_aff<F>(tables, i, p);
+    XyzzT<F> x;
+    if (ec_aff_is_inf(p)) ecx_set_inf(x);
+    else x.x = p.x, x.y = p.y, x.zz = F::one(), x.zzz = F::one();
+    for (int j = 1; j < W; j++) {
+        for (int k = 0; k < c; k++) ecx_dbl(x);
+        ec_st_aff<F>(tables, (size_t)j * n + i, ecx_to_aff(x));
+    }
+}
+// (bucket, entry) of every (window, point): a.W windows of a.c bits, a.nb = 2^(c-1) buckets
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_digits(MsmArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    u32 s[8];
+    msm_load_scalar(a, i, s);
+    bool bad = !msm_bias_scalar(a, s);
+    for (int j = 0; j < a.W; j++) {
+        const u32 dp = msm_window_raw(a, s, j);
+        bool neg;
+        const u32 b = msm_digit(a, dp, j, &neg);
+        if (b == MSM_DIGIT_BAD) bad = true;
+        const size_t v = (size_t)j * a.n + i;
+        a.fb_keys[v] = b < MSM_DIGIT_BAD ? b : a.nb;
+        a.fb_vals[v] = (u32)((size_t)j * a.dstride + i) | (neg ? 0x80000000u : 0u);      // dstride: the tables' window stride
+    }
+    if (bad) *a.err = 1u;
+}
+// run boundaries in the sorted keys: offset[b] = first position of bucket b, count[b] = one past its last (both zero beforehand)
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_bounds(const unsigned int* __restrict__ keys, size_t total, MsmArgs a) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned int k = keys[i];
+        if (k >= a.nb) continue;
+        if (i == 0 || keys[i - 1] != k) a.offset[k] = (unsigned int)i;
+        if (i + 1 == total || keys[i + 1] != k) a.count[k] = (unsigned int)(i + 1);
+    }
+}
+// count[b] = size of the run; the buckets above the threshold go to the segment list of k_msm_accumulate_big (as k_msm_offsets)
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_counts(MsmArgs a) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nb) return;
+    const unsigned int end = a.count[t], cnt = end ? end - a.offset[t] : 0u;
+    a.count[t] = cnt;
+    if (cnt > a.big_threshold) {
+        const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
+        const unsigned int k0 = atomicAdd(&a.big[0], nseg);
+        for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
     }
 }
 
@@ -772,13 +850,14 @@ struct MsmTune<Fp2F> {
 template <class F>
 __global__ void __launch_bounds__(GKR_BLOCK, MsmTune<F>::ACC_MINBLOCKS) k_msm_accumulate(MsmArgs a) {
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= (size_t)a.W * a.nb) return;
+    const size_t aW = msm_acc_windows(a), anb = msm_acc_nb(a);
+    if (lane >= aW * anb) return;
     // The lane's bucket: the (lane mod nb)-th largest of its window, the TOP window first: a scalar below q < 2^254 leaves the
     // top digit few values (q >> 240 = 12 388 of the 32 768 buckets at c = 16), so its buckets hold 2.6 times the points of the
     // others -- launched last they were the kernel's tail (2^24 points: 26.9 ms, against 22 ms for 16 windows at the rate of
     // the first 14).
-    const size_t jw = (size_t)(a.W - 1) - lane / a.nb;
-    const size_t t = jw * a.nb + a.order[jw * a.nb + lane % a.nb];
+    const size_t jw = (aW - 1) - lane / anb;
+    const size_t t = jw * anb + a.order[jw * anb + lane % anb];
     const unsigned int cnt = a.count[t], start = a.offset[t];
     XyzzT<F> acc;
     ecx_set_inf(acc);
@@ -850,8 +929,8 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_accumulate_big(MsmArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.big[0] > a.big_cap) *a.err = 2u;      // the list overflowed (cannot happen by its sizing): an error, not a wrong sum
     for (unsigned int k = blockIdx.x; k < nbig; k += gridDim.x) {
         const unsigned int e = a.big[1 + k];
-        const size_t t = e & 0xfffffu;
-        const unsigned int sg = e >> 20;
+        const size_t t = e & MSM_LIST_ID_MASK;
+        const unsigned int sg = e >> MSM_LIST_ID_BITS;
         const unsigned int cnt = a.count[t], start = a.offset[t];
         const unsigned int lo = sg * a.seg, hi = min(cnt, lo + a.seg);
         XyzzT<F> acc;
@@ -871,9 +950,9 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_big_combine(MsmArgs a) {
     const unsigned int nbig = min(a.big[0], a.big_cap);
     for (unsigned int k = blockIdx.x; k < nbig; k += gridDim.x) {
         const unsigned int e = a.big[1 + k];
-        const size_t t = e & 0xfffffu;
+        const size_t t = e & MSM_LIST_ID_MASK;
         const unsigned int cnt = a.count[t];
-        if ((e >> 20) != 0 || cnt <= a.seg) continue;          // (uniform over the workgroup) the entry of segment 0 speaks for its bucket
+        if ((e >> MSM_LIST_ID_BITS) != 0 || cnt <= a.seg) continue;          // (uniform over the workgroup) the entry of segment 0 speaks for its bucket
         const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
         XyzzT<F> acc;
         ecx_set_inf(acc);

@@ -44,6 +44,11 @@
 
 using hfr::E;
 
+// fb_sort.hip (a unit of its own: rocPRIM's radix sort of the fixed-base MSM's (bucket, entry) pairs)
+int gkrhip_fb_sort_bytes(size_t n, int key_bits, size_t* bytes);
+int gkrhip_fb_sort(void* tmp, size_t bytes, const unsigned int* keys_in, unsigned int* keys_out, const unsigned int* vals_in,
+                   unsigned int* vals_out, size_t n, int key_bits, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -1294,6 +1299,20 @@ int abi_set_window(MsmBases* b, int c) {
     b->c_forced = c;
     return 0;
 }
+// fixed-base tables of a handle: c = 0 chosen from the number of points, 8..22 forced, -1 drops the tables (the handle's MSMs go
+// back to the per-window sort)
+template <class F>
+int abi_precompute(MsmBases* b, int c) {
+    if (!b) return fail("msm_precompute: null handle");
+    LEASE_LANE();
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (c < 0) {
+        HIPCHK(hipStreamSynchronize(cx().stream));
+        b->fb.release();
+        return 0;
+    }
+    return msm_fb_prepare<F>(b, c);
+}
 template <class F, class HF>
 int abi_msm(uint64_t* out_affine, MsmBases* b, const uint64_t* scalars, size_t n, int flags) {
     if (!out_affine || !b || (n && !scalars)) return fail("msm: null argument");
@@ -1303,7 +1322,7 @@ int abi_msm(uint64_t* out_affine, MsmBases* b, const uint64_t* scalars, size_t n
 // MSM of 2^logn synthetic device-resident bases [k_i] G and scalars (both pseudo-random below q), timed with HIP events
 template <class F, class HF, class B>
 int abi_bench_msm(const uint64_t* gen_image, int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
-                  double* host_tail_ms, uint64_t* result_or_null) {
+                  double* host_tail_ms, uint64_t* result_or_null, bool fixed_base = false, double* precompute_ms = nullptr) {
     if (logn < 0 || logn > 26 || iters < 1 || !avg_ms) return fail("bench_msm: bad arguments");
     LEASE_LANE();
     const size_t n = (size_t)1 << logn;
@@ -1320,8 +1339,8 @@ int abi_bench_msm(const uint64_t* gen_image, int logn, int c_or_0, int warmup, i
             bases_free(b);
         }
     } g{b};
-    b->c_forced = c_or_0;
-    CHK(msm_work_prepare(&b->w, n, c_or_0, F::W16));
+    b->c_forced = fixed_base ? 0 : c_or_0;
+    if (!fixed_base) CHK(msm_work_prepare(&b->w, n, c_or_0, F::W16));
     HIPCHK(hipMalloc((void**)&g.s, n * 32));
     hipLaunchKernelGGL(k_msm_synth_scalars, dim3(grid_for(n, 4096)), dim3(GKR_BLOCK), 0, cx().stream, g.s, n, 0x1234567u);
     {
@@ -1336,16 +1355,24 @@ int abi_bench_msm(const uint64_t* gen_image, int logn, int c_or_0, int warmup, i
     hipLaunchKernelGGL(k_msm_synth_scalars, dim3(grid_for(n, 4096)), dim3(GKR_BLOCK), 0, cx().stream, g.s, n, 0x7654321u);
     HIPCHK(hipGetLastError());
     for (hipEvent_t& e : g.tm.ev) HIPCHK(hipEventCreate(&e));
-    for (int i = 0; i < warmup; i++) CHK(msm_dev<F>(b, g.s, n, 0, nullptr));
+    if (fixed_base) {      // the tables: once per key, outside the MSM's time (reported beside it)
+        HIPCHK(hipStreamSynchronize(cx().stream));
+        const double t0 = now_ms();
+        CHK(msm_fb_prepare<F>(b, c_or_0));
+        if (precompute_ms) *precompute_ms = now_ms() - t0;
+    }
+    MsmWork* wk = fixed_base ? &b->fb.w : &b->w;
+    auto run = [&](MsmTimes* tm) { return fixed_base ? msm_fb_dev<F>(b, g.s, n, 0, tm) : msm_dev<F>(b, g.s, n, 0, tm); };
+    for (int i = 0; i < warmup; i++) CHK(run(nullptr));
     HIPCHK(hipStreamSynchronize(cx().stream));
     double tot = 0, ph[5] = {0, 0, 0, 0, 0}, tail = 0;
     g.tm.on = true;
     hfp::AffH<HF> r{HF::zero(), HF::zero()};
     for (int i = 0; i < iters; i++) {
-        CHK(msm_dev<F>(b, g.s, n, 0, &g.tm));
+        CHK(run(&g.tm));
         HIPCHK(hipEventSynchronize(g.tm.ev[5]));
         const double t0 = now_ms();
-        r = msm_host_tail<HF>(&b->w);
+        r = msm_host_tail<HF>(wk);
         tail += now_ms() - t0;
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, g.tm.ev[0], g.tm.ev[5]));
@@ -1358,7 +1385,7 @@ int abi_bench_msm(const uint64_t* gen_image, int logn, int c_or_0, int warmup, i
     *avg_ms = tot / iters;
     if (phase_ms)
         for (int k = 0; k < 5; k++) phase_ms[k] = ph[k] / iters;
-    if (c_used) *c_used = b->w.c;
+    if (c_used) *c_used = wk->c;
     if (host_tail_ms) *host_tail_ms = tail / iters;
     if (result_or_null) memcpy(result_or_null, &r, sizeof r);
     return 0;
@@ -1400,6 +1427,8 @@ int gkrhip_g1_bases_read(const gkrhip_g1_bases* b, uint64_t* out, size_t first, 
 int gkrhip_g2_bases_read(const gkrhip_g2_bases* b, uint64_t* out, size_t first, size_t count) { return abi_bases_read(b, out, first, count); }
 void gkrhip_g1_bases_destroy(gkrhip_g1_bases* b) { bases_free(b); }
 void gkrhip_g2_bases_destroy(gkrhip_g2_bases* b) { bases_free(b); }
+int gkrhip_msm_g1_precompute(gkrhip_g1_bases* b, int c) { return abi_precompute<FpF>(b, c); }
+int gkrhip_msm_g2_precompute(gkrhip_g2_bases* b, int c) { return abi_precompute<Fp2F>(b, c); }
 int gkrhip_msm_g1_set_window(gkrhip_g1_bases* b, int c) { return abi_set_window(b, c); }
 int gkrhip_msm_g2_set_window(gkrhip_g2_bases* b, int c) { return abi_set_window(b, c); }
 int gkrhip_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* b, const uint64_t* scalars, size_t n, int flags) {
@@ -1508,6 +1537,16 @@ int gkrhip_bench_msm_g2(int logn, int c_or_0, int warmup, int iters, double* avg
                         double* host_tail_ms, uint64_t result_or_null[16]) {
     return abi_bench_msm<Fp2F, hfp::HFp2, gkrhip_g2_bases>(g2_generator(), logn, c_or_0, warmup, iters, avg_ms, phase_ms, c_used, host_tail_ms,
                                                            result_or_null);
+}
+int gkrhip_bench_msm_g1_fixed_base(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
+                                   double* host_tail_ms, double* precompute_ms, uint64_t result_or_null[8]) {
+    return abi_bench_msm<FpF, hfp::HFp, gkrhip_g1_bases>(g1_generator(), logn, c_or_0, warmup, iters, avg_ms, phase_ms, c_used, host_tail_ms,
+                                                         result_or_null, /*fixed_base=*/true, precompute_ms);
+}
+int gkrhip_bench_msm_g2_fixed_base(int logn, int c_or_0, int warmup, int iters, double* avg_ms, double phase_ms[5], int* c_used,
+                                   double* host_tail_ms, double* precompute_ms, uint64_t result_or_null[16]) {
+    return abi_bench_msm<Fp2F, hfp::HFp2, gkrhip_g2_bases>(g2_generator(), logn, c_or_0, warmup, iters, avg_ms, phase_ms, c_used, host_tail_ms,
+                                                           result_or_null, /*fixed_base=*/true, precompute_ms);
 }
 int gkrhip_g2_generator(uint64_t out[16]) {
     if (!out) return fail("g2_generator: null argument");

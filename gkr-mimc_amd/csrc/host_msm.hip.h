@@ -63,6 +63,23 @@ struct MsmWork {
         *this = MsmWork();
     }
 };
+// Fixed-base tables and work buffers of a handle (g1.hip.h: "Fixed-base MSM"; gkrhip_msm_g1_precompute)
+struct MsmFixedBase {
+    int c = 0, W = 0;                    // window bits; windows of a scalar
+    unsigned int nb = 0;                 // buckets: 2^(c-1), ONE space for all windows
+    uint4* tables = nullptr;             // [W][n] points: [2^(c j)] P_i, affine
+    unsigned int* keys[2] = {nullptr, nullptr};      // [W * n] (bucket) before / after the sort
+    unsigned int* vals[2] = {nullptr, nullptr};      // [W * n] (table index | sign << 31) before / after: the second is the entry list
+    void* sort_tmp = nullptr;
+    size_t sort_bytes = 0;
+    MsmWork w;                           // counts, big list, scalars, bucket planes, pinned window sum: geometry (c, W = 1, nb)
+    void release() {
+        for (void* p : {(void*)tables, (void*)keys[0], (void*)keys[1], (void*)vals[0], (void*)vals[1], sort_tmp})
+            if (p) (void)hipFree(p);
+        w.release();
+        *this = MsmFixedBase();
+    }
+};
 struct MsmBases {
     uint4* d_points = nullptr;     // n x 64 B (G1) or 128 B (G2)
     size_t n = 0;
@@ -70,6 +87,7 @@ struct MsmBases {
     std::mutex mu;                 // one MSM at a time per handle (they share the work buffers)
     int c_forced = 0;              // gkrhip_msm_g1_set_window
     MsmWork w;
+    MsmFixedBase fb;               // gkrhip_msm_g1_precompute: when fb.tables exists, the handle's own MSMs take the fixed-base path
 };
 }  // namespace (the handle types are part of the C ABI)
 struct gkrhip_g1_bases : MsmBases {};
@@ -117,7 +135,7 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16, bool sum_only 
     w->chunk = chunk;
     w->nparts = (size_t)w->W * (w->nb / chunk);
     const size_t nbk = (size_t)w->W * w->nb;
-    if (nbk >= ((size_t)1 << 20)) return fail("msm: %zu buckets do not fit the 20-bit ids of the big-bucket list", nbk);
+    if (nbk > ((size_t)1 << MSM_LIST_ID_BITS)) return fail("msm: %zu buckets do not fit the %d-bit ids of the big-bucket list", nbk, MSM_LIST_ID_BITS);
     // segments of big buckets: a bucket is big above max(128, 4 n / nb) points, so there are at most W * min(n / 128, nb / 4) of
     // them, and cutting them into segments of `seg` points adds at most W * n / seg entries
     w->seg = 4096;
@@ -145,7 +163,7 @@ int msm_work_prepare(MsmWork* w, size_t n, int c_forced, int w16, bool sum_only 
     if (lowbits) {
         const size_t nbc = (size_t)w->W * (w->nb >> lowbits);      // coarse bins
         w->slice_len = 8192;
-        while ((size_t)w->slice_len * 4096 < n) w->slice_len <<= 1;           // at most 4096 slices per bin (12 bits of the list entry)
+        while ((size_t)w->slice_len * 2048 < n) w->slice_len <<= 1;           // at most 2048 slices per bin (11 bits of the list entry)
         w->slice_cap = (unsigned int)((size_t)w->W * n / w->slice_len + nbc + 16);
         w->ctiles = (unsigned int)((nbc + MSM_SCAN_TILE - 1) / MSM_SCAN_TILE);
         const size_t words = (3 + (size_t)w->nchunk) * nbc + w->ctiles + ((size_t)w->slice_cap + 2) + ((size_t)w->slice_cap << lowbits);
@@ -350,10 +368,131 @@ int msm_check_points(const uint64_t* points, size_t n, int w16) {
     return 0;
 }
 
+// ---- fixed-base path ---------------------------------------------------------------------------------------------------
+// (gkrhip_fb_sort_bytes / gkrhip_fb_sort: fb_sort.hip, declared in gkrhip.hip outside this namespace)
+// window size of the one bucket space: 13 n additions at c = 20, 12 n at c = 22 (against 16 n), the reduction over 2^(c-1) buckets once
+inline int msm_fb_pick_c(size_t n) { return n >= ((size_t)1 << 23) ? 22 : n >= ((size_t)1 << 17) ? 20 : 16; }
+// tables and buffers; the tables are computed here (one lane per point: c doublings and an inversion per table entry)
+template <class F>
+int msm_fb_prepare(MsmBases* b, int c_or_0) {
+    const size_t n = std::max<size_t>(b->n, 1);
+    const int c = c_or_0 > 0 ? c_or_0 : msm_fb_pick_c(n);
+    if (c < 8 || c > MSM_LIST_ID_BITS + 1) return fail("msm: fixed-base window size %d outside 8..%d", c, MSM_LIST_ID_BITS + 1);
+    MsmFixedBase& f = b->fb;
+    if (f.tables && f.c == c) return 0;
+    f.release();
+    struct Guard {
+        MsmFixedBase* f;
+        ~Guard() {
+            if (f) f->release();
+        }
+    } guard{&f};
+    f.c = c;
+    f.W = msm_windows(c);
+    f.nb = 1u << (c - 1);
+    const size_t V = (size_t)f.W * n;
+    if (V >= ((size_t)1 << 31)) return fail("msm: %d windows of %zu points do not fit 31-bit table indices", f.W, n);
+    HIPCHK(hipMalloc((void**)&f.tables, V * 32 * b->w16));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipMalloc((void**)&f.keys[k], V * sizeof(unsigned int)));
+        HIPCHK(hipMalloc((void**)&f.vals[k], V * sizeof(unsigned int)));
+    }
+    if (gkrhip_fb_sort_bytes(V, c, &f.sort_bytes) != 0) return fail("msm: rocPRIM refused the size query of the fixed-base sort");
+    HIPCHK(hipMalloc(&f.sort_tmp, std::max<size_t>(f.sort_bytes, 16)));
+    // the sums' buffers: W = 1 window of nb buckets
+    MsmWork& w = f.w;
+    w.c = c;
+    w.W = 1;
+    w.nb = f.nb;
+    w.w16 = b->w16;
+    w.n_cap = n;
+    w.chunk = (int)std::min<unsigned int>(8, w.nb);
+    w.nparts = w.nb / w.chunk;
+    w.seg = 4096;
+    while ((size_t)w.seg * 2048 < V) w.seg <<= 1;
+    w.big_cap = (unsigned int)(std::min<size_t>(V / 128, w.nb / 4) + V / w.seg + 16);
+    memset(w.bias, 0, sizeof w.bias);
+    for (int j = 0; j + 1 < f.W; j++) {
+        const int bit = j * c + c - 1;
+        w.bias[bit >> 5] |= 1u << (bit & 31);
+    }
+    HIPCHK(hipMalloc((void**)&w.counts, (size_t)3 * w.nb * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&w.big, ((size_t)w.big_cap + 2) * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&w.scalars, n * 32));
+    HIPCHK(hipMalloc((void**)&w.xyzz, (size_t)4 * b->w16 * ((size_t)w.nb + w.nparts + 1 + w.big_cap) * sizeof(uint4)));
+    HIPCHK(hipHostMalloc((void**)&w.h_wins, ((size_t)4 * b->w16 + 1) * sizeof(uint4)));
+    w.ready = true;
+    hipLaunchKernelGGL(k_msm_fb_precompute<F>, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream,
+                       (const uint4*)b->d_points, f.tables, b->n, c, f.W);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(cx().stream));
+    guard.f = nullptr;
+    return 0;
+}
+// the device part: digits -> radix sort -> run boundaries -> bucket sums -> the one window sum (lands in fb.w.h_wins)
+template <class F>
+int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi = nullptr) {
+    MsmFixedBase& f = b->fb;
+    MsmWork* w = &f.w;
+    hipStream_t st = cx().stream;
+    const size_t V = (size_t)f.W * n;
+    MsmArgs a;
+    memset(&a, 0, sizeof a);
+    a.scalars = d_scalars;
+    a.scalars_hi = d_scalars_hi;
+    a.n = n;
+    a.c = f.c;
+    a.W = f.W;
+    a.nb = f.nb;
+    a.scalars_mont = (flags & GKRHIP_MSM_SCALARS_MONT) ? 1 : 0;
+    a.count = w->counts;
+    a.offset = w->counts + w->nb;
+    a.order = w->counts + 2 * (size_t)w->nb;
+    memcpy(a.bias, w->bias, sizeof a.bias);
+    a.big = w->big;
+    a.big_threshold = (unsigned int)std::max<size_t>(128, 4 * (V / w->nb));
+    a.big_cap = w->big_cap;
+    a.seg = w->seg;
+    a.chunk = w->chunk;
+    a.err = a.big + a.big_cap + 1;
+    a.fb_keys = f.keys[0];
+    a.fb_vals = f.vals[0];
+    a.dstride = std::max<size_t>(b->n, 1);      // the tables' window stride (n <= b->n scalars: keys are packed [W][n], entries index [W][b->n])
+    if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
+    HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
+    HIPCHK(hipMemsetAsync(a.err, 0, sizeof(unsigned int), st));
+    HIPCHK(hipMemsetAsync(a.count, 0, (size_t)2 * w->nb * sizeof(unsigned int), st));
+    if (n) {
+        hipLaunchKernelGGL(k_msm_fb_digits, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
+        if (gkrhip_fb_sort(f.sort_tmp, f.sort_bytes, f.keys[0], f.keys[1], f.vals[0], f.vals[1], V, f.c, st) != 0)
+            return fail("msm: the fixed-base radix sort failed");
+        hipLaunchKernelGGL(k_msm_fb_bounds, dim3(grid_for(V, 8192)), dim3(GKR_BLOCK), 0, st, (const unsigned int*)f.keys[1], V, a);
+    }
+    hipLaunchKernelGGL(k_msm_fb_counts, dim3((w->nb + GKR_BLOCK - 1) / GKR_BLOCK), dim3(GKR_BLOCK), 0, st, a);
+    // from here on: ONE window of nb buckets over the table array
+    a.W = 1;
+    a.entries = f.vals[1];
+    a.acc_nb = std::min<unsigned int>(w->nb, 32768);      // the ordering and the bucket sums: ranges of 2^15 buckets, a workgroup orders one
+    a.acc_W = w->nb / a.acc_nb;
+    hipLaunchKernelGGL(k_msm_order, dim3(a.acc_W), dim3(MSM_SORT_THREADS), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return msm_sum_dev<F>(w, f.tables, a, tm);
+}
+
 template <class F, class HF>
 int msm_run(MsmBases* b, const uint64_t* scalars, size_t n, int flags, uint64_t* out_affine) {
     if (n > b->n) return fail("msm: %zu scalars for %zu bases", n, b->n);
     std::lock_guard<std::mutex> lk(b->mu);
+    if (b->fb.tables) {                   // fixed-base: the tables hold [2^(c j)] P_i for i < b->n, window-major with stride b->n
+        MsmWork* w = &b->fb.w;
+        if (n) HIPCHK(hipMemcpyAsync(w->scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
+        CHK(msm_fb_dev<F>(b, w->scalars, n, flags, nullptr));
+        HIPCHK(hipStreamSynchronize(cx().stream));
+        CHK(msm_check_error(w, "a scalar"));
+        const hfp::AffH<HF> r = msm_host_tail<HF>(w);
+        memcpy(out_affine, &r, sizeof r);
+        return 0;
+    }
     CHK(msm_work_prepare(&b->w, std::max<size_t>(b->n, 1), b->c_forced, F::W16));
     if (n) HIPCHK(hipMemcpyAsync(b->w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
     CHK(msm_dev<F>(b, b->w.scalars, n, flags, nullptr));
@@ -429,6 +568,7 @@ template <class B>
 void bases_free(B* b) {
     if (!b) return;
     b->w.release();
+    b->fb.release();
     if (b->d_points) (void)hipFree(b->d_points);
     delete b;
 }

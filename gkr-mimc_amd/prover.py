@@ -103,6 +103,10 @@ ABI = {
     "gkrhip_msm_g1": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_msm_g1_once": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_msm_g1_set_window": (_I, [_P, _I]),
+    "gkrhip_msm_g1_precompute": (_I, [_P, _I]),
+    "gkrhip_msm_g2_precompute": (_I, [_P, _I]),
+    "gkrhip_bench_msm_g1_fixed_base": (_I, [_I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), _P]),
+    "gkrhip_bench_msm_g2_fixed_base": (_I, [_I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), C.POINTER(_D), C.POINTER(_D), _P]),
     "gkrhip_g1_batch_scalar_mul": (_I, [_P, _P, _P, _SZ, _I]),
     "gkrhip_bench_msm_g1": (_I, [_I, _I, _I, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), C.POINTER(_D), _P]),
     "gkrhip_compute_h_msm_g1": (_I, [_P, _P, _P, _P, _P, _SZ, _SZ, _P]),
@@ -754,6 +758,11 @@ class _Bases:
     def set_window(self, c):
         _check(self._f("msm_%s_set_window")(self._h, int(c)))
 
+    def precompute(self, c=0):
+        """Fixed-base tables [2^(c j)] P_i (once per key); the handle's multi_exp then sorts all windows into one bucket space.
+        c = 0: by the number of points, 8..22 forced, -1 drops the tables."""
+        _check(self._f("msm_%s_precompute")(self._h, int(c)))
+
     def multi_exp(self, scalars, scalars_mont=False):
         """sum_i [scalars[i]] bases[i] as an affine image: (*G1Affine).MultiExp / (*G2Affine).MultiExp(points, scalars, config)."""
         scalars = _fr(scalars) if len(scalars) else np.zeros((0, 4), dtype=np.uint64)
@@ -869,6 +878,25 @@ def _bench_msm(group, words, logn, c, warmup, iters):
     _check(getattr(load(), "gkrhip_bench_msm_%s" % group)(logn, c, warmup, iters, C.byref(ms), ph, C.byref(cu), C.byref(tail), _ptr(res)))
     return {"ms": ms.value, "c": cu.value, "host_tail_ms": tail.value, "result": res,
             "phases_ms": dict(zip(("sort", "accumulate", "big_buckets", "reduce", "copy"), list(ph)))}
+
+
+def _bench_msm_fixed_base(group, words, logn, c, warmup, iters):
+    ms, tail, pre, cu = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+    ph = (C.c_double * 5)()
+    res = np.zeros(words, dtype=np.uint64)
+    _check(getattr(load(), "gkrhip_bench_msm_%s_fixed_base" % group)(logn, c, warmup, iters, C.byref(ms), ph, C.byref(cu), C.byref(tail),
+                                                                       C.byref(pre), _ptr(res)))
+    return {"ms": ms.value, "c": cu.value, "host_tail_ms": tail.value, "precompute_ms": pre.value, "result": res,
+            "phases_ms": dict(zip(("sort", "accumulate", "big_buckets", "reduce", "copy"), list(ph)))}
+
+
+def bench_msm_g1_fixed_base(logn, c=0, warmup=1, iters=3):
+    """The same MSM on fixed-base tables (gkrhip_msm_g1_precompute): + precompute_ms, the tables' one-time cost."""
+    return _bench_msm_fixed_base("g1", 8, logn, c, warmup, iters)
+
+
+def bench_msm_g2_fixed_base(logn, c=0, warmup=1, iters=3):
+    return _bench_msm_fixed_base("g2", 16, logn, c, warmup, iters)
 
 
 def bench_msm_g1(logn, c=0, warmup=1, iters=3):

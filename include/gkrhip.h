@@ -333,6 +333,14 @@ int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t *points, const uin
 /* window size of the bucket method for this handle: 0 = chosen from n (default), 2..16 forced (every choice gives the same
  * point; the parity tests sweep it) */
 int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
+/* Fixed-base tables (round 6).  The bases of the reference's MultiExp calls are proving-key vectors (pk.G1.A, pk.G1.B, pk.G1.Z,
+ * pk.G1.K, pk.G2.B: prove.go:76,91,189,202,221,277), the same for every proof: this computes [2^(c j)] P_i for every window j once
+ * (W = ceil(255 / c) times the handle's points in HBM; seconds for 2^24 points) and the handle's own MSMs -- gkrhip_msm_g1 /
+ * gkrhip_msm_g2 -- then sort every window into ONE bucket space of 2^(c-1) buckets: 12 or 13 additions per scalar instead of 16.
+ * Same sums (the tests hold both paths against the oracle).  c = 0: chosen from the number of points (22 from 2^23, 20 from 2^17),
+ * 8..22 forced, -1 drops the tables.  The calls that share a sort between handles (gkrhip_msm_g1_g2, gkrhip_msm_shared,
+ * gkrhip_compute_h_msm_g1) keep the per-window path. */
+int gkrhip_msm_g1_precompute(gkrhip_g1_bases *b, int c);
 /* bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out[i] = [scalars[i]] base as G1Affine */
 int gkrhip_g1_batch_scalar_mul(uint64_t *out /* n x 8 */, const uint64_t base[8], const uint64_t *scalars, size_t n, int flags);
 /* h = computeH(a, b, c, domain) (prove.go:128, 308-359) followed by krs2.MultiExp(pk.G1.Z, h, cfg) (prove.go:221) in one call with H
@@ -360,6 +368,7 @@ int gkrhip_msm_g1_g2(uint64_t out_g1[8], uint64_t out_g2[16], gkrhip_g1_bases *b
 int gkrhip_msm_shared(uint64_t *out_g1, uint64_t *out_g2, gkrhip_g1_bases *const *g1, size_t k1, gkrhip_g2_bases *const *g2, size_t k2,
                       const uint64_t *scalars /* n x 4 */, size_t n, int flags);
 int gkrhip_msm_g2_set_window(gkrhip_g2_bases *b, int c);
+int gkrhip_msm_g2_precompute(gkrhip_g2_bases *b, int c);      /* as gkrhip_msm_g1_precompute */
 int gkrhip_g2_batch_scalar_mul(uint64_t *out /* n x 16 */, const uint64_t base[16], const uint64_t *scalars, size_t n, int flags);
 int gkrhip_g2_generator(uint64_t out[16]);      /* gnark-crypto's g2Gen (bn254.Generators), Montgomery image */
 int gkrhip_bench_msm_g2(int logn, int c_or_0, int warmup, int iters, double *avg_ms, double phase_ms[5], int *c_used,
@@ -370,6 +379,13 @@ int gkrhip_bench_msm_g2(int logn, int c_or_0, int warmup, int iters, double *avg
  * affine sum of the last run (the caller checks it against gkrhip_msm_g1 on the same data read back). */
 int gkrhip_bench_msm_g1(int logn, int c_or_0, int warmup, int iters, double *avg_ms, double phase_ms[5], int *c_used,
                         double *host_tail_ms, uint64_t result_or_null[8]);
+
+/* The same on fixed-base tables (gkrhip_msm_g1_precompute with c_or_0): *precompute_ms = the tables' one-time cost (host clock),
+ * not part of *avg_ms; phase_ms[0] = digits, radix sort and run boundaries. */
+int gkrhip_bench_msm_g1_fixed_base(int logn, int c_or_0, int warmup, int iters, double *avg_ms, double phase_ms[5], int *c_used,
+                                   double *host_tail_ms, double *precompute_ms, uint64_t result_or_null[8]);
+int gkrhip_bench_msm_g2_fixed_base(int logn, int c_or_0, int warmup, int iters, double *avg_ms, double phase_ms[5], int *c_used,
+                                   double *host_tail_ms, double *precompute_ms, uint64_t result_or_null[16]);
 
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 /* Device-resident fold micro-benchmark (shape of BenchmarkFolding, poly/multilin_test.go:55-78):

@@ -461,6 +461,11 @@ func (b *G1Bases) Free() {
 
 func (b *G1Bases) Len() int { return int(C.gkrhip_g1_bases_len(b.h)) }
 
+// Precompute builds the fixed-base tables [2^(c j)] P_i of the handle once (a proving-key vector is the same for every proof):
+// MultiExp on the handle then sorts all windows into one bucket space -- 12 or 13 additions per scalar instead of 16.
+// c = 0: chosen from the number of points; -1 drops the tables.
+func (b *G1Bases) Precompute(c int) { must(C.gkrhip_msm_g1_precompute(b.h, C.int(c))) }
+
 // MultiExp writes sum_i [scalars[i]] bases[i] into out (a *bn254.G1Affine) for the first len(scalars) bases.
 func (b *G1Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont bool) {
 	flags := C.int(0)
@@ -506,6 +511,9 @@ func (b *G2Bases) Free() {
 }
 
 func (b *G2Bases) Len() int { return int(C.gkrhip_g2_bases_len(b.h)) }
+
+// Precompute: as (*G1Bases).Precompute.
+func (b *G2Bases) Precompute(c int) { must(C.gkrhip_msm_g2_precompute(b.h, C.int(c))) }
 
 // MultiExp writes sum_i [scalars[i]] bases[i] into out (a *bn254.G2Affine).
 func (b *G2Bases) MultiExp(out unsafe.Pointer, scalars []fr.Element, scalarsMont bool) {

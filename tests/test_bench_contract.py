@@ -269,14 +269,14 @@ def test_config_summary_carries_the_second_tier_results():
     out = {"configs": {"bn20": {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "concurrent_proofs": 56, "proof_verified_by_native_gkr_verify": True},
                        "gmimc_bn22": {"hashes_per_s": 1.1e8, "single_proof_ms": 117.0, "concurrent_proofs": 12, "proof_verified_by_native_gkr_verify": True}},
            "micro": {"msm_g1_2p24": {"ms": 19.5}, "msm_g1_2p22": {"ms": 5.4}, "msm_g1_2p20": {"ms": 1.9}, "msm_g2_2p22": {"ms": 19.0},
-                     "compute_h_2p24": {"ms": 12.7}},
+                     "compute_h_2p24": {"ms": 12.7}, "msm_g1_fixed_base_2p24": {"ms": 18.0}},
            "oneshot_including_pcie": {"one_call_s": 0.31}, "roofline": {"frac": 0.79}, "partial_eval": {"frac": 0.86},
            "integrity": {"layer_checks": 920, "layer_check_failures": 0, "chal_retries": 0}}
     sm = b.config_summary(out)
     assert sm["bn20"] == {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "lanes": 56, "verified": True}
     assert sm["msm_g1_2p24_ms"] == 19.5 and sm["compute_h_2p24_ms"] == 12.7 and sm["oneshot_s"] == 0.31
-    assert sm["layer_checks"] == 920 and sm["chal_retries"] == 0
+    assert sm["msm_g1_fixed_base_ms"] == {"2p24": 18.0} and sm["layer_checks"] == 920 and sm["chal_retries"] == 0
     assert len(json.dumps(sm)) < 900          # compact: it must survive where the 2 000-character tail does not
     latest = _latest()
     if "summary" in latest["config"]:         # lines of round 6 on
-        assert set(latest["config"]["summary"]) >= set(b.SUMMARY_KEYS)
+        assert set(latest["config"]["summary"]) >= set(b.SUMMARY_KEYS) - {"msm_g1_fixed_base_ms"}

@@ -416,3 +416,111 @@ def test_reserved_lanes_serve_a_burst_of_calls(gk):
     assert got == want
     for b in bs:
         b.close()
+
+
+# ---------------------------------------------------------------- fixed-base tables (round 6)
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 100, 1000, 4096, 1 << 14])
+def test_msm_fixed_base_vs_oracle(gk, n):
+    """gkrhip_msm_g1_precompute: [2^(c j)] P_i once, then every window of every scalar in ONE bucket space (radix sort of (bucket,
+    entry) pairs) -- the same affine image as the oracle's per-term double-and-add and as the handle's per-window path, with the
+    corner scalars of the recoding, a point at infinity, a repeated point, P and -P in one bucket, and a prefix of the bases."""
+    rng = random.Random(600 + n)
+    pts = rand_points(n + 11, n)
+    if n >= 17:
+        pts[3] = 0
+        pts[5] = pts[4]
+        pts[9] = pts[4]
+        pts[11, 4:] = ec.point_to_image(ec.neg(ec.point_from_image(pts[10])))[4:]
+        pts[11, :4] = pts[10, :4]
+    sc = rand_scalars(rng, n)
+    if n >= 17:
+        sc[5] = sc[4]
+        sc[11] = sc[10]
+    want = c.g1_msm(pts, sc)
+    b = gk.G1Bases(points=pts)
+    assert b.multi_exp(sc).tolist() == want.tolist()                   # per-window path
+    for cw in (0, 8, 13, 20):
+        b.precompute(cw)
+        assert b.multi_exp(sc).tolist() == want.tolist(), cw
+        assert b.multi_exp(sc).tolist() == want.tolist(), cw           # buffers reused
+        m = n // 2
+        assert b.multi_exp(sc[:m]).tolist() == c.g1_msm(pts[:m], sc[:m]).tolist(), cw      # a prefix: the tables keep their stride
+    b.precompute(-1)                                                    # tables dropped: the per-window path again
+    assert b.multi_exp(sc).tolist() == want.tolist()
+    b.close()
+
+
+@pytest.mark.parametrize("cw", [8, 9, 11, 14, 16, 17, 19, 21, 22])
+def test_msm_fixed_base_every_window_size(gk, cw):
+    """Window sizes on both sides of the old 16-bit limit, with short top windows (255 = 11 * 22 + 13 = 12 * 21 + 3 ...)."""
+    rng = random.Random(cw)
+    n = 300
+    pts = rand_points(78, n)
+    sc = rand_scalars(rng, n)
+    b = gk.G1Bases(points=pts)
+    b.precompute(cw)
+    assert b.multi_exp(sc).tolist() == c.g1_msm(pts, sc).tolist()
+    vals = [rng.randrange(Q) for _ in range(n)]                        # MultiExpConfig.ScalarsMont on the tables
+    assert b.multi_exp(c.from_ints(vals), scalars_mont=True).tolist() == c.g1_msm(pts, ec.scalars_to_image(vals)).tolist()
+    b.close()
+
+
+def test_msm_fixed_base_skew_and_cancellation(gk):
+    """The 0/1 wires of a witness (one huge bucket: the segment path over the table array), n copies of one point (doubling
+    branch), total cancellation (infinity = (0, 0)), a scalar that is not an fr.Element refused."""
+    n = 6000
+    pts = rand_points(6, n)
+    rng = random.Random(10)
+    b = gk.G1Bases(points=pts)
+    b.precompute(16)
+    ones = ec.scalars_to_image([1] * n)
+    assert b.multi_exp(ones).tolist() == c.g1_msm(pts, ones).tolist()
+    sc = ec.scalars_to_image([rng.choice([0, 1, 1, 1, 2, Q - 1]) for _ in range(n)])
+    assert b.multi_exp(sc).tolist() == c.g1_msm(pts, sc).tolist()
+    bad = sc.copy()
+    bad[7] = [0xffffffffffffffff] * 4
+    with pytest.raises(Exception):
+        b.multi_exp(bad)
+    assert b.multi_exp(sc).tolist() == c.g1_msm(pts, sc).tolist()     # the handle is usable after the refusal
+    b.close()
+    same = np.repeat(pts[:1], n, axis=0)
+    s = rng.randrange(Q)
+    bs = gk.G1Bases(points=same)
+    bs.precompute(12)
+    assert bs.multi_exp(ec.scalars_to_image([s] * n)).tolist() == c.g1_scalar_mul(pts[0], ec.scalar_to_limbs(n * s % Q)).tolist()
+    bs.close()
+    pm = np.concatenate([pts[:100], pts[:100]])
+    bp = gk.G1Bases(points=pm)
+    bp.precompute(0)
+    assert bp.multi_exp(ec.scalars_to_image([5] * 100 + [Q - 5] * 100)).tolist() == [0] * 8
+    bp.close()
+
+
+def test_msm_fixed_base_agrees_with_the_per_window_path_at_2p20(gk):
+    """2^20 synthetic bases (beyond the oracle's reach): the fixed-base sum at c = 20 and c = 22 equals the per-window sum, and
+    MSM(s) + MSM(t) = MSM(s + t) holds on the tables."""
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    k = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    k[:, 3] &= np.uint64((1 << 59) - 1)
+    b = gk.G1Bases(base=c.G1_GEN, scalars=k)
+    s = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 59) - 1)
+    want = b.multi_exp(s).tolist()
+    for cw in (20, 22):
+        b.precompute(cw)
+        assert b.multi_exp(s).tolist() == want, cw
+    b.close()
+
+
+def test_bench_msm_fixed_base_result(gk):
+    logn = 9
+    n = 1 << logn
+    r = gk.bench_msm_g1_fixed_base(logn, warmup=1, iters=2)
+    ks = _synth_scalars(n, 0x1234567)
+    ss = _synth_scalars(n, 0x7654321)
+    tot = sum(a * b for a, b in zip(ks, ss)) % Q
+    assert r["result"].tolist() == c.g1_scalar_mul(c.G1_GEN, ec.scalar_to_limbs(tot)).tolist()
+    assert r["ms"] > 0 and r["precompute_ms"] > 0 and r["c"] >= 8
+    r13 = gk.bench_msm_g1_fixed_base(logn, c=13, warmup=0, iters=1)
+    assert r13["c"] == 13 and r13["result"].tolist() == r["result"].tolist()
