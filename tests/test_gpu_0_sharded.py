@@ -257,7 +257,8 @@ def test_bench_captures_rccl_warnings_of_a_failed_pass(tmp_path):
             continue
     assert line is not None, out.stdout[-1500:] + out.stderr[-3000:]
     p = line["passes"]["rccl_one_lane"]
-    assert "error" in p and out.returncode == 3, (p, out.returncode)          # one GPU cannot host two ranks of a communicator
+    # one GPU cannot host two ranks of a communicator: bench.py's rank 0 exits with code 3, which the launcher reports as a failure
+    assert "error" in p and out.returncode != 0, (p, out.returncode)
     assert line.get("degraded") == "all_passes_failed" and line["n_gpus_rccl"] == 0
     log = p.get("rccl_log", "")
     assert "NCCL WARN" in log, "no RCCL warning captured:\n%s\n--- stderr\n%s" % (json.dumps(p)[:1500], out.stderr[-3000:])
