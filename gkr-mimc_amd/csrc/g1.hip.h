@@ -856,7 +856,9 @@ __global__ void __launch_bounds__(GKR_BLOCK, MsmTune<F>::ACC_MINBLOCKS) k_msm_ac
     // top digit few values (q >> 240 = 12 388 of the 32 768 buckets at c = 16), so its buckets hold 2.6 times the points of the
     // others -- launched last they were the kernel's tail (2^24 points: 26.9 ms, against 22 ms for 16 windows at the rate of
     // the first 14).
-    const size_t jw = (aW - 1) - lane / anb;
+    // (fixed-base: the heavy buckets are the LOW ones -- a short top window puts all its entries below 2^(bits of that window) -- so
+    // the ranges go in ascending order there, for the same reason: 2^24 points at c = 20, 33.1 ms with the heavy range last)
+    const size_t jw = a.acc_W ? lane / anb : (aW - 1) - lane / anb;
     const size_t t = jw * anb + a.order[jw * anb + lane % anb];
     const unsigned int cnt = a.count[t], start = a.offset[t];
     XyzzT<F> acc;

@@ -66,6 +66,12 @@ def test_msm_g2_vs_oracle(gk, n):
         assert len(b) == n and b.multi_exp(sc).tolist() == want.tolist()
         m = n // 2
         assert b.multi_exp(sc[:m]).tolist() == ec.g2_point_to_image(ec.g2_msm(pts[:m], ints(sc[:m]))).tolist()
+        for cw in (9, 16, 22):              # fixed-base tables over Fp2 (gkrhip_msm_g2_precompute): the same image
+            b.precompute(cw)
+            assert b.multi_exp(sc).tolist() == want.tolist(), cw
+            assert b.multi_exp(sc[:m]).tolist() == ec.g2_point_to_image(ec.g2_msm(pts[:m], ints(sc[:m]))).tolist(), cw
+        b.precompute(-1)
+        assert b.multi_exp(sc).tolist() == want.tolist()
         b.close()
 
 
