@@ -799,8 +799,12 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_digits(MsmArgs a) {
         const u32 b = msm_digit(a, dp, j, &neg);
         if (b == MSM_DIGIT_BAD) bad = true;
         const size_t v = (size_t)j * a.n + i;
-        a.fb_keys[v] = b < MSM_DIGIT_BAD ? b : a.nb;
-        a.fb_vals[v] = (u32)((size_t)j * a.dstride + i) | (neg ? 0x80000000u : 0u);      // dstride: the tables' window stride
+        if (a.fb_vals) {      // the library radix sort's (key, value) pairs
+            a.fb_keys[v] = b < MSM_DIGIT_BAD ? b : a.nb;
+            a.fb_vals[v] = (u32)((size_t)j * a.dstride + i) | (neg ? 0x80000000u : 0u);      // dstride: the tables' window stride
+        } else {              // the three-level counting sort's digit planes: bucket | sign << 31, or none
+            a.fb_keys[v] = b < MSM_DIGIT_BAD ? (b | (neg ? 0x80000000u : 0u)) : 0xffffffffu;
+        }
     }
     if (bad) *a.err = 1u;
 }
@@ -823,6 +827,266 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_counts(MsmArgs a) {
         const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
         const unsigned int k0 = atomicAdd(&a.big[0], nseg);
         for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
+    }
+}
+
+// ---- the fixed-base MSM's own sort: three levels of the LDS counting sort above ---------------------------------------------
+// (bucket, entry) pairs of ONE bucket space of 2^kb buckets (kb = c - 1 <= 21) and W * n <= 2^31 entries: bucket bits
+// bits1 | bits2 | bits3 (<= 10 | 7 | 7).  Level 1 reads the digit planes (window j, chunk k per workgroup, as the coarse pass
+// above) and files an entry under the top bits1 bits; levels 2 and 3 are one kernel triple -- count per slice, offsets per
+// output bin, staged scatter per slice -- run twice, each resolving up to seven more bits inside bins that fit the L2.  Every
+// level writes the 32-bit entry (table index | sign << 31) and, beside it, the bucket bits still to be resolved (16 bits):
+// 44 bytes of traffic per entry in all, no atomic outside LDS.  (The library radix sort this replaced: 5.4 ms of a 23.8 ms MSM
+// at 2^24 points; profiles/r06_msm_fixed_base_v1.txt.)
+struct FbSortArgs {
+    // level 1
+    const unsigned int* raw;      // [W][n] bucket | sign << 31, 0xffffffff: none (k_msm_fb_digits)
+    size_t n, tstride;            // scalars; the tables' window stride
+    int W;
+    unsigned int nchunk;
+    size_t chunk_len;             // a multiple of eight
+    int sh1;                      // bin = bucket >> sh1
+    unsigned int nb1;             // 2^bits1 <= 1024
+    unsigned int* chist;          // [W * nchunk][nb1] counts, then write positions
+    // levels 2 and 3: output bin = input bin << bits | ((key >> sh) & (2^bits - 1))
+    const unsigned int* e_in;
+    const unsigned short* k_in;
+    unsigned int* e_out;
+    unsigned short* k_out;        // nullptr at the last level
+    int sh, bits;
+    unsigned int nbins_in;
+    const unsigned int *in_count, *in_offset, *in_first;      // per input bin (in_first: its first slice-list entry)
+    const unsigned int* slices;   // [0] = number of slices, [1 + k] = bin | slice << MSM_LIST_ID_BITS
+    unsigned int slice_cap, slice_len;
+    unsigned int* slice_hist;     // [slice][2^bits] counts, then write positions
+    // what a level leaves for the next one (level 1 and 2: the next slice list; level 3: bucket sizes and the big-bucket list)
+    unsigned int *out_count, *out_offset, *out_first;
+    unsigned int* next_list;
+    unsigned int next_cap, next_seg, next_threshold;
+    unsigned int* err;
+};
+template <int T>
+struct FbStage {
+    u32 se[8 * T];
+    unsigned short sk[8 * T], sbin[8 * T];
+    unsigned int cursor[T], lcnt[T], lstart[T], wsum[T / 64], total;
+};
+template <int T>
+__device__ __forceinline__ unsigned int fb_stage_scan(FbStage<T>& sh, unsigned int v) {
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) sh.wsum[wave] = x;
+    __syncthreads();
+    unsigned int base = 0;
+    for (unsigned int w = 0; w < wave; w++) base += sh.wsum[w];
+    return base + x - v;
+}
+// one batch (as msm_stage_batch, with the residual key beside the entry); out_k may be null
+template <int T>
+__device__ __forceinline__ void fb_stage_batch(FbStage<T>& sh, unsigned int nbins, const u32 (&e)[8], const u32 (&k)[8], const u32 (&bin)[8],
+                                               unsigned int* out_e, unsigned short* out_k) {
+    unsigned int rank[8];
+    for (unsigned int b = threadIdx.x; b < nbins; b += T) sh.lcnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if (bin[r] != 0xffffffffu) rank[r] = msm_wave_counter_add(sh.lcnt, bin[r]);
+    __syncthreads();
+    const unsigned int mine = threadIdx.x < nbins ? sh.lcnt[threadIdx.x] : 0u;      // nbins <= T
+    const unsigned int start = fb_stage_scan(sh, mine);
+    if (threadIdx.x < nbins) {
+        sh.lstart[threadIdx.x] = start;
+        sh.lcnt[threadIdx.x] = sh.cursor[threadIdx.x] - start;
+        sh.cursor[threadIdx.x] += mine;
+        if (threadIdx.x == nbins - 1) sh.total = start + mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if (bin[r] != 0xffffffffu) {
+            const unsigned int p = sh.lstart[bin[r]] + rank[r];
+            sh.se[p] = e[r];
+            sh.sk[p] = (unsigned short)k[r];
+            sh.sbin[p] = (unsigned short)bin[r];
+        }
+    __syncthreads();
+    const unsigned int total = sh.total;
+    for (unsigned int p = threadIdx.x; p < total; p += T) {
+        const unsigned int o = sh.lcnt[sh.sbin[p]] + p;
+        out_e[o] = sh.se[p];
+        if (out_k) out_k[o] = sh.sk[p];
+    }
+    __syncthreads();
+}
+// level 1: counts of window j, chunk k per top-bits bin
+GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_fb_l1_hist(FbSortArgs a) {
+    __shared__ unsigned int hist[1024];
+    const unsigned int j = blockIdx.x, k = blockIdx.y;
+    for (unsigned int b = threadIdx.x; b < a.nb1; b += MSM_SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
+    const unsigned int* raw = a.raw + (size_t)j * a.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_THREADS) {
+        const unsigned int r = raw[i];
+        if (r != 0xffffffffu) (void)msm_wave_counter_add(hist, (r & 0x7fffffffu) >> a.sh1);
+    }
+    __syncthreads();
+    unsigned int* out = a.chist + ((size_t)j * a.nchunk + k) * a.nb1;
+    for (unsigned int b = threadIdx.x; b < a.nb1; b += MSM_SORT_THREADS) out[b] = hist[b];
+}
+// level 1: bin sizes, their exclusive scan, every workgroup's write positions, the slice list of level 2 (one workgroup)
+GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_fb_l1_offsets(FbSortArgs a) {
+    __shared__ unsigned int sh[MSM_SCAN_THREADS];
+    const unsigned int b = threadIdx.x, nw = (unsigned int)a.W * a.nchunk;
+    unsigned int cnt = 0;
+    if (b < a.nb1)
+        for (unsigned int kk = 0; kk < nw; kk++) cnt += a.chist[(size_t)kk * a.nb1 + b];
+    const unsigned int off = msm_block_scan(sh, cnt) - cnt;
+    if (b >= a.nb1) return;
+    a.out_count[b] = cnt;
+    a.out_offset[b] = off;
+    unsigned int run = off;
+    for (unsigned int kk = 0; kk < nw; kk++) {
+        unsigned int* p = &a.chist[(size_t)kk * a.nb1 + b];
+        const unsigned int x = *p;
+        *p = run;
+        run += x;
+    }
+    const unsigned int nsl = (cnt + a.next_seg - 1) / a.next_seg;
+    const unsigned int k0 = nsl ? atomicAdd(&a.next_list[0], nsl) : 0u;
+    for (unsigned int sg = 0; sg < nsl && k0 + sg < a.next_cap; sg++) a.next_list[1 + k0 + sg] = b | (sg << MSM_LIST_ID_BITS);
+    a.out_first[b] = k0;
+}
+// level 1: the chunk again, staged scatter: entry = table index | sign << 31, key = the bucket bits below the bin's
+#define FB_L1_SCATTER_THREADS 512      // (its staging area with the keys beside the entries: 38 KB; at most 512 bins -- level 1 has <= 128)
+GKR_KERNEL void __launch_bounds__(FB_L1_SCATTER_THREADS) k_fb_l1_scatter(FbSortArgs a) {
+    __shared__ FbStage<FB_L1_SCATTER_THREADS> sh;
+    const unsigned int j = blockIdx.x, k = blockIdx.y;
+    const unsigned int* in = a.chist + ((size_t)j * a.nchunk + k) * a.nb1;
+    if (threadIdx.x < a.nb1) sh.cursor[threadIdx.x] = in[threadIdx.x];
+    __syncthreads();
+    const size_t lo = (size_t)k * a.chunk_len, hi = min(a.n, lo + a.chunk_len);
+    const unsigned int* raw = a.raw + (size_t)j * a.n;
+    const u32 kmask = (1u << a.sh1) - 1u;
+    for (size_t i0 = lo; i0 < hi; i0 += 8 * FB_L1_SCATTER_THREADS) {
+        u32 e[8], kk[8], bin[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {      // (lane-strided: consecutive lanes read consecutive words)
+            const size_t i = i0 + (size_t)r * FB_L1_SCATTER_THREADS + threadIdx.x;
+            bin[r] = 0xffffffffu;
+            e[r] = kk[r] = 0;
+            if (i < hi) {
+                const unsigned int x = raw[i];
+                if (x != 0xffffffffu) {
+                    const u32 b = x & 0x7fffffffu;
+                    bin[r] = b >> a.sh1;
+                    kk[r] = b & kmask;
+                    e[r] = (u32)((size_t)j * a.tstride + i) | (x & 0x80000000u);
+                }
+            }
+        }
+        fb_stage_batch(sh, a.nb1, e, kk, bin, a.e_out, a.k_out);
+    }
+}
+// levels 2 and 3
+__device__ __forceinline__ bool fb_slice_range(const FbSortArgs& a, unsigned int* bin, unsigned int* lo, unsigned int* hi) {
+    if (blockIdx.x >= min(a.slices[0], a.slice_cap)) return false;
+    const unsigned int e = a.slices[1 + blockIdx.x];
+    *bin = e & MSM_LIST_ID_MASK;
+    const unsigned int base = a.in_offset[*bin], cnt = a.in_count[*bin], s0 = (e >> MSM_LIST_ID_BITS) * a.slice_len;
+    *lo = base + s0;
+    *hi = base + min(cnt, s0 + a.slice_len);
+    return true;
+}
+GKR_KERNEL void __launch_bounds__(MSM_REFINE_THREADS) k_fb_lv_count(FbSortArgs a) {
+    __shared__ unsigned int hist[MSM_REFINE_MAXLOW];
+    unsigned int bin, lo, hi;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.slices[0] > a.slice_cap) *a.err = 2u;      // cannot happen by the list's sizing
+    if (!fb_slice_range(a, &bin, &lo, &hi)) return;
+    const unsigned int nlow = 1u << a.bits;
+    if (threadIdx.x < nlow) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned int i0 = lo; i0 < hi; i0 += 4 * MSM_REFINE_THREADS) {
+        u32 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned int i = i0 + (unsigned int)r * MSM_REFINE_THREADS + threadIdx.x;
+            x[r] = i < hi ? a.k_in[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (i0 + (unsigned int)r * MSM_REFINE_THREADS + threadIdx.x < hi) (void)msm_wave_counter_add(hist, (x[r] >> a.sh) & (nlow - 1u));
+    }
+    __syncthreads();
+    if (threadIdx.x < nlow) a.slice_hist[(size_t)blockIdx.x * nlow + threadIdx.x] = hist[threadIdx.x];
+}
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_fb_lv_offsets(FbSortArgs a) {
+    __shared__ unsigned int sh[GKR_BLOCK];
+    const size_t t = (size_t)blockIdx.x * GKR_BLOCK + threadIdx.x;       // nbins_out is a multiple of the block or smaller than it
+    const size_t total = (size_t)a.nbins_in << a.bits;
+    const unsigned int nlow = 1u << a.bits, low = (unsigned int)t & (nlow - 1u);
+    const size_t bin = t >> a.bits;
+    unsigned int cnt = 0, nsl = 0, k0 = 0;
+    if (t < total) {
+        const unsigned int cb = a.in_count[bin];
+        nsl = (cb + a.slice_len - 1) / a.slice_len;
+        k0 = nsl ? a.in_first[bin] : 0u;
+        for (unsigned int s = 0; s < nsl; s++) cnt += a.slice_hist[(size_t)(k0 + s) * nlow + low];
+    }
+    sh[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int d = 1; d < GKR_BLOCK; d <<= 1) {
+        const unsigned int x = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    if (t >= total) return;
+    const unsigned int g0 = threadIdx.x & ~(nlow - 1u);                  // first lane of this input bin in the block
+    unsigned int run = a.in_offset[bin] + sh[threadIdx.x] - cnt - (g0 ? sh[g0 - 1] : 0u);
+    a.out_count[t] = cnt;
+    a.out_offset[t] = run;
+    if (cnt > a.next_threshold) {
+        const unsigned int nseg = (cnt + a.next_seg - 1) / a.next_seg;
+        const unsigned int b0 = atomicAdd(&a.next_list[0], nseg);
+        for (unsigned int sg = 0; sg < nseg && b0 + sg < a.next_cap; sg++) a.next_list[1 + b0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
+        if (a.out_first) a.out_first[t] = b0;
+    }
+    for (unsigned int s = 0; s < nsl; s++) {
+        unsigned int* p = &a.slice_hist[(size_t)(k0 + s) * nlow + low];
+        const unsigned int x = *p;
+        *p = run;
+        run += x;
+    }
+}
+GKR_KERNEL void __launch_bounds__(MSM_REFINE_THREADS) k_fb_lv_scatter(FbSortArgs a) {
+    __shared__ FbStage<MSM_REFINE_THREADS> sh;
+    unsigned int bin, lo, hi;
+    if (!fb_slice_range(a, &bin, &lo, &hi)) return;
+    const unsigned int nlow = 1u << a.bits;
+    if (threadIdx.x < nlow) sh.cursor[threadIdx.x] = a.slice_hist[(size_t)blockIdx.x * nlow + threadIdx.x];
+    __syncthreads();
+    const u32 kmask = (1u << a.sh) - 1u;
+    for (unsigned int i0 = lo; i0 < hi; i0 += 8 * MSM_REFINE_THREADS) {
+        u32 e[8], kk[8], low[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned int i = i0 + (unsigned int)r * MSM_REFINE_THREADS + threadIdx.x;
+            low[r] = 0xffffffffu;
+            e[r] = kk[r] = 0;
+            if (i < hi) {
+                const u32 key = a.k_in[i];
+                low[r] = (key >> a.sh) & (nlow - 1u);
+                kk[r] = key & kmask;
+                e[r] = a.e_in[i];
+            }
+        }
+        fb_stage_batch(sh, nlow, e, kk, low, a.e_out, a.k_out);
     }
 }
 

@@ -447,6 +447,10 @@ int gkrhip_set_option(const char* key, long value) {
         g_wait_override.store((int)std::max(-2L, value));
         return 0;
     }
+    if (!strcmp(key, "msm_fb_sort")) {          // host_msm.hip.h: the fixed-base MSM's sort, 0 the library's own (default), 1 rocPRIM's radix sort; applies to tables made afterwards
+        g_msm_fb_sort.store(value == 1 ? 1 : 0);
+        return 0;
+    }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
         g_msm_sort_levels.store((int)value);
         return 0;

@@ -72,9 +72,16 @@ struct MsmFixedBase {
     unsigned int* vals[2] = {nullptr, nullptr};      // [W * n] (table index | sign << 31) before / after: the second is the entry list
     void* sort_tmp = nullptr;
     size_t sort_bytes = 0;
+    // the library's own three-level counting sort (g1.hip.h: FbSortArgs): residual keys of levels 1 and 2, the levels' bookkeeping
+    unsigned short* k16[2] = {nullptr, nullptr};
+    unsigned int* lv = nullptr;
+    int bits1 = 0, bits2 = 0, bits3 = 0;
+    unsigned int nchunk = 0, slice_len = 0, cap1 = 0, cap2 = 0;
+    size_t chunk_len = 0;
+    bool lib_sort = false;               // option msm_fb_sort = 1: rocPRIM's radix sort instead (A/B, tests)
     MsmWork w;                           // counts, big list, scalars, bucket planes, pinned window sum: geometry (c, W = 1, nb)
     void release() {
-        for (void* p : {(void*)tables, (void*)keys[0], (void*)keys[1], (void*)vals[0], (void*)vals[1], sort_tmp})
+        for (void* p : {(void*)tables, (void*)keys[0], (void*)keys[1], (void*)vals[0], (void*)vals[1], sort_tmp, (void*)k16[0], (void*)k16[1], (void*)lv})
             if (p) (void)hipFree(p);
         w.release();
         *this = MsmFixedBase();
@@ -371,6 +378,7 @@ int msm_check_points(const uint64_t* points, size_t n, int w16) {
 // ---- fixed-base path ---------------------------------------------------------------------------------------------------
 // (gkrhip_fb_sort_bytes / gkrhip_fb_sort: fb_sort.hip, declared in gkrhip.hip outside this namespace)
 // window size of the one bucket space: 13 n additions at c = 20, 12 n at c = 22 (against 16 n), the reduction over 2^(c-1) buckets once
+std::atomic<int> g_msm_fb_sort{0};      // gkrhip_set_option("msm_fb_sort", 0 | 1): 0 the three-level counting sort, 1 rocPRIM's radix sort
 inline int msm_fb_pick_c(size_t n) { return n >= ((size_t)1 << 23) ? 22 : n >= ((size_t)1 << 17) ? 20 : 16; }
 // tables and buffers; the tables are computed here (one lane per point: c doublings and an inversion per table entry)
 template <class F>
@@ -379,7 +387,8 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     const int c = c_or_0 > 0 ? c_or_0 : msm_fb_pick_c(n);
     if (c < 8 || c > MSM_LIST_ID_BITS + 1) return fail("msm: fixed-base window size %d outside 8..%d", c, MSM_LIST_ID_BITS + 1);
     MsmFixedBase& f = b->fb;
-    if (f.tables && f.c == c) return 0;
+    const bool lib_sort = g_msm_fb_sort.load() == 1;
+    if (f.tables && f.c == c && f.lib_sort == lib_sort) return 0;
     f.release();
     struct Guard {
         MsmFixedBase* f;
@@ -393,12 +402,30 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     const size_t V = (size_t)f.W * n;
     if (V >= ((size_t)1 << 31)) return fail("msm: %d windows of %zu points do not fit 31-bit table indices", f.W, n);
     HIPCHK(hipMalloc((void**)&f.tables, V * 32 * b->w16));
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(hipMalloc((void**)&f.keys[k], V * sizeof(unsigned int)));
-        HIPCHK(hipMalloc((void**)&f.vals[k], V * sizeof(unsigned int)));
+    f.lib_sort = lib_sort;
+    HIPCHK(hipMalloc((void**)&f.keys[0], V * sizeof(unsigned int)));
+    for (int k = 0; k < 2; k++) HIPCHK(hipMalloc((void**)&f.vals[k], V * sizeof(unsigned int)));
+    if (lib_sort) {
+        HIPCHK(hipMalloc((void**)&f.keys[1], V * sizeof(unsigned int)));
+        if (gkrhip_fb_sort_bytes(V, c, &f.sort_bytes) != 0) return fail("msm: rocPRIM refused the size query of the fixed-base sort");
+        HIPCHK(hipMalloc(&f.sort_tmp, std::max<size_t>(f.sort_bytes, 16)));
+    } else {
+        const int kb = c - 1;
+        f.bits3 = std::min(7, kb);
+        f.bits2 = std::min(7, kb - f.bits3);
+        f.bits1 = kb - f.bits3 - f.bits2;                        // <= 7 (c <= 22)
+        f.nchunk = (unsigned int)std::min<size_t>(128, std::max<size_t>(1, n / 131072));
+        f.chunk_len = ((n + f.nchunk - 1) / f.nchunk + 7) & ~(size_t)7;
+        f.slice_len = 8192;
+        while ((size_t)f.slice_len * 2048 < V) f.slice_len <<= 1;      // at most 2048 slices per bin (11 bits of the list entry)
+        const size_t nb1 = (size_t)1 << f.bits1, nb2 = nb1 << f.bits2;
+        f.cap1 = (unsigned int)(V / f.slice_len + nb1 + 16);
+        f.cap2 = (unsigned int)(V / f.slice_len + nb2 + 16);
+        const size_t words = (size_t)f.W * f.nchunk * nb1 + 3 * nb1 + (f.cap1 + 2) + ((size_t)f.cap1 << f.bits2) + 3 * nb2 + (f.cap2 + 2) +
+                             ((size_t)f.cap2 << f.bits3);
+        HIPCHK(hipMalloc((void**)&f.lv, words * sizeof(unsigned int)));
+        for (int k = 0; k < 2; k++) HIPCHK(hipMalloc((void**)&f.k16[k], V * sizeof(unsigned short)));
     }
-    if (gkrhip_fb_sort_bytes(V, c, &f.sort_bytes) != 0) return fail("msm: rocPRIM refused the size query of the fixed-base sort");
-    HIPCHK(hipMalloc(&f.sort_tmp, std::max<size_t>(f.sort_bytes, 16)));
     // the sums' buffers: W = 1 window of nb buckets
     MsmWork& w = f.w;
     w.c = c;
@@ -456,22 +483,120 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
     a.chunk = w->chunk;
     a.err = a.big + a.big_cap + 1;
     a.fb_keys = f.keys[0];
-    a.fb_vals = f.vals[0];
+    a.fb_vals = f.lib_sort ? f.vals[0] : nullptr;      // (null: k_msm_fb_digits writes the digit planes of the library's own sort)
     a.dstride = std::max<size_t>(b->n, 1);      // the tables' window stride (n <= b->n scalars: keys are packed [W][n], entries index [W][b->n])
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
     HIPCHK(hipMemsetAsync(a.err, 0, sizeof(unsigned int), st));
-    HIPCHK(hipMemsetAsync(a.count, 0, (size_t)2 * w->nb * sizeof(unsigned int), st));
-    if (n) {
-        hipLaunchKernelGGL(k_msm_fb_digits, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
-        if (gkrhip_fb_sort(f.sort_tmp, f.sort_bytes, f.keys[0], f.keys[1], f.vals[0], f.vals[1], V, f.c, st) != 0)
-            return fail("msm: the fixed-base radix sort failed");
-        hipLaunchKernelGGL(k_msm_fb_bounds, dim3(grid_for(V, 8192)), dim3(GKR_BLOCK), 0, st, (const unsigned int*)f.keys[1], V, a);
+    if (n) hipLaunchKernelGGL(k_msm_fb_digits, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
+    if (f.lib_sort) {
+        HIPCHK(hipMemsetAsync(a.count, 0, (size_t)2 * w->nb * sizeof(unsigned int), st));
+        if (n) {
+            if (gkrhip_fb_sort(f.sort_tmp, f.sort_bytes, f.keys[0], f.keys[1], f.vals[0], f.vals[1], V, f.c, st) != 0)
+                return fail("msm: the fixed-base radix sort failed");
+            hipLaunchKernelGGL(k_msm_fb_bounds, dim3(grid_for(V, 8192)), dim3(GKR_BLOCK), 0, st, (const unsigned int*)f.keys[1], V, a);
+        }
+        hipLaunchKernelGGL(k_msm_fb_counts, dim3((w->nb + GKR_BLOCK - 1) / GKR_BLOCK), dim3(GKR_BLOCK), 0, st, a);
+        a.entries = f.vals[1];
+    } else {
+        // three levels of the LDS counting sort: (vals[0], k16[0]) <- level 1, (vals[1], k16[1]) <- level 2, vals[0] <- level 3
+        const size_t nb1 = (size_t)1 << f.bits1, nb2 = nb1 << f.bits2;
+        unsigned int* p = f.lv;
+        unsigned int* chist = p;             p += (size_t)f.W * f.nchunk * nb1;
+        unsigned int* cnt1 = p;              p += nb1;
+        unsigned int* off1 = p;              p += nb1;
+        unsigned int* first1 = p;            p += nb1;
+        unsigned int* slices1 = p;           p += f.cap1 + 2;
+        unsigned int* hist1 = p;             p += (size_t)f.cap1 << f.bits2;
+        unsigned int* cnt2 = p;              p += nb2;
+        unsigned int* off2 = p;              p += nb2;
+        unsigned int* first2 = p;            p += nb2;
+        unsigned int* slices2 = p;           p += f.cap2 + 2;
+        unsigned int* hist2 = p;
+        HIPCHK(hipMemsetAsync(slices1, 0, sizeof(unsigned int), st));
+        HIPCHK(hipMemsetAsync(slices2, 0, sizeof(unsigned int), st));
+        FbSortArgs s1;
+        memset(&s1, 0, sizeof s1);
+        s1.raw = f.keys[0];
+        s1.n = n;
+        s1.tstride = a.dstride;
+        s1.W = f.W;
+        s1.nchunk = f.nchunk;
+        s1.chunk_len = f.chunk_len;
+        s1.sh1 = f.bits2 + f.bits3;
+        s1.nb1 = (unsigned int)nb1;
+        s1.chist = chist;
+        s1.e_out = f.vals[0];
+        s1.k_out = f.k16[0];
+        s1.out_count = cnt1;
+        s1.out_offset = off1;
+        s1.out_first = first1;
+        s1.next_list = slices1;
+        s1.next_cap = f.cap1;
+        s1.next_seg = f.slice_len;
+        s1.err = a.err;
+        const dim3 g1(f.W, f.nchunk);
+        hipLaunchKernelGGL(k_fb_l1_hist, g1, dim3(MSM_SORT_THREADS), 0, st, s1);
+        hipLaunchKernelGGL(k_fb_l1_offsets, dim3(1), dim3(MSM_SCAN_THREADS), 0, st, s1);
+        hipLaunchKernelGGL(k_fb_l1_scatter, g1, dim3(FB_L1_SCATTER_THREADS), 0, st, s1);
+        FbSortArgs s2;
+        memset(&s2, 0, sizeof s2);
+        s2.e_in = f.vals[0];
+        s2.k_in = f.k16[0];
+        s2.e_out = f.vals[1];
+        s2.k_out = f.k16[1];
+        s2.sh = f.bits3;
+        s2.bits = f.bits2;
+        s2.nbins_in = (unsigned int)nb1;
+        s2.in_count = cnt1;
+        s2.in_offset = off1;
+        s2.in_first = first1;
+        s2.slices = slices1;
+        s2.slice_cap = f.cap1;
+        s2.slice_len = f.slice_len;
+        s2.slice_hist = hist1;
+        s2.out_count = cnt2;
+        s2.out_offset = off2;
+        s2.out_first = first2;
+        s2.next_list = slices2;
+        s2.next_cap = f.cap2;
+        s2.next_seg = f.slice_len;
+        s2.next_threshold = 0;
+        s2.err = a.err;
+        hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap1), dim3(MSM_REFINE_THREADS), 0, st, s2);
+        hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((nb2 + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s2);
+        hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap1), dim3(MSM_REFINE_THREADS), 0, st, s2);
+        FbSortArgs s3;
+        memset(&s3, 0, sizeof s3);
+        s3.e_in = f.vals[1];
+        s3.k_in = f.k16[1];
+        s3.e_out = f.vals[0];
+        s3.k_out = nullptr;
+        s3.sh = 0;
+        s3.bits = f.bits3;
+        s3.nbins_in = (unsigned int)nb2;
+        s3.in_count = cnt2;
+        s3.in_offset = off2;
+        s3.in_first = first2;
+        s3.slices = slices2;
+        s3.slice_cap = f.cap2;
+        s3.slice_len = f.slice_len;
+        s3.slice_hist = hist2;
+        s3.out_count = a.count;
+        s3.out_offset = a.offset;
+        s3.out_first = nullptr;
+        s3.next_list = a.big;
+        s3.next_cap = a.big_cap;
+        s3.next_seg = a.seg;
+        s3.next_threshold = a.big_threshold;
+        s3.err = a.err;
+        hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap2), dim3(MSM_REFINE_THREADS), 0, st, s3);
+        hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((w->nb + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s3);
+        hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap2), dim3(MSM_REFINE_THREADS), 0, st, s3);
+        a.entries = f.vals[0];
     }
-    hipLaunchKernelGGL(k_msm_fb_counts, dim3((w->nb + GKR_BLOCK - 1) / GKR_BLOCK), dim3(GKR_BLOCK), 0, st, a);
     // from here on: ONE window of nb buckets over the table array
     a.W = 1;
-    a.entries = f.vals[1];
     a.acc_nb = std::min<unsigned int>(w->nb, 32768);      // the ordering and the bucket sums: ranges of 2^15 buckets, a workgroup orders one
     a.acc_W = w->nb / a.acc_nb;
     hipLaunchKernelGGL(k_msm_order, dim3(a.acc_W), dim3(MSM_SORT_THREADS), 0, st, a);

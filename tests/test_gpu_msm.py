@@ -439,12 +439,17 @@ def test_msm_fixed_base_vs_oracle(gk, n):
     want = c.g1_msm(pts, sc)
     b = gk.G1Bases(points=pts)
     assert b.multi_exp(sc).tolist() == want.tolist()                   # per-window path
-    for cw in (0, 8, 13, 20):
-        b.precompute(cw)
-        assert b.multi_exp(sc).tolist() == want.tolist(), cw
-        assert b.multi_exp(sc).tolist() == want.tolist(), cw           # buffers reused
-        m = n // 2
-        assert b.multi_exp(sc[:m]).tolist() == c.g1_msm(pts[:m], sc[:m]).tolist(), cw      # a prefix: the tables keep their stride
+    try:
+        for lib_sort in (0, 1):             # the library's three-level counting sort | rocPRIM's radix sort (the A/B partner)
+            gk.set_option("msm_fb_sort", lib_sort)
+            for cw in (0, 8, 13, 20):
+                b.precompute(cw)
+                assert b.multi_exp(sc).tolist() == want.tolist(), (cw, lib_sort)
+                assert b.multi_exp(sc).tolist() == want.tolist(), (cw, lib_sort)           # buffers reused
+                m = n // 2
+                assert b.multi_exp(sc[:m]).tolist() == c.g1_msm(pts[:m], sc[:m]).tolist(), (cw, lib_sort)      # a prefix: the tables keep their stride
+    finally:
+        gk.set_option("msm_fb_sort", 0)
     b.precompute(-1)                                                    # tables dropped: the per-window path again
     assert b.multi_exp(sc).tolist() == want.tolist()
     b.close()
@@ -507,9 +512,22 @@ def test_msm_fixed_base_agrees_with_the_per_window_path_at_2p20(gk):
     s = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 59) - 1)
     want = b.multi_exp(s).tolist()
-    for cw in (20, 22):
-        b.precompute(cw)
-        assert b.multi_exp(s).tolist() == want, cw
+    try:
+        for lib_sort, cw in ((0, 20), (0, 22), (1, 22)):
+            gk.set_option("msm_fb_sort", lib_sort)
+            b.precompute(cw)
+            assert b.multi_exp(s).tolist() == want, (cw, lib_sort)
+    finally:
+        gk.set_option("msm_fb_sort", 0)
+    # the 0/1 wires of a witness on the tables: one bucket holds 40 % of all entries of window 0 (segments, slices of one bin)
+    w = s.copy()
+    w[: n // 5 * 2] = 0
+    w[: n // 5 * 2, 0] = 1
+    w[n // 5 * 2: n // 5 * 4] = 0
+    b.precompute(22)
+    got = b.multi_exp(w).tolist()
+    b.precompute(-1)
+    assert got == b.multi_exp(w).tolist()
     b.close()
 
 
