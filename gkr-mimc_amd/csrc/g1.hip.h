@@ -856,8 +856,10 @@ struct FbSortArgs {
     int sh, bits;
     unsigned int nbins_in;
     const unsigned int *in_count, *in_offset, *in_first;      // per input bin (in_first: its first slice-list entry)
-    const unsigned int* slices;   // [0] = number of slices, [1 + k] = bin | slice << MSM_LIST_ID_BITS
+    const unsigned int* slices;   // [0] = number of slices, [1 + k] = bin | slice << id_bits
     unsigned int slice_cap, slice_len;
+    int id_bits, next_id_bits;    // id / segment split of the list read and of the list written (a level has few bins and may have many
+                                  // slices per bin: 7 + 25 bits at level 2; the big-bucket list keeps MSM_LIST_ID_BITS)
     unsigned int* slice_hist;     // [slice][2^bits] counts, then write positions
     // what a level leaves for the next one (level 1 and 2: the next slice list; level 3: bucket sizes and the big-bucket list)
     unsigned int *out_count, *out_offset, *out_first;
@@ -959,7 +961,7 @@ GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_fb_l1_offsets(FbSortArgs a
     }
     const unsigned int nsl = (cnt + a.next_seg - 1) / a.next_seg;
     const unsigned int k0 = nsl ? atomicAdd(&a.next_list[0], nsl) : 0u;
-    for (unsigned int sg = 0; sg < nsl && k0 + sg < a.next_cap; sg++) a.next_list[1 + k0 + sg] = b | (sg << MSM_LIST_ID_BITS);
+    for (unsigned int sg = 0; sg < nsl && k0 + sg < a.next_cap; sg++) a.next_list[1 + k0 + sg] = b | (sg << a.next_id_bits);
     a.out_first[b] = k0;
 }
 // level 1: the chunk again, staged scatter: entry = table index | sign << 31, key = the bucket bits below the bin's
@@ -997,8 +999,8 @@ GKR_KERNEL void __launch_bounds__(FB_L1_SCATTER_THREADS) k_fb_l1_scatter(FbSortA
 __device__ __forceinline__ bool fb_slice_range(const FbSortArgs& a, unsigned int* bin, unsigned int* lo, unsigned int* hi) {
     if (blockIdx.x >= min(a.slices[0], a.slice_cap)) return false;
     const unsigned int e = a.slices[1 + blockIdx.x];
-    *bin = e & MSM_LIST_ID_MASK;
-    const unsigned int base = a.in_offset[*bin], cnt = a.in_count[*bin], s0 = (e >> MSM_LIST_ID_BITS) * a.slice_len;
+    *bin = e & ((1u << a.id_bits) - 1u);
+    const unsigned int base = a.in_offset[*bin], cnt = a.in_count[*bin], s0 = (e >> a.id_bits) * a.slice_len;
     *lo = base + s0;
     *hi = base + min(cnt, s0 + a.slice_len);
     return true;
@@ -1054,7 +1056,7 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_fb_lv_offsets(FbSortArgs a) {
     if (cnt > a.next_threshold) {
         const unsigned int nseg = (cnt + a.next_seg - 1) / a.next_seg;
         const unsigned int b0 = atomicAdd(&a.next_list[0], nseg);
-        for (unsigned int sg = 0; sg < nseg && b0 + sg < a.next_cap; sg++) a.next_list[1 + b0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
+        for (unsigned int sg = 0; sg < nseg && b0 + sg < a.next_cap; sg++) a.next_list[1 + b0 + sg] = (unsigned int)t | (sg << a.next_id_bits);
         if (a.out_first) a.out_first[t] = b0;
     }
     for (unsigned int s = 0; s < nsl; s++) {

@@ -414,10 +414,9 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
         f.bits3 = std::min(7, kb);
         f.bits2 = std::min(7, kb - f.bits3);
         f.bits1 = kb - f.bits3 - f.bits2;                        // <= 7 (c <= 22)
-        f.nchunk = (unsigned int)std::min<size_t>(128, std::max<size_t>(1, n / 131072));
+        f.nchunk = (unsigned int)std::min<size_t>(512, std::max<size_t>(1, n / 32768));
         f.chunk_len = ((n + f.nchunk - 1) / f.nchunk + 7) & ~(size_t)7;
-        f.slice_len = 8192;
-        while ((size_t)f.slice_len * 2048 < V) f.slice_len <<= 1;      // at most 2048 slices per bin (11 bits of the list entry)
+        f.slice_len = 8192;                                      // (the slice lists of the levels split their words by the level's bins: no cap on slices per bin)
         const size_t nb1 = (size_t)1 << f.bits1, nb2 = nb1 << f.bits2;
         f.cap1 = (unsigned int)(V / f.slice_len + nb1 + 16);
         f.cap2 = (unsigned int)(V / f.slice_len + nb2 + 16);
@@ -534,6 +533,7 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         s1.next_list = slices1;
         s1.next_cap = f.cap1;
         s1.next_seg = f.slice_len;
+        s1.next_id_bits = std::max(f.bits1, 1);
         s1.err = a.err;
         const dim3 g1(f.W, f.nchunk);
         hipLaunchKernelGGL(k_fb_l1_hist, g1, dim3(MSM_SORT_THREADS), 0, st, s1);
@@ -562,6 +562,8 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         s2.next_cap = f.cap2;
         s2.next_seg = f.slice_len;
         s2.next_threshold = 0;
+        s2.id_bits = std::max(f.bits1, 1);
+        s2.next_id_bits = std::max(f.bits1 + f.bits2, 1);
         s2.err = a.err;
         hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap1), dim3(MSM_REFINE_THREADS), 0, st, s2);
         hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((nb2 + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s2);
@@ -589,6 +591,8 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         s3.next_cap = a.big_cap;
         s3.next_seg = a.seg;
         s3.next_threshold = a.big_threshold;
+        s3.id_bits = std::max(f.bits1 + f.bits2, 1);
+        s3.next_id_bits = MSM_LIST_ID_BITS;
         s3.err = a.err;
         hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap2), dim3(MSM_REFINE_THREADS), 0, st, s3);
         hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((w->nb + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s3);
