@@ -537,6 +537,7 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         s1.err = a.err;
         const dim3 g1(f.W, f.nchunk);
         hipLaunchKernelGGL(k_fb_l1_hist, g1, dim3(MSM_SORT_THREADS), 0, st, s1);
+        hipLaunchKernelGGL(k_fb_l1_columns, dim3(s1.nb1), dim3(MSM_SCAN_THREADS), 0, st, s1);
         hipLaunchKernelGGL(k_fb_l1_offsets, dim3(1), dim3(MSM_SCAN_THREADS), 0, st, s1);
         hipLaunchKernelGGL(k_fb_l1_scatter, g1, dim3(FB_L1_SCATTER_THREADS), 0, st, s1);
         FbSortArgs s2;
@@ -565,9 +566,9 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         s2.id_bits = std::max(f.bits1, 1);
         s2.next_id_bits = std::max(f.bits1 + f.bits2, 1);
         s2.err = a.err;
-        hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap1), dim3(MSM_REFINE_THREADS), 0, st, s2);
+        hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap1), dim3(FB_LV_THREADS), 0, st, s2);
         hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((nb2 + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s2);
-        hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap1), dim3(MSM_REFINE_THREADS), 0, st, s2);
+        hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap1), dim3(FB_LV_THREADS), 0, st, s2);
         FbSortArgs s3;
         memset(&s3, 0, sizeof s3);
         s3.e_in = f.vals[1];
@@ -594,9 +595,9 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         s3.id_bits = std::max(f.bits1 + f.bits2, 1);
         s3.next_id_bits = MSM_LIST_ID_BITS;
         s3.err = a.err;
-        hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap2), dim3(MSM_REFINE_THREADS), 0, st, s3);
+        hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap2), dim3(FB_LV_THREADS), 0, st, s3);
         hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((w->nb + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s3);
-        hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap2), dim3(MSM_REFINE_THREADS), 0, st, s3);
+        hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap2), dim3(FB_LV_THREADS), 0, st, s3);
         a.entries = f.vals[0];
     }
     // from here on: ONE window of nb buckets over the table array

@@ -45,6 +45,10 @@ int main() {
     gkrhip_g1_bases* b = nullptr;
     if (gkrhip_g1_bases_create(&b, pts.data(), n) != 0 || gkrhip_g1_bases_len(b) != n) { printf("FAIL bases_create\n"); fails++; }
     if (gkrhip_msm_g1(got, b, s.data(), n, 0) != 0 || memcmp(got, want, 64)) { printf("FAIL msm_g1\n"); fails++; }
+    // fixed-base tables of the handle (round 6): the same call, the same point; dropped again for what follows
+    if (gkrhip_msm_g1_precompute(b, 0) != 0 || gkrhip_msm_g1(got, b, s.data(), n, 0) != 0 || memcmp(got, want, 64)) { printf("FAIL msm_g1 on fixed-base tables\n"); fails++; }
+    if (gkrhip_msm_g1_precompute(b, 23) == 0) { printf("FAIL a window of 23 bits accepted\n"); fails++; }
+    if (gkrhip_msm_g1_precompute(b, -1) != 0 || gkrhip_msm_g1(got, b, s.data(), n, 0) != 0 || memcmp(got, want, 64)) { printf("FAIL msm_g1 after dropping the tables\n"); fails++; }
     // four host threads on ONE handle (serialised by the handle) and four on handles of their own (concurrent lanes)
     {
         std::vector<std::thread> th;
