@@ -36,7 +36,7 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_host", 
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-ldl", "-lpthread"]
 FLAGS = CFLAGS + LDFLAGS                     # (what the recorded hash covers)
 # (name, source, extra flags): gkrhip.hip first -- the longest single compilation starts first
-UNITS = [("host", "gkrhip.hip", []), ("fbsort", "fb_sort.hip", [])] + \
+UNITS = [("host", "gkrhip.hip", [])] + \
         [(g.lower(), "kern_unit.hip", ["-DGKR_GROUP_" + g]) for g in ("MSM_G2A", "MSM_G2B", "MSM_G1", "WIDE2", "WIDEPRE", "ROUND", "NTT")]
 
 # half-rate vector instructions on gfx950 (4.2-4.4 cycles per wave: profiles/r01_ubench_*.txt); the others issue in 2.4

@@ -289,8 +289,7 @@ struct MsmArgs {
     int rbits;                         // refine: the coarse pass's lowbits
     unsigned int* slice_hist;          // [slice][2^rbits] counts, then write cursors
     // fixed-base MSM (k_msm_fb_*): ONE bucket space for all windows; W here is the number of windows of a scalar, the sums run with W = 1
-    unsigned int* fb_keys;             // [W][n] bucket of (window, point), nb for a zero digit (sorts behind every bucket)
-    unsigned int* fb_vals;             // [W][n] entry: index into the table array (window * n + point) | sign << 31
+    unsigned int* fb_raw;              // [W][n] digit planes of the fixed-base sort: bucket | sign << 31, 0xffffffff for a zero digit
     // the size ordering (k_msm_order) and the bucket sums (k_msm_accumulate) see the fixed-base MSM's one bucket space as acc_W
     // ranges of acc_nb consecutive buckets (a workgroup orders one range in LDS); 0: the windows themselves
     unsigned int acc_W, acc_nb;
@@ -768,8 +767,8 @@ GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
 // HBM), window j of scalar i contributes d_ij * T_j[i] and every window shares ONE bucket space -- so the window can be wide
 // (c = 20..22: 13 or 12 additions per scalar instead of 16) without paying 2^(c-1) buckets per window in the reduction.  The sort
 // then has 21-bit keys and 28-bit table indices, which the counting sort above (16-bit digit planes, 32-bit entries with the low
-// bucket bits inside) does not hold: it is a radix sort of (bucket, entry) pairs (fb_sort.hip: rocPRIM), followed by the run
-// boundaries.  Bucket sums, big buckets and the window sum are the kernels below with W = 1 and the table array as `points`.
+// bucket bits inside) does not hold: three levels of the same LDS counting sort follow (FbSortArgs).  Bucket sums, big buckets
+// and the window sum are the kernels below with W = 1 and the table array as `points`.
 // ------------------------------------------------------------------------------------------------
 // tables[j * n + i] = [2^(c j)] points[i], affine, canonical (infinity stays (0, 0)); one lane per point, one inversion per entry
 template <class F>
@@ -798,46 +797,18 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_digits(MsmArgs a) {
         bool neg;
         const u32 b = msm_digit(a, dp, j, &neg);
         if (b == MSM_DIGIT_BAD) bad = true;
-        const size_t v = (size_t)j * a.n + i;
-        if (a.fb_vals) {      // the library radix sort's (key, value) pairs
-            a.fb_keys[v] = b < MSM_DIGIT_BAD ? b : a.nb;
-            a.fb_vals[v] = (u32)((size_t)j * a.dstride + i) | (neg ? 0x80000000u : 0u);      // dstride: the tables' window stride
-        } else {              // the three-level counting sort's digit planes: bucket | sign << 31, or none
-            a.fb_keys[v] = b < MSM_DIGIT_BAD ? (b | (neg ? 0x80000000u : 0u)) : 0xffffffffu;
-        }
+        a.fb_raw[(size_t)j * a.n + i] = b < MSM_DIGIT_BAD ? (b | (neg ? 0x80000000u : 0u)) : 0xffffffffu;
     }
     if (bad) *a.err = 1u;
 }
-// run boundaries in the sorted keys: offset[b] = first position of bucket b, count[b] = one past its last (both zero beforehand)
-GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_bounds(const unsigned int* __restrict__ keys, size_t total, MsmArgs a) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned int k = keys[i];
-        if (k >= a.nb) continue;
-        if (i == 0 || keys[i - 1] != k) a.offset[k] = (unsigned int)i;
-        if (i + 1 == total || keys[i + 1] != k) a.count[k] = (unsigned int)(i + 1);
-    }
-}
-// count[b] = size of the run; the buckets above the threshold go to the segment list of k_msm_accumulate_big (as k_msm_offsets)
-GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_counts(MsmArgs a) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.nb) return;
-    const unsigned int end = a.count[t], cnt = end ? end - a.offset[t] : 0u;
-    a.count[t] = cnt;
-    if (cnt > a.big_threshold) {
-        const unsigned int nseg = (cnt + a.seg - 1) / a.seg;
-        const unsigned int k0 = atomicAdd(&a.big[0], nseg);
-        for (unsigned int sg = 0; sg < nseg && k0 + sg < a.big_cap; sg++) a.big[1 + k0 + sg] = (unsigned int)t | (sg << MSM_LIST_ID_BITS);
-    }
-}
-
 // ---- the fixed-base MSM's own sort: three levels of the LDS counting sort above ---------------------------------------------
 // (bucket, entry) pairs of ONE bucket space of 2^kb buckets (kb = c - 1 <= 21) and W * n <= 2^31 entries: bucket bits
 // bits1 | bits2 | bits3 (<= 10 | 7 | 7).  Level 1 reads the digit planes (window j, chunk k per workgroup, as the coarse pass
 // above) and files an entry under the top bits1 bits; levels 2 and 3 are one kernel triple -- count per slice, offsets per
 // output bin, staged scatter per slice -- run twice, each resolving up to seven more bits inside bins that fit the L2.  Every
 // level writes the 32-bit entry (table index | sign << 31) and, beside it, the bucket bits still to be resolved (16 bits):
-// 44 bytes of traffic per entry in all, no atomic outside LDS.  (The library radix sort this replaced: 5.4 ms of a 23.8 ms MSM
-// at 2^24 points; profiles/r06_msm_fixed_base_v1.txt.)
+// 44 bytes of traffic per entry in all, no atomic outside LDS.  (rocPRIM's radix sort of the same (bucket, entry) pairs, the first
+// version: 5.3 ms of a 23.5 ms MSM at 2^24 points against 4.2 of 22.6 -- profiles/r06_msm_fixed_base.txt, commit d5e303d has both.)
 struct FbSortArgs {
     // level 1
     const unsigned int* raw;      // [W][n] bucket | sign << 31, 0xffffffff: none (k_msm_fb_digits)

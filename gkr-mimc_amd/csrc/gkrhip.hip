@@ -44,11 +44,6 @@
 
 using hfr::E;
 
-// fb_sort.hip (a unit of its own: rocPRIM's radix sort of the fixed-base MSM's (bucket, entry) pairs)
-int gkrhip_fb_sort_bytes(size_t n, int key_bits, size_t* bytes);
-int gkrhip_fb_sort(void* tmp, size_t bytes, const unsigned int* keys_in, unsigned int* keys_out, const unsigned int* vals_in,
-                   unsigned int* vals_out, size_t n, int key_bits, hipStream_t st);
-
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -445,10 +440,6 @@ int gkrhip_set_option(const char* key, long value) {
     }
     if (!strcmp(key, "wait_spin_us")) {         // host_ctx.hip.h: how host threads wait (-2: by the CPUs available; -1: always spin; n: spin n us, then sleep)
         g_wait_override.store((int)std::max(-2L, value));
-        return 0;
-    }
-    if (!strcmp(key, "msm_fb_sort")) {          // host_msm.hip.h: the fixed-base MSM's sort, 0 the library's own (default), 1 rocPRIM's radix sort; applies to tables made afterwards
-        g_msm_fb_sort.store(value == 1 ? 1 : 0);
         return 0;
     }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle

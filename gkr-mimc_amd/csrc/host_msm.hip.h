@@ -68,20 +68,17 @@ struct MsmFixedBase {
     int c = 0, W = 0;                    // window bits; windows of a scalar
     unsigned int nb = 0;                 // buckets: 2^(c-1), ONE space for all windows
     uint4* tables = nullptr;             // [W][n] points: [2^(c j)] P_i, affine
-    unsigned int* keys[2] = {nullptr, nullptr};      // [W * n] (bucket) before / after the sort
-    unsigned int* vals[2] = {nullptr, nullptr};      // [W * n] (table index | sign << 31) before / after: the second is the entry list
-    void* sort_tmp = nullptr;
-    size_t sort_bytes = 0;
-    // the library's own three-level counting sort (g1.hip.h: FbSortArgs): residual keys of levels 1 and 2, the levels' bookkeeping
+    // the three-level counting sort (g1.hip.h: FbSortArgs): digit planes, the entries and residual keys of levels 1 and 2, bookkeeping
+    unsigned int* raw = nullptr;                     // [W][n] bucket | sign << 31 (k_msm_fb_digits)
+    unsigned int* vals[2] = {nullptr, nullptr};      // [W * n] entries (table index | sign << 31): level 1 and 3 write [0], level 2 writes [1]
     unsigned short* k16[2] = {nullptr, nullptr};
     unsigned int* lv = nullptr;
     int bits1 = 0, bits2 = 0, bits3 = 0;
     unsigned int nchunk = 0, slice_len = 0, cap1 = 0, cap2 = 0;
     size_t chunk_len = 0;
-    bool lib_sort = false;               // option msm_fb_sort = 1: rocPRIM's radix sort instead (A/B, tests)
     MsmWork w;                           // counts, big list, scalars, bucket planes, pinned window sum: geometry (c, W = 1, nb)
     void release() {
-        for (void* p : {(void*)tables, (void*)keys[0], (void*)keys[1], (void*)vals[0], (void*)vals[1], sort_tmp, (void*)k16[0], (void*)k16[1], (void*)lv})
+        for (void* p : {(void*)tables, (void*)raw, (void*)vals[0], (void*)vals[1], (void*)k16[0], (void*)k16[1], (void*)lv})
             if (p) (void)hipFree(p);
         w.release();
         *this = MsmFixedBase();
@@ -376,9 +373,7 @@ int msm_check_points(const uint64_t* points, size_t n, int w16) {
 }
 
 // ---- fixed-base path ---------------------------------------------------------------------------------------------------
-// (gkrhip_fb_sort_bytes / gkrhip_fb_sort: fb_sort.hip, declared in gkrhip.hip outside this namespace)
 // window size of the one bucket space: 13 n additions at c = 20, 12 n at c = 22 (against 16 n), the reduction over 2^(c-1) buckets once
-std::atomic<int> g_msm_fb_sort{0};      // gkrhip_set_option("msm_fb_sort", 0 | 1): 0 the three-level counting sort, 1 rocPRIM's radix sort
 inline int msm_fb_pick_c(size_t n) { return n >= ((size_t)1 << 23) ? 22 : n >= ((size_t)1 << 17) ? 20 : 16; }
 // tables and buffers; the tables are computed here (one lane per point: c doublings and an inversion per table entry)
 template <class F>
@@ -387,8 +382,7 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     const int c = c_or_0 > 0 ? c_or_0 : msm_fb_pick_c(n);
     if (c < 8 || c > MSM_LIST_ID_BITS + 1) return fail("msm: fixed-base window size %d outside 8..%d", c, MSM_LIST_ID_BITS + 1);
     MsmFixedBase& f = b->fb;
-    const bool lib_sort = g_msm_fb_sort.load() == 1;
-    if (f.tables && f.c == c && f.lib_sort == lib_sort) return 0;
+    if (f.tables && f.c == c) return 0;
     f.release();
     struct Guard {
         MsmFixedBase* f;
@@ -402,14 +396,9 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     const size_t V = (size_t)f.W * n;
     if (V >= ((size_t)1 << 31)) return fail("msm: %d windows of %zu points do not fit 31-bit table indices", f.W, n);
     HIPCHK(hipMalloc((void**)&f.tables, V * 32 * b->w16));
-    f.lib_sort = lib_sort;
-    HIPCHK(hipMalloc((void**)&f.keys[0], V * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&f.raw, V * sizeof(unsigned int)));
     for (int k = 0; k < 2; k++) HIPCHK(hipMalloc((void**)&f.vals[k], V * sizeof(unsigned int)));
-    if (lib_sort) {
-        HIPCHK(hipMalloc((void**)&f.keys[1], V * sizeof(unsigned int)));
-        if (gkrhip_fb_sort_bytes(V, c, &f.sort_bytes) != 0) return fail("msm: rocPRIM refused the size query of the fixed-base sort");
-        HIPCHK(hipMalloc(&f.sort_tmp, std::max<size_t>(f.sort_bytes, 16)));
-    } else {
+    {
         const int kb = c - 1;
         f.bits3 = std::min(7, kb);
         f.bits2 = std::min(7, kb - f.bits3);
@@ -481,23 +470,13 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
     a.seg = w->seg;
     a.chunk = w->chunk;
     a.err = a.big + a.big_cap + 1;
-    a.fb_keys = f.keys[0];
-    a.fb_vals = f.lib_sort ? f.vals[0] : nullptr;      // (null: k_msm_fb_digits writes the digit planes of the library's own sort)
+    a.fb_raw = f.raw;
     a.dstride = std::max<size_t>(b->n, 1);      // the tables' window stride (n <= b->n scalars: keys are packed [W][n], entries index [W][b->n])
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));
     HIPCHK(hipMemsetAsync(a.err, 0, sizeof(unsigned int), st));
     if (n) hipLaunchKernelGGL(k_msm_fb_digits, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, a);
-    if (f.lib_sort) {
-        HIPCHK(hipMemsetAsync(a.count, 0, (size_t)2 * w->nb * sizeof(unsigned int), st));
-        if (n) {
-            if (gkrhip_fb_sort(f.sort_tmp, f.sort_bytes, f.keys[0], f.keys[1], f.vals[0], f.vals[1], V, f.c, st) != 0)
-                return fail("msm: the fixed-base radix sort failed");
-            hipLaunchKernelGGL(k_msm_fb_bounds, dim3(grid_for(V, 8192)), dim3(GKR_BLOCK), 0, st, (const unsigned int*)f.keys[1], V, a);
-        }
-        hipLaunchKernelGGL(k_msm_fb_counts, dim3((w->nb + GKR_BLOCK - 1) / GKR_BLOCK), dim3(GKR_BLOCK), 0, st, a);
-        a.entries = f.vals[1];
-    } else {
+    {
         // three levels of the LDS counting sort: (vals[0], k16[0]) <- level 1, (vals[1], k16[1]) <- level 2, vals[0] <- level 3
         const size_t nb1 = (size_t)1 << f.bits1, nb2 = nb1 << f.bits2;
         unsigned int* p = f.lv;
@@ -516,7 +495,7 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
         HIPCHK(hipMemsetAsync(slices2, 0, sizeof(unsigned int), st));
         FbSortArgs s1;
         memset(&s1, 0, sizeof s1);
-        s1.raw = f.keys[0];
+        s1.raw = f.raw;
         s1.n = n;
         s1.tstride = a.dstride;
         s1.W = f.W;

@@ -421,8 +421,8 @@ def test_reserved_lanes_serve_a_burst_of_calls(gk):
 # ---------------------------------------------------------------- fixed-base tables (round 6)
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 100, 1000, 4096, 1 << 14])
 def test_msm_fixed_base_vs_oracle(gk, n):
-    """gkrhip_msm_g1_precompute: [2^(c j)] P_i once, then every window of every scalar in ONE bucket space (radix sort of (bucket,
-    entry) pairs) -- the same affine image as the oracle's per-term double-and-add and as the handle's per-window path, with the
+    """gkrhip_msm_g1_precompute: [2^(c j)] P_i once, then every window of every scalar in ONE bucket space (three levels of the LDS
+    counting sort) -- the same affine image as the oracle's per-term double-and-add and as the handle's per-window path, with the
     corner scalars of the recoding, a point at infinity, a repeated point, P and -P in one bucket, and a prefix of the bases."""
     rng = random.Random(600 + n)
     pts = rand_points(n + 11, n)
@@ -439,17 +439,12 @@ def test_msm_fixed_base_vs_oracle(gk, n):
     want = c.g1_msm(pts, sc)
     b = gk.G1Bases(points=pts)
     assert b.multi_exp(sc).tolist() == want.tolist()                   # per-window path
-    try:
-        for lib_sort in (0, 1):             # the library's three-level counting sort | rocPRIM's radix sort (the A/B partner)
-            gk.set_option("msm_fb_sort", lib_sort)
-            for cw in (0, 8, 13, 20):
-                b.precompute(cw)
-                assert b.multi_exp(sc).tolist() == want.tolist(), (cw, lib_sort)
-                assert b.multi_exp(sc).tolist() == want.tolist(), (cw, lib_sort)           # buffers reused
-                m = n // 2
-                assert b.multi_exp(sc[:m]).tolist() == c.g1_msm(pts[:m], sc[:m]).tolist(), (cw, lib_sort)      # a prefix: the tables keep their stride
-    finally:
-        gk.set_option("msm_fb_sort", 0)
+    for cw in (0, 8, 13, 20):
+        b.precompute(cw)
+        assert b.multi_exp(sc).tolist() == want.tolist(), cw
+        assert b.multi_exp(sc).tolist() == want.tolist(), cw           # buffers reused
+        m = n // 2
+        assert b.multi_exp(sc[:m]).tolist() == c.g1_msm(pts[:m], sc[:m]).tolist(), cw      # a prefix: the tables keep their stride
     b.precompute(-1)                                                    # tables dropped: the per-window path again
     assert b.multi_exp(sc).tolist() == want.tolist()
     b.close()
@@ -512,13 +507,9 @@ def test_msm_fixed_base_agrees_with_the_per_window_path_at_2p20(gk):
     s = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 59) - 1)
     want = b.multi_exp(s).tolist()
-    try:
-        for lib_sort, cw in ((0, 20), (0, 22), (1, 22)):
-            gk.set_option("msm_fb_sort", lib_sort)
-            b.precompute(cw)
-            assert b.multi_exp(s).tolist() == want, (cw, lib_sort)
-    finally:
-        gk.set_option("msm_fb_sort", 0)
+    for cw in (20, 22):
+        b.precompute(cw)
+        assert b.multi_exp(s).tolist() == want, cw
     # the 0/1 wires of a witness on the tables: one bucket holds 40 % of all entries of window 0 (segments, slices of one bin)
     w = s.copy()
     w[: n // 5 * 2] = 0

@@ -6,10 +6,7 @@ gk.init(0)
 for lg in [int(a) for a in sys.argv[1:]] or [16, 20, 22, 24]:
     base = gk.bench_msm_g1(lg, warmup=1, iters=3)
     print("2^%d per-window c=%d: %.3f ms  %s" % (lg, base["c"], base["ms"], {k: round(v, 3) for k, v in base["phases_ms"].items()}), flush=True)
-    for lib_sort in (0, 1):
-        gk.set_option("msm_fb_sort", lib_sort)
-        for c in ([0] if lg < 20 else [20, 22]):
-            r = gk.bench_msm_g1_fixed_base(lg, c=c, warmup=1, iters=3)
-            assert r["result"].tolist() == base["result"].tolist(), "fixed-base result differs"
-            print("2^%d fixed-base c=%d %s: %.3f ms  %s  tables %.0f ms" % (lg, r["c"], "rocPRIM sort" if lib_sort else "own sort    ", r["ms"], {k: round(v, 3) for k, v in r["phases_ms"].items()}, r["precompute_ms"]), flush=True)
-    gk.set_option("msm_fb_sort", 0)
+    for c in ([0] if lg < 20 else [20, 22]):
+        r = gk.bench_msm_g1_fixed_base(lg, c=c, warmup=1, iters=3)
+        assert r["result"].tolist() == base["result"].tolist(), "fixed-base result differs"
+        print("2^%d fixed-base c=%d: %.3f ms  %s  tables %.0f ms" % (lg, r["c"], r["ms"], {k: round(v, 3) for k, v in r["phases_ms"].items()}, r["precompute_ms"]), flush=True)
