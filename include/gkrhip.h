@@ -337,7 +337,7 @@ int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
  * pk.G1.K, pk.G2.B: prove.go:76,91,189,202,221,277), the same for every proof: this computes [2^(c j)] P_i for every window j once
  * (W = ceil(255 / c) times the handle's points in HBM; seconds for 2^24 points) and the handle's own MSMs -- gkrhip_msm_g1 /
  * gkrhip_msm_g2 -- then sort every window into ONE bucket space of 2^(c-1) buckets: 12 or 13 additions per scalar instead of 16.
- * Same sums (the tests hold both paths against the oracle).  c = 0: chosen from the number of points (22 from 2^23, 20 from 2^17),
+ * Same sums (the tests hold both paths against the oracle).  c = 0: chosen from the number of points (22 from 2^22, 20 from 2^17),
  * 8..22 forced, -1 drops the tables.  The calls that share a sort between handles (gkrhip_msm_g1_g2, gkrhip_msm_shared,
  * gkrhip_compute_h_msm_g1) keep the per-window path. */
 int gkrhip_msm_g1_precompute(gkrhip_g1_bases *b, int c);
