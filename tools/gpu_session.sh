@@ -21,8 +21,8 @@ for step in "$@"; do
     rccl1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python bench.py --pass rccl_tick --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_tick.json 2> $OUT/bench_rccl_tick.err ;;
     rccl_lanes) GKRHIP_FORCE_COLLECTIVE=1 GPU_MAX_HW_QUEUES=8 timeout 600 python bench.py --pass rccl_lanes --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_rccl_lanes.json 2> $OUT/bench_rccl_lanes.err ;;
     shm1) GKRHIP_FORCE_COLLECTIVE=1 timeout 600 python bench.py --pass shm --no-cpu-baseline --no-micro --no-oneshot --no-configs > $OUT/bench_shm1.json 2> $OUT/bench_shm1.err ;;
-    w8) for v in default spin25; do
-          E=""; [ $v = spin25 ] && E="GKRHIP_WAIT_SPIN_US=25"
+    w8) for v in default; do      # (the spin/sleep policy of the waiting threads is the option wait_spin_us since round 6)
+          E=""
           ( time env $E python - <<'PY'
 import subprocess, sys, os, uuid
 here = os.path.join(os.getcwd(), "tests")

@@ -3,7 +3,7 @@
 the arena and every lane runs the same kernels at the same time): each proof must equal the first one byte for byte.
     python tools/stress_one_size.py [bn] [lanes] [proofs per lane]
 This is the load that exposed the look-ahead kernel's lowest-priority stream (round 4): with GKRHIP_PRELAUNCH=2 GKRHIP_PRE=2
-GKRHIP_PRELAUNCH_LG=30 and twelve lanes at bN = 18, 4 % of the proofs were wrong."""
+(and pre-launch for every round size) and twelve lanes at bN = 18, 4 % of the proofs were wrong."""
 import importlib
 import os
 import sys
