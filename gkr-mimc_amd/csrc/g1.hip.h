@@ -290,6 +290,8 @@ struct MsmArgs {
     unsigned int* slice_hist;          // [slice][2^rbits] counts, then write cursors
     // fixed-base MSM (k_msm_fb_*): ONE bucket space for all windows; W here is the number of windows of a scalar, the sums run with W = 1
     unsigned int* fb_raw;              // [W][n] digit planes of the fixed-base sort: bucket | sign << 31, 0xffffffff for a zero digit
+    unsigned char fb_wb[32];           // fixed-base: bits of window j (255 bits dealt evenly: floor(255 / W) or one more, the wider ones on top) ...
+    unsigned short fb_wo[32];          // ... and its first bit: T_j = [2^fb_wo[j]] P
     // the size ordering (k_msm_order) and the bucket sums (k_msm_accumulate) see the fixed-base MSM's one bucket space as acc_W
     // ranges of acc_nb consecutive buckets (a workgroup orders one range in LDS); 0: the windows themselves
     unsigned int acc_W, acc_nb;
@@ -770,9 +772,15 @@ GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
 // bucket bits inside) does not hold: three levels of the same LDS counting sort follow (FbSortArgs).  Bucket sums, big buckets
 // and the window sum are the kernels below with W = 1 and the table array as `points`.
 // ------------------------------------------------------------------------------------------------
-// tables[j * n + i] = [2^(c j)] points[i], affine, canonical (infinity stays (0, 0)); one lane per point, one inversion per entry
+// tables[j * n + i] = [2^(first bit of window j)] points[i], affine, canonical (infinity stays (0, 0)); one lane per point, one
+// inversion per entry.  The windows deal the 255 bits evenly -- floor(255 / W) bits or one more, the wider ones on top -- instead
+// of W - 1 windows of c bits and a short one: a short top window (254 = 11 * 22 + 12) puts all its entries into 4 096 buckets,
+// which then go through the segment path (2^24 points: 1.85 of 22 ms).
+struct FbWindows {
+    unsigned char wb[32];      // bits of window j
+};
 template <class F>
-__global__ void __launch_bounds__(GKR_BLOCK) k_msm_fb_precompute(const uint4* __restrict__ points, uint4* __restrict__ tables, size_t n, int c, int W) {
+__global__ void __launch_bounds__(GKR_BLOCK) k_msm_fb_precompute(const uint4* __restrict__ points, uint4* __restrict__ tables, size_t n, FbWindows fw, int W) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const AffT<F> p = ec_ld_aff<F>(points, i);
@@ -781,7 +789,7 @@ __global__ void __launch_bounds__(GKR_BLOCK) k_msm_fb_precompute(const uint4* __
     if (ec_aff_is_inf(p)) ecx_set_inf(x);
     else x.x = p.x, x.y = p.y, x.zz = F::one(), x.zzz = F::one();
     for (int j = 1; j < W; j++) {
-        for (int k = 0; k < c; k++) ecx_dbl(x);
+        for (int k = 0; k < fw.wb[j - 1]; k++) ecx_dbl(x);
         ec_st_aff<F>(tables, (size_t)j * n + i, ecx_to_aff(x));
     }
 }
@@ -795,9 +803,25 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_msm_fb_digits(MsmArgs a) {
     msm_load_scalar(a, i, s);
     bool bad = !msm_bias_scalar(a, s);
     for (int j = 0; j < a.W; j++) {
-        const u32 dp = msm_window_raw(a, s, j);
-        bool neg;
-        const u32 b = msm_digit(a, dp, j, &neg);
+        // window j: fb_wb[j] bits from bit fb_wo[j] (uniform over the launch: selects, not indexed registers)
+        const int bit = a.fb_wo[j], wb = a.fb_wb[j], limb = bit >> 5, sh = bit & 31;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            lo = (l == limb) ? s[l] : lo;
+            hi = (l == limb + 1) ? s[l] : hi;
+        }
+        const u32 dp = (u32)((((u64)hi << 32) | lo) >> sh) & ((1u << wb) - 1u);
+        const u32 half = 1u << (wb - 1);
+        bool neg = false;
+        u32 b;
+        if (j == a.W - 1) {
+            b = dp == 0 ? MSM_DIGIT_NONE : (dp > half ? MSM_DIGIT_BAD : dp - 1u);
+        } else {
+            neg = dp < half;
+            const u32 mag = neg ? half - dp : dp - half;
+            b = mag ? mag - 1u : MSM_DIGIT_NONE;
+        }
         if (b == MSM_DIGIT_BAD) bad = true;
         a.fb_raw[(size_t)j * a.n + i] = b < MSM_DIGIT_BAD ? (b | (neg ? 0x80000000u : 0u)) : 0xffffffffu;
     }

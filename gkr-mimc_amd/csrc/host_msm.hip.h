@@ -73,6 +73,8 @@ struct MsmFixedBase {
     unsigned int* vals[2] = {nullptr, nullptr};      // [W * n] entries (table index | sign << 31): level 1 and 3 write [0], level 2 writes [1]
     unsigned short* k16[2] = {nullptr, nullptr};
     unsigned int* lv = nullptr;
+    unsigned char wb[32] = {0};          // bits of window j: the 255 bits dealt evenly over the W windows, the wider ones on top
+    unsigned short wo[32] = {0};         // first bit of window j
     int bits1 = 0, bits2 = 0, bits3 = 0;
     unsigned int nchunk = 0, slice_len = 0, cap1 = 0, cap2 = 0;
     size_t chunk_len = 0;
@@ -395,6 +397,16 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     f.c = c;
     f.W = msm_windows(c);
     f.nb = 1u << (c - 1);
+    if (f.W > 32) return fail("msm: %d windows (at most 32)", f.W);
+    {
+        const int base = 255 / f.W, extra = 255 - base * f.W;      // `extra` windows of base + 1 bits (<= c), on top
+        int bit = 0;
+        for (int j = 0; j < f.W; j++) {
+            f.wb[j] = (unsigned char)(base + (j >= f.W - extra ? 1 : 0));
+            f.wo[j] = (unsigned short)bit;
+            bit += f.wb[j];
+        }
+    }
     const size_t V = (size_t)f.W * n;
     if (V >= ((size_t)1 << 31)) return fail("msm: %d windows of %zu points do not fit 31-bit table indices", f.W, n);
     HIPCHK(hipMalloc((void**)&f.tables, V * 32 * b->w16));
@@ -433,7 +445,7 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     w.big_cap = (unsigned int)(std::min<size_t>(V / 128, w.nb / 4) + V / w.seg + 16);
     memset(w.bias, 0, sizeof w.bias);
     for (int j = 0; j + 1 < f.W; j++) {
-        const int bit = j * c + c - 1;
+        const int bit = f.wo[j] + f.wb[j] - 1;
         w.bias[bit >> 5] |= 1u << (bit & 31);
     }
     HIPCHK(hipMalloc((void**)&w.counts, (size_t)3 * w.nb * sizeof(unsigned int)));
@@ -442,8 +454,10 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     HIPCHK(hipMalloc((void**)&w.xyzz, (size_t)4 * b->w16 * ((size_t)w.nb + w.nparts + 1 + w.big_cap) * sizeof(uint4)));
     HIPCHK(hipHostMalloc((void**)&w.h_wins, ((size_t)4 * b->w16 + 1) * sizeof(uint4)));
     w.ready = true;
+    FbWindows fw;
+    memcpy(fw.wb, f.wb, sizeof fw.wb);
     hipLaunchKernelGGL(k_msm_fb_precompute<F>, dim3((unsigned)((n + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, cx().stream,
-                       (const uint4*)b->d_points, f.tables, b->n, c, f.W);
+                       (const uint4*)b->d_points, f.tables, b->n, fw, f.W);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(cx().stream));
     guard.f = nullptr;
@@ -476,6 +490,8 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
     a.chunk = w->chunk;
     a.err = a.big + a.big_cap + 1;
     a.fb_raw = f.raw;
+    memcpy(a.fb_wb, f.wb, sizeof a.fb_wb);
+    memcpy(a.fb_wo, f.wo, sizeof a.fb_wo);
     a.dstride = std::max<size_t>(b->n, 1);      // the tables' window stride (n <= b->n scalars: keys are packed [W][n], entries index [W][b->n])
     if (tm && tm->on) HIPCHK(hipEventRecord(tm->ev[0], st));
     HIPCHK(hipMemsetAsync(a.big, 0, sizeof(unsigned int), st));

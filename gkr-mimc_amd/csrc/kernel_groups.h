@@ -53,7 +53,7 @@ GKR_INST template __global__ void k_msm_big_combine<FpF>(MsmArgs);
 GKR_INST template __global__ void k_msm_reduce_chunks<FpF>(MsmArgs);
 GKR_INST template __global__ void k_msm_reduce_windows<FpF>(MsmArgs);
 GKR_INST template __global__ void k_ec_batch_scalar_mul<FpF>(MsmArgs, AffT<FpF>, uint4*);
-GKR_INST template __global__ void k_msm_fb_precompute<FpF>(const uint4*, uint4*, size_t, int, int);
+GKR_INST template __global__ void k_msm_fb_precompute<FpF>(const uint4*, uint4*, size_t, FbWindows, int);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_MSM_G2A)
 GKR_INST template __global__ void k_msm_accumulate<Fp2F>(MsmArgs);
@@ -64,7 +64,7 @@ GKR_INST template __global__ void k_msm_big_combine<Fp2F>(MsmArgs);
 GKR_INST template __global__ void k_msm_reduce_chunks<Fp2F>(MsmArgs);
 GKR_INST template __global__ void k_msm_reduce_windows<Fp2F>(MsmArgs);
 GKR_INST template __global__ void k_ec_batch_scalar_mul<Fp2F>(MsmArgs, AffT<Fp2F>, uint4*);
-GKR_INST template __global__ void k_msm_fb_precompute<Fp2F>(const uint4*, uint4*, size_t, int, int);
+GKR_INST template __global__ void k_msm_fb_precompute<Fp2F>(const uint4*, uint4*, size_t, FbWindows, int);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_NTT)
 GKR_INST template __global__ void k_ntt_tile<false, true>(NttPassArgs);
