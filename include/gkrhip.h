@@ -334,8 +334,8 @@ int gkrhip_msm_g1_once(uint64_t out_affine[8], const uint64_t *points, const uin
  * point; the parity tests sweep it) */
 int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
 /* Fixed-base tables (round 6).  The bases of the reference's MultiExp calls are proving-key vectors (pk.G1.A, pk.G1.B, pk.G1.Z,
- * pk.G1.K, pk.G2.B: prove.go:76,91,189,202,221,277), the same for every proof: this computes [2^(c j)] P_i for every window j once
- * (W = ceil(255 / c) times the handle's points in HBM; seconds for 2^24 points) and the handle's own MSMs -- gkrhip_msm_g1 /
+ * pk.G1.K, pk.G2.B: prove.go:76,91,189,202,221,277), the same for every proof: this computes [2^(o_j)] P_i (o_j: the first bit of window j) for every window once
+ * (W = ceil(255 / c) windows of floor(255 / W) bits or one more; W times the handle's points in HBM; seconds for 2^24 points) and the handle's own MSMs -- gkrhip_msm_g1 /
  * gkrhip_msm_g2 -- then sort every window into ONE bucket space of 2^(c-1) buckets: 12 or 13 additions per scalar instead of 16.
  * Same sums (the tests hold both paths against the oracle).  c = 0: chosen from the number of points (22 from 2^22, 20 from 2^17),
  * 8..22 forced, -1 drops the tables.  The calls that share a sort between handles (gkrhip_msm_g1_g2, gkrhip_msm_shared,
