@@ -984,7 +984,7 @@ def main():
         # HBM bytes per launch from the PMC counters need rocprofv3 around the process (separate --pmc passes): they are NOT
         # of this run -- the number is read from the committed builder-side pass and labelled as such
         traffic, traffic_source = None, None
-        for name in ("r05_pmc_fold_traffic.json", "r04_pmc_fold_traffic.json", "r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # tools/pmc_bench.sh
+        for name in ("r06_pmc_fold_traffic.json", "r05_pmc_fold_traffic.json", "r04_pmc_fold_traffic.json", "r03_pmc_fold_traffic.json", "r02_pmc_fold_traffic.json"):   # tools/pmc_bench.sh
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pm.get("bn") == bn_gpu:
