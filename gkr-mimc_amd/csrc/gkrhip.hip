@@ -1511,12 +1511,17 @@ int gkrhip_compute_h_msm_g1(uint64_t out_affine[8], gkrhip_g1_bases* bases_z, co
     CHK(compute_h_dev(tp, logn, nullptr));
     {
         std::lock_guard<std::mutex> lk(bases_z->mu);
-        CHK(msm_work_prepare(&bases_z->w, std::max<size_t>(bases_z->n, 1), bases_z->c_forced, FpF::W16));
         const CPlanes hp = t[0].cplanes();
-        CHK(msm_dev<FpF>(bases_z, hp.lo, card, 0, nullptr, hp.hi));
+        MsmWork* w = bases_z->fb.tables ? &bases_z->fb.w : &bases_z->w;
+        if (bases_z->fb.tables) {      // pk.G1.Z with fixed-base tables (gkrhip_msm_g1_precompute): H's limb planes straight into the digit kernel
+            CHK(msm_fb_dev<FpF>(bases_z, hp.lo, card, 0, nullptr, hp.hi));
+        } else {
+            CHK(msm_work_prepare(&bases_z->w, std::max<size_t>(bases_z->n, 1), bases_z->c_forced, FpF::W16));
+            CHK(msm_dev<FpF>(bases_z, hp.lo, card, 0, nullptr, hp.hi));
+        }
         HIPCHK(hipStreamSynchronize(cx().stream));
-        CHK(msm_check_error(&bases_z->w, "a value of H"));
-        const hfp::Aff r = msm_host_tail<hfp::HFp>(&bases_z->w);
+        CHK(msm_check_error(w, "a value of H"));
+        const hfp::Aff r = msm_host_tail<hfp::HFp>(w);
         memcpy(out_affine, &r, sizeof r);
     }
     if (h_or_null) CHK(download_table(&t[0], h_or_null, card));

@@ -463,9 +463,10 @@ int msm_fb_prepare(MsmBases* b, int c_or_0) {
     guard.f = nullptr;
     return 0;
 }
-// the device part: digits -> radix sort -> run boundaries -> bucket sums -> the one window sum (lands in fb.w.h_wins)
-template <class F>
-int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi = nullptr) {
+// The device part in two steps, as the per-window path: msm_fb_sort_dev -- digits and the three-level sort, a function of the
+// scalars and the window geometry alone, so handles with tables of one geometry share it (msm_run_shared) -- fills *out;
+// msm_sum_dev<F> (above) then runs on the handle's own tables and bucket planes.
+int msm_fb_sort_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi, MsmArgs* out) {
     MsmFixedBase& f = b->fb;
     MsmWork* w = &f.w;
     hipStream_t st = cx().stream;
@@ -606,7 +607,14 @@ int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTime
     a.acc_W = w->nb / a.acc_nb;
     hipLaunchKernelGGL(k_msm_order, dim3(a.acc_W), dim3(MSM_SORT_THREADS), 0, st, a);
     HIPCHK(hipGetLastError());
-    return msm_sum_dev<F>(w, f.tables, a, tm);
+    *out = a;
+    return 0;
+}
+template <class F>
+int msm_fb_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, MsmTimes* tm, const uint4* d_scalars_hi = nullptr) {
+    MsmArgs a;
+    CHK(msm_fb_sort_dev(b, d_scalars, n, flags, tm, d_scalars_hi, &a));
+    return msm_sum_dev<F>(&b->fb.w, b->fb.tables, a, tm);
 }
 
 template <class F, class HF>
@@ -658,6 +666,28 @@ int msm_run_shared(MsmBases* const* g1, size_t k1, MsmBases* const* g2, size_t k
     std::vector<std::unique_lock<std::mutex>> locks;
     for (MsmBases* b : order) locks.emplace_back(b->mu);
     MsmBases* first = all[0];
+    // every handle with fixed-base tables of one geometry: the tables' sort (digits + three levels) once, then every handle's sums on
+    // its own tables -- ar, bs1 and Bs of the Groth16 back half at 12 additions per scalar
+    bool all_fb = true;
+    for (MsmBases* b : all) all_fb = all_fb && b->fb.tables && b->fb.c == first->fb.c;
+    if (all_fb) {
+        if (n) HIPCHK(hipMemcpyAsync(first->fb.w.scalars, scalars, n * 32, hipMemcpyHostToDevice, cx().stream));
+        MsmArgs a;
+        CHK(msm_fb_sort_dev(first, first->fb.w.scalars, n, flags, nullptr, nullptr, &a));
+        for (size_t i = 0; i < k1; i++) CHK(msm_sum_dev<FpF>(&g1[i]->fb.w, g1[i]->fb.tables, a, nullptr));
+        for (size_t i = 0; i < k2; i++) CHK(msm_sum_dev<Fp2F>(&g2[i]->fb.w, g2[i]->fb.tables, a, nullptr));
+        HIPCHK(hipStreamSynchronize(cx().stream));
+        CHK(msm_check_error(&all.back()->fb.w, "a scalar"));
+        for (size_t i = 0; i < k1; i++) {
+            const hfp::AffH<hfp::HFp> r = msm_host_tail<hfp::HFp>(&g1[i]->fb.w);
+            memcpy(out_g1 + 8 * i, &r, sizeof r);
+        }
+        for (size_t i = 0; i < k2; i++) {
+            const hfp::AffH<hfp::HFp2> r = msm_host_tail<hfp::HFp2>(&g2[i]->fb.w);
+            memcpy(out_g2 + 16 * i, &r, sizeof r);
+        }
+        return 0;
+    }
     CHK(msm_work_prepare(&first->w, std::max<size_t>(first->n, 1), first->c_forced, first->w16));
     // (the other handles sum on the first one's sort: buckets, partial sums and window sums only -- unless they already hold
     // the sort's buffers of a call of their own with this geometry)

@@ -338,8 +338,9 @@ int gkrhip_msm_g1_set_window(gkrhip_g1_bases *b, int c);
  * (W = ceil(255 / c) windows of floor(255 / W) bits or one more; W times the handle's points in HBM; seconds for 2^24 points) and the handle's own MSMs -- gkrhip_msm_g1 /
  * gkrhip_msm_g2 -- then sort every window into ONE bucket space of 2^(c-1) buckets: 12 or 13 additions per scalar instead of 16.
  * Same sums (the tests hold both paths against the oracle).  c = 0: chosen from the number of points (22 from 2^22, 20 from 2^17),
- * 8..22 forced, -1 drops the tables.  The calls that share a sort between handles (gkrhip_msm_g1_g2, gkrhip_msm_shared,
- * gkrhip_compute_h_msm_g1) keep the per-window path. */
+ * 8..22 forced, -1 drops the tables.  gkrhip_compute_h_msm_g1 takes them too, and so do the calls that
+ * share a sort between handles (gkrhip_msm_g1_g2, gkrhip_msm_shared) when EVERY handle of the call has tables of one window size
+ * (the tables' sort once; otherwise the per-window path). */
 int gkrhip_msm_g1_precompute(gkrhip_g1_bases *b, int c);
 /* bn254.BatchScalarMultiplicationG1(base, scalars) (prove.go:177): out[i] = [scalars[i]] base as G1Affine */
 int gkrhip_g1_batch_scalar_mul(uint64_t *out /* n x 8 */, const uint64_t base[8], const uint64_t *scalars, size_t n, int flags);

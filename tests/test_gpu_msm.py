@@ -270,6 +270,11 @@ def test_compute_h_then_multi_exp_on_the_device(gk, n, card):
     if cardinality <= 4096:
         assert got.tolist() == c.g1_msm(bases.read(), h_ref).tolist()
     assert bases.compute_h_multi_exp(a, b, cc, card).tolist() == got.tolist()
+    bases.precompute(0)                 # pk.G1.Z on fixed-base tables: H's limb planes go straight into the tables' digit kernel
+    assert bases.compute_h_multi_exp(a, b, cc, card).tolist() == got.tolist()
+    bases.precompute(13)
+    got2, h2 = bases.compute_h_multi_exp(a, b, cc, card, want_h=True)
+    assert got2.tolist() == got.tolist() and np.array_equal(h2, h_ref)
     bases.close()
 
 

@@ -167,6 +167,19 @@ def test_msm_g1_g2_pair_shares_the_sort(gk):
             s = rand_scalars(random.Random(seed), n)
         o1, o2 = gk.multi_exp_g1_g2(b1, b2, s[:n])
         assert o1.tolist() == b1.multi_exp(s[:n]).tolist() and o2.tolist() == b2.multi_exp(s[:n]).tolist(), n
+        if n in (300, 1 << 15):
+            # both handles on fixed-base tables of one geometry: the tables' sort once, each handle's sums on its own tables; tables of
+            # different geometries (or on one handle only): the per-window path, the same points
+            for c1, c2 in ((13, 13), (20, 20), (13, 16), (0, -1)):
+                b1.precompute(c1)
+                b2.precompute(c2)
+                f1, f2 = gk.multi_exp_g1_g2(b1, b2, s[:n])
+                assert f1.tolist() == o1.tolist() and f2.tolist() == o2.tolist(), (n, c1, c2)
+                m = n // 3
+                h1, h2 = gk.multi_exp_g1_g2(b1, b2, s[:m])
+                assert h1.tolist() == b1.multi_exp(s[:m]).tolist() and h2.tolist() == b2.multi_exp(s[:m]).tolist(), (n, c1, c2)
+            b1.precompute(-1)
+            b2.precompute(-1)
         if n == 300:
             assert o1.tolist() == c.g1_msm(b1.read(0, n), s).tolist()
             tot = sum(x * y for x, y in zip(ints(k), ints(s))) % Q

@@ -1,7 +1,7 @@
 """The device side of ComputeGroth16Proof (prover/gadget/prove.go:100-306) at one size: computeH, then the MSMs over pk.G1.A,
 pk.G1.B, pk.G1.Z (with h), pk.privKNotGkr and pk.G2.B -- one after the other and from five host threads at once (every call
 leases a lane of its own).  Bases resident, scalars from host memory; synthetic data ([k_i]G bases, random scalars).
-python tools/groth16_backhalf.py [logn]"""
+python tools/groth16_backhalf.py [logn] [--fixed-base]"""
 import importlib
 import os
 import sys
@@ -16,6 +16,8 @@ gk.init(0)
 gk.reserve_lanes(5)      # the five calls at once lease a lane each
 G1 = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f,
                0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
+FIXED_BASE = "--fixed-base" in sys.argv      # round 6: every key vector on fixed-base tables (gkrhip_msm_g1_precompute / _g2_precompute)
+sys.argv = [a for a in sys.argv if a != "--fixed-base"]
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 n = 1 << logn
 rng = np.random.default_rng(1)
@@ -30,6 +32,11 @@ def rnd():
 k = rnd()
 bases = {name: gk.G1Bases(base=G1, scalars=k) for name in ("A", "B1", "Z", "K")}
 b2 = gk.G2Bases(base=gk.g2_generator(), scalars=k)
+if FIXED_BASE:
+    t0 = time.perf_counter()
+    for h in list(bases.values()) + [b2]:
+        h.precompute(0)
+    print("fixed-base tables of the five key vectors: %.0f ms (once per key)" % (1e3 * (time.perf_counter() - t0)))
 wires, a, b, c = rnd(), rnd(), rnd(), rnd()
 jobs = {
     "computeH + krs2 (pk.G1.Z)": lambda: bases["Z"].compute_h_multi_exp(a, b, c),
