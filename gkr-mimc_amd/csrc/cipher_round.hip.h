@@ -98,31 +98,6 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a
     eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// Per-round iteration weights (round 6, the thread policy for many proofs in flight: host_sumcheck.hip.h, threads_log2): a round
-// that runs on fewer lanes than the layer's pyramids were split for takes its 2^lj weights eq(q[k+1 .. k+lj], j) -- lj <= 5 --
-// from this table instead: one tiny launch per layer, workgroup r = one round, lane j = one entry (and its 2^-128 image).
-struct RoundTablesArgs {
-    Planes out, out2;              // entry j of round r at off[r] + j
-    const Fr* q;
-    int nrounds;
-    unsigned char k[32], lj[32];   // the round, log2 of its iterations
-    unsigned short off[32];
-};
-GKR_KERNEL void __launch_bounds__(64) k_eq_round_tables(RoundTablesArgs a) {
-    const int r = blockIdx.x, lj = a.lj[r];
-    const unsigned int j = threadIdx.x;
-    if (j >= (1u << lj)) return;
-    const Fr one = fr_one();
-    const Fr two128 = {{0u, 0u, 0u, 0u, 1u, 0u, 0u, 0u}};
-    Fr cur = one;
-    for (int s = 1; s <= lj; s++) {          // bit s-1 of j <-> q[k + lj + 1 - s] (as eq_suffix_pyramid_body with nc = k + lj + 1)
-        const Fr qc = a.q[a.k[r] + lj + 1 - s];
-        cur = fr_mul(cur, ((j >> (s - 1)) & 1u) ? qc : fr_sub(one, qc));
-    }
-    st_fr(a.out.lo, a.out.hi, (size_t)a.off[r] + j, cur);
-    st_fr(a.out2.lo, a.out2.hi, (size_t)a.off[r] + j, fr_mul(cur, two128));
-}
-
 // ------------------------------------------------------------------------------------------------
 // the round kernel
 // ------------------------------------------------------------------------------------------------

@@ -442,14 +442,6 @@ int gkrhip_set_option(const char* key, long value) {
         g_wait_override.store((int)std::max(-2L, value));
         return 0;
     }
-    if (!strcmp(key, "fat_lj")) {               // host_ctx.hip.h: 2^n pairs per lane from round 1 on when many proofs are in flight (0: off)
-        g_fat_lj.store((int)std::max(0L, std::min(5L, value)));
-        return 0;
-    }
-    if (!strcmp(key, "fat_from")) {
-        g_fat_from.store((int)std::max(1L, value));
-        return 0;
-    }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
         g_msm_sort_levels.store((int)value);
         return 0;

@@ -284,10 +284,6 @@ inline int round_threads_log2_max() {
     if (!cx().g_max_auto) return cx().g_max;
     return g_proofs_in_flight.load(std::memory_order_relaxed) >= 10 ? 15 : 16;
 }
-// Round kernels on few, fat lanes when many proofs are in flight (host_sumcheck.hip.h: CipherLoop::threads_log2): from `fat_from`
-// proofs in flight on, rounds 1.. run with 2^fat_lj pairs per lane.  Options "fat_lj" (0: off), "fat_from".
-std::atomic<int> g_fat_lj{0};
-std::atomic<int> g_fat_from{10};
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }
     ~ProofInFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); }

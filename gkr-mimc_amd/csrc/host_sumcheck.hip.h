@@ -696,26 +696,16 @@ struct CipherLoop {
           spec_seq((size_t)m_ + 2, 0u) {}
 
     void release_tables() {      // the stream is idle (run_rounds synchronised it)
-        for (ScopedTable* t : {&pyrT, &pyrH, &pyrU[0], &pyrU[1], &pyrU2[0], &pyrU2[1], &ks, &ss, &ks2, &ss2, &rtab, &rtab2})
+        for (ScopedTable* t : {&pyrT, &pyrH, &pyrU[0], &pyrU[1], &pyrU2[0], &pyrU2[1], &ks, &ss, &ks2, &ss2})
             if (t->base) table_release(t);
     }
     // Threads of a round = 2^g.  With other proofs in flight 2^g_max threads (one workgroup per CU) is best: the other lanes'
     // kernels fill the second wave slot.  A proof that is alone on the GPU gets twice the threads for the rounds that still
     // have two pairs per lane, and runs the round with 2^g_big pairs one pair per lane (two waves per SIMD).
-    // Many proofs in flight (round 6): the GPU is then bound by workgroup slots, and a round kernel's fixed cost per lane -- its
-    // pyramid loads, seven reductions with the lane weight, the block reduction, the atomics -- is paid per workgroup slot: from
-    // round 1 on a round runs on as few lanes as give every lane 2^fat_lj pairs (16), down to one workgroup.  Rounds whose lane
-    // count differs from the pyramids' split take their iteration weights from a per-layer table (k_eq_round_tables).
-    int fat_lj = 0;                                  // 0: off
     int threads_log2(int k) const {
         const int rem = m - 1 - k;                     // log2(pairs of the round)
-        const int g = rem >= g_big ? g_big : std::min(g_m, rem);
-        if (fat_lj > 0 && k >= 1) return std::min(g, std::max(std::min(rem, 8), rem - fat_lj));
-        return g;
+        return rem >= g_big ? g_big : std::min(g_m, rem);
     }
-    ScopedTable rtab, rtab2;                         // the per-round iteration weights and their 2^-128 images
-    unsigned short rtab_off[32] = {0};
-    bool rtab_has[32] = {false};
     volatile unsigned int* spec_flag(int k) const {
         return (volatile unsigned int*)(cx().h_spec + (size_t)(k & 1) * GKR_SPEC_BUF_WORDS + GKR_SPEC_FLAG_WORD);
     }
@@ -732,10 +722,6 @@ struct CipherLoop {
                           (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
         g_m = round_threads_log2_max();                // fixed for the layer: the number of proofs in flight may change under it
         g_big = solo ? std::min(g_m + 1, 17) : g_m;
-        {
-            const int want = g_fat_lj.load(std::memory_order_relaxed), from = g_fat_from.load(std::memory_order_relaxed);
-            fat_lj = (want > 0 && !collective && m <= 31 && g_proofs_in_flight.load(std::memory_order_relaxed) >= from) ? std::min(want, 5) : 0;
-        }
         const int gT = std::max(threads_log2(0), std::min(g_m, m - 1));   // highest level of the per-lane pyramid
         LAP("setup: enter");
         CHK(stage_coords(q, (size_t)m));
@@ -795,31 +781,6 @@ struct CipherLoop {
             hipLaunchKernelGGL(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
             HIPCHK(hipGetLastError());
         }
-        if (fat_lj > 0) {
-            RoundTablesArgs ra;
-            memset(&ra, 0, sizeof ra);
-            unsigned int nxt = 0;
-            for (int k = 1; k < m; k++) {
-                const int gk = threads_log2(k), lj = m - 1 - k - gk;
-                if (lj <= 0 || gk == gsplit[0] || gk == gsplit[1]) continue;      // (no iteration weight, or the pyramids' own split)
-                ra.k[ra.nrounds] = (unsigned char)k;
-                ra.lj[ra.nrounds] = (unsigned char)lj;
-                ra.off[ra.nrounds] = (unsigned short)nxt;
-                rtab_off[k] = (unsigned short)nxt;
-                rtab_has[k] = true;
-                nxt += 1u << lj;
-                ra.nrounds++;
-            }
-            if (ra.nrounds) {
-                CHK(table_alloc(&rtab, std::max<size_t>(nxt, 1)));
-                CHK(table_alloc(&rtab2, std::max<size_t>(nxt, 1)));
-                ra.out = rtab.planes();
-                ra.out2 = rtab2.planes();
-                ra.q = cx().d_q;
-                hipLaunchKernelGGL(k_eq_round_tables, dim3(ra.nrounds), dim3(64), 0, cx().stream, ra);
-                HIPCHK(hipGetLastError());
-            }
-        }
         LAP("setup: pyramid launches");
         CHK(rounds_begin(collective));
         pl = plan_rounds(m, collective, gamma_tail, did_gamma, 2, g_proofs_in_flight.load(std::memory_order_relaxed) <= 1 ? cx().host_tail_solo : cx().host_tail);
@@ -853,10 +814,7 @@ struct CipherLoop {
         a.s_dst = ss.planes();
         const size_t offT = ((size_t)1 << gk) - 1;
         a.wt = CPlanes{pyrT.base + offT, pyrT.base + pyrT.cap + offT};
-        if (lj > 0 && rtab_has[k]) {                      // a round on fewer lanes than the pyramids' split: its own weights
-            a.wj = CPlanes{rtab.base + rtab_off[k], rtab.base + rtab.cap + rtab_off[k]};
-            a.wj2 = CPlanes{rtab2.base + rtab_off[k], rtab2.base + rtab2.cap + rtab_off[k]};
-        } else if (lj > 0) {
+        if (lj > 0) {
             const DevTable& pu = pyrU[gk == gsplit[0] ? 0 : 1];
             const size_t offU = ((size_t)1 << lj) - 1;
             a.wj = CPlanes{pu.base + offU, pu.base + pu.cap + offU};

@@ -342,19 +342,6 @@ def test_round_kernel_small_thread_budget(gk):
     _run_case({"GKRHIP_GMAX": "10"}, "11,12,14")
 
 
-def test_round_kernels_on_few_fat_lanes(gk):
-    """Round 6: with many proofs in flight a round from round 1 on runs on as few lanes as give every lane 2^fat_lj pairs, and takes
-    its iteration weights from a per-layer table (k_eq_round_tables).  Forced on for a proof alone (fat_from = 1), every fat_lj, with
-    and without the host tail, early and late lane weights, MiMC and GMiMC (whose add layers keep their own policy), several sessions."""
-    for lj in ("1", "3", "4", "5"):
-        _run_case({"GKR_CASE_OPTIONS": "fat_lj=%s,fat_from=1" % lj}, "9,12,14,15")
-    _run_case({"GKR_CASE_OPTIONS": "fat_lj=4,fat_from=1", "GKRHIP_HOST_TAIL": "0"}, "10,13")
-    _run_case({"GKR_CASE_OPTIONS": "fat_lj=4,fat_from=1,wt_late_lj=99", "GKRHIP_GMAX": "10"}, "12,15")
-    _run_case({"GKR_CASE_OPTIONS": "fat_lj=2,fat_from=1,claim_trick=0", "GKRHIP_PRELAUNCH": "2", "GKRHIP_SPEC": "0"}, "11,13")
-    _run_case({"GKR_CASE_OPTIONS": "fat_lj=4,fat_from=1"}, "10,13", circuit="gmimc")
-    _run_case({"GKR_CASE_OPTIONS": "fat_lj=4,fat_from=1", "GKRHIP_CASE_SESSIONS": "3"}, "12,14")
-
-
 def test_eq_pyramid_in_two_launches(gk):
     """The per-lane eq pyramid built in two launches (levels up to 2^n entries with short chains, the upper levels with one
     product per entry from a small second pyramid) and in one: same weights, same transcript, for splits below, at and above
