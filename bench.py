@@ -776,6 +776,10 @@ def main():
             emit({"error": "gkrhip_init: %s" % e})
         raise
 
+    # A/B runs: library options (not environment switches of the library) from the harness, "key=value,key=value"
+    for kv in filter(None, os.environ.get("GKRHIP_BENCH_OPTIONS", "").split(",")):
+        gk.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+
     import numpy as np
     gamma = world.bit_length() - 1 if dist is not None else 0
     if dist is not None and (1 << gamma) != world:
