@@ -571,7 +571,9 @@ int run_rounds(L& lp, const RoundPlan& pl, double t_setup0) {
             CHK(lp.launch_spec(k + 2));                          // one by one, two rounds ahead: it polls for r_k
         }
         // the next layer's q-independent round-0 products, on the look-ahead stream, once this layer's rounds are small
-        if (pre_requested && k >= 1 && (P <= ((size_t)1 << cx().pre_start_lg) || k == pl.m_dev - 1)) {
+        // (from 2^24 entries on one round earlier: 2^24 alone 263.5 -> 260.6 ms with the start at 2^21 pairs, 2^23 181.6 / 181.9 / 180.9 with
+        // 20 / 21 / 19: profiles/r06_pre_start_ab.txt)
+        if (pre_requested && k >= 1 && (P <= ((size_t)1 << (cx().pre_start_lg + std::max(0, m - 23))) || k == pl.m_dev - 1)) {
             CHK(launch_pre());
             pre_requested = false;
         }
