@@ -1080,6 +1080,56 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_fb_lv_offsets(FbSortArgs a) {
         run += x;
     }
 }
+// The same for a level with FEW input bins of MANY slices (level 2: <= 128 bins of ~200 slices at 2^24 points): one workgroup per
+// input bin, the bin's slices dealt to 1024 / 2^bits parts per output bin, so that a lane walks nsl / parts slices instead of all
+// (one lane per output bin walking them all, the kernel above: 0.55 ms of a 3.4 ms sort -- 400 dependent loads in a row).
+GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_fb_lv_offsets_bin(FbSortArgs a) {
+    __shared__ unsigned int psum[MSM_SCAN_THREADS];      // [part][low]: the part's count, then its exclusive prefix over the parts
+    __shared__ unsigned int base[MSM_REFINE_MAXLOW];     // output bin's first position
+    const unsigned int bin = blockIdx.x, nlow = 1u << a.bits, low = threadIdx.x & (nlow - 1u), part = threadIdx.x >> a.bits;
+    const unsigned int nparts = MSM_SCAN_THREADS >> a.bits;
+    const unsigned int cb = a.in_count[bin], nsl = (cb + a.slice_len - 1) / a.slice_len, k0 = nsl ? a.in_first[bin] : 0u;
+    const unsigned int per = (nsl + nparts - 1) / nparts, s_lo = min(nsl, part * per), s_hi = min(nsl, s_lo + per);
+    unsigned int mine = 0;
+    for (unsigned int sl = s_lo; sl < s_hi; sl++) mine += a.slice_hist[(size_t)(k0 + sl) * nlow + low];
+    psum[threadIdx.x] = mine;
+    __syncthreads();
+    if (part == 0) {                                     // exclusive prefix over the parts of this output bin (<= 8 parts at 128 bins)
+        unsigned int run = 0;
+        for (unsigned int p = 0; p < nparts; p++) {
+            const unsigned int x = psum[p * nlow + low];
+            psum[p * nlow + low] = run;
+            run += x;
+        }
+        base[low] = run;                                 // the output bin's size, for now
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                              // exclusive prefix over the <= 128 output bins of this input bin
+        unsigned int run = a.in_offset[bin];
+        for (unsigned int l = 0; l < nlow; l++) {
+            const unsigned int c = base[l];
+            const size_t t = ((size_t)bin << a.bits) | l;
+            a.out_count[t] = c;
+            a.out_offset[t] = run;
+            if (c > a.next_threshold) {
+                const unsigned int nseg = (c + a.next_seg - 1) / a.next_seg;
+                const unsigned int b0 = atomicAdd(&a.next_list[0], nseg);
+                for (unsigned int sg = 0; sg < nseg && b0 + sg < a.next_cap; sg++) a.next_list[1 + b0 + sg] = (unsigned int)t | (sg << a.next_id_bits);
+                if (a.out_first) a.out_first[t] = b0;
+            }
+            base[l] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    unsigned int run = base[low] + psum[threadIdx.x];
+    for (unsigned int sl = s_lo; sl < s_hi; sl++) {
+        unsigned int* p = &a.slice_hist[(size_t)(k0 + sl) * nlow + low];
+        const unsigned int x = *p;
+        *p = run;
+        run += x;
+    }
+}
 GKR_KERNEL void __launch_bounds__(FB_LV_THREADS) k_fb_lv_scatter(FbSortArgs a) {
     __shared__ FbStage<FB_LV_THREADS> sh;
     unsigned int bin, lo, hi;

@@ -568,7 +568,7 @@ int msm_fb_sort_dev(MsmBases* b, const uint4* d_scalars, size_t n, int flags, Ms
         s2.next_id_bits = std::max(f.bits1 + f.bits2, 1);
         s2.err = a.err;
         hipLaunchKernelGGL(k_fb_lv_count, dim3(f.cap1), dim3(FB_LV_THREADS), 0, st, s2);
-        hipLaunchKernelGGL(k_fb_lv_offsets, dim3((unsigned)((nb2 + GKR_BLOCK - 1) / GKR_BLOCK)), dim3(GKR_BLOCK), 0, st, s2);
+        hipLaunchKernelGGL(k_fb_lv_offsets_bin, dim3((unsigned)nb1), dim3(MSM_SCAN_THREADS), 0, st, s2);      // few bins, many slices each
         hipLaunchKernelGGL(k_fb_lv_scatter, dim3(f.cap1), dim3(FB_LV_THREADS), 0, st, s2);
         FbSortArgs s3;
         memset(&s3, 0, sizeof s3);
