@@ -376,8 +376,8 @@ int msm_check_points(const uint64_t* points, size_t n, int w16) {
 
 // ---- fixed-base path ---------------------------------------------------------------------------------------------------
 // window size of the one bucket space: 13 n additions at c = 20, 12 n at c = 22 (against 16 n), the reduction over 2^(c-1) buckets once
-// (measured, profiles/r06_msm_fixed_base.txt, fixed-base c = 20 / c = 22 / per-window: 2^20 points 2.07 / 2.36 / 2.21 ms, 2^22 6.35 / 6.19 /
-// 6.85, 2^23 12.1 / 11.5 / 13.7, 2^24 23.0 / 20.8 / 26.7, 2^25 45.1 / 40.3 / 52.0)
+// (measured, profiles/r06_msm_fixed_base.txt, fixed-base c = 20 / c = 22 / per-window: 2^20 points 2.03 / 2.36 / 2.22 ms, 2^22 6.24 / 6.12 /
+// 6.87, 2^23 11.7 / 11.3 / 13.3, 2^24 21.9 / 20.4 / 25.8, 2^25 42.8 / 38.6 / 50.2)
 inline int msm_fb_pick_c(size_t n) { return n >= ((size_t)1 << 22) ? 22 : n >= ((size_t)1 << 17) ? 20 : 16; }
 // tables and buffers; the tables are computed here (one lane per point: c doublings and an inversion per table entry)
 template <class F>
