@@ -972,7 +972,7 @@ GKR_KERNEL void __launch_bounds__(MSM_SCAN_THREADS) k_fb_l1_offsets(FbSortArgs a
     a.out_first[b] = k0;
 }
 // level 1: the chunk again, staged scatter: entry = table index | sign << 31, key = the bucket bits below the bin's
-#define FB_L1_SCATTER_THREADS 1024     // (its staging area with the keys beside the entries: 76 KB, two workgroups per CU; batches of 8192 entries)
+#define FB_L1_SCATTER_THREADS 512      // (its staging area with the keys beside the entries: 38 KB; at most 512 bins -- level 1 has <= 128.  1024 lanes and 76 KB: measured slower, 3.55 against 3.32 ms of sort at 2^24 points)
 GKR_KERNEL void __launch_bounds__(FB_L1_SCATTER_THREADS) k_fb_l1_scatter(FbSortArgs a) {
     __shared__ FbStage<FB_L1_SCATTER_THREADS> sh;
     const unsigned int j = blockIdx.x, k = blockIdx.y;
@@ -1004,7 +1004,7 @@ GKR_KERNEL void __launch_bounds__(FB_L1_SCATTER_THREADS) k_fb_l1_scatter(FbSortA
 }
 // levels 2 and 3
 #ifndef FB_LV_THREADS
-#define FB_LV_THREADS 1024     // lanes of a slice's workgroup: one batch of 8192 entries per slice, 64 per bin (256-byte runs)
+#define FB_LV_THREADS 512      // lanes of a slice's workgroup: batches of 4096 entries, 32 per bin (128-byte runs)
 #endif
 __device__ __forceinline__ bool fb_slice_range(const FbSortArgs& a, unsigned int* bin, unsigned int* lo, unsigned int* hi) {
     if (blockIdx.x >= min(a.slices[0], a.slice_cap)) return false;
