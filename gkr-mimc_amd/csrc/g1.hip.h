@@ -765,8 +765,8 @@ GKR_KERNEL void __launch_bounds__(MSM_SORT_THREADS) k_msm_order(MsmArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Fixed-base MSM (round 6).  The bases of the reference's MSMs are proving-key vectors, fixed across proofs (prove.go:76,91,189,
-// 202,221,277 all name pk.*): with the multiples T_j[i] = [2^(c j)] P_i computed ONCE (k_msm_fb_precompute; W x the key's size in
-// HBM), window j of scalar i contributes d_ij * T_j[i] and every window shares ONE bucket space -- so the window can be wide
+// 202,221,277 all name pk.*): with the multiples T_j[i] = [2^(o_j)] P_i (o_j: the first bit of window j) computed ONCE (k_msm_fb_precompute;
+// W x the key's size in HBM), window j of scalar i contributes d_ij * T_j[i] and every window shares ONE bucket space -- so the window can be wide
 // (c = 20..22: 13 or 12 additions per scalar instead of 16) without paying 2^(c-1) buckets per window in the reduction.  The sort
 // then has 21-bit keys and 28-bit table indices, which the counting sort above (16-bit digit planes, 32-bit entries with the low
 // bucket bits inside) does not hold: three levels of the same LDS counting sort follow (FbSortArgs).  Bucket sums, big buckets
