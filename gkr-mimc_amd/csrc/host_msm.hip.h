@@ -378,12 +378,17 @@ int msm_check_points(const uint64_t* points, size_t n, int w16) {
 // window size of the one bucket space: 13 n additions at c = 20, 12 n at c = 22 (against 16 n), the reduction over 2^(c-1) buckets once
 // (measured, profiles/r06_msm_fixed_base.txt, fixed-base c = 20 / c = 22 / per-window: 2^20 points 2.03 / 2.36 / 2.22 ms, 2^22 6.24 / 6.12 /
 // 6.87, 2^23 11.7 / 11.3 / 13.3, 2^24 21.9 / 20.4 / 25.8, 2^25 42.8 / 38.6 / 50.2)
-inline int msm_fb_pick_c(size_t n) { return n >= ((size_t)1 << 22) ? 22 : n >= ((size_t)1 << 17) ? 20 : 16; }
+// G2 (w16 = 4: the reduction over 2^21 buckets of Fp2 points is 3.4 ms): c = 20 / c = 22 / per-window 2^20 points 6.00 / 7.40 / 6.66 ms,
+// 2^21 9.76 / 10.75 / 11.14, 2^22 16.3 / 17.4 / 19.7, 2^23 29.75 / 29.81 / 36.3
+inline int msm_fb_pick_c(size_t n, int w16) {
+    const size_t from22 = (size_t)1 << (w16 == 4 ? 24 : 22);
+    return n >= from22 ? 22 : n >= ((size_t)1 << 17) ? 20 : 16;
+}
 // tables and buffers; the tables are computed here (one lane per point: c doublings and an inversion per table entry)
 template <class F>
 int msm_fb_prepare(MsmBases* b, int c_or_0) {
     const size_t n = std::max<size_t>(b->n, 1);
-    const int c = c_or_0 > 0 ? c_or_0 : msm_fb_pick_c(n);
+    const int c = c_or_0 > 0 ? c_or_0 : msm_fb_pick_c(n, b->w16);
     if (c < 8 || c > MSM_LIST_ID_BITS + 1) return fail("msm: fixed-base window size %d outside 8..%d", c, MSM_LIST_ID_BITS + 1);
     MsmFixedBase& f = b->fb;
     if (f.tables && f.c == c) return 0;

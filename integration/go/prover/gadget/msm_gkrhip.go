@@ -28,11 +28,11 @@ var (
 // FixedBaseFromG1 / FixedBaseFromG2: key vectors of at least this many points get fixed-base tables when they are uploaded
 // (gkrhip_msm_g1_precompute / _g2_precompute: the window multiples of every point once, 12-13 x the vector's size in HBM; then 12
 // or 13 additions per scalar instead of 16).  Measured on one MI355X: G1 pays from 2^18 points (2^22: 6.85 -> 6.19 ms, 2^24:
-// 26.7 -> 20.8), G2 from 2^21 (2^22: 19.7 -> 17.1); the back half of ComputeGroth16Proof at 2^22: 75.5 -> 62.6 ms.
+// 26.7 -> 20.8), G2 from 2^20 (2^22: 19.7 -> 16.3); the back half of ComputeGroth16Proof at 2^22: 75.5 -> 62.6 ms.
 // 0 switches the tables off (the vector itself only: 64 / 128 bytes per point).
 var (
 	FixedBaseFromG1 = 1 << 18
-	FixedBaseFromG2 = 1 << 21
+	FixedBaseFromG2 = 1 << 20
 )
 
 // g1BasesOf returns the device-resident copy of a proving-key vector, uploading it on first use.
