@@ -92,7 +92,7 @@ def cpu_baseline(target_seconds=40.0):
                       "multiplication alone; not the Go binary" % (b, secs)}
 
 
-SUMMARY_KEYS = ("bn20", "gmimc_bn22", "oneshot_s", "msm_g1_2p20_ms", "msm_g1_2p22_ms", "msm_g1_2p24_ms", "msm_g1_fixed_base_ms", "msm_g2_2p22_ms", "compute_h_2p24_ms", "fold_frac_of_hbm_peak", "partial_eval_frac_of_issue_ceiling", "layer_checks",
+SUMMARY_KEYS = ("bn20", "gmimc_bn22", "oneshot_s", "msm_g1_2p20_ms", "msm_g1_2p22_ms", "msm_g1_2p24_ms", "msm_g1_fixed_base_ms", "msm_g2_2p22_ms", "msm_g2_fixed_base_2p22_ms", "compute_h_2p24_ms", "fold_frac_of_hbm_peak", "partial_eval_frac_of_issue_ceiling", "layer_checks",
                 "layer_check_failures", "chal_retries", "bench_attempts")
 
 
@@ -117,6 +117,7 @@ def config_summary(out):
     fb = {("2p%d" % lg): r(mi["msm_g1_fixed_base_2p%d" % lg]["ms"]) for lg in (20, 22, 24) if mi.get("msm_g1_fixed_base_2p%d" % lg)}
     sm["msm_g1_fixed_base_ms"] = fb or None
     sm["msm_g2_2p22_ms"] = r(mi["msm_g2_2p22"]["ms"]) if mi.get("msm_g2_2p22") else None
+    sm["msm_g2_fixed_base_2p22_ms"] = r(mi["msm_g2_fixed_base_2p22"]["ms"]) if mi.get("msm_g2_fixed_base_2p22") else None
     sm["compute_h_2p24_ms"] = r(mi["compute_h_2p24"]["ms"]) if mi.get("compute_h_2p24") else None
     sm["fold_frac_of_hbm_peak"] = r((out.get("roofline") or {}).get("frac"), 4)
     sm["partial_eval_frac_of_issue_ceiling"] = r((out.get("partial_eval") or {}).get("frac"), 4)
@@ -1231,6 +1232,12 @@ def main():
                                          "mirrors": "(*G2Jac).MultiExp(points, scalars, cfg) (prover/gadget/prove.go:277): 2^%d random points [k_i]G2, "
                                                     "random scalars; the same kernels as G1 over Fp2 coordinates (a mixed addition is 28 Fp products "
                                                     "instead of 10)" % lg}
+        for lg in (20, 22):      # G2 on fixed-base tables (c = 20 up to 2^23 points)
+            r = gk.bench_msm_g2_fixed_base(lg, warmup=1, iters=3)
+            micro["msm_g2_fixed_base_2p%d" % lg] = {"ms": r["ms"], "points_per_s": float(1 << lg) / (r["ms"] * 1e-3), "window_bits": r["c"],
+                                                    "windows": -(-255 // r["c"]), "phases_ms": r["phases_ms"], "host_tail_ms": r["host_tail_ms"],
+                                                    "precompute_ms": r["precompute_ms"], "vs_per_window_sort": r["ms"] / micro["msm_g2_2p%d" % lg]["ms"],
+                                                    "mirrors": "(*G2Jac).MultiExp(pk.G2.B, scalars, cfg) (prove.go:277) with the key's points fixed across proofs"}
         ms, npass, by = gk.bench_compute_h(24, warmup=1, iters=3)
         # issue ceiling from the ISA of this build: the innermost loop of the tile kernels is one sub-pass of two stages on a lane's
         # four elements (four butterflies with their LDS traffic and twiddle loads); 4 inverse DIF and 3 forward DIT transforms
