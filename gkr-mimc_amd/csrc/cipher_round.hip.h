@@ -26,6 +26,20 @@
 #define GKR_CR_WORDS (GKR_CR_NSUM * GKR_ACC_WORDS)
 
 // ------------------------------------------------------------------------------------------------
+// Proof groups (host_group.hip.h): the kernels of a layer's rounds take the arguments of up to GKR_GROUP_MAX proofs of the same
+// shape that one host thread proves in lock-step -- blockIdx.z selects the proof, every workgroup works for exactly one.  The
+// proofs share nothing (tables, accumulators, counters, hand-off words and flags are the proof's own); what they share is the
+// launch: at 2^20 entries a proof is ~1 700 launches of mostly tiny kernels, and the GPU's dispatch of such launches from many
+// queues -- not its arithmetic -- is what bounds many small proofs in flight (profiles/r04_bn20_plateau.txt).  One proof alone
+// is a group of one (inst[0], grid.z = 1).  By value: the whole batch is kernel-argument memory (8 x 400 bytes at most; scalar
+// loads at a uniform offset, no scratch).
+// ------------------------------------------------------------------------------------------------
+#define GKR_GROUP_MAX 8
+template <class A>
+struct Batch {
+    A inst[GKR_GROUP_MAX];
+};
+// ------------------------------------------------------------------------------------------------
 // suffix pyramid: level s (s = 0..max_level) is the table eq(q[nc-s .. nc-1], .) of 2^s entries,
 // stored at element offset 2^s - 1.  Thread idx computes the running product over its low bits
 // (LSB <-> q[nc-1]) and writes level s when idx < 2^s.  max_level muls per thread, no dependencies
@@ -76,7 +90,8 @@ struct PyramidExpandArgs {
     CPlanes h;           // H pyramid (levels 1 .. hi_level - lo_level)
     int lo_level, hi_level;
 };
-GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandArgs a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(Batch<PyramidExpandArgs> ba) {
+    const PyramidExpandArgs& a = ba.inst[blockIdx.z];
     // a few products per lane in front of a layer's first round: ahead of the other lanes' big rounds on a shared SIMD (same-box
     // A/B, profiles/r05_prio_pyramids.txt: bN = 20 x 24 lanes +0.7 %, bN = 24 x 5 +0.5 %, GMiMC bN = 22 x 12 +1.0 %)
     __builtin_amdgcn_s_setprio(3);
@@ -91,9 +106,9 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(PyramidExpandAr
         st_fr(a.out.lo, a.out.hi, (((size_t)1 << s) - 1) + idx, fr_mul(base, hv));
     }
 }
-GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(PyramidArgs3 a) {
+GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(Batch<PyramidArgs3> ba) {
     __builtin_amdgcn_s_setprio(3);      // (as k_eq_pyramid_expand)
-    const PyramidArgs& p = a.p[blockIdx.y];
+    const PyramidArgs& p = ba.inst[blockIdx.z].p[blockIdx.y];
     if (p.max_level < 0) return;
     eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -390,12 +405,12 @@ __device__ __forceinline__ void cipher_round_body(const CipherRoundArgs& a) {
 }
 
 template <bool FOLD, bool HAS_WJ>
-__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(CipherRoundArgs a) {
-    cipher_round_body<FOLD, HAS_WJ, false>(a);
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round(Batch<CipherRoundArgs> ba) {
+    cipher_round_body<FOLD, HAS_WJ, false>(ba.inst[blockIdx.z]);
 }
 template <bool FOLD, bool HAS_WJ>
-__global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(CipherRoundArgs a) {
-    cipher_round_body<FOLD, HAS_WJ, true>(a);
+__global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(Batch<CipherRoundArgs> ba) {
+    cipher_round_body<FOLD, HAS_WJ, true>(ba.inst[blockIdx.z]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,7 +549,8 @@ __device__ __forceinline__ void wide_lds_store(WideShared& sh, int slot, const u
 // everywhere: bN = 20 x 24 / x 56 lanes -8.6 / -9.3 %, GMiMC bN = 22 x 12 -5.5 %, bN = 24 x 5 -6.4 %, one proof alone 2-6 % slower
 // (profiles/r06_occupancy_ab.txt, commit 69ae821 has the variant and the switch).  Two waves, nothing spilled, stays.)
 template <bool FOLD, bool WT_LATE, bool PRE = false, bool AHEAD = false>
-__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(CipherRoundArgs a) {
+__global__ void __launch_bounds__(GKR_BLOCK, 2) k_cipher_round_wide(Batch<CipherRoundArgs> ba) {
+    const CipherRoundArgs& a = ba.inst[blockIdx.z];
     static_assert(!(FOLD && PRE), "the precomputed products exist for round 0 only");
     static_assert(!AHEAD || (WT_LATE && !FOLD), "round 0 ahead of its point: late lane weights, no fold");
     round_wave_priority(a.prio);

@@ -51,6 +51,7 @@ namespace {
 #include "host_ctx.hip.h"
 #include "host_gates.hip.h"
 #include "host_coll.hip.h"
+#include "host_group.hip.h"
 #include "host_sumcheck.hip.h"
 #include "host_circuit.hip.h"
 #include "host_ntt.hip.h"
@@ -844,6 +845,75 @@ int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_
     const int rc = session_prove(s, (const E*)qprime, (E*)flat);
     if (rc != 0) shm_abort();     // a sharded proof that fails on this rank must not leave the peers waiting
     return rc;
+}
+
+// gkr.Prove for n sessions of the same shape from ONE host thread, in lock-step (host_group.hip.h): every proof is the proof
+// gkrhip_mimc_session_prove returns for its session and point -- same transcript, bit for bit -- but the round kernels of the n
+// proofs go to the GPU as one launch.  For many small proofs in flight (BASELINE config 2: bN = 20): a quarter of the launches,
+// each with four times the work, where the dispatch of tiny kernels is the bound.  Sessions with lanes of their own (un-sharded),
+// all different; rcs[i] (may be NULL) receives proof i's code; returns 0 or the first failing proof's code.
+int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint64_t* const* qprimes, uint64_t* const* flats, int* rcs) {
+    if (n < 1 || n > GKR_GROUP_MAX) return fail("prove_group: %d proofs (1..%d)", n, GKR_GROUP_MAX);
+    if (!ss || !qprimes || !flats) return fail("prove_group: null argument");
+    for (int i = 0; i < n; i++) {
+        if (!ss[i] || !ss[i]->lane) return fail("prove_group: null session (%d)", i);
+        if (ss[i]->lane == &g0) return fail("prove_group: session %d is sharded (it proves on the default lane, with its peers)", i);
+        if (!flats[i] || (ss[i]->bN > 0 && !qprimes[i])) return fail("prove_group: null buffer (%d)", i);
+        for (int j = 0; j < i; j++)
+            if (ss[j] == ss[i]) return fail("prove_group: session %d is given twice", i);
+    }
+    HIPCHK(hipSetDevice(g0.device));
+    // every lane's mutex, in address order (two groups over the same sessions cannot deadlock)
+    std::vector<Ctx*> lanes(n);
+    for (int i = 0; i < n; i++) lanes[i] = ss[i]->lane;
+    std::vector<Ctx*> order(lanes);
+    std::sort(order.begin(), order.end());
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (Ctx* l : order) locks.emplace_back(l->mu);
+    // the group queues on the first lane's streams; what a lane has in its own stream is waited for first
+    struct StreamSwap {
+        std::vector<Ctx*>& lanes;
+        std::vector<std::pair<hipStream_t, hipStream_t>> own;
+        bool swapped = false;
+        explicit StreamSwap(std::vector<Ctx*>& l) : lanes(l) {}
+        ~StreamSwap() {
+            if (!swapped) return;
+            (void)hipStreamSynchronize(lanes[0]->stream);
+            if (lanes[0]->aux) (void)hipStreamSynchronize(lanes[0]->aux);
+            for (size_t i = 0; i < lanes.size(); i++) {
+                lanes[i]->stream = own[i].first;
+                lanes[i]->aux = own[i].second;
+            }
+        }
+    } sw(lanes);
+    for (int i = 1; i < n; i++) {
+        HIPCHK(hipStreamSynchronize(lanes[i]->stream));
+        if (lanes[i]->aux) HIPCHK(hipStreamSynchronize(lanes[i]->aux));
+    }
+    for (int i = 0; i < n; i++) sw.own.emplace_back(lanes[i]->stream, lanes[i]->aux);
+    for (int i = 1; i < n; i++) {
+        lanes[i]->stream = lanes[0]->stream;
+        lanes[i]->aux = lanes[0]->aux;
+    }
+    sw.swapped = true;
+    Group g;
+    g.proofs.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        gkrhip_session* s = ss[i];
+        const E* q = (const E*)qprimes[i];
+        E* flat = (E*)flats[i];
+        g.proofs[(size_t)i].body = [s, q, flat]() {
+            UseLane ul(s->lane);
+            return session_prove(s, q, flat);
+        };
+    }
+    CHK(group_run(g));
+    int first = 0;
+    for (int i = 0; i < n; i++) {
+        if (rcs) rcs[i] = g.proofs[(size_t)i].rc;
+        if (!first) first = g.proofs[(size_t)i].rc;
+    }
+    return first;
 }
 
 int gkrhip_mimc_session_outputs(gkrhip_session* s, uint64_t* outputs) {

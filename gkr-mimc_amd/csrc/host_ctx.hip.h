@@ -254,12 +254,20 @@ inline int usable_cpus() {
 std::atomic<int> g_wait_override{-2};           // option wait_spin_us (-2: not set; -1: always spin; n: spin n us, then sleep)
 std::atomic<int> g_wait_ranks{1};               // ranks assumed to share this host (set with the communicator)
 std::atomic<int> g_proofs_in_flight{0};          // gkr.Prove calls currently running in this process (any lane)
+std::atomic<int> g_group_passengers{0};          // ... of which this many share their host thread with another proof of their group (host_group.hip.h)
+// What the plans of a layer read: the proofs of a group must all see the same number (they take the same decisions, launch for
+// launch), so inside a group it is the number the group's driver read before it resumed them.
+thread_local int t_group_in_flight = -1;
+inline int proofs_in_flight_now() {
+    return t_group_in_flight >= 0 ? t_group_in_flight : g_proofs_in_flight.load(std::memory_order_relaxed);
+}
 inline int wait_spin_limit_us() {
     static const int cpus = usable_cpus();
     const int ov = g_wait_override.load(std::memory_order_relaxed);
     if (ov > -2) return ov;
-    // one waiting host thread per proof in flight and rank
-    const int waiting = g_wait_ranks.load(std::memory_order_relaxed) * std::max(1, g_proofs_in_flight.load(std::memory_order_relaxed));
+    // one waiting host thread per proof in flight (per group of proofs) and rank
+    const int waiting = g_wait_ranks.load(std::memory_order_relaxed) *
+                        std::max(1, g_proofs_in_flight.load(std::memory_order_relaxed) - g_group_passengers.load(std::memory_order_relaxed));
     return cpus >= waiting + 2 ? -1 : 25;
 }
 struct Waiter {                                 // one per wait: call step() in the polling loop
@@ -282,7 +290,7 @@ struct Waiter {                                 // one per wait: call step() in 
 // 54.4; GMiMC bN = 22, 12 in flight: 101.9 against 97.3): the more lanes, the more the other lanes' kernels fill the CUs.
 inline int round_threads_log2_max() {
     if (!cx().g_max_auto) return cx().g_max;
-    return g_proofs_in_flight.load(std::memory_order_relaxed) >= 10 ? 15 : 16;
+    return proofs_in_flight_now() >= 10 ? 15 : 16;
 }
 struct ProofInFlight {
     ProofInFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); }

@@ -3,13 +3,14 @@
 #pragma once
 // ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
 template <bool FOLD, bool HAS_WJ>
-void launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat, bool alone) {
+int launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat, bool alone) {
     // a latency-bound launch of at most one workgroup per CU asks for enough (unused) dynamic LDS that two of its
     // workgroups cannot share a CU: the dispatcher otherwise packs some CUs with two lone-wave workgroups and leaves others idle
     // (only for a proof that is alone on the GPU: beside other proofs' kernels the extra LDS would keep the launch waiting)
     const size_t spread = (alone && grid <= cx().n_cu) ? (size_t)64 * 1024 : 0;
-    if (lat) hipLaunchKernelGGL((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), spread, cx().stream, a);
-    else hipLaunchKernelGGL((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+    if (lat) GKR_LAUNCH_BATCH((k_cipher_round_lat<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), spread, cx().stream, a);
+    else GKR_LAUNCH_BATCH((k_cipher_round<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+    return 0;
 }
 
 // ---- hand-off of a fused round's sums ---------------------------------------------------------------------------
@@ -393,7 +394,7 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
     pa3.p[1].nc = m - g;
     pa3.p[1].max_level = lj;
     pa3.p[1].seed = to_dev(hfr::ONE);
-    hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(g - t, lj), 1 << 20), 2), dim3(GKR_BLOCK), 0, cx().stream, pa3);
+    GKR_LAUNCH_BATCH(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(g - t, lj), 1 << 20), 2), dim3(GKR_BLOCK), 0, cx().stream, pa3);
     HIPCHK(hipGetLastError());
     CipherRoundArgs a;
     memset(&a, 0, sizeof a);
@@ -419,10 +420,10 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
         HIPCHK(hipStreamWaitEvent(cx().stream, cx().pre_done, 0));
         for (int i = 0; i < 6; i++) a.pre[i] = cx().pre_t[i].cplanes();
         cx().pre_K = cx().pre_S = nullptr;             // consumed
-        hipLaunchKernelGGL((k_cipher_round_wide<false, true, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+        GKR_LAUNCH_BATCH((k_cipher_round_wide<false, true, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
         g_cnt_lookahead.fetch_add(1, std::memory_order_relaxed);
     } else {
-        hipLaunchKernelGGL((k_cipher_round_wide<false, true, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+        GKR_LAUNCH_BATCH((k_cipher_round_wide<false, true, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
     }
     HIPCHK(hipGetLastError());
     cx().ahead_in_flight = true;
@@ -464,7 +465,7 @@ inline RoundPlan plan_rounds(int m, bool collective, int gamma_tail, bool* did_g
     RoundPlan p;
     p.m = m;
     p.collective = collective;
-    p.alone = g_proofs_in_flight.load(std::memory_order_relaxed) <= 1;
+    p.alone = proofs_in_flight_now() <= 1;
     const int hs = cx().host_tail_sharded;
     p.sh_tail = collective && gamma_tail > 0 && did_gamma && hs > 0 && m >= hs + 2 && (cx().lc.comm || cx().lc.shm || cx().lc.tick_lane >= 0) &&
                 sharded_tail_pays(tables * (2 << hs), hs);
@@ -721,7 +722,7 @@ struct CipherLoop {
                     memcmp(q, cx().ahead_q.data(), sizeof(E) * (size_t)(m - cx().ahead_t)) == 0;
         cx().ahead_K = cx().ahead_S = nullptr;
         const bool solo = cx().solo_boost && !collective &&
-                          (cx().solo_boost >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) <= 1);   // 2: always
+                          (cx().solo_boost >= 2 || proofs_in_flight_now() <= 1);   // 2: always
         g_m = round_threads_log2_max();                // fixed for the layer: the number of proofs in flight may change under it
         g_big = solo ? std::min(g_m + 1, 17) : g_m;
         const int gT = std::max(threads_log2(0), std::min(g_m, m - 1));   // highest level of the per-lane pyramid
@@ -772,7 +773,7 @@ struct CipherLoop {
             }
         }
         LAP("setup: table allocs");
-        hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 4), dim3(GKR_BLOCK), 0, cx().stream, pa3);
+        GKR_LAUNCH_BATCH(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << widest, 1 << 20), 4), dim3(GKR_BLOCK), 0, cx().stream, pa3);
         HIPCHK(hipGetLastError());
         if (gLow < gT) {
             PyramidExpandArgs xa;
@@ -780,12 +781,12 @@ struct CipherLoop {
             xa.h = pyrH.cplanes();
             xa.lo_level = gLow;
             xa.hi_level = gT;
-            hipLaunchKernelGGL(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
+            GKR_LAUNCH_BATCH(k_eq_pyramid_expand, dim3(grid_for((size_t)1 << gT, 1 << 20)), dim3(GKR_BLOCK), 0, cx().stream, xa);
             HIPCHK(hipGetLastError());
         }
         LAP("setup: pyramid launches");
         CHK(rounds_begin(collective));
-        pl = plan_rounds(m, collective, gamma_tail, did_gamma, 2, g_proofs_in_flight.load(std::memory_order_relaxed) <= 1 ? cx().host_tail_solo : cx().host_tail);
+        pl = plan_rounds(m, collective, gamma_tail, did_gamma, 2, proofs_in_flight_now() <= 1 ? cx().host_tail_solo : cx().host_tail);
         if (pl.pre_on) CHK(pre_prepare());               // nothing of this lane is waiting for the host yet
         LAP("setup: begin, plan, pre_prepare");
         coop_on = cx().coop >= 2 || (cx().coop == 1 && pl.alone);
@@ -871,23 +872,23 @@ struct CipherLoop {
             else hipLaunchKernelGGL((k_cipher_round_coop<false>), dim3(cgrid), dim3(GKR_BLOCK), 0, cx().stream, a);
             g_cnt_coop.fetch_add(1, std::memory_order_relaxed);
         } else if (pre) {
-            if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-            else hipLaunchKernelGGL((k_cipher_round_wide<false, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            if (late) GKR_LAUNCH_BATCH((k_cipher_round_wide<false, true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else GKR_LAUNCH_BATCH((k_cipher_round_wide<false, false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             g_cnt_lookahead.fetch_add(1, std::memory_order_relaxed);
         } else if (wide) {
             if (fold) {
-                if (late) hipLaunchKernelGGL((k_cipher_round_wide<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-                else hipLaunchKernelGGL((k_cipher_round_wide<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+                if (late) GKR_LAUNCH_BATCH((k_cipher_round_wide<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+                else GKR_LAUNCH_BATCH((k_cipher_round_wide<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             } else {
-                if (late) hipLaunchKernelGGL((k_cipher_round_wide<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-                else hipLaunchKernelGGL((k_cipher_round_wide<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+                if (late) GKR_LAUNCH_BATCH((k_cipher_round_wide<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+                else GKR_LAUNCH_BATCH((k_cipher_round_wide<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
             }
         } else if (fold) {
-            if (lj > 0) launch_cipher_round<true, true>(a, grid, lat, pl.alone);
-            else launch_cipher_round<true, false>(a, grid, lat, pl.alone);
+            if (lj > 0) CHK((launch_cipher_round<true, true>(a, grid, lat, pl.alone)));
+            else CHK((launch_cipher_round<true, false>(a, grid, lat, pl.alone)));
         } else {
-            if (lj > 0) launch_cipher_round<false, true>(a, grid, lat, pl.alone);
-            else launch_cipher_round<false, false>(a, grid, lat, pl.alone);
+            if (lj > 0) CHK((launch_cipher_round<false, true>(a, grid, lat, pl.alone)));
+            else CHK((launch_cipher_round<false, false>(a, grid, lat, pl.alone)));
         }
         HIPCHK(hipGetLastError());
         if (timed) {
@@ -1234,7 +1235,7 @@ struct LinearLoop {
             pa3.p[1].max_level = mU;
             pa3.p[1].seed = to_dev(hfr::ONE);
         }
-        hipLaunchKernelGGL(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(gT, mU), 1 << 20), 3), dim3(GKR_BLOCK), 0,
+        GKR_LAUNCH_BATCH(k_eq_suffix_pyramids, dim3(grid_for((size_t)1 << std::max(gT, mU), 1 << 20), 3), dim3(GKR_BLOCK), 0,
                            cx().stream, pa3);
         HIPCHK(hipGetLastError());
         CHK(rounds_begin(collective));

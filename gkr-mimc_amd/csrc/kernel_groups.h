@@ -11,26 +11,26 @@
 #error "define GKR_INST (extern | nothing) before including kernel_groups.h"
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_WIDE2)
-GKR_INST template __global__ void k_cipher_round_wide<false, false, false, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, false, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<true, false, false, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<true, true, false, false>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, false, false, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, false, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_wide<true, false, false, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_wide<true, true, false, false>(Batch<CipherRoundArgs>);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_WIDEPRE)
-GKR_INST template __global__ void k_cipher_round_wide<false, false, true, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, true, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, false, true>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_wide<false, true, true, true>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round_wide<false, false, true, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, true, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, false, true>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_wide<false, true, true, true>(Batch<CipherRoundArgs>);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_ROUND)
-GKR_INST template __global__ void k_cipher_round<false, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round<false, true>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round<true, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round<true, true>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_lat<false, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_lat<false, true>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_lat<true, false>(CipherRoundArgs);
-GKR_INST template __global__ void k_cipher_round_lat<true, true>(CipherRoundArgs);
+GKR_INST template __global__ void k_cipher_round<false, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round<false, true>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round<true, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round<true, true>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_lat<false, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_lat<false, true>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_lat<true, false>(Batch<CipherRoundArgs>);
+GKR_INST template __global__ void k_cipher_round_lat<true, true>(Batch<CipherRoundArgs>);
 GKR_INST template __global__ void k_cipher_round_coop<false>(CipherRoundArgs);
 GKR_INST template __global__ void k_cipher_round_coop<true>(CipherRoundArgs);
 GKR_INST template __global__ void k_linear_round<false, false>(LinearRoundArgs);

@@ -57,6 +57,7 @@ ABI = {
     "gkrhip_mimc_session_synth_inputs": (_I, [_P, _U64, _U64]),
     "gkrhip_mimc_session_assign": (_I, [_P]),
     "gkrhip_mimc_session_prove": (_I, [_P, _P, _P]),
+    "gkrhip_mimc_session_prove_group": (_I, [_I, _P, _P, _P, _P]),
     "gkrhip_mimc_session_outputs": (_I, [_P, _P]),
     "gkrhip_mimc_session_evaluate_layer": (_I, [_P, _I, _P, _P]),
     "gkrhip_mimc_session_destroy": (None, [_P]),
@@ -554,6 +555,21 @@ class MimcSession:
         flat = np.zeros((self.proof_len, 4), np.uint64)
         _check(load().gkrhip_mimc_session_prove(self._h, _ptr(q_prime) if self.bN else None, _ptr(flat)))
         return flat
+
+    @staticmethod
+    def prove_group(sessions, q_primes):
+        """gkr.Prove for up to eight sessions of the same shape from the calling thread, in lock-step: proof i is bit for bit
+        sessions[i].prove(q_primes[i]), the round kernels of the proofs go to the GPU as one launch (gkrhip_mimc_session_prove_group)."""
+        n = len(sessions)
+        assert n == len(q_primes) and n >= 1
+        qs = [_fr(q).reshape(-1, 4) for q in q_primes]
+        flats = [np.zeros((s.proof_len, 4), np.uint64) for s in sessions]
+        hs = (C.c_void_p * n)(*[s._h for s in sessions])
+        qp = (C.c_void_p * n)(*[_ptr(q) if s.bN else None for s, q in zip(sessions, qs)])
+        fp = (C.c_void_p * n)(*[_ptr(f) for f in flats])
+        rcs = (C.c_int * n)()
+        _check(load().gkrhip_mimc_session_prove_group(n, hs, qp, fp, rcs))
+        return flats
 
     def outputs(self):
         out = np.zeros((self.local_n, 4), np.uint64)

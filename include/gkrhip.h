@@ -158,6 +158,12 @@ int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session *s, const uint64_t *in0,
 int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session *s, uint64_t index_stride, uint64_t index_offset);
 int gkrhip_mimc_session_assign(gkrhip_mimc_session *s);
 int gkrhip_mimc_session_prove(gkrhip_mimc_session *s, const uint64_t *qprime, uint64_t *flat);
+/* gkr.Prove (gkr/prover.go:21-91) for n sessions of the same shape from one host thread, in lock-step: proof i is, bit for bit,
+ * what gkrhip_mimc_session_prove(s[i], qprime[i], flat[i]) returns, but the round kernels of the n proofs go to the GPU as ONE
+ * launch (1 <= n <= 8).  For many small proofs in flight: the reference proves them from n goroutines; here one cgo call
+ * proves n of them.  Un-sharded sessions, all different.  rcs (may be NULL) receives every proof's code; returns 0 or the first
+ * failing proof's code. */
+int gkrhip_mimc_session_prove_group(int n, gkrhip_session *const *s, const uint64_t *const *qprime, uint64_t *const *flat, int *rcs);
 int gkrhip_mimc_session_outputs(gkrhip_mimc_session *s, uint64_t *outputs);
 /* MultiLin.Evaluate of an assignment layer at `coords` on the device (verifier helper, gkr/verifier.go:36,120-132). */
 int gkrhip_mimc_session_evaluate_layer(gkrhip_mimc_session *s, int layer, const uint64_t *coords, uint64_t out[4]);
