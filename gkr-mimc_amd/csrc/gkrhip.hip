@@ -870,30 +870,49 @@ int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint
     std::sort(order.begin(), order.end());
     std::vector<std::unique_lock<std::mutex>> locks;
     for (Ctx* l : order) locks.emplace_back(l->mu);
-    // the group queues on the first lane's streams; what a lane has in its own stream is waited for first
+    // The group queues on the streams of ONE of its lanes -- the one whose hardware queue the fewest groups under way use: the
+    // runtime deals its hardware queues to streams in creation order, and groups that all took their first lane's stream would
+    // share a few queues (sessions created in a row, groups of 4: queues 0, 4, 8, 12 of 16 -- measured 62 M hashes/s at bN = 20 x 60
+    // in flight against 75-80 M for groups of 3 and 6, whose first lanes happen to cover all the queues; profiles/r06_proof_groups.txt).
+    // What a lane has in its own stream is waited for first.
     struct StreamSwap {
         std::vector<Ctx*>& lanes;
         std::vector<std::pair<hipStream_t, hipStream_t>> own;
         bool swapped = false;
+        int lead = 0, slot = -1;
         explicit StreamSwap(std::vector<Ctx*>& l) : lanes(l) {}
         ~StreamSwap() {
+            if (slot >= 0) {
+                std::lock_guard<std::mutex> g(g_group_queue_mu);
+                g_group_queue_use[slot]--;
+            }
             if (!swapped) return;
-            (void)hipStreamSynchronize(lanes[0]->stream);
-            if (lanes[0]->aux) (void)hipStreamSynchronize(lanes[0]->aux);
+            (void)hipStreamSynchronize(own[(size_t)lead].first);
+            if (own[(size_t)lead].second) (void)hipStreamSynchronize(own[(size_t)lead].second);
             for (size_t i = 0; i < lanes.size(); i++) {
                 lanes[i]->stream = own[i].first;
                 lanes[i]->aux = own[i].second;
             }
         }
     } sw(lanes);
-    for (int i = 1; i < n; i++) {
+    for (int i = 0; i < n; i++) {
         HIPCHK(hipStreamSynchronize(lanes[i]->stream));
         if (lanes[i]->aux) HIPCHK(hipStreamSynchronize(lanes[i]->aux));
     }
+    int lead = 0;
+    {
+        const int nq = std::max(1, std::min(64, hw_queue_count()));
+        std::lock_guard<std::mutex> g(g_group_queue_mu);
+        for (int i = 1; i < n; i++)
+            if (g_group_queue_use[lanes[i]->ordinal % nq] < g_group_queue_use[lanes[lead]->ordinal % nq]) lead = i;
+        sw.slot = (int)(lanes[lead]->ordinal % nq);
+        g_group_queue_use[sw.slot]++;
+        sw.lead = lead;
+    }
     for (int i = 0; i < n; i++) sw.own.emplace_back(lanes[i]->stream, lanes[i]->aux);
-    for (int i = 1; i < n; i++) {
-        lanes[i]->stream = lanes[0]->stream;
-        lanes[i]->aux = lanes[0]->aux;
+    for (int i = 0; i < n; i++) {
+        lanes[i]->stream = sw.own[(size_t)lead].first;
+        lanes[i]->aux = sw.own[(size_t)lead].second;
     }
     sw.swapped = true;
     Group g;

@@ -115,6 +115,7 @@ struct LaneColl {
 struct Ctx {
     bool ready = false;
     int device = -1;
+    unsigned ordinal = 0;                      // the lane's number in creation order: its stream was the ordinal-th the library created (the runtime deals hardware queues to streams in turn)
     hipStream_t stream = nullptr;
     unsigned long long* d_partials = nullptr;  // per-block limb-split partial sums (reference-shaped evaluator)
     bool racc_dirty = false;                   // a call that uses d_racc / d_counter is under way or failed half-way
@@ -587,6 +588,8 @@ Ctx* lane_create() {
         }
     }
     Ctx* l = new Ctx();
+    static std::atomic<unsigned> created{1};   // (0: the default lane)
+    l->ordinal = created.fetch_add(1, std::memory_order_relaxed);
     lane_configure(l);
     UseLane u(l);
     if (lane_alloc() != 0) {

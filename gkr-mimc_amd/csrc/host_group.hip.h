@@ -70,6 +70,12 @@ struct Group {
     unsigned long long combined = 0, launches = 0;      // combined launches, and what they stood for
 };
 thread_local Group* t_group = nullptr;
+std::mutex g_group_queue_mu;
+int g_group_queue_use[64] = {0};            // groups under way by the hardware queue (stream ordinal mod the queue count) they launch on
+inline int hw_queue_count() {
+    const int a = g_hwq_set_by_library.load(), b = g_hwq_from_env.load();
+    return a > 0 ? a : (b > 0 ? b : 4);       // (4: the runtime's default)
+}
 std::atomic<unsigned long long> g_cnt_group_launches{0}, g_cnt_group_combined{0};
 
 // the launch site of a batched kernel
