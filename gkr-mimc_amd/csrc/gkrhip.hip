@@ -355,7 +355,7 @@ void gkrhip_shutdown(void) {
     {
         std::lock_guard<std::mutex> pl(g_pool.mu);
         for (auto& f : g_pool.free_list)
-            for (uint4* b : f.second) pool_free_raw(b);
+            for (uint4* b : f.second) (void)hipFree(b);
         g_pool.free_list.clear();
     }
     {

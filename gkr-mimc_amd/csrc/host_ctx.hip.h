@@ -305,7 +305,6 @@ struct Pool {
     // 5 000 buffers of ITS size behind, every allocation of another size walked them all under the arena's lock -- ten allocations
     // per layer and lane: GMiMC bN = 22 with 12 lanes 103.8 M hashes/s behind such a job against 113.9 before it.)
     std::unordered_map<size_t, std::vector<uint4*>> free_list;
-    std::unordered_map<uint4*, void*> raw;      // staggered tables: what hipMalloc returned for them
 } g_pool;
 // arena_check (table_release): 0 off, 1 count releases with the lane still busy, 2 also poison what is released
 std::atomic<int> g_arena_check{0};
@@ -639,26 +638,6 @@ int ensure_ctx() {
 }
 
 // ---- device table arena (replaces poly/pool.go:69-126; no 2^24 cap) ---------------------------------
-// Tables of 2^14 elements and more do not start on the allocator's (2 MiB-aligned) address but a few KiB further on, differently for
-// every allocation: the tables of the proofs of a GROUP are read in the same launch at the same offsets, and allocated at strides of
-// exactly their (power-of-two) size they fall on the same cache sets and memory channels (measured: groups of 4 and 8 ran 20-35 %
-// slower than groups of 3 and 6 until their tables were staggered: profiles/r06_proof_groups.txt).
-const size_t kStaggerFromCap = (size_t)1 << 14;
-const size_t kStaggerSpan = (size_t)256 << 10;
-inline size_t table_stagger_bytes() {       // (g_pool.mu held)
-    static const long step = getenv("GKRHIP_X_STAGGER") ? atol(getenv("GKRHIP_X_STAGGER")) : 4096;
-    static unsigned long n = 0;
-    return step > 0 ? ((n++ * 37) % (kStaggerSpan / (size_t)step)) * (size_t)step : 0;
-}
-inline void pool_free_raw(uint4* b) {      // (g_pool.mu held)
-    auto it = g_pool.raw.find(b);
-    if (it == g_pool.raw.end()) {
-        (void)hipFree(b);
-        return;
-    }
-    (void)hipFree(it->second);
-    g_pool.raw.erase(it);
-}
 int table_alloc(DevTable* t, size_t cap) {
     if (cap == 0) cap = 1;
     std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -672,23 +651,17 @@ int table_alloc(DevTable* t, size_t cap) {
         }
     }
     void* p = nullptr;
-    // big tables start at staggered offsets (table_stagger_bytes)
-    const size_t pad = cap >= kStaggerFromCap ? kStaggerSpan : 0;
-    hipError_t e = hipMalloc(&p, sizeof(uint4) * 2 * cap + pad);
+    hipError_t e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
     if (e != hipSuccess) {
         // drop the cache and retry once
         (void)hipGetLastError();       // the failed attempt must not surface later as a stale "out of memory"
         for (auto& f : g_pool.free_list)
-            for (uint4* b : f.second) pool_free_raw(b);
+            for (uint4* b : f.second) (void)hipFree(b);
         g_pool.free_list.clear();
-        e = hipMalloc(&p, sizeof(uint4) * 2 * cap + pad);
+        e = hipMalloc(&p, sizeof(uint4) * 2 * cap);
         if (e != hipSuccess) return fail("hipMalloc of a %zu-element table failed: %s", cap, hipGetErrorString(e));
     }
     t->base = (uint4*)p;
-    if (pad) {
-        t->base = (uint4*)((char*)p + table_stagger_bytes());
-        g_pool.raw[t->base] = p;
-    }
     t->cap = cap;
     return 0;
 }
@@ -740,10 +713,7 @@ void table_release(DevTable* t, int line = __builtin_LINE(), const char* file = 
 }
 void table_release_fwd(DevTable* t) { table_release(t, -1, "pre_release"); }
 void table_free(DevTable* t) {
-    if (t->base) {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        pool_free_raw(t->base);
-    }
+    if (t->base) (void)hipFree(t->base);
     t->base = nullptr;
     t->cap = 0;
 }
