@@ -1,6 +1,6 @@
 """Proof groups (gkrhip_mimc_session_prove_group): parity with the single proofs, then throughput of T host threads x groups of k
 against the same number of proofs in flight on lanes of their own.
-python tools/r6_group_probe.py [bn] [in_flight] [k,k,...] [proofs_per_session]"""
+python tools/r6_group_probe.py [bn] [in_flight] [k,k,...] [proofs_per_session] [g_max,g_max,...]"""
 import importlib
 import os
 import sys
@@ -16,6 +16,7 @@ bn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nfl = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 ks = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8").split(",")]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+gmaxes = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [None]
 for kv in os.environ.get("GKRHIP_BENCH_OPTIONS", "").split(","):
     if "=" in kv:
         gk.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -76,9 +77,12 @@ def run(k):
         if trial:
             best = dt if best is None else min(best, dt)
     per = best / (reps * nfl)
-    print("bN=%d, %d proofs in flight, groups of %d (%d host threads): %.2f ms per proof, %.2f M hashes/s" %
-          (bn, nfl, k, len(chunks), 1e3 * per, (1 << bn) / per / 1e6), flush=True)
+    print("bN=%d, %d proofs in flight, groups of %d (%d host threads)%s: %.2f ms per proof, %.2f M hashes/s" %
+          (bn, nfl, k, len(chunks), "" if gm is None else ", g_max %d" % gm, 1e3 * per, (1 << bn) / per / 1e6), flush=True)
 
 
-for k in ks:
-    run(k)
+for gm in gmaxes:
+    if gm is not None:
+        gk.set_option("g_max", gm)
+    for k in ks:
+        run(k)
