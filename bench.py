@@ -108,7 +108,9 @@ def config_summary(out):
         c = cf.get(key)
         if c:
             sm[key] = {"hashes_per_s": r(c["hashes_per_s"], 0), "single_proof_ms": r(c["single_proof_ms"], 2),
-                       "lanes": c["concurrent_proofs"], "verified": c["proof_verified_by_native_gkr_verify"]}
+                       "lanes": c["concurrent_proofs"], "proofs_per_group": c.get("proofs_per_group", 1),
+                       "lanes_only_hashes_per_s": r((c.get("lanes_only") or {}).get("hashes_per_s"), 0),
+                       "verified": c["proof_verified_by_native_gkr_verify"]}
     one = out.get("oneshot_including_pcie")
     sm["oneshot_s"] = r(one["one_call_s"], 4) if one else None
     for lg in (20, 22, 24):
@@ -341,8 +343,9 @@ class GlooRendezvous:
 class Job:
     """nconc resident sessions (one lane each) of the same circuit and size, proving concurrently."""
 
-    def __init__(self, gk, bn, nconc, layers):
+    def __init__(self, gk, bn, nconc, layers, group=1):
         self.gk, self.bn, self.nconc = gk, bn, nconc
+        self.group = group      # > 1: the sessions prove in groups of this many, one host thread per group (gkrhip_mimc_session_prove_group)
         self.sessions = []
         for _ in range(nconc):
             s = gk.MimcSession(bn, layers=layers)
@@ -363,6 +366,8 @@ class Job:
                 if self.keep is not None:
                     self.keep.append(self.last[0])
             return
+        if self.group > 1:
+            return self.run_steps_grouped(total)
         counts = [total // self.nconc + (1 if k < total % self.nconc else 0) for k in range(self.nconc)]
 
         def work(k):
@@ -381,6 +386,41 @@ class Job:
             t.join()
         if self.errors:
             raise self.errors[0]
+
+    def run_steps_grouped(self, total):
+        """`total` full proofs by groups of self.group sessions: every group has one host thread, which proves its sessions in
+        lock-step (one library call = self.group proofs); the proofs are dealt to the groups in turn, whole groups at a time."""
+        g = self.group
+        chunks = [list(range(i, min(i + g, self.nconc))) for i in range(0, self.nconc, g)]
+        calls = [0] * len(chunks)
+        left, c = total, 0
+        while left > 0:
+            calls[c % len(chunks)] += 1
+            left -= len(chunks[c % len(chunks)])
+            c += 1
+        qs = {len(ch): [self.qprime] * len(ch) for ch in chunks}
+
+        def work(ci):
+            idx = chunks[ci]
+            ss = [self.sessions[i] for i in idx]
+            try:
+                for _ in range(calls[ci]):
+                    got = self.gk.MimcSession.prove_group(ss, qs[len(idx)])
+                    for i, p in zip(idx, got):
+                        self.last[i] = p
+                    if self.keep is not None:
+                        self.keep.extend(got)
+            except Exception as e:   # noqa: BLE001 -- re-raised on the main thread
+                self.errors.append(e)
+
+        ths = [threading.Thread(target=work, args=(ci,)) for ci in range(len(chunks))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if self.errors:
+            raise self.errors[0]
+        self.proofs_run = sum(calls[ci] * len(chunks[ci]) for ci in range(len(chunks)))      # >= total (whole groups)
 
     def transcripts_identical(self, ref):
         """Every lane proves the same statement: each kept transcript must be the one `ref` that gkr.Verify is run on."""
@@ -1126,11 +1166,18 @@ def main():
         # 16 / 24 / 32 / 48), GMiMC bN = 22 78.7 / 85.5 with 5 / 8 (later: 85.8 / 89.3 / 89.2 with 8 / 12 / 16)
         # Round 5, with the round kernels' wave priorities (kernels.hip.h: round_wave_priority): bN = 20 60.5 / 63.5 / 63.3 / 65.0 / 64.4 / 65.2 M
         # with 24 / 40 / 48 / 56 / 64 / 80 lanes (profiles/r05_lanes20.txt) -> 56; GMiMC bN = 22 101.8 / 115.0 / 107.7 with 8 / 12 / 16 -> 12
-        for key, circ, cbn, csteps, clanes in (("bn20", "mimc", 20, 168, 56), ("gmimc_bn22", "gmimc", 22, 48, 12)):      # three / four proofs per lane in the timed region
-            cl = lanes_that_fit(circ, cbn, max(args.concurrent, clanes) if args.concurrent > 1 else 1, csteps)
-            note("config %s: %d lanes: creating the sessions" % (key, cl))
-            cj = Job(gk, cbn, cl, gk.gmimc_t2_circuit() if circ == "gmimc" else None)
+        # Round 6, proof groups (gkrhip_mimc_session_prove_group: the round kernels of the proofs of a group in ONE launch, one host thread per
+        # group): bN = 20 64.4 M with 56 lanes -> 82.4 M with 72 proofs in flight in groups of 3 (profiles/r06_proof_groups.txt).  The lanes-only
+        # figure is measured beside it on the first 56 sessions ("lanes_only").
+        for key, circ, cbn, csteps, clanes, group, glanes in (("bn20", "mimc", 20, 168, 56, 3, 72), ("gmimc_bn22", "gmimc", 22, 48, 12, 1, 12)):      # three / four proofs per lane in the timed region
+            want = max(args.concurrent, clanes) if args.concurrent > 1 else 1
+            cl = lanes_that_fit(circ, cbn, want, csteps)
+            gl = lanes_that_fit(circ, cbn, glanes, 3 * glanes) if (group > 1 and want > 1) else cl
+            gl -= gl % group if gl >= group else 0
+            note("config %s: %d lanes: creating the sessions" % (key, max(cl, gl)))
+            cj = Job(gk, cbn, max(cl, gl), gk.gmimc_t2_circuit() if circ == "gmimc" else None)
             note("config %s: sessions assigned, running" % key)
+            cj.nconc = cl
             cj.run_steps(max(2, cl))
             sync_all()
             cj.last[0] = cj.sessions[0].prove(cj.qprime)      # untimed: the first proof ALONE takes the lane's one-time set-up of the solo paths
@@ -1144,12 +1191,35 @@ def main():
             cdt = timed(cj, csteps)
             note("config %s: timed region done" % key)
             ok = bool(cj.sessions[0].verify(cj.qprime, cj.last[0]))
-            ckept, csame = cj.transcripts_identical(cj.last[0])
+            ref_proof = cj.last[0]
+            ckept, csame = cj.transcripts_identical(ref_proof)
             ok = ok and ckept == csteps and csame == ckept      # every timed proof is the verified transcript, bit for bit
+            lanes_res = {"hashes_per_s": float(1 << cbn) * csteps / cdt, "ms_per_step": 1e3 * cdt / csteps, "steps": csteps, "concurrent_proofs": cl}
+            grp_res = None
+            if group > 1 and gl >= 2 * group:
+                cj.nconc, cj.group = gl, group
+                gsteps = 3 * gl
+                cj.run_steps(gl)                                  # warm-up: one call per group
+                gk.profile_reset(1 << 40)
+                cj.keep = []
+                gdt = timed(cj, gsteps)
+                gran = cj.proofs_run
+                gkept, gsame = cj.transcripts_identical(ref_proof)
+                ok = ok and gkept == gran and gsame == gkept      # ... and so is every proof of the groups
+                wanted, made = gk.profile_counter("group_launches_wanted"), gk.profile_counter("group_launches_made")
+                grp_res = {"hashes_per_s": float(1 << cbn) * gran / gdt, "ms_per_step": 1e3 * gdt / gran, "steps": gran, "concurrent_proofs": gl,
+                           "proofs_per_group": group, "host_threads": (gl + group - 1) // group,
+                           "proofs_per_launch": (wanted / made) if made else None,
+                           "note": "gkrhip_mimc_session_prove_group: every host thread proves its group's sessions in lock-step, their round "
+                                   "kernels go to the GPU as one launch; each proof is bit for bit the single call's (checked above)"}
+                note("config %s: groups done" % key)
             cj.close()
             note("config %s: closed" % key)
-            configs[key] = {"hashes_per_s": float(1 << cbn) * csteps / cdt, "ms_per_step": 1e3 * cdt / csteps, "steps": csteps,
-                            "concurrent_proofs": cl, "single_proof_ms": sorted(lat)[1], "single_proof_samples_ms": lat,
+            best = grp_res if (grp_res and grp_res["hashes_per_s"] > lanes_res["hashes_per_s"]) else lanes_res
+            configs[key] = {"hashes_per_s": best["hashes_per_s"], "ms_per_step": best["ms_per_step"], "steps": best["steps"],
+                            "concurrent_proofs": best["concurrent_proofs"], "proofs_per_group": best.get("proofs_per_group", 1),
+                            "lanes_only": lanes_res, "groups": grp_res,
+                            "single_proof_ms": sorted(lat)[1], "single_proof_samples_ms": lat,
                             "single_proof_hashes_per_s": float(1 << cbn) / (sorted(lat)[1] * 1e-3),
                             "proof_verified_by_native_gkr_verify": ok,
                             "hw_queues": {"set_by_library": gk.profile_counter("hw_queues_set_by_library"),

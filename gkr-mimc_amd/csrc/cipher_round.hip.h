@@ -37,7 +37,8 @@
 #define GKR_GROUP_MAX 8
 template <class A>
 struct Batch {
-    A inst[GKR_GROUP_MAX];
+    static const int N = sizeof(A) * GKR_GROUP_MAX <= 4096 ? GKR_GROUP_MAX : (int)(4096 / sizeof(A));      // (4 KiB of kernel arguments: a group beyond N takes two launches)
+    A inst[N];
 };
 // ------------------------------------------------------------------------------------------------
 // suffix pyramid: level s (s = 0..max_level) is the table eq(q[nc-s .. nc-1], .) of 2^s entries,

@@ -1810,6 +1810,8 @@ int gkrhip_profile_reset(size_t min_n) {
     g_cnt_layer_checks = 0;
     g_cnt_ahead = 0;
     g_cnt_layer_check_failures = 0;
+    g_cnt_group_launches = 0;
+    g_cnt_group_combined = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
         prof_clear(l->prof);
@@ -2322,6 +2324,8 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "layer_checks") *value = g_cnt_layer_checks.load();
     else if (n == "layer_check_failures") *value = g_cnt_layer_check_failures.load();
     else if (n == "arena_busy_releases") *value = g_cnt_busy_releases.load();
+    else if (n == "group_launches_wanted") *value = g_cnt_group_launches.load();      // launches the proofs of the groups asked for ...
+    else if (n == "group_launches_made") *value = g_cnt_group_combined.load();       // ... and the combined launches that served them
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);
     return 0;
 }

@@ -289,8 +289,12 @@ struct Waiter {                                 // one per wait: call step() in 
 // log2 of the threads a round kernel may use.  Measured (profiles/r04_gmax_by_lanes.txt): 2^16 (one workgroup per CU) with a few
 // proofs in flight (bN = 24, five: 84.7 M hashes/s against 81.9 with 2^15), 2^15 with many (bN = 20, 24 in flight: 57.8 against
 // 54.4; GMiMC bN = 22, 12 in flight: 101.9 against 97.3): the more lanes, the more the other lanes' kernels fill the CUs.
+// The proofs of a group (host_group.hip.h) share their launches: 2^13 threads each (bN = 20, 72 in flight in groups of 3: 82.4 M hashes/s
+// against 71.7 / 79.2 with 2^12 / 2^14 and 68-71 with 2^15; groups of 4 and 6 likewise: profiles/r06_proof_groups.txt).
+thread_local int t_group_size = 0;
 inline int round_threads_log2_max() {
     if (!cx().g_max_auto) return cx().g_max;
+    if (t_group_size >= 2) return 13;
     return proofs_in_flight_now() >= 10 ? 15 : 16;
 }
 struct ProofInFlight {

@@ -27,6 +27,7 @@ struct PendingLaunch {
     hipStream_t stream = nullptr;
     const void* arg = nullptr;      // the proof's argument struct (on the proof's stack, which is parked)
     size_t arg_size = 0;
+    unsigned cap = 1;               // proofs one launch of this kernel takes (Batch<A>::N)
     hipError_t rc = hipSuccess;
 };
 struct GroupTls {                   // the calling thread's per-proof state
@@ -97,6 +98,7 @@ inline hipError_t launch_batch(void (*kern)(Batch<A>), dim3 grid, dim3 block, si
     me.pend.stream = st;
     me.pend.arg = &a;
     me.pend.arg_size = sizeof(A);
+    me.pend.cap = (unsigned)Batch<A>::N;
     me.pend.rc = hipSuccess;
     me.at_launch = true;
     me.tls.save();
@@ -121,7 +123,7 @@ inline void group_fire(Group& g) {
         if (!p.at_launch) continue;
         unsigned cnt = 0;
         size_t member[GKR_GROUP_MAX];
-        for (size_t j = i; j < n && cnt < GKR_GROUP_MAX; j++) {
+        for (size_t j = i; j < n && cnt < p.pend.cap; j++) {
             GroupProof& o = g.proofs[j];
             const PendingLaunch &x = p.pend, &y = o.pend;
             if (!o.at_launch || x.fn != y.fn || x.stream != y.stream || x.shmem != y.shmem || x.arg_size != y.arg_size || x.grid.x != y.grid.x ||
@@ -170,6 +172,7 @@ inline int group_run(Group& g) {
         t_group = &g;
         const int passengers = (int)g.proofs.size() - 1;
         g_group_passengers.fetch_add(passengers, std::memory_order_relaxed);
+        t_group_size = (int)g.proofs.size();
         for (;;) {
             // what the proofs' plans read until they are parked again: one number for all of them
             t_group_in_flight = std::max(g_proofs_in_flight.load(std::memory_order_relaxed), (int)g.proofs.size());
@@ -188,6 +191,7 @@ inline int group_run(Group& g) {
         }
         g_group_passengers.fetch_sub(passengers, std::memory_order_relaxed);
         t_group_in_flight = -1;
+        t_group_size = 0;
         t_group = nullptr;
         g.cur = -1;
         g_cnt_group_launches.fetch_add(g.launches, std::memory_order_relaxed);

@@ -1295,11 +1295,11 @@ struct LinearLoop {
         a.need_m0 = derive_m0 ? 0u : 1u;
         const int grid = (int)std::max<size_t>(((size_t)1 << gk) / GKR_BLOCK, 1);
         if (fold) {
-            if (lj > 0) hipLaunchKernelGGL((k_linear_round<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-            else hipLaunchKernelGGL((k_linear_round<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            if (lj > 0) GKR_LAUNCH_BATCH((k_linear_round<true, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else GKR_LAUNCH_BATCH((k_linear_round<true, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
         } else {
-            if (lj > 0) hipLaunchKernelGGL((k_linear_round<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-            else hipLaunchKernelGGL((k_linear_round<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            if (lj > 0) GKR_LAUNCH_BATCH((k_linear_round<false, true>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
+            else GKR_LAUNCH_BATCH((k_linear_round<false, false>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
         }
         HIPCHK(hipGetLastError());
         return 0;

@@ -33,10 +33,10 @@ GKR_INST template __global__ void k_cipher_round_lat<true, false>(Batch<CipherRo
 GKR_INST template __global__ void k_cipher_round_lat<true, true>(Batch<CipherRoundArgs>);
 GKR_INST template __global__ void k_cipher_round_coop<false>(CipherRoundArgs);
 GKR_INST template __global__ void k_cipher_round_coop<true>(CipherRoundArgs);
-GKR_INST template __global__ void k_linear_round<false, false>(LinearRoundArgs);
-GKR_INST template __global__ void k_linear_round<false, true>(LinearRoundArgs);
-GKR_INST template __global__ void k_linear_round<true, false>(LinearRoundArgs);
-GKR_INST template __global__ void k_linear_round<true, true>(LinearRoundArgs);
+GKR_INST template __global__ void k_linear_round<false, false>(Batch<LinearRoundArgs>);
+GKR_INST template __global__ void k_linear_round<false, true>(Batch<LinearRoundArgs>);
+GKR_INST template __global__ void k_linear_round<true, false>(Batch<LinearRoundArgs>);
+GKR_INST template __global__ void k_linear_round<true, true>(Batch<LinearRoundArgs>);
 GKR_INST template __global__ void k_partial_eval<1, 1, 3>(PartialEvalArgs);
 GKR_INST template __global__ void k_partial_eval<1, 2, 3>(PartialEvalArgs);
 GKR_INST template __global__ void k_partial_eval<1, 3, 3>(PartialEvalArgs);

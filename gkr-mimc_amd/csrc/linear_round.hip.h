@@ -41,7 +41,8 @@ struct LinearRoundArgs {
 };
 
 template <bool FOLD, bool HAS_WJ>
-__global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(LinearRoundArgs a) {
+__global__ void __launch_bounds__(GKR_BLOCK) k_linear_round(Batch<LinearRoundArgs> ba) {
+    const LinearRoundArgs& a = ba.inst[blockIdx.z];
     __shared__ unsigned int s_last;
     round_wave_priority(a.prio);
     u32 T0[FR_WIDE_LIMBS], T1[FR_WIDE_LIMBS];      // wide sums of W*u and W*d: reduced once per lane

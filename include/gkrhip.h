@@ -436,7 +436,9 @@ int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_rou
  * layers whose round 0 was queued by the layer before them; "hw_queues_set_by_library": the count gkrhip_init put into the
  * process's GPU_MAX_HW_QUEUES (0: it found the variable set -- "hw_queues_from_environment" -- or was told to leave it
  * alone); the runtime reads the variable when it initialises, so the setting only takes effect if the library made the
- * process's first HIP call; "arena_busy_releases": see gkrhip_set_option, "arena_check".  Unknown name: error. */
+ * process's first HIP call; "arena_busy_releases": see gkrhip_set_option, "arena_check";
+ * "group_launches_wanted" / "group_launches_made": the kernel launches the proofs of gkrhip_mimc_session_prove_group asked for, and
+ * the combined launches that served them (wanted / made = proofs per launch).  Unknown name: error. */
 int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus

@@ -266,14 +266,16 @@ def test_config_summary_carries_the_second_tier_results():
     spec.loader.exec_module(b)
     empty = b.config_summary({})
     assert set(empty) == set(b.SUMMARY_KEYS) and empty["bn20"] is None and empty["bench_attempts"] == 1
-    out = {"configs": {"bn20": {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "concurrent_proofs": 56, "proof_verified_by_native_gkr_verify": True},
+    out = {"configs": {"bn20": {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "concurrent_proofs": 72, "proofs_per_group": 3, "lanes_only": {"hashes_per_s": 6.4e7},
+                                "proof_verified_by_native_gkr_verify": True},
                        "gmimc_bn22": {"hashes_per_s": 1.1e8, "single_proof_ms": 117.0, "concurrent_proofs": 12, "proof_verified_by_native_gkr_verify": True}},
            "micro": {"msm_g1_2p24": {"ms": 19.5}, "msm_g1_2p22": {"ms": 5.4}, "msm_g1_2p20": {"ms": 1.9}, "msm_g2_2p22": {"ms": 19.0},
                      "compute_h_2p24": {"ms": 12.7}, "msm_g1_fixed_base_2p24": {"ms": 18.0}},
            "oneshot_including_pcie": {"one_call_s": 0.31}, "roofline": {"frac": 0.79}, "partial_eval": {"frac": 0.86},
            "integrity": {"layer_checks": 920, "layer_check_failures": 0, "chal_retries": 0}}
     sm = b.config_summary(out)
-    assert sm["bn20"] == {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "lanes": 56, "verified": True}
+    assert sm["bn20"] == {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "lanes": 72, "proofs_per_group": 3, "lanes_only_hashes_per_s": 6.4e7, "verified": True}
+    assert sm["gmimc_bn22"]["proofs_per_group"] == 1 and sm["gmimc_bn22"]["lanes_only_hashes_per_s"] is None
     assert sm["msm_g1_2p24_ms"] == 19.5 and sm["compute_h_2p24_ms"] == 12.7 and sm["oneshot_s"] == 0.31
     assert sm["msm_g1_fixed_base_ms"] == {"2p24": 18.0} and sm["layer_checks"] == 920 and sm["chal_retries"] == 0
     assert len(json.dumps(sm)) < 900          # compact: it must survive where the 2 000-character tail does not
