@@ -292,9 +292,9 @@ struct Waiter {                                 // one per wait: call step() in 
 // The proofs of a group (host_group.hip.h) share their launches: 2^13 threads each (bN = 20, 72 in flight in groups of 3: 82.4 M hashes/s
 // against 71.7 / 79.2 with 2^12 / 2^14 and 68-71 with 2^15; groups of 4 and 6 likewise: profiles/r06_proof_groups.txt).
 thread_local int t_group_size = 0;
-inline int round_threads_log2_max() {
+inline int round_threads_log2_max(int m) {        // m: log2 of the layer's table
     if (!cx().g_max_auto) return cx().g_max;
-    if (t_group_size >= 2) return 13;
+    if (t_group_size >= 2) return std::max(13, std::min(15, m - 7));      // (2^13 is for the proofs groups are for: 2^20 entries; 2^24 in groups of 2 with 2^13 threads ran at half the lanes' rate)
     return proofs_in_flight_now() >= 10 ? 15 : 16;
 }
 struct ProofInFlight {

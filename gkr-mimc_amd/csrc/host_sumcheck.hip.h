@@ -359,7 +359,7 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
     const DevTable* S = cx().nxt_S;
     const int t = m - 1 - k_known;
     if (!K || !S || cx().req_m != m || t < 1 || t > GKR_AHEAD_TMAX || !cx().wide_mode) return 0;
-    const int g_m = round_threads_log2_max();
+    const int g_m = round_threads_log2_max(m);
     const int g = std::min(solo ? std::min(g_m + 1, 17) : g_m, m - 2);      // threads = 2^g, at least two pairs per lane
     if (g < t || g < 8) return 0;
     const int lj = m - 1 - g;
@@ -723,7 +723,7 @@ struct CipherLoop {
         cx().ahead_K = cx().ahead_S = nullptr;
         const bool solo = cx().solo_boost && !collective &&
                           (cx().solo_boost >= 2 || proofs_in_flight_now() <= 1);   // 2: always
-        g_m = round_threads_log2_max();                // fixed for the layer: the number of proofs in flight may change under it
+        g_m = round_threads_log2_max(m);                // fixed for the layer: the number of proofs in flight may change under it
         g_big = solo ? std::min(g_m + 1, 17) : g_m;
         const int gT = std::max(threads_log2(0), std::min(g_m, m - 1));   // highest level of the per-lane pyramid
         LAP("setup: enter");
@@ -1213,7 +1213,7 @@ struct LinearLoop {
         }
     }
     int setup() {
-        g_lin = round_threads_log2_max();
+        g_lin = round_threads_log2_max(m);
         const int gT = std::min(g_lin, m - 1);
         const int mU = m - 1 - gT;
         CHK(stage_coords(q, (size_t)m));

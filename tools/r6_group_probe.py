@@ -1,6 +1,6 @@
 """Proof groups (gkrhip_mimc_session_prove_group): parity with the single proofs, then throughput of T host threads x groups of k
 against the same number of proofs in flight on lanes of their own.
-python tools/r6_group_probe.py [bn] [in_flight] [k,k,...] [proofs_per_session] [g_max,g_max,...]"""
+python tools/r6_group_probe.py [gmimc] [bn] [in_flight] [k,k,...] [proofs_per_session] [g_max,g_max,...]"""
 import importlib
 import os
 import sys
@@ -12,6 +12,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 gk = importlib.import_module("gkr-mimc_amd")
 gk.init(0)
+GMIMC = "gmimc" in sys.argv      # the GMiMC t = 2 circuit (BASELINE config 5) instead of examples.MimcCircuit
+sys.argv = [a for a in sys.argv if a != "gmimc"]
 bn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nfl = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 ks = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8").split(",")]
@@ -31,7 +33,7 @@ def rnd_q():
 
 sessions = []
 for i in range(nfl):
-    s = gk.MimcSession(bn)
+    s = gk.MimcSession(bn, layers=gk.gmimc_t2_circuit() if GMIMC else None)
     s.synth_inputs(stride=1, offset=i * 7919)      # every session its own inputs
     s.assign()
     sessions.append(s)
