@@ -53,7 +53,7 @@ struct PyramidArgs {
     int nc, max_level;
     Fr seed;          // level-0 value (1, or the multiplier)
 };
-__device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, size_t idx) {
+__device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, size_t idx, const Fr* __restrict__ q) {
     if (idx >= ((size_t)1 << a.max_level)) return;
     const Fr one = fr_one();
     const Fr two128 = {{0u, 0u, 0u, 0u, 1u, 0u, 0u, 0u}};   // the plain integer 2^128: a Montgomery product with it divides by 2^128
@@ -63,7 +63,7 @@ __device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, siz
         if (a.out2.lo) st_fr(a.out2.lo, a.out2.hi, 0, fr_mul(cur, two128));
     }
     for (int s = 1; s <= a.max_level; s++) {
-        const Fr qc = a.q[a.nc - s];
+        const Fr qc = q[a.nc - s];
         const bool bit = (idx >> (s - 1)) & 1;
         const Fr f = bit ? qc : fr_sub(one, qc);
         cur = fr_mul(cur, f);
@@ -74,11 +74,16 @@ __device__ __forceinline__ void eq_suffix_pyramid_body(const PyramidArgs& a, siz
     }
 }
 GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramid(PyramidArgs a) {
-    eq_suffix_pyramid_body(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    eq_suffix_pyramid_body(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x, a.q);
 }
 // up to four pyramids of a layer in one launch (blockIdx.y selects; unused slots have max_level < 0)
+// The coordinates travel with the launch (qv, for the pyramids whose q is null): up to GKR_PYR_MAXQ of them -- every layer of up to
+// 2^30 entries -- instead of a copy to device memory queued in front of the launch, which is a dispatch of its own (a blit kernel:
+// two per layer, one in eight of a small proof's dispatches -- and the dispatches are what many small proofs in flight are bound by).
+#define GKR_PYR_MAXQ 30
 struct PyramidArgs3 {
     PyramidArgs p[4];
+    Fr qv[GKR_PYR_MAXQ];
 };
 // The upper levels of a wide pyramid without the long chains: level s > lo_level of the pyramid over q[.. nc) is
 //     level_s[idx] = level_lo[idx mod 2^lo_level] * H_(s - lo_level)[idx >> lo_level],
@@ -109,9 +114,11 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_pyramid_expand(Batch<PyramidEx
 }
 GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_eq_suffix_pyramids(Batch<PyramidArgs3> ba) {
     __builtin_amdgcn_s_setprio(3);      // (as k_eq_pyramid_expand)
-    const PyramidArgs& p = ba.inst[blockIdx.z].p[blockIdx.y];
+    const PyramidArgs3& a3 = ba.inst[blockIdx.z];
+    const PyramidArgs& p = a3.p[blockIdx.y];
     if (p.max_level < 0) return;
-    eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (p.q) eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x, p.q);
+    else eq_suffix_pyramid_body(p, (size_t)blockIdx.x * blockDim.x + threadIdx.x, a3.qv);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -354,6 +354,18 @@ inline void ahead_contract(const E* S, const E* q_low, int t, E* out) {
 // Queue round 0 of the layer gkr.Prove proves next (cx().nxt_*), whose point is THIS layer's challenges: chal[0 .. k_known]
 // exist, the last t = m - 1 - k_known are still to come (this layer's host tail).  Called where the host tail starts; the
 // stream is idle from here to the end of the layer.  The products of k_cipher_pre are used when they exist for that layer.
+// the coordinates of a layer's pyramids: with the launch when they fit (PyramidArgs3::qv), else staged to cx().d_q; returns what the
+// pyramids' q must be (nullptr: qv)
+int pyramid_coords(PyramidArgs3& pa3, const E* coords, size_t n, const Fr** qsrc) {
+    if (n <= (size_t)GKR_PYR_MAXQ) {
+        for (size_t i = 0; i < n; i++) pa3.qv[i] = to_dev(coords[i]);
+        *qsrc = nullptr;
+        return 0;
+    }
+    CHK(stage_coords(coords, n));
+    *qsrc = cx().d_q;
+    return 0;
+}
 int ahead_launch(int m, const E* chal, int k_known, bool solo) {
     const DevTable* K = cx().nxt_K;
     const DevTable* S = cx().nxt_S;
@@ -374,23 +386,24 @@ int ahead_launch(int m, const E* chal, int k_known, bool solo) {
             if (tc.first->base) table_release(tc.first);
             CHK(table_alloc(tc.first, tc.second));
         }
-    CHK(stage_coords(chal, (size_t)(m - t)));
+    PyramidArgs3 pa3;
+    memset(&pa3, 0, sizeof pa3);
+    const Fr* qsrc = nullptr;
+    CHK(pyramid_coords(pa3, chal, (size_t)(m - t), &qsrc));
     if (g_arena_check.load(std::memory_order_relaxed)) {      // table_release: everything in front of this point must be done when this layer's scratch goes back
         if (!cx().chk_fence) HIPCHK(hipEventCreateWithFlags(&cx().chk_fence, hipEventDisableTiming));
         HIPCHK(hipEventRecord(cx().chk_fence, cx().stream));
     }
-    PyramidArgs3 pa3;
-    memset(&pa3, 0, sizeof pa3);
     for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
     pa3.p[0].out = cx().ahead_pyrTh.planes();      // lane weight over the known low bits: level g - t = eq(q[m-g .. m-t-1], gtid >> t)
     pa3.p[0].out2 = Planes{nullptr, nullptr};
-    pa3.p[0].q = cx().d_q;
+    pa3.p[0].q = qsrc;
     pa3.p[0].nc = m - t;
     pa3.p[0].max_level = g - t;
     pa3.p[0].seed = to_dev(hfr::ONE);
     pa3.p[1].out = cx().ahead_pyrU.planes();       // iteration weight: level lj = eq(q[1 .. m-g-1], j)
     pa3.p[1].out2 = cx().ahead_pyrU2.planes();
-    pa3.p[1].q = cx().d_q;
+    pa3.p[1].q = qsrc;
     pa3.p[1].nc = m - g;
     pa3.p[1].max_level = lj;
     pa3.p[1].seed = to_dev(hfr::ONE);
@@ -727,7 +740,10 @@ struct CipherLoop {
         g_big = solo ? std::min(g_m + 1, 17) : g_m;
         const int gT = std::max(threads_log2(0), std::min(g_m, m - 1));   // highest level of the per-lane pyramid
         LAP("setup: enter");
-        CHK(stage_coords(q, (size_t)m));
+        PyramidArgs3 pa3;
+        memset(&pa3, 0, sizeof pa3);
+        const Fr* qsrc = nullptr;
+        CHK(pyramid_coords(pa3, q, (size_t)m, &qsrc));
         LAP("setup: stage_coords");
         gsplit[0] = std::min(g_m, m - 1);
         gsplit[1] = g_big;
@@ -735,15 +751,13 @@ struct CipherLoop {
         CHK(table_alloc(&ks, std::max<size_t>(n / 2, 1)));
         CHK(table_alloc(&ss, std::max<size_t>(n / 2, 1)));
         // the per-lane pyramid (over all of q) and the per-iteration pyramids (one per thread split) in ONE launch
-        PyramidArgs3 pa3;
-        memset(&pa3, 0, sizeof pa3);
         for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
         // the per-lane pyramid in two steps when it is wide (option pyr_split, default 12): levels up to 2^12 entries and the small
         // pyramid H over the next coordinates here, the upper levels by k_eq_pyramid_expand with one product per entry
         const int gLow = (cx().pyr_split > 0 && gT > cx().pyr_split + 1) ? cx().pyr_split : gT;
         pa3.p[0].out = pyrT.planes();
         pa3.p[0].out2 = Planes{nullptr, nullptr};
-        pa3.p[0].q = cx().d_q;
+        pa3.p[0].q = qsrc;
         pa3.p[0].nc = m;
         pa3.p[0].max_level = gLow;
         pa3.p[0].seed = to_dev(seed);
@@ -751,7 +765,7 @@ struct CipherLoop {
             CHK(table_alloc(&pyrH, (size_t)2 << (gT - gLow)));
             pa3.p[3].out = pyrH.planes();
             pa3.p[3].out2 = Planes{nullptr, nullptr};
-            pa3.p[3].q = cx().d_q;
+            pa3.p[3].q = qsrc;
             pa3.p[3].nc = m - gLow;
             pa3.p[3].max_level = gT - gLow;
             pa3.p[3].seed = to_dev(hfr::ONE);
@@ -765,7 +779,7 @@ struct CipherLoop {
                 PyramidArgs& pa = pa3.p[1 + v];
                 pa.out = pyrU[v].planes();
                 pa.out2 = pyrU2[v].planes();
-                pa.q = cx().d_q;
+                pa.q = qsrc;
                 pa.nc = m - gsplit[v];                     // q[0 .. m-g-1]; level L = eq(q[nc-L .. nc-1], .)
                 pa.max_level = mU;
                 pa.seed = to_dev(hfr::ONE);
@@ -1216,21 +1230,22 @@ struct LinearLoop {
         g_lin = round_threads_log2_max(m);
         const int gT = std::min(g_lin, m - 1);
         const int mU = m - 1 - gT;
-        CHK(stage_coords(q, (size_t)m));
+        PyramidArgs3 pa3;
+        memset(&pa3, 0, sizeof pa3);
+        const Fr* qsrc = nullptr;
+        CHK(pyramid_coords(pa3, q, (size_t)m, &qsrc));
         CHK(table_alloc(&pyrT, (size_t)2 << gT));
         CHK(table_alloc(&pyrU, (size_t)2 << std::max(mU, 0)));
         for (int t = 0; t < arity; t++) CHK(table_alloc(&scratch[t], std::max<size_t>(n / 2, 1)));
-        PyramidArgs3 pa3;
-        memset(&pa3, 0, sizeof pa3);
         for (int v = 0; v < 4; v++) pa3.p[v].max_level = -1;
         pa3.p[0].out = pyrT.planes();
-        pa3.p[0].q = cx().d_q;
+        pa3.p[0].q = qsrc;
         pa3.p[0].nc = m;
         pa3.p[0].max_level = gT;
         pa3.p[0].seed = to_dev(seed);
         if (mU > 0) {
             pa3.p[1].out = pyrU.planes();
-            pa3.p[1].q = cx().d_q;
+            pa3.p[1].q = qsrc;
             pa3.p[1].nc = m - gT;
             pa3.p[1].max_level = mU;
             pa3.p[1].seed = to_dev(hfr::ONE);
