@@ -308,6 +308,43 @@ func (s *Session) Prove(qPrime []fr.Element) []fr.Element {
 	return flat
 }
 
+// MaxGroup is the largest number of sessions ProveGroup takes.
+const MaxGroup = 8
+
+// ProveGroup is gkr.Prove (gkr/prover.go:21-47) for up to MaxGroup sessions of the same circuit and size in ONE cgo call: proof i
+// is, bit for bit, ss[i].Prove(qPrimes[i]); the library proves them in lock-step on the calling thread and sends the round kernels
+// of all of them to the GPU as one launch (gkrhip_mimc_session_prove_group).  Where the reference's host proves many small
+// statements from a goroutine each, one goroutine per three of them is the faster shape here: bN = 20, 72 in flight, 81 M against
+// 64 M hashes/s (profiles/r06_proof_groups.txt); from 2^22 hashes per proof on, plain Prove from a goroutine each is as fast or faster.
+func ProveGroup(ss []*Session, qPrimes [][]fr.Element) [][]fr.Element {
+	n := len(ss)
+	if n == 0 || n > MaxGroup || n != len(qPrimes) {
+		panic("gkrhip: ProveGroup takes 1..8 sessions and as many points")
+	}
+	flats := make([][]fr.Element, n)
+	// cgo: no Go pointers to Go pointers -- the three arrays of pointers live in C memory, what they point to is pinned for the call
+	word := C.size_t(unsafe.Sizeof(uintptr(0)))
+	arr := C.malloc(3 * MaxGroup * word)
+	defer C.free(arr)
+	hs := (*[MaxGroup]*C.gkrhip_session)(arr)
+	qs := (*[MaxGroup]*C.uint64_t)(unsafe.Add(arr, MaxGroup*int(word)))
+	fs := (*[MaxGroup]*C.uint64_t)(unsafe.Add(arr, 2*MaxGroup*int(word)))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	for i, s := range ss {
+		flats[i] = make([]fr.Element, s.ProofLen())
+		hs[i] = s.h
+		qs[i] = ptr(qPrimes[i])
+		fs[i] = ptr(flats[i])
+		if len(qPrimes[i]) > 0 {
+			pin.Pin(&qPrimes[i][0])
+		}
+		pin.Pin(&flats[i][0])
+	}
+	must(C.gkrhip_mimc_session_prove_group(C.int(n), &hs[0], &qs[0], &fs[0], nil))
+	return flats
+}
+
 // Outputs downloads the assignment of the last layer.
 func (s *Session) Outputs() []fr.Element {
 	out := make([]fr.Element, 1<<s.bN)
