@@ -19,6 +19,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -443,6 +445,10 @@ int gkrhip_set_option(const char* key, long value) {
         g_wait_override.store((int)std::max(-2L, value));
         return 0;
     }
+    if (!strcmp(key, "group_size")) {           // single calls that meet form proof groups of this many (0 | 1: never; gkrhip_mimc_session_prove)
+        g_group_size.store((int)std::max(0L, std::min((long)GKR_GROUP_MAX, value)));
+        return 0;
+    }
     if (!strcmp(key, "msm_sort_levels")) {      // 0: by size, 1 | 2: forced (host_msm.hip.h); takes effect at the next MSM of a handle
         g_msm_sort_levels.store((int)value);
         return 0;
@@ -840,11 +846,114 @@ int gkrhip_mimc_session_assign(gkrhip_session* s) {
     return session_assign(s);
 }
 
-int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_t* flat) {
+static int session_prove_on_its_lane(gkrhip_session* s, const uint64_t* qprime, uint64_t* flat) {
     SESSION_ENTER(s);
     const int rc = session_prove(s, (const E*)qprime, (E*)flat);
     if (rc != 0) shm_abort();     // a sharded proof that fails on this rank must not leave the peers waiting
     return rc;
+}
+int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint64_t* const* qprimes, uint64_t* const* flats, int* rcs);
+
+// ---- single calls that meet form groups ---------------------------------------------------------------------------------------
+// The reference proves independent statements from a goroutine each: many host threads inside gkrhip_mimc_session_prove at once.
+// When enough of them prove SMALL statements (2^21 entries and fewer: where proof groups pay) the calls that arrive
+// together are proven as a group by the first of them -- the others wait for their result -- so that the host gets the groups'
+// throughput through the reference's own call shape.  A caller waits for company at most kCoalesceWaitUs; a call that finds none
+// runs as it always did.  Option "group_size" (default 3; 0 or 1: never).  Same transcripts either way.
+namespace {
+std::atomic<int> g_small_callers{0};               // threads inside gkrhip_mimc_session_prove with a small un-sharded session
+const int kCoalesceFromCallers = 6, kCoalesceMaxBn = 21, kCoalesceWaitUs = 300;
+struct Forming {
+    int n = 0, want = 0, refs = 0;
+    gkrhip_session* s[GKR_GROUP_MAX];
+    const uint64_t* q[GKR_GROUP_MAX];
+    uint64_t* flat[GKR_GROUP_MAX];
+    int rc[GKR_GROUP_MAX];
+    bool closed = false, done = false;
+    std::condition_variable cv_full, cv_done;
+};
+std::mutex g_forming_mu;
+std::unordered_map<unsigned long long, Forming*> g_forming;      // by shape: the group that is waiting for company
+}  // namespace
+
+int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_t* flat) {
+    if (!s || !s->lane) return fail("null session");
+    const int want = g_group_size.load(std::memory_order_relaxed);
+    const bool small = want >= 2 && s->lane != &g0 && s->bN >= 1 && s->bN <= kCoalesceMaxBn && !t_group && !g_regular_io && !g_safe_mode && !g_local_only;
+    if (!small) return session_prove_on_its_lane(s, qprime, flat);
+    struct Count {
+        Count() { g_small_callers.fetch_add(1, std::memory_order_relaxed); }
+        ~Count() { g_small_callers.fetch_sub(1, std::memory_order_relaxed); }
+    } count;
+    if (g_small_callers.load(std::memory_order_relaxed) < kCoalesceFromCallers) return session_prove_on_its_lane(s, qprime, flat);
+    const unsigned long long key = ((unsigned long long)s->bN << 32) ^ (unsigned long long)s->c.size();
+    std::unique_lock<std::mutex> lk(g_forming_mu);
+    auto it = g_forming.find(key);
+    if (it != g_forming.end()) {
+        Forming* f = it->second;
+        bool twice = false;
+        for (int i = 0; i < f->n; i++) twice = twice || f->s[i] == s;
+        if (!twice) {                     // join: the first caller proves, this one waits for its result
+            const int me = f->n++;
+            f->s[me] = s;
+            f->q[me] = qprime;
+            f->flat[me] = flat;
+            f->refs++;
+            if (f->n >= f->want) {
+                f->closed = true;
+                g_forming.erase(it);
+                f->cv_full.notify_all();
+            }
+            f->cv_done.wait(lk, [&] { return f->done; });
+            const int rc = f->rc[me];
+            if (--f->refs == 0) delete f;
+            lk.unlock();
+            if (rc != 0) {                // the message of this proof's failure, on this thread too
+                std::string m;
+                if (error_lookup(rc, &m)) g_err = m;
+            }
+            return rc;
+        }
+        lk.unlock();                      // the same session from two threads: they take turns on its lane, as ever
+        return session_prove_on_its_lane(s, qprime, flat);
+    }
+    Forming* f = new Forming();
+    f->want = std::min(want, GKR_GROUP_MAX);
+    f->n = 1;
+    f->refs = 1;
+    f->s[0] = s;
+    f->q[0] = qprime;
+    f->flat[0] = flat;
+    g_forming[key] = f;
+    f->cv_full.wait_for(lk, std::chrono::microseconds(kCoalesceWaitUs), [&] { return f->closed; });
+    if (!f->closed) {
+        f->closed = true;
+        g_forming.erase(key);
+    }
+    const int n = f->n;
+    lk.unlock();
+    int rc0;
+    if (n == 1) {
+        rc0 = session_prove_on_its_lane(s, qprime, flat);
+        f->rc[0] = rc0;
+    } else {
+        for (int i = 0; i < n; i++) f->rc[i] = 0;
+        const int rc = gkrhip_mimc_session_prove_group(n, f->s, f->q, f->flat, f->rc);
+        if (rc != 0) {                     // the group call itself was refused (no proof has a code of its own): every caller gets that code
+            bool any = false;
+            for (int i = 0; i < n; i++) any = any || f->rc[i] != 0;
+            if (!any)
+                for (int i = 0; i < n; i++) f->rc[i] = rc;
+        }
+        rc0 = f->rc[0];
+        g_cnt_coalesced.fetch_add((unsigned long long)n, std::memory_order_relaxed);
+    }
+    lk.lock();
+    f->done = true;
+    f->cv_done.notify_all();
+    if (--f->refs == 0) delete f;
+    lk.unlock();
+    return rc0;
 }
 
 // gkr.Prove for n sessions of the same shape from ONE host thread, in lock-step (host_group.hip.h): every proof is the proof
@@ -1812,6 +1921,7 @@ int gkrhip_profile_reset(size_t min_n) {
     g_cnt_layer_check_failures = 0;
     g_cnt_group_launches = 0;
     g_cnt_group_combined = 0;
+    g_cnt_coalesced = 0;
     return for_each_lane([&](Ctx* l) {
         HIPCHK(hipStreamSynchronize(l->stream));
         prof_clear(l->prof);
@@ -2324,6 +2434,7 @@ int gkrhip_profile_counter(const char* name, uint64_t* value) {
     else if (n == "layer_checks") *value = g_cnt_layer_checks.load();
     else if (n == "layer_check_failures") *value = g_cnt_layer_check_failures.load();
     else if (n == "arena_busy_releases") *value = g_cnt_busy_releases.load();
+    else if (n == "coalesced_proofs") *value = g_cnt_coalesced.load();              // single calls that were proven in a group formed from single calls
     else if (n == "group_launches_wanted") *value = g_cnt_group_launches.load();      // launches the proofs of the groups asked for ...
     else if (n == "group_launches_made") *value = g_cnt_group_combined.load();       // ... and the combined launches that served them
     else return fail("gkrhip_profile_counter: unknown counter '%s'", name);

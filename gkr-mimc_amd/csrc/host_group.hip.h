@@ -78,6 +78,8 @@ inline int hw_queue_count() {
     return a > 0 ? a : (b > 0 ? b : 4);       // (4: the runtime's default)
 }
 std::atomic<unsigned long long> g_cnt_group_launches{0}, g_cnt_group_combined{0};
+std::atomic<int> g_group_size{3};                     // option group_size: single calls that meet form groups of this many (gkrhip_mimc_session_prove)
+std::atomic<unsigned long long> g_cnt_coalesced{0};   // proofs that were proven in a group formed from single calls
 
 // the launch site of a batched kernel
 template <class A>

@@ -16,7 +16,7 @@ GMIMC = "gmimc" in sys.argv      # the GMiMC t = 2 circuit (BASELINE config 5) i
 sys.argv = [a for a in sys.argv if a != "gmimc"]
 bn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nfl = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-ks = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8").split(",")]
+ks = [x for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8").split(",")]      # "3": explicit groups of 3; "1": single calls, never grouped; "c3": single calls, the library forms groups of 3 (option group_size)
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 gmaxes = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [None]
 for kv in os.environ.get("GKRHIP_BENCH_OPTIONS", "").split(","):
@@ -40,6 +40,7 @@ for i in range(nfl):
 qs = [rnd_q() for _ in range(nfl)]
 
 # parity: groups of every size up to 8 against the single proofs
+gk.set_option("group_size", 0)
 single = [s.prove(q) for s, q in zip(sessions[:8], qs[:8])]
 for k in (1, 2, 3, 5, 8):
     if k > nfl:
@@ -52,6 +53,12 @@ for k in (1, 2, 3, 5, 8):
 
 
 def run(k):
+    coalesce = 0
+    if str(k).startswith("c"):
+        coalesce, k = int(k[1:]), 1
+    k = int(k)
+    gk.set_option("group_size", coalesce)
+    gk.profile_reset(1 << 40)
     chunks = [list(range(i, min(i + k, nfl))) for i in range(0, nfl, k)]
     errs = []
 
@@ -79,8 +86,9 @@ def run(k):
         if trial:
             best = dt if best is None else min(best, dt)
     per = best / (reps * nfl)
-    print("bN=%d, %d proofs in flight, groups of %d (%d host threads)%s: %.2f ms per proof, %.2f M hashes/s" %
-          (bn, nfl, k, len(chunks), "" if gm is None else ", g_max %d" % gm, 1e3 * per, (1 << bn) / per / 1e6), flush=True)
+    what = ("single calls, groups of %d formed by the library (%d of %d proofs)" % (coalesce, gk.profile_counter("coalesced_proofs"), 3 * reps * nfl)) if coalesce else "groups of %d" % k
+    print("bN=%d, %d proofs in flight, %s (%d host threads)%s: %.2f ms per proof, %.2f M hashes/s" %
+          (bn, nfl, what, len(chunks), "" if gm is None else ", g_max %d" % gm, 1e3 * per, (1 << bn) / per / 1e6), flush=True)
 
 
 for gm in gmaxes:
