@@ -110,6 +110,7 @@ def config_summary(out):
             sm[key] = {"hashes_per_s": r(c["hashes_per_s"], 0), "single_proof_ms": r(c["single_proof_ms"], 2),
                        "lanes": c["concurrent_proofs"], "proofs_per_group": c.get("proofs_per_group", 1),
                        "lanes_only_hashes_per_s": r((c.get("lanes_only") or {}).get("hashes_per_s"), 0),
+                       "single_calls_grouped_hashes_per_s": r((c.get("single_calls_grouped_by_the_library") or {}).get("hashes_per_s"), 0),
                        "verified": c["proof_verified_by_native_gkr_verify"]}
     one = out.get("oneshot_including_pcie")
     sm["oneshot_s"] = r(one["one_call_s"], 4) if one else None
@@ -1178,6 +1179,7 @@ def main():
             cj = Job(gk, cbn, max(cl, gl), gk.gmimc_t2_circuit() if circ == "gmimc" else None)
             note("config %s: sessions assigned, running" % key)
             cj.nconc = cl
+            gk.set_option("group_size", 0)                       # "lanes_only": single calls never meet in groups
             cj.run_steps(max(2, cl))
             sync_all()
             cj.last[0] = cj.sessions[0].prove(cj.qprime)      # untimed: the first proof ALONE takes the lane's one-time set-up of the solo paths
@@ -1195,8 +1197,23 @@ def main():
             ckept, csame = cj.transcripts_identical(ref_proof)
             ok = ok and ckept == csteps and csame == ckept      # every timed proof is the verified transcript, bit for bit
             lanes_res = {"hashes_per_s": float(1 << cbn) * csteps / cdt, "ms_per_step": 1e3 * cdt / csteps, "steps": csteps, "concurrent_proofs": cl}
-            grp_res = None
+            gk.set_option("group_size", 3)                       # the library's default
+            grp_res = coal_res = None
             if group > 1 and gl >= 2 * group:
+                # the reference's call shape -- one host thread per statement, gkr.Prove each -- with the library's default: calls that
+                # meet are proven as groups of 3 by the first of them (gkrhip_mimc_session_prove)
+                cj.nconc, cj.group = gl, 1
+                cj.run_steps(gl)
+                gk.profile_reset(1 << 40)
+                cj.keep = []
+                csteps2 = 3 * gl
+                cdt2 = timed(cj, csteps2)
+                ckept2, csame2 = cj.transcripts_identical(ref_proof)
+                ok = ok and ckept2 == csteps2 and csame2 == ckept2
+                coal_res = {"hashes_per_s": float(1 << cbn) * csteps2 / cdt2, "ms_per_step": 1e3 * cdt2 / csteps2, "steps": csteps2, "concurrent_proofs": gl,
+                            "host_threads": gl, "proofs_per_group": group, "proofs_proven_in_groups": gk.profile_counter("coalesced_proofs"),
+                            "note": "single gkrhip_mimc_session_prove calls from one host thread per session; the library forms the groups"}
+                note("config %s: single calls that meet done" % key)
                 cj.nconc, cj.group = gl, group
                 gsteps = 3 * gl
                 cj.run_steps(gl)                                  # warm-up: one call per group
@@ -1215,10 +1232,10 @@ def main():
                 note("config %s: groups done" % key)
             cj.close()
             note("config %s: closed" % key)
-            best = grp_res if (grp_res and grp_res["hashes_per_s"] > lanes_res["hashes_per_s"]) else lanes_res
+            best = max([r_ for r_ in (lanes_res, grp_res, coal_res) if r_], key=lambda r_: r_["hashes_per_s"])
             configs[key] = {"hashes_per_s": best["hashes_per_s"], "ms_per_step": best["ms_per_step"], "steps": best["steps"],
                             "concurrent_proofs": best["concurrent_proofs"], "proofs_per_group": best.get("proofs_per_group", 1),
-                            "lanes_only": lanes_res, "groups": grp_res,
+                            "lanes_only": lanes_res, "groups": grp_res, "single_calls_grouped_by_the_library": coal_res,
                             "single_proof_ms": sorted(lat)[1], "single_proof_samples_ms": lat,
                             "single_proof_hashes_per_s": float(1 << cbn) / (sorted(lat)[1] * 1e-3),
                             "proof_verified_by_native_gkr_verify": ok,

@@ -80,6 +80,7 @@ int gkrhip_reserve_lanes(int n);
  * "coop", "coop_lg", "coop_wgs", "spec", "spec_lg", "ahead", "solo_boost", "pyr_split" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
  * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums);
+ * "group_size" (process-wide, default 3; 0 | 1: never): gkrhip_mimc_session_prove calls that meet are proven in groups of this many;
  * "wait_spin_us" (how host threads wait for a round kernel: -2 by the CPUs available -- the default --, -1 always spin, n: spin n us, then sleep).
  * Integrity (process-wide): "layer_check" (default 1) -- every sumcheck the library produces is held against the verifier's own
  * identities before it is returned (sumcheck/verifier.go:41-47 per round, the closing identity of gkr/verifier.go:93-114; host
@@ -157,6 +158,12 @@ int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session *s, const uint64_t *in0,
  * index_stride/index_offset select the shard i = j*stride + offset (1, 0 for the whole hypercube). */
 int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session *s, uint64_t index_stride, uint64_t index_offset);
 int gkrhip_mimc_session_assign(gkrhip_mimc_session *s);
+/* gkr.Prove (gkr/prover.go:21-91) on the resident assignment.  Thread-safe: sessions with lanes of their own prove concurrently from
+ * different host threads (the reference's goroutine per statement).  When six or more host threads are inside this call with SMALL
+ * un-sharded sessions (2^21 entries and fewer), calls that arrive within 300 us of each other are proven together as a proof group by
+ * the first of them -- the others block until their proof is there (see gkrhip_mimc_session_prove_group: same transcripts, the
+ * round kernels of the group in one launch; bN = 20, 72 callers: 66 -> 79 M hashes/s).  gkrhip_set_option("group_size", 0) turns
+ * that off; counter "coalesced_proofs". */
 int gkrhip_mimc_session_prove(gkrhip_mimc_session *s, const uint64_t *qprime, uint64_t *flat);
 /* gkr.Prove (gkr/prover.go:21-91) for n sessions of the same shape from one host thread, in lock-step: proof i is, bit for bit,
  * what gkrhip_mimc_session_prove(s[i], qprime[i], flat[i]) returns, but the round kernels of the n proofs go to the GPU as ONE
@@ -438,7 +445,8 @@ int gkrhip_profile_latency(uint64_t *prelaunched_rounds, uint64_t *lookahead_rou
  * alone); the runtime reads the variable when it initialises, so the setting only takes effect if the library made the
  * process's first HIP call; "arena_busy_releases": see gkrhip_set_option, "arena_check";
  * "group_launches_wanted" / "group_launches_made": the kernel launches the proofs of gkrhip_mimc_session_prove_group asked for, and
- * the combined launches that served them (wanted / made = proofs per launch).  Unknown name: error. */
+ * the combined launches that served them (wanted / made = proofs per launch); "coalesced_proofs": gkrhip_mimc_session_prove calls that
+ * were proven in a group formed from single calls.  Unknown name: error. */
 int gkrhip_profile_counter(const char *name, uint64_t *value);
 
 #ifdef __cplusplus

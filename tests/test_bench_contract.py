@@ -274,7 +274,7 @@ def test_config_summary_carries_the_second_tier_results():
            "oneshot_including_pcie": {"one_call_s": 0.31}, "roofline": {"frac": 0.79}, "partial_eval": {"frac": 0.86},
            "integrity": {"layer_checks": 920, "layer_check_failures": 0, "chal_retries": 0}}
     sm = b.config_summary(out)
-    assert sm["bn20"] == {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "lanes": 72, "proofs_per_group": 3, "lanes_only_hashes_per_s": 6.4e7, "verified": True}
+    assert sm["bn20"] == {"hashes_per_s": 7.2e7, "single_proof_ms": 92.5, "lanes": 72, "proofs_per_group": 3, "lanes_only_hashes_per_s": 6.4e7, "single_calls_grouped_hashes_per_s": None, "verified": True}
     assert sm["gmimc_bn22"]["proofs_per_group"] == 1 and sm["gmimc_bn22"]["lanes_only_hashes_per_s"] is None
     assert sm["msm_g1_2p24_ms"] == 19.5 and sm["compute_h_2p24_ms"] == 12.7 and sm["oneshot_s"] == 0.31
     assert sm["msm_g1_fixed_base_ms"] == {"2p24": 18.0} and sm["layer_checks"] == 920 and sm["chal_retries"] == 0
