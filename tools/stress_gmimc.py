@@ -37,7 +37,7 @@ def main():
 
     ths = [threading.Thread(target=work, args=(k,)) for k in range(len(sessions))]
     [t.start() for t in ths]; [t.join() for t in ths]
-    print("gmimc soak: proofs per lane:", counts, "total", sum(counts), "mismatches:", bad, "spec rounds", gk.profile_get()["spec_rounds"], "layers retried after a missed challenge:", gk.profile_get()["chal_retries"], "sumchecks checked / not closing:", gk.profile_get()["layer_checks"], "/", gk.profile_get()["layer_check_failures"], "round 0 ahead:", gk.profile_get()["ahead_round0"])
+    print("gmimc soak: proofs per lane:", counts, "total", sum(counts), "mismatches:", bad, "spec rounds", gk.profile_get()["spec_rounds"], "layers retried after a missed challenge:", gk.profile_get()["chal_retries"], "sumchecks checked / not closing:", gk.profile_get()["layer_checks"], "/", gk.profile_get()["layer_check_failures"], "round 0 ahead:", gk.profile_get()["ahead_round0"], "proven in groups formed from single calls:", gk.profile_counter("coalesced_proofs"))
     sys.exit(1 if bad else 0)
 
 main()

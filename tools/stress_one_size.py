@@ -46,8 +46,8 @@ def main():
         t.join()
     p = gk.profile_get()
     print("bN = %d, %d lanes x %d proofs, mismatches (lane, proof, last differing row): %s; sumchecks checked %d, not closing %d, "
-          "layers retried after a missed challenge %d, round 0 ahead %d"
-          % (bn, lanes, per, bad, p["layer_checks"], p["layer_check_failures"], p["chal_retries"], p["ahead_round0"]))
+          "layers retried after a missed challenge %d, round 0 ahead %d, proven in groups formed from single calls %d"
+          % (bn, lanes, per, bad, p["layer_checks"], p["layer_check_failures"], p["chal_retries"], p["ahead_round0"], gk.profile_counter("coalesced_proofs")))
     sys.exit(1 if bad else 0)
 
 
