@@ -856,13 +856,17 @@ int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint
 
 // ---- single calls that meet form groups ---------------------------------------------------------------------------------------
 // The reference proves independent statements from a goroutine each: many host threads inside gkrhip_mimc_session_prove at once.
-// When enough of them prove SMALL statements (2^21 entries and fewer: where proof groups pay) the calls that arrive
+// When enough of them prove SMALL statements (2^18..2^21 entries: where proof groups pay) the calls that arrive
 // together are proven as a group by the first of them -- the others wait for their result -- so that the host gets the groups'
 // throughput through the reference's own call shape.  A caller waits for company at most kCoalesceWaitUs; a call that finds none
 // runs as it always did.  Option "group_size" (default 3; 0 or 1: never).  Same transcripts either way.
 namespace {
 std::atomic<int> g_small_callers{0};               // threads inside gkrhip_mimc_session_prove with a small un-sharded session
-const int kCoalesceFromCallers = 6, kCoalesceMaxBn = 21, kCoalesceWaitUs = 300;
+// Where groups pay: the job must be bound by the GPU's dispatch, not by the hosts' hashing -- a group's proofs take turns on ONE host
+// thread.  Fourteen callers with statements of 2^7..2^22 entries lost a quarter of their throughput to grouping (7 125 -> 5 064 proofs
+// in 45 s, tools/stress.py; GMiMC lanes 9 890 -> 7 446): few callers and tiny statements are host-bound, every caller needs its
+// own core.  So: from 24 callers on, statements of 2^18..2^21 entries.
+const int kCoalesceFromCallers = 24, kCoalesceMinBn = 18, kCoalesceMaxBn = 21, kCoalesceWaitUs = 300;
 struct Forming {
     int n = 0, want = 0, refs = 0;
     gkrhip_session* s[GKR_GROUP_MAX];
@@ -879,7 +883,12 @@ std::unordered_map<unsigned long long, Forming*> g_forming;      // by shape: th
 int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_t* flat) {
     if (!s || !s->lane) return fail("null session");
     const int want = g_group_size.load(std::memory_order_relaxed);
-    const bool small = want >= 2 && s->lane != &g0 && s->bN >= 1 && s->bN <= kCoalesceMaxBn && !t_group && !g_regular_io && !g_safe_mode && !g_local_only;
+    // (a lane with a serial-latency path forced on -- the tests do that -- proves as it is told to: those paths queue kernels that poll
+    // for the host, which a group never does)
+    const Ctx* ln = s->lane;
+    const bool forced = ln->prelaunch >= 2 || ln->pre_mode >= 2 || ln->spec >= 2 || ln->coop >= 2;
+    const bool small = want >= 2 && ln != &g0 && s->bN >= kCoalesceMinBn && s->bN <= kCoalesceMaxBn && !forced && !t_group && !g_regular_io &&
+                       !g_safe_mode && !g_local_only;
     if (!small) return session_prove_on_its_lane(s, qprime, flat);
     struct Count {
         Count() { g_small_callers.fetch_add(1, std::memory_order_relaxed); }

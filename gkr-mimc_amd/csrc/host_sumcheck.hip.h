@@ -489,6 +489,10 @@ inline RoundPlan plan_rounds(int m, bool collective, int gamma_tail, bool* did_g
     p.m_dev = p.h_tail ? p.k_export + 1 : m;
     p.pl_on = !g_safe_mode && (cx().prelaunch >= 2 || (cx().prelaunch == 1 && p.alone));
     p.pre_on = !g_safe_mode && (cx().pre_mode >= 2 || (cx().pre_mode == 1 && p.alone));
+    // Inside a proof group (host_group.hip.h) nothing is queued that polls for the host: the group's proofs take turns on one thread, a
+    // kernel waiting for proof A's challenge would hold the stream while B and C hash (forced on, twelve lanes of bN = 18 in groups of
+    // 3 missed 91 challenges in 720 proofs -- each a second of waiting and a layer run again; profiles/r06_soaks_groups.txt)
+    if (t_group) p.pl_on = p.pre_on = false;
     // with round 0 running ahead of its point during the host tail (ahead_launch) the look-ahead products only pay from 2^22 entries
     // on: below, the whole round 0 fits the tail (bN = 18 / 20 / 21 alone: 75.9 / 92.9 / 107.7 ms without against 77.0 / 93.8 / 108.9 with
     // the products; bN = 22: 140.0 against 136.4)

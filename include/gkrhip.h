@@ -159,8 +159,8 @@ int gkrhip_mimc_session_load_inputs(gkrhip_mimc_session *s, const uint64_t *in0,
 int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session *s, uint64_t index_stride, uint64_t index_offset);
 int gkrhip_mimc_session_assign(gkrhip_mimc_session *s);
 /* gkr.Prove (gkr/prover.go:21-91) on the resident assignment.  Thread-safe: sessions with lanes of their own prove concurrently from
- * different host threads (the reference's goroutine per statement).  When six or more host threads are inside this call with SMALL
- * un-sharded sessions (2^21 entries and fewer), calls that arrive within 300 us of each other are proven together as a proof group by
+ * different host threads (the reference's goroutine per statement).  When 24 or more host threads are inside this call with
+ * un-sharded sessions of 2^18..2^21 entries, calls that arrive within 300 us of each other are proven together as a proof group by
  * the first of them -- the others block until their proof is there (see gkrhip_mimc_session_prove_group: same transcripts, the
  * round kernels of the group in one launch; bN = 20, 72 callers: 66 -> 79 M hashes/s).  gkrhip_set_option("group_size", 0) turns
  * that off; counter "coalesced_proofs". */
