@@ -13,6 +13,7 @@ echo "== GMiMC circuit lanes ($T s)"; timeout 600 python tools/stress_gmimc.py $
 echo "== twelve lanes of bN = 18, look-ahead, pre-launch and round 0 ahead forced, thread cap 2^15"; GKRHIP_GMAX=15 GKRHIP_PRELAUNCH=2 GKRHIP_PRE=2 GKRHIP_COOP=2 GKRHIP_SPEC=0 GKRHIP_AHEAD=2 timeout 600 python tools/stress_one_size.py 18 12 120 | tail -1
 echo "== twelve lanes of bN = 18, every solo path and speculation forced"; GKRHIP_PRELAUNCH=2 GKRHIP_PRE=2 GKRHIP_COOP=2 GKRHIP_SPEC=2 GKRHIP_AHEAD=2 timeout 600 python tools/stress_one_size.py 18 12 60 | tail -1
 echo "== twenty-four lanes of bN = 20, defaults"; timeout 600 python tools/stress_one_size.py 20 24 20 | tail -1
+echo "== forty-eight lanes of bN = 19, defaults: single calls that meet are proven in groups of 3"; timeout 600 python tools/stress_one_size.py 19 48 15 | tail -1
 echo "== lanes, mixed sizes, every solo path forced ($T s)"; GKRHIP_PRELAUNCH=2 GKRHIP_PRE=2 GKRHIP_COOP=2 GKRHIP_SPEC=0 GKRHIP_AHEAD=2 timeout 600 python tools/stress.py $T | tail -1
 echo "== sharded, 4 ranks on one GPU, shared-memory exchange (40 s)"; timeout 600 python tools/stress_sharded.py 40 4 shm | tail -2
 } > $OUT/soaks.txt 2>&1
