@@ -244,6 +244,41 @@ int main(int argc, char** argv) {
         check_proof_structure(c, degree, bN, a, qp, flat, "GMiMC t=4");
         gkrhip_mimc_session_destroy(s);
     }
+    // Proof groups from a compiled caller (gkrhip_mimc_session_prove_group): three MiMC statements with inputs and points of their own,
+    // proven in lock-step in one call -- each transcript is the oracle's for its statement; bad arguments are refused with a message.
+    {
+        const int bN = 8, G = 3;
+        const size_t n = (size_t)1 << bN, len = gkrhip_mimc_proof_len(bN);
+        std::vector<std::vector<ofr_t>> in0(G, std::vector<ofr_t>(n)), in1(G, std::vector<ofr_t>(n)), qp(G, std::vector<ofr_t>(bN)),
+            flat(G, std::vector<ofr_t>(len)), oflat(G, std::vector<ofr_t>(len)), oouts(G, std::vector<ofr_t>(n));
+        gkrhip_session* ss[G];
+        const uint64_t* qs[G];
+        uint64_t* fs[G];
+        int rcs[G] = {-1, -1, -1};
+        for (int g = 0; g < G; g++) {
+            for (size_t i = 0; i < n; i++) {
+                oracle_fr_from_u64(&in0[g][i], 0x9E3779B97F4A7C15ULL * (i + 1) + 31 * g);
+                oracle_fr_from_u64(&in1[g][i], 0xC2B2AE3D27D4EB4FULL * (i + 5) + 17 * g);
+            }
+            for (int k = 0; k < bN; k++) oracle_fr_from_u64(&qp[g][k], 0xD6E8FEB86659FD93ULL * (k + 2) + 101 * g);
+            CHECK(oracle_gkr_prove_mimc(bN, in0[g].data(), in1[g].data(), qp[g].data(), oflat[g].data(), oouts[g].data(), nullptr) == 0, "oracle prove (group)");
+            OK(gkrhip_mimc_session_create(&ss[g], bN));
+            OK(gkrhip_mimc_session_load_inputs(ss[g], (const uint64_t*)in0[g].data(), (const uint64_t*)in1[g].data()));
+            OK(gkrhip_mimc_session_assign(ss[g]));
+            qs[g] = (const uint64_t*)qp[g].data();
+            fs[g] = (uint64_t*)flat[g].data();
+        }
+        OK(gkrhip_mimc_session_prove_group(G, ss, qs, fs, rcs));
+        for (int g = 0; g < G; g++) {
+            CHECK(rcs[g] == 0, "group proof %d: code %d", g, rcs[g]);
+            CHECK(memcmp(flat[g].data(), oflat[g].data(), len * sizeof(ofr_t)) == 0, "group proof %d differs from the oracle's transcript", g);
+        }
+        gkrhip_session* twice[2] = {ss[0], ss[0]};
+        CHECK(gkrhip_mimc_session_prove_group(2, twice, qs, fs, nullptr) != 0 && strstr(gkrhip_last_error(), "twice"), "a session given twice was accepted");
+        CHECK(gkrhip_mimc_session_prove_group(0, ss, qs, fs, nullptr) != 0, "an empty group was accepted");
+        CHECK(gkrhip_mimc_session_prove_group(9, ss, qs, fs, nullptr) != 0, "a group of nine was accepted");
+        for (int g = 0; g < G; g++) gkrhip_mimc_session_destroy(ss[g]);
+    }
     // The hint's own safety net (prover/gadget/hints.go:224-228 `if debug`), as a compiled caller would use it: every sumcheck
     // of gkr.Prove is checked before it is returned and re-run if it does not close (a flipped bit of a device sum: same
     // transcript, one re-run counted); with that check off, verify_after_prove turns the wrong proof into an error.
