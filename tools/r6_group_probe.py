@@ -91,8 +91,14 @@ def run(k):
           (bn, nfl, what, len(chunks), "" if gm is None else ", g_max %d" % gm, 1e3 * per, (1 << bn) / per / 1e6), flush=True)
 
 
-for gm in gmaxes:
-    if gm is not None:
-        gk.set_option("g_max", gm)
-    for k in ks:
-        run(k)
+sweeps = sys.argv[6].split(";") if len(sys.argv) > 6 else [""]      # e.g. "slim=0;slim=1,slim_lg=14": option sets, one pass each
+for sw in sweeps:
+    for kv in filter(None, sw.split(",")):
+        gk.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    if sw:
+        print("--- options:", sw, flush=True)
+    for gm in gmaxes:
+        if gm is not None:
+            gk.set_option("g_max", gm)
+        for k in ks:
+            run(k)
