@@ -18,7 +18,7 @@ bn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nfl = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 ks = [x for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8").split(",")]      # "3": explicit groups of 3; "1": single calls, never grouped; "c3": single calls, the library forms groups of 3 (option group_size)
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-gmaxes = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [None]
+gmaxes = [None if x in ("-", "None") else int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [None]
 for kv in os.environ.get("GKRHIP_BENCH_OPTIONS", "").split(","):
     if "=" in kv:
         gk.set_option(kv.split("=")[0], int(kv.split("=")[1]))
