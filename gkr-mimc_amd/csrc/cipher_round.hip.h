@@ -420,15 +420,9 @@ template <bool FOLD, bool HAS_WJ>
 __global__ void __launch_bounds__(GKR_BLOCK, 1) k_cipher_round_lat(Batch<CipherRoundArgs> ba) {
     cipher_round_body<FOLD, HAS_WJ, true>(ba.inst[blockIdx.z]);
 }
-// The same round in at most 80 registers (six waves per SIMD by the compiler's count; the rest of its state lives in scratch): a wave
-// of it starts BESIDE two waves of the wide kernel (2 x 216 of a SIMD's 512 registers), where the 193-243 registers of the kernels
-// above wait for a wide workgroup to retire -- with many proofs in flight the small rounds spend 130 us per launch mostly waiting
-// for a slot (profiles/r06_groups_bn20_kernel_stats.csv), and they are latency, not arithmetic: a slower kernel that starts at once.
-template <bool FOLD, bool HAS_WJ>
-__global__ void __attribute__((amdgpu_flat_work_group_size(GKR_BLOCK, GKR_BLOCK), amdgpu_waves_per_eu(6, 6)))
-k_cipher_round_slim(Batch<CipherRoundArgs> ba) {
-    cipher_round_body<FOLD, HAS_WJ, false>(ba.inst[blockIdx.z]);
-}
+// (Round 6 measured this round in at most 80 registers -- amdgpu_waves_per_eu(6, 6): 208 registers spilled, 468 B of scratch per lane --
+// so that its waves start BESIDE two wide waves instead of waiting for a wide workgroup to retire: bN = 20, 72 in flight in groups of
+// 3 83.5 / 83.7 -> 82.9 / 82.7 M hashes/s, on lanes 66.4 / 66.2 -> 64.4 / 64.0: profiles/r06_slim_small_rounds.txt, commit 34d6a6d.  Not kept.)
 
 // ------------------------------------------------------------------------------------------------
 // Round 0 AHEAD of its evaluation point.  Round 0 of a layer needs the layer's whole point q -- the challenges of the layer

@@ -396,7 +396,7 @@ const char* gkrhip_version(void) { return "gkrhip 0.3 (gfx950)"; }
 int gkrhip_set_option(const char* key, long value) {
     static const char* keys[] = {"fold_grid", "fold_split", "g_max", "lat_mode", "wide_mode", "wt_late_lj", "claim_trick", "host_tail",
                                  "prelaunch", "prelaunch_lg", "lookahead", "coop", "spec", "spec_lg", "ahead", "solo_boost", "pyr_split",
-                                 "coop_wgs", "coop_lg", "pre_start_lg", "slim", "slim_lg"};
+                                 "coop_wgs", "coop_lg", "pre_start_lg"};
     // fault injection of the tests (host_sumcheck.hip.h): process-wide, fires once, -1 disarms
     if (!strcmp(key, "test_fail_after_prelaunch")) {
         g_test_fail_round.store((int)value);
@@ -480,8 +480,6 @@ int gkrhip_set_option(const char* key, long value) {
         else if (!strcmp(key, "coop_wgs")) l->coop_wgs = (int)std::max(1L, std::min(4096L, value));      // (the tests: several iterations per workgroup)
         else if (!strcmp(key, "coop_lg")) l->coop_lg = (int)std::max(0L, std::min(20L, value));
         else if (!strcmp(key, "pre_start_lg")) l->pre_start_lg = (int)std::max(8L, std::min(30L, value));
-        else if (!strcmp(key, "slim")) l->slim_mode = (int)value;
-        else if (!strcmp(key, "slim_lg")) l->slim_lg = (int)std::max(8L, std::min(20L, value));
         return 0;
     });
 }

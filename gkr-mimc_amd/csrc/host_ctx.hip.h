@@ -149,8 +149,6 @@ struct Ctx {
     bool claim_trick = true;                   // option claim_trick = 0: always compute all eight monomial sums
     int lat_mode = 1;                          // GKRHIP_LAT: 0 never, 1 rounds with one pair per lane, 2 always
     int wide_mode = 1;                         // GKRHIP_WIDE: deferred-reduction kernel for the rounds with several pairs per lane
-    int slim_mode = 0;                         // option slim: small rounds of proofs with company run the 80-register kernel (k_cipher_round_slim)
-    int slim_lg = 13;                          // ... rounds of at most 2^slim_lg threads
     int solo_boost = 1;                        // option solo_boost: twice the threads for the big rounds of a proof that is alone on the GPU
     int pyr_split = 12;                        // option pyr_split: the per-lane eq pyramid above 2^n entries in two launches (0: one launch)
     int wt_late_lj = 3;                        // ... and from 2^3 pairs per lane on, the lane weight is applied after the loop
@@ -557,8 +555,6 @@ void lane_configure(Ctx* l) {
     l->force_generic = g0.force_generic;
     l->lat_mode = g0.lat_mode;
     l->wide_mode = g0.wide_mode;
-    l->slim_mode = g0.slim_mode;
-    l->slim_lg = g0.slim_lg;
     l->wt_late_lj = g0.wt_late_lj;
     l->solo_boost = g0.solo_boost;
     l->claim_trick = g0.claim_trick;

@@ -4,13 +4,6 @@
 // ---- single-point cipher sumcheck: one fused launch per round (cipher_round.hip.h) -------------------
 template <bool FOLD, bool HAS_WJ>
 int launch_cipher_round(const CipherRoundArgs& a, int grid, bool lat, bool alone) {
-    if constexpr (FOLD) {
-        // with other proofs in flight: the 80-register form of the round, which starts beside the other proofs' wide waves (option slim)
-        if (!alone && cx().slim_mode && (size_t)grid * GKR_BLOCK <= ((size_t)1 << cx().slim_lg)) {
-            GKR_LAUNCH_BATCH((k_cipher_round_slim<FOLD, HAS_WJ>), dim3(grid), dim3(GKR_BLOCK), 0, cx().stream, a);
-            return 0;
-        }
-    }
     // a latency-bound launch of at most one workgroup per CU asks for enough (unused) dynamic LDS that two of its
     // workgroups cannot share a CU: the dispatcher otherwise packs some CUs with two lone-wave workgroups and leaves others idle
     // (only for a proof that is alone on the GPU: beside other proofs' kernels the extra LDS would keep the launch waiting)

@@ -31,8 +31,6 @@ GKR_INST template __global__ void k_cipher_round_lat<false, false>(Batch<CipherR
 GKR_INST template __global__ void k_cipher_round_lat<false, true>(Batch<CipherRoundArgs>);
 GKR_INST template __global__ void k_cipher_round_lat<true, false>(Batch<CipherRoundArgs>);
 GKR_INST template __global__ void k_cipher_round_lat<true, true>(Batch<CipherRoundArgs>);
-GKR_INST template __global__ void k_cipher_round_slim<true, false>(Batch<CipherRoundArgs>);
-GKR_INST template __global__ void k_cipher_round_slim<true, true>(Batch<CipherRoundArgs>);
 GKR_INST template __global__ void k_cipher_round_coop<false>(CipherRoundArgs);
 GKR_INST template __global__ void k_cipher_round_coop<true>(CipherRoundArgs);
 GKR_INST template __global__ void k_linear_round<false, false>(Batch<LinearRoundArgs>);
