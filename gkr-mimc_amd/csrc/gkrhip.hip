@@ -967,8 +967,8 @@ int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_
 
 // gkr.Prove for n sessions of the same shape from ONE host thread, in lock-step (host_group.hip.h): every proof is the proof
 // gkrhip_mimc_session_prove returns for its session and point -- same transcript, bit for bit -- but the round kernels of the n
-// proofs go to the GPU as one launch.  For many small proofs in flight (BASELINE config 2: bN = 20): a quarter of the launches,
-// each with four times the work, where the dispatch of tiny kernels is the bound.  Sessions with lanes of their own (un-sharded),
+// proofs go to the GPU as one launch.  For many small proofs in flight (BASELINE config 2: bN = 20): with groups of 3 a third of the launches,
+// each with three times the work, where the dispatch of tiny kernels is the bound.  Sessions with lanes of their own (un-sharded),
 // all different; rcs[i] (may be NULL) receives proof i's code; returns 0 or the first failing proof's code.
 int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint64_t* const* qprimes, uint64_t* const* flats, int* rcs) {
     if (n < 1 || n > GKR_GROUP_MAX) return fail("prove_group: %d proofs (1..%d)", n, GKR_GROUP_MAX);

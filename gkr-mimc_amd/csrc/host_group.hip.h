@@ -4,16 +4,16 @@
 //
 // Why: a proof of 2^20 hashes is ~1 700 dependent launches, most of them of a few microseconds; with 56 such proofs in flight
 // the GPU's dispatch of tiny kernels from many queues bounds the job, not its arithmetic (profiles/r04_bn20_plateau.txt; round
-// 6's A/Bs of the kernels changed nothing: profiles/r06_variants_ab.txt).  Four proofs in one launch are a quarter of the
-// launches, each with four times the work.
+// 6's A/Bs of the kernels changed nothing: profiles/r06_variants_ab.txt).  Three proofs in one launch are a third of the
+// launches, each with three times the work: bN = 20 64 -> 82 M hashes/s (profiles/r06_proof_groups.txt).
 //
 // How: every proof of the group runs the unchanged prover (session_prove) on a stack of its own (ucontext), on its own lane's
 // buffers but on the GROUP's stream.  launch_batch() -- the launch site of the batched kernels -- does not launch: it records
 // what the proof wants launched and switches to the driver.  When every proof of the group has arrived at a launch, the driver
 // puts the launches that agree (same kernel, grid, stream) into one and resumes the proofs in turn.  Everything else a proof
-// queues (copies of its coordinates, the odd memset, kernels that are not batched) goes to the shared stream at once, in the
-// proof's own order, and the combined launch is queued behind all of it -- stream order is what the prover relies on, and it
-// holds.  A proof only ever waits (flag words, stream synchronisation) for work that has been queued: a proof resumes only
+// queues (the odd memset or copy, kernels that are not batched) goes to the shared stream at once, in the proof's own order, and
+// the combined launch is queued behind all of it -- stream order is what the prover relies on, and it holds.  (The coordinates
+// of a layer's pyramids travel in the launch's arguments -- PyramidArgs3::qv -- so a layer queues nothing but batched kernels.)  A proof only ever waits (flag words, stream synchronisation) for work that has been queued: a proof resumes only
 // after its launch is in the stream.  Proofs that part ways (a challenge retry, a layer run again in safe mode, an error) get
 // launches of their own until they meet again; a proof that returns leaves the group.
 #pragma once
