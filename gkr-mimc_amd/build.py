@@ -37,7 +37,7 @@ LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-
 FLAGS = CFLAGS + LDFLAGS                     # (what the recorded hash covers)
 # (name, source, extra flags): gkrhip.hip first -- the longest single compilation starts first
 UNITS = [("host", "gkrhip.hip", [])] + \
-        [(g.lower(), "kern_unit.hip", ["-DGKR_GROUP_" + g]) for g in ("MSM_G2A", "MSM_G2B", "MSM_G1", "WIDE2", "WIDEPRE", "ROUND", "NTT")]
+        [(g.lower(), "kern_unit.hip", ["-DGKR_GROUP_" + g]) for g in ("MSM_G2A", "MSM_G2B", "MSM_G2C", "MSM_G1", "WIDE2", "WIDEPRE", "ROUND", "NTT")]
 
 # half-rate vector instructions on gfx950 (4.2-4.4 cycles per wave: profiles/r01_ubench_*.txt); the others issue in 2.4
 HALF = ("v_mad_u64", "v_addc", "v_subb", "v_add_co", "v_sub_co", "v_subrev_co", "v_mul_lo", "v_mul_hi", "v_lshl_add_u64",

@@ -3,7 +3,7 @@
 // instantiations `extern template` and launches them.  No host code here beyond the kernels' launch stubs.
 #define GKR_KERNEL_TU
 #include <hip/hip_runtime.h>
-#if defined(GKR_GROUP_MSM_G1) || defined(GKR_GROUP_MSM_G2A) || defined(GKR_GROUP_MSM_G2B)
+#if defined(GKR_GROUP_MSM_G1) || defined(GKR_GROUP_MSM_G2A) || defined(GKR_GROUP_MSM_G2B) || defined(GKR_GROUP_MSM_G2C)
 #include "g1.hip.h"
 #elif defined(GKR_GROUP_NTT)
 #include "ntt.hip.h"

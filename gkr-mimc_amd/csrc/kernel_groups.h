@@ -62,6 +62,8 @@ GKR_INST template __global__ void k_msm_big_combine<Fp2F>(MsmArgs);
 #endif
 #if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_MSM_G2B)
 GKR_INST template __global__ void k_msm_reduce_chunks<Fp2F>(MsmArgs);
+#endif
+#if defined(GKR_INST_EXTERN) || defined(GKR_GROUP_MSM_G2C)
 GKR_INST template __global__ void k_msm_reduce_windows<Fp2F>(MsmArgs);
 GKR_INST template __global__ void k_ec_batch_scalar_mul<Fp2F>(MsmArgs, AffT<Fp2F>, uint4*);
 GKR_INST template __global__ void k_msm_fb_precompute<Fp2F>(const uint4*, uint4*, size_t, FbWindows, int);
