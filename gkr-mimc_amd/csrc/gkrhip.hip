@@ -895,7 +895,13 @@ int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_
         ~Count() { g_small_callers.fetch_sub(1, std::memory_order_relaxed); }
     } count;
     if (g_small_callers.load(std::memory_order_relaxed) < kCoalesceFromCallers) return session_prove_on_its_lane(s, qprime, flat);
-    const unsigned long long key = ((unsigned long long)s->bN << 32) ^ (unsigned long long)s->c.size();
+    // groups form among statements of one shape: the size and the circuit's gates and wiring, layer by layer (FNV-1a)
+    unsigned long long key = 1469598103934665603ull ^ (unsigned long long)s->bN;
+    for (const Layer& l : s->c) {
+        key = (key ^ (unsigned long long)(unsigned)l.gate) * 1099511628211ull;
+        for (int in : l.in) key = (key ^ (unsigned long long)(unsigned)in) * 1099511628211ull;
+        key = (key ^ 0xffull) * 1099511628211ull;
+    }
     std::unique_lock<std::mutex> lk(g_forming_mu);
     auto it = g_forming.find(key);
     if (it != g_forming.end()) {
