@@ -73,12 +73,15 @@ int ntt_domain(int logn, NttDomain** out) {
     d->coset_fwd.cap = n;
     d->coset_inv.base = d->coset_fwd.base + 2 * n;
     d->coset_inv.cap = n;
+    // (-2)^-1: Z = X^n - 1 on the coset; the pointwise step's constant is folded into the inverse coset factors (prove.go:341-347)
+    const E minus_two_inv = hfr::pow_q_minus_2(hfr::sub(hfr::ZERO, hfr::from_u64(2)));
     hipLaunchKernelGGL(k_ntt_twiddles, dim3(grid_for(ntw, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->tw.planes(), tlo.cplanes(),
                        thi.cplanes(), l0, logn);
     hipLaunchKernelGGL(k_ntt_coset_table, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->coset_fwd.planes(),
                        d->tw.cplanes(), logn, 0, to_dev(d->card_inv), to_dev(hfr::mul(d->card_inv, d->finer)));
     hipLaunchKernelGGL(k_ntt_coset_table, dim3(grid_for(n, cx().max_grid)), dim3(GKR_BLOCK), 0, cx().stream, d->coset_inv.planes(),
-                       d->tw.cplanes(), logn, 1, to_dev(to_plain(d->card_inv)), to_dev(to_plain(hfr::mul(d->card_inv, d->finer_inv))));
+                       d->tw.cplanes(), logn, 1, to_dev(to_plain(hfr::mul(d->card_inv, minus_two_inv))),
+                       to_dev(to_plain(hfr::mul(hfr::mul(d->card_inv, minus_two_inv), d->finer_inv))));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(cx().stream));
     table_release(&tlo);
@@ -151,14 +154,11 @@ int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_o
         return 0;
     };
     // FFTInverse(., DIF, coset): strided tiles over the large distances, then the contiguous tile
-    auto dif_inverse = [&](int narr, bool pointwise, int post, const E& k2) -> int {
+    auto dif_inverse = [&](int narr, bool pointwise, int post) -> int {
         int s0 = 0;
         for (size_t i = 0; i < plan.size(); i++) {
             base_args(narr, true);
-            if (pointwise && i == 0) {
-                a.pre = 3;
-                a.k2 = to_dev(k2);
-            }
+            if (pointwise && i == 0) a.pre = 3;
             if (i + 1 == plan.size() && post) {
                 a.post = post;
                 a.coset = dom->coset_inv.cplanes();
@@ -169,7 +169,7 @@ int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_o
         return 0;
     };
     // 1. FFTInverse(a | b | c, DIF, 0) without its 1/n (folded into the next load)                      (:326-328)
-    CHK(dif_inverse(3, false, 0, hfr::ZERO));
+    CHK(dif_inverse(3, false, 0));
     // 2. FFT(., DIT, 1): the first load multiplies position p by u^rev(p) / n                            (:330-332)
     {
         int s0 = 0;
@@ -183,10 +183,9 @@ int compute_h_dev(DevTable* const* t, int logn, int* passes_out, double* bytes_o
             s0 += plan[i].stages;
         }
     }
-    // 3. (a * b - c) * (-2)^-1 when the last transform loads (:334-347); FFTInverse(a, DIF, 1): the last store multiplies
-    //    position p by u^-rev(p) / n and leaves Montgomery form                                            (:350-356)
-    const E minus_two_inv = hfr::pow_q_minus_2(hfr::sub(hfr::ZERO, hfr::from_u64(2)));
-    CHK(dif_inverse(1, true, 3, minus_two_inv));
+    // 3. a * b - c when the last transform loads (:334-347); FFTInverse(a, DIF, 1): the last store multiplies
+    //    position p by (-2)^-1 u^-rev(p) / n and leaves Montgomery form                                    (:350-356)
+    CHK(dif_inverse(1, true, 3));
     if (passes_out) *passes_out = passes;
     if (bytes_out) *bytes_out = bytes;
     return 0;

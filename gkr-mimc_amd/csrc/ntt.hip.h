@@ -17,9 +17,9 @@
 // tiles of up to 128 rows x 16 consecutive elements (256-byte segments per plane and row).  A 2^24-point transform is
 // THREE passes over HBM (7 + 6 + 11 stages) instead of six.
 // The element-wise factors ride on passes that exist anyway: the 1/n of the first inverse transforms and the coset shift
-// u^rev(p) are ONE factor applied when the first DIT pass loads; the pointwise step (a*b - c) * (-2)^-1 is done by the first
-// pass of the last transform when it loads (three arrays in, one out); the final 1/n, the inverse coset shift and
-// FromMont are one factor (kept in regular form, so the Montgomery product leaves the Montgomery domain) applied when the
+// u^rev(p) are ONE factor applied when the first DIT pass loads; the pointwise step a*b - c is done by the first
+// pass of the last transform when it loads (three arrays in, one out); its (-2)^-1 (round 6), the final 1/n, the inverse coset
+// shift and FromMont are one factor (kept in regular form, so the Montgomery product leaves the Montgomery domain) applied when the
 // last pass stores.
 // No MFMA: exact modular arithmetic.  One twiddle table omega^i, i < n/2, serves every stage and both directions
 // (omega^-i = -omega^(n/2 - i)); a group of four elements loads two twiddles and derives the third by a product with a
@@ -34,9 +34,8 @@ struct NttPassArgs {
     int lrows, lcols, lgQ;   // tile: 2^lrows rows at stride 2^lgQ, 2^lcols consecutive elements per row
     CPlanes coset;        // pre 2 / post 3: the per-position factor table of the domain (k_ntt_coset_table)
     int pre, post;        // 0 none | pre 2: x *= coset[p] = u^rev(p) / n                       (coset shift and the 1/n of step 1)
-                          //        | pre 3: x = (d[0][p] * d[1][p] - d[2][p]) * k2            (pointwise step, prove.go:341-347)
-                          //        | post 3: x *= coset[p] = u^-rev(p) / n in REGULAR form    (the product leaves Montgomery form)
-    Fr k2;                // pre 3: (-2)^-1
+                          //        | pre 3: x = d[0][p] * d[1][p] - d[2][p]                    (pointwise step, prove.go:341-347; its (-2)^-1: post 3)
+                          //        | post 3: x *= coset[p] = (-2)^-1 u^-rev(p) / n in REGULAR form    (the product leaves Montgomery form)
 };
 
 // Twiddles are kept PER STAGE SHIFT s: T_s[j] = omega^(j * 2^s), j <= n / 2^(s+1) (the last entry is -1), T_s starting at
@@ -91,7 +90,7 @@ __device__ __forceinline__ Fr ntt_sub_plus2q(const Fr& a, const Fr& b) {     // 
 __device__ __forceinline__ Fr ntt_load(const NttPassArgs& a, const Planes& d, size_t p) {
     if (a.pre == 3) {
         const Fr x = ld_fr(a.d[0].lo, a.d[0].hi, p), y = ld_fr(a.d[1].lo, a.d[1].hi, p), z = ld_fr(a.d[2].lo, a.d[2].hi, p);
-        return fr_mont_mul_raw(ntt_sub_plus2q(fr_mont_mul_raw(x, y), z), a.k2);      // (< 2q - z + 2q) * k2, k2 canonical
+        return ntt_sub2q(fr_mont_mul_raw(x, y), z);      // x y - c mod 2q; the (-2)^-1 of the step is part of the last store's factor (the transform between is linear)
     }
     const Fr x = ld_fr(d.lo, d.hi, p);
     if (a.pre != 2) return x;
@@ -253,7 +252,8 @@ GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_ntt_twiddles(Planes tw, CPlanes l
 }
 // The per-position factors of the coset transforms, as gnark-crypto's fft.Domain precomputes its CosetTable / CosetTableInv
 // (here indexed by the position in the bit-reversed vector the factor is applied to, with the 1/n folded in):
-//     fwd[p] = u^rev(p) * k0        inv[p] = u^-rev(p) * k0'         (u^e = omega^(e >> 1) * (e odd ? u : 1); k1 = k0 * u, k1' = k0' / u)
+//     fwd[p] = u^rev(p) * k0        inv[p] = u^-rev(p) * k0'         (u^e = omega^(e >> 1) * (e odd ? u : 1); k1 = k0 * u, k1' = k0' / u;
+//     k0 = 1/n, k0' = (-2)^-1 / n in regular form: the constant of computeH's pointwise step rides on the last store)
 GKR_KERNEL void __launch_bounds__(GKR_BLOCK) k_ntt_coset_table(Planes out, CPlanes tw, int logn, int inverse, Fr k0, Fr k1) {
     const size_t n = (size_t)1 << logn;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
