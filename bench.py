@@ -41,11 +41,12 @@ N_SIMD = 1024             # 256 CUs x 4 SIMDs
 def COMPUTE_H_PRODUCTS(logn):
     """Field products of one computeH on 2^logn points: seven transforms of logn * n / 2 butterflies (one product each), the
     per-element factors (coset shift and 1/n on the three forward loads: 2 products; the last store's factor: 2), the
-    pointwise step (2).  The products that derive a group's twiddles from the loaded ones are overhead, not counted."""
+    pointwise step (1: its constant (-2)^-1 rides on the last store's factor since round 6).  The products that derive a group's
+    twiddles from the loaded ones are overhead, not counted."""
     n = float(1 << logn)
     # (round 6: the sub-pass at element stride 1 -- twiddles omega^0 and the 4th root of unity -- issues one product per group of
     # four instead of four: 1.5 of a transform's stages carry no product)
-    return 7 * (logn - 1.5) * n / 2 + 3 * 2 * n + 2 * n + 2 * n
+    return 7 * (logn - 1.5) * n / 2 + 3 * 2 * n + 2 * n + 1 * n
 BN_TOTAL_MULTI = 26       # BASELINE config 4
 
 
@@ -1328,7 +1329,7 @@ def main():
         ms, npass, by = gk.bench_compute_h(24, warmup=1, iters=3)
         # issue ceiling from the ISA of this build: the innermost loop of the tile kernels is one sub-pass of two stages on a lane's
         # four elements (four butterflies with their LDS traffic and twiddle loads); 4 inverse DIF and 3 forward DIT transforms
-        # of 24 * 2^23 butterflies each, plus the 10 products per position of the factors and the pointwise step priced as a
+        # of 24 * 2^23 butterflies each, plus the 9 products per position of the factors and the pointwise step priced as a
         # butterfly's product each (an under-count: no adds)
         h_ceiling = None
         if "ntt_dif" in loops and "ntt_dit" in loops:
@@ -1338,7 +1339,7 @@ def main():
             n24 = float(1 << 24)
             # 24 stages of 2^23 butterflies per transform, 1.5 of them without a product (the sub-pass at element stride 1: priced at
             # nothing, an under-count: their additions remain)
-            cycles = (4 * per_bfly["ntt_dif"] + 3 * per_bfly["ntt_dit"]) * (12 - 0.75) * n24 + 10 * n24 * HALF_RATE_CYCLES * 230
+            cycles = (4 * per_bfly["ntt_dif"] + 3 * per_bfly["ntt_dit"]) * (12 - 0.75) * n24 + 9 * n24 * HALF_RATE_CYCLES * 230
             h_ceiling = cycles / (N_SIMD * 64) / (NOMINAL_GHZ * 1e9) * 1e3
         micro["compute_h_2p24"] = {"ms": ms, "passes": npass, "GB_per_s": by / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "bound": "integer VALU issue (no MFMA: modular arithmetic); HBM at 0.2 of its peak is not the limit",
