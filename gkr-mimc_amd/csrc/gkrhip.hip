@@ -445,6 +445,10 @@ int gkrhip_set_option(const char* key, long value) {
         g_wait_override.store((int)std::max(-2L, value));
         return 0;
     }
+    if (!strcmp(key, "group_wait_us")) {        // ... and how long the first caller of a group waits for company
+        g_group_wait_us.store((int)std::max(0L, std::min(100000L, value)));
+        return 0;
+    }
     if (!strcmp(key, "group_size")) {           // single calls that meet form proof groups of this many (0 | 1: never; gkrhip_mimc_session_prove)
         g_group_size.store((int)std::max(0L, std::min((long)GKR_GROUP_MAX, value)));
         return 0;
@@ -858,7 +862,7 @@ int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint
 // The reference proves independent statements from a goroutine each: many host threads inside gkrhip_mimc_session_prove at once.
 // When enough of them prove SMALL statements (2^18..2^21 entries: where proof groups pay) the calls that arrive
 // together are proven as a group by the first of them -- the others wait for their result -- so that the host gets the groups'
-// throughput through the reference's own call shape.  A caller waits for company at most kCoalesceWaitUs; a call that finds none
+// throughput through the reference's own call shape.  A caller waits for company at most group_wait_us (option; default 300 us); a call that finds none
 // runs as it always did.  Option "group_size" (default 3; 0 or 1: never).  Same transcripts either way.
 namespace {
 std::atomic<int> g_small_callers{0};               // threads inside gkrhip_mimc_session_prove with a small un-sharded session
@@ -866,7 +870,7 @@ std::atomic<int> g_small_callers{0};               // threads inside gkrhip_mimc
 // thread.  Fourteen callers with statements of 2^7..2^22 entries lost a quarter of their throughput to grouping (7 125 -> 5 064 proofs
 // in 45 s, tools/stress.py; GMiMC lanes 9 890 -> 7 446): few callers and tiny statements are host-bound, every caller needs its
 // own core.  So: from 24 callers on, statements of 2^18..2^21 entries.
-const int kCoalesceFromCallers = 24, kCoalesceMinBn = 18, kCoalesceMaxBn = 21, kCoalesceWaitUs = 300;
+const int kCoalesceFromCallers = 24, kCoalesceMinBn = 18, kCoalesceMaxBn = 21;
 struct Forming {
     int n = 0, want = 0, refs = 0;
     gkrhip_session* s[GKR_GROUP_MAX];
@@ -940,7 +944,7 @@ int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_
     f->q[0] = qprime;
     f->flat[0] = flat;
     g_forming[key] = f;
-    f->cv_full.wait_for(lk, std::chrono::microseconds(kCoalesceWaitUs), [&] { return f->closed; });
+    f->cv_full.wait_for(lk, std::chrono::microseconds(g_group_wait_us.load(std::memory_order_relaxed)), [&] { return f->closed; });
     if (!f->closed) {
         f->closed = true;
         g_forming.erase(key);

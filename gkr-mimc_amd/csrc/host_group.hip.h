@@ -79,6 +79,7 @@ inline int hw_queue_count() {
 }
 std::atomic<unsigned long long> g_cnt_group_launches{0}, g_cnt_group_combined{0};
 std::atomic<int> g_group_size{3};                     // option group_size: single calls that meet form groups of this many (gkrhip_mimc_session_prove)
+std::atomic<int> g_group_wait_us{300};                // option group_wait_us: how long the first caller waits for company
 std::atomic<unsigned long long> g_cnt_coalesced{0};   // proofs that were proven in a group formed from single calls
 
 // the launch site of a batched kernel
