@@ -862,7 +862,7 @@ int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint
 // The reference proves independent statements from a goroutine each: many host threads inside gkrhip_mimc_session_prove at once.
 // When enough of them prove SMALL statements (2^18..2^21 entries: where proof groups pay) the calls that arrive
 // together are proven as a group by the first of them -- the others wait for their result -- so that the host gets the groups'
-// throughput through the reference's own call shape.  A caller waits for company at most group_wait_us (option; default 300 us); a call that finds none
+// throughput through the reference's own call shape.  A caller waits for company at most group_wait_us (option; default 10 ms); a call that finds none
 // runs as it always did.  Option "group_size" (default 3; 0 or 1: never).  Same transcripts either way.
 namespace {
 std::atomic<int> g_small_callers{0};               // threads inside gkrhip_mimc_session_prove with a small un-sharded session

@@ -79,7 +79,11 @@ inline int hw_queue_count() {
 }
 std::atomic<unsigned long long> g_cnt_group_launches{0}, g_cnt_group_combined{0};
 std::atomic<int> g_group_size{3};                     // option group_size: single calls that meet form groups of this many (gkrhip_mimc_session_prove)
-std::atomic<int> g_group_wait_us{300};                // option group_wait_us: how long the first caller waits for company
+// option group_wait_us: how long the first caller of a group waits for company.  A caller that went alone once comes back out of step
+// with everybody else and goes alone again unless the wait is long enough for another one to come by: bN = 20, 72 callers: 100 us /
+// 300 us / 1 ms / 3 ms / 10 ms / 30 ms -> 71.5 / 74.4-76.4 / 76.0 / 78.5-78.8 / 81.7 / 78.5 M hashes/s (explicit groups: 82;
+// profiles/r06_proof_groups.txt).  10 ms is 1 % of such a group's 0.9 s and only ever spent while 24 callers are inside the call.
+std::atomic<int> g_group_wait_us{10000};
 std::atomic<unsigned long long> g_cnt_coalesced{0};   // proofs that were proven in a group formed from single calls
 
 // the launch site of a batched kernel

@@ -80,7 +80,8 @@ int gkrhip_reserve_lanes(int n);
  * "coop", "coop_lg", "coop_wgs", "spec", "spec_lg", "ahead", "solo_boost", "pyr_split" -- applied to every existing lane,
  * waiting for the proofs in flight on them ("Runtime switches", lists the environment variables read at
  * gkrhip_init); "msm_sort_levels" (0: by size, 1 | 2: the one- / two-level counting sort of the MSM forced; same sums);
- * "group_size" (process-wide, default 3; 0 | 1: never): gkrhip_mimc_session_prove calls that meet are proven in groups of this many;
+ * "group_size" (process-wide, default 3; 0 | 1: never): gkrhip_mimc_session_prove calls that meet are proven in groups of this many,
+ * "group_wait_us" (default 10000): how long the first caller of such a group waits for the others;
  * "wait_spin_us" (how host threads wait for a round kernel: -2 by the CPUs available -- the default --, -1 always spin, n: spin n us, then sleep).
  * Integrity (process-wide): "layer_check" (default 1) -- every sumcheck the library produces is held against the verifier's own
  * identities before it is returned (sumcheck/verifier.go:41-47 per round, the closing identity of gkr/verifier.go:93-114; host
@@ -160,9 +161,9 @@ int gkrhip_mimc_session_synth_inputs(gkrhip_mimc_session *s, uint64_t index_stri
 int gkrhip_mimc_session_assign(gkrhip_mimc_session *s);
 /* gkr.Prove (gkr/prover.go:21-91) on the resident assignment.  Thread-safe: sessions with lanes of their own prove concurrently from
  * different host threads (the reference's goroutine per statement).  When 24 or more host threads are inside this call with
- * un-sharded sessions of 2^18..2^21 entries, calls that arrive within 300 us of each other are proven together as a proof group by
+ * un-sharded sessions of 2^18..2^21 entries, calls that arrive within 10 ms of each other (option "group_wait_us") are proven together as a proof group by
  * the first of them -- the others block until their proof is there (see gkrhip_mimc_session_prove_group: same transcripts, the
- * round kernels of the group in one launch; bN = 20, 72 callers: 66 -> 79 M hashes/s).  gkrhip_set_option("group_size", 0) turns
+ * round kernels of the group in one launch; bN = 20, 72 callers: 66 -> 80 M hashes/s).  gkrhip_set_option("group_size", 0) turns
  * that off; counter "coalesced_proofs". */
 int gkrhip_mimc_session_prove(gkrhip_mimc_session *s, const uint64_t *qprime, uint64_t *flat);
 /* gkr.Prove (gkr/prover.go:21-91) for n sessions of the same shape from one host thread, in lock-step: proof i is, bit for bit,
