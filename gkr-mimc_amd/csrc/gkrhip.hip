@@ -2432,6 +2432,82 @@ int gkrhip_host_ahead_contract(uint64_t out[28], const uint64_t* class_sums, con
     return 0;
 }
 
+// Host-only self-test of the proof groups' driver (host_group.hip.h; no GPU): n proofs on stacks of their own ask for `steps` launches
+// each through launch_batch; a recorder stands in for hipLaunchKernel.  Proof 1 (if any) asks for another grid at step
+// `diverge_at` (it must get a launch of its own there and be back in the common one afterwards), the last proof returns after
+// `leave_after` steps (it must leave the group without holding the others up).  The recorder checks every combined launch:
+// its arguments are exactly what the proofs that are in it asked for, each proof's steps arrive in order, nobody is launched twice.
+// counts[0] = launches asked for, counts[1] = launches made, counts[2] = the most proofs in one launch; *verdict 0 when all of it held.
+namespace {
+struct SelfArgs {
+    int proof, step;
+    unsigned long long tag;
+};
+GKR_KERNEL void k_group_selftest(Batch<SelfArgs>) {}
+struct SelfRecorder {
+    int n = 0, bad = 0, diverge_at = -1;
+    std::vector<int> next_step;        // by proof
+    unsigned long long made = 0, most = 0;
+} g_self;
+hipError_t self_launch(const void* fn, dim3 grid, dim3, void** params, size_t, hipStream_t) {
+    const SelfArgs* a = (const SelfArgs*)params[0];
+    if (fn != reinterpret_cast<const void*>(&k_group_selftest) || grid.z < 1 || grid.z > (unsigned)g_self.n) g_self.bad++;
+    for (unsigned z = 0; z < grid.z; z++) {
+        const SelfArgs& x = a[z];
+        if (x.proof < 0 || x.proof >= g_self.n || x.tag != 0x9e3779b97f4a7c15ull * (unsigned long long)(x.proof * 1000 + x.step + 1) ||
+            x.step != g_self.next_step[(size_t)x.proof] || grid.x != ((x.proof == 1 && x.step == g_self.diverge_at) ? 7u : 3u)) {
+            g_self.bad++;
+            continue;
+        }
+        g_self.next_step[(size_t)x.proof]++;
+        for (unsigned y = 0; y < z; y++)
+            if (a[y].proof == x.proof) g_self.bad++;
+    }
+    g_self.made++;
+    g_self.most = std::max<unsigned long long>(g_self.most, grid.z);
+    return hipSuccess;
+}
+std::mutex g_self_mu;
+}  // namespace
+int gkrhip_host_group_selftest(int n, int steps, int diverge_at, int leave_after, uint64_t counts[3], int* verdict) {
+    if (n < 1 || n > GKR_GROUP_MAX || steps < 1 || !counts || !verdict) return fail("group_selftest: bad argument");
+    std::lock_guard<std::mutex> lk(g_self_mu);
+    g_self = SelfRecorder();
+    g_self.n = n;
+    g_self.diverge_at = diverge_at;
+    g_self.next_step.assign((size_t)n, 0);
+    Group g;
+    g.launch = self_launch;
+    g.proofs.resize((size_t)n);
+    std::vector<int> done_steps((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        g.proofs[(size_t)i].body = [i, n, steps, diverge_at, leave_after, &done_steps]() {
+            const int mine = (i == n - 1 && n > 1 && leave_after >= 0) ? std::min(steps, leave_after) : steps;
+            for (int k = 0; k < mine; k++) {
+                SelfArgs a = {i, k, 0x9e3779b97f4a7c15ull * (unsigned long long)(i * 1000 + k + 1)};
+                const unsigned gx = (i == 1 && k == diverge_at) ? 7u : 3u;
+                if (launch_batch(k_group_selftest, dim3(gx), dim3(64), 0, nullptr, a) != hipSuccess) return -1;
+                done_steps[(size_t)i] = k + 1;
+            }
+            return 100 + i;
+        };
+    }
+    CHK(group_run(g));
+    unsigned long long wanted = 0;
+    int bad = g_self.bad;
+    for (int i = 0; i < n; i++) {
+        const int mine = (i == n - 1 && n > 1 && leave_after >= 0) ? std::min(steps, leave_after) : steps;
+        wanted += (unsigned long long)mine;
+        if (g.proofs[(size_t)i].rc != 100 + i || done_steps[(size_t)i] != mine || g_self.next_step[(size_t)i] != mine) bad++;
+    }
+    if (g.launches != wanted || g.combined != g_self.made) bad++;
+    counts[0] = wanted;
+    counts[1] = g_self.made;
+    counts[2] = g_self.most;
+    *verdict = bad;
+    return 0;
+}
+
 int gkrhip_profile_latency(uint64_t* prelaunched_rounds, uint64_t* lookahead_round0, uint64_t* coop_rounds) {
     if (prelaunched_rounds) *prelaunched_rounds = g_cnt_prelaunched.load();
     if (lookahead_round0) *lookahead_round0 = g_cnt_lookahead.load();

@@ -63,7 +63,9 @@ struct GroupProof {
     int rc = 0;
     std::function<int()> body;
 };
+typedef hipError_t (*GroupLaunchFn)(const void* fn, dim3 grid, dim3 block, void** params, size_t shmem, hipStream_t st);
 struct Group {
+    GroupLaunchFn launch = nullptr;      // nullptr: hipLaunchKernel (the host-only self-test records instead)
     ucontext_t driver;
     GroupTls driver_tls;
     std::vector<GroupProof> proofs;
@@ -140,7 +142,8 @@ inline void group_fire(Group& g) {
             member[cnt++] = j;
         }
         void* params[1] = {args};
-        const hipError_t rc = hipLaunchKernel(p.pend.fn, dim3(p.pend.grid.x, p.pend.grid.y, cnt), p.pend.block, params, p.pend.shmem, p.pend.stream);
+        const hipError_t rc = (g.launch ? g.launch : (GroupLaunchFn)hipLaunchKernel)(p.pend.fn, dim3(p.pend.grid.x, p.pend.grid.y, cnt), p.pend.block, params,
+                                                                                     p.pend.shmem, p.pend.stream);
         if (rc != hipSuccess) (void)hipGetLastError();      // handed to the proofs below
         for (unsigned c = 0; c < cnt; c++) {
             g.proofs[member[c]].pend.rc = rc;

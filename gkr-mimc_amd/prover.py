@@ -131,6 +131,7 @@ ABI = {
     "gkrhip_profile_counter": (_I, [C.c_char_p, C.POINTER(_U64)]),
     "gkrhip_host_sumcheck_closes": (_I, [_I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, C.POINTER(C.c_int)]),
     "gkrhip_host_ahead_contract": (_I, [_P, _P, _P, _I]),
+    "gkrhip_host_group_selftest": (_I, [_I, _I, _I, _I, _P, _P]),
 }
 
 
@@ -930,6 +931,14 @@ def bench_partial_eval(bn, warmup=10, iters=200):
     e0 = np.zeros((1, 4), dtype=np.uint64)
     _check(load().gkrhip_bench_partial_eval(bn, warmup, iters, C.byref(us), _ptr(e0)))
     return us.value, e0
+
+
+def host_group_selftest(n, steps, diverge_at=-1, leave_after=-1):
+    """gkrhip_host_group_selftest (no GPU): (launches asked for, launches made, most proofs in one launch, verdict)."""
+    counts = (C.c_uint64 * 3)()
+    verdict = C.c_int(-1)
+    _check(load().gkrhip_host_group_selftest(n, steps, diverge_at, leave_after, counts, C.byref(verdict)))
+    return int(counts[0]), int(counts[1]), int(counts[2]), verdict.value
 
 
 def profile_counter(name):

@@ -302,6 +302,13 @@ int gkrhip_host_sumcheck_closes(int gate, const uint64_t *ark_or_null, int arity
  * significant of the t low index bits). */
 int gkrhip_host_ahead_contract(uint64_t out[28], const uint64_t *class_sums, const uint64_t *q_low, int t);
 
+/* Host-only self-test of the proof groups' driver (no GPU; the -m "not gpu" tests call it): n proofs on stacks of their own ask
+ * for `steps` launches each, a recorder stands in for the GPU.  Proof 1 asks for another grid at step diverge_at (-1: never) and must
+ * get a launch of its own there; the last proof returns after leave_after steps (-1: never) and must leave the group without holding
+ * the others up.  counts: launches asked for, launches made, the most proofs in one launch; *verdict: 0 when every combined launch held
+ * exactly what its proofs asked for, in order. */
+int gkrhip_host_group_selftest(int n, int steps, int diverge_at, int leave_after, uint64_t counts[3], int *verdict);
+
 /* ---- computeH: the H part of Groth16's Krs (prover/gadget/prove.go:308-359) --------------------------------------
  * The next prover cost once GKR is fast: three inverse FFTs, three coset FFTs, the pointwise
  * (a*b - c) * (-2)^-1, one inverse coset FFT over BN254 Fr, FromMont.  a, b, c: n Montgomery elements each (zero-padded to

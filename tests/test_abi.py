@@ -317,3 +317,24 @@ def test_round0_ahead_factorisation(gk):
     flat = c.from_ints([v for Sj in S for v in Sj])
     got = gk.host_ahead_contract(flat, c.from_ints(q[m - t:]))
     assert c.to_ints(got) == want
+
+
+def test_proof_group_driver_without_a_gpu(gk):
+    """host_group.hip.h on the host alone (gkrhip_host_group_selftest): proofs on stacks of their own ask for launches through
+    launch_batch, a recorder stands in for hipLaunchKernel.  Launches that agree go out as ONE with the arguments of every proof in it,
+    in each proof's order; a proof that asks for another grid gets a launch of its own at that step and is back in the common launch
+    at the next; a proof that returns early leaves the group without holding the others up."""
+    for n in (1, 2, 3, 8):
+        wanted, made, most, verdict = gk.host_group_selftest(n, 50)
+        assert verdict == 0 and wanted == 50 * n and made == 50 and most == n, (n, wanted, made, most, verdict)
+    # proof 1 parts ways at step 7: that step takes two launches (its own and the others'), every other step one
+    wanted, made, most, verdict = gk.host_group_selftest(4, 40, 7, -1)
+    assert verdict == 0 and wanted == 160 and made == 41 and most == 4, (wanted, made, most, verdict)
+    # the last of five proofs returns after 10 of 30 steps: 10 launches of five, then 20 of four
+    wanted, made, most, verdict = gk.host_group_selftest(5, 30, -1, 10)
+    assert verdict == 0 and wanted == 4 * 30 + 10 and made == 30 and most == 5, (wanted, made, most, verdict)
+    # both at once, and a proof that asks for nothing at all
+    wanted, made, most, verdict = gk.host_group_selftest(3, 25, 24, 0)
+    assert verdict == 0 and wanted == 50 and made == 26 and most == 2, (wanted, made, most, verdict)
+    with pytest.raises(gk.GkrHipError):
+        gk.host_group_selftest(9, 5)
