@@ -891,7 +891,8 @@ int gkrhip_mimc_session_prove(gkrhip_session* s, const uint64_t* qprime, uint64_
     // for the host, which a group never does)
     const Ctx* ln = s->lane;
     const bool forced = ln->prelaunch >= 2 || ln->pre_mode >= 2 || ln->spec >= 2 || ln->coop >= 2;
-    const bool small = want >= 2 && ln != &g0 && s->bN >= kCoalesceMinBn && s->bN <= kCoalesceMaxBn && !forced && !t_group && !g_regular_io &&
+    const bool sharded = ln == &g0 || ln->lc.comm || ln->lc.shm || ln->lc.tick_lane >= 0;
+    const bool small = want >= 2 && !sharded && s->bN >= kCoalesceMinBn && s->bN <= kCoalesceMaxBn && !forced && !t_group && !g_regular_io &&
                        !g_safe_mode && !g_local_only;
     if (!small) return session_prove_on_its_lane(s, qprime, flat);
     struct Count {
@@ -985,7 +986,8 @@ int gkrhip_mimc_session_prove_group(int n, gkrhip_session* const* ss, const uint
     if (!ss || !qprimes || !flats) return fail("prove_group: null argument");
     for (int i = 0; i < n; i++) {
         if (!ss[i] || !ss[i]->lane) return fail("prove_group: null session (%d)", i);
-        if (ss[i]->lane == &g0) return fail("prove_group: session %d is sharded (it proves on the default lane, with its peers)", i);
+        if (ss[i]->lane == &g0 || ss[i]->lane->lc.comm || ss[i]->lane->lc.shm || ss[i]->lane->lc.tick_lane >= 0 || shard_view().world > 1)
+            return fail("prove_group: session %d is sharded (its rounds are exchanged with its peers, in step with them)", i);
         if (!flats[i] || (ss[i]->bN > 0 && !qprimes[i])) return fail("prove_group: null buffer (%d)", i);
         for (int j = 0; j < i; j++)
             if (ss[j] == ss[i]) return fail("prove_group: session %d is given twice", i);
